@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""sim+render steps/s at 800x800 on the synthetic chair (BASELINE.json configs[1]); one JSON line on rank 0.
+
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one GUI-frame equivalent (nerf/gui.py:588-603 / nerf/trainer.py:300-318 of the reference):
+get_rays -> get_IP_info -> stepforward(iters=10) -> render_deformed at 800x800, inputs resident in HBM, outputs left in HBM.
+N > 1 is frame-parallel: every rank owns a simulator replica + checkpoint and renders its own frames
+(weak scaling, no data-path collective); value = frames all ranks completed / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HASH_BYTES_PER_SAMPLE = 1164   # 16 levels x 8 corners x 8 B gathered + 12 B position in + 128 B features out
+FUSED_BYTES_PER_SAMPLE = 1076  # fused network kernel: 1024 B gathered + 24 B xyz/dir + 12 B slot id/.. in + 16 B sigma/rgb out
+MLP_FLOP_PER_SAMPLE = 18688
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+F32_MFMA_PEAK_TF = 157.3       # dense fp32-input MFMA peak
+
+
+def cuda_time_ms(fn, iters=20, warmup=3):
+    """Average duration of fn() on torch's current stream, HIP events (kernels are launched on that stream)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def cpu_baseline(opt, cloud, ckpt, budget_s=20.0):
+    """The CPU oracle ("port") on this box's host cores: sim steps + full 800x800 renders for ~budget_s seconds."""
+    import oracle
+    from oracle.sim_init import OracleSimulator
+    from pienerf_amd import scene
+    t0 = time.time()
+    ref = OracleSimulator(dt=opt["sim_dt"], iters=opt["sim_iters"], bbox=torch.tensor([2.0 * opt["bound"]] * 3), dx=opt["sim_dx"],
+                          stiff=opt["sim_stiff"], base=torch.tensor([-opt["bound"]] * 3))
+    ref.InitializeFromArrays(cloud["pos"], cloud["mass"], cloud["mu"], cloud["lam"], cloud["pin"])
+    init_s = time.time() - t0
+    p_ori, _, _ = ref.get_IP_info()
+    pose, intr = scene.orbit_pose(opt["radius"]), scene.orbit_intrinsics(opt["W"], opt["H"], opt["fovy"])
+    times = []
+    t_all = time.time()
+    while True:
+        t = time.time()
+        o, d = oracle.get_rays(pose, intr, opt["H"], opt["W"])
+        p_def, F, dF = ref.get_IP_info()
+        ref.stepforward()
+        oracle.render_deformed(o, d, dict(p_def=p_def, p_ori=p_ori, F=F, dF=dF, IP_dx=ref.dx * 1.05), ckpt, opt)
+        times.append(time.time() - t)
+        if len(times) >= 3 and (time.time() - t_all > budget_s or len(times) >= 12):
+            break
+    steady = times[1:]
+    return {"value": round(1.0 / float(np.median(steady)), 4), "unit": "steps/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": f"{len(steady)} full 800x800 sim+render steps of the C++/OpenMP oracle (median; first step discarded; init {init_s:.1f}s untimed)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from pienerf_amd import scene
+    from pienerf_amd.harness import SimRenderHarness
+
+    opt = scene.default_opt()  # chair demo options (README.md:123): 800x800, bound 1, dt_gamma 0, num_seek_IP 3, max_iter_num 1, sim_dx 0.05, iters 10
+    cloud = scene.make_chair_points(hgs=opt["hash_grid_size"])
+    ckpt = scene.make_checkpoint(bound=opt["bound"], seed=0)
+    h = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device=dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        h.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        h.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        # ---- per-kernel measurements on the frame's real sample set (HIP events on the launch stream)
+        out = h.step(simulate=False, collect_stats=True)
+        st = dict(h.model.last_stats)
+        m = h.model
+        # rebuild the frame's samples with the op-by-op path to feed the stand-alone kernel timings
+        rays_o, rays_d = out["rays_o"], out["rays_d"]
+        kw = h.render_kwargs()
+        from pienerf_amd import raymarching
+        from pienerf_amd.gridencoder import grid_encode
+        from pienerf_amd.nerf.utils import get_pnts_in_grids
+        samples = collect_samples(m, rays_o, rays_d, kw)
+        xyz, dirs = samples
+        B = xyz.shape[0]
+        u = ((xyz + m.bound) / (2 * m.bound)).contiguous()
+        enc = m.encoder
+        t_grid = cuda_time_ms(lambda: grid_encode(u, enc.embeddings, enc.offsets, enc.per_level_scale, enc.base_resolution, False, 0, False, 0,
+                                                  offsets_host=enc._offsets_host))
+        t_net = cuda_time_ms(lambda: m(xyz, dirs))
+        t_sim = cuda_time_ms(lambda: h.sim.stepforward(), iters=10)
+        t_frame = cuda_time_ms(lambda: h.step(simulate=False), iters=10)
+        grid_gbs = HASH_BYTES_PER_SAMPLE * B / (t_grid * 1e-3) / 1e9
+        net_gbs = FUSED_BYTES_PER_SAMPLE * B / (t_net * 1e-3) / 1e9
+        net_tf = MLP_FLOP_PER_SAMPLE * B / (t_net * 1e-3) / 1e12
+        res = {
+            "metric": "sim+render steps/s @800x800 chair", "value": round(args.steps * world / elapsed, 3), "unit": "steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 render / f64 sim", "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic chair 800x800, sim_dx=0.05, sim_iters=10, num_seek_IP=3, max_iter_num=1, fp32, "
+                                   "1 sim+render step per frame", "rays": opt["W"] * opt["H"], "n_IP": h.sim.n_IP, "n_kernels": h.sim.n_k,
+                       "samples_per_frame": st["samples"], "trips_per_frame": st["trips"],
+                       "parallelism": f"frame-parallel x{world}" if world > 1 else "single GPU"},
+            "roofline": {"kernel": "k_nerf_forward (hash-grid gather + SH + MLP fused)", "bound": "hbm", "achieved": round(net_gbs, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(net_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                         "launch_ms": round(t_net, 4), "samples": B, "mfma_tflops": round(net_tf, 2),
+                         "mfma_frac_of_f32_peak": round(net_tf / F32_MFMA_PEAK_TF, 4)},
+            "hash_lookup": {"kernel": "k_grid_encode<2> (stand-alone hash-grid lookup)", "achieved_GBps": round(grid_gbs, 1),
+                            "frac_of_hbm_peak": round(grid_gbs / HBM_PEAK_GBS, 4), "launch_ms": round(t_grid, 4), "bytes_per_sample": HASH_BYTES_PER_SAMPLE},
+            "breakdown_ms": {"stepforward": round(t_sim, 4), "render_frame": round(t_frame, 4), "local_global_iters_per_s": round(opt["sim_iters"] / (t_sim * 1e-3), 1)},
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(opt, cloud, ckpt, args.cpu_budget)
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def collect_samples(m, rays_o, rays_d, kw):
+    """All (xyz, dir) samples of one frame, gathered with the op-by-op loop (same kernels as the fused path)."""
+    from pienerf_amd import raymarching
+    from pienerf_amd.nerf.utils import get_pnts_in_grids
+    xs, ds = [], []
+    orig = m.forward
+
+    def tap(x, d):
+        s, c = orig(x, d)
+        xs.append(x)
+        ds.append(d)
+        return s, c
+    m.forward = tap
+    try:
+        out = m.rund_cuda_ops(rays_o, rays_d, **kw)
+    finally:
+        m.forward = orig
+    # keep only real samples: the op-level path evaluates padded slots too; real ones have a non-zero direction
+    x = torch.cat(xs)
+    d = torch.cat(ds)
+    keep = (d.abs().sum(-1) > 0)
+    return x[keep].contiguous(), d[keep].contiguous()
+
+
+if __name__ == "__main__":
+    main()

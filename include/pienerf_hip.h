@@ -1,0 +1,171 @@
+/* pienerf_hip.h — C ABI of libpienerf_hip.so: the MI355X (gfx950) kernels behind the
+ * PIE-NeRF simulate-and-render hot path.
+ *
+ * Every entry point replaces one reference interface, cited as file:line relative to
+ * /root/reference.  Conventions (SURVEY.md §8b "What a C-ABI replacement must export"):
+ *   - plain device pointers + extents + scalars; no torch types;
+ *   - the CALLER allocates every output (the reference's Python wrappers do, e.g.
+ *     raymarching/raymarching.py:415-417) and zero-fills where stated;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); nothing blocks the
+ *     host unless stated — the reference's per-call cudaEventSynchronize
+ *     (raymarching/src/raymarching.cu:1481-1482) is deliberately not reproduced;
+ *   - return value: 0 on success, a PN_ERR_* code otherwise (the pybind functions return void
+ *     and TORCH_CHECK-throw; the Python mirror raises RuntimeError on non-zero).
+ * Pointers are DEVICE pointers unless the parameter is marked [host].
+ */
+#ifndef PIENERF_HIP_H
+#define PIENERF_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN_OK 0
+#define PN_ERR_ARG 1      /* unsupported D / C / degree / num_seek_IP, null pointer, ... */
+#define PN_ERR_HIP 2      /* a HIP runtime call or kernel launch failed; see pn_last_error() */
+#define PN_ERR_CAPACITY 3 /* a caller-provided scratch buffer is too small */
+
+/* Library identity: "pienerf_hip <version> gfx950".  Never NULL. */
+const char* pn_version(void);
+/* Text of the last PN_ERR_HIP on the calling thread ("" if none). */
+const char* pn_last_error(void);
+
+/* ------------------------------------------------------------------ raymarching ---- */
+
+/* raymarching/src/raymarching.h:7 near_far_from_aabb (kernel raymarching.cu:91-159). */
+int pn_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near, float* nears, float* fars,
+                          void* stream);
+
+/* raymarching/src/raymarching.h:20-36 march_rays_quadratic_bending (kernel raymarching.cu:1121-1434,
+ * host :1436-1489).  Same argument order as the pybind function (p_def before p_ori).
+ * xyzs [M,3], dirs [M,3], deltas [M,2] must be zero-filled, M >= n_alive*n_step.
+ * num_seek_IP must be in [1,3] (get_opts.py:97,117-120).  err_flag (int[1], may be NULL) is OR-ed with
+ * 1 when a sample's search cell falls outside the spatial-hash grid (reference: device printf "ERROR"). */
+int pn_march_rays_quadratic_bending(const int* pig_cnt, const int* pig_bgn, const int* pig_idx, int n_vtx, int n_grid, const float* p_def,
+                                    const float* p_ori, const float* F_IP, const float* dF_IP, int max_iter_num, const float* bbmin,
+                                    const float* bbmax, float hgs, const int* resolution, int num_seek_IP, float IP_dx, int cut,
+                                    const float* cut_bounds, uint32_t n_alive, uint32_t n_step, const int* rays_alive, const float* rays_t,
+                                    const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
+                                    uint32_t H, const uint8_t* grid, const float* nears, const float* fars, float* xyzs, float* dirs,
+                                    float* deltas, const float* noises, int* err_flag, void* stream);
+
+/* raymarching/src/raymarching.h:18 composite_rays (kernel raymarching.cu:827-923).  In place on rays_alive,
+ * rays_t, weights_sum, depth, image. */
+int pn_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int* rays_alive, float* rays_t, const float* sigmas, const float* rgbs,
+                      const float* deltas, float* weights_sum, float* depth, float* image, void* stream);
+
+/* nerf/renderer.py:887  rays_alive = rays_alive[rays_alive >= 0]  — stable stream compaction.
+ * out [n] receives the survivors in order; *n_out (device int[1]) their count.  scratch: >= pn_compact_scratch_ints(n) ints. */
+int pn_compact_rays(const int* rays_alive, uint32_t n, int* out, int* n_out, int* scratch, void* stream);
+uint32_t pn_compact_scratch_ints(uint32_t n);
+
+/* nerf/utils.py:355-443 get_pnts_in_grids (+ Warp kernels get_pig_cnt / get_pig_idx / p2g).  Slot order inside a
+ * cell is ascending point id (the reference's is atomic-race order).  bbmin [3] and resolution [3] are device arrays,
+ * as in the reference.  err_flag (may be NULL) is OR-ed with 2 when a point's cell id is outside [0,n_grid). */
+int pn_pnts_in_grids(int n_vtx, int n_grid, const float* pnts, const float* bbmin, float hgs, const int* resolution, int* pig_cnt, int* pig_bgn,
+                     int* pig_idx, int* err_flag, void* stream);
+
+/* nerf/utils.py:54-138 get_rays, N=-1 path.  pose [host]: row-major 4x4 cam2world.  rays_o/rays_d [H*W,3]. */
+int pn_get_rays(const float* pose_host, float fx, float fy, float cx, float cy, int H, int W, float* rays_o, float* rays_d, void* stream);
+
+/* ------------------------------------------------------------------ gridencoder ---- */
+
+/* gridencoder/src/gridencoder.h:11 grid_encode_forward (kernel gridencoder.cu:87-245, D=3, C in {1,2,4,8}, fp32,
+ * dy_dx must be NULL).  offsets [host or device]: pass the device pointer in `offsets` and the same L+1 values on the
+ * host in `offsets_host` (the launcher derives per-level scale/resolution/table size on the host with the
+ * reference's formulas :132-134).  outputs [L,B,C] exactly like the reference kernel; with out_bl_major != 0 the
+ * kernel writes [B, L*C] directly (what grid.py:57 produces by permute+reshape). */
+int pn_grid_encode_forward(const float* inputs, const float* embeddings, const int* offsets_host, float* outputs, uint32_t B, uint32_t D,
+                           uint32_t C, uint32_t L, float S, uint32_t H, const float* dy_dx, uint32_t gridtype, int align_corners,
+                           uint32_t interp, int out_bl_major, void* stream);
+
+/* ------------------------------------------------------------------ shencoder ---- */
+
+/* shencoder/src/shencoder.h:9 sh_encode_forward (kernel shencoder.cu:27-123), D=3, degree C in [1,4], dy_dx NULL. */
+int pn_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C, const float* dy_dx, void* stream);
+
+/* ------------------------------------------------------------------ network -------- */
+
+/* NeRFNetwork.forward (nerf/network.py:98-127): hash grid (16x2) -> 32->64->16 -> exp | SH(16)+15 -> 31->64->64->3 -> sigmoid,
+ * no biases, fp32, fused in one kernel (MFMA f32).  Weights row-major [out,in] as in the state dict.
+ * pn_net_create packs them (and the per-level table geometry) into a device-side context. */
+typedef struct pn_net pn_net;
+int pn_net_create(pn_net** out, const float* embeddings /*device, [n,2]*/, const int* offsets_host /*[L+1]*/, uint32_t L, uint32_t C,
+                  float per_level_scale_log2, uint32_t base_resolution, float bound, const float* W0_host, const float* W1_host,
+                  const float* W2_host, const float* W3_host, const float* W4_host, void* stream);
+void pn_net_destroy(pn_net* net);
+/* sigmas[M], rgbs[M,3] for xyzs[M,3] in [-bound,bound], dirs[M,3] unit.  density_scale multiplies sigma (renderer.py:875). */
+int pn_nerf_forward(const pn_net* net, const float* xyzs, const float* dirs, uint32_t M, float density_scale, float* sigmas, float* rgbs,
+                    void* stream);
+
+/* ------------------------------------------------------------------ whole frame ---- */
+
+/* NeRFRenderer.rund_cuda (nerf/renderer.py:755-907) for one frame with no host synchronisation inside the loop:
+ * bbox/resolution of the deformed IPs, spatial hash, near/far, then trips of { march, network, composite,
+ * stable compaction } driven by a device-side (n_alive, n_step) record that follows renderer.py:839-846,887-891.
+ * Results are those of the op-by-op loop.  Workspace comes from pn_frame_create (sized for N rays, n_vtx IPs). */
+typedef struct pn_frame pn_frame;
+typedef struct {
+    int max_iter_num;     /* --max_iter_num */
+    float hash_grid_size; /* opt.hash_grid_size = 1.2*sim_dx (get_opts.py:96) */
+    int num_seek_IP;
+    float IP_dx;          /* model.IP_dx = 1.05*sim_dx (main_gui.py:56) */
+    int cut;
+    float cut_bounds[6];
+    float bound;
+    float min_near;
+    float dt_gamma;
+    uint32_t max_steps;
+    float T_thresh;
+    uint32_t cascade;     /* C */
+    uint32_t grid_size;   /* H = 128 */
+    float density_scale;
+    float bg_color;       /* scalar background (renderer.py:803-804: bg_color = 1) */
+} pn_render_opts;
+int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_vtx, uint32_t max_grid_cells);
+void pn_frame_destroy(pn_frame* f);
+/* rays_o/rays_d [N,3]; p_def/p_ori [n_vtx,3], F_IP [n_vtx,9], dF_IP [n_vtx,27]; bitfield [C*H^3/8];
+ * outputs image [N,3], depth [N], depth_0 [N], weights_sum [N].  stats_host (may be NULL) [host, int64[4]] =
+ * {trips, emitted samples, error flags, rays alive at exit}; reading it synchronises the stream. */
+int pn_render_deformed(pn_frame* f, const pn_net* net, const pn_render_opts* opts, const float* rays_o, const float* rays_d, uint32_t N,
+                       const float* p_def, const float* p_ori, const float* F_IP, const float* dF_IP, int n_vtx, const uint8_t* bitfield,
+                       float* image, float* depth, float* depth_0, float* weights_sum, int64_t* stats_host, void* stream);
+
+/* ------------------------------------------------------------------ simulator ------ */
+
+/* Simulator.get_IP_info (simulator/solver.py:402-424) = update_F_kernel (simulator/cuda_utils.py:206-233) + the
+ * permute/cast: pos [n_IP,3], F [n_IP,9] (flat c*3+r), dF [n_IP,27] (flat c*9+r*3+j), fp32.
+ * topo [n_IP,8] int32; dof [10 n_k,3]; Nx [n_IP,8,10]; dNx [n_IP,8,3,10]; ddNx [n_IP,8,3,3,10] fp64. */
+int pn_sim_update_F(int n_IP, const int* topo, const double* dof, const double* Nx, const double* dNx, const double* ddNx, float* pos, float* F,
+                    float* dF, void* stream);
+
+/* calc_elastic (simulator/cuda_utils.py:83-121) + volume_invariant_project (simulator/func_utils.py:21-40).
+ * RF, VF [n_IP,3,3] fp64 row-major; FF may be NULL. */
+int pn_sim_calc_elastic(int n_IP, const int* topo, const double* dNx, const double* dof, double* RF, double* VF, double* FF, void* stream);
+
+/* collect_rhs_IP (simulator/cuda_utils.py:124-151) in its deterministic gather form (the reference ships the same
+ * idea unused: collect_rhs_kernel :153-188, CSR built at solver.py:284-313).  csr_bg/csr_cnt [n_k], csr_buf [8 n_IP]
+ * of (vid*8+dir) ascending per kernel.  rhs [10 n_k,3] is overwritten. */
+int pn_sim_collect_rhs(int n_k, double dx, const int* csr_bg, const int* csr_cnt, const int* csr_buf, const double* mu, const double* lam,
+                       const double* dNx, const double* RF, const double* VF, double* rhs, void* stream);
+
+/* Y[n,3] = A[n,n] X[n,3]: the kron(A,I3) form of `global_matrix @ rhs` / `mass_matrix_invt2 @ dof_tilde`
+ * (simulator/solver.py:493-496,532-538,576,600). */
+int pn_sim_matvec3(int n, const double* A, const double* X, double* Y, void* stream);
+
+/* Simulator.stepforward (simulator/solver.py:595-602) incl. compute_momentum (:574-576) and build_rhs (:541-571).
+ * All vectors [10 n_k,3] fp64.  dof and dof_vel are updated in place.  work: >= pn_sim_work_doubles(n_k, n_IP) doubles. */
+int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, double dx, const int* topo, const int* csr_bg, const int* csr_cnt,
+                       const int* csr_buf, const double* mu, const double* lam, const double* dNx, const double* Ainv, const double* Mmat,
+                       const double* dof_rest, const double* rhs_rest, const double* rhs_gravity, const double* dof_f, double* dof,
+                       double* dof_vel, double* work, void* stream);
+uint64_t pn_sim_work_doubles(int n_k, int n_IP);
+
+/* Simulator.update_force (simulator/solver.py:578-588): dof_f [10 n_k,3] is overwritten with the pick force of IP `vid`. */
+int pn_sim_update_force(int n_k, int vid, const double* f3_host, double dx, const int* topo, const double* rho, const double* Nx, double* dof_f,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIENERF_HIP_H */

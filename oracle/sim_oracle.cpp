@@ -1,0 +1,261 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
+//
+// CPU restatement of the simulator half of the PIE-NeRF hot path (SURVEY.md
+// §8a rows R1-R6): the per-substep local/global iteration of
+// simulator/solver.py:541-602 and the Warp kernels of
+// simulator/cuda_utils.py:83-151,206-233.  fp64 throughout, like the reference
+// (simulator/func_utils.py:9-18).  Only tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg may load this library.
+//
+// Unpinned third-party arithmetic: `wp.svd3` (warp-lang 0.13.0, not vendored
+// under /root/reference).  Its published contract is U, V proper rotations
+// (det +1) with a possibly negative smallest singular value; this file
+// restates that contract with a converged cyclic-Jacobi decomposition, so
+// R = U V^T is always the proper polar rotation.  All downstream quantities
+// (R, U diag(sigma') V^T) are invariant to the remaining freedom (simultaneous
+// column permutations / sign pairs).
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+struct M3 { double m[3][3]; };
+
+inline M3 mul(const M3& a, const M3& b) {
+    M3 c;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) c.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j];
+    return c;
+}
+inline M3 transpose(const M3& a) {
+    M3 c;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c.m[i][j] = a.m[j][i];
+    return c;
+}
+inline double det(const M3& a) {
+    return a.m[0][0] * (a.m[1][1] * a.m[2][2] - a.m[1][2] * a.m[2][1]) - a.m[0][1] * (a.m[1][0] * a.m[2][2] - a.m[1][2] * a.m[2][0]) +
+           a.m[0][2] * (a.m[1][0] * a.m[2][1] - a.m[1][1] * a.m[2][0]);
+}
+
+// svd3 contract of wp.svd3 (simulator/cuda_utils.py:107): F = U diag(sig) V^T,
+// det(U) = det(V) = +1, sig[0] >= sig[1] >= |sig[2]|, sig[2] carries the sign of det(F).
+void svd3(const M3& F, M3& U, double sig[3], M3& V) {
+    // symmetric eigen-decomposition of S = F^T F by cyclic Jacobi
+    M3 S = mul(transpose(F), F);
+    M3 Q;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Q.m[i][j] = (i == j);
+    for (int sweep = 0; sweep < 64; sweep++) {
+        const double off = S.m[0][1] * S.m[0][1] + S.m[0][2] * S.m[0][2] + S.m[1][2] * S.m[1][2];
+        const double dia = S.m[0][0] * S.m[0][0] + S.m[1][1] * S.m[1][1] + S.m[2][2] * S.m[2][2];
+        if (off <= 1e-34 * dia || off == 0.0) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (S.m[p][q] == 0.0) continue;
+                const double theta = (S.m[q][q] - S.m[p][p]) / (2.0 * S.m[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                // S <- J^T S J, Q <- Q J with J = rotation in (p,q)
+                for (int k = 0; k < 3; k++) {
+                    const double skp = S.m[k][p], skq = S.m[k][q];
+                    S.m[k][p] = c * skp - s * skq;
+                    S.m[k][q] = s * skp + c * skq;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double spk = S.m[p][k], sqk = S.m[q][k];
+                    S.m[p][k] = c * spk - s * sqk;
+                    S.m[q][k] = s * spk + c * sqk;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double qkp = Q.m[k][p], qkq = Q.m[k][q];
+                    Q.m[k][p] = c * qkp - s * qkq;
+                    Q.m[k][q] = s * qkp + c * qkq;
+                }
+            }
+    }
+    // B = F Q ; order columns by descending norm
+    M3 B = mul(F, Q);
+    double nrm[3];
+    int ord[3] = {0, 1, 2};
+    for (int j = 0; j < 3; j++) nrm[j] = std::sqrt(B.m[0][j] * B.m[0][j] + B.m[1][j] * B.m[1][j] + B.m[2][j] * B.m[2][j]);
+    std::sort(ord, ord + 3, [&](int a, int b) { return nrm[a] > nrm[b]; });
+    M3 Vs, Bs;
+    for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) { Vs.m[i][j] = Q.m[i][ord[j]]; Bs.m[i][j] = B.m[i][ord[j]]; }
+    if (det(Vs) < 0) for (int i = 0; i < 3; i++) { Vs.m[i][2] = -Vs.m[i][2]; Bs.m[i][2] = -Bs.m[i][2]; }
+    // U by Gram-Schmidt on the two dominant columns, third = cross product (det U = +1)
+    double u0[3], u1[3], u2[3];
+    double n0 = std::sqrt(Bs.m[0][0] * Bs.m[0][0] + Bs.m[1][0] * Bs.m[1][0] + Bs.m[2][0] * Bs.m[2][0]);
+    if (n0 > 0) for (int i = 0; i < 3; i++) u0[i] = Bs.m[i][0] / n0; else { u0[0] = 1; u0[1] = 0; u0[2] = 0; }
+    double d01 = u0[0] * Bs.m[0][1] + u0[1] * Bs.m[1][1] + u0[2] * Bs.m[2][1];
+    for (int i = 0; i < 3; i++) u1[i] = Bs.m[i][1] - d01 * u0[i];
+    double n1 = std::sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+    if (n1 > 1e-300 && n1 > 1e-14 * n0) for (int i = 0; i < 3; i++) u1[i] /= n1;
+    else {  // rank <= 1: any unit vector orthogonal to u0
+        int k = std::fabs(u0[0]) < std::fabs(u0[1]) ? (std::fabs(u0[0]) < std::fabs(u0[2]) ? 0 : 2) : (std::fabs(u0[1]) < std::fabs(u0[2]) ? 1 : 2);
+        double e[3] = {0, 0, 0};
+        e[k] = 1;
+        double d = u0[k];
+        for (int i = 0; i < 3; i++) u1[i] = e[i] - d * u0[i];
+        double n = std::sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+        for (int i = 0; i < 3; i++) u1[i] /= n;
+    }
+    u2[0] = u0[1] * u1[2] - u0[2] * u1[1];
+    u2[1] = u0[2] * u1[0] - u0[0] * u1[2];
+    u2[2] = u0[0] * u1[1] - u0[1] * u1[0];
+    for (int i = 0; i < 3; i++) { U.m[i][0] = u0[i]; U.m[i][1] = u1[i]; U.m[i][2] = u2[i]; }
+    V = Vs;
+    for (int j = 0; j < 3; j++) sig[j] = U.m[0][j] * Bs.m[0][j] + U.m[1][j] * Bs.m[1][j] + U.m[2][j] * Bs.m[2][j];
+}
+
+// simulator/func_utils.py:21-40
+void volume_invariant_project(const double sig[3], double out[3]) {
+    double D[3] = {0, 0, 0};
+    for (int i = 0; i < 3; i++) {
+        const double a = sig[0] + D[0], b = sig[1] + D[1], c = sig[2] + D[2];
+        const double C = a * b * c - 1.0;
+        const double dC[3] = {b * c, a * c, a * b};
+        const double dCTD = dC[0] * D[0] + dC[1] * D[1] + dC[2] * D[2];
+        const double coef = (dCTD - C) / (dC[0] * dC[0] + dC[1] * dC[1] + dC[2] * dC[2]);
+        D[0] = coef * dC[0]; D[1] = coef * dC[1]; D[2] = coef * dC[2];
+    }
+    for (int i = 0; i < 3; i++) out[i] = sig[i] + D[i];
+}
+
+inline M3 udv(const M3& U, const double s[3], const M3& V) {  // U diag(s) V^T
+    M3 r;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) r.m[i][j] = U.m[i][0] * s[0] * V.m[j][0] + U.m[i][1] * s[1] * V.m[j][1] + U.m[i][2] * s[2] * V.m[j][2];
+    return r;
+}
+
+}  // namespace
+
+extern "C" {
+
+void orc_svd3(const double* F9, double* U9, double* sig3, double* V9) {
+    M3 F, U, V;
+    std::memcpy(F.m, F9, sizeof(F.m));
+    svd3(F, U, sig3, V);
+    std::memcpy(U9, U.m, sizeof(U.m));
+    std::memcpy(V9, V.m, sizeof(V.m));
+}
+
+void orc_volume_invariant_project(const double* sig, double* out) { volume_invariant_project(sig, out); }
+
+// update_F_kernel (cuda_utils.py:206-233) followed by the layout transform and
+// fp32 cast of Simulator.get_IP_info (solver.py:402-424):
+//   pos[n,3]; F flat [c*3+r]; dF flat [c*9 + r*3 + j].
+// Nx [n,8,10], dNx [n,8,3,10], ddNx [n,8,3,3,10] fp64; dof [10 n_k, 3] fp64.
+void orc_update_F(int n_IP, const int* topo, const double* dof, const double* Nx, const double* dNx, const double* ddNx, float* pos, float* F, float* dF) {
+#pragma omp parallel for schedule(static)
+    for (int v = 0; v < n_IP; v++) {
+        double p[3] = {0, 0, 0}, Fm[3][3] = {{0}}, dFm[3][3][3] = {{{0}}};  // dFm[j][r][c]
+        for (int i = 0; i < 8; i++) {
+            const int kid = topo[v * 8 + i];
+            for (int x = 0; x < 10; x++) {
+                const double* d = dof + ((size_t)kid * 10 + x) * 3;
+                const double N = Nx[((size_t)v * 8 + i) * 10 + x];
+                for (int r = 0; r < 3; r++) p[r] += N * d[r];
+                for (int r = 0; r < 3; r++)
+                    for (int c = 0; c < 3; c++) Fm[r][c] += d[r] * dNx[(((size_t)v * 8 + i) * 3 + c) * 10 + x];
+                for (int j = 0; j < 3; j++)
+                    for (int r = 0; r < 3; r++)
+                        for (int c = 0; c < 3; c++) dFm[j][r][c] += d[r] * ddNx[((((size_t)v * 8 + i) * 3 + j) * 3 + c) * 10 + x];
+            }
+        }
+        for (int r = 0; r < 3; r++) pos[v * 3 + r] = (float)p[r];
+        for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) F[v * 9 + c * 3 + r] = (float)Fm[r][c];
+        for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) for (int j = 0; j < 3; j++) dF[v * 27 + c * 9 + r * 3 + j] = (float)dFm[j][r][c];
+    }
+}
+
+// calc_elastic (cuda_utils.py:83-121): RF, VF, FF [n_IP,3,3] row-major.
+void orc_calc_elastic(int n_IP, const int* topo, const double* dNx, const double* dof, double* RF, double* VF, double* FF) {
+#pragma omp parallel for schedule(static)
+    for (int v = 0; v < n_IP; v++) {
+        M3 F;
+        std::memset(F.m, 0, sizeof(F.m));
+        for (int i = 0; i < 8; i++) {
+            const int kid = topo[v * 8 + i];
+            for (int x = 0; x < 10; x++) {
+                const double* d = dof + ((size_t)kid * 10 + x) * 3;
+                for (int r = 0; r < 3; r++)
+                    for (int c = 0; c < 3; c++) F.m[r][c] += d[r] * dNx[(((size_t)v * 8 + i) * 3 + c) * 10 + x];
+            }
+        }
+        M3 U, V;
+        double sig[3], sigp[3];
+        svd3(F, U, sig, V);
+        M3 R = mul(U, transpose(V));
+        volume_invariant_project(sig, sigp);
+        M3 Vm = udv(U, sigp, V);
+        M3 Fr = udv(U, sig, V);
+        std::memcpy(RF + (size_t)v * 9, R.m, sizeof(R.m));
+        std::memcpy(VF + (size_t)v * 9, Vm.m, sizeof(Vm.m));
+        if (FF) std::memcpy(FF + (size_t)v * 9, Fr.m, sizeof(Fr.m));
+    }
+}
+
+// collect_rhs_IP (cuda_utils.py:124-151).  The reference accumulates with fp64
+// atomics in race order; the oracle adds in ascending IP id (one member of the
+// reference's outcome set).  rhs [10 n_k, 3] must be zeroed by the caller.
+void orc_collect_rhs_IP(int n_IP, double dx, const int* topo, const double* mu, const double* lam, const double* dNx, double* rhs, const double* RF,
+                        const double* VF) {
+    const double dx3 = std::pow(dx, 3.0);
+    for (int v = 0; v < n_IP; v++) {
+        double P[3][3];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) P[r][c] = dx3 * (mu[v] * RF[(size_t)v * 9 + r * 3 + c] + lam[v] * VF[(size_t)v * 9 + r * 3 + c]);
+        for (int i = 0; i < 8; i++) {
+            const int kid = topo[v * 8 + i];
+            for (int x = 0; x < 10; x++) {
+                double dN[3];
+                for (int c = 0; c < 3; c++) dN[c] = dNx[(((size_t)v * 8 + i) * 3 + c) * 10 + x];
+                double* o = rhs + ((size_t)kid * 10 + x) * 3;
+                for (int r = 0; r < 3; r++) o[r] += P[r][0] * dN[0] + P[r][1] * dN[1] + P[r][2] * dN[2];
+            }
+        }
+    }
+}
+
+// Y[n,3] = A[n,n] X[n,3] — the kron(A, I3) form of `global_matrix @ rhs` /
+// `mass_matrix_invt2 @ dof_tilde` (solver.py:493-496,532-538,576,600): the
+// reference's (30 n_k)^2 matrices are A interleaved per xyz, so each output
+// sums exactly the same non-zero products in the same column order.
+void orc_matvec3(int n, const double* A, const double* X, double* Y) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) {
+        double s0 = 0, s1 = 0, s2 = 0;
+        const double* a = A + (size_t)i * n;
+        for (int j = 0; j < n; j++) { s0 += a[j] * X[j * 3]; s1 += a[j] * X[j * 3 + 1]; s2 += a[j] * X[j * 3 + 2]; }
+        Y[i * 3] = s0; Y[i * 3 + 1] = s1; Y[i * 3 + 2] = s2;
+    }
+}
+
+// Simulator.stepforward (solver.py:595-602) + compute_momentum (:574-576) + build_rhs (:541-571).
+// All vectors are [10 n_k, 3] fp64 flattened (index kernel*30 + coef*3 + xyz).  n = 10 n_k.
+void orc_stepforward(int n, int n_IP, int iters, double dt, double dx, const int* topo, const double* mu, const double* lam, const double* dNx,
+                     const double* Ainv, const double* Mmat, const double* dof_rest, const double* rhs_rest, const double* rhs_gravity,
+                     const double* dof_f, double* dof, double* dof_vel) {
+    const size_t n3 = (size_t)n * 3;
+    std::vector<double> tilde(n3), momentum(n3), last(dof, dof + n3), rhs(n3), tot(n3), x(n3), RF((size_t)n_IP * 9), VF((size_t)n_IP * 9);
+    for (size_t i = 0; i < n3; i++) tilde[i] = dof[i] + dt * dof_vel[i];
+    orc_matvec3(n, Mmat, tilde.data(), momentum.data());
+    for (size_t i = 0; i < n3; i++) momentum[i] = momentum[i] + dof_f[i] + rhs_gravity[i];
+    for (int it = 0; it < iters; it++) {
+        orc_calc_elastic(n_IP, topo, dNx, dof, RF.data(), VF.data(), nullptr);
+        std::fill(rhs.begin(), rhs.end(), 0.0);
+        orc_collect_rhs_IP(n_IP, dx, topo, mu, lam, dNx, rhs.data(), RF.data(), VF.data());
+        for (size_t i = 0; i < n3; i++) tot[i] = momentum[i] + rhs[i] - rhs_rest[i];
+        orc_matvec3(n, Ainv, tot.data(), x.data());
+        for (size_t i = 0; i < n3; i++) dof[i] = dof_rest[i] + x[i];
+    }
+    for (size_t i = 0; i < n3; i++) dof_vel[i] = (dof[i] - last[i]) / dt * 0.998;
+}
+
+}  // extern "C"

@@ -1,0 +1,92 @@
+"""ctypes binding of libpienerf_hip.so (include/pienerf_hip.h).
+
+There is NO CPU fallback: if the library is missing or a symbol is absent this module raises at
+first use, and every op raises RuntimeError when handed a non-GPU tensor.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpienerf_hip.so")
+
+P = C.c_void_p
+u32, i32, f32, f64, u64 = C.c_uint32, C.c_int, C.c_float, C.c_double, C.c_uint64
+
+
+class RenderOpts(C.Structure):
+    """pn_render_opts (include/pienerf_hip.h)."""
+    _fields_ = [("max_iter_num", i32), ("hash_grid_size", f32), ("num_seek_IP", i32), ("IP_dx", f32), ("cut", i32), ("cut_bounds", f32 * 6),
+                ("bound", f32), ("min_near", f32), ("dt_gamma", f32), ("max_steps", u32), ("T_thresh", f32), ("cascade", u32), ("grid_size", u32),
+                ("density_scale", f32), ("bg_color", f32)]
+
+
+# name -> (restype, argtypes); every function declared in include/pienerf_hip.h
+SIGNATURES = {
+    "pn_version": (C.c_char_p, []),
+    "pn_last_error": (C.c_char_p, []),
+    "pn_near_far_from_aabb": (i32, [P, P, P, u32, f32, P, P, P]),
+    "pn_march_rays_quadratic_bending": (i32, [P, P, P, i32, i32, P, P, P, P, i32, P, P, f32, P, i32, f32, i32, P, u32, u32, P, P, P, P, f32, f32, u32,
+                                              u32, u32, P, P, P, P, P, P, P, P, P]),
+    "pn_composite_rays": (i32, [u32, u32, f32, P, P, P, P, P, P, P, P, P]),
+    "pn_compact_rays": (i32, [P, u32, P, P, P, P]),
+    "pn_compact_scratch_ints": (u32, [u32]),
+    "pn_pnts_in_grids": (i32, [i32, i32, P, P, f32, P, P, P, P, P, P]),
+    "pn_get_rays": (i32, [P, f32, f32, f32, f32, i32, i32, P, P, P]),
+    "pn_grid_encode_forward": (i32, [P, P, P, P, u32, u32, u32, u32, f32, u32, P, u32, i32, u32, i32, P]),
+    "pn_sh_encode_forward": (i32, [P, P, u32, u32, u32, P, P]),
+    "pn_net_create": (i32, [C.POINTER(P), P, P, u32, u32, f32, u32, f32, P, P, P, P, P, P]),
+    "pn_net_destroy": (None, [P]),
+    "pn_nerf_forward": (i32, [P, P, P, u32, f32, P, P, P]),
+    "pn_frame_create": (i32, [C.POINTER(P), u32, u32, u32]),
+    "pn_frame_destroy": (None, [P]),
+    "pn_render_deformed": (i32, [P, P, C.POINTER(RenderOpts), P, P, u32, P, P, P, P, i32, P, P, P, P, P, P, P]),
+    "pn_sim_update_F": (i32, [i32, P, P, P, P, P, P, P, P, P]),
+    "pn_sim_calc_elastic": (i32, [i32, P, P, P, P, P, P, P]),
+    "pn_sim_collect_rhs": (i32, [i32, f64, P, P, P, P, P, P, P, P, P, P]),
+    "pn_sim_matvec3": (i32, [i32, P, P, P, P]),
+    "pn_sim_stepforward": (i32, [i32, i32, i32, f64, f64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "pn_sim_work_doubles": (u64, [i32, i32]),
+    "pn_sim_update_force": (i32, [i32, i32, P, f64, P, P, P, P, P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library with argtypes set.  Raises if it was not built (python -m pienerf_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m pienerf_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().pn_last_error().decode(errors="replace")
+        raise RuntimeError(f"libpienerf_hip: {what} failed with code {rc}: {msg}")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("pienerf_amd ops run on the GPU only (HIP kernels); got a CPU tensor and there is no CPU fallback")
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensor must be contiguous"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,67 @@
+"""Builds libpienerf_hip.so (hand-written HIP, gfx950 only) with hipcc.
+
+    python -m pienerf_amd.build [--force] [--save-temps]
+
+hipcc cross-compiles without a GPU.  The library is built in-tree (pienerf_amd/lib/) so that it
+travels with the source tree; `*.so` is git-ignored.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "lib", "obj")
+LIB = os.path.join(HERE, "lib", "libpienerf_hip.so")
+ARCH = "gfx950"
+
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function",
+          "-Wno-unused-variable"]
+# per-translation-unit flags: the ray-side kernels round every operation once, in source order (bit-exact integer
+# decisions vs the CPU oracle); the encoder/MLP and the fp64 simulator let the compiler contract to FMA.
+UNITS = {
+    "pn_render_ops.hip": ["-ffp-contract=off"],
+    "pn_nerf_forward.hip": ["-ffp-contract=fast"],
+    "pn_sim.hip": ["-ffp-contract=fast"],
+}
+
+
+def hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: libpienerf_hip.so cannot be built (there is no CPU fallback)")
+
+
+def _stale(out, deps):
+    return (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+
+
+def build(force=False, save_temps=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "pienerf_hip.h"),
+                                                                                     os.path.abspath(__file__)]
+    cc = hipcc()
+    objs = []
+    for src, extra in UNITS.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [cc] + COMMON + extra + ["-c", s, "-o", o]
+            if save_temps:
+                cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True, cwd=OBJ)
+    if force or _stale(LIB, objs):
+        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True))

@@ -1,0 +1,65 @@
+// Shared host/device helpers for libpienerf_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/pienerf_hip.h"
+
+#define PN_WAVE 64
+
+extern thread_local char pn_err_buf[512];
+
+#define PN_HIP_CHECK(expr)                                                                                   \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess) {                                                                              \
+            snprintf(pn_err_buf, sizeof(pn_err_buf), "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return PN_ERR_HIP;                                                                               \
+        }                                                                                                    \
+    } while (0)
+
+#define PN_LAUNCH_CHECK() PN_HIP_CHECK(hipGetLastError())
+
+#define PN_REQUIRE(cond)                                                                       \
+    do {                                                                                       \
+        if (!(cond)) {                                                                         \
+            snprintf(pn_err_buf, sizeof(pn_err_buf), "%s:%d argument check failed: %s", __FILE__, __LINE__, #cond); \
+            return PN_ERR_ARG;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+static inline uint32_t pn_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// Per-level geometry of the multiresolution hash grid, derived on the host with the reference's formulas
+// (gridencoder/src/gridencoder.cu:132-134) so that host libm — not the GPU's approximate exp2 — fixes
+// `scale` and `resolution` bit-for-bit.
+#define PN_MAX_LEVELS 16
+struct PnGridLevels {
+    uint32_t L, C;
+    uint32_t offset[PN_MAX_LEVELS];        // entries (not floats) before this level
+    uint32_t hashmap_size[PN_MAX_LEVELS];  // offsets[l+1] - offsets[l]
+    uint32_t resolution[PN_MAX_LEVELS];    // ceil(scale) + 1
+    float scale[PN_MAX_LEVELS];            // exp2f(l*S)*H - 1
+    uint32_t dense[PN_MAX_LEVELS];         // 0: hashed (fast_hash), else number of dims entering the direct index (3 = fully dense)
+    uint32_t mask[PN_MAX_LEVELS];          // hashmap_size - 1 when it is a power of two, else 0
+    uint32_t nomod[PN_MAX_LEVELS];         // 1 when the direct index is provably < hashmap_size (no modulo needed)
+};
+
+int pn_fill_grid_levels(PnGridLevels* g, const int* offsets_host, uint32_t L, uint32_t C, float S, uint32_t H, uint32_t gridtype,
+                        int align_corners);
+
+// The packed network context (pn_net in the C ABI).
+struct pn_net {
+    PnGridLevels levels;
+    const float* embeddings;  // device, not owned
+    float* wpack;             // device, owned: MFMA A-operand stream, [PN_NET_MFMAS][64]
+    float bound;
+};
+#define PN_NET_MFMAS 192
+
+// internal launcher shared by pn_nerf_forward and the frame driver: evaluates the network on the `count` samples whose
+// slot ids are list[0..count) (list == NULL: slots 0..M-1); when ctl_count != NULL the count is read from device memory.
+int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* dirs, const int* list, const int* ctl_count, uint32_t M_max,
+                           float density_scale, float* sigmas, float* rgbs, hipStream_t stream);

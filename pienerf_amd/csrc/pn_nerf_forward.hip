@@ -1,0 +1,463 @@
+// Hash-grid / SH encoders and the fused NeRFNetwork.forward kernel for gfx950.
+//
+// Reference: gridencoder/src/gridencoder.cu:50-245 (kernel_grid), shencoder/src/shencoder.cu:27-123 (kernel_sh),
+// nerf/network.py:98-127 (forward), nerf/activation.py (trunc_exp) — paths relative to /root/reference.
+//
+// Fused kernel layout (one wave = 32 samples, two lanes per sample):
+//   lane l: sample s = l & 31, half h = l >> 5.  Half h gathers hash levels [8h, 8h+8) -> 16 features per lane.
+//   Every dense layer is a chain of v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, D = W·X^T):
+//     A operand (lane l) = W[out = tile*32 + (l&31)][k(h)]   — pre-permuted on the host, streamed from LDS
+//     B operand (lane l) = this lane's own activation register — k(0) comes from the low half, k(1) from the high half
+//     D layout: lane l holds out-rows (r&3) + 8*(r>>2) + 4h, r = 0..15, of column s.
+//   The D layout of one layer is exactly the B layout of the next (rows i and i+4 pair up), so activations never
+//   leave registers; the only LDS traffic is the 48 KB weight stream shared by all waves of a workgroup.
+#include <math.h>
+
+#include "pn_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------ level table
+int pn_fill_grid_levels(PnGridLevels* g, const int* offsets_host, uint32_t L, uint32_t C, float S, uint32_t H, uint32_t gridtype,
+                        int align_corners) {
+    if (L == 0 || L > PN_MAX_LEVELS) return PN_ERR_ARG;
+    g->L = L;
+    g->C = C;
+    for (uint32_t l = 0; l < L; l++) {
+        const float scale = exp2f(l * S) * H - 1.0f;            // gridencoder.cu:133
+        const uint32_t res = (uint32_t)ceilf(scale) + 1;        // :134
+        const uint32_t hs = (uint32_t)(offsets_host[l + 1] - offsets_host[l]);
+        // replay get_grid_index's stride loop (gridencoder.cu:65-84) to learn whether this level is hashed
+        uint32_t stride = 1, dims = 0;
+        for (uint32_t d = 0; d < 3 && stride <= hs; d++) { stride *= align_corners ? res : (res + 1); dims++; }
+        const bool hashed = (gridtype == 0 && stride > hs);
+        g->offset[l] = (uint32_t)offsets_host[l];
+        g->hashmap_size[l] = hs;
+        g->resolution[l] = res;
+        g->scale[l] = scale;
+        g->dense[l] = hashed ? 0u : dims;  // number of dims that enter the direct index (3 = fully dense)
+        g->mask[l] = (hs & (hs - 1)) == 0 ? hs - 1 : 0u;
+        // fully dense, untiled: max index = (res+1)^3 - 1 < stride <= hs, so `% hs` is the identity
+        g->nomod[l] = (!hashed && dims == 3 && !align_corners && gridtype == 0) ? 1u : 0u;
+    }
+    return PN_OK;
+}
+
+// get_grid_index for D = 3 (gridencoder.cu:65-84); `dense` = 0 -> fast_hash, else number of strided dims.
+struct LevelIdx { uint32_t dense, hs, mask, nomod, stride1; };
+__device__ __forceinline__ LevelIdx level_idx(const PnGridLevels& lv, uint32_t level, int align_corners) {
+    return LevelIdx{lv.dense[level], lv.hashmap_size[level], lv.mask[level], lv.nomod[level],
+                    align_corners ? lv.resolution[level] : lv.resolution[level] + 1};
+}
+__device__ __forceinline__ uint32_t grid_index3(const LevelIdx& L, uint32_t g0, uint32_t g1, uint32_t g2) {
+    if (L.dense == 0) {
+        const uint32_t index = g0 ^ (g1 * 2654435761u) ^ (g2 * 805459861u);
+        return L.mask ? (index & L.mask) : (index % L.hs);
+    }
+    const uint32_t index = g0 + (L.dense > 1 ? g1 * L.stride1 : 0u) + (L.dense > 2 ? g2 * L.stride1 * L.stride1 : 0u);
+    return L.nomod ? index : (index % L.hs);
+}
+
+// ------------------------------------------------------------------------------------------------ op-level grid encoder
+// One thread per (sample, level); blockIdx.y = level keeps one level's table hot in the XCD L2s (gridencoder.cu:103,388).
+template <uint32_t C>
+__global__ void __launch_bounds__(256) k_grid_encode(const float* __restrict__ inputs, const float* __restrict__ emb, PnGridLevels lv, uint32_t B,
+                                                     int align_corners, uint32_t interp, int out_bl_major, float* __restrict__ outputs) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+    float* out = out_bl_major ? outputs + ((size_t)b * lv.L + level) * C : outputs + ((size_t)level * B + b) * C;
+    const float in0 = inputs[b * 3], in1 = inputs[b * 3 + 1], in2 = inputs[b * 3 + 2];
+    if (in0 < 0 || in0 > 1 || in1 < 0 || in1 > 1 || in2 < 0 || in2 > 1) {
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) out[c] = 0;
+        return;
+    }
+    const float* __restrict__ table = emb + (size_t)lv.offset[level] * C;
+    const LevelIdx LI = level_idx(lv, level, align_corners);
+    const float scale = lv.scale[level];
+    float pos[3] = {in0, in1, in2};
+    uint32_t pg[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        pos[d] = pos[d] * scale + (align_corners ? 0.0f : 0.5f);
+        pg[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pg[d];
+        if (interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+    }
+    float res[C];
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) res[c] = 0;
+#pragma unroll
+    for (uint32_t idx = 0; idx < 8; idx++) {
+        float w = 1;
+        uint32_t pl[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pg[d]; }
+            else { w *= pos[d]; pl[d] = pg[d] + 1; }
+        }
+        const uint32_t index = grid_index3(LI, pl[0], pl[1], pl[2]) * C;
+        if (C == 2) {
+            const float2 v = *reinterpret_cast<const float2*>(table + index);
+            res[0] += w * v.x;
+            res[1] += w * v.y;
+        } else {
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) res[c] += w * table[index + c];
+        }
+    }
+    if (C == 2) *reinterpret_cast<float2*>(out) = make_float2(res[0], res[1]);
+    else {
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) out[c] = res[c];
+    }
+}
+
+extern "C" int pn_grid_encode_forward(const float* inputs, const float* embeddings, const int* offsets_host, float* outputs, uint32_t B, uint32_t D,
+                                      uint32_t C, uint32_t L, float S, uint32_t H, const float* dy_dx, uint32_t gridtype, int align_corners,
+                                      uint32_t interp, int out_bl_major, void* stream) {
+    PN_REQUIRE(inputs && embeddings && offsets_host && outputs);
+    PN_REQUIRE(D == 3);                                   // the reference also has D = 2,4,5 (gridencoder.cu:386-395); not on this path
+    PN_REQUIRE(C == 1 || C == 2 || C == 4 || C == 8);     // gridencoder.cu:376-382
+    PN_REQUIRE(dy_dx == nullptr && gridtype <= 1 && interp <= 1);
+    if (B == 0) return PN_OK;
+    PnGridLevels lv;
+    if (pn_fill_grid_levels(&lv, offsets_host, L, C, S, H, gridtype, align_corners)) { PN_REQUIRE(L >= 1 && L <= PN_MAX_LEVELS); }
+    dim3 grid(pn_div_up(B, 256), L, 1);
+    hipStream_t st = (hipStream_t)stream;
+    switch (C) {
+        case 1: k_grid_encode<1><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
+        case 2: k_grid_encode<2><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
+        case 4: k_grid_encode<4><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
+        default: k_grid_encode<8><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
+    }
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ SH (degree <= 4)
+// Real SH basis in the reference's sign convention (shencoder.cu:50-68); constants are the closed forms of its comments.
+#define SH_C0 0.28209479177387814f   /* 1/(2 sqrt(pi)) */
+#define SH_C1 0.48860251190291992f   /* sqrt(3)/(2 sqrt(pi)) */
+#define SH_C2A 1.0925484305920792f   /* sqrt(15)/(2 sqrt(pi)) */
+#define SH_C2B 0.94617469575755997f  /* 3 sqrt(5)/(4 sqrt(pi)) */
+#define SH_C2C 0.31539156525251999f  /* sqrt(5)/(4 sqrt(pi)) */
+#define SH_C2D 0.54627421529603959f  /* sqrt(15)/(4 sqrt(pi)) */
+#define SH_C3A 0.59004358992664352f  /* sqrt(70)/(8 sqrt(pi)) */
+#define SH_C3B 2.8906114426405538f   /* sqrt(105)/(2 sqrt(pi)) */
+#define SH_C3C 0.45704579946446572f  /* sqrt(42)/(8 sqrt(pi)) */
+#define SH_C3D 0.3731763325901154f   /* sqrt(7)/(4 sqrt(pi)) */
+#define SH_C3E 1.4453057213202769f   /* sqrt(105)/(4 sqrt(pi)) */
+
+__device__ __forceinline__ void sh16(float x, float y, float z, float* o) {
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    o[0] = SH_C0;
+    o[1] = -SH_C1 * y;
+    o[2] = SH_C1 * z;
+    o[3] = -SH_C1 * x;
+    o[4] = SH_C2A * xy;
+    o[5] = -SH_C2A * yz;
+    o[6] = SH_C2B * z2 - SH_C2C;
+    o[7] = -SH_C2A * xz;
+    o[8] = SH_C2D * x2 - SH_C2D * y2;
+    o[9] = SH_C3A * y * (-3.0f * x2 + y2);
+    o[10] = SH_C3B * xy * z;
+    o[11] = SH_C3C * y * (1.0f - 5.0f * z2);
+    o[12] = SH_C3D * z * (5.0f * z2 - 3.0f);
+    o[13] = SH_C3C * x * (1.0f - 5.0f * z2);
+    o[14] = SH_C3E * z * (x2 - y2);
+    o[15] = SH_C3A * x * (-x2 + 3.0f * y2);
+}
+
+__global__ void __launch_bounds__(256) k_sh_encode(const float* __restrict__ inputs, float* __restrict__ outputs, uint32_t B, uint32_t C) {
+    const uint32_t b = threadIdx.x + blockIdx.x * blockDim.x;
+    if (b >= B) return;
+    float o[16];
+    sh16(inputs[b * 3], inputs[b * 3 + 1], inputs[b * 3 + 2], o);
+    const uint32_t C2 = C * C;
+    for (uint32_t i = 0; i < C2; i++) outputs[(size_t)b * C2 + i] = o[i];
+}
+
+extern "C" int pn_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C, const float* dy_dx, void* stream) {
+    PN_REQUIRE(inputs && outputs && D == 3 && C >= 1 && C <= 4 && dy_dx == nullptr);  // degrees 5-8 (shencoder.cu:70-122): not on this path
+    if (B == 0) return PN_OK;
+    k_sh_encode<<<pn_div_up(B, 256), 256, 0, (hipStream_t)stream>>>(inputs, outputs, B, C);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ fused network
+// colour-net input slot -> index into cat([SH16, geo15]) (31 = zero pad); low half / high half of the lane pair
+static const int PN_MAPL[16] = {16, 17, 18, 23, 24, 25, 26, 0, 1, 2, 3, 4, 5, 6, 7, 8};
+static const int PN_MAPU[16] = {19, 20, 21, 22, 27, 28, 29, 30, 9, 10, 11, 12, 13, 14, 15, 31};
+
+// Host: A-operand stream, wpack[m][lane], in MFMA issue order (see header comment).
+static void pack_weights(const float* W0, const float* W1, const float* W2, const float* W3, const float* W4, float* wp) {
+    auto krow = [](int q, int h) { const int t = q >> 4, r = q & 15; return t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; };
+    int m = 0;
+    for (int t = 0; t < 2; t++)  // layer 0: 32 -> 64
+        for (int kk = 0; kk < 16; kk++, m++)
+            for (int l = 0; l < 64; l++) wp[m * 64 + l] = W0[(t * 32 + (l & 31)) * 32 + kk + 16 * (l >> 5)];
+    for (int q = 0; q < 32; q++, m++)  // layer 1: 64 -> 16 (rows 16..31 zero)
+        for (int l = 0; l < 64; l++) wp[m * 64 + l] = ((l & 31) < 16) ? W1[(l & 31) * 64 + krow(q, l >> 5)] : 0.0f;
+    for (int t = 0; t < 2; t++)  // layer 2: 31 (+1 pad) -> 64
+        for (int kk = 0; kk < 16; kk++, m++)
+            for (int l = 0; l < 64; l++) {
+                const int ci = (l >> 5) ? PN_MAPU[kk] : PN_MAPL[kk];
+                wp[m * 64 + l] = (ci < 31) ? W2[(t * 32 + (l & 31)) * 31 + ci] : 0.0f;
+            }
+    for (int t = 0; t < 2; t++)  // layer 3: 64 -> 64
+        for (int q = 0; q < 32; q++, m++)
+            for (int l = 0; l < 64; l++) wp[m * 64 + l] = W3[(t * 32 + (l & 31)) * 64 + krow(q, l >> 5)];
+    for (int q = 0; q < 32; q++, m++)  // layer 4: 64 -> 3 (rows 3..31 zero)
+        for (int l = 0; l < 64; l++) wp[m * 64 + l] = ((l & 31) < 3) ? W4[(l & 31) * 64 + krow(q, l >> 5)] : 0.0f;
+}
+
+extern "C" int pn_net_create(pn_net** out, const float* embeddings, const int* offsets_host, uint32_t L, uint32_t C, float per_level_scale_log2,
+                             uint32_t base_resolution, float bound, const float* W0, const float* W1, const float* W2, const float* W3,
+                             const float* W4, void* stream) {
+    PN_REQUIRE(out && embeddings && offsets_host && W0 && W1 && W2 && W3 && W4);
+    PN_REQUIRE(L == 16 && C == 2);  // the architecture of nerf/network.py:14-95 / nerf/encoding.py:40-70
+    pn_net* n = new pn_net();
+    if (pn_fill_grid_levels(&n->levels, offsets_host, L, C, per_level_scale_log2, base_resolution, 0, 0)) { delete n; return PN_ERR_ARG; }
+    for (uint32_t l = 0; l < L; l++)
+        if (n->levels.dense[l] != 0 && n->levels.dense[l] != 3) { delete n; PN_REQUIRE(!"partially strided level"); }
+    n->embeddings = embeddings;
+    n->bound = bound;
+    float* host = new float[PN_NET_MFMAS * 64];
+    pack_weights(W0, W1, W2, W3, W4, host);
+    // LDS image: [m/4][lane][4] so that one ds_read_b128 fetches the A operands of 4 consecutive MFMAs
+    float* img = new float[PN_NET_MFMAS * 64];
+    for (int m = 0; m < PN_NET_MFMAS; m++)
+        for (int l = 0; l < 64; l++) img[((m >> 2) * 64 + l) * 4 + (m & 3)] = host[m * 64 + l];
+    hipError_t e = hipMalloc((void**)&n->wpack, sizeof(float) * PN_NET_MFMAS * 64);
+    if (e == hipSuccess) e = hipMemcpyAsync(n->wpack, img, sizeof(float) * PN_NET_MFMAS * 64, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    delete[] host;
+    delete[] img;
+    if (e != hipSuccess) {
+        snprintf(pn_err_buf, sizeof(pn_err_buf), "pn_net_create: %s", hipGetErrorString(e));
+        delete n;
+        return PN_ERR_HIP;
+    }
+    *out = n;
+    return PN_OK;
+}
+
+extern "C" void pn_net_destroy(pn_net* n) {
+    if (!n) return;
+    if (n->wpack) (void)hipFree(n->wpack);
+    delete n;
+}
+
+// 8 hash levels for one lane: feat[2j + c] = level (8h + j), channel c   (kernel_grid<float,3,2>, gridencoder.cu:87-197)
+__device__ __forceinline__ void encode8(const PnGridLevels& lv, const float* __restrict__ emb, int half, float u0, float u1, float u2, bool oob,
+                                        float* feat) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int level = half * 8 + j;
+        const float scale = lv.scale[level];
+        const LevelIdx LI = level_idx(lv, level, 0);
+        const float2* __restrict__ table = reinterpret_cast<const float2*>(emb) + lv.offset[level];
+        float p0 = u0 * scale + 0.5f, p1 = u1 * scale + 0.5f, p2 = u2 * scale + 0.5f;
+        const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+        const uint32_t g0 = (uint32_t)f0, g1 = (uint32_t)f1, g2 = (uint32_t)f2;
+        p0 -= f0; p1 -= f1; p2 -= f2;
+        float2 v[8];
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+            const uint32_t index = grid_index3(LI, g0 + (idx & 1), g1 + ((idx >> 1) & 1), g2 + ((idx >> 2) & 1));
+            v[idx] = table[index];
+        }
+        float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+            float w = 1;
+            w *= (idx & 1) ? p0 : 1 - p0;
+            w *= (idx & 2) ? p1 : 1 - p1;
+            w *= (idx & 4) ? p2 : 1 - p2;
+            r0 += w * v[idx].x;
+            r1 += w * v[idx].y;
+        }
+        feat[2 * j] = oob ? 0.f : r0;
+        feat[2 * j + 1] = oob ? 0.f : r1;
+    }
+}
+
+#define PN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f32x16 relu16(f32x16 v) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = fmaxf(v[r], 0.0f);
+    return v;
+}
+
+// Workgroup = 4 waves; LDS = the 48 KB packed weight image.
+__global__ void __launch_bounds__(256) k_nerf_forward(PnGridLevels lv, const float* __restrict__ emb, const float* __restrict__ wpack, float bound,
+                                                      const float* __restrict__ xyzs, const float* __restrict__ dirs, const int* __restrict__ list,
+                                                      const int* __restrict__ count_dev, uint32_t M_arg, float density_scale,
+                                                      float* __restrict__ sigmas, float* __restrict__ rgbs) {
+    extern __shared__ __attribute__((aligned(16))) float4 wlds[];  // [48][64] float4
+    const uint32_t M = count_dev ? (uint32_t)*count_dev : M_arg;
+    const uint32_t n_tiles = (M + 31) / 32;
+    const uint32_t waves_total = gridDim.x * 4;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x * 4 >= n_tiles) return;  // no tile for any wave of this block
+    {
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(wpack);
+        for (int i = threadIdx.x; i < PN_NET_MFMAS * 16; i += 256) wlds[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int s = lane & 31, half = lane >> 5;
+    const float4* __restrict__ wl = wlds + lane;
+
+    for (uint32_t tile = wave; tile < n_tiles; tile += waves_total) {
+        const uint32_t li = tile * 32 + s;
+        const bool valid = li < M;
+        const uint32_t slot = valid ? (list ? (uint32_t)list[li] : li) : 0u;
+        float x = 0.f, y = 0.f, z = 0.f, dx = 0.f, dy = 0.f, dz = 1.f;
+        if (valid) {
+            x = xyzs[slot * 3]; y = xyzs[slot * 3 + 1]; z = xyzs[slot * 3 + 2];
+            dx = dirs[slot * 3]; dy = dirs[slot * 3 + 1]; dz = dirs[slot * 3 + 2];
+        }
+        // GridEncoder.forward: inputs = (x + bound) / (2 * bound)  (gridencoder/grid.py:149)
+        const float u0 = (x + bound) / (2 * bound), u1 = (y + bound) / (2 * bound), u2 = (z + bound) / (2 * bound);
+        const bool oob = (u0 < 0 || u0 > 1 || u1 < 0 || u1 > 1 || u2 < 0 || u2 > 1);
+        float feat[16];
+        encode8(lv, emb, half, oob ? 0.f : u0, oob ? 0.f : u1, oob ? 0.f : u2, oob, feat);
+
+        // ---- sigma net layer 0: 32 -> 64, ReLU
+        f32x16 a0 = {0}, a1 = {0};
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 w = wl[(0 + g) * 64];
+            a0 = PN_MFMA(w.x, feat[4 * g + 0], a0);
+            a0 = PN_MFMA(w.y, feat[4 * g + 1], a0);
+            a0 = PN_MFMA(w.z, feat[4 * g + 2], a0);
+            a0 = PN_MFMA(w.w, feat[4 * g + 3], a0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 w = wl[(4 + g) * 64];
+            a1 = PN_MFMA(w.x, feat[4 * g + 0], a1);
+            a1 = PN_MFMA(w.y, feat[4 * g + 1], a1);
+            a1 = PN_MFMA(w.z, feat[4 * g + 2], a1);
+            a1 = PN_MFMA(w.w, feat[4 * g + 3], a1);
+        }
+        a0 = relu16(a0);
+        a1 = relu16(a1);
+        // ---- sigma net layer 1: 64 -> 16
+        f32x16 h2 = {0};
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 w = wl[(8 + g) * 64];
+            h2 = PN_MFMA(w.x, a0[4 * g + 0], h2);
+            h2 = PN_MFMA(w.y, a0[4 * g + 1], h2);
+            h2 = PN_MFMA(w.z, a0[4 * g + 2], h2);
+            h2 = PN_MFMA(w.w, a0[4 * g + 3], h2);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 w = wl[(12 + g) * 64];
+            h2 = PN_MFMA(w.x, a1[4 * g + 0], h2);
+            h2 = PN_MFMA(w.y, a1[4 * g + 1], h2);
+            h2 = PN_MFMA(w.z, a1[4 * g + 2], h2);
+            h2 = PN_MFMA(w.w, a1[4 * g + 3], h2);
+        }
+        const float sigma_logit = h2[0];  // row 0 lives in the low half's register 0
+        // ---- colour net input: 16 values per lane (see PN_MAPL / PN_MAPU)
+        float sh[16];
+        sh16(dx, dy, dz, sh);
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 7; k++) v[k] = half ? h2[k] : h2[k + 1];
+        v[7] = half ? h2[7] : sh[0];
+#pragma unroll
+        for (int k = 8; k < 15; k++) v[k] = half ? sh[k + 1] : sh[k - 7];
+        v[15] = half ? 0.0f : sh[8];
+        // ---- colour layer 0: 31 -> 64, ReLU
+        f32x16 c0 = {0}, c1 = {0};
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 w = wl[(16 + g) * 64];
+            c0 = PN_MFMA(w.x, v[4 * g + 0], c0);
+            c0 = PN_MFMA(w.y, v[4 * g + 1], c0);
+            c0 = PN_MFMA(w.z, v[4 * g + 2], c0);
+            c0 = PN_MFMA(w.w, v[4 * g + 3], c0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 w = wl[(20 + g) * 64];
+            c1 = PN_MFMA(w.x, v[4 * g + 0], c1);
+            c1 = PN_MFMA(w.y, v[4 * g + 1], c1);
+            c1 = PN_MFMA(w.z, v[4 * g + 2], c1);
+            c1 = PN_MFMA(w.w, v[4 * g + 3], c1);
+        }
+        c0 = relu16(c0);
+        c1 = relu16(c1);
+        // ---- colour layer 1: 64 -> 64, ReLU
+        f32x16 d0 = {0}, d1 = {0};
+#pragma unroll
+        for (int t2 = 0; t2 < 2; t2++) {
+#pragma unroll
+            for (int g = 0; g < 8; g++) {
+                const float4 w = wl[(24 + t2 * 8 + g) * 64];
+                const f32x16& src = (g < 4) ? c0 : c1;
+                const int r = (g & 3) * 4;
+                if (t2 == 0) {
+                    d0 = PN_MFMA(w.x, src[r + 0], d0);
+                    d0 = PN_MFMA(w.y, src[r + 1], d0);
+                    d0 = PN_MFMA(w.z, src[r + 2], d0);
+                    d0 = PN_MFMA(w.w, src[r + 3], d0);
+                } else {
+                    d1 = PN_MFMA(w.x, src[r + 0], d1);
+                    d1 = PN_MFMA(w.y, src[r + 1], d1);
+                    d1 = PN_MFMA(w.z, src[r + 2], d1);
+                    d1 = PN_MFMA(w.w, src[r + 3], d1);
+                }
+            }
+        }
+        d0 = relu16(d0);
+        d1 = relu16(d1);
+        // ---- colour layer 2: 64 -> 3
+        f32x16 e = {0};
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const float4 w = wl[(40 + g) * 64];
+            const f32x16& src = (g < 4) ? d0 : d1;
+            const int r = (g & 3) * 4;
+            e = PN_MFMA(w.x, src[r + 0], e);
+            e = PN_MFMA(w.y, src[r + 1], e);
+            e = PN_MFMA(w.z, src[r + 2], e);
+            e = PN_MFMA(w.w, src[r + 3], e);
+        }
+        if (valid && half == 0) {
+            sigmas[slot] = density_scale * expf(sigma_logit);           // trunc_exp forward = exp (nerf/activation.py:8-10)
+            rgbs[slot * 3 + 0] = 1.0f / (1.0f + expf(-e[0]));          // torch.sigmoid
+            rgbs[slot * 3 + 1] = 1.0f / (1.0f + expf(-e[1]));
+            rgbs[slot * 3 + 2] = 1.0f / (1.0f + expf(-e[2]));
+        }
+    }
+}
+
+int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* dirs, const int* list, const int* ctl_count, uint32_t M_max,
+                           float density_scale, float* sigmas, float* rgbs, hipStream_t stream) {
+    if (M_max == 0) return PN_OK;
+    const uint32_t tiles = pn_div_up(M_max, 32);
+    uint32_t blocks = pn_div_up(tiles, 4);
+    if (blocks > 768) blocks = 768;  // 3 workgroups per CU (48 KB LDS each) x 256 CUs; waves stride over tiles
+    const size_t lds = sizeof(float) * PN_NET_MFMAS * 64;
+    k_nerf_forward<<<blocks, 256, lds, stream>>>(net->levels, net->embeddings, net->wpack, net->bound, xyzs, dirs, list, ctl_count, M_max,
+                                                density_scale, sigmas, rgbs);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+extern "C" int pn_nerf_forward(const pn_net* net, const float* xyzs, const float* dirs, uint32_t M, float density_scale, float* sigmas, float* rgbs,
+                               void* stream) {
+    PN_REQUIRE(net && xyzs && dirs && sigmas && rgbs);
+    return pn_nerf_forward_launch(net, xyzs, dirs, nullptr, nullptr, M, density_scale, sigmas, rgbs, (hipStream_t)stream);
+}

@@ -1,0 +1,604 @@
+// Ray-side kernels of the render path + the whole-frame driver (gfx950).
+// Built with -ffp-contract=off (see pn_march.h).  Reference citations are relative to /root/reference.
+#include <float.h>
+
+#include "pn_march.h"
+
+thread_local char pn_err_buf[512] = {0};
+
+// Device-side record driving one loop trip of rund_cuda (nerf/renderer.py:836-891).
+struct PnTrip {
+    int n_alive;    // rays entering this trip
+    int n_step;     // max(min(N // n_alive, 8), 1)
+    int step_base;  // renderer's `step` before this trip
+    int n_samples;  // samples emitted by this trip's march (filled by atomics)
+};
+
+// ------------------------------------------------------------------------------------------------ near/far
+// kernel_near_far_from_aabb, raymarching.cu:91-159
+__global__ void __launch_bounds__(256) k_near_far(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ aabb,
+                                                  uint32_t N, float min_near, float* __restrict__ nears, float* __restrict__ fars,
+                                                  float* __restrict__ rays_t) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx;
+    if (near > far) { float c = near; near = far; far = c; }
+    float near_y = (aabb[1] - oy) * rdy, far_y = (aabb[4] - oy) * rdy;
+    if (near_y > far_y) { float c = near_y; near_y = far_y; far_y = c; }
+    bool miss = (near > far_y || near_y > far);
+    if (!miss) {
+        if (near_y > near) near = near_y;
+        if (far_y < far) far = far_y;
+        float near_z = (aabb[2] - oz) * rdz, far_z = (aabb[5] - oz) * rdz;
+        if (near_z > far_z) { float c = near_z; near_z = far_z; far_z = c; }
+        miss = (near > far_z || near_z > far);
+        if (!miss) {
+            if (near_z > near) near = near_z;
+            if (far_z < far) far = far_z;
+            if (near < min_near) near = min_near;
+        }
+    }
+    if (miss) near = far = FLT_MAX;
+    nears[n] = near;
+    fars[n] = far;
+    if (rays_t) rays_t[n] = near;  // frame driver: rays_t = nears.clone() (renderer.py:829)
+}
+
+extern "C" int pn_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near, float* nears,
+                                     float* fars, void* stream) {
+    PN_REQUIRE(rays_o && rays_d && aabb && nears && fars);
+    if (N == 0) return PN_OK;
+    k_near_far<<<pn_div_up(N, 256), 256, 0, (hipStream_t)stream>>>(rays_o, rays_d, aabb, N, min_near, nears, fars, nullptr);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ get_rays
+struct PnPose { float R[9]; float t[3]; };
+// nerf/utils.py:54-138 (N = -1): pixel p -> (i = p%W + .5, j = p/W + .5)
+__global__ void __launch_bounds__(256) k_get_rays(PnPose pose, float fx, float fy, float cx, float cy, int HW, int W, float* __restrict__ rays_o,
+                                                  float* __restrict__ rays_d) {
+    const int p = threadIdx.x + blockIdx.x * blockDim.x;
+    if (p >= HW) return;
+    const float i = (float)(p % W) + 0.5f, j = (float)(p / W) + 0.5f;
+    const float xs = (i - cx) / fx, ys = (j - cy) / fy, zs = 1.0f;
+    const float nrm = sqrtf(xs * xs + ys * ys + zs * zs);
+    const float d0 = xs / nrm, d1 = ys / nrm, d2 = zs / nrm;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        rays_d[p * 3 + c] = d0 * pose.R[c * 3] + d1 * pose.R[c * 3 + 1] + d2 * pose.R[c * 3 + 2];
+        rays_o[p * 3 + c] = pose.t[c];
+    }
+}
+
+extern "C" int pn_get_rays(const float* pose_host, float fx, float fy, float cx, float cy, int H, int W, float* rays_o, float* rays_d,
+                           void* stream) {
+    PN_REQUIRE(pose_host && rays_o && rays_d && H > 0 && W > 0);
+    PnPose pose;
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) pose.R[r * 3 + c] = pose_host[r * 4 + c];
+        pose.t[r] = pose_host[r * 4 + 3];
+    }
+    k_get_rays<<<pn_div_up((uint64_t)H * W, 256), 256, 0, (hipStream_t)stream>>>(pose, fx, fy, cx, cy, H * W, W, rays_o, rays_d);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ spatial hash of IPs
+// p2g, nerf/utils.py:389-407
+__device__ __forceinline__ int p2g(const float* __restrict__ p, const float* __restrict__ bbmin, float hgs, const int* __restrict__ res, int n_grid) {
+    const int g0 = (int)floorf((p[0] - bbmin[0]) / hgs);
+    const int g1 = (int)floorf((p[1] - bbmin[1]) / hgs);
+    const int g2 = (int)floorf((p[2] - bbmin[2]) / hgs);
+    const int gid = g2 * res[1] * res[0] + g1 * res[0] + g0;
+    return (gid < 0 || gid >= n_grid) ? -1 : gid;
+}
+
+__global__ void __launch_bounds__(256) k_pig_zero(int* __restrict__ cnt, int n_grid_max, const int* __restrict__ n_grid_dev) {
+    const int n_grid = n_grid_dev ? min(*n_grid_dev, n_grid_max) : n_grid_max;
+    for (int g = threadIdx.x + blockIdx.x * blockDim.x; g < n_grid; g += gridDim.x * blockDim.x) cnt[g] = 0;
+}
+
+// get_pig_cnt, nerf/utils.py:410-424
+__global__ void __launch_bounds__(256) k_pig_count(int n_vtx, int n_grid_max, const int* __restrict__ n_grid_dev, const float* __restrict__ pnts,
+                                                   const float* __restrict__ bbmin, float hgs, const int* __restrict__ res, int* cnt,
+                                                   int* err_flag) {
+    const int p = threadIdx.x + blockIdx.x * blockDim.x;
+    if (p >= n_vtx) return;
+    const int n_grid = n_grid_dev ? min(*n_grid_dev, n_grid_max) : n_grid_max;
+    const int gid = p2g(pnts + p * 3, bbmin, hgs, res, n_grid);
+    if (gid >= 0) atomicAdd(cnt + gid, 1);
+    else if (err_flag) atomicOr(err_flag, 2);
+}
+
+// pig_bgn = cumsum(cnt) - cnt (nerf/utils.py:369), one workgroup, 4 cells per thread per tile.
+__global__ void __launch_bounds__(1024) k_pig_scan(int n_grid_max, const int* __restrict__ n_grid_dev, const int* __restrict__ cnt,
+                                                   int* __restrict__ bgn, int* __restrict__ cursor) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int n_grid = n_grid_dev ? min(*n_grid_dev, n_grid_max) : n_grid_max;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n_grid; base += 4096) {
+        const int i0 = base + threadIdx.x * 4;
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = (i0 + k < n_grid) ? __hip_atomic_load(cnt + i0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        const int tsum = v[0] + v[1] + v[2] + v[3];
+        int inc = tsum;  // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wid; w++) woff += wsum[w];
+        int total = 0;
+        for (int w = 0; w < 16; w++) total += wsum[w];
+        int run = carry_s + woff + inc - tsum;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + k < n_grid) { bgn[i0 + k] = run; cursor[i0 + k] = run; }
+            run += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += total;
+        __syncthreads();
+    }
+}
+
+// get_pig_idx, nerf/utils.py:427-443 — slots claimed through a per-cell cursor ...
+__global__ void __launch_bounds__(256) k_pig_fill(int n_vtx, int n_grid_max, const int* __restrict__ n_grid_dev, const float* __restrict__ pnts,
+                                                  const float* __restrict__ bbmin, float hgs, const int* __restrict__ res, int* cursor,
+                                                  int* __restrict__ idx) {
+    const int p = threadIdx.x + blockIdx.x * blockDim.x;
+    if (p >= n_vtx) return;
+    const int n_grid = n_grid_dev ? min(*n_grid_dev, n_grid_max) : n_grid_max;
+    const int gid = p2g(pnts + p * 3, bbmin, hgs, res, n_grid);
+    if (gid >= 0) idx[atomicAdd(cursor + gid, 1)] = p;
+}
+// ... then each cell's few entries are put in ascending point id, which makes the table independent of atomic order.
+__global__ void __launch_bounds__(256) k_pig_sort(int n_grid_max, const int* __restrict__ n_grid_dev, const int* __restrict__ cnt,
+                                                  const int* __restrict__ bgn, int* __restrict__ idx) {
+    const int n_grid = n_grid_dev ? min(*n_grid_dev, n_grid_max) : n_grid_max;
+    for (int g = threadIdx.x + blockIdx.x * blockDim.x; g < n_grid; g += gridDim.x * blockDim.x) {
+        const int c = __hip_atomic_load(cnt + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c < 2) continue;
+        int* a = idx + bgn[g];
+        for (int i = 1; i < c; i++) {
+            const int v = __hip_atomic_load(a + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int j = i - 1;
+            while (j >= 0) {
+                const int u = __hip_atomic_load(a + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (u <= v) break;
+                __hip_atomic_store(a + j + 1, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                j--;
+            }
+            __hip_atomic_store(a + j + 1, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+static int pig_build(int n_vtx, int n_grid_max, const int* n_grid_dev, const float* pnts, const float* bbmin, float hgs, const int* res, int* cnt,
+                     int* bgn, int* idx, int* cursor, int* err_flag, hipStream_t st) {
+    const int gz = (int)pn_div_up(n_grid_max, 256) < 1024 ? (int)pn_div_up(n_grid_max, 256) : 1024;
+    k_pig_zero<<<gz, 256, 0, st>>>(cnt, n_grid_max, n_grid_dev);
+    k_pig_count<<<pn_div_up(n_vtx, 256), 256, 0, st>>>(n_vtx, n_grid_max, n_grid_dev, pnts, bbmin, hgs, res, cnt, err_flag);
+    k_pig_scan<<<1, 1024, 0, st>>>(n_grid_max, n_grid_dev, cnt, bgn, cursor);
+    k_pig_fill<<<pn_div_up(n_vtx, 256), 256, 0, st>>>(n_vtx, n_grid_max, n_grid_dev, pnts, bbmin, hgs, res, cursor, idx);
+    k_pig_sort<<<gz, 256, 0, st>>>(n_grid_max, n_grid_dev, cnt, bgn, idx);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+extern "C" int pn_pnts_in_grids(int n_vtx, int n_grid, const float* pnts, const float* bbmin, float hgs, const int* resolution, int* pig_cnt,
+                                int* pig_bgn, int* pig_idx, int* err_flag, void* stream) {
+    PN_REQUIRE(n_vtx > 0 && n_grid > 0 && pnts && bbmin && resolution && pig_cnt && pig_bgn && pig_idx);
+    int* cursor = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    PN_HIP_CHECK(hipMallocAsync((void**)&cursor, sizeof(int) * (size_t)n_grid, st));
+    int rc = pig_build(n_vtx, n_grid, nullptr, pnts, bbmin, hgs, resolution, pig_cnt, pig_bgn, pig_idx, cursor, err_flag, st);
+    PN_HIP_CHECK(hipFreeAsync(cursor, st));
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------ march
+struct MarchIO {
+    uint32_t n_alive, n_step;
+    const int* rays_alive;
+    float *xyzs, *dirs, *deltas;
+    const float* noises;
+    // frame-driver mode (trip != nullptr): counts come from device memory, valid sample slots are appended to `list`
+    PnTrip* trip;
+    int* list;
+};
+
+__global__ void __launch_bounds__(256) k_march(pnm::MarchParams a, MarchIO io) {
+    uint32_t n_alive = io.n_alive, n_step = io.n_step;
+    if (io.trip) { n_alive = (uint32_t)io.trip->n_alive; n_step = (uint32_t)io.trip->n_step; }
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (blockIdx.x * blockDim.x >= n_alive) return;  // whole block idle
+    uint32_t emitted = 0;
+    if (n < n_alive) {
+        const int index = io.rays_alive[n];
+        const float noise = io.noises ? io.noises[n] : 0.0f;
+        float* dl = io.deltas + (size_t)n * n_step * 2;
+        emitted = pnm::march_one(a, index, noise, n_step, io.xyzs + (size_t)n * n_step * 3, io.dirs + (size_t)n * n_step * 3, dl);
+        if (io.trip) {  // the op-level wrapper zero-fills instead (raymarching.py:415-417)
+            for (uint32_t s = emitted; s < n_step; s++) { dl[2 * s] = 0.0f; dl[2 * s + 1] = 0.0f; }
+        }
+    }
+    if (io.trip) {
+        // wave-aggregated append of this wave's valid sample slots
+        const int lane = threadIdx.x & 63;
+        int inc = (int)emitted;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        const int total = __shfl(inc, 63);
+        int base = 0;
+        if (lane == 63 && total > 0) base = atomicAdd(&io.trip->n_samples, total);
+        base = __shfl(base, 63);
+        const int first = base + inc - (int)emitted;
+        for (uint32_t s = 0; s < emitted; s++) io.list[first + s] = (int)(n * n_step + s);
+    }
+}
+
+static pnm::MarchParams make_march_params(const int* pig_cnt, const int* pig_bgn, const int* pig_idx, int n_vtx, int n_grid, const float* p_def,
+                                          const float* p_ori, const float* F_IP, const float* dF_IP, int max_iter_num, const float* bbmin,
+                                          const float* bbmax, float hgs, const int* resolution, int num_seek_IP, float IP_dx, int cut,
+                                          const float* cut_bounds, const float* rays_t, const float* rays_o, const float* rays_d, float bound,
+                                          float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid, const float* fars,
+                                          int* err_flag) {
+    pnm::MarchParams a;
+    a.pig_cnt = pig_cnt; a.pig_bgn = pig_bgn; a.pig_idx = pig_idx; a.n_vtx = n_vtx; a.n_grid = n_grid;
+    a.p_ori = p_ori; a.p_def = p_def; a.F_IP = F_IP; a.dF_IP = dF_IP; a.max_iter_num = max_iter_num;
+    a.bbmin = bbmin; a.bbmax = bbmax; a.hgs = hgs; a.resolution = resolution; a.num_seek_IP = num_seek_IP; a.IP_dx = IP_dx;
+    a.cut = cut; a.cut_bounds = cut_bounds; a.rays_t = rays_t; a.rays_o = rays_o; a.rays_d = rays_d;
+    a.bound = bound; a.dt_gamma = dt_gamma; a.max_steps = max_steps; a.C = C; a.H = H; a.grid = grid; a.fars = fars; a.err_flag = err_flag;
+    return a;
+}
+
+extern "C" int pn_march_rays_quadratic_bending(const int* pig_cnt, const int* pig_bgn, const int* pig_idx, int n_vtx, int n_grid,
+                                               const float* p_def, const float* p_ori, const float* F_IP, const float* dF_IP, int max_iter_num,
+                                               const float* bbmin, const float* bbmax, float hgs, const int* resolution, int num_seek_IP,
+                                               float IP_dx, int cut, const float* cut_bounds, uint32_t n_alive, uint32_t n_step,
+                                               const int* rays_alive, const float* rays_t, const float* rays_o, const float* rays_d, float bound,
+                                               float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid, const float* nears,
+                                               const float* fars, float* xyzs, float* dirs, float* deltas, const float* noises, int* err_flag,
+                                               void* stream) {
+    (void)nears;
+    PN_REQUIRE(pig_cnt && pig_bgn && pig_idx && p_def && p_ori && F_IP && dF_IP && bbmin && bbmax && resolution);
+    PN_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas);
+    PN_REQUIRE(num_seek_IP >= 1 && num_seek_IP <= 3);
+    PN_REQUIRE(!cut || cut_bounds);
+    PN_REQUIRE(C >= 1 && C <= 8 && H > 0 && n_step >= 1);
+    if (n_alive == 0) return PN_OK;
+    pnm::MarchParams a = make_march_params(pig_cnt, pig_bgn, pig_idx, n_vtx, n_grid, p_def, p_ori, F_IP, dF_IP, max_iter_num, bbmin, bbmax, hgs,
+                                           resolution, num_seek_IP, IP_dx, cut, cut_bounds, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C,
+                                           H, grid, fars, err_flag);
+    MarchIO io{n_alive, n_step, rays_alive, xyzs, dirs, deltas, noises, nullptr, nullptr};
+    k_march<<<pn_div_up(n_alive, 256), 256, 0, (hipStream_t)stream>>>(a, io);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ composite
+// kernel_composite_rays, raymarching.cu:827-923.  __expf -> the gfx950 fast exponential (v_exp_f32 on x*log2e).
+__device__ __forceinline__ bool composite_one(uint32_t n, uint32_t n_step, float T_thresh, int* rays_alive, float* rays_t,
+                                              const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ deltas,
+                                              float* weights_sum, float* depth, float* image) {
+    const int index = rays_alive[n];
+    sigmas += (size_t)n * n_step;
+    rgbs += (size_t)n * n_step * 3;
+    deltas += (size_t)n * n_step * 2;
+    float t = rays_t[index];
+    float ws = weights_sum[index], d = depth[index];
+    float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
+    uint32_t step = 0;
+    while (step < n_step) {
+        if (deltas[0] == 0) break;
+        const float alpha = 1.0f - __expf(-sigmas[0] * deltas[0]);
+        const float T = 1 - ws;
+        const float w = alpha * T;
+        ws += w;
+        t += deltas[1];
+        d += w * t;
+        r += w * rgbs[0];
+        g += w * rgbs[1];
+        b += w * rgbs[2];
+        if (T < T_thresh) break;
+        sigmas++; rgbs += 3; deltas += 2; step++;
+    }
+    const bool alive = !(step < n_step);
+    if (!alive) rays_alive[n] = -1; else rays_t[index] = t;
+    weights_sum[index] = ws;
+    depth[index] = d;
+    image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+    return alive;
+}
+
+// One 256-ray chunk per block; in frame-driver mode also records the chunk's survivor count for the compaction pass.
+__global__ void __launch_bounds__(256) k_composite(uint32_t n_alive_arg, uint32_t n_step_arg, float T_thresh, int* rays_alive, float* rays_t,
+                                                   const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                   const float* __restrict__ deltas, float* weights_sum, float* depth, float* image,
+                                                   const PnTrip* trip, int* chunk_counts) {
+    uint32_t n_alive = n_alive_arg, n_step = n_step_arg;
+    if (trip) { n_alive = (uint32_t)trip->n_alive; n_step = (uint32_t)trip->n_step; }
+    if (blockIdx.x * blockDim.x >= n_alive) return;
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    bool alive = false;
+    if (n < n_alive) alive = composite_one(n, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+    if (chunk_counts) {
+        const int c = __syncthreads_count(alive);
+        if (threadIdx.x == 0) chunk_counts[blockIdx.x] = c;
+    }
+}
+
+extern "C" int pn_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int* rays_alive, float* rays_t, const float* sigmas,
+                                 const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image, void* stream) {
+    PN_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image && n_step >= 1);
+    if (n_alive == 0) return PN_OK;
+    k_composite<<<pn_div_up(n_alive, 256), 256, 0, (hipStream_t)stream>>>(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas,
+                                                                         weights_sum, depth, image, nullptr, nullptr);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ stable compaction
+__global__ void __launch_bounds__(256) k_chunk_count(const int* __restrict__ rays_alive, uint32_t n, int* chunk_counts) {
+    const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+    const int c = __syncthreads_count(i < n && rays_alive[i] >= 0);
+    if (threadIdx.x == 0) chunk_counts[blockIdx.x] = c;
+}
+
+// Block c moves the survivors of chunk c to out[prefix(c) ...], keeping order (== rays_alive[rays_alive >= 0]).
+// Block 0 also publishes the total and, in frame-driver mode, the next trip's record (renderer.py:839-846,891).
+__global__ void __launch_bounds__(256) k_compact(const int* __restrict__ in, uint32_t n_arg, const int* __restrict__ chunk_counts,
+                                                 int* __restrict__ out, int* n_out, const PnTrip* trip, PnTrip* next, uint32_t N_rays,
+                                                 uint32_t max_steps) {
+    __shared__ int red[4];
+    __shared__ int woff[4];
+    const uint32_t n = trip ? (uint32_t)trip->n_alive : n_arg;
+    const uint32_t c = blockIdx.x;
+    if (c * 256 >= n && c != 0) return;
+    const uint32_t n_chunks = (n + 255) / 256;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // prefix over earlier chunks (and, for block 0, the grand total)
+    const uint32_t upto = (c == 0) ? n_chunks : c;
+    int part = 0;
+    for (uint32_t k = threadIdx.x; k < upto; k += 256) part += chunk_counts[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 0) red[wid] = part;
+    __syncthreads();
+    const int sum = red[0] + red[1] + red[2] + red[3];
+    const int offset = (c == 0) ? 0 : sum;
+    if (c == 0 && threadIdx.x == 0) {
+        if (n_out) *n_out = sum;
+        if (next) {
+            const int step = trip->step_base + trip->n_step;
+            const bool done = (sum <= 0) || ((uint32_t)step >= max_steps);
+            next->n_alive = done ? 0 : sum;
+            next->n_step = done ? 1 : max(min((int)(N_rays / (uint32_t)sum), 8), 1);
+            next->step_base = step;
+            next->n_samples = 0;
+        }
+    }
+    const uint32_t i = c * 256 + threadIdx.x;
+    const int v = (i < n) ? in[i] : -1;
+    const bool keep = v >= 0;
+    const unsigned long long m = __ballot(keep);
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) woff[wid] = __popcll(m);
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < wid; w++) wbase += woff[w];
+    if (keep) out[offset + wbase + rank] = v;
+}
+
+extern "C" uint32_t pn_compact_scratch_ints(uint32_t n) { return pn_div_up(n, 256) + 1; }
+
+extern "C" int pn_compact_rays(const int* rays_alive, uint32_t n, int* out, int* n_out, int* scratch, void* stream) {
+    PN_REQUIRE(out && n_out && scratch);
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) { PN_HIP_CHECK(hipMemsetAsync(n_out, 0, sizeof(int), st)); return PN_OK; }
+    PN_REQUIRE(rays_alive);
+    const uint32_t chunks = pn_div_up(n, 256);
+    k_chunk_count<<<chunks, 256, 0, st>>>(rays_alive, n, scratch);
+    k_compact<<<chunks, 256, 0, st>>>(rays_alive, n, scratch, out, n_out, nullptr, nullptr, 0, 0);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ whole frame
+struct PnFrameDev {
+    float aabb[6];      // bbmin = aabb, bbmax = aabb + 3   (aabb = cat(bbmin, bbmax), renderer.py:796)
+    int resolution[4];  // [3] = n_grid
+    int err;
+    int pad;
+};
+
+#define PN_MAX_TRIPS 1100
+#define PN_TRIP_BATCH 8
+
+struct pn_frame {
+    uint32_t max_rays, max_vtx, max_cells;
+    float *nears, *fars, *rays_t, *xyzs, *dirs, *deltas, *sigmas, *rgbs;
+    int *alive_a, *alive_b, *list, *chunk_counts;
+    int *pig_cnt, *pig_bgn, *pig_idx, *pig_cursor;
+    PnTrip* trips;  // [PN_MAX_TRIPS + 2]
+    PnFrameDev* dev;
+    float* cut_bounds;
+    PnTrip* trips_pinned;  // host-pinned mirror
+    PnFrameDev* dev_pinned;
+};
+
+// bbox of the deformed IPs +-1e-3 and the spatial-hash resolution (nerf/renderer.py:782-791), one workgroup.
+__global__ void __launch_bounds__(1024) k_frame_bbox(const float* __restrict__ p_def, int n_vtx, int cut, float bound, float hgs, int max_cells,
+                                                     PnFrameDev* dev) {
+    __shared__ float smin[3][16], smax[3][16];
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = threadIdx.x; i < n_vtx; i += blockDim.x)
+#pragma unroll
+        for (int c = 0; c < 3; c++) { const float v = p_def[i * 3 + c]; mn[c] = fminf(mn[c], v); mx[c] = fmaxf(mx[c], v); }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mn[c] = fminf(mn[c], __shfl_xor(mn[c], o)); mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o)); }
+        if (lane == 0) { smin[c][wid] = mn[c]; smax[c][wid] = mx[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ncell = 1;
+        for (int c = 0; c < 3; c++) {
+            float a = smin[c][0], b = smax[c][0];
+            for (int w = 1; w < 16; w++) { a = fminf(a, smin[c][w]); b = fmaxf(b, smax[c][w]); }
+            if (cut) { a = -bound; b = bound; }
+            const float lo = a - 1e-3f, hi = b + 1e-3f;
+            dev->aabb[c] = lo;
+            dev->aabb[3 + c] = hi;
+            const int r = (int)ceilf((hi - lo) / hgs);
+            dev->resolution[c] = r;
+            ncell *= r;
+        }
+        int err = 0;
+        if (ncell > max_cells || ncell <= 0) { err = 4; ncell = 0; }
+        dev->resolution[3] = ncell;
+        dev->err = err;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_frame_init(PnTrip* trips, uint32_t N, int* alive, const PnFrameDev* dev) {
+    const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+    if (i < N) alive[i] = (int)i;  // rays_alive = arange(N) (renderer.py:828)
+    if (i == 0) {
+        trips[0].n_alive = dev->err ? 0 : (int)N;
+        trips[0].n_step = 1;  // max(min(N // N, 8), 1)
+        trips[0].step_base = 0;
+        trips[0].n_samples = 0;
+    }
+}
+
+// image += (1 - weights_sum) * bg ; depth = clamp(depth - nears, 0) / (fars - nears) (renderer.py:896-899)
+__global__ void __launch_bounds__(256) k_frame_finish(uint32_t N, float bg, const float* __restrict__ nears, const float* __restrict__ fars,
+                                                      const float* __restrict__ weights_sum, const float* __restrict__ depth_0,
+                                                      float* __restrict__ image, float* __restrict__ depth) {
+    const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+    if (i >= N) return;
+    const float k = (1 - weights_sum[i]) * bg;
+    image[i * 3] = image[i * 3] + k;
+    image[i * 3 + 1] = image[i * 3 + 1] + k;
+    image[i * 3 + 2] = image[i * 3 + 2] + k;
+    depth[i] = fmaxf(depth_0[i] - nears[i], 0.0f) / (fars[i] - nears[i]);
+}
+
+extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_vtx, uint32_t max_grid_cells) {
+    PN_REQUIRE(out && max_rays > 0 && max_vtx > 0 && max_grid_cells > 0);
+    pn_frame* f = new pn_frame();
+    memset(f, 0, sizeof(*f));
+    f->max_rays = max_rays; f->max_vtx = max_vtx; f->max_cells = max_grid_cells;
+    const size_t N = max_rays;
+#define PN_ALLOC(ptr, bytes) PN_HIP_CHECK(hipMalloc((void**)&(ptr), (bytes)))
+    PN_ALLOC(f->nears, N * 4); PN_ALLOC(f->fars, N * 4); PN_ALLOC(f->rays_t, N * 4);
+    PN_ALLOC(f->xyzs, N * 12); PN_ALLOC(f->dirs, N * 12); PN_ALLOC(f->deltas, N * 8); PN_ALLOC(f->sigmas, N * 4); PN_ALLOC(f->rgbs, N * 12);
+    PN_ALLOC(f->alive_a, N * 4); PN_ALLOC(f->alive_b, N * 4); PN_ALLOC(f->list, N * 4); PN_ALLOC(f->chunk_counts, (N / 256 + 2) * 4);
+    PN_ALLOC(f->pig_cnt, (size_t)max_grid_cells * 4); PN_ALLOC(f->pig_bgn, (size_t)max_grid_cells * 4);
+    PN_ALLOC(f->pig_cursor, (size_t)max_grid_cells * 4); PN_ALLOC(f->pig_idx, (size_t)max_vtx * 4);
+    PN_ALLOC(f->trips, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)); PN_ALLOC(f->dev, sizeof(PnFrameDev)); PN_ALLOC(f->cut_bounds, 6 * 4);
+#undef PN_ALLOC
+    PN_HIP_CHECK(hipHostMalloc((void**)&f->trips_pinned, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)));
+    PN_HIP_CHECK(hipHostMalloc((void**)&f->dev_pinned, sizeof(PnFrameDev)));
+    *out = f;
+    return PN_OK;
+}
+
+extern "C" void pn_frame_destroy(pn_frame* f) {
+    if (!f) return;
+    void* ptrs[] = {f->nears, f->fars, f->rays_t, f->xyzs, f->dirs, f->deltas, f->sigmas, f->rgbs, f->alive_a, f->alive_b, f->list,
+                    f->chunk_counts, f->pig_cnt, f->pig_bgn, f->pig_cursor, f->pig_idx, f->trips, f->dev, f->cut_bounds};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (f->trips_pinned) (void)hipHostFree(f->trips_pinned);
+    if (f->dev_pinned) (void)hipHostFree(f->dev_pinned);
+    delete f;
+}
+
+extern "C" int pn_render_deformed(pn_frame* f, const pn_net* net, const pn_render_opts* o, const float* rays_o, const float* rays_d, uint32_t N,
+                                  const float* p_def, const float* p_ori, const float* F_IP, const float* dF_IP, int n_vtx,
+                                  const uint8_t* bitfield, float* image, float* depth, float* depth_0, float* weights_sum, int64_t* stats_host,
+                                  void* stream) {
+    PN_REQUIRE(f && net && o && rays_o && rays_d && p_def && p_ori && F_IP && dF_IP && bitfield && image && depth && depth_0 && weights_sum);
+    PN_REQUIRE(N > 0 && N <= f->max_rays && n_vtx > 0 && (uint32_t)n_vtx <= f->max_vtx);
+    PN_REQUIRE(o->num_seek_IP >= 1 && o->num_seek_IP <= 3 && o->cascade >= 1 && o->cascade <= 8 && o->max_steps <= PN_MAX_TRIPS - PN_TRIP_BATCH);
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t nblk = pn_div_up(N, 256);
+
+    PN_HIP_CHECK(hipMemcpyAsync(f->cut_bounds, o->cut_bounds, 6 * sizeof(float), hipMemcpyHostToDevice, st));
+    PN_HIP_CHECK(hipMemsetAsync(weights_sum, 0, (size_t)N * 4, st));  // renderer.py:807-809
+    PN_HIP_CHECK(hipMemsetAsync(depth_0, 0, (size_t)N * 4, st));
+    PN_HIP_CHECK(hipMemsetAsync(image, 0, (size_t)N * 12, st));
+    PN_HIP_CHECK(hipMemsetAsync(f->trips, 0, sizeof(PnTrip) * (PN_MAX_TRIPS + 2), st));
+
+    k_frame_bbox<<<1, 1024, 0, st>>>(p_def, n_vtx, o->cut, o->bound, o->hash_grid_size, (int)f->max_cells, f->dev);
+    const float* bbmin = f->dev->aabb;  // device addresses of struct members
+    const float* bbmax = f->dev->aabb + 3;
+    const int* res = f->dev->resolution;
+    const int* n_grid_dev = f->dev->resolution + 3;
+    int* err = &f->dev->err;
+    int rc = pig_build(n_vtx, (int)f->max_cells, n_grid_dev, p_def, bbmin, o->hash_grid_size, res, f->pig_cnt, f->pig_bgn, f->pig_idx,
+                       f->pig_cursor, err, st);
+    if (rc) return rc;
+    k_near_far<<<nblk, 256, 0, st>>>(rays_o, rays_d, f->dev->aabb, N, o->min_near, f->nears, f->fars, f->rays_t);
+    k_frame_init<<<nblk, 256, 0, st>>>(f->trips, N, f->alive_a, f->dev);
+    PN_LAUNCH_CHECK();
+
+    pnm::MarchParams mp = make_march_params(f->pig_cnt, f->pig_bgn, f->pig_idx, n_vtx, 0, p_def, p_ori, F_IP, dF_IP, o->max_iter_num, bbmin, bbmax,
+                                            o->hash_grid_size, res, o->num_seek_IP, o->IP_dx, o->cut, f->cut_bounds, f->rays_t, rays_o, rays_d,
+                                            o->bound, o->dt_gamma, o->max_steps, o->cascade, o->grid_size, bitfield, f->fars, err);
+    int t = 0;
+    bool done = false;
+    while (!done && t < PN_MAX_TRIPS) {
+        for (int k = 0; k < PN_TRIP_BATCH; k++, t++) {
+            int* cur = (t & 1) ? f->alive_b : f->alive_a;
+            int* nxt = (t & 1) ? f->alive_a : f->alive_b;
+            MarchIO io{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + t, f->list};
+            k_march<<<nblk, 256, 0, st>>>(mp, io);
+            rc = pn_nerf_forward_launch(net, f->xyzs, f->dirs, f->list, &f->trips[t].n_samples, N, o->density_scale, f->sigmas, f->rgbs, st);
+            if (rc) return rc;
+            k_composite<<<nblk, 256, 0, st>>>(0, 0, o->T_thresh, cur, f->rays_t, f->sigmas, f->rgbs, f->deltas, weights_sum, depth_0, image,
+                                              f->trips + t, f->chunk_counts);
+            k_compact<<<nblk, 256, 0, st>>>(cur, 0, f->chunk_counts, nxt, nullptr, f->trips + t, f->trips + t + 1, N, o->max_steps);
+        }
+        PN_LAUNCH_CHECK();
+        // one small readback per batch decides whether more trips are needed (the reference syncs every trip)
+        PN_HIP_CHECK(hipMemcpyAsync(f->trips_pinned + t, f->trips + t, sizeof(PnTrip), hipMemcpyDeviceToHost, st));
+        PN_HIP_CHECK(hipStreamSynchronize(st));
+        done = f->trips_pinned[t].n_alive <= 0;
+    }
+    k_frame_finish<<<nblk, 256, 0, st>>>(N, o->bg_color, f->nears, f->fars, weights_sum, depth_0, image, depth);
+    PN_LAUNCH_CHECK();
+    if (stats_host) {
+        PN_HIP_CHECK(hipMemcpyAsync(f->trips_pinned, f->trips, sizeof(PnTrip) * (t + 1), hipMemcpyDeviceToHost, st));
+        PN_HIP_CHECK(hipMemcpyAsync(f->dev_pinned, f->dev, sizeof(PnFrameDev), hipMemcpyDeviceToHost, st));
+        PN_HIP_CHECK(hipStreamSynchronize(st));
+        int64_t trips = 0, samples = 0;
+        for (int k = 0; k < t; k++) {
+            if (f->trips_pinned[k].n_alive > 0) trips++;
+            samples += f->trips_pinned[k].n_samples;
+        }
+        stats_host[0] = trips;
+        stats_host[1] = samples;
+        stats_host[2] = f->dev_pinned->err;
+        stats_host[3] = f->trips_pinned[t].n_alive;
+    }
+    return PN_OK;
+}

@@ -1,0 +1,434 @@
+// Q-GMLS elastodynamics substep for gfx950 (fp64, like the reference: simulator/func_utils.py:9-18).
+//
+// Reference (paths relative to /root/reference): simulator/solver.py:541-602 (build_rhs, compute_momentum,
+// stepforward), simulator/cuda_utils.py:83-151,206-233 (calc_elastic, collect_rhs_IP, update_F_kernel),
+// simulator/func_utils.py:21-40 (volume_invariant_project).  `wp.svd3` (warp-lang 0.13.0, not vendored) is restated
+// by its contract: U, V proper rotations, smallest singular value carries the sign of det F.
+//
+// MI355X mapping:
+//   * the reference's (30 n_k)^2 fp64 matrices are kron(A, I3) (solver.py:493-496), so only A (10 n_k)^2 is stored and
+//     X[n,3] = A RHS[n,3] is one wave per row with a DPP/shuffle reduction: 9x fewer HBM bytes than the dense product;
+//   * collect_rhs runs in gather form over a per-kernel CSR list (one wave per kernel, fixed summation tree): no fp64
+//     atomics, bit-reproducible run to run;
+//   * calc_elastic uses 8 lanes per integration point (one per neighbour kernel) so the 1.9 KB/IP of dNx is read coalesced.
+#include <math.h>
+
+#include "pn_common.h"
+
+namespace {
+
+struct M3 { double m[3][3]; };
+
+__device__ __forceinline__ M3 mul33(const M3& a, const M3& b) {
+    M3 c;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) c.m[i][j] = a.m[i][0] * b.m[0][j] + a.m[i][1] * b.m[1][j] + a.m[i][2] * b.m[2][j];
+    return c;
+}
+__device__ __forceinline__ double det33(const M3& a) {
+    return a.m[0][0] * (a.m[1][1] * a.m[2][2] - a.m[1][2] * a.m[2][1]) - a.m[0][1] * (a.m[1][0] * a.m[2][2] - a.m[1][2] * a.m[2][0]) +
+           a.m[0][2] * (a.m[1][0] * a.m[2][1] - a.m[1][1] * a.m[2][0]);
+}
+
+// One Jacobi rotation zeroing S[p][q] of the symmetric S, accumulated into Q (columns = eigenvectors).
+template <int p, int q>
+__device__ __forceinline__ void jacobi_rot(M3& S, M3& Q) {
+    const double spq = S.m[p][q];
+    if (spq == 0.0) return;
+    const double theta = (S.m[q][q] - S.m[p][p]) / (2.0 * spq);
+    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double a = S.m[k][p], b = S.m[k][q];
+        S.m[k][p] = c * a - s * b;
+        S.m[k][q] = s * a + c * b;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double a = S.m[p][k], b = S.m[q][k];
+        S.m[p][k] = c * a - s * b;
+        S.m[q][k] = s * a + c * b;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double a = Q.m[k][p], b = Q.m[k][q];
+        Q.m[k][p] = c * a - s * b;
+        Q.m[k][q] = s * a + c * b;
+    }
+}
+
+// F = U diag(sig) V^T with det U = det V = +1, |sig| descending, sig[2] signed (contract of wp.svd3, cuda_utils.py:107).
+__device__ void svd3(const M3& F, M3& U, double* sig, M3& V) {
+    M3 S, Q;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            S.m[i][j] = F.m[0][i] * F.m[0][j] + F.m[1][i] * F.m[1][j] + F.m[2][i] * F.m[2][j];
+            Q.m[i][j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 32; sweep++) {
+        const double off = S.m[0][1] * S.m[0][1] + S.m[0][2] * S.m[0][2] + S.m[1][2] * S.m[1][2];
+        const double dia = S.m[0][0] * S.m[0][0] + S.m[1][1] * S.m[1][1] + S.m[2][2] * S.m[2][2];
+        if (off <= 1e-34 * dia || off == 0.0) break;
+        jacobi_rot<0, 1>(S, Q);
+        jacobi_rot<0, 2>(S, Q);
+        jacobi_rot<1, 2>(S, Q);
+    }
+    M3 B = mul33(F, Q);
+    double n0 = B.m[0][0] * B.m[0][0] + B.m[1][0] * B.m[1][0] + B.m[2][0] * B.m[2][0];
+    double n1 = B.m[0][1] * B.m[0][1] + B.m[1][1] * B.m[1][1] + B.m[2][1] * B.m[2][1];
+    double n2 = B.m[0][2] * B.m[0][2] + B.m[1][2] * B.m[1][2] + B.m[2][2] * B.m[2][2];
+    // sort columns by descending norm with explicit swaps (each swap flips det; fixed afterwards)
+    auto swapc = [&](int a, int b) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            double t = B.m[i][a]; B.m[i][a] = B.m[i][b]; B.m[i][b] = t;
+            t = Q.m[i][a]; Q.m[i][a] = Q.m[i][b]; Q.m[i][b] = t;
+        }
+    };
+    if (n0 < n1) { swapc(0, 1); double t = n0; n0 = n1; n1 = t; }
+    if (n0 < n2) { swapc(0, 2); double t = n0; n0 = n2; n2 = t; }
+    if (n1 < n2) { swapc(1, 2); double t = n1; n1 = n2; n2 = t; }
+    if (det33(Q) < 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) { Q.m[i][2] = -Q.m[i][2]; B.m[i][2] = -B.m[i][2]; }
+    }
+    double u0[3], u1[3], u2[3];
+    const double l0 = sqrt(n0);
+    if (l0 > 0) { u0[0] = B.m[0][0] / l0; u0[1] = B.m[1][0] / l0; u0[2] = B.m[2][0] / l0; }
+    else { u0[0] = 1; u0[1] = 0; u0[2] = 0; }
+    const double d01 = u0[0] * B.m[0][1] + u0[1] * B.m[1][1] + u0[2] * B.m[2][1];
+#pragma unroll
+    for (int i = 0; i < 3; i++) u1[i] = B.m[i][1] - d01 * u0[i];
+    double l1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+    if (l1 > 1e-300 && l1 > 1e-14 * l0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) u1[i] /= l1;
+    } else {  // rank <= 1: any unit vector orthogonal to u0
+        const double a0 = fabs(u0[0]), a1 = fabs(u0[1]), a2 = fabs(u0[2]);
+        const int k = a0 < a1 ? (a0 < a2 ? 0 : 2) : (a1 < a2 ? 1 : 2);
+        const double d = (k == 0) ? u0[0] : (k == 1 ? u0[1] : u0[2]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) u1[i] = ((i == k) ? 1.0 : 0.0) - d * u0[i];
+        l1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) u1[i] /= l1;
+    }
+    u2[0] = u0[1] * u1[2] - u0[2] * u1[1];
+    u2[1] = u0[2] * u1[0] - u0[0] * u1[2];
+    u2[2] = u0[0] * u1[1] - u0[1] * u1[0];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { U.m[i][0] = u0[i]; U.m[i][1] = u1[i]; U.m[i][2] = u2[i]; }
+    V = Q;
+#pragma unroll
+    for (int j = 0; j < 3; j++) sig[j] = U.m[0][j] * B.m[0][j] + U.m[1][j] * B.m[1][j] + U.m[2][j] * B.m[2][j];
+}
+
+// simulator/func_utils.py:21-40
+__device__ __forceinline__ void volume_invariant_project(const double* sig, double* out) {
+    double D0 = 0, D1 = 0, D2 = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double a = sig[0] + D0, b = sig[1] + D1, c = sig[2] + D2;
+        const double C = a * b * c - 1.0;
+        const double g0 = b * c, g1 = a * c, g2 = a * b;
+        const double coef = ((g0 * D0 + g1 * D1 + g2 * D2) - C) / (g0 * g0 + g1 * g1 + g2 * g2);
+        D0 = coef * g0; D1 = coef * g1; D2 = coef * g2;
+    }
+    out[0] = sig[0] + D0; out[1] = sig[1] + D1; out[2] = sig[2] + D2;
+}
+
+__device__ __forceinline__ double shfl_xor_d(double v, int m) {
+    int2 t = *reinterpret_cast<int2*>(&v);
+    t.x = __shfl_xor(t.x, m);
+    t.y = __shfl_xor(t.y, m);
+    return *reinterpret_cast<double*>(&t);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ update_F / get_IP_info
+// One thread per (IP, shape-function row): row 0 = Nx -> pos; rows 1..3 = dNx[c] -> F[:,c]; rows 4..12 = ddNx[j][c] -> dF[j][:,c].
+// Output already in get_IP_info's permuted fp32 layout (solver.py:422-424).
+__global__ void __launch_bounds__(256) k_update_F(int n_IP, const int* __restrict__ topo, const double* __restrict__ dof, const double* __restrict__ Nx,
+                                                  const double* __restrict__ dNx, const double* __restrict__ ddNx, float* __restrict__ pos,
+                                                  float* __restrict__ F, float* __restrict__ dF) {
+    const int tid = threadIdx.x + blockIdx.x * blockDim.x;
+    const int v = tid / 13, row = tid % 13;
+    if (v >= n_IP) return;
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int i = 0; i < 8; i++) {
+        const int kid = topo[v * 8 + i];
+        const double* __restrict__ S;
+        if (row == 0) S = Nx + ((size_t)v * 8 + i) * 10;
+        else if (row < 4) S = dNx + (((size_t)v * 8 + i) * 3 + (row - 1)) * 10;
+        else S = ddNx + (((size_t)v * 8 + i) * 9 + (row - 4)) * 10;
+        const double* __restrict__ d = dof + (size_t)kid * 30;
+#pragma unroll
+        for (int x = 0; x < 10; x++) {
+            const double s = S[x];
+            a0 += d[x * 3] * s;
+            a1 += d[x * 3 + 1] * s;
+            a2 += d[x * 3 + 2] * s;
+        }
+    }
+    if (row == 0) {
+        pos[v * 3] = (float)a0; pos[v * 3 + 1] = (float)a1; pos[v * 3 + 2] = (float)a2;
+    } else if (row < 4) {
+        const int c = row - 1;  // F[r][c] -> flat c*3 + r
+        F[v * 9 + c * 3] = (float)a0; F[v * 9 + c * 3 + 1] = (float)a1; F[v * 9 + c * 3 + 2] = (float)a2;
+    } else {
+        const int j = (row - 4) / 3, c = (row - 4) % 3;  // dF[j][r][c] -> flat c*9 + r*3 + j
+        dF[v * 27 + c * 9 + j] = (float)a0; dF[v * 27 + c * 9 + 3 + j] = (float)a1; dF[v * 27 + c * 9 + 6 + j] = (float)a2;
+    }
+}
+
+extern "C" int pn_sim_update_F(int n_IP, const int* topo, const double* dof, const double* Nx, const double* dNx, const double* ddNx, float* pos,
+                               float* F, float* dF, void* stream) {
+    PN_REQUIRE(n_IP > 0 && topo && dof && Nx && dNx && ddNx && pos && F && dF);
+    k_update_F<<<pn_div_up((uint64_t)n_IP * 13, 256), 256, 0, (hipStream_t)stream>>>(n_IP, topo, dof, Nx, dNx, ddNx, pos, F, dF);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ calc_elastic
+// 8 lanes per IP.  Writes RF/VF/FF (op-level, any may be NULL) and/or P = dx^3 (mu R + lam V) (step driver).
+__global__ void __launch_bounds__(256) k_elastic(int n_IP, const int* __restrict__ topo, const double* __restrict__ dNx, const double* __restrict__ dof,
+                                                 double* __restrict__ RF, double* __restrict__ VF, double* __restrict__ FF, double* __restrict__ P,
+                                                 const double* __restrict__ mu, const double* __restrict__ lam, double dx3) {
+    const int tid = threadIdx.x + blockIdx.x * blockDim.x;
+    const int v = tid >> 3, i = tid & 7;
+    const bool live = v < n_IP;
+    M3 Fm;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) Fm.m[r][c] = 0.0;
+    if (live) {
+        const int kid = topo[v * 8 + i];
+        const double* __restrict__ d = dof + (size_t)kid * 30;
+        const double* __restrict__ dn = dNx + ((size_t)v * 8 + i) * 30;
+#pragma unroll
+        for (int x = 0; x < 10; x++) {
+            const double d0 = d[x * 3], d1 = d[x * 3 + 1], d2 = d[x * 3 + 2];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double g = dn[c * 10 + x];
+                Fm.m[0][c] += d0 * g;
+                Fm.m[1][c] += d1 * g;
+                Fm.m[2][c] += d2 * g;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double s = Fm.m[r][c];
+            s += shfl_xor_d(s, 1);
+            s += shfl_xor_d(s, 2);
+            s += shfl_xor_d(s, 4);
+            Fm.m[r][c] = s;
+        }
+    if (!live || i != 0) return;
+    M3 U, V;
+    double sig[3], sp[3];
+    svd3(Fm, U, sig, V);
+    volume_invariant_project(sig, sp);
+    const double m_ = mu ? mu[v] : 0.0, l_ = lam ? lam[v] : 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const double R = U.m[r][0] * V.m[c][0] + U.m[r][1] * V.m[c][1] + U.m[r][2] * V.m[c][2];
+            const double Vv = U.m[r][0] * sp[0] * V.m[c][0] + U.m[r][1] * sp[1] * V.m[c][1] + U.m[r][2] * sp[2] * V.m[c][2];
+            if (RF) RF[(size_t)v * 9 + r * 3 + c] = R;
+            if (VF) VF[(size_t)v * 9 + r * 3 + c] = Vv;
+            if (FF) FF[(size_t)v * 9 + r * 3 + c] = U.m[r][0] * sig[0] * V.m[c][0] + U.m[r][1] * sig[1] * V.m[c][1] + U.m[r][2] * sig[2] * V.m[c][2];
+            if (P) P[(size_t)v * 9 + r * 3 + c] = dx3 * (m_ * R + l_ * Vv);
+        }
+}
+
+extern "C" int pn_sim_calc_elastic(int n_IP, const int* topo, const double* dNx, const double* dof, double* RF, double* VF, double* FF,
+                                   void* stream) {
+    PN_REQUIRE(n_IP > 0 && topo && dNx && dof && RF && VF);
+    k_elastic<<<pn_div_up((uint64_t)n_IP * 8, 256), 256, 0, (hipStream_t)stream>>>(n_IP, topo, dNx, dof, RF, VF, FF, nullptr, nullptr, nullptr, 0.0);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ collect_rhs (gather form)
+// One wave per kernel k.  Entry e of the CSR list = vid*8 + dir.  Lane-strided accumulation of the 10x3 block, fixed
+// xor-tree reduction.  mode 0: rhs = sum (P from mu/lam/RF/VF); mode 1 (step driver): out = momentum + sum - rhs_rest.
+__global__ void __launch_bounds__(256) k_rhs_gather(int n_k, double dx3, const int* __restrict__ csr_bg, const int* __restrict__ csr_cnt,
+                                                    const int* __restrict__ csr_buf, const double* __restrict__ mu, const double* __restrict__ lam,
+                                                    const double* __restrict__ dNx, const double* __restrict__ RF, const double* __restrict__ VF,
+                                                    const double* __restrict__ P, const double* __restrict__ momentum,
+                                                    const double* __restrict__ rhs_rest, double* __restrict__ out) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n_k) return;
+    const int lane = threadIdx.x & 63;
+    double acc[30];
+#pragma unroll
+    for (int q = 0; q < 30; q++) acc[q] = 0.0;
+    const int bg = csr_bg[k], cnt = csr_cnt[k];
+    for (int e = lane; e < cnt; e += 64) {
+        const int code = csr_buf[bg + e];
+        const int v = code >> 3;
+        double Pm[9];
+        if (P) {
+#pragma unroll
+            for (int q = 0; q < 9; q++) Pm[q] = P[(size_t)v * 9 + q];
+        } else {
+            const double m_ = mu[v], l_ = lam[v];
+#pragma unroll
+            for (int q = 0; q < 9; q++) Pm[q] = dx3 * (m_ * RF[(size_t)v * 9 + q] + l_ * VF[(size_t)v * 9 + q]);
+        }
+        const double* __restrict__ dn = dNx + (size_t)code * 30;  // [c][x]
+#pragma unroll
+        for (int x = 0; x < 10; x++) {
+            const double g0 = dn[x], g1 = dn[10 + x], g2 = dn[20 + x];
+#pragma unroll
+            for (int r = 0; r < 3; r++) acc[x * 3 + r] += Pm[r * 3] * g0 + Pm[r * 3 + 1] * g1 + Pm[r * 3 + 2] * g2;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 30; q++) {
+        double s = acc[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += shfl_xor_d(s, o);
+        acc[q] = s;
+    }
+    if (lane < 30) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 30; q++) if (q == lane) s = acc[q];
+        const size_t o = (size_t)k * 30 + lane;
+        out[o] = momentum ? (momentum[o] + s - rhs_rest[o]) : s;
+    }
+}
+
+extern "C" int pn_sim_collect_rhs(int n_k, double dx, const int* csr_bg, const int* csr_cnt, const int* csr_buf, const double* mu, const double* lam,
+                                  const double* dNx, const double* RF, const double* VF, double* rhs, void* stream) {
+    PN_REQUIRE(n_k > 0 && csr_bg && csr_cnt && csr_buf && mu && lam && dNx && RF && VF && rhs);
+    k_rhs_gather<<<pn_div_up(n_k, 4), 256, 0, (hipStream_t)stream>>>(n_k, pow(dx, 3.0), csr_bg, csr_cnt, csr_buf, mu, lam, dNx, RF, VF, nullptr, nullptr,
+                                                                   nullptr, rhs);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ structured matvec
+// Y[i,:] = sum_j A[i,j] X[j,:], one wave per row.  Epilogues: 0: Y = s ; 1: Y = s + add1 + add2 (momentum, solver.py:576) ;
+// 2: Y = add1 + s (dof = dof_rest + x, solver.py:601).
+__global__ void __launch_bounds__(256) k_matvec3(int n, const double* __restrict__ A, const double* __restrict__ X, double* __restrict__ Y, int mode,
+                                                 const double* __restrict__ add1, const double* __restrict__ add2) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    const double* __restrict__ a = A + (size_t)i * n;
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (int j = lane; j < n; j += 64) {
+        const double w = a[j];
+        s0 += w * X[j * 3];
+        s1 += w * X[j * 3 + 1];
+        s2 += w * X[j * 3 + 2];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += shfl_xor_d(s0, o);
+        s1 += shfl_xor_d(s1, o);
+        s2 += shfl_xor_d(s2, o);
+    }
+    if (lane < 3) {
+        double s = lane == 0 ? s0 : (lane == 1 ? s1 : s2);
+        const size_t o = (size_t)i * 3 + lane;
+        if (mode == 1) s = s + add1[o] + add2[o];
+        else if (mode == 2) s = add1[o] + s;
+        Y[o] = s;
+    }
+}
+
+extern "C" int pn_sim_matvec3(int n, const double* A, const double* X, double* Y, void* stream) {
+    PN_REQUIRE(n > 0 && A && X && Y);
+    k_matvec3<<<pn_div_up(n, 4), 256, 0, (hipStream_t)stream>>>(n, A, X, Y, 0, nullptr, nullptr);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ stepforward
+__global__ void __launch_bounds__(256) k_step_begin(int n3, double dt, const double* __restrict__ dof, const double* __restrict__ vel,
+                                                    double* __restrict__ tilde, double* __restrict__ last) {
+    const int i = threadIdx.x + blockIdx.x * blockDim.x;
+    if (i >= n3) return;
+    const double d = dof[i];
+    tilde[i] = d + dt * vel[i];  // solver.py:575
+    last[i] = d;                 // dof_last = dof.clone() (:597)
+}
+__global__ void __launch_bounds__(256) k_step_end(int n3, double dt, const double* __restrict__ dof, const double* __restrict__ last,
+                                                  double* __restrict__ vel) {
+    const int i = threadIdx.x + blockIdx.x * blockDim.x;
+    if (i >= n3) return;
+    vel[i] = (dof[i] - last[i]) / dt * 0.998;  // solver.py:602
+}
+
+extern "C" uint64_t pn_sim_work_doubles(int n_k, int n_IP) { return (uint64_t)n_k * 30 * 4 + (uint64_t)n_IP * 9; }
+
+extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, double dx, const int* topo, const int* csr_bg, const int* csr_cnt,
+                                  const int* csr_buf, const double* mu, const double* lam, const double* dNx, const double* Ainv,
+                                  const double* Mmat, const double* dof_rest, const double* rhs_rest, const double* rhs_gravity,
+                                  const double* dof_f, double* dof, double* dof_vel, double* work, void* stream) {
+    PN_REQUIRE(n_k > 0 && n_IP > 0 && iters >= 0 && topo && csr_bg && csr_cnt && csr_buf && mu && lam && dNx && Ainv && Mmat);
+    PN_REQUIRE(dof_rest && rhs_rest && rhs_gravity && dof_f && dof && dof_vel && work);
+    hipStream_t st = (hipStream_t)stream;
+    const int n = n_k * 10, n3 = n * 3;
+    double* tilde = work;
+    double* last = work + n3;
+    double* momentum = work + 2 * (size_t)n3;
+    double* tot = work + 3 * (size_t)n3;
+    double* P = work + 4 * (size_t)n3;
+    const double dx3 = pow(dx, 3.0);
+    k_step_begin<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, dt, dof, dof_vel, tilde, last);
+    k_matvec3<<<pn_div_up(n, 4), 256, 0, st>>>(n, Mmat, tilde, momentum, 1, dof_f, rhs_gravity);  // compute_momentum (:574-576)
+    for (int it = 0; it < iters; it++) {
+        k_elastic<<<pn_div_up((uint64_t)n_IP * 8, 256), 256, 0, st>>>(n_IP, topo, dNx, dof, nullptr, nullptr, nullptr, P, mu, lam, dx3);
+        k_rhs_gather<<<pn_div_up(n_k, 4), 256, 0, st>>>(n_k, dx3, csr_bg, csr_cnt, csr_buf, mu, lam, dNx, nullptr, nullptr, P, momentum, rhs_rest, tot);
+        k_matvec3<<<pn_div_up(n, 4), 256, 0, st>>>(n, Ainv, tot, dof, 2, dof_rest, nullptr);  // x = G @ rhs ; dof = dof_rest + x (:600-601)
+    }
+    k_step_end<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, dt, dof, last, dof_vel);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ update_force
+// Simulator.update_force (solver.py:578-588): 80 entries of dof_f for the picked IP; everything else zero.
+__global__ void k_update_force(int vid, double fx, double fy, double fz, double dx3, const int* __restrict__ topo, const double* __restrict__ rho,
+                               const double* __restrict__ Nx, double* __restrict__ dof_f) {
+    const int t = threadIdx.x;
+    if (t >= 80) return;
+    const int i = t / 10, j = t % 10;
+    const int kid = topo[vid * 8 + i];
+    const double m = rho[vid] * dx3;
+    const double w = m * Nx[((size_t)vid * 8 + i) * 10 + j];
+    // distinct (i,j) address distinct rows because an IP's 8 neighbour kernels are distinct
+    dof_f[((size_t)kid * 10 + j) * 3] += w * fx;
+    dof_f[((size_t)kid * 10 + j) * 3 + 1] += w * fy;
+    dof_f[((size_t)kid * 10 + j) * 3 + 2] += w * fz;
+}
+
+extern "C" int pn_sim_update_force(int n_k, int vid, const double* f3_host, double dx, const int* topo, const double* rho, const double* Nx,
+                                   double* dof_f, void* stream) {
+    PN_REQUIRE(n_k > 0 && vid >= 0 && f3_host && topo && rho && Nx && dof_f);
+    hipStream_t st = (hipStream_t)stream;
+    PN_HIP_CHECK(hipMemsetAsync(dof_f, 0, sizeof(double) * (size_t)n_k * 30, st));
+    k_update_force<<<1, 128, 0, st>>>(vid, f3_host[0], f3_host[1], f3_host[2], pow(dx, 3.0), topo, rho, Nx, dof_f);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ misc
+extern "C" const char* pn_version(void) { return "pienerf_hip 0.1.0 gfx950"; }
+extern "C" const char* pn_last_error(void) { return pn_err_buf; }

@@ -1,0 +1,79 @@
+"""Headless counterpart of the reference's per-frame harness.
+
+One ``step()`` = what ``NeRFSimGUI.test_step`` -> ``Trainer.test_gui`` -> ``Trainer.test_step`` do for one GUI frame
+(nerf/gui.py:556-645, nerf/trainer.py:284-329,531-602), minus the window:
+
+    rays = get_rays(pose, intrinsics, H, W)            # trainer.py:543
+    IP_pos, IP_F, IP_dF = solver.get_IP_info()         # trainer.py:303   (state BEFORE the step: render lags sim by one frame)
+    model.p_def / IP_F / IP_dF = ...                   # trainer.py:304-306
+    solver.stepforward()                               # trainer.py:308
+    model.render_deformed(rays_o, rays_d, **vars(opt)) # trainer.py:316-318
+
+Start-up mirrors main_gui.py:26-56.
+"""
+import numpy as np
+import torch
+
+from . import scene
+from .nerf.network import NeRFNetwork
+from .nerf.utils import get_rays
+from .simulator.solver import Simulator
+
+
+class SimRenderHarness:
+    def __init__(self, opt=None, cloud=None, ckpt=None, device="cuda"):
+        self.opt = dict(opt or scene.default_opt())
+        o = self.opt
+        self.device = torch.device(device)
+        self.cloud = cloud if cloud is not None else scene.make_chair_points(hgs=o["hash_grid_size"], bound=o["bound"])
+        self.ckpt = ckpt if ckpt is not None else scene.make_checkpoint(bound=o["bound"])
+        # main_gui.py:26-34
+        self.model = NeRFNetwork(encoding="hashgrid", bound=o["bound"], cuda_ray=True, density_scale=1, min_near=o["min_near"],
+                                 density_thresh=o["density_thresh"], bg_radius=o["bg_radius"]).to(self.device)
+        self.model.load_checkpoint_dict(self.ckpt)
+        self.model.eval()
+        # main_gui.py:39-48
+        self.sim = Simulator(dt=o["sim_dt"], iters=o["sim_iters"], bbox=torch.tensor([2.0 * o["bound"]] * 3), dx=o["sim_dx"], stiff=o["sim_stiff"],
+                             base=torch.tensor([-o["bound"]] * 3), device=self.device)
+        c = self.cloud
+        self.sim.InitializeFromArrays(c["pos"], c["mass"], c["mu"], c["lam"], c["pin"])
+        # main_gui.py:50-56
+        IP_pos, IP_F, IP_dF = self.sim.get_IP_info()
+        m = self.model
+        m.p_ori, m.p_def, m.IP_F, m.IP_dF = IP_pos, IP_pos, IP_F, IP_dF
+        m.IP_dx = self.sim.dx * 1.05
+        self.frame = 0
+        self.pose = scene.orbit_pose(o["radius"])
+        self.intrinsics = scene.orbit_intrinsics(o["W"], o["H"], o["fovy"])
+        self._pose_dev = None
+
+    def render_kwargs(self):
+        """**vars(opt) as the reference passes it (trainer.py:318); renderer reads these by name."""
+        return dict(self.opt)
+
+    @torch.no_grad()
+    def step(self, pose=None, intrinsics=None, W=None, H=None, simulate=True, collect_stats=False, fused=True):
+        o = self.opt
+        W, H = W or o["W"], H or o["H"]
+        pose = self.pose if pose is None else pose
+        intrinsics = self.intrinsics if intrinsics is None else intrinsics
+        pose_t = torch.from_numpy(np.asarray(pose, np.float32)).unsqueeze(0).to(self.device)   # trainer.py:541
+        rays = get_rays(pose_t, intrinsics, H, W, -1)
+        m = self.model
+        if simulate:
+            IP_pos, IP_F, IP_dF = self.sim.get_IP_info()
+            m.p_def, m.IP_F, m.IP_dF = IP_pos, IP_F, IP_dF
+            self.sim.stepforward()
+            self.frame += 1
+        kw = self.render_kwargs()
+        kw["collect_stats"] = collect_stats
+        if fused:
+            out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **kw)
+        else:
+            out = m.rund_cuda_ops(rays["rays_o"], rays["rays_d"], bg_color=None, perturb=False, **kw)
+        return {"image": out["image"].reshape(-1, H, W, 3), "depth": out["depth"].reshape(-1, H, W), "depth_0": out["depth_0"].reshape(-1, H, W),
+                "rays_o": rays["rays_o"], "rays_d": rays["rays_d"]}
+
+    def to_host(self, out):
+        """The reference's device->host boundary (trainer.py:589-592)."""
+        return {k: out[k][0].detach().cpu().numpy() for k in ("image", "depth", "depth_0")}

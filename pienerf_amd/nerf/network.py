@@ -1,0 +1,98 @@
+"""NeRFNetwork with the reference's constructor, state-dict keys and forward (nerf/network.py:14-127).
+
+``forward(x, d)`` runs the fused HIP kernel (hash grid + SH + both MLPs on f32 MFMA); ``forward_ops`` is the same
+computation op by op (grid_encode -> torch Linear -> sh_encode -> ...) like the reference, kept for parity tests.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .._lib import check, lib, ptr, require_gpu, stream_ptr
+from .encoding import get_encoder
+from .renderer import NeRFRenderer
+
+
+class NeRFNetwork(NeRFRenderer):
+    def __init__(self, encoding="hashgrid", encoding_dir="sphere_harmonics", encoding_bg="hashgrid", num_layers=2, hidden_dim=64, geo_feat_dim=15,
+                 num_layers_color=3, hidden_dim_color=64, num_layers_bg=2, hidden_dim_bg=64, bound=1, **kwargs):
+        super().__init__(bound, **kwargs)
+        if self.bg_radius > 0:
+            raise NotImplementedError("background model (bg_radius > 0) is not on the simulate-and-render path (main_gui.py uses -1)")
+        self.num_layers, self.hidden_dim, self.geo_feat_dim = num_layers, hidden_dim, geo_feat_dim
+        self.encoder, self.in_dim = get_encoder(encoding, desired_resolution=2048 * bound)
+        dims = [self.in_dim] + [hidden_dim] * (num_layers - 1) + [1 + geo_feat_dim]  # 1 sigma + 15 geo features
+        self.sigma_net = nn.ModuleList([nn.Linear(dims[i], dims[i + 1], bias=False) for i in range(num_layers)])
+        self.num_layers_color, self.hidden_dim_color = num_layers_color, hidden_dim_color
+        self.encoder_dir, self.in_dim_dir = get_encoder(encoding_dir)
+        cdims = [self.in_dim_dir + geo_feat_dim] + [hidden_dim_color] * (num_layers_color - 1) + [3]
+        self.color_net = nn.ModuleList([nn.Linear(cdims[i], cdims[i + 1], bias=False) for i in range(num_layers_color)])
+        self.bg_net = None
+        self._net = None
+        self._net_sig = None
+
+    # ---- packed device context for the fused kernel; rebuilt when the parameters change
+    def _signature(self):
+        ts = [self.encoder.embeddings] + [l.weight for l in self.sigma_net] + [l.weight for l in self.color_net]
+        return tuple((t.data_ptr(), t._version, str(t.device)) for t in ts)
+
+    def _net_handle(self):
+        sig = self._signature()
+        if self._net is None or sig != self._net_sig:
+            if (self.num_layers, self.hidden_dim, self.geo_feat_dim, self.num_layers_color, self.hidden_dim_color) != (2, 64, 15, 3, 64):
+                raise RuntimeError("fused network kernel implements the reference architecture only (32->64->16 | 31->64->64->3)")
+            emb = self.encoder.embeddings
+            require_gpu(emb)
+            assert emb.dtype == torch.float32 and emb.is_contiguous()
+            Ws = [np.ascontiguousarray(l.weight.detach().cpu().numpy(), dtype=np.float32) for l in list(self.sigma_net) + list(self.color_net)]
+            off = self.encoder._offsets_host
+            if self._net is not None:
+                lib().pn_net_destroy(self._net)
+            h = C.c_void_p()
+            check(lib().pn_net_create(C.byref(h), ptr(emb), off.data_ptr(), self.encoder.num_levels, self.encoder.level_dim,
+                                      float(np.float32(np.log2(self.encoder.per_level_scale))), int(self.encoder.base_resolution), float(self.bound),
+                                      Ws[0].ctypes.data, Ws[1].ctypes.data, Ws[2].ctypes.data, Ws[3].ctypes.data, Ws[4].ctypes.data,
+                                      stream_ptr()), "net_create")
+            self._net, self._net_sig = h, sig
+        return self._net
+
+    def forward(self, x, d):
+        """x [N,3] in [-bound,bound], d [N,3] unit -> sigma [N], color [N,3] (network.py:98-127), one fused launch."""
+        x = x.to(torch.float32).contiguous().view(-1, 3)
+        d = d.to(torch.float32).contiguous().view(-1, 3)
+        require_gpu(x, d)
+        M = x.shape[0]
+        sigma = torch.empty(M, dtype=torch.float32, device=x.device)
+        color = torch.empty(M, 3, dtype=torch.float32, device=x.device)
+        check(lib().pn_nerf_forward(self._net_handle(), ptr(x), ptr(d), M, 1.0, ptr(sigma), ptr(color), stream_ptr()), "nerf_forward")
+        return sigma, color
+
+    def forward_ops(self, x, d):
+        """The reference's op sequence: GridEncoder -> Linear/ReLU -> exp | SHEncoder, cat -> Linear/ReLU x3 -> sigmoid."""
+        h = self.encoder(x, bound=self.bound)
+        for i, layer in enumerate(self.sigma_net):
+            h = layer(h)
+            if i != self.num_layers - 1:
+                h = F.relu(h, inplace=True)
+        sigma = torch.exp(h[..., 0])  # trunc_exp forward (nerf/activation.py:8-10)
+        h = torch.cat([self.encoder_dir(d), h[..., 1:]], dim=-1)
+        for i, layer in enumerate(self.color_net):
+            h = layer(h)
+            if i != self.num_layers_color - 1:
+                h = F.relu(h, inplace=True)
+        return sigma, torch.sigmoid(h)
+
+    def load_checkpoint_dict(self, ck):
+        """Loads the synthetic checkpoint dict of pienerf_amd.scene.make_checkpoint (same tensors as the reference's
+        state dict: encoder.embeddings, sigma_net.{0,1}.weight, color_net.{0,1,2}.weight, density_bitfield)."""
+        dev = self.encoder.embeddings.device
+        with torch.no_grad():
+            assert tuple(self.encoder.offsets.cpu().numpy()) == tuple(np.asarray(ck["offsets"])), "hash-grid geometry mismatch"
+            self.encoder.embeddings.copy_(torch.from_numpy(ck["embeddings"]).to(dev))
+            for layer, key in zip(list(self.sigma_net) + list(self.color_net), ("W0", "W1", "W2", "W3", "W4")):
+                layer.weight.copy_(torch.from_numpy(ck[key]).to(dev))
+            self.density_bitfield.copy_(torch.from_numpy(ck["density_bitfield"]).to(dev))
+        self._net_sig = None
+        return self

@@ -1,0 +1,184 @@
+"""Deformed-space renderer with the reference's surface (nerf/renderer.py:74-113, 587-599, 755-907).
+
+``NeRFRenderer.render_deformed(rays_o, rays_d, **vars(opt))`` is what ``Trainer.test_step`` calls
+(nerf/trainer.py:316-318); the caller sets ``p_ori, p_def, IP_F, IP_dF, IP_dx`` on the model
+(main_gui.py:52-56, trainer.py:303-306).  Two implementations of ``rund_cuda`` are provided:
+
+  * ``rund_cuda``      — one C call (pn_render_deformed): the whole loop runs on the GPU with a device-side
+                         (n_alive, n_step) record; no per-trip host synchronisation.
+  * ``rund_cuda_ops``  — the reference's Python loop verbatim in structure, on the drop-in ops
+                         (near_far_from_aabb / get_pnts_in_grids / march_rays_quadratic_bending / network /
+                         composite_rays / compaction).  Used by the parity tests and as documentation of semantics.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import raymarching
+from .._lib import RenderOpts, check, lib, ptr, require_gpu, stream_ptr
+from .utils import get_pnts_in_grids
+
+
+class NeRFRenderer(nn.Module):
+    def __init__(self, bound=1, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1):
+        super().__init__()
+        self.bound = bound
+        self.cascade = 1 + math.ceil(math.log2(bound))
+        self.grid_size = 128
+        self.density_scale = density_scale
+        self.min_near = min_near
+        self.density_thresh = density_thresh
+        self.bg_radius = bg_radius
+        aabb = torch.FloatTensor([-bound, -bound, -bound, bound, bound, bound])
+        self.register_buffer("aabb_train", aabb)
+        self.register_buffer("aabb_infer", aabb.clone())
+        self.cuda_ray = cuda_ray
+        if cuda_ray:  # same state-dict keys as renderer.py:94-111
+            self.register_buffer("density_grid", torch.zeros([self.cascade, self.grid_size ** 3]))
+            self.register_buffer("density_bitfield", torch.zeros(self.cascade * self.grid_size ** 3 // 8, dtype=torch.uint8))
+            self.register_buffer("step_counter", torch.zeros(16, 2, dtype=torch.int32))
+            self.mean_density = 0
+            self.iter_density = 0
+            self.mean_count = 0
+            self.local_step = 0
+        self._frame = None
+        self._frame_key = None
+        self.last_stats = None
+
+    def forward(self, x, d):
+        raise NotImplementedError()
+
+    def _net_handle(self):
+        raise NotImplementedError()
+
+    # ------------------------------------------------------------------ entry point (renderer.py:587-599)
+    def render_deformed(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
+        if not self.cuda_ray:
+            raise RuntimeError("render_deformed: only the cuda_ray path (main_gui.py / main_render.py with -O) is implemented")
+        return self.rund_cuda(rays_o, rays_d, **kwargs)
+
+    def _ip_state(self, device):
+        return [t.to(device=device, dtype=torch.float32).contiguous() for t in (self.p_def, self.p_ori, self.IP_F, self.IP_dF)]
+
+    def _frame_handle(self, N, n_vtx, hgs):
+        # spatial-hash capacity: the IP cloud lives inside the simulation box (2.04*bound per side, solver.py:24-32); x2 margin per axis
+        side = int(math.ceil(2.2 * float(self.bound) / hgs)) + 2
+        cells = side ** 3
+        key = (N, n_vtx, cells)
+        if self._frame_key != key:
+            if self._frame is not None:
+                lib().pn_frame_destroy(self._frame)
+            h = C.c_void_p()
+            check(lib().pn_frame_create(C.byref(h), N, n_vtx, cells), "frame_create")
+            self._frame, self._frame_key = h, key
+        return self._frame
+
+    # ------------------------------------------------------------------ fused loop
+    def rund_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-2, **kwargs):
+        if perturb:
+            return self.rund_cuda_ops(rays_o, rays_d, dt_gamma, bg_color, perturb, max_steps, T_thresh, **kwargs)
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.to(torch.float32).contiguous().view(-1, 3)
+        rays_d = rays_d.to(torch.float32).contiguous().view(-1, 3)
+        require_gpu(rays_o, rays_d)
+        N, device = rays_o.shape[0], rays_o.device
+        if self.bg_radius > 0:
+            raise RuntimeError("background model (bg_radius > 0) is not on the simulate-and-render path")
+        if bg_color is None:
+            bg_color = 1
+        if torch.is_tensor(bg_color):
+            raise RuntimeError("rund_cuda: tensor bg_color is not supported by the fused path; use rund_cuda_ops")
+        p_def, p_ori, F_IP, dF_IP = self._ip_state(device)
+        assert p_def.shape == p_ori.shape and p_ori.shape[0] > 0  # renderer.py:816-817
+        n_vtx = p_ori.shape[0]
+        hgs = float(kwargs.get("hash_grid_size"))
+        o = RenderOpts()
+        o.max_iter_num = int(kwargs.get("max_iter_num"))
+        o.hash_grid_size = hgs
+        o.num_seek_IP = int(kwargs.get("num_seek_IP"))
+        o.IP_dx = float(self.IP_dx)
+        o.cut = int(bool(kwargs.get("cut")))
+        cb = kwargs.get("cut_bounds") or [0.0] * 6
+        for i in range(6):
+            o.cut_bounds[i] = float(cb[i])
+        o.bound = float(kwargs.get("bound", self.bound))
+        o.min_near = float(self.min_near)
+        o.dt_gamma = float(dt_gamma)
+        o.max_steps = int(max_steps)
+        o.T_thresh = float(T_thresh)
+        o.cascade = int(self.cascade)
+        o.grid_size = int(self.grid_size)
+        o.density_scale = float(self.density_scale)
+        o.bg_color = float(bg_color)
+        image = torch.empty(N, 3, dtype=torch.float32, device=device)
+        depth = torch.empty(N, dtype=torch.float32, device=device)
+        depth_0 = torch.empty(N, dtype=torch.float32, device=device)
+        weights_sum = torch.empty(N, dtype=torch.float32, device=device)
+        stats = (C.c_int64 * 4)() if kwargs.get("collect_stats") else None
+        check(lib().pn_render_deformed(self._frame_handle(N, n_vtx, hgs), self._net_handle(), C.byref(o), ptr(rays_o), ptr(rays_d), N, ptr(p_def),
+                                       ptr(p_ori), ptr(F_IP), ptr(dF_IP), n_vtx, ptr(self.density_bitfield), ptr(image), ptr(depth), ptr(depth_0),
+                                       ptr(weights_sum), stats, stream_ptr()), "render_deformed")
+        if stats is not None:
+            self.last_stats = dict(trips=int(stats[0]), samples=int(stats[1]), err=int(stats[2]), alive_at_exit=int(stats[3]))
+            if stats[2]:
+                raise RuntimeError(f"render_deformed: device error flags {int(stats[2])} (1: sample cell outside the spatial hash, "
+                                   "2: IP outside it, 4: spatial-hash capacity exceeded)")
+        return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "depth_0": depth_0.view(*prefix), "weights_sum": weights_sum}
+
+    # ------------------------------------------------------------------ op-by-op loop (reference structure, renderer.py:755-907)
+    def rund_cuda_ops(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-2, **kwargs):
+        dtype = torch.float32
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        N, device = rays_o.shape[0], rays_o.device
+        max_iter_num, hgs, bound = kwargs.get("max_iter_num"), kwargs.get("hash_grid_size"), kwargs.get("bound")
+        cut = kwargs.get("cut")
+        cut_bounds = torch.tensor(kwargs.get("cut_bounds") or [0.0] * 6, dtype=dtype, device=device)
+        p_def, p_ori, F_IP, dF_IP = self._ip_state(device)
+        bmin, bmax = p_def.min(axis=0).values, p_def.max(axis=0).values
+        if cut:
+            bmin = -bound * torch.ones(3, dtype=dtype, device=device)
+            bmax = bound * torch.ones(3, dtype=dtype, device=device)
+        marg = 1e-3
+        bbmin = bmin - marg * torch.ones(3, dtype=dtype, device=device)
+        bbmax = bmax + marg * torch.ones(3, dtype=dtype, device=device)
+        resolution = torch.ceil((bbmax - bbmin) / hgs).to(torch.int32)
+        aabb = torch.cat((bbmin, bbmax), dim=0)
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
+        if bg_color is None:
+            bg_color = 1
+        weights_sum = torch.zeros(N, dtype=dtype, device=device)
+        depth = torch.zeros(N, dtype=dtype, device=device)
+        image = torch.zeros(N, 3, dtype=dtype, device=device)
+        num_seek_IP = kwargs.get("num_seek_IP")
+        n_vtx = p_ori.shape[0]
+        n_grid = int(resolution[2] * resolution[1] * resolution[0])
+        assert p_def.shape == p_ori.shape and n_vtx > 0
+        pig_cnt, pig_bgn, pig_idx = get_pnts_in_grids(n_vtx, n_grid, p_def, bbmin, bbmax, hgs, resolution)
+        rays_alive = torch.arange(N, dtype=torch.int32, device=device)
+        rays_t = nears.clone()
+        step, trips, samples = 0, 0, 0
+        while step < max_steps:
+            n_alive = rays_alive.shape[0]
+            if n_alive <= 0:
+                break
+            n_step = max(min(N // n_alive, 8), 1)
+            xyzs, dirs, deltas = raymarching.march_rays_quadratic_bending(
+                pig_cnt, pig_bgn, pig_idx, n_vtx, n_grid, p_def, p_ori, F_IP, dF_IP, max_iter_num, bbmin, bbmax, hgs, resolution, num_seek_IP,
+                self.IP_dx, cut, cut_bounds, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
+                self.grid_size, nears, fars, 128, perturb if step == 0 else False, dt_gamma, max_steps)
+            sigmas, rgbs = self(xyzs, dirs)
+            sigmas = self.density_scale * sigmas
+            raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh)
+            rays_alive = raymarching.compact_rays(rays_alive)  # == rays_alive[rays_alive >= 0]
+            samples += int((deltas[:, 0] != 0).sum())
+            step += n_step
+            trips += 1
+        self.last_stats = dict(trips=trips, samples=samples, err=0, alive_at_exit=int(rays_alive.shape[0]))
+        depth_0 = depth
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "depth_0": depth_0.view(*prefix), "weights_sum": weights_sum}

@@ -1,0 +1,88 @@
+"""Drop-in mirror of the reference's ``raymarching`` package for the simulate-and-render path.
+
+Same function names, argument order and in-place/ownership behaviour as
+/root/reference/raymarching/raymarching.py (cited per function); the native side is
+libpienerf_hip.so (include/pienerf_hip.h) instead of the pybind ``_raymarching`` module.
+Wrappers allocate every output, exactly like the reference.  GPU tensors only.
+"""
+import torch
+
+from .._lib import check, lib, ptr, require_gpu, stream_ptr
+
+__all__ = ["near_far_from_aabb", "march_rays_quadratic_bending", "composite_rays", "compact_rays"]
+
+
+def _f32(t):
+    return t.to(torch.float32).contiguous()  # custom_fwd(cast_inputs=torch.float32) in the reference
+
+
+def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2):
+    """raymarching/raymarching.py:21-51.  rays_o, rays_d [N,3]; aabb [6] -> nears [N], fars [N]."""
+    if not rays_o.is_cuda:
+        rays_o = rays_o.cuda()
+    if not rays_d.is_cuda:
+        rays_d = rays_d.cuda()
+    rays_o = _f32(rays_o).view(-1, 3)
+    rays_d = _f32(rays_d).view(-1, 3)
+    aabb = _f32(aabb)
+    require_gpu(rays_o, rays_d, aabb)
+    N = rays_o.shape[0]
+    nears = torch.empty(N, dtype=rays_o.dtype, device=rays_o.device)
+    fars = torch.empty(N, dtype=rays_o.dtype, device=rays_o.device)
+    check(lib().pn_near_far_from_aabb(ptr(rays_o), ptr(rays_d), ptr(aabb), N, float(min_near), ptr(nears), ptr(fars), stream_ptr()),
+          "near_far_from_aabb")
+    return nears, fars
+
+
+def march_rays_quadratic_bending(pig_cnt, pig_bgn, pig_idx, n_vtx, n_grid, p_def, p_ori, F_IP, dF_IP, max_iter_num, bbmin, bbmax, hgs, res,
+                                 num_seek_IP, IP_dx, cut, cut_bounds, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound,
+                                 density_bitfield, C, H, near, far, align=-1, perturb=False, dt_gamma=0, max_steps=1024):
+    """raymarching/raymarching.py:387-441.  Returns zero-initialised xyzs [M,3], dirs [M,3], deltas [M,2]."""
+    if not rays_o.is_cuda:
+        rays_o = rays_o.cuda()
+    if not rays_d.is_cuda:
+        rays_d = rays_d.cuda()
+    rays_o = _f32(rays_o).view(-1, 3)
+    rays_d = _f32(rays_d).view(-1, 3)
+    n_alive, n_step, n_grid = int(n_alive), int(n_step), int(n_grid)
+    M = n_alive * n_step
+    if align > 0:
+        M += align - (M % align)
+    dev = rays_o.device
+    xyzs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
+    dirs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
+    deltas = torch.zeros(M, 2, dtype=rays_o.dtype, device=dev)
+    if perturb:
+        noises = torch.rand(n_alive, dtype=rays_o.dtype, device=dev)
+    else:
+        noises = torch.zeros(n_alive, dtype=rays_o.dtype, device=dev)
+    ts = [pig_cnt, pig_bgn, pig_idx, p_def, p_ori, F_IP, dF_IP, bbmin, bbmax, res, cut_bounds, rays_alive, rays_t, density_bitfield, near, far]
+    require_gpu(*ts)
+    p_def, p_ori, F_IP, dF_IP, bbmin, bbmax, cut_bounds, rays_t, near, far = (_f32(t) for t in (p_def, p_ori, F_IP, dF_IP, bbmin, bbmax, cut_bounds,
+                                                                                              rays_t, near, far))
+    check(lib().pn_march_rays_quadratic_bending(
+        ptr(pig_cnt), ptr(pig_bgn), ptr(pig_idx), int(n_vtx), n_grid, ptr(p_def), ptr(p_ori), ptr(F_IP), ptr(dF_IP), int(max_iter_num), ptr(bbmin),
+        ptr(bbmax), float(hgs), ptr(res), int(num_seek_IP), float(IP_dx), int(bool(cut)), ptr(cut_bounds), n_alive, n_step, ptr(rays_alive),
+        ptr(rays_t), ptr(rays_o), ptr(rays_d), float(bound), float(dt_gamma), int(max_steps), int(C), int(H), ptr(density_bitfield), ptr(near),
+        ptr(far), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(noises), None, stream_ptr()), "march_rays_quadratic_bending")
+    return xyzs, dirs, deltas
+
+
+def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh=1e-2):
+    """raymarching/raymarching.py:362-384.  In place on rays_alive, rays_t, weights_sum, depth, image."""
+    require_gpu(rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image)
+    sigmas, rgbs, deltas = _f32(sigmas), _f32(rgbs), _f32(deltas)
+    check(lib().pn_composite_rays(int(n_alive), int(n_step), float(T_thresh), ptr(rays_alive), ptr(rays_t), ptr(sigmas), ptr(rgbs), ptr(deltas),
+                                  ptr(weights_sum), ptr(depth), ptr(image), stream_ptr()), "composite_rays")
+    return tuple()
+
+
+def compact_rays(rays_alive):
+    """Stable filter ``rays_alive[rays_alive >= 0]`` (nerf/renderer.py:887) as a HIP kernel; returns the new int32 tensor."""
+    require_gpu(rays_alive)
+    n = rays_alive.shape[0]
+    out = torch.empty_like(rays_alive)
+    n_out = torch.zeros(1, dtype=torch.int32, device=rays_alive.device)
+    scratch = torch.empty(int(lib().pn_compact_scratch_ints(n)), dtype=torch.int32, device=rays_alive.device)
+    check(lib().pn_compact_rays(ptr(rays_alive), n, ptr(out), ptr(n_out), ptr(scratch), stream_ptr()), "compact_rays")
+    return out[: int(n_out.item())]  # the .item() is the same D2H sync the reference's boolean mask implies

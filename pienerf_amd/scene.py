@@ -1,0 +1,233 @@
+"""Synthetic inputs for the simulate-and-render path.
+
+The reference's assets (``chair_0.ply``, ``model/chair/checkpoints/ngp_ep0300.pth``) are
+hosted off-repo and absent, so every test and benchmark runs on a
+procedural stand-in built here, deterministically from a numpy seed:
+
+  * point cloud   — lattice samples of a box-union "chair" with the vertex attributes the
+                    simulator reads (x,y,z,mass,mu,lam,pin; solver.py:116-135, README.md:98-108);
+  * checkpoint    — the inference state-dict keys of SURVEY.md §5: hash-grid ``offsets`` /
+                    ``embeddings`` (gridencoder/grid.py:96-134), the five bias-free MLP weights
+                    (nerf/network.py:36-71) and a morton-ordered ``density_bitfield``
+                    (nerf/renderer.py:94-111, raymarching.cu:1398-1399) rasterised from the solid;
+  * camera        — ``OrbitCamera`` pose / intrinsics (nerf/gui.py:13-44);
+  * PLY IO        — reader/writer for the one-element vertex PLY (``plyfile`` is not installed).
+
+Pure numpy: no GPU, no torch, no oracle.
+"""
+import math
+import struct
+
+import numpy as np
+
+# ------------------------------------------------------------------ solid
+# (xmin, xmax, ymin, ymax, zmin, zmax), y up
+CHAIR_BOXES = np.array([
+    [-0.40, 0.40, -0.05, 0.05, -0.40, 0.40],   # seat
+    [-0.40, 0.40, 0.05, 0.60, -0.40, -0.30],   # back
+    [-0.40, -0.30, -0.60, -0.05, -0.40, -0.30],  # legs
+    [0.30, 0.40, -0.60, -0.05, -0.40, -0.30],
+    [-0.40, -0.30, -0.60, -0.05, 0.30, 0.40],
+    [0.30, 0.40, -0.60, -0.05, 0.30, 0.40],
+    [-0.40, -0.30, 0.20, 0.28, -0.30, 0.30],   # arm rests
+    [0.30, 0.40, 0.20, 0.28, -0.30, 0.30],
+    [-0.40, -0.30, 0.05, 0.20, 0.20, 0.30],    # arm supports
+    [0.30, 0.40, 0.05, 0.20, 0.20, 0.30],
+], dtype=np.float64) * 1.4  # the blender-synthetic chair at scale 0.8 spans roughly +-0.8 of the bound-1 box
+
+
+def chair_solid(p, margin=0.0, boxes=CHAIR_BOXES):
+    """Boolean inside-test for points p [...,3] against the box union grown by `margin`."""
+    p = np.asarray(p, np.float64)
+    inside = np.zeros(p.shape[:-1], bool)
+    for b in boxes:
+        inside |= ((p[..., 0] >= b[0] - margin) & (p[..., 0] <= b[1] + margin) & (p[..., 1] >= b[2] - margin) & (p[..., 1] <= b[3] + margin)
+                   & (p[..., 2] >= b[4] - margin) & (p[..., 2] <= b[5] + margin))
+    return inside
+
+
+def make_chair_points(sub_res=60, bound=1.0, lam=1e6, mu=1e6, density=1e3, pin_height=0.05, boxes=CHAIR_BOXES, hgs=0.06):
+    """Lattice point cloud like main_sample.py's uniform stage (main_sample.py:214-223): centres of a
+    sub_res^3 lattice over [-bound,bound]^3 that fall inside the solid.  vp = hgs^3 / count_in_cell
+    (main_sample.py:181-200); mass = density * vp (README.md:106-108); pin = lowest `pin_height` of the solid."""
+    h = 2.0 * bound / sub_res
+    c = -bound + (np.arange(sub_res) + 0.5) * h
+    X, Y, Z = np.meshgrid(c, c, c, indexing="ij")
+    pts = np.stack([X, Y, Z], -1).reshape(-1, 3)
+    pts = pts[chair_solid(pts, boxes=boxes)]
+    cell = np.floor((pts + bound) / hgs).astype(np.int64)
+    key = (cell[:, 0] * 100003 + cell[:, 1]) * 100003 + cell[:, 2]
+    _, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+    vp = hgs ** 3 / cnt[inv]
+    ymin = boxes[:, 2].min()
+    return dict(pos=pts, vp=vp, mass=density * vp, mu=np.full(len(pts), mu), lam=np.full(len(pts), lam),
+                pin=(pts[:, 1] < ymin + pin_height).astype(np.int32))
+
+
+# ------------------------------------------------------------------ PLY
+_PLY_PROPS = [("x", "f8"), ("y", "f8"), ("z", "f8"), ("mass", "f8"), ("mu", "f8"), ("lam", "f8"), ("pin", "i4")]
+_PLY_TYPES = {"f8": "double", "f4": "float", "i4": "int", "u1": "uchar", "i2": "short", "u2": "ushort", "u4": "uint", "i1": "char"}
+_PLY_NAMES = {"double": "f8", "float64": "f8", "float": "f4", "float32": "f4", "int": "i4", "int32": "i4", "uchar": "u1", "uint8": "u1",
+              "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2", "uint": "u4", "uint32": "u4", "char": "i1", "int8": "i1"}
+
+
+def write_ply(path, cloud, binary=True):
+    """Vertex-only PLY with the simulator's attributes (solver.py:116-135)."""
+    n = len(cloud["pos"])
+    rec = np.zeros(n, dtype=[(k, "<" + t) for k, t in _PLY_PROPS])
+    rec["x"], rec["y"], rec["z"] = cloud["pos"][:, 0], cloud["pos"][:, 1], cloud["pos"][:, 2]
+    for k in ("mass", "mu", "lam", "pin"):
+        rec[k] = cloud[k]
+    hdr = ["ply", "format binary_little_endian 1.0" if binary else "format ascii 1.0", f"element vertex {n}"]
+    hdr += [f"property {_PLY_TYPES[t]} {k}" for k, t in _PLY_PROPS] + ["end_header"]
+    with open(path, "wb") as f:
+        f.write(("\n".join(hdr) + "\n").encode())
+        if binary:
+            f.write(rec.tobytes())
+        else:
+            for r in rec:
+                f.write((" ".join(repr(float(v)) if isinstance(v, np.floating) else str(int(v)) for v in r) + "\n").encode())
+
+
+def read_ply(path):
+    """Reads the first (vertex) element of an ascii / binary_little_endian PLY into a dict of columns."""
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"ply", "not a PLY file"
+        fmt, n, props, in_vertex = None, 0, [], False
+        while True:
+            line = f.readline().decode().strip()
+            if line == "end_header":
+                break
+            tok = line.split()
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                in_vertex = (n == 0 and not props)  # only the first element is read (plydata.elements[0])
+                if in_vertex:
+                    n = int(tok[2])
+            elif tok[0] == "property" and in_vertex:
+                assert tok[1] != "list", "list properties are not supported"
+                props.append((tok[2], _PLY_NAMES[tok[1]]))
+        if fmt == "ascii":
+            rows = [f.readline().split() for _ in range(n)]
+            cols = {k: np.array([r[i] for r in rows], dtype=np.float64).astype(t) for i, (k, t) in enumerate(props)}
+        elif fmt == "binary_little_endian":
+            rec = np.frombuffer(f.read(n * sum(np.dtype(t).itemsize for _, t in props)), dtype=[(k, "<" + t) for k, t in props], count=n)
+            cols = {k: np.array(rec[k]) for k, _ in props}
+        else:
+            raise ValueError(f"unsupported PLY format {fmt}")
+    return cols
+
+
+def cloud_from_ply(path):
+    c = read_ply(path)
+    return dict(pos=np.stack([c["x"], c["y"], c["z"]], 1).astype(np.float64), mass=c["mass"].astype(np.float64), mu=c["mu"].astype(np.float64),
+                lam=c["lam"].astype(np.float64), pin=c["pin"].astype(bool))
+
+
+# ------------------------------------------------------------------ checkpoint
+def _expand_bits(v):
+    v = (v * 0x00010001) & 0xFF0000FF
+    v = (v * 0x00000101) & 0x0F00F00F
+    v = (v * 0x00000011) & 0xC30C30C3
+    v = (v * 0x00000005) & 0x49249249
+    return v
+
+
+def morton3D(x, y, z):
+    x, y, z = (np.asarray(a, np.uint64) for a in (x, y, z))
+    return (_expand_bits(x) | (_expand_bits(y) << np.uint64(1)) | (_expand_bits(z) << np.uint64(2))).astype(np.uint32)
+
+
+def hashgrid_offsets(bound=1.0, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, input_dim=3):
+    """gridencoder/grid.py:96-134 with desired_resolution = 2048*bound (nerf/network.py:35)."""
+    per_level_scale = np.exp2(np.log2(2048 * bound / base_resolution) / (num_levels - 1))
+    offsets, offset = [], 0
+    for i in range(num_levels):
+        res = int(np.ceil(base_resolution * per_level_scale ** i))
+        n = min(2 ** log2_hashmap_size, (res + 1) ** input_dim)
+        n = int(np.ceil(n / 8) * 8)
+        offsets.append(offset)
+        offset += n
+    offsets.append(offset)
+    return np.array(offsets, np.int32), float(per_level_scale)
+
+
+def make_density_bitfield(bound=1.0, grid_size=128, solid=chair_solid):
+    """cascade x grid_size^3 occupancy bits in morton order (bit i%8 of byte i/8).  Level c covers
+    [-min(2^c,bound), +...]^3 (raymarching.cu:1389-1396).  A cell is occupied when its centre is inside the
+    solid grown by half a cell diagonal-ish margin (trained density grids are slightly fat)."""
+    cascade = 1 + math.ceil(math.log2(bound))
+    H = grid_size
+    bits = np.zeros(cascade * H ** 3 // 8, np.uint8)
+    idx = np.arange(H)
+    X, Y, Z = np.meshgrid(idx, idx, idx, indexing="ij")
+    mort = morton3D(X.ravel(), Y.ravel(), Z.ravel()).astype(np.int64)
+    for c in range(cascade):
+        mb = min(2.0 ** c, bound)
+        cs = 2.0 * mb / H
+        ctr = (np.stack([X, Y, Z], -1).reshape(-1, 3) + 0.5) * cs - mb
+        occ = solid(ctr, margin=cs)
+        lin = c * H ** 3 + mort[occ]
+        np.bitwise_or.at(bits, lin // 8, (1 << (lin % 8)).astype(np.uint8))
+    return bits, cascade
+
+
+def make_checkpoint(bound=1.0, seed=0, sigma_target=60.0, grid_size=128, solid=chair_solid):
+    """Random-init network of the reference architecture with an analytically calibrated density:
+
+    feature 0 (level 0, channel 0) is the constant 0.5 (level 0 is dense, so trilinear interpolation
+    returns it everywhere), hidden unit 0 = ReLU(2 * 0.5) = 1 and sigma_net[1].weight[0,0] = ln(sigma_target),
+    so sigma = sigma_target * exp(small random term) — median ~ sigma_target without a forward pass.
+    """
+    rng = np.random.default_rng(seed)
+    offsets, pls = hashgrid_offsets(bound)
+    n = int(offsets[-1])
+    emb = rng.uniform(-0.5, 0.5, size=(n, 2)).astype(np.float32)
+    emb[offsets[0]:offsets[1], 0] = 0.5
+
+    def w(o, i):
+        return (rng.standard_normal((o, i)) * math.sqrt(2.0 / i)).astype(np.float32)
+
+    W0, W1, W2, W3, W4 = w(64, 32), w(16, 64), w(64, 31), w(64, 64), w(3, 64)
+    W0[0, :] = 0.0
+    W0[0, 0] = 2.0
+    W1[0, :] *= 0.25
+    W1[0, 0] = math.log(sigma_target)
+    bits, cascade = make_density_bitfield(bound, grid_size, solid)
+    return dict(embeddings=emb, offsets=offsets, per_level_scale=pls, base_resolution=16, W0=W0, W1=W1, W2=W2, W3=W3, W4=W4,
+                density_bitfield=bits, cascade=cascade, grid_size=grid_size, bound=float(bound), min_near=0.2, density_scale=1.0)
+
+
+# ------------------------------------------------------------------ camera
+def orbit_pose(radius=5.0, azimuth_deg=0.0, elevation_deg=0.0, center=(0.0, 0.0, 0.0)):
+    """OrbitCamera.pose (nerf/gui.py:29-39) for rot = R_y(az) R_x(el) * from_quat([1,0,0,0])."""
+    res = np.eye(4, dtype=np.float32)
+    res[2, 3] -= radius
+    base = np.diag([1.0, -1.0, -1.0])
+    az, el = math.radians(azimuth_deg), math.radians(elevation_deg)
+    Ry = np.array([[math.cos(az), 0, math.sin(az)], [0, 1, 0], [-math.sin(az), 0, math.cos(az)]])
+    Rx = np.array([[1, 0, 0], [0, math.cos(el), -math.sin(el)], [0, math.sin(el), math.cos(el)]])
+    rot = np.eye(4, dtype=np.float32)
+    rot[:3, :3] = (Ry @ Rx @ base).astype(np.float32)
+    res = rot @ res
+    res[:3, 3] -= np.asarray(center, np.float32)
+    return res.astype(np.float32)
+
+
+def orbit_intrinsics(W, H, fovy=50.0):
+    """OrbitCamera.intrinsics (nerf/gui.py:41-44)."""
+    focal = H / (2 * np.tan(np.radians(fovy) / 2))
+    return np.array([focal, focal, W // 2, H // 2], dtype=np.float64)
+
+
+# ------------------------------------------------------------------ options
+def default_opt(**over):
+    """The option names render_deformed / Simulator read (get_opts.py), chair-demo values (README.md:123)."""
+    opt = dict(bound=1.0, scale=0.8, dt_gamma=0.0, W=800, H=800, max_steps=1024, T_thresh=1e-2, min_near=0.2, density_thresh=10, bg_radius=-1,
+               radius=5.0, fovy=50.0, max_iter_num=1, num_seek_IP=3, sim_dt=1e-2, sim_dx=0.05, sim_iters=10, sim_stiff=1e5, cut=False,
+               cut_bounds=[0.0, 2.0, -2.0, 1.0, -1.42, 0.92], timing_on=False)
+    opt.update(over)
+    opt["hash_grid_size"] = 1.2 * opt["sim_dx"]
+    opt["num_seek_IP"] = max(min(3, opt["num_seek_IP"]), 1)
+    return opt

@@ -1,0 +1,210 @@
+"""``Simulator`` with the reference's public surface (simulator/solver.py:12-617, /root/reference).
+
+Kept: constructor arguments, ``InitializeFromPly``, ``get_IP_info`` (fp32, permuted layouts of solver.py:422-424),
+``stepforward`` (+ alias ``step``), ``update_force`` / ``clear_force``, ``OutputToPly``, attributes ``dx``, ``IP_pos``,
+``dof`` ... as torch tensors on the GPU.  Changed on purpose:
+  * the per-substep work is HIP (libpienerf_hip.so: pn_sim_stepforward / pn_sim_update_F / pn_sim_update_force);
+  * ``global_matrix`` / ``mass_matrix_invt2`` are stored in their kron(A, I3) factor form ``Ainv`` / ``Mmat``
+    ([10 n_k]^2 instead of [30 n_k]^2, solver.py:493-496,532-538) — same products, 9x fewer bytes;
+  * importing this module does not call ``torch.set_default_device("cuda")`` (func_utils.py:6).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import scene
+from .._lib import check, lib, ptr, stream_ptr
+from . import gmls
+
+torchfloat = torch.float64
+npfloat = np.float64
+
+
+class Simulator:
+    def __init__(self, dt=1e-2, iters=20, bbox=torch.tensor([1.0, 1.0, 1.0], dtype=torchfloat), kres=7, dx=1,
+                 gravity=torch.tensor([0.0, -9.8, 0.0], dtype=torchfloat), stiff=1e5, base=torch.tensor([-0.5, -0.5, -0.5], dtype=torchfloat),
+                 device="cuda"):
+        self.device = torch.device(device)
+        bbox = bbox.clone() * 1.02   # solver.py:24-25 multiply in the caller's dtype (main_gui.py passes float32), then widen
+        base = base.clone() * 1.01
+        self.dt, self.iters, self.dx, self.kres, self.stiff = dt, iters, dx, kres, stiff
+        bbox = bbox.to(dtype=torchfloat)
+        self.res = (bbox // dx).to(dtype=torch.int32).to(self.device)
+        self.base = base.to(dtype=torchfloat).to(self.device)
+        self.gravity = gravity.to(dtype=torchfloat).to(self.device)
+        self.dof = None
+        self._work = None
+
+    # ------------------------------------------------------------------ IO (solver.py:109-137)
+    def InitializeFromPly(self, path):
+        c = scene.cloud_from_ply(path)
+        self.InitializeFromArrays(c["pos"], c["mass"], c["mu"], c["lam"], c["pin"])
+
+    def InitializeFromArrays(self, pos, mass, mu, lam, pin):
+        dev = self.device
+        self.pos = torch.from_numpy(np.asarray(pos, npfloat)).to(dev)
+        assert self.pos.shape[0] > 0
+        self.mass = torch.from_numpy(np.asarray(mass, npfloat)).to(dev)
+        self.mu = torch.from_numpy(np.asarray(mu, npfloat)).to(dev)
+        self.lam = torch.from_numpy(np.asarray(lam, npfloat)).to(dev)
+        self.is_pin = torch.from_numpy(np.asarray(pin).astype(bool)).to(dev)
+        self.initialize()
+
+    def OutputToPly(self, path):
+        p = self.update_pos().cpu().numpy().astype(np.float64)
+        n = p.shape[0]
+        scene.write_ply(path, dict(pos=p, mass=np.zeros(n), mu=np.zeros(n), lam=np.zeros(n), pin=np.zeros(n, np.int32)))
+
+    # ------------------------------------------------------------------ init (solver.py:139-331)
+    def initialize(self):
+        self.precompute()
+        self._work = torch.empty(int(lib().pn_sim_work_doubles(self.n_k, self.n_IP)), dtype=torchfloat, device=self.device)
+        self.rhs_rest = (self.build_rhs() + self._matvec(self.Mmat, self.dof)).contiguous()   # solver.py:314
+
+    def precompute(self):
+        """Everything of initialize() that is tensor bookkeeping / torch.linalg (device-agnostic); the HIP-backed rest
+        state (rhs_rest) is finished by initialize()."""
+        dev, res, kres = self.device, self.res, self.kres
+        r0, r1, r2 = (int(v) for v in res.cpu())
+        self.grid_idx = ((self.pos - self.base) // self.dx).to(dtype=torch.int32).long()
+        gi = self.grid_idx
+        self.IP_mask = torch.zeros((r0, r1, r2), dtype=torch.bool, device=dev)
+        self.IP_mask[gi[:, 0], gi[:, 1], gi[:, 2]] = True
+        n_IP = int(self.IP_mask.sum())
+        self.IP_idx = -torch.ones((r0, r1, r2), dtype=torch.int32, device=dev)
+        self.IP_idx[self.IP_mask] = torch.arange(0, n_IP, 1, dtype=torch.int32, device=dev)
+        self.pts_IP = self.IP_idx[gi[:, 0], gi[:, 1], gi[:, 2]]
+        # kornia.create_meshgrid3d + channel swap (solver.py:162-169) == grid[i,j,k] = (i,j,k)
+        ax = [torch.arange(r, dtype=torch.int32, device=dev) for r in (r0, r1, r2)]
+        cell_ijk = torch.stack(torch.meshgrid(*ax, indexing="ij"), dim=-1)
+        self.IP_grid = cell_ijk[self.IP_mask, :]
+        self.IP_pos = (self.IP_grid + 0.5) * self.dx + self.base          # float32 product, then float64 sum (:177)
+        self.kernel_mask = torch.zeros((kres, kres, kres), dtype=torch.bool, device=dev)
+        self.kdx = ((res.max()) * self.dx) / (kres - 1)                  # 0-dim float32 tensor (:184)
+        IP2K = ((self.IP_pos - self.base) // self.kdx).to(dtype=torch.int32).long()
+        corners = [(S >> 2 & 1, S >> 1 & 1, S & 1) for S in range(8)]
+        for x, y, z in corners:
+            self.kernel_mask[IP2K[:, 0] + x, IP2K[:, 1] + y, IP2K[:, 2] + z] |= True
+        n_k = int(self.kernel_mask.sum())
+        self.kernel_idx = torch.zeros((kres, kres, kres), dtype=torch.int32, device=dev)
+        self.kernel_idx[self.kernel_mask] = torch.arange(0, n_k, 1, dtype=torch.int32, device=dev)
+        pts2K = ((self.pos - self.base) // self.kdx).to(dtype=torch.int32).long()
+        self.IP_kernel = torch.stack([self.kernel_idx[IP2K[:, 0] + x, IP2K[:, 1] + y, IP2K[:, 2] + z] for x, y, z in corners], dim=1).contiguous()
+        self.pts_kernel = torch.stack([self.kernel_idx[pts2K[:, 0] + x, pts2K[:, 1] + y, pts2K[:, 2] + z] for x, y, z in corners], dim=1).contiguous()
+        ka = torch.arange(kres, dtype=torch.int32, device=dev)
+        self.kernel_grid = torch.stack(torch.meshgrid(ka, ka, ka, indexing="ij"), dim=-1)[self.kernel_mask, :]
+        self.kernel_pos = self.kernel_grid * self.kdx + self.base       # float32 product, then float64 sum (:248)
+        self.n_k, self.n_IP = n_k, n_IP
+
+        kdx = float(self.kdx)
+        self.pts_Nx, self.pts_dNx, self.pts_ddNx = gmls.init_GMLS(kdx, self.pos, self.pts_kernel, self.kernel_pos)
+        self.IP_Nx, self.IP_dNx, self.IP_ddNx = gmls.init_GMLS(kdx, self.IP_pos, self.IP_kernel, self.kernel_pos)
+        self.IP_mu, self.IP_lam, self.IP_rho = self.collect_IP()
+        self.build_global()
+
+        # rest state: translation = kernel position, affine = identity, quadratic = 0 (solver.py:258-275)
+        dof = torch.zeros((n_k, 10, 3), dtype=torchfloat, device=dev)
+        dof[:, 0, :] = self.kernel_pos
+        for x in range(3):
+            dof[:, 1 + x, x] = 1.0
+        self.dof = dof.reshape(-1).contiguous()
+        self.dof_tilde = self.dof.clone()
+        self.dof_rest = self.dof.clone()
+        self.dof_vel = torch.zeros_like(self.dof)
+        self.dof_f = torch.zeros_like(self.dof)
+
+        # per-kernel CSR of (IP, neighbour slot) pairs (count_IP_kernel / allocate_IP_kernel, solver.py:277-313), in ascending order
+        keys = self.IP_kernel.reshape(-1).long()
+        order = torch.sort(keys, stable=True).indices
+        self.buffer = order.to(torch.int32).contiguous()                 # entry = vid*8 + dir
+        self.kernel_cnt = torch.bincount(keys, minlength=n_k).to(torch.int32).contiguous()
+        self.kernel_bg = (torch.cumsum(self.kernel_cnt, dim=0, dtype=torch.int32) - self.kernel_cnt).contiguous()
+        self.tot = int(self.kernel_cnt.sum())
+
+        m = (self.IP_rho * self.dx * self.dx * self.dx)                                      # collect_gravity, cuda_utils.py:262-279
+        rg = torch.zeros((n_k * 10, 3), dtype=torchfloat, device=dev)
+        rows = (self.IP_kernel.long()[:, :, None] * 10 + torch.arange(10, device=dev)[None, None, :]).reshape(-1)
+        rg.index_add_(0, rows, (m[:, None, None] * self.IP_Nx).reshape(-1)[:, None] * self.gravity[None, :])
+        self.rhs_gravity = rg.reshape(-1).contiguous()
+
+    def collect_IP(self):  # solver.py:427-450
+        n_IP, idx = self.n_IP, self.pts_IP.long()
+        z = torch.zeros(n_IP, dtype=torchfloat, device=self.device)
+        s_mu = z.clone().index_add_(0, idx, self.mu * self.mass)
+        s_lam = z.clone().index_add_(0, idx, self.lam * self.mass)
+        s_m = z.clone().index_add_(0, idx, self.mass)
+        return (s_mu / s_m).contiguous(), (s_lam / s_m).contiguous(), (s_m / (self.dx ** 3)).contiguous()
+
+    def build_global(self):  # solver.py:453-538
+        dim = self.n_k * 10
+        mat = gmls.assemble_IP_matrix(dim, self.dx, self.dt, self.IP_kernel, self.IP_mu, self.IP_lam, self.IP_rho, self.IP_Nx, self.IP_dNx, self.IP_ddNx)
+        assert self.pts_kernel.min() >= 0 and self.pts_kernel.max() < self.n_k
+        vid = torch.nonzero(self.is_pin).reshape(-1)
+        mat = gmls.add_pin_penalty(mat, self.stiff, vid, self.pts_kernel, self.pts_Nx)
+        diag = mat.diagonal()[0::10]
+        self.active_kernels = torch.nonzero(diag > 0.0).reshape(-1)                      # `global_matrix[i*30, i*30] > 0` (:499-504)
+        lst = (self.active_kernels[:, None] * 10 + torch.arange(10, device=self.device)[None, :]).reshape(-1)
+        sub = mat[lst][:, lst].clone()
+        sub.diagonal().add_(1e-3)                                                         # :507
+        inv = gmls.inverse_spd(sub)
+        self.Ainv = torch.zeros((dim, dim), dtype=torchfloat, device=self.device)
+        self.Ainv[lst[:, None], lst[None, :]] = inv
+        self.Ainv = self.Ainv.contiguous()
+        zero = torch.zeros_like(self.IP_mu)
+        self.Mmat = gmls.assemble_IP_matrix(dim, self.dx, self.dt, self.IP_kernel, zero, zero, self.IP_rho, self.IP_Nx, self.IP_dNx, self.IP_ddNx).contiguous()
+
+    # the reference's (30 n_k)^2 forms, materialised on demand (tests / interop only)
+    @property
+    def global_matrix(self):
+        return torch.kron(self.Ainv, torch.eye(3, dtype=torchfloat, device=self.device))
+
+    @property
+    def mass_matrix_invt2(self):
+        return torch.kron(self.Mmat, torch.eye(3, dtype=torchfloat, device=self.device))
+
+    # ------------------------------------------------------------------ per-frame (HIP)
+    def _matvec(self, A, x):
+        y = torch.empty_like(x)
+        check(lib().pn_sim_matvec3(A.shape[0], ptr(A), ptr(x), ptr(y), stream_ptr()), "sim_matvec3")
+        return y
+
+    def build_rhs(self):  # solver.py:541-571
+        n = self.n_IP
+        RF = torch.empty((n, 3, 3), dtype=torchfloat, device=self.device)
+        VF = torch.empty_like(RF)
+        check(lib().pn_sim_calc_elastic(n, ptr(self.IP_kernel), ptr(self.IP_dNx), ptr(self.dof), ptr(RF), ptr(VF), None, stream_ptr()), "calc_elastic")
+        rhs = torch.empty_like(self.dof)
+        check(lib().pn_sim_collect_rhs(self.n_k, float(self.dx), ptr(self.kernel_bg), ptr(self.kernel_cnt), ptr(self.buffer), ptr(self.IP_mu),
+                                       ptr(self.IP_lam), ptr(self.IP_dNx), ptr(RF), ptr(VF), ptr(rhs), stream_ptr()), "collect_rhs")
+        return rhs
+
+    def get_IP_info(self):  # solver.py:402-424
+        n, dev = self.n_IP, self.device
+        pos = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        F = torch.empty((n, 9), dtype=torch.float32, device=dev)
+        dF = torch.empty((n, 27), dtype=torch.float32, device=dev)
+        check(lib().pn_sim_update_F(n, ptr(self.IP_kernel), ptr(self.dof), ptr(self.IP_Nx), ptr(self.IP_dNx), ptr(self.IP_ddNx), ptr(pos), ptr(F),
+                                    ptr(dF), stream_ptr()), "update_F")
+        return pos, F, dF
+
+    def stepforward(self):  # solver.py:595-602
+        check(lib().pn_sim_stepforward(self.n_k, self.n_IP, int(self.iters), float(self.dt), float(self.dx), ptr(self.IP_kernel), ptr(self.kernel_bg),
+                                       ptr(self.kernel_cnt), ptr(self.buffer), ptr(self.IP_mu), ptr(self.IP_lam), ptr(self.IP_dNx), ptr(self.Ainv),
+                                       ptr(self.Mmat), ptr(self.dof_rest), ptr(self.rhs_rest), ptr(self.rhs_gravity), ptr(self.dof_f), ptr(self.dof),
+                                       ptr(self.dof_vel), ptr(self._work), stream_ptr()), "stepforward")
+
+    step = stepforward  # BASELINE.json's name for the same entry point
+
+    def update_force(self, vid, f):  # solver.py:578-588
+        f3 = np.ascontiguousarray(f.detach().cpu().numpy() if torch.is_tensor(f) else f, dtype=np.float64)
+        check(lib().pn_sim_update_force(self.n_k, int(vid), f3.ctypes.data, float(self.dx), ptr(self.IP_kernel), ptr(self.IP_rho), ptr(self.IP_Nx),
+                                        ptr(self.dof_f), stream_ptr()), "update_force")
+
+    def clear_force(self):  # solver.py:590-593
+        self.dof_f.zero_()
+
+    def update_pos(self):  # solver.py:604-617 (update_pos_kernel) — only used by OutputToPly
+        d = self.dof.view(self.n_k, 10, 3)[self.pts_kernel.long()]
+        self.pos = torch.einsum("nic,nicr->nr", self.pts_Nx, d)
+        return self.pos
