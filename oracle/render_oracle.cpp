@@ -406,7 +406,10 @@ void grid_one(const float* in3, const float* table /*level base*/, uint32_t hash
     float pos[3];
     uint32_t pg[3];
     for (int d = 0; d < 3; d++) {
-        pos[d] = in3[d] * scale + (align_corners ? 0.0f : 0.5f);
+        // single-rounding multiply-add: nvcc's default -fmad=true contracts `inputs[d] * scale + 0.5f` (gridencoder.cu:143)
+        // and at fine levels (pos ~ 2000, ulp 1.2e-4) the choice moves the interpolation weights, so it is made explicit
+        // here and in the HIP kernels.
+        pos[d] = fmaf(in3[d], scale, align_corners ? 0.0f : 0.5f);
         pg[d] = (uint32_t)floorf(pos[d]);
         pos[d] -= (float)pg[d];
         if (interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);

@@ -58,6 +58,10 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m pienerf_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+        # One HIP runtime per process: torch ships its own libamdhip64.so.7 and device memory / streams come from torch, so
+        # torch must be loaded first — the library's NEEDED libamdhip64.so.7 then binds to that already-loaded copy instead of
+        # pulling in /opt/rocm's second runtime (which would see "no ROCm-capable device").
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)  # AttributeError if the symbol is not exported

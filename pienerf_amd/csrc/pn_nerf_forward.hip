@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256) k_grid_encode(const float* __restrict__ i
     uint32_t pg[3];
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        pos[d] = pos[d] * scale + (align_corners ? 0.0f : 0.5f);
+        pos[d] = fmaf(pos[d], scale, align_corners ? 0.0f : 0.5f);  // explicit single rounding, as in the oracle
         pg[d] = (uint32_t)floorf(pos[d]);
         pos[d] -= (float)pg[d];
         if (interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
@@ -261,7 +261,7 @@ __device__ __forceinline__ void encode8(const PnGridLevels& lv, const float* __r
         const float scale = lv.scale[level];
         const LevelIdx LI = level_idx(lv, level, 0);
         const float2* __restrict__ table = reinterpret_cast<const float2*>(emb) + lv.offset[level];
-        float p0 = u0 * scale + 0.5f, p1 = u1 * scale + 0.5f, p2 = u2 * scale + 0.5f;
+        float p0 = fmaf(u0, scale, 0.5f), p1 = fmaf(u1, scale, 0.5f), p2 = fmaf(u2, scale, 0.5f);
         const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
         const uint32_t g0 = (uint32_t)f0, g1 = (uint32_t)f1, g2 = (uint32_t)f2;
         p0 -= f0; p1 -= f1; p2 -= f2;

@@ -64,7 +64,7 @@ def test_pnts_in_grids_bit_exact(deformed_ip_state, small_opt):
 
 
 # ------------------------------------------------------------------------------------------------ march
-def _march_inputs(ip, opt, ck, W=40, az=25.0, el=-15.0):
+def _march_inputs(ip, opt, ck, W=72, az=25.0, el=-15.0):
     pose = scene.orbit_pose(5.0, az, el)
     intr = scene.orbit_intrinsics(W, W, 50.0)
     o, d = oracle.get_rays(pose, intr, W, W)
