@@ -111,6 +111,15 @@ def march_rays_quadratic_bending(pig_cnt, pig_bgn, pig_idx, n_vtx, n_grid, p_def
     return xyzs, dirs, deltas
 
 
+def warp_point(x, p_ori, p_def, F9, dF27, max_iter_num, IP_dx):
+    """Per-IP Newton inverse warp (raymarching.cu:1262-1324). Returns (rest point [3], rejected flag)."""
+    x, p_ori, p_def, F9, dF27 = _f32(x), _f32(p_ori), _f32(p_def), _f32(F9), _f32(dF27)
+    out = np.empty(3, np.float32)
+    lib().orc_warp_point.restype = I
+    rej = lib().orc_warp_point(_p(x, F), _p(p_ori, F), _p(p_def, F), _p(F9, F), _p(dF27, F), I(max_iter_num), F(IP_dx), _p(out, F))
+    return out, bool(rej)
+
+
 def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh=1e-2):
     """In place on rays_alive, rays_t, weights_sum, depth, image (all must be contiguous numpy arrays of the right dtype)."""
     for a, ty in ((rays_alive, np.int32), (rays_t, np.float32), (weights_sum, np.float32), (depth, np.float32), (image, np.float32)):

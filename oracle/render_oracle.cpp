@@ -171,6 +171,36 @@ int find_closest_IPs(float x, float y, float z, const float* p_def, const Pig& p
     return found;
 }
 
+// Per-IP Newton inverse warp, raymarching.cu:1262-1324: solve F q + 1/2 (dF.q) q = q' for q = p - p_ori, q' = x - p_def,
+// starting at p = p_ori, at most max_iter_num updates, stopping when |dq|^2 < 1e-12 (checked after the update).
+// Returns true when the result is further than IP_dx (inf-norm) from p_ori — the caller then decrements n_IP.
+bool newton_warp(const float* x3, const float* pk, const float* pk_, const float* Fk, const float* dFk, int max_iter_num, float IP_dx, float* p) {
+    p[0] = pk[0]; p[1] = pk[1]; p[2] = pk[2];
+    int num_itr = 0;
+    const float q_[3] = {x3[0] - pk_[0], x3[1] - pk_[1], x3[2] - pk_[2]};
+    while (num_itr < max_iter_num) {
+        const float q[3] = {p[0] - pk[0], p[1] - pk[1], p[2] - pk[2]};
+        float dFk_q[9];
+        dot31(dFk, q, dFk_q);
+        float A[9];
+        for (int j = 0; j < 9; j++) A[j] = Fk[j] + dFk_q[j];
+        float A_inv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        inv3x3(A, A_inv);  // quirk R7q-ii: failure is never acted on; A_inv stays 0 (:1285-1287)
+        float Fk_q[3], dFk_q_q[3], b[3], dq[3];
+        mul31(Fk, q, Fk_q);
+        mul31(dFk_q, q, dFk_q_q);
+        for (int i = 0; i < 3; i++) b[i] = (float)(((double)Fk_q[i] + 0.5 * (double)dFk_q_q[i]) - (double)q_[i]);
+        mul31(A_inv, b, dq);
+        p[0] -= dq[0];
+        p[1] -= dq[1];
+        p[2] -= dq[2];
+        if ((double)(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2]) < 1e-12) break;
+        num_itr++;
+    }
+    const float e0 = p[0] - pk[0], e1 = p[1] - pk[1], e2 = p[2] - pk[2];
+    return fabsf(e0) > IP_dx || fabsf(e1) > IP_dx || fabsf(e2) > IP_dx;
+}
+
 struct MarchArgs {
     Pig pg;
     int n_vtx;
@@ -257,34 +287,10 @@ uint32_t march_one(const MarchArgs& a, int index, float noise, float* xyzs, floa
                 const float p_[3] = {x, y, z};
                 float ps[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
                 for (int k = 0; k < n_IP; k++) {
-                    const float* pk = &a.p_ori[IPs[k] * 3];
-                    const float* pk_ = &a.p_def[IPs[k] * 3];
-                    const float* Fk = &a.F_IP[IPs[k] * 9];
-                    const float* dFk = &a.dF_IP[IPs[k] * 27];
-                    float p[3] = {pk[0], pk[1], pk[2]};
-                    int num_itr = 0;
-                    const float q_[3] = {p_[0] - pk_[0], p_[1] - pk_[1], p_[2] - pk_[2]};
-                    while (num_itr < a.max_iter_num) {
-                        const float q[3] = {p[0] - pk[0], p[1] - pk[1], p[2] - pk[2]};
-                        float dFk_q[9];
-                        dot31(dFk, q, dFk_q);
-                        float A[9];
-                        for (int j = 0; j < 9; j++) A[j] = Fk[j] + dFk_q[j];
-                        float A_inv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                        inv3x3(A, A_inv);  // quirk R7q-ii: failure is never acted on; A_inv stays 0 (:1285-1287)
-                        float Fk_q[3], dFk_q_q[3], b[3], dq[3];
-                        mul31(Fk, q, Fk_q);
-                        mul31(dFk_q, q, dFk_q_q);
-                        for (int i = 0; i < 3; i++) b[i] = (float)(((double)Fk_q[i] + 0.5 * (double)dFk_q_q[i]) - (double)q_[i]);
-                        mul31(A_inv, b, dq);
-                        p[0] -= dq[0];
-                        p[1] -= dq[1];
-                        p[2] -= dq[2];
-                        if ((double)(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2]) < 1e-12) break;
-                        num_itr++;
-                    }
-                    const float e0 = p[0] - pk[0], e1 = p[1] - pk[1], e2 = p[2] - pk[2];
-                    if (fabsf(e0) > a.IP_dx || fabsf(e1) > a.IP_dx || fabsf(e2) > a.IP_dx) n_IP--;  // quirk R7q-iii (:1316-1319)
+                    float p[3];
+                    const bool reject = newton_warp(p_, &a.p_ori[IPs[k] * 3], &a.p_def[IPs[k] * 3], &a.F_IP[IPs[k] * 9], &a.dF_IP[IPs[k] * 27],
+                                                    a.max_iter_num, a.IP_dx, p);
+                    if (reject) n_IP--;  // quirk R7q-iii (:1316-1319)
                     ps[3 * k] = p[0];
                     ps[3 * k + 1] = p[1];
                     ps[3 * k + 2] = p[2];
@@ -750,6 +756,13 @@ int orc_render_deformed(const float* rays_o, const float* rays_d, uint32_t N, co
     }
     if (stats) { stats[0] = trips; stats[1] = emitted; stats[2] = slots; }
     return trips;
+}
+
+// Test hook: the per-IP Newton inverse warp used by the march (same function), for one deformed point and one IP.
+// out[0..2] = rest-space point; returns 1 when the IP would be rejected (|p - p_ori|_inf > IP_dx).
+int orc_warp_point(const float* x3, const float* p_ori, const float* p_def, const float* F9, const float* dF27, int max_iter_num, float IP_dx,
+                   float* out) {
+    return newton_warp(x3, p_ori, p_def, F9, dF27, max_iter_num, IP_dx, out) ? 1 : 0;
 }
 
 int orc_num_threads(void) {

@@ -1,0 +1,143 @@
+"""Host-side logic and the C-ABI surface, on CPU (no kernel is launched here)."""
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, make_oracle_sim, rel_err
+from pienerf_amd import scene
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pienerf_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pn_[A-Za-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pienerf_amd import _lib
+    names = _declared_symbols()
+    assert len(names) >= 20
+    h = _lib.lib()  # loads libpienerf_hip.so and resolves every name in SIGNATURES (AttributeError otherwise)
+    for n in names:
+        assert hasattr(h, n), f"{n} is declared in include/pienerf_hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == names
+    assert b"gfx950" in h.pn_version()
+    assert h.pn_compact_scratch_ints(1000) >= 4 and h.pn_sim_work_doubles(10, 20) >= 10 * 30 * 4
+
+
+def test_ops_fail_loudly_without_gpu_tensors():
+    from pienerf_amd import gridencoder, raymarching, shencoder
+    with pytest.raises(RuntimeError, match="GPU only"):
+        shencoder.sh_encode(torch.zeros(4, 3), 4)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        gridencoder.grid_encode(torch.zeros(4, 3), torch.zeros(16, 2), torch.tensor([0, 8, 16], dtype=torch.int32), 2.0, 16)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        raymarching.composite_rays(1, 1, torch.zeros(1, dtype=torch.int32), torch.zeros(1), torch.zeros(1), torch.zeros(1, 3), torch.zeros(1, 2),
+                                   torch.zeros(1), torch.zeros(1), torch.zeros(1, 3))
+    with pytest.raises(RuntimeError):
+        shencoder.sh_encode(torch.zeros(4, 3), 4, True)  # no dy_dx on the inference path
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    from pienerf_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under pienerf_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pienerf_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports oracle"
+                assert "liboracle" not in src and "oracle/" not in src.replace("the oracle/", ""), f"{f} references oracle/"
+
+
+def test_ply_round_trip(tmp_path, small_cloud):
+    for binary in (True, False):
+        p = tmp_path / f"c{int(binary)}.ply"
+        scene.write_ply(str(p), small_cloud, binary=binary)
+        back = scene.cloud_from_ply(str(p))
+        assert np.array_equal(back["pos"], small_cloud["pos"]) and np.array_equal(back["mass"], small_cloud["mass"])
+        assert np.array_equal(back["pin"], small_cloud["pin"].astype(bool))
+    assert small_cloud["pin"].sum() > 0 and small_cloud["pin"].sum() < len(small_cloud["pin"]) / 4  # leg tips only
+
+
+def test_scene_generators_are_deterministic(ckpt):
+    c2 = scene.make_checkpoint(bound=1.0, seed=0)
+    for k in ("embeddings", "W0", "W1", "W2", "W3", "W4", "density_bitfield"):
+        assert hashlib.sha1(c2[k].tobytes()).hexdigest() == hashlib.sha1(ckpt[k].tobytes()).hexdigest()
+    assert ckpt["cascade"] == 1 and ckpt["density_bitfield"].shape == (128 ** 3 // 8,)
+    occ = np.unpackbits(ckpt["density_bitfield"]).sum()
+    assert 0.02 < occ / 128 ** 3 < 0.2  # a chair-sized solid in the unit box
+    # occupancy bits are in morton order: the voxel at the seat centre is set, a far corner is not
+    m = scene.morton3D([64], [64], [64])[0]
+    assert (ckpt["density_bitfield"][m // 8] >> (m % 8)) & 1
+    m = scene.morton3D([2], [2], [2])[0]
+    assert not (ckpt["density_bitfield"][m // 8] >> (m % 8)) & 1
+
+
+def test_hashgrid_geometry_matches_encoder_module(ckpt):
+    from pienerf_amd.gridencoder import GridEncoder
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048)
+    assert np.array_equal(enc.offsets.numpy(), ckpt["offsets"]) and abs(enc.per_level_scale - ckpt["per_level_scale"]) < 1e-12
+    assert enc.embeddings.shape == (6119864, 2) and enc.output_dim == 32
+    assert set(enc.state_dict().keys()) == {"offsets", "embeddings"}
+
+
+def test_network_state_dict_keys_match_reference():
+    from pienerf_amd.nerf.network import NeRFNetwork
+    net = NeRFNetwork(encoding="hashgrid", bound=1.0, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1)
+    keys = set(net.state_dict().keys())
+    want = {"aabb_train", "aabb_infer", "density_grid", "density_bitfield", "step_counter", "encoder.offsets", "encoder.embeddings",
+            "sigma_net.0.weight", "sigma_net.1.weight", "color_net.0.weight", "color_net.1.weight", "color_net.2.weight"}
+    assert keys == want
+    assert net.sigma_net[0].weight.shape == (64, 32) and net.sigma_net[1].weight.shape == (16, 64)
+    assert net.color_net[0].weight.shape == (64, 31) and net.color_net[2].weight.shape == (3, 64)
+    assert net.cascade == 1 and net.grid_size == 128
+
+
+def test_default_options_follow_get_opts():
+    o = scene.default_opt()
+    assert abs(o["hash_grid_size"] - 0.06) < 1e-12 and o["W"] == o["H"] == 800 and o["bound"] == 1.0 and o["dt_gamma"] == 0.0  # get_opts.py:96,100-105
+    assert scene.default_opt(num_seek_IP=7)["num_seek_IP"] == 3 and scene.default_opt(num_seek_IP=0)["num_seek_IP"] == 1     # :97,117-120
+
+
+def test_simulator_precompute_matches_oracle_init(small_cloud, small_opt, oracle_sim):
+    """The product's init (torch, matrix-free GMLS formulation) against the oracle's (numpy, explicit matrices)."""
+    from pienerf_amd.simulator.solver import Simulator
+    o = small_opt
+    s = Simulator(dt=o["sim_dt"], iters=o["sim_iters"], bbox=torch.tensor([2.0 * o["bound"]] * 3), dx=o["sim_dx"], stiff=o["sim_stiff"],
+                  base=torch.tensor([-o["bound"]] * 3), device="cpu")
+    c = small_cloud
+    s.pos, s.mass, s.mu, s.lam = (torch.from_numpy(np.asarray(c[k], np.float64)) for k in ("pos", "mass", "mu", "lam"))
+    s.is_pin = torch.from_numpy(c["pin"].astype(bool))
+    s.precompute()
+    r = oracle_sim
+    assert (s.n_IP, s.n_k) == (r.n_IP, r.n_k) and np.array_equal(s.IP_kernel.numpy(), r.IP_kernel.numpy())
+    assert np.array_equal(s.kernel_pos.numpy(), r.kernel_pos.numpy()) and np.array_equal(s.IP_pos.numpy(), r.IP_pos.numpy())
+    for a, b in ((s.IP_Nx, r.IP_Nx), (s.IP_dNx, r.IP_dNx), (s.IP_ddNx, r.IP_ddNx), (s.pts_Nx, r.pts_Nx), (s.Mmat, r.Mmat)):
+        assert rel_err(a.numpy(), b) < 1e-12
+    assert rel_err(s.Ainv.numpy(), r.Ainv) < 1e-8
+    assert rel_err(s.rhs_gravity.numpy().reshape(-1, 3), r.rhs_gravity) < 1e-13
+    assert np.array_equal(s.active_kernels.numpy(), r.active)
+    # CSR of (IP, slot) pairs per kernel: ascending, complete
+    buf, bg, cnt = s.buffer.numpy(), s.kernel_bg.numpy(), s.kernel_cnt.numpy()
+    assert cnt.sum() == 8 * s.n_IP and np.array_equal(np.sort(buf), np.arange(8 * s.n_IP))
+    topo = s.IP_kernel.numpy().reshape(-1)
+    for k in (0, s.n_k // 2, s.n_k - 1):
+        seg = buf[bg[k]:bg[k] + cnt[k]]
+        assert np.all(topo[seg] == k) and np.all(np.diff(seg) > 0)
+    # the reference's (30 n_k)^2 views
+    assert s.global_matrix.shape == (s.n_k * 30, s.n_k * 30)
+    x = torch.randn(s.n_k * 30, dtype=torch.float64)
+    assert torch.allclose(s.global_matrix @ x, (s.Ainv @ x.view(-1, 3)).reshape(-1), atol=1e-9 * float(s.Ainv.abs().max()) * 100)
+    assert s.step == s.stepforward

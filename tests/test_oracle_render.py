@@ -1,0 +1,306 @@
+"""Pins the render half of the CPU oracle with independent maths (the reference ships no tests or golden vectors —
+SURVEY.md §4/§8c — so each check below re-derives the expected value by a different route)."""
+import numpy as np
+import pytest
+
+import oracle
+from pienerf_amd import scene
+
+
+def test_morton_matches_bit_interleave():
+    rng = np.random.default_rng(0)
+    xyz = rng.integers(0, 1024, size=(500, 3))
+    want = np.zeros(500, np.uint32)
+    for b in range(10):
+        for c in range(3):
+            want |= (((xyz[:, c] >> b) & 1) << (3 * b + c)).astype(np.uint32)
+    assert np.array_equal(scene.morton3D(xyz[:, 0], xyz[:, 1], xyz[:, 2]), want)
+
+
+def test_near_far_slab_test():
+    rng = np.random.default_rng(1)
+    N = 4000
+    o = rng.uniform(-3, 3, (N, 3)).astype(np.float32)
+    d = rng.standard_normal((N, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    aabb = np.array([-0.7, -0.9, -0.6, 0.8, 0.9, 0.5], np.float32)
+    near, far = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    # textbook slab test in float64
+    t0 = (aabb[None, :3] - o.astype(np.float64)) / d
+    t1 = (aabb[None, 3:] - o.astype(np.float64)) / d
+    tn, tf = np.minimum(t0, t1).max(1), np.maximum(t0, t1).min(1)
+    hit = tn <= tf
+    FMAX = np.finfo(np.float32).max
+    decided = np.abs(tn - tf) > 1e-4  # grazing rays may flip in fp32
+    assert np.array_equal((near != FMAX)[decided], hit[decided])
+    ok = hit & decided
+    assert np.allclose(near[ok], np.maximum(tn[ok], 0.2), rtol=1e-4, atol=1e-5)
+    assert np.allclose(far[ok], tf[ok], rtol=1e-4, atol=1e-5)
+    assert np.all(far[~hit & decided] == FMAX)
+
+
+def _numpy_grid_reference(x, emb, offsets, pls, base):
+    """Independent 20-line trilinear / hash reference in float64 (instant-ngp indexing)."""
+    L = len(offsets) - 1
+    out = np.zeros((len(x), L, 2))
+    S = np.float32(np.log2(pls))
+    for l in range(L):
+        scale = np.float32(np.exp2(np.float32(l) * S) * np.float32(base) - np.float32(1.0))
+        res = int(np.ceil(scale)) + 1
+        hs = int(offsets[l + 1] - offsets[l])
+        pos = x.astype(np.float64) * float(scale) + 0.5
+        g = np.floor(pos).astype(np.int64)
+        w = pos - g
+        for c in range(8):
+            bit = np.array([(c >> k) & 1 for k in range(3)])
+            gc = g + bit
+            wc = np.prod(np.where(bit, w, 1 - w), axis=1)
+            if (res + 1) ** 3 <= hs:
+                idx = gc[:, 0] + gc[:, 1] * (res + 1) + gc[:, 2] * (res + 1) ** 2
+            else:
+                idx = (gc[:, 0] ^ (gc[:, 1] * 2654435761 & 0xFFFFFFFF) ^ (gc[:, 2] * 805459861 & 0xFFFFFFFF)) & 0xFFFFFFFF
+            out[:, l] += wc[:, None] * emb[offsets[l] + idx % hs]
+    return out.reshape(len(x), -1)
+
+
+def test_grid_encode_vs_numpy(ckpt):
+    rng = np.random.default_rng(2)
+    x = rng.random((300, 3)).astype(np.float32) * 0.98 + 0.01
+    got = oracle.grid_encode_forward(x, ckpt["embeddings"], ckpt["offsets"], ckpt["per_level_scale"], ckpt["base_resolution"])
+    want = _numpy_grid_reference(x, ckpt["embeddings"], ckpt["offsets"], ckpt["per_level_scale"], ckpt["base_resolution"])
+    # fine levels: pos ~ 2000 so one fp32 ulp of pos moves a weight by 1.2e-4; the weights multiply values |v| <= 0.5
+    assert np.abs(got - want).max() < 2e-4
+    assert np.abs(got[:, :10] - want[:, :10]).max() < 1e-5  # coarse levels are tight
+    assert np.allclose(got[:, 0], 0.5, atol=1e-6)  # the constant channel of the synthetic checkpoint
+    oob = oracle.grid_encode_forward(np.array([[1.5, 0.5, 0.5], [0.5, -0.01, 0.5]], np.float32), ckpt["embeddings"], ckpt["offsets"],
+                                     ckpt["per_level_scale"], ckpt["base_resolution"])
+    assert np.all(oob == 0)
+
+
+def test_grid_offsets_and_level_params(ckpt):
+    off = ckpt["offsets"]
+    # chair geometry quoted in SURVEY.md §8a R10
+    assert off[-1] == 6119864 and list(np.diff(off)[:5]) == [4920, 13824, 32768, 85184, 216000] and np.all(np.diff(off)[5:] == 524288)
+    scales, res = oracle.grid_level_params(16, ckpt["per_level_scale"], 16)
+    assert scales[0] == 15.0 and res[0] == 16
+    assert abs(scales[15] - 2047.0) < 0.01 and res[15] in (2048, 2049)
+
+
+def test_sh_vs_scipy():
+    import warnings
+    from scipy.special import sph_harm
+    warnings.filterwarnings('ignore', category=DeprecationWarning)
+    rng = np.random.default_rng(3)
+    d = rng.standard_normal((200, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    got = oracle.sh_encode_forward(d.astype(np.float32), 4)
+    theta = np.arctan2(d[:, 1], d[:, 0])  # azimuth
+    phi = np.arccos(np.clip(d[:, 2], -1, 1))  # polar
+    k = 0
+    for l in range(4):
+        for m in range(-l, l + 1):
+            Y = sph_harm(abs(m), l, theta, phi)
+            if m < 0:
+                real = np.sqrt(2) * Y.imag
+            elif m == 0:
+                real = Y.real
+            else:
+                real = np.sqrt(2) * Y.real
+            # the reference's basis (shencoder.cu:50-68) is the real SH basis that KEEPS the Condon-Shortley phase (Y_1,-1 = -c y)
+            assert np.abs(got[:, k] - real).max() < 2e-6, (l, m)
+            k += 1
+
+
+def test_composite_closed_form():
+    rng = np.random.default_rng(4)
+    n_alive, n_step, N = 50, 8, 80
+    alive = np.arange(n_alive, dtype=np.int32) + 5
+    sig = rng.random(n_alive * n_step).astype(np.float32) * 20
+    rgb = rng.random((n_alive * n_step, 3)).astype(np.float32)
+    deltas = np.full((n_alive * n_step, 2), 0.01, np.float32)
+    t0 = np.full(N, 2.0, np.float32)
+    ws, dep, img = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+    al = alive.copy()
+    oracle.composite_rays(n_alive, n_step, al, t0, sig, rgb, deltas, ws, dep, img, T_thresh=0.0)
+    alpha = 1 - np.exp(-sig.reshape(n_alive, n_step).astype(np.float64) * 0.01)
+    T = np.cumprod(np.concatenate([np.ones((n_alive, 1)), 1 - alpha[:, :-1]], 1), 1)
+    w = alpha * T
+    assert np.allclose(ws[alive], 1 - np.prod(1 - alpha, 1), atol=1e-5)
+    assert np.allclose(img[alive], (w[..., None] * rgb.reshape(n_alive, n_step, 3)).sum(1), atol=1e-5)
+    tt = 2.0 + 0.01 * np.arange(1, n_step + 1)
+    assert np.allclose(dep[alive], (w * tt).sum(1), atol=1e-4)
+    assert np.all(al == alive) and np.allclose(t0[alive], 2.0 + 0.01 * n_step, atol=1e-5)  # all rays survive, t advanced
+    assert np.all(ws[:5] == 0)
+
+
+def test_composite_termination_rules():
+    # deltas == 0 ends the ray; T < T_thresh is checked AFTER accumulating the sample (raymarching.cu:867,903)
+    alive = np.array([0, 1, 2], np.int32)
+    n_step = 4
+    sig = np.array([1000, 1, 1, 1, 5, 5, 5, 5, 5, 5, 0, 0], np.float32)
+    deltas = np.tile(np.array([[0.01, 0.01]], np.float32), (12, 1))
+    deltas[10:] = 0  # ray 2 emitted only two samples
+    rgb = np.ones((12, 3), np.float32)
+    t = np.ones(3, np.float32)
+    ws, dep, img = np.zeros(3, np.float32), np.zeros(3, np.float32), np.zeros((3, 3), np.float32)
+    oracle.composite_rays(3, n_step, alive, t, sig, rgb, deltas, ws, dep, img, T_thresh=1e-2)
+    assert list(alive) == [-1, 1, -1]
+    a0, a1 = 1 - np.exp(-10.0), 1 - np.exp(-0.01)
+    assert abs(ws[0] - (a0 + (1 - a0) * a1)) < 1e-6  # opaque first sample, then exactly one more sample is accumulated
+    assert abs(t[1] - 1.04) < 1e-6 and t[0] == 1 and t[2] == 1
+
+
+def test_compaction_is_stable_filter():
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 7, 1000):
+        a = rng.integers(0, 10 ** 6, n).astype(np.int32)
+        a[rng.random(n) < 0.5] = -1
+        assert np.array_equal(oracle.compact_rays(a), a[a >= 0])
+
+
+def test_pnts_in_grids_counting_sort():
+    rng = np.random.default_rng(6)
+    p = rng.uniform(-0.5, 0.5, (700, 3)).astype(np.float32)
+    hgs = np.float32(0.06)
+    bbmin, bbmax, res = oracle.render_bbox(p, hgs)
+    n_grid = int(res.prod())
+    cnt, bgn, idx = oracle.get_pnts_in_grids(len(p), n_grid, p, bbmin, bbmax, hgs, res)
+    g = np.floor((p - bbmin) / hgs).astype(np.int64)
+    gid = g[:, 2] * res[1] * res[0] + g[:, 1] * res[0] + g[:, 0]
+    assert np.array_equal(cnt, np.bincount(gid, minlength=n_grid))
+    assert np.array_equal(bgn, np.cumsum(cnt) - cnt)
+    assert np.array_equal(np.sort(idx), np.arange(len(p)))
+    assert np.array_equal(gid[idx], np.sort(gid, kind="stable"))       # grouped by cell ...
+    assert np.array_equal(idx, np.argsort(gid, kind="stable"))          # ... ascending id inside a cell
+
+
+def _quadratic_map(F, dF, q):
+    """phi(q) with the kernel's own flat-index arithmetic (raymarching.cu:940-951,1278-1296): A(q) = F + D(q),
+    D[m] = sum_b dF[b*9+m] q_b, phi = mul31(F, q) + 0.5 mul31(D, q) where mul31(M, v)[r] = sum_c M[c*3+r] v_c."""
+    D = sum(dF[b * 9:(b + 1) * 9] * q[b] for b in range(3))
+    m31 = lambda M, v: np.array([M[0] * v[0] + M[3] * v[1] + M[6] * v[2], M[1] * v[0] + M[4] * v[1] + M[7] * v[2], M[2] * v[0] + M[5] * v[1] + M[8] * v[2]])
+    return m31(F, q) + 0.5 * m31(D, q)
+
+
+def test_newton_warp_round_trip():
+    rng = np.random.default_rng(7)
+    for trial in range(20):
+        F = (np.eye(3) + 0.2 * rng.standard_normal((3, 3))).T.reshape(9)
+        dF = 0.5 * rng.standard_normal(27)
+        p_ori, p_def = rng.uniform(-0.5, 0.5, 3), rng.uniform(-0.5, 0.5, 3)
+        q = rng.uniform(-0.04, 0.04, 3)
+        x = p_def + _quadratic_map(F, dF, q)
+        p5, rej = oracle.warp_point(x, p_ori, p_def, F, dF, 8, 0.0525)
+        assert not rej and np.abs(p5 - (p_ori + q)).max() < 2e-6  # converged Newton recovers the rest point
+        p1, _ = oracle.warp_point(x, p_ori, p_def, F, dF, 1, 0.0525)
+        lin = p_ori + np.linalg.solve(np.array(F).reshape(3, 3).T, x - p_def)  # one iteration from q=0 is the linear inverse
+        assert np.abs(p1 - lin).max() < 2e-6
+    far, rej = oracle.warp_point(p_def + np.array([0.2, 0, 0]), p_ori, p_def, np.eye(3).reshape(9), np.zeros(27), 1, 0.0525)
+    assert rej  # outside the IP's trust region -> rejected (raymarching.cu:1316-1319)
+    same, rej = oracle.warp_point(p_def, p_ori, p_def, np.zeros(9), np.zeros(27), 3, 0.0525)
+    assert not rej and np.allclose(same, p_ori)  # singular A: A_inv stays 0, dq = 0, exits on the 1e-12 test (quirk R7q-ii)
+
+
+def _rest_state(n_side=8, dx=0.05):
+    g = (np.arange(n_side) - n_side / 2 + 0.5) * dx
+    p = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    n = len(p)
+    return dict(p_def=p, p_ori=p.copy(), F=np.tile(np.eye(3, dtype=np.float32).reshape(1, 9), (n, 1)), dF=np.zeros((n, 27), np.float32), IP_dx=dx * 1.05)
+
+
+@pytest.mark.parametrize("num_seek_IP", [1, 2, 3])
+def test_march_at_rest_is_plain_ray_marching(num_seek_IP):
+    """With p_def = p_ori, F = I, dF = 0 the warp is the identity, so emitted points lie on the ray, inside occupied voxels,
+    dt = dt_min apart, and deltas[1] telescopes to the distance marched."""
+    ip = _rest_state()
+    H = 128
+    bits = np.full(H ** 3 // 8, 0xFF, np.uint8)  # fully occupied grid: every found sample is emitted
+    hgs = np.float32(0.06)
+    bbmin, bbmax, res = oracle.render_bbox(ip["p_def"], hgs)
+    n_grid = int(res.prod())
+    pig = oracle.get_pnts_in_grids(len(ip["p_def"]), n_grid, ip["p_def"], bbmin, bbmax, hgs, res)
+    rng = np.random.default_rng(8)
+    N = 64
+    o = np.tile(np.array([[0.01, 0.02, 3.0]], np.float32), (N, 1))
+    tgt = rng.uniform(-0.12, 0.12, (N, 3)).astype(np.float32)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    nears, fars = oracle.near_far_from_aabb(o, d, np.concatenate([bbmin, bbmax]), 0.2)
+    alive = np.arange(N, dtype=np.int32)
+    n_step = 8
+    xyz, dirs, deltas = oracle.march_rays_quadratic_bending(*pig, len(ip["p_def"]), n_grid, ip["p_def"], ip["p_ori"], ip["F"], ip["dF"], 2, bbmin, bbmax,
+                                                            hgs, res, num_seek_IP, np.float32(ip["IP_dx"]), False, np.zeros(6, np.float32), N, n_step,
+                                                            alive, nears, o, d, 1.0, bits, 1, H, nears, fars, 128)
+    assert not oracle.march_rays_quadratic_bending.last_oob
+    xyz, deltas, dirs = xyz[:N * n_step].reshape(N, n_step, 3), deltas[:N * n_step].reshape(N, n_step, 2), dirs[:N * n_step].reshape(N, n_step, 3)
+    assert np.all(deltas[..., 0] > 0), "every ray crosses the IP block and the grid is full"
+    dt_min = np.float32(2 * np.sqrt(3) / 1024)
+    assert np.allclose(deltas[..., 0], dt_min, rtol=1e-6)
+    t = nears[:, None] + np.cumsum(deltas[..., 1], axis=1) - deltas[..., 0]  # sample parameter
+    on_ray = o[:, None, :] + t[..., None] * d[:, None, :]
+    assert np.abs(xyz - on_ray).max() < 5e-6  # identity warp (Newton on F = I)
+    assert np.array_equal(dirs, np.broadcast_to(d[:, None, :], dirs.shape))
+
+
+def test_march_respects_density_bitfield_and_skips(ckpt, deformed_ip_state, small_opt):
+    """Emitted rest-space points fall in occupied voxels of the morton-ordered bitfield; nothing is emitted for rays that miss."""
+    ip = deformed_ip_state
+    W = 40
+    o, d = oracle.get_rays(scene.orbit_pose(5.0, 25.0, -15.0), scene.orbit_intrinsics(W, W, 50.0), W, W)
+    hgs = np.float32(small_opt["hash_grid_size"])
+    bbmin, bbmax, res = oracle.render_bbox(ip["p_def"], hgs)
+    n_grid = int(res.prod())
+    pig = oracle.get_pnts_in_grids(len(ip["p_def"]), n_grid, ip["p_def"], bbmin, bbmax, hgs, res)
+    nears, fars = oracle.near_far_from_aabb(o, d, np.concatenate([bbmin, bbmax]), 0.2)
+    alive = np.arange(W * W, dtype=np.int32)
+    xyz, _, deltas = oracle.march_rays_quadratic_bending(*pig, len(ip["p_def"]), n_grid, ip["p_def"], ip["p_ori"], ip["F"], ip["dF"], 1, bbmin, bbmax, hgs,
+                                                         res, 3, np.float32(ip["IP_dx"]), False, np.zeros(6, np.float32), W * W, 4, alive, nears, o, d,
+                                                         1.0, ckpt["density_bitfield"], 1, 128, nears, fars, 128)
+    em = deltas[:, 0] != 0
+    assert em.sum() > 100
+    p = xyz[em]
+    n = np.clip((0.5 * (p.astype(np.float64) + 1) * 128).astype(np.int64), 0, 127)
+    m = scene.morton3D(n[:, 0], n[:, 1], n[:, 2]).astype(np.int64)
+    assert np.all((ckpt["density_bitfield"][m // 8] >> (m % 8)) & 1)
+    miss = np.repeat(nears > 1e30, 4)
+    assert not em[:W * W * 4][miss].any()
+
+
+def test_render_frame_properties(ckpt, deformed_ip_state, small_opt):
+    ip = deformed_ip_state
+    W = 48
+    o, d = oracle.get_rays(scene.orbit_pose(5.0, 20.0, -15.0), scene.orbit_intrinsics(W, W, 50.0), W, W)
+    r1 = oracle.render_deformed(o, d, ip, ckpt, small_opt)
+    r2 = oracle.render_deformed(o, d, ip, ckpt, small_opt)
+    assert np.array_equal(r1["image"], r2["image"])  # deterministic (OpenMP only partitions independent rays)
+    ws = r1["weights_sum"]
+    assert np.all(ws >= 0) and np.all(ws <= 1 + 1e-5)
+    assert np.all(r1["image"] >= 0) and np.all(r1["image"] <= 1 + 1e-5)
+    assert np.all(r1["image"][ws == 0] == 1.0)  # background = 1 where nothing was hit (renderer.py:803-804,896)
+    assert (ws > 0.5).sum() > 20 and r1["trips"] >= 3 and r1["samples"] > 1000
+    # T_thresh: a hit ray stops once transmittance < 1e-2, so alpha saturates just above 0.99
+    assert np.percentile(ws[ws > 0.5], 50) > 0.9
+    # depth is NaN exactly where the ray misses the IP bbox (renderer.py:898)
+    bbmin, bbmax, _ = oracle.render_bbox(ip["p_def"], np.float32(small_opt["hash_grid_size"]))
+    nears, _ = oracle.near_far_from_aabb(o, d, np.concatenate([bbmin, bbmax]), 0.2)
+    assert np.array_equal(np.isnan(r1["depth"]), nears > 1e30)
+    # num_seek_IP = 1 takes the find_closest_IP path (own cell first): still a picture of the same object
+    r3 = oracle.render_deformed(o, d, ip, ckpt, dict(small_opt, num_seek_IP=1))
+    both = (r3["weights_sum"] > 0.5) & (ws > 0.5)
+    assert both.sum() > 0.6 * (ws > 0.5).sum()
+
+
+def test_get_rays_matches_reference_formulation():
+    W, H = 30, 20
+    pose = scene.orbit_pose(5.0, 33.0, -12.0)
+    intr = scene.orbit_intrinsics(W, H, 50.0)
+    o, d = oracle.get_rays(pose, intr, H, W)
+    j, i = np.meshgrid(np.arange(H) + 0.5, np.arange(W) + 0.5, indexing="ij")  # row-major pixels, centres at +0.5 (nerf/utils.py:72-74)
+    dirs = np.stack([(i - intr[2]) / intr[0], (j - intr[3]) / intr[1], np.ones_like(i)], -1).reshape(-1, 3)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    assert np.abs(d - dirs @ pose[:3, :3].T).max() < 1e-6
+    assert np.all(o == pose[:3, 3][None, :])
+    assert abs(np.linalg.norm(pose[:3, 3]) - 5.0) < 1e-5 and abs(intr[0] - H / (2 * np.tan(np.radians(25.0)))) < 1e-9
+    # default OrbitCamera: at +z looking down -z, y up (nerf/gui.py:13-44)
+    p0 = scene.orbit_pose(5.0)
+    assert np.allclose(p0[:3, 3], [0, 0, 5]) and np.allclose(p0[:3, :3], np.diag([1, -1, -1]))
