@@ -5,8 +5,9 @@
 
 A step = one GUI-frame equivalent (nerf/gui.py:588-603 / nerf/trainer.py:300-318 of the reference):
 get_rays -> get_IP_info -> stepforward(iters=10) -> render_deformed at 800x800, inputs resident in HBM, outputs left in HBM.
-N > 1 is frame-parallel: every rank owns a simulator replica + checkpoint and renders its own frames
-(weak scaling, no data-path collective); value = frames all ranks completed / max-over-ranks time.
+N > 1 is frame-parallel (BASELINE.json configs[3]): rank 0 owns the simulator and broadcasts the DOF
+state (<= 82 KB) per frame over RCCL; every rank holds the checkpoint and renders frames f = rank (mod N).  K steps per
+rank = K*N frames in total (weak scaling); value = frames all ranks completed / max-over-ranks time.
 """
 import argparse
 import json
@@ -103,14 +104,40 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        h.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        h.step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    if world == 1:
+        run_steps = lambda n: [h.step() for _ in range(n)]
+    else:
+        # frame-parallel (pienerf_amd/frames.py): rank 0 owns the simulator and broadcasts dof[30 n_k] per frame over RCCL;
+        # frame f is rendered by rank f % world from the pre-step state.  `n` steps per rank = n * world frames in total.
+        from pienerf_amd.frames import FrameParallel, broadcast_tensors
+        from pienerf_amd.nerf.utils import get_rays
+        m, sim = h.model, h.sim
+        broadcast_tensors([m.encoder.embeddings.data, m.density_bitfield] + [l.weight.data for l in list(m.sigma_net) + list(m.color_net)], src=0)
+        pose_t = torch.from_numpy(h.pose).unsqueeze(0).to(dev)
+        kw = h.render_kwargs()
+
+        def render(frame):
+            rays = get_rays(pose_t, h.intrinsics, opt["H"], opt["W"], -1)
+            m.p_def, m.IP_F, m.IP_dF = sim.get_IP_info()
+            return m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **kw)["image"]
+
+        def set_dof(t):
+            sim.dof.copy_(t)
+
+        fp = FrameParallel(sim.stepforward, lambda: sim.dof, set_dof, render)
+        counter = {"f": 0}
+
+        def run_steps(n):
+            fp.run(n * world, first_frame=counter["f"])
+            counter["f"] += n * world
+
+    with torch.no_grad():
+        run_steps(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -71,9 +71,9 @@ int pn_get_rays(const float* pose_host, float fx, float fy, float cx, float cy, 
 /* ------------------------------------------------------------------ gridencoder ---- */
 
 /* gridencoder/src/gridencoder.h:11 grid_encode_forward (kernel gridencoder.cu:87-245, D=3, C in {1,2,4,8}, fp32,
- * dy_dx must be NULL).  offsets [host or device]: pass the device pointer in `offsets` and the same L+1 values on the
- * host in `offsets_host` (the launcher derives per-level scale/resolution/table size on the host with the
- * reference's formulas :132-134).  outputs [L,B,C] exactly like the reference kernel; with out_bl_major != 0 the
+ * dy_dx must be NULL).  offsets_host [host]: the L+1 int32 level offsets (the reference passes a device tensor; the
+ * launcher derives per-level scale / resolution / table size on the host with the reference's formulas :132-134 and
+ * hands them to the kernel by value).  outputs [L,B,C] exactly like the reference kernel; with out_bl_major != 0 the
  * kernel writes [B, L*C] directly (what grid.py:57 produces by permute+reshape). */
 int pn_grid_encode_forward(const float* inputs, const float* embeddings, const int* offsets_host, float* outputs, uint32_t B, uint32_t D,
                            uint32_t C, uint32_t L, float S, uint32_t H, const float* dy_dx, uint32_t gridtype, int align_corners,

@@ -1,0 +1,291 @@
+// Cooperative ray march with the inverse-GMLS warp: 8 lanes per ray (gfx950, wave = 64 -> 8 rays per wave).
+//
+// Why: at 800x800 only ~70k rays cross the IP bounding box — one wave per SIMD with one lane per ray — and every
+// marching step is a chain of dependent loads (27-cell stencil -> point ids -> positions -> F/dF -> bitfield).  The
+// one-lane-per-ray form of the reference (raymarching.cu:1121-1434) is therefore latency-bound with nothing to overlap.
+// Here the 8 lanes of a group (a) scan the candidate list of the sample's cell in parallel and merge their top-K by
+// xor-shuffles, (b) run the <= 3 per-IP Newton warps on lanes 0..2 concurrently, (c) replicate the cheap scalar logic;
+// 8x more waves are resident and the serial depth of a step drops from ~100 loads to ~6.
+//
+// Per-frame side tables (built by k_nb_* / k_pack_ip in pn_render_ops.hip):
+//   nb_bgn[n_grid+1], nb[...]  per cell: the candidates of its 27-cell neighbourhood as float4(p_def.xyz, bitcast id), in the
+//                              reference's visiting order (own cell first, then NBR26; own-cell order = ascending id), so
+//                              "position in the list" is "visiting order" and ties resolve exactly as the sequential scan does
+//   rec[n_vtx][44]             packed IP record: p_ori(3) p_def(3) F(9) dF(27) pad(2) — 176 B, float4-aligned
+//
+// Semantics are those of pn_march.h / the oracle, bit for bit (same -ffp-contract=off arithmetic):
+//   * sequential insertion with strict '<' over candidates in visiting order  ==  top-K by the key (dist2, position);
+//   * `n_IP--` inside the loops it bounds is replayed on the gathered per-IP flags;
+//   * Newton iteration 0 starts at q = +0, where dF.q = 0 and mul31(F, q) = 0: it is evaluated as A = F, b = -q'
+//     (identical results for finite F, dF; dF is only loaded if a second iteration runs).
+#pragma once
+#include "pn_march.h"
+
+namespace pnm2 {
+using namespace pnm;
+
+#define PN_G 8  // lanes per ray
+
+struct March2Tables {
+    const int* nb_bgn;    // [n_grid + 1]
+    const float4* nb;     // candidate entries
+    const float4* rec;    // [n_vtx * 11]
+};
+
+struct Cand { float d; int ord; };
+
+__device__ __forceinline__ bool cand_less(float da, int oa, float db, int ob) { return da < db || (da == db && oa < ob); }
+
+// insert (d, ord) into the sorted triple (c0 <= c1 <= c2 by key)
+template <int K>
+__device__ __forceinline__ void cand_insert(float d, int ord, float& d0, int& o0, float& d1, int& o1, float& d2, int& o2) {
+    if (cand_less(d, ord, d0, o0)) { d2 = d1; o2 = o1; d1 = d0; o1 = o0; d0 = d; o0 = ord; }
+    else if (K > 1 && cand_less(d, ord, d1, o1)) { d2 = d1; o2 = o1; d1 = d; o1 = ord; }
+    else if (K > 2 && cand_less(d, ord, d2, o2)) { d2 = d; o2 = ord; }
+}
+
+// Group-cooperative scan of nb[b..e): every lane of the group returns the same top-K (ord = list position, -1 if none).
+// dinit = FLT_MAX (find_closest_IPs, raymarching.cu:1056) or 9999.9f (find_closest_IP, :997).
+template <int K>
+__device__ __forceinline__ void group_topk(const float4* __restrict__ nb, int b, int e, int sub, float x, float y, float z, float dinit, int* ord_out) {
+    const int NONE = 0x7fffffff;
+    float d0 = dinit, d1 = dinit, d2 = dinit;
+    int o0 = NONE, o1 = NONE, o2 = NONE;
+    for (int j = b + sub; j < e; j += PN_G) {
+        const float4 v = nb[j];
+        const float ax = v.x - x, ay = v.y - y, az = v.z - z;
+        const float d = ax * ax + ay * ay + az * az;  // (pk_[0]-x)*(pk_[0]-x) + ... (raymarching.cu:1002)
+        // inside one lane candidates arrive in increasing position, so strict '<' on the distance is the full key test
+        if (d < d0) { d2 = d1; o2 = o1; d1 = d0; o1 = o0; d0 = d; o0 = j; }
+        else if (K > 1 && d < d1) { d2 = d1; o2 = o1; d1 = d; o1 = j; }
+        else if (K > 2 && d < d2) { d2 = d; o2 = j; }
+    }
+#pragma unroll
+    for (int m = 1; m < PN_G; m <<= 1) {
+        const float e0 = __shfl_xor(d0, m), e1 = __shfl_xor(d1, m), e2 = __shfl_xor(d2, m);
+        const int p0 = __shfl_xor(o0, m), p1 = __shfl_xor(o1, m), p2 = __shfl_xor(o2, m);
+        if (p0 != NONE) cand_insert<K>(e0, p0, d0, o0, d1, o1, d2, o2);
+        if (K > 1 && p1 != NONE) cand_insert<K>(e1, p1, d0, o0, d1, o1, d2, o2);
+        if (K > 2 && p2 != NONE) cand_insert<K>(e2, p2, d0, o0, d1, o1, d2, o2);
+    }
+    ord_out[0] = (o0 == NONE) ? -1 : o0;
+    ord_out[1] = (K > 1 && o1 != NONE) ? o1 : -1;
+    ord_out[2] = (K > 2 && o2 != NONE) ? o2 : -1;
+}
+
+// Newton inverse warp through one packed IP record (raymarching.cu:1262-1324).  Returns the reject flag.
+__device__ inline bool warp_record(const float4* __restrict__ r, int max_iter_num, float IP_dx, float x, float y, float z, float* p_out, float* dist_out) {
+    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+    const float pk0 = r0.x, pk1 = r0.y, pk2 = r0.z;          // p_ori
+    const float pd0 = r0.w, pd1 = r1.x, pd2 = r1.y;          // p_def
+    const float Fk[9] = {r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z};
+    float p[3] = {pk0, pk1, pk2};
+    const float q_[3] = {x - pd0, y - pd1, z - pd2};
+    int num_itr = 0;
+    if (max_iter_num > 0) {
+        // iteration 0: q = p - pk = +0  =>  dFk_q = 0, A = Fk, b = (0 + 0.5*0) - q_ = -q_
+        float A_inv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3], dq[3];
+        inv3x3(Fk, A_inv);
+#pragma unroll
+        for (int i = 0; i < 3; i++) b[i] = (float)(-(double)q_[i]);
+        mul31(A_inv, b, dq);
+        p[0] -= dq[0];
+        p[1] -= dq[1];
+        p[2] -= dq[2];
+        const bool conv = (double)(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2]) < 1e-12;
+        num_itr = 1;
+        if (!conv && max_iter_num > 1) {
+            float dFk[27];
+            const float* rf = reinterpret_cast<const float*>(r);
+#pragma unroll
+            for (int j = 0; j < 27; j++) dFk[j] = rf[15 + j];
+            while (num_itr < max_iter_num) {
+                const float q[3] = {p[0] - pk0, p[1] - pk1, p[2] - pk2};
+                float dFk_q[9], A[9], Ai[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Fk_q[3], dFk_q_q[3];
+                dot31(dFk, q, dFk_q);
+#pragma unroll
+                for (int j = 0; j < 9; j++) A[j] = Fk[j] + dFk_q[j];
+                inv3x3(A, Ai);
+                mul31(Fk, q, Fk_q);
+                mul31(dFk_q, q, dFk_q_q);
+#pragma unroll
+                for (int i = 0; i < 3; i++) b[i] = (float)(((double)Fk_q[i] + 0.5 * (double)dFk_q_q[i]) - (double)q_[i]);
+                mul31(Ai, b, dq);
+                p[0] -= dq[0];
+                p[1] -= dq[1];
+                p[2] -= dq[2];
+                if ((double)(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2]) < 1e-12) break;
+                num_itr++;
+            }
+        }
+    }
+    p_out[0] = p[0];
+    p_out[1] = p[1];
+    p_out[2] = p[2];
+    *dist_out = sqrtf((pk0 - x) * (pk0 - x) + (pk1 - y) * (pk1 - y) + (pk2 - z) * (pk2 - z));  // blend weight distance (:1345,1362)
+    return fabsf(p[0] - pk0) > IP_dx || fabsf(p[1] - pk1) > IP_dx || fabsf(p[2] - pk2) > IP_dx;
+}
+
+// One ray, executed by its 8 lanes in lock step.  `sub` = lane within the group; all per-ray state is replicated.
+// Returns the number of samples emitted (same value on all 8 lanes); lane 0 of the group writes them.
+template <int K>
+__device__ inline uint32_t march_group(const MarchParams& a, const March2Tables& tb, int index, float noise, uint32_t n_step, int sub, int gbase,
+                                       float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas) {
+    const float ox = a.rays_o[index * 3], oy = a.rays_o[index * 3 + 1], oz = a.rays_o[index * 3 + 2];
+    const float dx = a.rays_d[index * 3], dy = a.rays_d[index * 3 + 1], dz = a.rays_d[index * 3 + 2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    const uint32_t H = a.H, C = a.C;
+    const float rH = 1 / (float)H;
+    const float H3 = (float)(H * H * H);
+    float t = a.rays_t[index];
+    const float far = a.fars[index];
+    const float dt_min = 2 * 1.7320508075688772f / a.max_steps;
+    const float dt_max = 2 * 1.7320508075688772f * (1 << (C - 1)) / H;
+    uint32_t step = 0;
+    t += clampf(t * a.dt_gamma, dt_min, dt_max) * noise;
+    float last_t = t;
+    if (!(t < far)) return 0;
+
+    const float bmin0 = a.bbmin[0], bmin1 = a.bbmin[1], bmin2 = a.bbmin[2];
+    const float bmax0 = a.bbmax[0], bmax1 = a.bbmax[1], bmax2 = a.bbmax[2];
+    const float hi0 = (float)((double)bmax0 - 1e-6), hi1 = (float)((double)bmax1 - 1e-6), hi2 = (float)((double)bmax2 - 1e-6);
+    const int r0 = a.resolution[0], r1 = a.resolution[1], r2 = a.resolution[2];
+
+    while (t < far && step < n_step) {
+        bool found = false;
+        float x, y, z;
+        if (a.cut) {
+            x = clampf(ox + t * dx, -a.bound, a.bound);
+            y = clampf(oy + t * dy, -a.bound, a.bound);
+            z = clampf(oz + t * dz, -a.bound, a.bound);
+        } else {
+            x = clampf(ox + t * dx, bmin0, hi0);
+            y = clampf(oy + t * dy, bmin1, hi1);
+            z = clampf(oz + t * dz, bmin2, hi2);
+        }
+        bool in_cut = true;
+        if (a.cut) {
+            const float* cb = a.cut_bounds;  // `x < cb[3]` is the reference's own test (raymarching.cu:1210)
+            in_cut = (x > cb[0] && x < cb[1] && y > cb[2] && x < cb[3] && z > cb[4] && z < cb[5]);
+        }
+        if (in_cut) {
+            float x_map = 0.0f, y_map = 0.0f, z_map = 0.0f;
+            const int g0 = (int)floorf((x - bmin0) / a.hgs);
+            const int g1 = (int)floorf((y - bmin1) / a.hgs);
+            const int g2 = (int)floorf((z - bmin2) / a.hgs);
+            const bool oob = (g0 < 0 || g1 < 0 || g2 < 0 || g0 >= r0 || g1 >= r1 || g2 >= r2);
+            int ord[3] = {-1, -1, -1};
+            if (oob) {
+                if (a.err_flag && sub == 0) atomicOr(a.err_flag, 1);
+            } else {
+                const int gid = g2 * r1 * r0 + g1 * r0 + g0;
+                const int b = tb.nb_bgn[gid], e = tb.nb_bgn[gid + 1];
+                if (K == 1) {  // find_closest_IP: own cell first, the 26 neighbours only if that found nothing (:986-1043)
+                    const int own = a.pig_cnt[gid];
+                    group_topk<1>(tb.nb, b, b + own, sub, x, y, z, (float)9999.9, ord);
+                    if (ord[0] == -1) group_topk<1>(tb.nb, b + own, e, sub, x, y, z, (float)9999.9, ord);
+                } else {
+                    group_topk<K>(tb.nb, b, e, sub, x, y, z, FLT_MAX, ord);
+                }
+            }
+            int n_IP = (ord[0] != -1) + (ord[1] != -1) + (ord[2] != -1);
+            found = n_IP > 0;
+            if (found) {
+                // lanes 0..K-1 each own one selected IP: pre-filter flag, Newton warp, reject flag, blend distance
+                const int mine = (sub < 3) ? ((sub == 0) ? ord[0] : (sub == 1 ? ord[1] : ord[2])) : -1;
+                float pw[3] = {0.f, 0.f, 0.f}, dist = 0.f;
+                int flags = 0;  // bit0: pre-filter hit, bit1: reject
+                if (mine != -1) {
+                    const float4 c = tb.nb[mine];
+                    const int ip = __float_as_int(c.w);
+                    if (c.x <= bmin0 || c.y <= bmin1 || c.z < bmin2 || c.x >= bmax0 || c.y >= bmax1 || c.z >= bmax2) flags |= 1;  // (:1249)
+                    if (warp_record(tb.rec + (size_t)ip * 11, a.max_iter_num, a.IP_dx, x, y, z, pw, &dist)) flags |= 2;
+                }
+                float ps[9], dk[3];
+                int fl[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    if (k < K) {
+                        ps[3 * k] = __shfl(pw[0], gbase + k);
+                        ps[3 * k + 1] = __shfl(pw[1], gbase + k);
+                        ps[3 * k + 2] = __shfl(pw[2], gbase + k);
+                        dk[k] = __shfl(dist, gbase + k);
+                        fl[k] = __shfl(flags, gbase + k);
+                    } else {
+                        ps[3 * k] = ps[3 * k + 1] = ps[3 * k + 2] = 0.f;
+                        dk[k] = 0.f;
+                        fl[k] = 0;
+                    }
+                }
+                // replay of the two loops whose bound shrinks inside them (:1246-1251, :1262-1324)
+#pragma unroll
+                for (int k = 0; k < 3; k++) if (k < n_IP && (fl[k] & 1)) n_IP--;
+                if (n_IP <= 0) found = false;
+                if (found) {
+                    float pz[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        if (k < n_IP) {
+                            if (fl[k] & 2) n_IP--;
+                            pz[3 * k] = ps[3 * k];
+                            pz[3 * k + 1] = ps[3 * k + 1];
+                            pz[3 * k + 2] = ps[3 * k + 2];
+                        }
+                    }
+                    if (n_IP == 1) {
+                        x_map = pz[0]; y_map = pz[1]; z_map = pz[2];
+                    } else if (n_IP == 2) {
+                        const float dist_sum = dk[0] + dk[1];
+                        const float w0 = dk[1] / dist_sum, w1 = dk[0] / dist_sum;
+                        x_map = w0 * pz[0] + w1 * pz[3];
+                        y_map = w0 * pz[1] + w1 * pz[4];
+                        z_map = w0 * pz[2] + w1 * pz[5];
+                    } else if (n_IP == 3) {
+                        const float dist_sum = dk[0] * dk[1] + dk[1] * dk[2] + dk[2] * dk[0];
+                        const float w0 = dk[1] * dk[2] / dist_sum;
+                        const float w1 = dk[0] * dk[2] / dist_sum;
+                        const float w2 = dk[0] * dk[1] / dist_sum;
+                        x_map = w0 * pz[0] + w1 * pz[3] + w2 * pz[6];
+                        y_map = w0 * pz[1] + w1 * pz[4] + w2 * pz[7];
+                        z_map = w0 * pz[2] + w1 * pz[5] + w2 * pz[8];
+                    }
+                    x = x_map; y = y_map; z = z_map;  // n_IP == 0 here maps the sample to the origin (:1372-1374)
+                }
+            }
+        } else {
+            found = true;  // cut mode, outside the cut box: un-warped background sample (:1380-1383)
+        }
+
+        const float dt = clampf(t * a.dt_gamma, dt_min, dt_max);
+        const int level = max(mip_from_pos(x, y, z, (float)C), mip_from_dt(dt, (float)H, (float)C));
+        const float mip_bound = fminf(scalbnf(1.0f, level), a.bound);
+        const float mip_rbound = 1 / mip_bound;
+        const int nx = (int)clampf((float)(0.5 * (double)(x * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+        const int ny = (int)clampf((float)(0.5 * (double)(y * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+        const int nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+        const uint32_t vox = (uint32_t)(level * H3 + (float)morton3D(nx, ny, nz));
+        const bool occ = a.grid[vox / 8] & (1 << (vox % 8));
+
+        if (occ && found) {
+            t += dt;
+            if (sub == 0) {
+                xyzs[0] = x; xyzs[1] = y; xyzs[2] = z;
+                dirs[0] = dx; dirs[1] = dy; dirs[2] = dz;
+                deltas[0] = dt;
+                deltas[1] = t - last_t;
+            }
+            last_t = t;
+            xyzs += 3; dirs += 3; deltas += 2;
+            step++;
+        } else {
+            const float tx = (((nx + 0.5f + 0.5f * signf(dx)) * rH * 2 - 1) * mip_bound - x) * rdx;
+            const float ty = (((ny + 0.5f + 0.5f * signf(dy)) * rH * 2 - 1) * mip_bound - y) * rdy;
+            const float tz = (((nz + 0.5f + 0.5f * signf(dz)) * rH * 2 - 1) * mip_bound - z) * rdz;
+            const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+            do { t += clampf(t * a.dt_gamma, dt_min, dt_max); } while (t < tt);
+        }
+    }
+    return step;
+}
+
+}  // namespace pnm2

@@ -2,7 +2,7 @@
 // Built with -ffp-contract=off (see pn_march.h).  Reference citations are relative to /root/reference.
 #include <float.h>
 
-#include "pn_march.h"
+#include "pn_march2.h"
 
 thread_local char pn_err_buf[512] = {0};
 
@@ -209,6 +209,96 @@ extern "C" int pn_pnts_in_grids(int n_vtx, int n_grid, const float* pnts, const 
 }
 
 // ------------------------------------------------------------------------------------------------ march
+// Side tables of the cooperative march (pn_march2.h): per-cell candidate lists and packed IP records.
+__device__ __forceinline__ void nb_cell_coords(int c, int r0, int r1, int& g0, int& g1, int& g2) {
+    g0 = c % r0;
+    g1 = (c / r0) % r1;
+    g2 = c / (r0 * r1);
+}
+// neighbour k of cell (g0,g1,g2) in the visiting order of find_closest_IPs (offset applied as (g0+a, g1+b, g2+c), raymarching.cu:1095-1102)
+// or, for num_seek_IP == 1, of find_closest_IP (offset applied as (g2+a, g1+b, g0+c), :1018-1025).  Returns -1 when out of the grid.
+__device__ __forceinline__ int nb_neighbour(int k, int swap, int g0, int g1, int g2, int r0, int r1, int r2) {
+    const int a = pnm::NBR26[k][0], b = pnm::NBR26[k][1], c = pnm::NBR26[k][2];
+    const int n0 = g0 + (swap ? c : a), n1 = g1 + b, n2 = g2 + (swap ? a : c);
+    if (n0 < 0 || n0 >= r0 || n1 < 0 || n1 >= r1 || n2 < 0 || n2 >= r2) return -1;
+    return n2 * r1 * r0 + n1 * r0 + n0;
+}
+
+__global__ void __launch_bounds__(256) k_nb_count(int n_grid_max, const int* __restrict__ n_grid_dev, const int* __restrict__ res,
+                                                  const int* __restrict__ pig_cnt, int swap, int* __restrict__ nb_cnt) {
+    const int n_grid = n_grid_dev ? min(*n_grid_dev, n_grid_max) : n_grid_max;
+    const int r0 = res[0], r1 = res[1], r2 = res[2];
+    for (int c = threadIdx.x + blockIdx.x * blockDim.x; c < n_grid; c += gridDim.x * blockDim.x) {
+        int g0, g1, g2;
+        nb_cell_coords(c, r0, r1, g0, g1, g2);
+        int s = pig_cnt[c];
+        for (int k = 0; k < 26; k++) {
+            const int nbc = nb_neighbour(k, swap, g0, g1, g2, r0, r1, r2);
+            if (nbc >= 0) s += pig_cnt[nbc];
+        }
+        nb_cnt[c] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_nb_fill(int n_grid_max, const int* __restrict__ n_grid_dev, const int* __restrict__ res,
+                                                 const int* __restrict__ pig_cnt, const int* __restrict__ pig_bgn, const int* __restrict__ pig_idx,
+                                                 const float* __restrict__ p_def, int swap, const int* __restrict__ nb_cnt, int* __restrict__ nb_bgn,
+                                                 float4* __restrict__ nb, int nb_capacity, int* err_flag) {
+    const int n_grid = n_grid_dev ? min(*n_grid_dev, n_grid_max) : n_grid_max;
+    const int r0 = res[0], r1 = res[1], r2 = res[2];
+    for (int c = threadIdx.x + blockIdx.x * blockDim.x; c < n_grid; c += gridDim.x * blockDim.x) {
+        int w = nb_bgn[c];
+        if (c == n_grid - 1) nb_bgn[n_grid] = w + nb_cnt[c];  // closing offset
+        if (nb_cnt[c] == 0) continue;
+        if (w + nb_cnt[c] > nb_capacity) { if (err_flag) atomicOr(err_flag, 8); continue; }
+        int g0, g1, g2;
+        nb_cell_coords(c, r0, r1, g0, g1, g2);
+        for (int k = -1; k < 26; k++) {
+            const int cell = (k < 0) ? c : nb_neighbour(k, swap, g0, g1, g2, r0, r1, r2);
+            if (cell < 0) continue;
+            const int n = pig_cnt[cell], b = pig_bgn[cell];
+            for (int i = 0; i < n; i++) {
+                const int ip = pig_idx[b + i];
+                nb[w++] = make_float4(p_def[ip * 3], p_def[ip * 3 + 1], p_def[ip * 3 + 2], __int_as_float(ip));
+            }
+        }
+    }
+}
+
+// rec[ip] = p_ori(3) p_def(3) F(9) dF(27) pad(2)
+__global__ void __launch_bounds__(256) k_pack_ip(int n_vtx, const float* __restrict__ p_ori, const float* __restrict__ p_def,
+                                                 const float* __restrict__ F_IP, const float* __restrict__ dF_IP, float* __restrict__ rec) {
+    const int t = threadIdx.x + blockIdx.x * blockDim.x;
+    const int ip = t / 44, j = t % 44;
+    if (ip >= n_vtx) return;
+    float v = 0.f;
+    if (j < 3) v = p_ori[ip * 3 + j];
+    else if (j < 6) v = p_def[ip * 3 + j - 3];
+    else if (j < 15) v = F_IP[ip * 9 + j - 6];
+    else if (j < 42) v = dF_IP[ip * 27 + j - 15];
+    rec[t] = v;
+}
+
+struct MarchSide {  // device buffers of the side tables
+    int *nb_cnt, *nb_bgn, *nb_cursor;  // [n_grid_max + 1]
+    float4* nb;                         // [nb_capacity]
+    float* rec;                         // [n_vtx * 44]
+    int nb_capacity;
+};
+
+static int march_side_build(const MarchSide& s, int n_vtx, int n_grid_max, const int* n_grid_dev, const int* res, const int* pig_cnt,
+                            const int* pig_bgn, const int* pig_idx, const float* p_def, const float* p_ori, const float* F_IP, const float* dF_IP,
+                            int num_seek_IP, int* err_flag, hipStream_t st) {
+    const int swap = (num_seek_IP == 1) ? 1 : 0;
+    const int gz = (int)pn_div_up(n_grid_max, 256) < 1024 ? (int)pn_div_up(n_grid_max, 256) : 1024;
+    k_nb_count<<<gz, 256, 0, st>>>(n_grid_max, n_grid_dev, res, pig_cnt, swap, s.nb_cnt);
+    k_pig_scan<<<1, 1024, 0, st>>>(n_grid_max, n_grid_dev, s.nb_cnt, s.nb_bgn, s.nb_cursor);
+    k_nb_fill<<<gz, 256, 0, st>>>(n_grid_max, n_grid_dev, res, pig_cnt, pig_bgn, pig_idx, p_def, swap, s.nb_cnt, s.nb_bgn, s.nb, s.nb_capacity, err_flag);
+    k_pack_ip<<<pn_div_up((uint64_t)n_vtx * 44, 256), 256, 0, st>>>(n_vtx, p_ori, p_def, F_IP, dF_IP, s.rec);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
 struct MarchIO {
     uint32_t n_alive, n_step;
     const int* rays_alive;
@@ -219,25 +309,28 @@ struct MarchIO {
     int* list;
 };
 
-__global__ void __launch_bounds__(256) k_march(pnm::MarchParams a, MarchIO io) {
+// 8 lanes per ray, 32 rays per 256-thread block.
+template <int K>
+__global__ void __launch_bounds__(256) k_march(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
     uint32_t n_alive = io.n_alive, n_step = io.n_step;
     if (io.trip) { n_alive = (uint32_t)io.trip->n_alive; n_step = (uint32_t)io.trip->n_step; }
-    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
-    if (blockIdx.x * blockDim.x >= n_alive) return;  // whole block idle
+    if (blockIdx.x * 32u >= n_alive) return;  // whole block idle
+    const uint32_t n = blockIdx.x * 32u + (threadIdx.x >> 3);
+    const int lane = threadIdx.x & 63, sub = lane & 7, gbase = lane & ~7;
     uint32_t emitted = 0;
+    float* dl = nullptr;
     if (n < n_alive) {
         const int index = io.rays_alive[n];
         const float noise = io.noises ? io.noises[n] : 0.0f;
-        float* dl = io.deltas + (size_t)n * n_step * 2;
-        emitted = pnm::march_one(a, index, noise, n_step, io.xyzs + (size_t)n * n_step * 3, io.dirs + (size_t)n * n_step * 3, dl);
-        if (io.trip) {  // the op-level wrapper zero-fills instead (raymarching.py:415-417)
-            for (uint32_t s = emitted; s < n_step; s++) { dl[2 * s] = 0.0f; dl[2 * s + 1] = 0.0f; }
-        }
+        dl = io.deltas + (size_t)n * n_step * 2;
+        emitted = pnm2::march_group<K>(a, tb, index, noise, n_step, sub, gbase, io.xyzs + (size_t)n * n_step * 3, io.dirs + (size_t)n * n_step * 3, dl);
     }
     if (io.trip) {
-        // wave-aggregated append of this wave's valid sample slots
-        const int lane = threadIdx.x & 63;
-        int inc = (int)emitted;
+        // slots the ray did not fill end it in composite (delta == 0); the op-level wrapper zero-fills instead (raymarching.py:415-417)
+        if (dl)
+            for (uint32_t s = emitted + sub; s < n_step; s += PN_G) { dl[2 * s] = 0.0f; dl[2 * s + 1] = 0.0f; }
+        // wave-aggregated append of this wave's valid sample slots (one atomic per wave)
+        int inc = (sub == 0) ? (int)emitted : 0;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int u = __shfl_up(inc, o);
@@ -247,9 +340,15 @@ __global__ void __launch_bounds__(256) k_march(pnm::MarchParams a, MarchIO io) {
         int base = 0;
         if (lane == 63 && total > 0) base = atomicAdd(&io.trip->n_samples, total);
         base = __shfl(base, 63);
-        const int first = base + inc - (int)emitted;
-        for (uint32_t s = 0; s < emitted; s++) io.list[first + s] = (int)(n * n_step + s);
+        const int first = base + __shfl(inc, gbase) - (int)emitted;  // exclusive prefix of this group's first lane
+        for (uint32_t s = sub; s < emitted; s += PN_G) io.list[first + s] = (int)(n * n_step + s);
     }
+}
+
+static void launch_march(int K, uint32_t blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb, const MarchIO& io) {
+    if (K == 1) k_march<1><<<blocks, 256, 0, st>>>(a, tb, io);
+    else if (K == 2) k_march<2><<<blocks, 256, 0, st>>>(a, tb, io);
+    else k_march<3><<<blocks, 256, 0, st>>>(a, tb, io);
 }
 
 static pnm::MarchParams make_march_params(const int* pig_cnt, const int* pig_bgn, const int* pig_idx, int n_vtx, int n_grid, const float* p_def,
@@ -280,13 +379,29 @@ extern "C" int pn_march_rays_quadratic_bending(const int* pig_cnt, const int* pi
     PN_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas);
     PN_REQUIRE(num_seek_IP >= 1 && num_seek_IP <= 3);
     PN_REQUIRE(!cut || cut_bounds);
-    PN_REQUIRE(C >= 1 && C <= 8 && H > 0 && n_step >= 1);
+    PN_REQUIRE(C >= 1 && C <= 8 && H > 0 && n_step >= 1 && n_vtx > 0 && n_grid > 0);
     if (n_alive == 0) return PN_OK;
-    pnm::MarchParams a = make_march_params(pig_cnt, pig_bgn, pig_idx, n_vtx, n_grid, p_def, p_ori, F_IP, dF_IP, max_iter_num, bbmin, bbmax, hgs,
-                                           resolution, num_seek_IP, IP_dx, cut, cut_bounds, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C,
-                                           H, grid, fars, err_flag);
-    MarchIO io{n_alive, n_step, rays_alive, xyzs, dirs, deltas, noises, nullptr, nullptr};
-    k_march<<<pn_div_up(n_alive, 256), 256, 0, (hipStream_t)stream>>>(a, io);
+    hipStream_t st = (hipStream_t)stream;
+    // side tables are rebuilt from the caller's spatial hash on every call (stream-ordered pool allocations)
+    MarchSide s;
+    s.nb_capacity = 27 * n_vtx;
+    char* pool = nullptr;
+    const size_t ints = ((size_t)n_grid + 1) * 3 * sizeof(int), nbb = (size_t)s.nb_capacity * sizeof(float4), recb = (size_t)n_vtx * 44 * sizeof(float);
+    const size_t off_nb = (ints + 255) & ~(size_t)255, off_rec = (off_nb + nbb + 255) & ~(size_t)255;
+    PN_HIP_CHECK(hipMallocAsync((void**)&pool, off_rec + recb, st));
+    s.nb_cnt = (int*)pool; s.nb_bgn = s.nb_cnt + n_grid + 1; s.nb_cursor = s.nb_bgn + n_grid + 1;
+    s.nb = (float4*)(pool + off_nb); s.rec = (float*)(pool + off_rec);
+    int rc = march_side_build(s, n_vtx, n_grid, nullptr, resolution, pig_cnt, pig_bgn, pig_idx, p_def, p_ori, F_IP, dF_IP, num_seek_IP, err_flag, st);
+    if (rc == PN_OK) {
+        pnm::MarchParams a = make_march_params(pig_cnt, pig_bgn, pig_idx, n_vtx, n_grid, p_def, p_ori, F_IP, dF_IP, max_iter_num, bbmin, bbmax, hgs,
+                                               resolution, num_seek_IP, IP_dx, cut, cut_bounds, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps,
+                                               C, H, grid, fars, err_flag);
+        pnm2::March2Tables tb{s.nb_bgn, s.nb, (const float4*)s.rec};
+        MarchIO io{n_alive, n_step, rays_alive, xyzs, dirs, deltas, noises, nullptr, nullptr};
+        launch_march(num_seek_IP, pn_div_up(n_alive, 32), st, a, tb, io);
+    }
+    PN_HIP_CHECK(hipFreeAsync(pool, st));
+    if (rc) return rc;
     PN_LAUNCH_CHECK();
     return PN_OK;
 }
@@ -435,6 +550,7 @@ struct pn_frame {
     float *nears, *fars, *rays_t, *xyzs, *dirs, *deltas, *sigmas, *rgbs;
     int *alive_a, *alive_b, *list, *chunk_counts;
     int *pig_cnt, *pig_bgn, *pig_idx, *pig_cursor;
+    MarchSide side;  // candidate lists + packed IP records of the cooperative march
     PnTrip* trips;  // [PN_MAX_TRIPS + 2]
     PnFrameDev* dev;
     float* cut_bounds;
@@ -514,6 +630,10 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
     PN_ALLOC(f->alive_a, N * 4); PN_ALLOC(f->alive_b, N * 4); PN_ALLOC(f->list, N * 4); PN_ALLOC(f->chunk_counts, (N / 256 + 2) * 4);
     PN_ALLOC(f->pig_cnt, (size_t)max_grid_cells * 4); PN_ALLOC(f->pig_bgn, (size_t)max_grid_cells * 4);
     PN_ALLOC(f->pig_cursor, (size_t)max_grid_cells * 4); PN_ALLOC(f->pig_idx, (size_t)max_vtx * 4);
+    PN_ALLOC(f->side.nb_cnt, ((size_t)max_grid_cells + 1) * 4); PN_ALLOC(f->side.nb_bgn, ((size_t)max_grid_cells + 1) * 4);
+    PN_ALLOC(f->side.nb_cursor, ((size_t)max_grid_cells + 1) * 4);
+    f->side.nb_capacity = 27 * (int)max_vtx;
+    PN_ALLOC(f->side.nb, (size_t)f->side.nb_capacity * sizeof(float4)); PN_ALLOC(f->side.rec, (size_t)max_vtx * 44 * 4);
     PN_ALLOC(f->trips, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)); PN_ALLOC(f->dev, sizeof(PnFrameDev)); PN_ALLOC(f->cut_bounds, 6 * 4);
 #undef PN_ALLOC
     PN_HIP_CHECK(hipHostMalloc((void**)&f->trips_pinned, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)));
@@ -525,7 +645,8 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
 extern "C" void pn_frame_destroy(pn_frame* f) {
     if (!f) return;
     void* ptrs[] = {f->nears, f->fars, f->rays_t, f->xyzs, f->dirs, f->deltas, f->sigmas, f->rgbs, f->alive_a, f->alive_b, f->list,
-                    f->chunk_counts, f->pig_cnt, f->pig_bgn, f->pig_cursor, f->pig_idx, f->trips, f->dev, f->cut_bounds};
+                    f->chunk_counts, f->pig_cnt, f->pig_bgn, f->pig_cursor, f->pig_idx, f->trips, f->dev, f->cut_bounds,
+                    f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, f->side.nb, f->side.rec};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (f->trips_pinned) (void)hipHostFree(f->trips_pinned);
     if (f->dev_pinned) (void)hipHostFree(f->dev_pinned);
@@ -557,6 +678,10 @@ extern "C" int pn_render_deformed(pn_frame* f, const pn_net* net, const pn_rende
     int rc = pig_build(n_vtx, (int)f->max_cells, n_grid_dev, p_def, bbmin, o->hash_grid_size, res, f->pig_cnt, f->pig_bgn, f->pig_idx,
                        f->pig_cursor, err, st);
     if (rc) return rc;
+    rc = march_side_build(f->side, n_vtx, (int)f->max_cells, n_grid_dev, res, f->pig_cnt, f->pig_bgn, f->pig_idx, p_def, p_ori, F_IP, dF_IP,
+                          o->num_seek_IP, err, st);
+    if (rc) return rc;
+    pnm2::March2Tables tb{f->side.nb_bgn, f->side.nb, (const float4*)f->side.rec};
     k_near_far<<<nblk, 256, 0, st>>>(rays_o, rays_d, f->dev->aabb, N, o->min_near, f->nears, f->fars, f->rays_t);
     k_frame_init<<<nblk, 256, 0, st>>>(f->trips, N, f->alive_a, f->dev);
     PN_LAUNCH_CHECK();
@@ -571,7 +696,7 @@ extern "C" int pn_render_deformed(pn_frame* f, const pn_net* net, const pn_rende
             int* cur = (t & 1) ? f->alive_b : f->alive_a;
             int* nxt = (t & 1) ? f->alive_a : f->alive_b;
             MarchIO io{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + t, f->list};
-            k_march<<<nblk, 256, 0, st>>>(mp, io);
+            launch_march(o->num_seek_IP, pn_div_up(N, 32), st, mp, tb, io);
             rc = pn_nerf_forward_launch(net, f->xyzs, f->dirs, f->list, &f->trips[t].n_samples, N, o->density_scale, f->sigmas, f->rgbs, st);
             if (rc) return rc;
             k_composite<<<nblk, 256, 0, st>>>(0, 0, o->T_thresh, cur, f->rays_t, f->sigmas, f->rgbs, f->deltas, weights_sum, depth_0, image,
