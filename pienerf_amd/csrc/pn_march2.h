@@ -32,48 +32,52 @@ struct March2Tables {
     const float4* rec;    // [n_vtx * 11]
 };
 
-struct Cand { float d; int ord; };
-
-__device__ __forceinline__ bool cand_less(float da, int oa, float db, int ob) { return da < db || (da == db && oa < ob); }
-
-// insert (d, ord) into the sorted triple (c0 <= c1 <= c2 by key)
-template <int K>
-__device__ __forceinline__ void cand_insert(float d, int ord, float& d0, int& o0, float& d1, int& o1, float& d2, int& o2) {
-    if (cand_less(d, ord, d0, o0)) { d2 = d1; o2 = o1; d1 = d0; o1 = o0; d0 = d; o0 = ord; }
-    else if (K > 1 && cand_less(d, ord, d1, o1)) { d2 = d1; o2 = o1; d1 = d; o1 = ord; }
-    else if (K > 2 && cand_less(d, ord, d2, o2)) { d2 = d; o2 = ord; }
+// Candidate key: (dist2 bits << 32) | list position.  dist2 >= 0, so its IEEE bit pattern orders like its value, and the
+// u64 order is exactly the lexicographic (dist2, visiting order) order that sequential strict-'<' insertion realises.
+typedef unsigned long long key_t;
+#define PN_KEY_NONE 0xFFFFFFFFFFFFFFFFull
+__device__ __forceinline__ key_t make_key(float d, int ord) { return ((key_t)__float_as_uint(d) << 32) | (unsigned)ord; }
+__device__ __forceinline__ key_t shfl_xor_key(key_t k, int m) {
+    return ((key_t)(unsigned)__shfl_xor((int)(k >> 32), m) << 32) | (unsigned)__shfl_xor((int)(unsigned)k, m);
 }
 
-// Group-cooperative scan of nb[b..e): every lane of the group returns the same top-K (ord = list position, -1 if none).
-// dinit = FLT_MAX (find_closest_IPs, raymarching.cu:1056) or 9999.9f (find_closest_IP, :997).
+// Group-cooperative scan of nb[b..e): every lane of the group returns the same top-K list positions (-1 if none).
+// dinit = FLT_MAX (find_closest_IPs, raymarching.cu:1056) or 9999.9f (find_closest_IP, :997): only d < dinit is accepted.
 template <int K>
 __device__ __forceinline__ void group_topk(const float4* __restrict__ nb, int b, int e, int sub, float x, float y, float z, float dinit, int* ord_out) {
-    const int NONE = 0x7fffffff;
-    float d0 = dinit, d1 = dinit, d2 = dinit;
-    int o0 = NONE, o1 = NONE, o2 = NONE;
+    key_t k0 = PN_KEY_NONE, k1 = PN_KEY_NONE, k2 = PN_KEY_NONE;  // this lane's sorted best
     for (int j = b + sub; j < e; j += PN_G) {
         const float4 v = nb[j];
         const float ax = v.x - x, ay = v.y - y, az = v.z - z;
         const float d = ax * ax + ay * ay + az * az;  // (pk_[0]-x)*(pk_[0]-x) + ... (raymarching.cu:1002)
-        // inside one lane candidates arrive in increasing position, so strict '<' on the distance is the full key test
-        if (d < d0) { d2 = d1; o2 = o1; d1 = d0; o1 = o0; d0 = d; o0 = j; }
-        else if (K > 1 && d < d1) { d2 = d1; o2 = o1; d1 = d; o1 = j; }
-        else if (K > 2 && d < d2) { d2 = d; o2 = j; }
+        if (d < dinit) {  // also rejects NaN, like the reference's `dist2_tmp < dist2`
+            const key_t k = make_key(d, j);
+            if (k < k0) { k2 = k1; k1 = k0; k0 = k; }
+            else if (K > 1 && k < k1) { k2 = k1; k1 = k; }
+            else if (K > 2 && k < k2) { k2 = k; }
+        }
     }
+    // K rounds of group-min: the lane that owns the winner pops it
 #pragma unroll
-    for (int m = 1; m < PN_G; m <<= 1) {
-        const float e0 = __shfl_xor(d0, m), e1 = __shfl_xor(d1, m), e2 = __shfl_xor(d2, m);
-        const int p0 = __shfl_xor(o0, m), p1 = __shfl_xor(o1, m), p2 = __shfl_xor(o2, m);
-        if (p0 != NONE) cand_insert<K>(e0, p0, d0, o0, d1, o1, d2, o2);
-        if (K > 1 && p1 != NONE) cand_insert<K>(e1, p1, d0, o0, d1, o1, d2, o2);
-        if (K > 2 && p2 != NONE) cand_insert<K>(e2, p2, d0, o0, d1, o1, d2, o2);
+    for (int r = 0; r < 3; r++) {
+        if (r < K) {
+            key_t m = k0;
+#pragma unroll
+            for (int s = 1; s < PN_G; s <<= 1) {
+                const key_t o = shfl_xor_key(m, s);
+                m = o < m ? o : m;
+            }
+            ord_out[r] = (m == PN_KEY_NONE) ? -1 : (int)(unsigned)m;
+            if (m == k0 && m != PN_KEY_NONE) { k0 = k1; k1 = k2; k2 = PN_KEY_NONE; }
+        } else {
+            ord_out[r] = -1;
+        }
     }
-    ord_out[0] = (o0 == NONE) ? -1 : o0;
-    ord_out[1] = (K > 1 && o1 != NONE) ? o1 : -1;
-    ord_out[2] = (K > 2 && o2 != NONE) ? o2 : -1;
 }
 
 // Newton inverse warp through one packed IP record (raymarching.cu:1262-1324).  Returns the reject flag.
+// MULTI = false is the max_iter_num <= 1 build (the chair / trex demo setting, README.md:123,134): no dF, far fewer registers.
+template <bool MULTI>
 __device__ inline bool warp_record(const float4* __restrict__ r, int max_iter_num, float IP_dx, float x, float y, float z, float* p_out, float* dist_out) {
     const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
     const float pk0 = r0.x, pk1 = r0.y, pk2 = r0.z;          // p_ori
@@ -94,7 +98,7 @@ __device__ inline bool warp_record(const float4* __restrict__ r, int max_iter_nu
         p[2] -= dq[2];
         const bool conv = (double)(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2]) < 1e-12;
         num_itr = 1;
-        if (!conv && max_iter_num > 1) {
+        if (MULTI && !conv && max_iter_num > 1) {
             float dFk[27];
             const float* rf = reinterpret_cast<const float*>(r);
 #pragma unroll
@@ -128,7 +132,7 @@ __device__ inline bool warp_record(const float4* __restrict__ r, int max_iter_nu
 
 // One ray, executed by its 8 lanes in lock step.  `sub` = lane within the group; all per-ray state is replicated.
 // Returns the number of samples emitted (same value on all 8 lanes); lane 0 of the group writes them.
-template <int K>
+template <int K, bool MULTI>
 __device__ inline uint32_t march_group(const MarchParams& a, const March2Tables& tb, int index, float noise, uint32_t n_step, int sub, int gbase,
                                        float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas) {
     const float ox = a.rays_o[index * 3], oy = a.rays_o[index * 3 + 1], oz = a.rays_o[index * 3 + 2];
@@ -180,9 +184,11 @@ __device__ inline uint32_t march_group(const MarchParams& a, const March2Tables&
             } else {
                 const int gid = g2 * r1 * r0 + g1 * r0 + g0;
                 const int b = tb.nb_bgn[gid], e = tb.nb_bgn[gid + 1];
-                if (K == 1) {  // find_closest_IP: own cell first, the 26 neighbours only if that found nothing (:986-1043)
+                if (b == e) {
+                    // no IP in the 27-cell neighbourhood: nothing found
+                } else if (K == 1) {  // find_closest_IP: own cell first, the 26 neighbours only if that found nothing (:986-1043)
                     const int own = a.pig_cnt[gid];
-                    group_topk<1>(tb.nb, b, b + own, sub, x, y, z, (float)9999.9, ord);
+                    if (own > 0) group_topk<1>(tb.nb, b, b + own, sub, x, y, z, (float)9999.9, ord);
                     if (ord[0] == -1) group_topk<1>(tb.nb, b + own, e, sub, x, y, z, (float)9999.9, ord);
                 } else {
                     group_topk<K>(tb.nb, b, e, sub, x, y, z, FLT_MAX, ord);
@@ -199,7 +205,7 @@ __device__ inline uint32_t march_group(const MarchParams& a, const March2Tables&
                     const float4 c = tb.nb[mine];
                     const int ip = __float_as_int(c.w);
                     if (c.x <= bmin0 || c.y <= bmin1 || c.z < bmin2 || c.x >= bmax0 || c.y >= bmax1 || c.z >= bmax2) flags |= 1;  // (:1249)
-                    if (warp_record(tb.rec + (size_t)ip * 11, a.max_iter_num, a.IP_dx, x, y, z, pw, &dist)) flags |= 2;
+                    if (warp_record<MULTI>(tb.rec + (size_t)ip * 11, a.max_iter_num, a.IP_dx, x, y, z, pw, &dist)) flags |= 2;
                 }
                 float ps[9], dk[3];
                 int fl[3];
@@ -264,7 +270,8 @@ __device__ inline uint32_t march_group(const MarchParams& a, const March2Tables&
         const int ny = (int)clampf((float)(0.5 * (double)(y * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
         const int nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
         const uint32_t vox = (uint32_t)(level * H3 + (float)morton3D(nx, ny, nz));
-        const bool occ = a.grid[vox / 8] & (1 << (vox % 8));
+        // the occupancy bit only matters when an IP was found (`occ && found`), so the load is skipped otherwise
+        const bool occ = found ? (bool)(a.grid[vox / 8] & (1 << (vox % 8))) : false;
 
         if (occ && found) {
             t += dt;

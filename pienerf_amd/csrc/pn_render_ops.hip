@@ -310,8 +310,8 @@ struct MarchIO {
 };
 
 // 8 lanes per ray, 32 rays per 256-thread block.
-template <int K>
-__global__ void __launch_bounds__(256) k_march(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
+template <int K, bool MULTI>
+__global__ void __launch_bounds__(256, 4) k_march(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
     uint32_t n_alive = io.n_alive, n_step = io.n_step;
     if (io.trip) { n_alive = (uint32_t)io.trip->n_alive; n_step = (uint32_t)io.trip->n_step; }
     if (blockIdx.x * 32u >= n_alive) return;  // whole block idle
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(256) k_march(pnm::MarchParams a, pnm2::March2T
         const int index = io.rays_alive[n];
         const float noise = io.noises ? io.noises[n] : 0.0f;
         dl = io.deltas + (size_t)n * n_step * 2;
-        emitted = pnm2::march_group<K>(a, tb, index, noise, n_step, sub, gbase, io.xyzs + (size_t)n * n_step * 3, io.dirs + (size_t)n * n_step * 3, dl);
+        emitted = pnm2::march_group<K, MULTI>(a, tb, index, noise, n_step, sub, gbase, io.xyzs + (size_t)n * n_step * 3, io.dirs + (size_t)n * n_step * 3, dl);
     }
     if (io.trip) {
         // slots the ray did not fill end it in composite (delta == 0); the op-level wrapper zero-fills instead (raymarching.py:415-417)
@@ -346,9 +346,10 @@ __global__ void __launch_bounds__(256) k_march(pnm::MarchParams a, pnm2::March2T
 }
 
 static void launch_march(int K, uint32_t blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb, const MarchIO& io) {
-    if (K == 1) k_march<1><<<blocks, 256, 0, st>>>(a, tb, io);
-    else if (K == 2) k_march<2><<<blocks, 256, 0, st>>>(a, tb, io);
-    else k_march<3><<<blocks, 256, 0, st>>>(a, tb, io);
+    const bool multi = a.max_iter_num > 1;
+    if (K == 1) { if (multi) k_march<1, true><<<blocks, 256, 0, st>>>(a, tb, io); else k_march<1, false><<<blocks, 256, 0, st>>>(a, tb, io); }
+    else if (K == 2) { if (multi) k_march<2, true><<<blocks, 256, 0, st>>>(a, tb, io); else k_march<2, false><<<blocks, 256, 0, st>>>(a, tb, io); }
+    else { if (multi) k_march<3, true><<<blocks, 256, 0, st>>>(a, tb, io); else k_march<3, false><<<blocks, 256, 0, st>>>(a, tb, io); }
 }
 
 static pnm::MarchParams make_march_params(const int* pig_cnt, const int* pig_bgn, const int* pig_idx, int n_vtx, int n_grid, const float* p_def,

@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""Runs a few sim+render steps of the 800x800 chair config (profiling target for rocprofv3).
+
+    python tools/run_frames.py [--frames 5] [--no-sim] [--W 800]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pienerf_amd import scene  # noqa: E402
+from pienerf_amd.harness import SimRenderHarness  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=5)
+ap.add_argument("--presim", type=int, default=20, help="untimed simulator steps first, so the rendered state is deformed")
+ap.add_argument("--no-sim", action="store_true")
+ap.add_argument("--W", type=int, default=800)
+args = ap.parse_args()
+opt = scene.default_opt(W=args.W, H=args.W)
+h = SimRenderHarness(opt, device="cuda:0")
+for _ in range(args.presim):
+    h.sim.stepforward()
+for _ in range(args.frames):
+    h.step(simulate=not args.no_sim, collect_stats=True)
+torch.cuda.synchronize()
+print(h.model.last_stats)
