@@ -159,8 +159,15 @@ def main():
         B = xyz.shape[0]
         u = ((xyz + m.bound) / (2 * m.bound)).contiguous()
         enc = m.encoder
-        t_grid = cuda_time_ms(lambda: grid_encode(u, enc.embeddings, enc.offsets, enc.per_level_scale, enc.base_resolution, False, 0, False, 0,
-                                                  offsets_host=enc._offsets_host))
+        from pienerf_amd._lib import check, lib, ptr, stream_ptr
+        feats = torch.empty(B * 32, device=dev)
+        S = float(np.float32(np.log2(enc.per_level_scale)))
+
+        def grid_launch(bl_major):
+            check(lib().pn_grid_encode_forward(ptr(u), ptr(enc.embeddings), enc._offsets_host.data_ptr(), ptr(feats), B, 3, 2, 16, S, 16, None, 0, 0, 0,
+                                               bl_major, stream_ptr()), "grid")
+        t_grid = cuda_time_ms(lambda: grid_launch(0))      # [L,B,C]: the reference kernel's own output layout (gridencoder.cu:105)
+        t_grid_bl = cuda_time_ms(lambda: grid_launch(1))   # [B,L*C] written directly (what grid.py:57 obtains with an extra permute pass)
         t_net = cuda_time_ms(lambda: m(xyz, dirs))
         t_sim = cuda_time_ms(lambda: h.sim.stepforward(), iters=10)
         t_frame = cuda_time_ms(lambda: h.step(simulate=False), iters=10)
@@ -179,8 +186,9 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(net_gbs / HBM_PEAK_GBS, 4), "traffic": None,
                          "launch_ms": round(t_net, 4), "samples": B, "mfma_tflops": round(net_tf, 2),
                          "mfma_frac_of_f32_peak": round(net_tf / F32_MFMA_PEAK_TF, 4)},
-            "hash_lookup": {"kernel": "k_grid_encode<2> (stand-alone hash-grid lookup)", "achieved_GBps": round(grid_gbs, 1),
-                            "frac_of_hbm_peak": round(grid_gbs / HBM_PEAK_GBS, 4), "launch_ms": round(t_grid, 4), "bytes_per_sample": HASH_BYTES_PER_SAMPLE},
+            "hash_lookup": {"kernel": "k_grid_encode<2> (stand-alone hash-grid lookup, output [L,B,C] like the reference kernel)",
+                            "achieved_GBps": round(grid_gbs, 1), "frac_of_hbm_peak": round(grid_gbs / HBM_PEAK_GBS, 4), "launch_ms": round(t_grid, 4),
+                            "bytes_per_sample": HASH_BYTES_PER_SAMPLE, "launch_ms_direct_BLC_output": round(t_grid_bl, 4)},
             "breakdown_ms": {"stepforward": round(t_sim, 4), "render_frame": round(t_frame, 4), "local_global_iters_per_s": round(opt["sim_iters"] / (t_sim * 1e-3), 1)},
         }
         if not args.no_cpu_baseline:

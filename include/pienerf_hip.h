@@ -65,8 +65,9 @@ uint32_t pn_compact_scratch_ints(uint32_t n);
 int pn_pnts_in_grids(int n_vtx, int n_grid, const float* pnts, const float* bbmin, float hgs, const int* resolution, int* pig_cnt, int* pig_bgn,
                      int* pig_idx, int* err_flag, void* stream);
 
-/* nerf/utils.py:54-138 get_rays, N=-1 path.  pose [host]: row-major 4x4 cam2world.  rays_o/rays_d [H*W,3]. */
-int pn_get_rays(const float* pose_host, float fx, float fy, float cx, float cy, int H, int W, float* rays_o, float* rays_d, void* stream);
+/* nerf/utils.py:54-138 get_rays, N=-1 path.  pose: device pointer to the row-major 4x4 cam2world (the reference's `poses[0]`).
+ * rays_o/rays_d [H*W,3]. */
+int pn_get_rays(const float* pose, float fx, float fy, float cx, float cy, int H, int W, float* rays_o, float* rays_d, void* stream);
 
 /* ------------------------------------------------------------------ gridencoder ---- */
 

@@ -47,6 +47,8 @@ struct PnGridLevels {
     uint32_t nomod[PN_MAX_LEVELS];         // 1 when the direct index is provably < hashmap_size (no modulo needed)
 };
 
+struct PnFusedLevel { float scale; uint32_t offset, m1, m2, mask, dense; uint32_t pad[2]; };  // see pn_nerf_forward.hip
+
 int pn_fill_grid_levels(PnGridLevels* g, const int* offsets_host, uint32_t L, uint32_t C, float S, uint32_t H, uint32_t gridtype,
                         int align_corners);
 
@@ -55,6 +57,7 @@ struct pn_net {
     PnGridLevels levels;
     const float* embeddings;  // device, not owned
     float* wpack;             // device, owned: MFMA A-operand stream, [PN_NET_MFMAS][64]
+    void* fused_levels;       // device, owned: PnFusedLevel[16] (pn_nerf_forward.hip)
     float bound;
 };
 #define PN_NET_MFMAS 192

@@ -12,6 +12,7 @@
 //   The D layout of one layer is exactly the B layout of the next (rows i and i+4 pair up), so activations never
 //   leave registers; the only LDS traffic is the 48 KB weight stream shared by all waves of a workgroup.
 #include <math.h>
+#include <stdlib.h>
 
 #include "pn_common.h"
 
@@ -222,8 +223,15 @@ extern "C" int pn_net_create(pn_net** out, const float* embeddings, const int* o
     PN_REQUIRE(L == 16 && C == 2);  // the architecture of nerf/network.py:14-95 / nerf/encoding.py:40-70
     pn_net* n = new pn_net();
     if (pn_fill_grid_levels(&n->levels, offsets_host, L, C, per_level_scale_log2, base_resolution, 0, 0)) { delete n; return PN_ERR_ARG; }
-    for (uint32_t l = 0; l < L; l++)
-        if (n->levels.dense[l] != 0 && n->levels.dense[l] != 3) { delete n; PN_REQUIRE(!"partially strided level"); }
+    PnFusedLevel fl[16];
+    for (uint32_t l = 0; l < L; l++) {
+        const PnGridLevels& g = n->levels;
+        const bool dense = g.dense[l] == 3 && g.nomod[l];
+        const bool hashed = g.dense[l] == 0 && g.mask[l] != 0;
+        if (!dense && !hashed) { delete n; PN_REQUIRE(!"level is neither fully dense nor hashed into a power-of-two table"); }
+        const uint32_t s1 = g.resolution[l] + 1;
+        fl[l] = PnFusedLevel{g.scale[l], g.offset[l], dense ? s1 : 2654435761u, dense ? s1 * s1 : 805459861u, g.mask[l], dense ? 1u : 0u, {0, 0}};
+    }
     n->embeddings = embeddings;
     n->bound = bound;
     float* host = new float[PN_NET_MFMAS * 64];
@@ -233,6 +241,8 @@ extern "C" int pn_net_create(pn_net** out, const float* embeddings, const int* o
     for (int m = 0; m < PN_NET_MFMAS; m++)
         for (int l = 0; l < 64; l++) img[((m >> 2) * 64 + l) * 4 + (m & 3)] = host[m * 64 + l];
     hipError_t e = hipMalloc((void**)&n->wpack, sizeof(float) * PN_NET_MFMAS * 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&n->fused_levels, sizeof(fl));
+    if (e == hipSuccess) e = hipMemcpyAsync(n->fused_levels, fl, sizeof(fl), hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e == hipSuccess) e = hipMemcpyAsync(n->wpack, img, sizeof(float) * PN_NET_MFMAS * 64, hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     delete[] host;
@@ -249,26 +259,37 @@ extern "C" int pn_net_create(pn_net** out, const float* embeddings, const int* o
 extern "C" void pn_net_destroy(pn_net* n) {
     if (!n) return;
     if (n->wpack) (void)hipFree(n->wpack);
+    if (n->fused_levels) (void)hipFree(n->fused_levels);
     delete n;
 }
 
 // 8 hash levels for one lane: feat[2j + c] = level (8h + j), channel c   (kernel_grid<float,3,2>, gridencoder.cu:87-197)
-__device__ __forceinline__ void encode8(const PnGridLevels& lv, const float* __restrict__ emb, int half, float u0, float u1, float u2, bool oob,
-                                        float* feat) {
-#pragma unroll
+// Per-level constants of the fused kernel, device-resident (scalar loads with a uniform index).  Every level is either
+// fully dense (index = g0 + g1*s + g2*s^2, provably < table size) or hashed into a power-of-two table
+// (index = (g0 ^ g1*P1 ^ g2*P2) & mask) — pn_net_create rejects anything else — so both cases share the form
+// t0 + t1 + t2 / (t0 ^ t1 ^ t2) & mask with t1 = g1*m1, t2 = g2*m2 and the +1 corner is t + m (uint32 wrap-around exact).
+// 8 hash levels for one lane: feat[2j + c] = level (8h + j), channel c   (kernel_grid<float,3,2>, gridencoder.cu:87-197)
+template <int LU>
+__device__ __forceinline__ void encode8(const PnFusedLevel* __restrict__ lv, const float* __restrict__ emb, int half, float u0, float u1, float u2,
+                                        bool oob, float* feat) {
+#pragma unroll(LU)
     for (int j = 0; j < 8; j++) {
-        const int level = half * 8 + j;
-        const float scale = lv.scale[level];
-        const LevelIdx LI = level_idx(lv, level, 0);
-        const float2* __restrict__ table = reinterpret_cast<const float2*>(emb) + lv.offset[level];
+        const PnFusedLevel A = lv[j], B = lv[j + 8];  // wave-uniform
+        const float scale = half ? B.scale : A.scale;
+        const uint32_t m1 = half ? B.m1 : A.m1, m2 = half ? B.m2 : A.m2, mask = half ? B.mask : A.mask;
+        const bool dense = (half ? B.dense : A.dense) != 0;
+        const float2* __restrict__ table = reinterpret_cast<const float2*>(emb) + (half ? B.offset : A.offset);
         float p0 = fmaf(u0, scale, 0.5f), p1 = fmaf(u1, scale, 0.5f), p2 = fmaf(u2, scale, 0.5f);
         const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
-        const uint32_t g0 = (uint32_t)f0, g1 = (uint32_t)f1, g2 = (uint32_t)f2;
         p0 -= f0; p1 -= f1; p2 -= f2;
+        const uint32_t t0[2] = {(uint32_t)f0, (uint32_t)f0 + 1u};
+        const uint32_t t1a = (uint32_t)f1 * m1, t2a = (uint32_t)f2 * m2;
+        const uint32_t t1[2] = {t1a, t1a + m1}, t2[2] = {t2a, t2a + m2};
         float2 v[8];
 #pragma unroll
         for (int idx = 0; idx < 8; idx++) {
-            const uint32_t index = grid_index3(LI, g0 + (idx & 1), g1 + ((idx >> 1) & 1), g2 + ((idx >> 2) & 1));
+            const uint32_t a0 = t0[idx & 1], a1 = t1[(idx >> 1) & 1], a2 = t2[(idx >> 2) & 1];
+            const uint32_t index = dense ? (a0 + a1 + a2) : ((a0 ^ a1 ^ a2) & mask);
             v[idx] = table[index];
         }
         float r0 = 0.f, r1 = 0.f;
@@ -294,8 +315,10 @@ __device__ __forceinline__ f32x16 relu16(f32x16 v) {
     return v;
 }
 
-// Workgroup = 4 waves; LDS = the 48 KB packed weight image.
-__global__ void __launch_bounds__(256) k_nerf_forward(PnGridLevels lv, const float* __restrict__ emb, const float* __restrict__ wpack, float bound,
+// Workgroup = 4 waves; LDS = the 48 KB packed weight image.  MINW = waves per SIMD the register allocator must leave room
+// for; LU = how many hash levels' gathers are in flight per lane at once.
+template <int MINW, int LU>
+__global__ void __launch_bounds__(256, MINW) k_nerf_forward(const PnFusedLevel* __restrict__ lv, const float* __restrict__ emb, const float* __restrict__ wpack, float bound,
                                                       const float* __restrict__ xyzs, const float* __restrict__ dirs, const int* __restrict__ list,
                                                       const int* __restrict__ count_dev, uint32_t M_arg, float density_scale,
                                                       float* __restrict__ sigmas, float* __restrict__ rgbs) {
@@ -327,8 +350,9 @@ __global__ void __launch_bounds__(256) k_nerf_forward(PnGridLevels lv, const flo
         const float u0 = (x + bound) / (2 * bound), u1 = (y + bound) / (2 * bound), u2 = (z + bound) / (2 * bound);
         const bool oob = (u0 < 0 || u0 > 1 || u1 < 0 || u1 > 1 || u2 < 0 || u2 > 1);
         float feat[16];
-        encode8(lv, emb, half, oob ? 0.f : u0, oob ? 0.f : u1, oob ? 0.f : u2, oob, feat);
+        encode8<LU>(lv, emb, half, oob ? 0.f : u0, oob ? 0.f : u1, oob ? 0.f : u2, oob, feat);
 
+        __builtin_amdgcn_sched_barrier(0);  // keep the next layer's LDS weight reads from being hoisted (register pressure)
         // ---- sigma net layer 0: 32 -> 64, ReLU
         f32x16 a0 = {0}, a1 = {0};
 #pragma unroll
@@ -349,6 +373,7 @@ __global__ void __launch_bounds__(256) k_nerf_forward(PnGridLevels lv, const flo
         }
         a0 = relu16(a0);
         a1 = relu16(a1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the next layer's LDS weight reads from being hoisted (register pressure)
         // ---- sigma net layer 1: 64 -> 16
         f32x16 h2 = {0};
 #pragma unroll
@@ -368,6 +393,7 @@ __global__ void __launch_bounds__(256) k_nerf_forward(PnGridLevels lv, const flo
             h2 = PN_MFMA(w.w, a1[4 * g + 3], h2);
         }
         const float sigma_logit = h2[0];  // row 0 lives in the low half's register 0
+        __builtin_amdgcn_sched_barrier(0);  // keep the next layer's LDS weight reads from being hoisted (register pressure)
         // ---- colour net input: 16 values per lane (see PN_MAPL / PN_MAPU)
         float sh[16];
         sh16(dx, dy, dz, sh);
@@ -378,6 +404,7 @@ __global__ void __launch_bounds__(256) k_nerf_forward(PnGridLevels lv, const flo
 #pragma unroll
         for (int k = 8; k < 15; k++) v[k] = half ? sh[k + 1] : sh[k - 7];
         v[15] = half ? 0.0f : sh[8];
+        __builtin_amdgcn_sched_barrier(0);  // keep the next layer's LDS weight reads from being hoisted (register pressure)
         // ---- colour layer 0: 31 -> 64, ReLU
         f32x16 c0 = {0}, c1 = {0};
 #pragma unroll
@@ -398,6 +425,7 @@ __global__ void __launch_bounds__(256) k_nerf_forward(PnGridLevels lv, const flo
         }
         c0 = relu16(c0);
         c1 = relu16(c1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the next layer's LDS weight reads from being hoisted (register pressure)
         // ---- colour layer 1: 64 -> 64, ReLU
         f32x16 d0 = {0}, d1 = {0};
 #pragma unroll
@@ -422,6 +450,7 @@ __global__ void __launch_bounds__(256) k_nerf_forward(PnGridLevels lv, const flo
         }
         d0 = relu16(d0);
         d1 = relu16(d1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the next layer's LDS weight reads from being hoisted (register pressure)
         // ---- colour layer 2: 64 -> 3
         f32x16 e = {0};
 #pragma unroll
@@ -450,8 +479,21 @@ int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* di
     uint32_t blocks = pn_div_up(tiles, 4);
     if (blocks > 768) blocks = 768;  // 3 workgroups per CU (48 KB LDS each) x 256 CUs; waves stride over tiles
     const size_t lds = sizeof(float) * PN_NET_MFMAS * 64;
-    k_nerf_forward<<<blocks, 256, lds, stream>>>(net->levels, net->embeddings, net->wpack, net->bound, xyzs, dirs, list, ctl_count, M_max,
-                                                density_scale, sigmas, rgbs);
+    static int variant = -1;
+    if (variant < 0) { const char* e = getenv("PN_NERF_VARIANT"); variant = e ? atoi(e) : 0; }
+#define PN_NF_LAUNCH(MINW, LU) k_nerf_forward<MINW, LU><<<blocks, 256, lds, stream>>>((const PnFusedLevel*)net->fused_levels, net->embeddings, net->wpack, net->bound, xyzs, dirs, \
+                                                                                       list, ctl_count, M_max, density_scale, sigmas, rgbs)
+    switch (variant) {
+        case 1: PN_NF_LAUNCH(1, 8); break;
+        case 2: PN_NF_LAUNCH(2, 8); break;
+        case 3: PN_NF_LAUNCH(2, 4); break;
+        case 4: PN_NF_LAUNCH(3, 4); break;
+        case 5: PN_NF_LAUNCH(3, 2); break;
+        case 6: PN_NF_LAUNCH(4, 2); break;
+        case 7: PN_NF_LAUNCH(4, 1); break;
+        default: PN_NF_LAUNCH(2, 4); break;
+    }
+#undef PN_NF_LAUNCH
     PN_LAUNCH_CHECK();
     return PN_OK;
 }

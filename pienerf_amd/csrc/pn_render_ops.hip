@@ -57,10 +57,10 @@ extern "C" int pn_near_far_from_aabb(const float* rays_o, const float* rays_d, c
 }
 
 // ------------------------------------------------------------------------------------------------ get_rays
-struct PnPose { float R[9]; float t[3]; };
-// nerf/utils.py:54-138 (N = -1): pixel p -> (i = p%W + .5, j = p/W + .5)
-__global__ void __launch_bounds__(256) k_get_rays(PnPose pose, float fx, float fy, float cx, float cy, int HW, int W, float* __restrict__ rays_o,
-                                                  float* __restrict__ rays_d) {
+// nerf/utils.py:54-138 (N = -1): pixel p -> (i = p%W + .5, j = p/W + .5).  pose: device pointer, row-major 4x4 cam2world
+// (the reference's `poses` is a device tensor too, so no host round trip is needed).
+__global__ void __launch_bounds__(256) k_get_rays(const float* __restrict__ pose, float fx, float fy, float cx, float cy, int HW, int W,
+                                                  float* __restrict__ rays_o, float* __restrict__ rays_d) {
     const int p = threadIdx.x + blockIdx.x * blockDim.x;
     if (p >= HW) return;
     const float i = (float)(p % W) + 0.5f, j = (float)(p / W) + 0.5f;
@@ -69,19 +69,13 @@ __global__ void __launch_bounds__(256) k_get_rays(PnPose pose, float fx, float f
     const float d0 = xs / nrm, d1 = ys / nrm, d2 = zs / nrm;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        rays_d[p * 3 + c] = d0 * pose.R[c * 3] + d1 * pose.R[c * 3 + 1] + d2 * pose.R[c * 3 + 2];
-        rays_o[p * 3 + c] = pose.t[c];
+        rays_d[p * 3 + c] = d0 * pose[c * 4] + d1 * pose[c * 4 + 1] + d2 * pose[c * 4 + 2];
+        rays_o[p * 3 + c] = pose[c * 4 + 3];
     }
 }
 
-extern "C" int pn_get_rays(const float* pose_host, float fx, float fy, float cx, float cy, int H, int W, float* rays_o, float* rays_d,
-                           void* stream) {
-    PN_REQUIRE(pose_host && rays_o && rays_d && H > 0 && W > 0);
-    PnPose pose;
-    for (int r = 0; r < 3; r++) {
-        for (int c = 0; c < 3; c++) pose.R[r * 3 + c] = pose_host[r * 4 + c];
-        pose.t[r] = pose_host[r * 4 + 3];
-    }
+extern "C" int pn_get_rays(const float* pose, float fx, float fy, float cx, float cy, int H, int W, float* rays_o, float* rays_d, void* stream) {
+    PN_REQUIRE(pose && rays_o && rays_d && H > 0 && W > 0);
     k_get_rays<<<pn_div_up((uint64_t)H * W, 256), 256, 0, (hipStream_t)stream>>>(pose, fx, fy, cx, cy, H * W, W, rays_o, rays_d);
     PN_LAUNCH_CHECK();
     return PN_OK;

@@ -21,7 +21,7 @@ from .simulator.solver import Simulator
 
 
 class SimRenderHarness:
-    def __init__(self, opt=None, cloud=None, ckpt=None, device="cuda"):
+    def __init__(self, opt=None, cloud=None, ckpt=None, device="cuda", overlap_sim=True):
         self.opt = dict(opt or scene.default_opt())
         o = self.opt
         self.device = torch.device(device)
@@ -46,6 +46,15 @@ class SimRenderHarness:
         self.pose = scene.orbit_pose(o["radius"])
         self.intrinsics = scene.orbit_intrinsics(o["W"], o["H"], o["fovy"])
         self._pose_dev = None
+        self.overlap_sim = overlap_sim
+        if overlap_sim:
+            self._sim_stream = torch.cuda.Stream(self.device)
+            self._ip_ready = torch.cuda.Event()
+            self._sim_done = torch.cuda.Event()
+            self._sim_done.record(torch.cuda.current_stream(self.device))
+
+    def synchronize(self):
+        torch.cuda.synchronize(self.device)
 
     def render_kwargs(self):
         """**vars(opt) as the reference passes it (trainer.py:318); renderer reads these by name."""
@@ -57,13 +66,27 @@ class SimRenderHarness:
         W, H = W or o["W"], H or o["H"]
         pose = self.pose if pose is None else pose
         intrinsics = self.intrinsics if intrinsics is None else intrinsics
-        pose_t = torch.from_numpy(np.asarray(pose, np.float32)).unsqueeze(0).to(self.device)   # trainer.py:541
-        rays = get_rays(pose_t, intrinsics, H, W, -1)
+        key = np.asarray(pose, np.float32).tobytes()
+        if self._pose_dev is None or self._pose_dev[0] != key:  # trainer.py:541 uploads the pose every frame; re-upload only when it changes
+            self._pose_dev = (key, torch.from_numpy(np.asarray(pose, np.float32)).unsqueeze(0).to(self.device))
+        rays = get_rays(self._pose_dev[1], intrinsics, H, W, -1)
         m = self.model
         if simulate:
+            main = torch.cuda.current_stream(self.device)
+            if self.overlap_sim:
+                main.wait_event(self._sim_done)            # the previous substep must have finished before dof is read
             IP_pos, IP_F, IP_dF = self.sim.get_IP_info()
             m.p_def, m.IP_F, m.IP_dF = IP_pos, IP_F, IP_dF
-            self.sim.stepforward()
+            if self.overlap_sim:
+                # the substep only feeds the NEXT frame (render lags sim by one frame, trainer.py:300-318), so it runs on a
+                # side stream concurrently with this frame's render
+                self._ip_ready.record(main)
+                self._sim_stream.wait_event(self._ip_ready)
+                with torch.cuda.stream(self._sim_stream):
+                    self.sim.stepforward()
+                    self._sim_done.record(self._sim_stream)
+            else:
+                self.sim.stepforward()
             self.frame += 1
         kw = self.render_kwargs()
         kw["collect_stats"] = collect_stats

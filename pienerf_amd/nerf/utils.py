@@ -16,10 +16,10 @@ def get_rays(poses, intrinsics, H, W, N=-1, error_map=None, patch_size=1):
         raise RuntimeError("get_rays: one pose per call (the GUI / render harness passes [1,4,4])")
     require_gpu(poses)
     fx, fy, cx, cy = (float(v) for v in intrinsics)
-    pose_host = np.ascontiguousarray(poses[0].detach().cpu().numpy(), dtype=np.float32)
+    pose = poses[0].detach().to(torch.float32).contiguous()
     rays_o = torch.empty(1, H * W, 3, dtype=torch.float32, device=poses.device)
     rays_d = torch.empty(1, H * W, 3, dtype=torch.float32, device=poses.device)
-    check(lib().pn_get_rays(pose_host.ctypes.data, fx, fy, cx, cy, int(H), int(W), ptr(rays_o), ptr(rays_d), stream_ptr()), "get_rays")
+    check(lib().pn_get_rays(ptr(pose), fx, fy, cx, cy, int(H), int(W), ptr(rays_o), ptr(rays_d), stream_ptr()), "get_rays")
     return {"rays_o": rays_o, "rays_d": rays_d}
 
 
