@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying the captured HIP graph")
+    ap.add_argument("--trips", type=int, default=8, help="render-loop trips baked into the captured graph")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -105,7 +107,13 @@ def main():
         torch.cuda.synchronize()
 
     if world == 1:
-        run_steps = lambda n: [h.step() for _ in range(n)]
+        # the whole step (get_rays, get_IP_info, stepforward on a forked stream, render prologue + 8 loop trips + epilogue) is one
+        # captured HIP graph; each replay re-checks that the previous frame left no ray alive
+        if args.eager:
+            run_steps = lambda n: [h.step() for _ in range(n)]
+        else:
+            h.capture(n_trips=args.trips)
+            run_steps = lambda n: [h.step_graph() for _ in range(n)]
     else:
         # frame-parallel (pienerf_amd/frames.py): rank 0 owns the simulator and broadcasts dof[30 n_k] per frame over RCCL;
         # frame f is rendered by rank f % world from the pre-step state.  `n` steps per rank = n * world frames in total.
@@ -138,6 +146,8 @@ def main():
         run_steps(args.steps)
         barrier()
         elapsed = time.perf_counter() - t0
+        if world == 1 and not args.eager:
+            h._check_previous_graph_frame()  # the last replayed frame must be complete too
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -132,6 +132,17 @@ int pn_render_deformed(pn_frame* f, const pn_net* net, const pn_render_opts* opt
                        const float* p_def, const float* p_ori, const float* F_IP, const float* dF_IP, int n_vtx, const uint8_t* bitfield,
                        float* image, float* depth, float* depth_0, float* weights_sum, int64_t* stats_host, void* stream);
 
+/* Non-blocking form of pn_render_deformed for HIP-graph capture / host run-ahead: enqueues exactly n_trips loop trips
+ * (trips past the last alive ray cost ~20 us each), the epilogue and an asynchronous copy of the trip records to pinned host
+ * memory.  Never synchronises.  The frame is complete iff pn_render_status reports 0 rays alive at exit; otherwise render again
+ * with more trips. */
+int pn_render_deformed_async(pn_frame* f, const pn_net* net, const pn_render_opts* opts, const float* rays_o, const float* rays_d, uint32_t N,
+                             const float* p_def, const float* p_ori, const float* F_IP, const float* dF_IP, int n_vtx, const uint8_t* bitfield,
+                             float* image, float* depth, float* depth_0, float* weights_sum, int n_trips, void* stream);
+/* stats_host [host, int64[4]] = {trips with alive rays, emitted samples, error flags, rays alive at exit} of the last render on f.
+ * synchronize != 0: waits for `stream` first; 0: the caller guarantees the render has completed (e.g. through an event). */
+int pn_render_status(pn_frame* f, int64_t* stats_host, int synchronize, void* stream);
+
 /* ------------------------------------------------------------------ simulator ------ */
 
 /* Simulator.get_IP_info (simulator/solver.py:402-424) = update_F_kernel (simulator/cuda_utils.py:206-233) + the

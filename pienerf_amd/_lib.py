@@ -40,6 +40,8 @@ SIGNATURES = {
     "pn_frame_create": (i32, [C.POINTER(P), u32, u32, u32]),
     "pn_frame_destroy": (None, [P]),
     "pn_render_deformed": (i32, [P, P, C.POINTER(RenderOpts), P, P, u32, P, P, P, P, i32, P, P, P, P, P, P, P]),
+    "pn_render_deformed_async": (i32, [P, P, C.POINTER(RenderOpts), P, P, u32, P, P, P, P, i32, P, P, P, P, P, i32, P]),
+    "pn_render_status": (i32, [P, P, i32, P]),
     "pn_sim_update_F": (i32, [i32, P, P, P, P, P, P, P, P, P]),
     "pn_sim_calc_elastic": (i32, [i32, P, P, P, P, P, P, P]),
     "pn_sim_collect_rhs": (i32, [i32, f64, P, P, P, P, P, P, P, P, P, P]),

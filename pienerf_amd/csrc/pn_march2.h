@@ -155,6 +155,7 @@ __device__ inline uint32_t march_group(const MarchParams& a, const March2Tables&
     const float hi0 = (float)((double)bmax0 - 1e-6), hi1 = (float)((double)bmax1 - 1e-6), hi2 = (float)((double)bmax2 - 1e-6);
     const int r0 = a.resolution[0], r1 = a.resolution[1], r2 = a.resolution[2];
 
+    int cell_id = -1, cell_b = 0, cell_e = 0;
     while (t < far && step < n_step) {
         bool found = false;
         float x, y, z;
@@ -183,7 +184,10 @@ __device__ inline uint32_t march_group(const MarchParams& a, const March2Tables&
                 if (a.err_flag && sub == 0) atomicOr(a.err_flag, 1);
             } else {
                 const int gid = g2 * r1 * r0 + g1 * r0 + g0;
-                const int b = tb.nb_bgn[gid], e = tb.nb_bgn[gid + 1];
+                // consecutive steps usually stay in one 1.2*dx cell (a voxel skip is ~1/4 of it): reuse its list range, so a
+                // run of steps through IP-free space costs no memory access at all
+                if (gid != cell_id) { cell_id = gid; cell_b = tb.nb_bgn[gid]; cell_e = tb.nb_bgn[gid + 1]; }
+                const int b = cell_b, e = cell_e;
                 if (b == e) {
                     // no IP in the 27-cell neighbourhood: nothing found
                 } else if (K == 1) {  // find_closest_IP: own cell first, the 26 neighbours only if that found nothing (:986-1043)

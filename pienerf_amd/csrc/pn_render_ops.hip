@@ -551,6 +551,9 @@ struct pn_frame {
     float* cut_bounds;
     PnTrip* trips_pinned;  // host-pinned mirror
     PnFrameDev* dev_pinned;
+    float cut_bounds_host[6];
+    int cut_bounds_valid;
+    int last_trips;  // trips enqueued by the last render
 };
 
 // bbox of the deformed IPs +-1e-3 and the spatial-hash resolution (nerf/renderer.py:782-791), one workgroup.
@@ -648,17 +651,37 @@ extern "C" void pn_frame_destroy(pn_frame* f) {
     delete f;
 }
 
-extern "C" int pn_render_deformed(pn_frame* f, const pn_net* net, const pn_render_opts* o, const float* rays_o, const float* rays_d, uint32_t N,
-                                  const float* p_def, const float* p_ori, const float* F_IP, const float* dF_IP, int n_vtx,
-                                  const uint8_t* bitfield, float* image, float* depth, float* depth_0, float* weights_sum, int64_t* stats_host,
-                                  void* stream) {
+static void frame_stats(pn_frame* f, int64_t* stats_host) {
+    int64_t trips = 0, samples = 0;
+    const int t = f->last_trips;
+    for (int k = 0; k < t; k++) {
+        if (f->trips_pinned[k].n_alive > 0) trips++;
+        samples += f->trips_pinned[k].n_samples;
+    }
+    stats_host[0] = trips;
+    stats_host[1] = samples;
+    stats_host[2] = f->dev_pinned->err;
+    stats_host[3] = f->trips_pinned[t].n_alive;
+}
+
+// async_trips == 0: blocking form (trips are enqueued in batches until a readback shows no ray alive).
+// async_trips  > 0: exactly that many trips are enqueued, then the epilogue and an async copy of the trip records to pinned
+//                   host memory; nothing blocks the host and every call is legal inside a HIP-graph stream capture.
+static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, const float* rays_o, const float* rays_d, uint32_t N,
+                       const float* p_def, const float* p_ori, const float* F_IP, const float* dF_IP, int n_vtx, const uint8_t* bitfield, float* image,
+                       float* depth, float* depth_0, float* weights_sum, int64_t* stats_host, int async_trips, void* stream) {
     PN_REQUIRE(f && net && o && rays_o && rays_d && p_def && p_ori && F_IP && dF_IP && bitfield && image && depth && depth_0 && weights_sum);
     PN_REQUIRE(N > 0 && N <= f->max_rays && n_vtx > 0 && (uint32_t)n_vtx <= f->max_vtx);
     PN_REQUIRE(o->num_seek_IP >= 1 && o->num_seek_IP <= 3 && o->cascade >= 1 && o->cascade <= 8 && o->max_steps <= PN_MAX_TRIPS - PN_TRIP_BATCH);
+    PN_REQUIRE(async_trips >= 0 && async_trips <= PN_MAX_TRIPS);
     hipStream_t st = (hipStream_t)stream;
     const uint32_t nblk = pn_div_up(N, 256);
 
-    PN_HIP_CHECK(hipMemcpyAsync(f->cut_bounds, o->cut_bounds, 6 * sizeof(float), hipMemcpyHostToDevice, st));
+    if (!f->cut_bounds_valid || memcmp(f->cut_bounds_host, o->cut_bounds, sizeof(f->cut_bounds_host)) != 0) {  // uploaded only when it changes
+        memcpy(f->cut_bounds_host, o->cut_bounds, sizeof(f->cut_bounds_host));
+        PN_HIP_CHECK(hipMemcpyAsync(f->cut_bounds, f->cut_bounds_host, 6 * sizeof(float), hipMemcpyHostToDevice, st));
+        f->cut_bounds_valid = 1;
+    }
     PN_HIP_CHECK(hipMemsetAsync(weights_sum, 0, (size_t)N * 4, st));  // renderer.py:807-809
     PN_HIP_CHECK(hipMemsetAsync(depth_0, 0, (size_t)N * 4, st));
     PN_HIP_CHECK(hipMemsetAsync(image, 0, (size_t)N * 12, st));
@@ -687,7 +710,8 @@ extern "C" int pn_render_deformed(pn_frame* f, const pn_net* net, const pn_rende
     int t = 0;
     bool done = false;
     while (!done && t < PN_MAX_TRIPS) {
-        for (int k = 0; k < PN_TRIP_BATCH; k++, t++) {
+        const int batch = async_trips > 0 ? async_trips : PN_TRIP_BATCH;
+        for (int k = 0; k < batch; k++, t++) {
             int* cur = (t & 1) ? f->alive_b : f->alive_a;
             int* nxt = (t & 1) ? f->alive_a : f->alive_b;
             MarchIO io{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + t, f->list};
@@ -699,6 +723,7 @@ extern "C" int pn_render_deformed(pn_frame* f, const pn_net* net, const pn_rende
             k_compact<<<nblk, 256, 0, st>>>(cur, 0, f->chunk_counts, nxt, nullptr, f->trips + t, f->trips + t + 1, N, o->max_steps);
         }
         PN_LAUNCH_CHECK();
+        if (async_trips > 0) break;
         // one small readback per batch decides whether more trips are needed (the reference syncs every trip)
         PN_HIP_CHECK(hipMemcpyAsync(f->trips_pinned + t, f->trips + t, sizeof(PnTrip), hipMemcpyDeviceToHost, st));
         PN_HIP_CHECK(hipStreamSynchronize(st));
@@ -706,19 +731,37 @@ extern "C" int pn_render_deformed(pn_frame* f, const pn_net* net, const pn_rende
     }
     k_frame_finish<<<nblk, 256, 0, st>>>(N, o->bg_color, f->nears, f->fars, weights_sum, depth_0, image, depth);
     PN_LAUNCH_CHECK();
-    if (stats_host) {
+    f->last_trips = t;
+    if (async_trips > 0 || stats_host) {
         PN_HIP_CHECK(hipMemcpyAsync(f->trips_pinned, f->trips, sizeof(PnTrip) * (t + 1), hipMemcpyDeviceToHost, st));
         PN_HIP_CHECK(hipMemcpyAsync(f->dev_pinned, f->dev, sizeof(PnFrameDev), hipMemcpyDeviceToHost, st));
-        PN_HIP_CHECK(hipStreamSynchronize(st));
-        int64_t trips = 0, samples = 0;
-        for (int k = 0; k < t; k++) {
-            if (f->trips_pinned[k].n_alive > 0) trips++;
-            samples += f->trips_pinned[k].n_samples;
-        }
-        stats_host[0] = trips;
-        stats_host[1] = samples;
-        stats_host[2] = f->dev_pinned->err;
-        stats_host[3] = f->trips_pinned[t].n_alive;
     }
+    if (async_trips == 0 && stats_host) {
+        PN_HIP_CHECK(hipStreamSynchronize(st));
+        frame_stats(f, stats_host);
+    }
+    return PN_OK;
+}
+
+extern "C" int pn_render_deformed(pn_frame* f, const pn_net* net, const pn_render_opts* o, const float* rays_o, const float* rays_d, uint32_t N,
+                                  const float* p_def, const float* p_ori, const float* F_IP, const float* dF_IP, int n_vtx,
+                                  const uint8_t* bitfield, float* image, float* depth, float* depth_0, float* weights_sum, int64_t* stats_host,
+                                  void* stream) {
+    return render_impl(f, net, o, rays_o, rays_d, N, p_def, p_ori, F_IP, dF_IP, n_vtx, bitfield, image, depth, depth_0, weights_sum, stats_host, 0, stream);
+}
+
+extern "C" int pn_render_deformed_async(pn_frame* f, const pn_net* net, const pn_render_opts* o, const float* rays_o, const float* rays_d,
+                                        uint32_t N, const float* p_def, const float* p_ori, const float* F_IP, const float* dF_IP, int n_vtx,
+                                        const uint8_t* bitfield, float* image, float* depth, float* depth_0, float* weights_sum, int n_trips,
+                                        void* stream) {
+    PN_REQUIRE(n_trips > 0);
+    return render_impl(f, net, o, rays_o, rays_d, N, p_def, p_ori, F_IP, dF_IP, n_vtx, bitfield, image, depth, depth_0, weights_sum, nullptr, n_trips,
+                       stream);
+}
+
+extern "C" int pn_render_status(pn_frame* f, int64_t* stats_host, int synchronize, void* stream) {
+    PN_REQUIRE(f && stats_host);
+    if (synchronize) PN_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    frame_stats(f, stats_host);
     return PN_OK;
 }

@@ -97,6 +97,73 @@ class SimRenderHarness:
         return {"image": out["image"].reshape(-1, H, W, 3), "depth": out["depth"].reshape(-1, H, W), "depth_0": out["depth_0"].reshape(-1, H, W),
                 "rays_o": rays["rays_o"], "rays_d": rays["rays_d"]}
 
+    # ------------------------------------------------------------------ whole step as one HIP graph
+    def _step_body(self, n_trips, W, H):
+        """get_rays -> get_IP_info -> { stepforward || render_deformed } with fork/join on the current stream (capturable)."""
+        m = self.model
+        main = torch.cuda.current_stream(self.device)
+        rays = get_rays(self._graph_pose, self.intrinsics, H, W, -1)
+        IP_pos, IP_F, IP_dF = self.sim.get_IP_info()
+        m.p_def, m.IP_F, m.IP_dF = IP_pos, IP_F, IP_dF
+        self._sim_stream.wait_stream(main)
+        with torch.cuda.stream(self._sim_stream):
+            self.sim.stepforward()
+        kw = self.render_kwargs()
+        kw["async_trips"] = n_trips
+        out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **kw)
+        main.wait_stream(self._sim_stream)
+        return {"image": out["image"].reshape(-1, H, W, 3), "depth": out["depth"].reshape(-1, H, W), "depth_0": out["depth_0"].reshape(-1, H, W),
+                "rays_o": rays["rays_o"], "rays_d": rays["rays_d"]}
+
+    @torch.no_grad()
+    def capture(self, n_trips=8, W=None, H=None):
+        """Captures one whole step (~85 kernel launches on two streams) into a HIP graph.  `n_trips` render-loop trips are
+        baked in (the chair needs 5); step_graph() verifies afterwards that no ray was left alive."""
+        o = self.opt
+        W, H = W or o["W"], H or o["H"]
+        if not hasattr(self, "_sim_stream"):
+            self._sim_stream = torch.cuda.Stream(self.device)
+        self._graph_pose = torch.from_numpy(np.asarray(self.pose, np.float32)).unsqueeze(0).to(self.device)
+        keep = (self.sim.dof.clone(), self.sim.dof_vel.clone())
+        warm = torch.cuda.Stream(self.device)
+        warm.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(warm):
+            for _ in range(2):  # warm-up outside capture: lazily created handles, allocator pools
+                self._step_body(n_trips, W, H)
+        torch.cuda.current_stream(self.device).wait_stream(warm)
+        torch.cuda.synchronize(self.device)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._graph_out = self._step_body(n_trips, W, H)
+        self.sim.dof.copy_(keep[0])       # warm-up advanced the simulator; capture itself executes nothing
+        self.sim.dof_vel.copy_(keep[1])
+        self._graph_trips = n_trips
+        self._graph_done = None
+        return self
+
+    @torch.no_grad()
+    def step_graph(self, pose=None):
+        """Replays the captured step.  Outputs are static tensors (overwritten by the next replay)."""
+        if getattr(self, "_graph", None) is None:
+            self.capture()
+        self._check_previous_graph_frame()
+        if pose is not None:
+            self._graph_pose.copy_(torch.from_numpy(np.asarray(pose, np.float32)).unsqueeze(0))
+        self._graph.replay()
+        self._graph_done = torch.cuda.Event()
+        self._graph_done.record(torch.cuda.current_stream(self.device))
+        self.frame += 1
+        return self._graph_out
+
+    def _check_previous_graph_frame(self):
+        if getattr(self, "_graph_done", None) is not None:
+            self._graph_done.synchronize()  # normally long complete: the host only ever runs one frame ahead
+            st = self.model.render_status(synchronize=False)
+            self._graph_done = None
+            if st["alive_at_exit"] > 0:
+                raise RuntimeError(f"captured step ran {self._graph_trips} render trips but {st['alive_at_exit']} rays were still alive: "
+                                   "re-capture with more trips (harness.capture(n_trips=...))")
+
     def to_host(self, out):
         """The reference's device->host boundary (trainer.py:589-592)."""
         return {k: out[k][0].detach().cpu().numpy() for k in ("image", "depth", "depth_0")}

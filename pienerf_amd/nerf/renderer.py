@@ -116,16 +116,36 @@ class NeRFRenderer(nn.Module):
         depth = torch.empty(N, dtype=torch.float32, device=device)
         depth_0 = torch.empty(N, dtype=torch.float32, device=device)
         weights_sum = torch.empty(N, dtype=torch.float32, device=device)
-        stats = (C.c_int64 * 4)() if kwargs.get("collect_stats") else None
-        check(lib().pn_render_deformed(self._frame_handle(N, n_vtx, hgs), self._net_handle(), C.byref(o), ptr(rays_o), ptr(rays_d), N, ptr(p_def),
-                                       ptr(p_ori), ptr(F_IP), ptr(dF_IP), n_vtx, ptr(self.density_bitfield), ptr(image), ptr(depth), ptr(depth_0),
-                                       ptr(weights_sum), stats, stream_ptr()), "render_deformed")
-        if stats is not None:
-            self.last_stats = dict(trips=int(stats[0]), samples=int(stats[1]), err=int(stats[2]), alive_at_exit=int(stats[3]))
-            if stats[2]:
-                raise RuntimeError(f"render_deformed: device error flags {int(stats[2])} (1: sample cell outside the spatial hash, "
-                                   "2: IP outside it, 4: spatial-hash capacity exceeded)")
+        async_trips = int(kwargs.get("async_trips") or 0)
+        frame, net = self._frame_handle(N, n_vtx, hgs), self._net_handle()
+        if async_trips > 0:
+            # non-blocking: a fixed number of trips, no host synchronisation (legal under HIP-graph capture); completion is
+            # checked later with render_status()
+            check(lib().pn_render_deformed_async(frame, net, C.byref(o), ptr(rays_o), ptr(rays_d), N, ptr(p_def), ptr(p_ori), ptr(F_IP), ptr(dF_IP),
+                                                 n_vtx, ptr(self.density_bitfield), ptr(image), ptr(depth), ptr(depth_0), ptr(weights_sum),
+                                                 async_trips, stream_ptr()), "render_deformed_async")
+        else:
+            stats = (C.c_int64 * 4)() if kwargs.get("collect_stats") else None
+            check(lib().pn_render_deformed(frame, net, C.byref(o), ptr(rays_o), ptr(rays_d), N, ptr(p_def), ptr(p_ori), ptr(F_IP), ptr(dF_IP), n_vtx,
+                                           ptr(self.density_bitfield), ptr(image), ptr(depth), ptr(depth_0), ptr(weights_sum), stats, stream_ptr()),
+                  "render_deformed")
+            if stats is not None:
+                self._set_stats(stats)
         return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "depth_0": depth_0.view(*prefix), "weights_sum": weights_sum}
+
+    def _set_stats(self, stats):
+        self.last_stats = dict(trips=int(stats[0]), samples=int(stats[1]), err=int(stats[2]), alive_at_exit=int(stats[3]))
+        if stats[2]:
+            raise RuntimeError(f"render_deformed: device error flags {int(stats[2])} (1: sample cell outside the spatial hash, "
+                               "2: IP outside it, 4: spatial-hash capacity exceeded, 8: candidate-list capacity exceeded)")
+
+    def render_status(self, synchronize=True):
+        """Outcome of the last render on this model's frame workspace: dict(trips, samples, err, alive_at_exit).
+        After an async render, alive_at_exit > 0 means the enqueued trips were not enough."""
+        stats = (C.c_int64 * 4)()
+        check(lib().pn_render_status(self._frame, stats, int(bool(synchronize)), stream_ptr()), "render_status")
+        self._set_stats(stats)
+        return self.last_stats
 
     # ------------------------------------------------------------------ op-by-op loop (reference structure, renderer.py:755-907)
     def rund_cuda_ops(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-2, **kwargs):

@@ -337,3 +337,28 @@ def test_harness_step_matches_oracle_sequence(small_cloud, small_opt, ckpt):
         out = h.to_host(h.step())
         assert np.abs(out["image"].reshape(-1, 3) - r["image"]).max() < 2e-4, frame
     assert h.frame == 3
+
+
+def test_graph_replay_equals_eager_steps(small_cloud, small_opt, ckpt):
+    """The whole step captured as one HIP graph (sim on a forked stream, async render with a fixed trip count) replays to the
+    same images and the same DOF trajectory as the eager path (two harness instances differ only by the summation order of
+    the init-time matrix assembly, i.e. at round-off)."""
+    from pienerf_amd.harness import SimRenderHarness
+    opt = dict(small_opt, W=64, H=64)
+    eager = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV)
+    graph = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture(n_trips=8)
+    assert torch.equal(graph.sim.dof, eager.sim.dof)  # capture left the simulator state untouched
+    for frame in range(4):
+        a = eager.step()
+        eager.synchronize()
+        b = graph.step_graph()
+        graph.synchronize()
+        assert (a["image"] - b["image"]).abs().max() < 1e-5 and (a["depth_0"] - b["depth_0"]).abs().max() < 1e-4, frame
+        assert rel_err((graph.sim.dof - graph.sim.dof_rest).cpu().numpy(), (eager.sim.dof - eager.sim.dof_rest).cpu().numpy()) < 1e-7, frame
+    st = graph.model.render_status()
+    assert st["alive_at_exit"] == 0 and st["err"] == 0 and st["trips"] >= 3
+    # too few trips is detected, not silently accepted
+    short = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture(n_trips=1)
+    short.step_graph()
+    with pytest.raises(RuntimeError, match="still alive"):
+        short.step_graph()
