@@ -26,6 +26,7 @@
 #include <cstdint>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 #ifdef _OPENMP
@@ -223,7 +224,14 @@ struct MarchArgs {
 // One ray of kernel_march_rays_quadratic_bending, raymarching.cu:1121-1434.
 // Returns the number of samples written.  xyzs/dirs/deltas point at this
 // ray-slot's first sample.
+// optional instrumentation (ORC_MARCH_STATS=1): loop iterations per call / max per ray / iterations with candidates
+static long long g_march_iters = 0, g_march_found = 0;
+static int g_march_max = 0;
+static std::vector<int> g_march_hist(16, 0);
+static const bool g_march_stats = getenv("ORC_MARCH_STATS") != nullptr;
+
 uint32_t march_one(const MarchArgs& a, int index, float noise, float* xyzs, float* dirs, float* deltas, int* oob_flag) {
+    int iters = 0, iters_found = 0;
     const float* ro = a.rays_o + (size_t)index * 3;
     const float* rd = a.rays_d + (size_t)index * 3;
     const float ox = ro[0], oy = ro[1], oz = ro[2];
@@ -245,6 +253,7 @@ uint32_t march_one(const MarchArgs& a, int index, float noise, float* xyzs, floa
     const int* res = a.pg.res;
 
     while (t < far && step < a.n_step) {
+        iters++;
         bool found = false;
         float x, y, z;
         if (a.cut) {
@@ -275,6 +284,7 @@ uint32_t march_one(const MarchArgs& a, int index, float noise, float* xyzs, floa
                 }
             }
             found = n_IP > 0;
+            if (found) iters_found++;
             if (found) {
                 // quirks R7q-iii/iv: n_IP-- inside the loop it bounds; strict '<' on z only (:1246-1251)
                 for (int k = 0; k < n_IP; k++) {
@@ -355,6 +365,15 @@ uint32_t march_one(const MarchArgs& a, int index, float noise, float* xyzs, floa
             const float tz = (((nz + 0.5f + 0.5f * signf(dz)) * rH * 2 - 1) * mip_bound - z) * rdz;
             const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
             do { t += clampf(t * a.dt_gamma, dt_min, dt_max); } while (t < tt);
+        }
+    }
+    if (g_march_stats) {
+#pragma omp critical
+        {
+            g_march_iters += iters; g_march_found += iters_found;
+            if (iters > g_march_max) g_march_max = iters;
+            int b = 0; while ((1 << b) <= iters && b < 15) b++;
+            g_march_hist[b]++;
         }
     }
     return step;
@@ -615,6 +634,12 @@ int orc_march_rays_quadratic_bending(const int* pig_cnt, const int* pig_bgn, con
         int oob = 0;
         march_one(a, rays_alive[n], noises[n], xyzs + (size_t)n * n_step * 3, dirs + (size_t)n * n_step * 3, deltas + (size_t)n * n_step * 2, &oob);
         any_oob |= oob;
+    }
+    if (g_march_stats) {
+        fprintf(stderr, "[march] n_alive=%u n_step=%u iters=%lld found=%lld max/ray=%d hist(log2):", n_alive, n_step, g_march_iters, g_march_found, g_march_max);
+        for (int b = 0; b < 12; b++) fprintf(stderr, " %d", g_march_hist[b]);
+        fprintf(stderr, "\n");
+        g_march_iters = g_march_found = 0; g_march_max = 0; std::fill(g_march_hist.begin(), g_march_hist.end(), 0);
     }
     return any_oob;
 }

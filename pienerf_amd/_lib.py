@@ -42,6 +42,8 @@ SIGNATURES = {
     "pn_render_deformed": (i32, [P, P, C.POINTER(RenderOpts), P, P, u32, P, P, P, P, i32, P, P, P, P, P, P, P]),
     "pn_render_deformed_async": (i32, [P, P, C.POINTER(RenderOpts), P, P, u32, P, P, P, P, i32, P, P, P, P, P, i32, P]),
     "pn_render_status": (i32, [P, P, i32, P]),
+    "pn_frame_march_counters": (i32, [P, i32, P, P]),
+    "pn_frame_trip_times": (i32, [P, P, P, i32, P, P]),
     "pn_sim_update_F": (i32, [i32, P, P, P, P, P, P, P, P, P]),
     "pn_sim_calc_elastic": (i32, [i32, P, P, P, P, P, P, P]),
     "pn_sim_collect_rhs": (i32, [i32, f64, P, P, P, P, P, P, P, P, P, P]),

@@ -151,6 +151,7 @@ struct MarchParams {
     const uint8_t* grid;
     const float* fars;
     int* err_flag;
+    unsigned long long* stats;  // optional [4]: marching iterations, candidates scanned, IP warps, samples emitted (bench instrumentation)
 };
 
 // Inverse warp of the deformed-space point (x,y,z) through IP k (raymarching.cu:1262-1324): Newton on

@@ -156,7 +156,9 @@ __device__ inline uint32_t march_group(const MarchParams& a, const March2Tables&
     const int r0 = a.resolution[0], r1 = a.resolution[1], r2 = a.resolution[2];
 
     int cell_id = -1, cell_b = 0, cell_e = 0;
+    unsigned n_iter = 0, n_cand = 0, n_warp = 0;  // instrumentation, only reported when a.stats != nullptr
     while (t < far && step < n_step) {
+        n_iter++;
         bool found = false;
         float x, y, z;
         if (a.cut) {
@@ -188,6 +190,7 @@ __device__ inline uint32_t march_group(const MarchParams& a, const March2Tables&
                 // run of steps through IP-free space costs no memory access at all
                 if (gid != cell_id) { cell_id = gid; cell_b = tb.nb_bgn[gid]; cell_e = tb.nb_bgn[gid + 1]; }
                 const int b = cell_b, e = cell_e;
+                n_cand += (unsigned)(e - b);
                 if (b == e) {
                     // no IP in the 27-cell neighbourhood: nothing found
                 } else if (K == 1) {  // find_closest_IP: own cell first, the 26 neighbours only if that found nothing (:986-1043)
@@ -206,6 +209,7 @@ __device__ inline uint32_t march_group(const MarchParams& a, const March2Tables&
                 float pw[3] = {0.f, 0.f, 0.f}, dist = 0.f;
                 int flags = 0;  // bit0: pre-filter hit, bit1: reject
                 if (mine != -1) {
+                    n_warp++;
                     const float4 c = tb.nb[mine];
                     const int ip = __float_as_int(c.w);
                     if (c.x <= bmin0 || c.y <= bmin1 || c.z < bmin2 || c.x >= bmax0 || c.y >= bmax1 || c.z >= bmax2) flags |= 1;  // (:1249)
@@ -295,6 +299,10 @@ __device__ inline uint32_t march_group(const MarchParams& a, const March2Tables&
             const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
             do { t += clampf(t * a.dt_gamma, dt_min, dt_max); } while (t < tt);
         }
+    }
+    if (a.stats) {
+        if (sub == 0) { atomicAdd(a.stats, (unsigned long long)n_iter); atomicAdd(a.stats + 1, (unsigned long long)n_cand); atomicAdd(a.stats + 3, (unsigned long long)step); }
+        if (n_warp) atomicAdd(a.stats + 2, (unsigned long long)n_warp);
     }
     return step;
 }

@@ -358,6 +358,7 @@ static pnm::MarchParams make_march_params(const int* pig_cnt, const int* pig_bgn
     a.bbmin = bbmin; a.bbmax = bbmax; a.hgs = hgs; a.resolution = resolution; a.num_seek_IP = num_seek_IP; a.IP_dx = IP_dx;
     a.cut = cut; a.cut_bounds = cut_bounds; a.rays_t = rays_t; a.rays_o = rays_o; a.rays_d = rays_d;
     a.bound = bound; a.dt_gamma = dt_gamma; a.max_steps = max_steps; a.C = C; a.H = H; a.grid = grid; a.fars = fars; a.err_flag = err_flag;
+    a.stats = nullptr;
     return a;
 }
 
@@ -539,6 +540,7 @@ struct PnFrameDev {
 
 #define PN_MAX_TRIPS 1100
 #define PN_TRIP_BATCH 8
+#define PN_TIMED_TRIPS 64
 
 struct pn_frame {
     uint32_t max_rays, max_vtx, max_cells;
@@ -554,6 +556,10 @@ struct pn_frame {
     float cut_bounds_host[6];
     int cut_bounds_valid;
     int last_trips;  // trips enqueued by the last render
+    unsigned long long* march_counters;  // device [4], see MarchParams::stats
+    int march_counters_on;
+    hipEvent_t ev[PN_TIMED_TRIPS][3];    // measurement mode: before march / after march / after network, per trip
+    int timed_trips;
 };
 
 // bbox of the deformed IPs +-1e-3 and the spatial-hash resolution (nerf/renderer.py:782-791), one workgroup.
@@ -634,6 +640,7 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
     PN_ALLOC(f->side.nb, (size_t)f->side.nb_capacity * sizeof(float4)); PN_ALLOC(f->side.rec, (size_t)max_vtx * 44 * 4);
     PN_ALLOC(f->trips, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)); PN_ALLOC(f->dev, sizeof(PnFrameDev)); PN_ALLOC(f->cut_bounds, 6 * 4);
 #undef PN_ALLOC
+    PN_HIP_CHECK(hipMalloc((void**)&f->march_counters, 4 * sizeof(unsigned long long)));
     PN_HIP_CHECK(hipHostMalloc((void**)&f->trips_pinned, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)));
     PN_HIP_CHECK(hipHostMalloc((void**)&f->dev_pinned, sizeof(PnFrameDev)));
     *out = f;
@@ -644,8 +651,10 @@ extern "C" void pn_frame_destroy(pn_frame* f) {
     if (!f) return;
     void* ptrs[] = {f->nears, f->fars, f->rays_t, f->xyzs, f->dirs, f->deltas, f->sigmas, f->rgbs, f->alive_a, f->alive_b, f->list,
                     f->chunk_counts, f->pig_cnt, f->pig_bgn, f->pig_cursor, f->pig_idx, f->trips, f->dev, f->cut_bounds,
-                    f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, f->side.nb, f->side.rec};
+                    f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, f->side.nb, f->side.rec, f->march_counters};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int t = 0; t < PN_TIMED_TRIPS; t++)
+        for (int e = 0; e < 3; e++) if (f->ev[t][e]) (void)hipEventDestroy(f->ev[t][e]);
     if (f->trips_pinned) (void)hipHostFree(f->trips_pinned);
     if (f->dev_pinned) (void)hipHostFree(f->dev_pinned);
     delete f;
@@ -707,6 +716,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     pnm::MarchParams mp = make_march_params(f->pig_cnt, f->pig_bgn, f->pig_idx, n_vtx, 0, p_def, p_ori, F_IP, dF_IP, o->max_iter_num, bbmin, bbmax,
                                             o->hash_grid_size, res, o->num_seek_IP, o->IP_dx, o->cut, f->cut_bounds, f->rays_t, rays_o, rays_d,
                                             o->bound, o->dt_gamma, o->max_steps, o->cascade, o->grid_size, bitfield, f->fars, err);
+    mp.stats = (f->march_counters_on & 1) ? f->march_counters : nullptr;
     int t = 0;
     bool done = false;
     while (!done && t < PN_MAX_TRIPS) {
@@ -715,9 +725,17 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             int* cur = (t & 1) ? f->alive_b : f->alive_a;
             int* nxt = (t & 1) ? f->alive_a : f->alive_b;
             MarchIO io{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + t, f->list};
+            const bool timed = (f->march_counters_on & 2) && async_trips == 0 && t < PN_TIMED_TRIPS;
+            if (timed) {  // measurement mode: HIP events around the two heavy launches of each trip, on the launch stream
+                for (int e = 0; e < 3; e++)
+                    if (!f->ev[t][e]) PN_HIP_CHECK(hipEventCreate(&f->ev[t][e]));
+                PN_HIP_CHECK(hipEventRecord(f->ev[t][0], st));
+            }
             launch_march(o->num_seek_IP, pn_div_up(N, 32), st, mp, tb, io);
+            if (timed) PN_HIP_CHECK(hipEventRecord(f->ev[t][1], st));
             rc = pn_nerf_forward_launch(net, f->xyzs, f->dirs, f->list, &f->trips[t].n_samples, N, o->density_scale, f->sigmas, f->rgbs, st);
             if (rc) return rc;
+            if (timed) { PN_HIP_CHECK(hipEventRecord(f->ev[t][2], st)); f->timed_trips = t + 1; }
             k_composite<<<nblk, 256, 0, st>>>(0, 0, o->T_thresh, cur, f->rays_t, f->sigmas, f->rgbs, f->deltas, weights_sum, depth_0, image,
                                               f->trips + t, f->chunk_counts);
             k_compact<<<nblk, 256, 0, st>>>(cur, 0, f->chunk_counts, nxt, nullptr, f->trips + t, f->trips + t + 1, N, o->max_steps);
@@ -757,6 +775,30 @@ extern "C" int pn_render_deformed_async(pn_frame* f, const pn_net* net, const pn
     PN_REQUIRE(n_trips > 0);
     return render_impl(f, net, o, rays_o, rays_d, N, p_def, p_ori, F_IP, dF_IP, n_vtx, bitfield, image, depth, depth_0, weights_sum, nullptr, n_trips,
                        stream);
+}
+
+extern "C" int pn_frame_march_counters(pn_frame* f, int enable, uint64_t* counters_host, void* stream) {
+    PN_REQUIRE(f);
+    hipStream_t st = (hipStream_t)stream;
+    if (counters_host) {
+        PN_HIP_CHECK(hipMemcpyAsync(counters_host, f->march_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        PN_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    if ((enable & 1) && !(f->march_counters_on & 1)) PN_HIP_CHECK(hipMemsetAsync(f->march_counters, 0, 4 * sizeof(unsigned long long), st));
+    f->march_counters_on = enable & 3;  // bit 0: work counters, bit 1: per-trip event timing
+    return PN_OK;
+}
+
+extern "C" int pn_frame_trip_times(pn_frame* f, float* march_ms_host, float* network_ms_host, int max_trips, int* n_trips_out, void* stream) {
+    PN_REQUIRE(f && march_ms_host && network_ms_host && n_trips_out && max_trips >= 0);
+    PN_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    const int n = f->timed_trips < max_trips ? f->timed_trips : max_trips;
+    for (int t = 0; t < n; t++) {
+        PN_HIP_CHECK(hipEventElapsedTime(march_ms_host + t, f->ev[t][0], f->ev[t][1]));
+        PN_HIP_CHECK(hipEventElapsedTime(network_ms_host + t, f->ev[t][1], f->ev[t][2]));
+    }
+    *n_trips_out = n;
+    return PN_OK;
 }
 
 extern "C" int pn_render_status(pn_frame* f, int64_t* stats_host, int synchronize, void* stream) {

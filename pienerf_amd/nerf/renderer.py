@@ -139,6 +139,18 @@ class NeRFRenderer(nn.Module):
             raise RuntimeError(f"render_deformed: device error flags {int(stats[2])} (1: sample cell outside the spatial hash, "
                                "2: IP outside it, 4: spatial-hash capacity exceeded, 8: candidate-list capacity exceeded)")
 
+    def march_counters(self, enable, read=False):
+        """Measurement hook: device-side work counters of the march kernel (iterations, candidates, warps, samples)."""
+        out = (C.c_uint64 * 4)() if read else None
+        check(lib().pn_frame_march_counters(self._frame, int(enable), out, stream_ptr()), "march_counters")  # 1: counters, 2: event timing
+        return None if out is None else dict(iterations=int(out[0]), candidates=int(out[1]), warps=int(out[2]), samples=int(out[3]))
+
+    def trip_times(self):
+        """Per-trip (march_ms, network_ms) of the last blocking render made while march_counters were enabled (HIP events)."""
+        a, b, n = (C.c_float * 64)(), (C.c_float * 64)(), C.c_int(0)
+        check(lib().pn_frame_trip_times(self._frame, a, b, 64, C.byref(n), stream_ptr()), "trip_times")
+        return [float(a[i]) for i in range(n.value)], [float(b[i]) for i in range(n.value)]
+
     def render_status(self, synchronize=True):
         """Outcome of the last render on this model's frame workspace: dict(trips, samples, err, alive_at_exit).
         After an async render, alive_at_exit > 0 means the enqueued trips were not enough."""

@@ -18,12 +18,20 @@ ap.add_argument("--frames", type=int, default=5)
 ap.add_argument("--presim", type=int, default=20, help="untimed simulator steps first, so the rendered state is deformed")
 ap.add_argument("--no-sim", action="store_true")
 ap.add_argument("--W", type=int, default=800)
+ap.add_argument("--graph", action="store_true")
 args = ap.parse_args()
 opt = scene.default_opt(W=args.W, H=args.W)
 h = SimRenderHarness(opt, device="cuda:0")
 for _ in range(args.presim):
     h.sim.stepforward()
-for _ in range(args.frames):
-    h.step(simulate=not args.no_sim, collect_stats=True)
-torch.cuda.synchronize()
-print(h.model.last_stats)
+if args.graph:
+    h.capture(n_trips=8)
+    for _ in range(args.frames):
+        h.step_graph()
+    torch.cuda.synchronize()
+    print(h.model.render_status())
+else:
+    for _ in range(args.frames):
+        h.step(simulate=not args.no_sim, collect_stats=True)
+    torch.cuda.synchronize()
+    print(h.model.last_stats)
