@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying the captured HIP graph")
     ap.add_argument("--trips", type=int, default=8, help="render-loop trips baked into the captured graph")
+    ap.add_argument("--lanes", type=int, default=1, help="frames in flight on the GPU (1 = strictly one frame after the other)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -200,6 +201,10 @@ def main():
     if world == 1:
         if args.eager:
             run_steps = lambda n: [h.step() for _ in range(n)]
+        elif args.lanes > 1:
+            # `lanes` frames in flight: render(f+1) overlaps render(f) on a second stream, the simulator runs ahead (harness.capture_pipelined)
+            h.capture_pipelined(lanes=args.lanes, n_trips=args.trips)
+            run_steps = lambda n: [h.step_pipelined() for _ in range(n)]
         else:
             # the whole step (get_rays, get_IP_info, stepforward on a forked stream, render prologue + loop trips + epilogue) is one
             # captured HIP graph; each replay re-checks that the previous frame left no ray alive
@@ -237,8 +242,11 @@ def main():
         run_steps(args.steps)
         barrier()
         elapsed = time.perf_counter() - t0
-        if world == 1 and not args.eager:
-            h._check_previous_graph_frame()  # the last replayed frame must be complete too
+        if world == 1 and not args.eager:  # the last replayed frame(s) must be complete too
+            if args.lanes > 1:
+                h.drain_pipeline()
+            else:
+                h._check_previous_graph_frame()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -254,7 +262,7 @@ def main():
             "config": {"workload": "configs[1]: synthetic chair 800x800, sim_dx=0.05, sim_iters=10, num_seek_IP=3, max_iter_num=1, fp32, "
                                    "1 sim+render step per frame", "rays": opt["W"] * opt["H"], "n_IP": h.sim.n_IP, "n_kernels": h.sim.n_k,
                        "samples_per_frame": st["samples"], "trips_per_frame": st["trips"],
-                       "launch": "eager" if (args.eager or world > 1) else f"hip graph, {args.trips} trips",
+                       "launch": "eager" if (args.eager or world > 1) else f"hip graph, {args.trips} trips, {args.lanes} frame(s) in flight",
                        "parallelism": f"frame-parallel x{world}, DOF broadcast over RCCL" if world > 1 else "single GPU"},
             "roofline": roofline,
         }

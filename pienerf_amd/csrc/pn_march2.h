@@ -37,8 +37,13 @@ struct March2Tables {
 typedef unsigned long long key_t;
 #define PN_KEY_NONE 0xFFFFFFFFFFFFFFFFull
 __device__ __forceinline__ key_t make_key(float d, int ord) { return ((key_t)__float_as_uint(d) << 32) | (unsigned)ord; }
-__device__ __forceinline__ key_t shfl_xor_key(key_t k, int m) {
-    return ((key_t)(unsigned)__shfl_xor((int)(k >> 32), m) << 32) | (unsigned)__shfl_xor((int)(unsigned)k, m);
+// DPP lane exchange inside a row of 16: all 8 lanes of a group are active together, so every source lane is live.
+template <int CTRL>
+__device__ __forceinline__ key_t dpp_key(key_t k) {
+    const int lo = (int)(unsigned)k, hi = (int)(k >> 32);
+    const unsigned rlo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    const unsigned rhi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return ((key_t)rhi << 32) | rlo;
 }
 
 // Group-cooperative scan of nb[b..e): every lane of the group returns the same top-K list positions (-1 if none).
@@ -46,27 +51,33 @@ __device__ __forceinline__ key_t shfl_xor_key(key_t k, int m) {
 template <int K>
 __device__ __forceinline__ void group_topk(const float4* __restrict__ nb, int b, int e, int sub, float x, float y, float z, float dinit, int* ord_out) {
     key_t k0 = PN_KEY_NONE, k1 = PN_KEY_NONE, k2 = PN_KEY_NONE;  // this lane's sorted best
-    for (int j = b + sub; j < e; j += PN_G) {
-        const float4 v = nb[j];
-        const float ax = v.x - x, ay = v.y - y, az = v.z - z;
-        const float d = ax * ax + ay * ay + az * az;  // (pk_[0]-x)*(pk_[0]-x) + ... (raymarching.cu:1002)
-        if (d < dinit) {  // also rejects NaN, like the reference's `dist2_tmp < dist2`
-            const key_t k = make_key(d, j);
-            if (k < k0) { k2 = k1; k1 = k0; k0 = k; }
-            else if (K > 1 && k < k1) { k2 = k1; k1 = k; }
-            else if (K > 2 && k < k2) { k2 = k; }
+    // four list entries per lane are fetched before any is consumed (clamped index, masked afterwards): one memory round
+    // trip covers 32 candidates instead of 8
+    for (int j0 = b + sub; j0 < e; j0 += 4 * PN_G) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = nb[min(j0 + u * PN_G, e - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * PN_G;
+            const float ax = v[u].x - x, ay = v[u].y - y, az = v[u].z - z;
+            const float d = ax * ax + ay * ay + az * az;  // (pk_[0]-x)*(pk_[0]-x) + ... (raymarching.cu:1002)
+            if (j < e && d < dinit) {  // `d < dinit` also rejects NaN, like the reference's `dist2_tmp < dist2`
+                const key_t k = make_key(d, j);
+                if (k < k0) { k2 = k1; k1 = k0; k0 = k; }
+                else if (K > 1 && k < k1) { k2 = k1; k1 = k; }
+                else if (K > 2 && k < k2) { k2 = k; }
+            }
         }
     }
-    // K rounds of group-min: the lane that owns the winner pops it
+    // K rounds of group-min (DPP quad-perm / half-row mirror: VALU latency, no LDS crossbar); the owner of the winner pops it
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         if (r < K) {
             key_t m = k0;
-#pragma unroll
-            for (int s = 1; s < PN_G; s <<= 1) {
-                const key_t o = shfl_xor_key(m, s);
-                m = o < m ? o : m;
-            }
+            { key_t o = dpp_key<0xB1>(m); m = o < m ? o : m; }   // lane ^ 1
+            { key_t o = dpp_key<0x4E>(m); m = o < m ? o : m; }   // lane ^ 2
+            { key_t o = dpp_key<0x141>(m); m = o < m ? o : m; }  // lane <-> 7 - lane within each 8 (row_half_mirror)
             ord_out[r] = (m == PN_KEY_NONE) ? -1 : (int)(unsigned)m;
             if (m == k0 && m != PN_KEY_NONE) { k0 = k1; k1 = k2; k2 = PN_KEY_NONE; }
         } else {
@@ -155,6 +166,7 @@ __device__ inline uint32_t march_group(const MarchParams& a, const March2Tables&
     const float hi0 = (float)((double)bmax0 - 1e-6), hi1 = (float)((double)bmax1 - 1e-6), hi2 = (float)((double)bmax2 - 1e-6);
     const int r0 = a.resolution[0], r1 = a.resolution[1], r2 = a.resolution[2];
 
+    const float rbound = 1 / a.bound;
     int cell_id = -1, cell_b = 0, cell_e = 0;
     unsigned n_iter = 0, n_cand = 0, n_warp = 0;  // instrumentation, only reported when a.stats != nullptr
     while (t < far && step < n_step) {
@@ -272,8 +284,11 @@ __device__ inline uint32_t march_group(const MarchParams& a, const March2Tables&
 
         const float dt = clampf(t * a.dt_gamma, dt_min, dt_max);
         const int level = max(mip_from_pos(x, y, z, (float)C), mip_from_dt(dt, (float)H, (float)C));
-        const float mip_bound = fminf(scalbnf(1.0f, level), a.bound);
-        const float mip_rbound = 1 / mip_bound;
+        // mip_bound = fminf(2^level, bound); 1 / mip_bound is exact for the power of two and loop-invariant for `bound`
+        const float pw = scalbnf(1.0f, level);
+        const bool use_pw = pw <= a.bound;
+        const float mip_bound = use_pw ? pw : a.bound;
+        const float mip_rbound = use_pw ? scalbnf(1.0f, -level) : rbound;
         const int nx = (int)clampf((float)(0.5 * (double)(x * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
         const int ny = (int)clampf((float)(0.5 * (double)(y * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
         const int nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));

@@ -598,14 +598,23 @@ __global__ void __launch_bounds__(1024) k_frame_bbox(const float* __restrict__ p
     }
 }
 
-__global__ void __launch_bounds__(256) k_frame_init(PnTrip* trips, uint32_t N, int* alive, const PnFrameDev* dev) {
+// Per-frame initialisation done by kernels (not memset nodes): zeroed accumulators (renderer.py:807-809), rays_alive = arange(N)
+// (:828), zeroed trip records and trip 0 = (N rays, n_step 1).
+__global__ void __launch_bounds__(256) k_frame_init(PnTrip* trips, int n_trip_records, uint32_t N, int* alive, const PnFrameDev* dev,
+                                                    float* __restrict__ weights_sum, float* __restrict__ depth_0, float* __restrict__ image) {
     const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-    if (i < N) alive[i] = (int)i;  // rays_alive = arange(N) (renderer.py:828)
-    if (i == 0) {
-        trips[0].n_alive = dev->err ? 0 : (int)N;
-        trips[0].n_step = 1;  // max(min(N // N, 8), 1)
-        trips[0].step_base = 0;
-        trips[0].n_samples = 0;
+    if (i < N) {
+        alive[i] = (int)i;
+        weights_sum[i] = 0.f;
+        depth_0[i] = 0.f;
+        image[i * 3] = 0.f; image[i * 3 + 1] = 0.f; image[i * 3 + 2] = 0.f;
+    }
+    if (blockIdx.x == 0) {
+        for (int t = threadIdx.x; t < n_trip_records; t += blockDim.x) {
+            PnTrip r{0, 0, 0, 0};
+            if (t == 0) { r.n_alive = dev->err ? 0 : (int)N; r.n_step = 1; }  // max(min(N // N, 8), 1)
+            trips[t] = r;
+        }
     }
 }
 
@@ -691,10 +700,6 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
         PN_HIP_CHECK(hipMemcpyAsync(f->cut_bounds, f->cut_bounds_host, 6 * sizeof(float), hipMemcpyHostToDevice, st));
         f->cut_bounds_valid = 1;
     }
-    PN_HIP_CHECK(hipMemsetAsync(weights_sum, 0, (size_t)N * 4, st));  // renderer.py:807-809
-    PN_HIP_CHECK(hipMemsetAsync(depth_0, 0, (size_t)N * 4, st));
-    PN_HIP_CHECK(hipMemsetAsync(image, 0, (size_t)N * 12, st));
-    PN_HIP_CHECK(hipMemsetAsync(f->trips, 0, sizeof(PnTrip) * (PN_MAX_TRIPS + 2), st));
 
     k_frame_bbox<<<1, 1024, 0, st>>>(p_def, n_vtx, o->cut, o->bound, o->hash_grid_size, (int)f->max_cells, f->dev);
     const float* bbmin = f->dev->aabb;  // device addresses of struct members
@@ -710,7 +715,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     if (rc) return rc;
     pnm2::March2Tables tb{f->side.nb_bgn, f->side.nb, (const float4*)f->side.rec};
     k_near_far<<<nblk, 256, 0, st>>>(rays_o, rays_d, f->dev->aabb, N, o->min_near, f->nears, f->fars, f->rays_t);
-    k_frame_init<<<nblk, 256, 0, st>>>(f->trips, N, f->alive_a, f->dev);
+    k_frame_init<<<nblk, 256, 0, st>>>(f->trips, PN_MAX_TRIPS + 2, N, f->alive_a, f->dev, weights_sum, depth_0, image);
     PN_LAUNCH_CHECK();
 
     pnm::MarchParams mp = make_march_params(f->pig_cnt, f->pig_bgn, f->pig_idx, n_vtx, 0, p_def, p_ori, F_IP, dF_IP, o->max_iter_num, bbmin, bbmax,

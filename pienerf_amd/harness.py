@@ -112,8 +112,10 @@ class SimRenderHarness:
         kw["async_trips"] = n_trips
         out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **kw)
         main.wait_stream(self._sim_stream)
+        # every tensor the graph touches is returned (and so stays referenced): memory freed after capture would go back to the
+        # graph's pool and could be handed out again
         return {"image": out["image"].reshape(-1, H, W, 3), "depth": out["depth"].reshape(-1, H, W), "depth_0": out["depth_0"].reshape(-1, H, W),
-                "rays_o": rays["rays_o"], "rays_d": rays["rays_d"]}
+                "weights_sum": out["weights_sum"], "rays_o": rays["rays_o"], "rays_d": rays["rays_d"], "_ip": (IP_pos, IP_F, IP_dF)}
 
     @torch.no_grad()
     def capture(self, n_trips=8, W=None, H=None):
@@ -163,6 +165,105 @@ class SimRenderHarness:
             if st["alive_at_exit"] > 0:
                 raise RuntimeError(f"captured step ran {self._graph_trips} render trips but {st['alive_at_exit']} rays were still alive: "
                                    "re-capture with more trips (harness.capture(n_trips=...))")
+
+    # ------------------------------------------------------------------ several frames in flight on one GPU
+    @torch.no_grad()
+    def capture_pipelined(self, lanes=2, n_trips=8, W=None, H=None):
+        """Throughput mode: the render of frame f overlaps the render of frame f+1 (and the simulator runs ahead).
+
+        A render is a chain of short latency-bound launches whose tails leave most of the 256 CUs idle, so frames are
+        software-pipelined over `lanes` render streams.  Per lane: a *sim graph* (update_F into the lane's IP buffers, then
+        the substep) replayed on the simulator stream, and a *render graph* replayed on the lane's stream, ordered by events:
+            sim(f) after sim(f-1) [same stream] and after render(f-lanes) [the lane's buffers are free again];
+            render(f) after sim(f)'s update_F.
+        Every frame is still rendered from the state before its substep (trainer.py:300-318)."""
+        o, m, dev = self.opt, self.model, self.device
+        W, H = W or o["W"], H or o["H"]
+        self._pipe = dict(lanes=lanes, W=W, H=H, trips=n_trips, sim_graph=[], ren_graph=[], out=[], stream=[], ip_ready=[], done=[], pending=[])
+        p = self._pipe
+        self._graph_pose = torch.from_numpy(np.asarray(self.pose, np.float32)).unsqueeze(0).to(dev)
+        p["sim_stream"] = torch.cuda.Stream(dev)
+        keep = (self.sim.dof.clone(), self.sim.dof_vel.clone())
+        kw = self.render_kwargs()
+        kw["async_trips"] = n_trips
+        main = torch.cuda.current_stream(dev)
+        streams = [torch.cuda.Stream(dev) for _ in range(lanes)]
+        for lane in range(lanes):  # warm-up of every lane outside capture (creates the per-lane frame workspaces)
+            s = streams[lane]
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    ip = self.sim.get_IP_info()
+                    self.sim.stepforward()
+                    m.p_def, m.IP_F, m.IP_dF = ip
+                    rays = get_rays(self._graph_pose, self.intrinsics, H, W, -1)
+                    m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **dict(kw, frame_slot=lane))
+            torch.cuda.synchronize(dev)
+        for lane in range(lanes):
+            kw_l = dict(kw, frame_slot=lane)
+            s = streams[lane]
+            gs = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gs, stream=p["sim_stream"]):
+                ip = self.sim.get_IP_info()
+                self.sim.stepforward()
+            m.p_def, m.IP_F, m.IP_dF = ip  # the render graph of this lane reads the lane's own IP buffers
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=s):
+                rays = get_rays(self._graph_pose, self.intrinsics, H, W, -1)
+                out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **kw_l)
+            p["sim_graph"].append(gs)
+            p["ren_graph"].append(gr)
+            # every tensor the graphs touch stays referenced: a tensor freed after capture goes back to the graph's memory pool
+            # and may be handed out again
+            p.setdefault("keepalive", []).append((ip, rays, out))
+            p["out"].append({"image": out["image"].reshape(-1, H, W, 3), "depth": out["depth"].reshape(-1, H, W),
+                             "depth_0": out["depth_0"].reshape(-1, H, W)})
+            p["stream"].append(s)
+            p["ip_ready"].append(torch.cuda.Event())
+            ev = torch.cuda.Event()
+            ev.record(main)
+            p["done"].append(ev)
+            p["pending"].append(False)
+        torch.cuda.synchronize(dev)
+        self.sim.dof.copy_(keep[0])
+        self.sim.dof_vel.copy_(keep[1])
+        torch.cuda.synchronize(dev)
+        return self
+
+    @torch.no_grad()
+    def step_pipelined(self):
+        """Enqueues frame `self.frame` on its lane and returns that lane's (static) outputs; they are complete once the lane's
+        `done` event has fired (synchronize() / the next use of the lane)."""
+        p = self._pipe
+        lane = self.frame % p["lanes"]
+        if p["pending"][lane]:  # the lane's previous frame: finished?  (host runs at most `lanes` frames ahead)
+            p["done"][lane].synchronize()
+            st = self.model.render_status(synchronize=False, slot=lane)
+            if st["alive_at_exit"] > 0:
+                raise RuntimeError(f"pipelined step ran {p['trips']} render trips but {st['alive_at_exit']} rays were still alive")
+        sim_s, ren_s = p["sim_stream"], p["stream"][lane]
+        sim_s.wait_event(p["done"][lane])
+        with torch.cuda.stream(sim_s):
+            p["sim_graph"][lane].replay()
+            p["ip_ready"][lane].record(sim_s)
+        ren_s.wait_event(p["ip_ready"][lane])
+        with torch.cuda.stream(ren_s):
+            p["ren_graph"][lane].replay()
+            p["done"][lane].record(ren_s)
+        p["pending"][lane] = True
+        self.frame += 1
+        return p["out"][lane]
+
+    def drain_pipeline(self):
+        """Waits for every frame in flight and verifies each lane's last render completed."""
+        p = self._pipe
+        torch.cuda.synchronize(self.device)
+        for lane in range(p["lanes"]):
+            if p["pending"][lane]:
+                st = self.model.render_status(synchronize=False, slot=lane)
+                p["pending"][lane] = False
+                if st["alive_at_exit"] > 0:
+                    raise RuntimeError(f"pipelined step ran {p['trips']} render trips but {st['alive_at_exit']} rays were still alive")
 
     def to_host(self, out):
         """The reference's device->host boundary (trainer.py:589-592)."""

@@ -44,7 +44,7 @@ class NeRFRenderer(nn.Module):
             self.mean_count = 0
             self.local_step = 0
         self._frame = None
-        self._frame_key = None
+        self._frames = {}
         self.last_stats = None
 
     def forward(self, x, d):
@@ -62,18 +62,23 @@ class NeRFRenderer(nn.Module):
     def _ip_state(self, device):
         return [t.to(device=device, dtype=torch.float32).contiguous() for t in (self.p_def, self.p_ori, self.IP_F, self.IP_dF)]
 
-    def _frame_handle(self, N, n_vtx, hgs):
+    def _frame_handle(self, N, n_vtx, hgs, slot=0):
+        """Per-frame workspace (pn_frame).  `slot` selects one of several independent workspaces so that frames can be in
+        flight concurrently on different streams (harness.capture_pipelined)."""
         # spatial-hash capacity: the IP cloud lives inside the simulation box (2.04*bound per side, solver.py:24-32); x2 margin per axis
         side = int(math.ceil(2.2 * float(self.bound) / hgs)) + 2
         cells = side ** 3
         key = (N, n_vtx, cells)
-        if self._frame_key != key:
-            if self._frame is not None:
-                lib().pn_frame_destroy(self._frame)
+        cur = self._frames.get(slot)
+        if cur is None or cur[1] != key:
+            if cur is not None:
+                lib().pn_frame_destroy(cur[0])
             h = C.c_void_p()
             check(lib().pn_frame_create(C.byref(h), N, n_vtx, cells), "frame_create")
-            self._frame, self._frame_key = h, key
-        return self._frame
+            self._frames[slot] = (h, key)
+        if slot == 0:
+            self._frame = self._frames[0][0]
+        return self._frames[slot][0]
 
     # ------------------------------------------------------------------ fused loop
     def rund_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-2, **kwargs):
@@ -117,7 +122,7 @@ class NeRFRenderer(nn.Module):
         depth_0 = torch.empty(N, dtype=torch.float32, device=device)
         weights_sum = torch.empty(N, dtype=torch.float32, device=device)
         async_trips = int(kwargs.get("async_trips") or 0)
-        frame, net = self._frame_handle(N, n_vtx, hgs), self._net_handle()
+        frame, net = self._frame_handle(N, n_vtx, hgs, int(kwargs.get("frame_slot") or 0)), self._net_handle()
         if async_trips > 0:
             # non-blocking: a fixed number of trips, no host synchronisation (legal under HIP-graph capture); completion is
             # checked later with render_status()
@@ -151,11 +156,11 @@ class NeRFRenderer(nn.Module):
         check(lib().pn_frame_trip_times(self._frame, a, b, 64, C.byref(n), stream_ptr()), "trip_times")
         return [float(a[i]) for i in range(n.value)], [float(b[i]) for i in range(n.value)]
 
-    def render_status(self, synchronize=True):
-        """Outcome of the last render on this model's frame workspace: dict(trips, samples, err, alive_at_exit).
+    def render_status(self, synchronize=True, slot=0):
+        """Outcome of the last render on frame workspace `slot`: dict(trips, samples, err, alive_at_exit).
         After an async render, alive_at_exit > 0 means the enqueued trips were not enough."""
         stats = (C.c_int64 * 4)()
-        check(lib().pn_render_status(self._frame, stats, int(bool(synchronize)), stream_ptr()), "render_status")
+        check(lib().pn_render_status(self._frames[slot][0], stats, int(bool(synchronize)), stream_ptr()), "render_status")
         self._set_stats(stats)
         return self.last_stats
 
