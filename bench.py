@@ -169,7 +169,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying the captured HIP graph")
     ap.add_argument("--trips", type=int, default=8, help="render-loop trips baked into the captured graph")
-    ap.add_argument("--lanes", type=int, default=1, help="frames in flight on the GPU (1 = strictly one frame after the other)")
+    ap.add_argument("--lanes", type=int, default=2, help="frames in flight on the GPU (1 = strictly one frame after the other)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
