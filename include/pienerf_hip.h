@@ -143,13 +143,15 @@ int pn_render_deformed_async(pn_frame* f, const pn_net* net, const pn_render_opt
  * synchronize != 0: waits for `stream` first; 0: the caller guarantees the render has completed (e.g. through an event). */
 int pn_render_status(pn_frame* f, int64_t* stats_host, int synchronize, void* stream);
 
-/* Measurement hook (bench.py): while enabled, renders on f accumulate march work counters on the device —
- * {marching-loop iterations, candidate entries scanned, per-IP inverse warps, samples emitted} — the units behind the march
- * kernel's algorithmic-bytes figure.  counters_host (uint64[4], may be NULL): synchronises and reads the
- * totals accumulated so far (before any re-zeroing caused by enabling). */
+/* Measurement hook (bench.py).  `enable` is a bitmask: bit 0 (1) — renders on f accumulate march work counters on the device,
+ * {marching-loop iterations, candidate entries scanned, per-IP inverse warps, samples emitted}, the units behind the march
+ * kernel's algorithmic-bytes figure (the counters add atomics, so never time with this bit set);
+ * bit 1 (2) — blocking renders bracket each trip's march and network launches with HIP events (see pn_frame_trip_times);
+ * 0 switches both off.  counters_host (uint64[4], may be NULL): synchronises and reads the totals accumulated so far
+ * (before any re-zeroing caused by enabling). */
 int pn_frame_march_counters(pn_frame* f, int enable, uint64_t* counters_host, void* stream);
-/* While the counters are enabled, blocking renders also bracket each trip's march and network launches with HIP events on the
- * launch stream.  This returns the per-trip durations (ms) of the last such render: *n_trips_out entries in each array. */
+/* With bit 1 of `enable` set: the per-trip durations (ms, HIP events on the launch stream) of the last blocking render:
+ * *n_trips_out entries in each array. */
 int pn_frame_trip_times(pn_frame* f, float* march_ms_host, float* network_ms_host, int max_trips, int* n_trips_out, void* stream);
 
 /* ------------------------------------------------------------------ simulator ------ */
