@@ -16,8 +16,10 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # one hardware queue per stream (see pienerf_amd/__init__.py); before HIP initialises
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -182,7 +184,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying the captured HIP graph")
     ap.add_argument("--trips", type=int, default=8, help="render-loop trips baked into the captured graph")
-    ap.add_argument("--lanes", type=int, default=2, help="frames in flight on the GPU (1 = strictly one frame after the other)")
+    ap.add_argument("--lanes", type=int, default=3,
+                    help="renders in flight on the GPU (1 = strictly one frame after the other; 3 render streams + the simulator stream = the 4 "
+                         "compute pipes of an XCD, more streams only time-slice)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 

@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <algorithm>
 
 #include "../../include/pienerf_hip.h"
 
@@ -31,6 +34,13 @@ extern thread_local char pn_err_buf[512];
     } while (0)
 
 static inline uint32_t pn_div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+// Tuning override read from the environment (experiments only; the defaults are the shipped configuration).
+static inline uint32_t pn_env_u32(const char* name, uint32_t dflt) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    const long x = strtol(v, nullptr, 10);
+    return x > 0 ? (uint32_t)x : dflt;
+}
 
 // Per-level geometry of the multiresolution hash grid, derived on the host with the reference's formulas
 // (gridencoder/src/gridencoder.cu:132-134) so that host libm — not the GPU's approximate exp2 — fixes

@@ -15,6 +15,11 @@
 
 #include "pn_common.h"
 
+// The substep is a chain of ~30 short dependent launches that runs concurrently with the render kernels of other frames
+// (harness.capture_pipelined): its waves ask the SIMD arbiter for the highest user priority so the chain's latency does not
+// stretch when the CUs are full of march waves.
+#define PN_SIM_PRIO() __builtin_amdgcn_s_setprio(3)
+
 namespace {
 
 struct M3 { double m[3][3]; };
@@ -157,6 +162,7 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) {
 __global__ void __launch_bounds__(256) k_update_F(int n_IP, const int* __restrict__ topo, const double* __restrict__ dof, const double* __restrict__ Nx,
                                                   const double* __restrict__ dNx, const double* __restrict__ ddNx, float* __restrict__ pos,
                                                   float* __restrict__ F, float* __restrict__ dF) {
+    PN_SIM_PRIO();
     const int tid = threadIdx.x + blockIdx.x * blockDim.x;
     const int v = tid / 13, row = tid % 13;
     if (v >= n_IP) return;
@@ -200,6 +206,7 @@ extern "C" int pn_sim_update_F(int n_IP, const int* topo, const double* dof, con
 __global__ void __launch_bounds__(256) k_elastic(int n_IP, const int* __restrict__ topo, const double* __restrict__ dNx, const double* __restrict__ dof,
                                                  double* __restrict__ RF, double* __restrict__ VF, double* __restrict__ FF, double* __restrict__ P,
                                                  const double* __restrict__ mu, const double* __restrict__ lam, double dx3) {
+    PN_SIM_PRIO();
     const int tid = threadIdx.x + blockIdx.x * blockDim.x;
     const int v = tid >> 3, i = tid & 7;
     const bool live = v < n_IP;
@@ -269,6 +276,7 @@ __global__ void __launch_bounds__(256) k_rhs_gather(int n_k, double dx3, const i
                                                     const double* __restrict__ dNx, const double* __restrict__ RF, const double* __restrict__ VF,
                                                     const double* __restrict__ P, const double* __restrict__ momentum,
                                                     const double* __restrict__ rhs_rest, double* __restrict__ out) {
+    PN_SIM_PRIO();
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= n_k) return;
     const int lane = threadIdx.x & 63;
@@ -326,6 +334,7 @@ extern "C" int pn_sim_collect_rhs(int n_k, double dx, const int* csr_bg, const i
 // 2: Y = add1 + s (dof = dof_rest + x, solver.py:601).
 __global__ void __launch_bounds__(256) k_matvec3(int n, const double* __restrict__ A, const double* __restrict__ X, double* __restrict__ Y, int mode,
                                                  const double* __restrict__ add1, const double* __restrict__ add2) {
+    PN_SIM_PRIO();
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
     const int lane = threadIdx.x & 63;
@@ -362,6 +371,7 @@ extern "C" int pn_sim_matvec3(int n, const double* A, const double* X, double* Y
 // ------------------------------------------------------------------------------------------------ stepforward
 __global__ void __launch_bounds__(256) k_step_begin(int n3, double dt, const double* __restrict__ dof, const double* __restrict__ vel,
                                                     double* __restrict__ tilde, double* __restrict__ last) {
+    PN_SIM_PRIO();
     const int i = threadIdx.x + blockIdx.x * blockDim.x;
     if (i >= n3) return;
     const double d = dof[i];
@@ -370,6 +380,7 @@ __global__ void __launch_bounds__(256) k_step_begin(int n3, double dt, const dou
 }
 __global__ void __launch_bounds__(256) k_step_end(int n3, double dt, const double* __restrict__ dof, const double* __restrict__ last,
                                                   double* __restrict__ vel) {
+    PN_SIM_PRIO();
     const int i = threadIdx.x + blockIdx.x * blockDim.x;
     if (i >= n3) return;
     vel[i] = (dof[i] - last[i]) / dt * 0.998;  // solver.py:602

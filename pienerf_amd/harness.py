@@ -168,58 +168,71 @@ class SimRenderHarness:
 
     # ------------------------------------------------------------------ several frames in flight on one GPU
     @torch.no_grad()
-    def capture_pipelined(self, lanes=2, n_trips=8, W=None, H=None):
-        """Throughput mode: the render of frame f overlaps the render of frame f+1 (and the simulator runs ahead).
+    def capture_pipelined(self, lanes=2, n_trips=8, W=None, H=None, sim_ahead=None, sim_priority=0, _probe_no_substep=False):
+        """Throughput mode: `lanes` renders in flight on their own streams, the simulator running `sim_ahead` frames ahead.
 
-        A render is a chain of short latency-bound launches whose tails leave most of the 256 CUs idle, so frames are
-        software-pipelined over `lanes` render streams.  Per lane: a *sim graph* (update_F into the lane's IP buffers, then
-        the substep) replayed on the simulator stream, and a *render graph* replayed on the lane's stream, ordered by events:
-            sim(f) after sim(f-1) [same stream] and after render(f-lanes) [the lane's buffers are free again];
-            render(f) after sim(f)'s update_F.
-        Every frame is still rendered from the state before its substep (trainer.py:300-318)."""
+        A render is a chain of short latency-bound launches whose tails leave most of the 256 CUs idle, and the substep is a
+        serial chain of ~30 small launches; neither fills the GPU alone, so frames are software-pipelined:
+          * simulator stream: for frame g, `snap[g % slots] <- dof` (33 KB: the state frame g is rendered from), then the
+            captured substep graph.  It depends on nothing but itself, so it never waits for a render;
+          * lane stream l = f % lanes: update_F(snap[f % slots]) into the lane's IP buffers, then the lane's captured render
+            graph, after the snapshot's event.
+        The host enqueues frame f only after frame f - lanes completed (its outputs and buffers are reused), and keeps the
+        simulator `sim_ahead` (default: lanes) frames ahead of that.  Every frame is still rendered from the state before
+        its own substep (trainer.py:300-318); `self.sim.dof` is `sim_ahead + 1` substeps ahead of the last enqueued frame, and a
+        force set with update_force() acts from the next substep that is enqueued."""
         o, m, dev = self.opt, self.model, self.device
         W, H = W or o["W"], H or o["H"]
-        self._pipe = dict(lanes=lanes, W=W, H=H, trips=n_trips, sim_graph=[], ren_graph=[], out=[], stream=[], ip_ready=[], done=[], pending=[])
+        ahead = lanes if sim_ahead is None else int(sim_ahead)
+        slots = lanes + ahead + 1
+        self._pipe = dict(lanes=lanes, ahead=ahead, slots=slots, W=W, H=H, trips=n_trips, ren_graph=[], out=[], stream=[], done=[], pending=[], ip=[],
+                          keepalive=[], sim_next=0)
         p = self._pipe
         self._graph_pose = torch.from_numpy(np.asarray(self.pose, np.float32)).unsqueeze(0).to(dev)
-        p["sim_stream"] = torch.cuda.Stream(dev)
+        p["sim_stream"] = torch.cuda.Stream(dev, priority=sim_priority)
+        p["snap"] = [torch.empty_like(self.sim.dof) for _ in range(slots)]
+        p["snap_ready"] = [torch.cuda.Event() for _ in range(slots)]
         keep = (self.sim.dof.clone(), self.sim.dof_vel.clone())
         kw = self.render_kwargs()
         kw["async_trips"] = n_trips
         main = torch.cuda.current_stream(dev)
         streams = [torch.cuda.Stream(dev) for _ in range(lanes)]
+        n_IP = self.sim.n_IP
         for lane in range(lanes):  # warm-up of every lane outside capture (creates the per-lane frame workspaces)
             s = streams[lane]
             s.wait_stream(main)
+            ip = tuple(torch.empty((n_IP, c), dtype=torch.float32, device=dev) for c in (3, 9, 27))
+            p["ip"].append(ip)
             with torch.cuda.stream(s):
                 for _ in range(2):
-                    ip = self.sim.get_IP_info()
+                    self.sim.get_IP_info(out=ip)
                     self.sim.stepforward()
                     m.p_def, m.IP_F, m.IP_dF = ip
                     rays = get_rays(self._graph_pose, self.intrinsics, H, W, -1)
                     m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **dict(kw, frame_slot=lane))
             torch.cuda.synchronize(dev)
+        gs = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gs, stream=p["sim_stream"]):
+            if not _probe_no_substep:
+                self.sim.stepforward()
+            else:
+                self.sim.dof_vel.mul_(1.0)
+        p["sim_graph"] = gs
         for lane in range(lanes):
             kw_l = dict(kw, frame_slot=lane)
             s = streams[lane]
-            gs = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gs, stream=p["sim_stream"]):
-                ip = self.sim.get_IP_info()
-                self.sim.stepforward()
-            m.p_def, m.IP_F, m.IP_dF = ip  # the render graph of this lane reads the lane's own IP buffers
+            m.p_def, m.IP_F, m.IP_dF = p["ip"][lane]  # the render graph of this lane reads the lane's own IP buffers
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr, stream=s):
                 rays = get_rays(self._graph_pose, self.intrinsics, H, W, -1)
                 out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **kw_l)
-            p["sim_graph"].append(gs)
             p["ren_graph"].append(gr)
             # every tensor the graphs touch stays referenced: a tensor freed after capture goes back to the graph's memory pool
             # and may be handed out again
-            p.setdefault("keepalive", []).append((ip, rays, out))
+            p["keepalive"].append((rays, out))
             p["out"].append({"image": out["image"].reshape(-1, H, W, 3), "depth": out["depth"].reshape(-1, H, W),
                              "depth_0": out["depth_0"].reshape(-1, H, W)})
             p["stream"].append(s)
-            p["ip_ready"].append(torch.cuda.Event())
             ev = torch.cuda.Event()
             ev.record(main)
             p["done"].append(ev)
@@ -242,17 +255,29 @@ class SimRenderHarness:
             if st["alive_at_exit"] > 0:
                 raise RuntimeError(f"pipelined step ran {p['trips']} render trips but {st['alive_at_exit']} rays were still alive")
         sim_s, ren_s = p["sim_stream"], p["stream"][lane]
-        sim_s.wait_event(p["done"][lane])
+        # simulator: substeps up to frame + ahead.  Snapshot slot g % slots was last read by frame g - slots <= frame - lanes - 1,
+        # which the host has already seen complete (above), so the simulator stream waits for nothing.
         with torch.cuda.stream(sim_s):
-            p["sim_graph"][lane].replay()
-            p["ip_ready"][lane].record(sim_s)
-        ren_s.wait_event(p["ip_ready"][lane])
+            while p["sim_next"] <= self.frame + p["ahead"]:
+                slot = p["sim_next"] % p["slots"]
+                p["snap"][slot].copy_(self.sim.dof)
+                p["snap_ready"][slot].record(sim_s)
+                p["sim_graph"].replay()
+                p["sim_next"] += 1
+        slot = self.frame % p["slots"]
+        ren_s.wait_event(p["snap_ready"][slot])
         with torch.cuda.stream(ren_s):
+            self.sim.get_IP_info(dof=p["snap"][slot], out=p["ip"][lane])
             p["ren_graph"][lane].replay()
             p["done"][lane].record(ren_s)
         p["pending"][lane] = True
         self.frame += 1
         return p["out"][lane]
+
+    @property
+    def substeps_enqueued(self):
+        """Simulator substeps enqueued so far in pipelined mode (= frames rendered + sim_ahead + 1 once running)."""
+        return self._pipe["sim_next"]
 
     def drain_pipeline(self):
         """Waits for every frame in flight and verifies each lane's last render completed."""

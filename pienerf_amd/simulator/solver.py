@@ -179,13 +179,18 @@ class Simulator:
                                        ptr(self.IP_lam), ptr(self.IP_dNx), ptr(RF), ptr(VF), ptr(rhs), stream_ptr()), "collect_rhs")
         return rhs
 
-    def get_IP_info(self):  # solver.py:402-424
+    def get_IP_info(self, dof=None, out=None):  # solver.py:402-424
+        """(IP_pos, IP_F, IP_dF) of the current state.  `dof` (a [30 n_k] fp64 snapshot of self.dof) and `out` (three preallocated
+        fp32 tensors) are extensions for the pipelined harness: frames in flight each own a snapshot and a set of IP buffers."""
         n, dev = self.n_IP, self.device
-        pos = torch.empty((n, 3), dtype=torch.float32, device=dev)
-        F = torch.empty((n, 9), dtype=torch.float32, device=dev)
-        dF = torch.empty((n, 27), dtype=torch.float32, device=dev)
-        check(lib().pn_sim_update_F(n, ptr(self.IP_kernel), ptr(self.dof), ptr(self.IP_Nx), ptr(self.IP_dNx), ptr(self.IP_ddNx), ptr(pos), ptr(F),
-                                    ptr(dF), stream_ptr()), "update_F")
+        if out is None:
+            pos = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            F = torch.empty((n, 9), dtype=torch.float32, device=dev)
+            dF = torch.empty((n, 27), dtype=torch.float32, device=dev)
+        else:
+            pos, F, dF = out
+        check(lib().pn_sim_update_F(n, ptr(self.IP_kernel), ptr(self.dof if dof is None else dof), ptr(self.IP_Nx), ptr(self.IP_dNx), ptr(self.IP_ddNx),
+                                    ptr(pos), ptr(F), ptr(dF), stream_ptr()), "update_F")
         return pos, F, dF
 
     def stepforward(self):  # solver.py:595-602

@@ -364,23 +364,30 @@ def test_graph_replay_equals_eager_steps(small_cloud, small_opt, ckpt):
         short.step_graph()
 
 
-def test_pipelined_frames_equal_eager_steps(small_cloud, small_opt, ckpt):
-    """Two frames in flight (sim graph + render graph per lane, ordered by events) give the eager sequence of images."""
+@pytest.mark.parametrize("lanes,ahead", [(2, None), (3, 1), (1, 0)])
+def test_pipelined_frames_equal_eager_steps(small_cloud, small_opt, ckpt, lanes, ahead):
+    """Frames in flight (simulator running ahead on its own stream, one render graph per lane, ordered by snapshot events) give
+    the eager sequence of images."""
     from pienerf_amd.harness import SimRenderHarness
     opt = dict(small_opt, W=64, H=64)
     eager = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV)
-    pipe = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture_pipelined(lanes=2, n_trips=8)
+    pipe = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture_pipelined(lanes=lanes, n_trips=8, sim_ahead=ahead)
+    n_frames = 7
     want = []
-    for _ in range(5):
+    for _ in range(n_frames):
         want.append(eager.step()["image"].clone())
     eager.synchronize()
     got = []
-    for f in range(5):
+    for f in range(n_frames):
         out = pipe.step_pipelined()
-        pipe._pipe["done"][f % 2].synchronize()  # the lane's buffers are reused two frames later: read them before that
+        pipe._pipe["done"][f % lanes].synchronize()  # the lane's buffers are reused `lanes` frames later: read them before that
         got.append(out["image"].clone())
     pipe.drain_pipeline()
-    for f in range(5):
+    for f in range(n_frames):
         assert (want[f] - got[f]).abs().max() < 1e-5, f
+    # the simulator ran ahead of the last rendered frame by a known number of substeps
+    assert pipe.substeps_enqueued == n_frames + (lanes if ahead is None else ahead)
+    for _ in range(pipe.substeps_enqueued - n_frames):
+        eager.sim.stepforward()
     assert rel_err((pipe.sim.dof - pipe.sim.dof_rest).cpu().numpy(), (eager.sim.dof - eager.sim.dof_rest).cpu().numpy()) < 1e-7
     assert (want[0] - want[4]).abs().max() > 1e-3  # the object really moved between frames
