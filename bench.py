@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=3,
                     help="renders in flight on the GPU (1 = strictly one frame after the other; 3 render streams + the simulator stream = the 4 "
                          "compute pipes of an XCD, more streams only time-slice)")
+    ap.add_argument("--single-graph", action="store_true", help="whole step as ONE captured graph (sim on a forked stream), one frame at a time")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -218,8 +219,9 @@ def main():
     if world == 1:
         if args.eager:
             run_steps = lambda n: [h.step() for _ in range(n)]
-        elif args.lanes > 1:
-            # `lanes` frames in flight: render(f+1) overlaps render(f) on a second stream, the simulator runs ahead (harness.capture_pipelined)
+        elif not args.single_graph:
+            # `lanes` renders in flight on their own streams, the simulator running ahead on dof snapshots (harness.capture_pipelined);
+            # lanes = 1 is one render at a time with the next substep overlapping it
             h.capture_pipelined(lanes=args.lanes, n_trips=args.trips)
             run_steps = lambda n: [h.step_pipelined() for _ in range(n)]
         else:
@@ -260,7 +262,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         if world == 1 and not args.eager:  # the last replayed frame(s) must be complete too
-            if args.lanes > 1:
+            if not args.single_graph:
                 h.drain_pipeline()
             else:
                 h._check_previous_graph_frame()
@@ -279,7 +281,8 @@ def main():
             "config": {"workload": "configs[1]: synthetic chair 800x800, sim_dx=0.05, sim_iters=10, num_seek_IP=3, max_iter_num=1, fp32, "
                                    "1 sim+render step per frame", "rays": opt["W"] * opt["H"], "n_IP": h.sim.n_IP, "n_kernels": h.sim.n_k,
                        "samples_per_frame": st["samples"], "trips_per_frame": st["trips"],
-                       "launch": "eager" if (args.eager or world > 1) else f"hip graph, {args.trips} trips, {args.lanes} frame(s) in flight",
+                       "launch": "eager" if (args.eager or world > 1) else (f"one hip graph per step, {args.trips} trips" if args.single_graph else
+                                                                                   f"hip graphs, {args.trips} trips, {args.lanes} render(s) in flight, simulator running ahead"),
                        "parallelism": f"frame-parallel x{world}, DOF broadcast over RCCL" if world > 1 else "single GPU"},
             "roofline": roofline,
         }

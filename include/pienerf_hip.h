@@ -27,6 +27,16 @@ extern "C" {
 
 /* Library identity: "pienerf_hip <version> gfx950".  Never NULL. */
 const char* pn_version(void);
+
+/* Stream confined to a subset of the GPU's compute units (hipExtStreamCreateWithCUMask), for the pipelined harness: the
+ * simulator's chain of small launches runs on `n_cu` CUs of its own, the render streams on the complement, so neither
+ * waits for the other's waves to release registers.  Mask bits first_cu .. first_cu+n_cu-1 are set when invert == 0, all
+ * the others (of total_cu) when invert != 0; consecutive mask bits fall on consecutive XCDs.  *stream_out is a hipStream_t
+ * (wrap it with torch.cuda.ExternalStream); destroy with pn_stream_destroy.  No reference counterpart. */
+int pn_stream_create_cu_mask(uint32_t total_cu, uint32_t first_cu, uint32_t n_cu, int invert, void** stream_out);
+int pn_stream_destroy(void* stream);
+/* Number of compute units of the current device. */
+int pn_device_cu_count(void);
 /* Text of the last PN_ERR_HIP on the calling thread ("" if none). */
 const char* pn_last_error(void);
 
@@ -179,9 +189,11 @@ int pn_sim_matvec3(int n, const double* A, const double* X, double* Y, void* str
 /* Simulator.stepforward (simulator/solver.py:595-602) incl. compute_momentum (:574-576) and build_rhs (:541-571).
  * All vectors [10 n_k,3] fp64.  dof and dof_vel are updated in place.  work: >= pn_sim_work_doubles(n_k, n_IP) doubles. */
 int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, double dx, const int* topo, const int* csr_bg, const int* csr_cnt,
-                       const int* csr_buf, const double* mu, const double* lam, const double* dNx, const double* Ainv, const double* Mmat,
-                       const double* dof_rest, const double* rhs_rest, const double* rhs_gravity, const double* dof_f, double* dof,
-                       double* dof_vel, double* work, void* stream);
+                       const int* csr_buf, const double* mu, const double* lam, const double* dNx, const double* dNx_csr, const double* Ainv,
+                       const double* Mmat, const double* dof_rest, const double* rhs_rest, const double* rhs_gravity, const double* dof_f,
+                       double* dof, double* dof_vel, double* work, void* stream);
+/* dNx_csr (may be NULL): dNx rows gathered in CSR order, dNx_csr[e] = dNx[csr_buf[e]] (30 doubles each), built once at
+ * initialisation; with it collect_rhs streams contiguous memory (one workgroup per kernel) instead of chasing csr_buf. */
 uint64_t pn_sim_work_doubles(int n_k, int n_IP);
 
 /* Simulator.update_force (simulator/solver.py:578-588): dof_f [10 n_k,3] is overwritten with the pick force of IP `vid`. */

@@ -53,7 +53,8 @@ void svd3(const M3& F, M3& U, double sig[3], M3& V) {
     for (int sweep = 0; sweep < 64; sweep++) {
         const double off = S.m[0][1] * S.m[0][1] + S.m[0][2] * S.m[0][2] + S.m[1][2] * S.m[1][2];
         const double dia = S.m[0][0] * S.m[0][0] + S.m[1][1] * S.m[1][1] + S.m[2][2] * S.m[2][2];
-        if (off <= 1e-34 * dia || off == 0.0) break;
+        // fp64 rounding leaves off ~ 1e-32 dia however long one sweeps; 1e-30 is reached one sweep after ~1e-15 (quadratic convergence)
+        if (off <= 1e-30 * dia || off == 0.0) break;
         for (int p = 0; p < 2; p++)
             for (int q = p + 1; q < 3; q++) {
                 if (S.m[p][q] == 0.0) continue;

@@ -24,6 +24,9 @@ class RenderOpts(C.Structure):
 SIGNATURES = {
     "pn_version": (C.c_char_p, []),
     "pn_last_error": (C.c_char_p, []),
+    "pn_stream_create_cu_mask": (i32, [u32, u32, u32, i32, C.POINTER(C.c_void_p)]),
+    "pn_stream_destroy": (i32, [P]),
+    "pn_device_cu_count": (i32, []),
     "pn_near_far_from_aabb": (i32, [P, P, P, u32, f32, P, P, P]),
     "pn_march_rays_quadratic_bending": (i32, [P, P, P, i32, i32, P, P, P, P, i32, P, P, f32, P, i32, f32, i32, P, u32, u32, P, P, P, P, f32, f32, u32,
                                               u32, u32, P, P, P, P, P, P, P, P, P]),
@@ -48,7 +51,7 @@ SIGNATURES = {
     "pn_sim_calc_elastic": (i32, [i32, P, P, P, P, P, P, P]),
     "pn_sim_collect_rhs": (i32, [i32, f64, P, P, P, P, P, P, P, P, P, P]),
     "pn_sim_matvec3": (i32, [i32, P, P, P, P]),
-    "pn_sim_stepforward": (i32, [i32, i32, i32, f64, f64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "pn_sim_stepforward": (i32, [i32, i32, i32, f64, f64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "pn_sim_work_doubles": (u64, [i32, i32]),
     "pn_sim_update_force": (i32, [i32, i32, P, f64, P, P, P, P, P]),
 }

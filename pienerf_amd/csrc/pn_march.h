@@ -22,7 +22,7 @@ __device__ __forceinline__ int mip_from_pos(float x, float y, float z, float max
     return (int)fminf(max_cascade - 1, fmaxf(0.0f, (float)e));
 }
 __device__ __forceinline__ int mip_from_dt(float dt, float H, float max_cascade) {
-    const float mx = (float)((double)(dt * H) * 0.5);
+    const float mx = (dt * H) * 0.5f;  // == (float)((double)(dt * H) * 0.5): halving is exact
     int e;
     frexpf(mx, &e);
     return (int)fminf(max_cascade - 1, fmaxf(0.0f, (float)e));

@@ -25,6 +25,10 @@ namespace pnm2 {
 using namespace pnm;
 
 #define PN_G 8  // lanes per ray
+#ifndef PN_TAIL_ITERS
+#define PN_TAIL_ITERS 12
+#define PN_TAIL_PRIO 3
+#endif
 
 struct March2Tables {
     const int* nb_bgn;    // [n_grid + 1]
@@ -141,11 +145,73 @@ __device__ inline bool warp_record(const float4* __restrict__ r, int max_iter_nu
     return fabsf(p[0] - pk0) > IP_dx || fabsf(p[1] - pk1) > IP_dx || fabsf(p[2] - pk2) > IP_dx;
 }
 
+// Leading run of marching iterations through search cells whose 27-neighbourhood holds no IP, ONE lane per ray.
+// At 800x800 ~86 % of the first trip's iterations are of this kind (rays crossing the empty part of the IP bounding box): no
+// candidate is found, so the sample is not warped and the ray just hops to the next density-grid voxel.  They need no memory but
+// the cell's list range, and in the cooperative kernel 7 of 8 lanes would replicate them.  Returns the t at which march_group
+// has to take over (first iteration whose cell has candidates, or t >= far); the arithmetic is march_group's, expression by
+// expression, so resuming there is bit-identical to having run every iteration in march_group.
+__device__ inline float skip_empty_cells(const MarchParams& a, const March2Tables& tb, int index, float noise, unsigned* n_iter_out) {
+    const float ox = a.rays_o[index * 3], oy = a.rays_o[index * 3 + 1], oz = a.rays_o[index * 3 + 2];
+    const float dx = a.rays_d[index * 3], dy = a.rays_d[index * 3 + 1], dz = a.rays_d[index * 3 + 2];
+    const uint32_t H = a.H, C = a.C;
+    const float far = a.fars[index];
+    const float dt_min = 2 * 1.7320508075688772f / a.max_steps;
+    const float dt_max = 2 * 1.7320508075688772f * (1 << (C - 1)) / H;
+    *n_iter_out = 0;
+    float t = a.rays_t[index];
+    t += clampf(t * a.dt_gamma, dt_min, dt_max) * noise;
+    if (!(t < far) || a.cut) return t;
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    const float rH = 1 / (float)H;
+    const float bmin0 = a.bbmin[0], bmin1 = a.bbmin[1], bmin2 = a.bbmin[2];
+    const float hi0 = (float)((double)a.bbmax[0] - 1e-6), hi1 = (float)((double)a.bbmax[1] - 1e-6), hi2 = (float)((double)a.bbmax[2] - 1e-6);
+    const int r0 = a.resolution[0], r1 = a.resolution[1], r2 = a.resolution[2];
+    const float rbound = 1 / a.bound;
+    const float halfH = 0.5f * (float)H;
+    int cell_id = -1;
+    unsigned n_iter = 0;
+    while (t < far) {
+        const float x = clampf(ox + t * dx, bmin0, hi0);
+        const float y = clampf(oy + t * dy, bmin1, hi1);
+        const float z = clampf(oz + t * dz, bmin2, hi2);
+        const int g0 = (int)floorf((x - bmin0) / a.hgs);
+        const int g1 = (int)floorf((y - bmin1) / a.hgs);
+        const int g2 = (int)floorf((z - bmin2) / a.hgs);
+        if (g0 < 0 || g1 < 0 || g2 < 0 || g0 >= r0 || g1 >= r1 || g2 >= r2) break;  // march_group raises the error flag
+        const int gid = g2 * r1 * r0 + g1 * r0 + g0;
+        if (gid != cell_id) {
+            if (tb.nb_bgn[gid] != tb.nb_bgn[gid + 1]) break;  // candidates: hand over
+            cell_id = gid;
+        }
+        n_iter++;
+        // found == false: un-warped voxel skip (raymarching.cu:1386-1428)
+        const float dt = clampf(t * a.dt_gamma, dt_min, dt_max);
+        const int level = max(mip_from_pos(x, y, z, (float)C), mip_from_dt(dt, (float)H, (float)C));
+        const float pw = scalbnf(1.0f, level);
+        const bool use_pw = pw <= a.bound;
+        const float mip_bound = use_pw ? pw : a.bound;
+        const float mip_rbound = use_pw ? scalbnf(1.0f, -level) : rbound;
+        // (float)(0.5 * (double)v * (double)H) == v * (0.5f * H): both round the exact product once (v has 24 significant bits, H < 2^24)
+        const int nx = (int)clampf((x * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
+        const int ny = (int)clampf((y * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
+        const int nz = (int)clampf((z * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
+        const float tx = (((nx + 0.5f + 0.5f * signf(dx)) * rH * 2 - 1) * mip_bound - x) * rdx;
+        const float ty = (((ny + 0.5f + 0.5f * signf(dy)) * rH * 2 - 1) * mip_bound - y) * rdy;
+        const float tz = (((nz + 0.5f + 0.5f * signf(dz)) * rH * 2 - 1) * mip_bound - z) * rdz;
+        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        do { t += clampf(t * a.dt_gamma, dt_min, dt_max); } while (t < tt);
+    }
+    *n_iter_out = n_iter;
+    return t;
+}
+
 // One ray, executed by its 8 lanes in lock step.  `sub` = lane within the group; all per-ray state is replicated.
 // Returns the number of samples emitted (same value on all 8 lanes); lane 0 of the group writes them.
 template <int K, bool MULTI>
+// `resume` (may be null): t left by skip_empty_cells for this ray; the loop starts there, `last_t` keeps the trip's start.
 __device__ inline uint32_t march_group(const MarchParams& a, const March2Tables& tb, int index, float noise, uint32_t n_step, int sub, int gbase,
-                                       float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas) {
+                                       float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, const float* resume) {
     const float ox = a.rays_o[index * 3], oy = a.rays_o[index * 3 + 1], oz = a.rays_o[index * 3 + 2];
     const float dx = a.rays_d[index * 3], dy = a.rays_d[index * 3 + 1], dz = a.rays_d[index * 3 + 2];
     const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
@@ -160,6 +226,7 @@ __device__ inline uint32_t march_group(const MarchParams& a, const March2Tables&
     t += clampf(t * a.dt_gamma, dt_min, dt_max) * noise;
     float last_t = t;
     if (!(t < far)) return 0;
+    if (resume) t = *resume;
 
     const float bmin0 = a.bbmin[0], bmin1 = a.bbmin[1], bmin2 = a.bbmin[2];
     const float bmax0 = a.bbmax[0], bmax1 = a.bbmax[1], bmax2 = a.bbmax[2];
@@ -167,10 +234,15 @@ __device__ inline uint32_t march_group(const MarchParams& a, const March2Tables&
     const int r0 = a.resolution[0], r1 = a.resolution[1], r2 = a.resolution[2];
 
     const float rbound = 1 / a.bound;
+    const float halfH = 0.5f * (float)H;
     int cell_id = -1, cell_b = 0, cell_e = 0;
     unsigned n_iter = 0, n_cand = 0, n_warp = 0;  // instrumentation, only reported when a.stats != nullptr
     while (t < far && step < n_step) {
         n_iter++;
+        // A ray that is still marching after many iterations is on the trip's critical path (a few hundred rays need 60-90
+        // serial iterations while the rest of the launch has long finished): its wave asks the SIMD arbiter for priority over
+        // the wide, throughput-bound waves of other frames in flight.
+        if (n_iter == PN_TAIL_ITERS) __builtin_amdgcn_s_setprio(PN_TAIL_PRIO);
         bool found = false;
         float x, y, z;
         if (a.cut) {
@@ -289,9 +361,11 @@ __device__ inline uint32_t march_group(const MarchParams& a, const March2Tables&
         const bool use_pw = pw <= a.bound;
         const float mip_bound = use_pw ? pw : a.bound;
         const float mip_rbound = use_pw ? scalbnf(1.0f, -level) : rbound;
-        const int nx = (int)clampf((float)(0.5 * (double)(x * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
-        const int ny = (int)clampf((float)(0.5 * (double)(y * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
-        const int nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+        // the reference's (float)(0.5 * (double)v * (double)H) rounds the exact product v*H/2 once (v: 24 significant bits, H < 2^24,
+        // so the double products are exact); so does the float product v * (0.5f*H) — same value without the fp64 pipe
+        const int nx = (int)clampf((x * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
+        const int ny = (int)clampf((y * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
+        const int nz = (int)clampf((z * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
         const uint32_t vox = (uint32_t)(level * H3 + (float)morton3D(nx, ny, nz));
         // the occupancy bit only matters when an IP was found (`occ && found`), so the load is skipped otherwise
         const bool occ = found ? (bool)(a.grid[vox / 8] & (1 << (vox % 8))) : false;

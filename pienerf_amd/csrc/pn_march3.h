@@ -1,0 +1,344 @@
+// Windowed ray march with the inverse-GMLS warp: G lanes per ray (G = 8 or 64), each lane evaluating ONE point of the ray.
+//
+// The reference loop (raymarching.cu:1121-1434) looks serial — evaluate the sample at t, then either emit it (t += dt) or hop
+// to the end of its density voxel (do t += dt while t < tt) — but both branches advance t by the same recurrence
+//     s_{k+1} = s_k + clamp(s_k * dt_gamma, dt_min, dt_max)          (float, rounded once per add)
+// so the t values a ray can ever visit are the fixed sequence s_0 = t_start, s_1, s_2, ...  Which of them ARE visited depends on
+// the evaluations, but the evaluation at s_k (search cell -> nearest IPs -> Newton warps -> blend -> density bit -> voxel exit)
+// is a pure function of s_k.  So per round the G lanes of a ray evaluate s_0..s_{G-1} independently, each lane then walks its
+// own voxel hop to find the index it would jump to, and every lane replays the visit chain 0 -> jump[0] -> jump[jump[0]] ...
+// (G = 8: the 8 jump indices are OR-packed into one dword by DPP; G = 64: one ds_bpermute per chain link).  Visited lanes that
+// found an occupied sample write it to the slot given by their rank in the chain.
+//
+// Two launches per loop trip use it (pn_render_ops.hip):
+//   k_march       G = 8, 8 rays per wave, at most `max_rounds` rounds per ray: a ray in a sample-dense region emits its 8
+//                 samples in one round.  Rays that are still going after the budget (a few hundred per trip: they graze the
+//                 object and hop through 60-90 voxels without emitting) are appended to a tail list with their state;
+//   k_march_tail  G = 64, one wave per listed ray: 64 sequence elements (~14 voxel hops) per round, so the critical path of
+//                 a trip is ~6 rounds instead of ~80 dependent iterations.
+// vs. the cooperative form (pn_march2.h: 8 lanes share ONE evaluation, one iteration at a time) the results are identical bit
+// for bit: same -ffp-contract=off expressions, sequential strict-'<' insertion over the candidate list in the reference's
+// visiting order, the `n_IP--` loops replayed literally.
+#pragma once
+#include "pn_march2.h"
+
+namespace pnm3 {
+using namespace pnm;
+using pnm2::March2Tables;
+using pnm2::warp_record;
+
+struct RayConsts {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
+    float bmin0, bmin1, bmin2, bmax0, bmax1, bmax2, hi0, hi1, hi2;
+    int r0, r1, r2;
+    float rH, H3, halfH, Hm1, Hf, Cf, rbound, dt_min, dt_max, far;
+};
+
+// Marching state of one ray inside a trip (what the reference keeps in t / last_t / step).
+struct RayState {
+    float t, last_t;
+    uint32_t step;
+};
+
+__device__ __forceinline__ float dtf(const MarchParams& a, const RayConsts& c, float t) { return clampf(t * a.dt_gamma, c.dt_min, c.dt_max); }
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+
+__device__ __forceinline__ void ray_consts(const MarchParams& a, int index, RayConsts& c) {
+    c.ox = a.rays_o[index * 3]; c.oy = a.rays_o[index * 3 + 1]; c.oz = a.rays_o[index * 3 + 2];
+    c.dx = a.rays_d[index * 3]; c.dy = a.rays_d[index * 3 + 1]; c.dz = a.rays_d[index * 3 + 2];
+    c.rdx = 1 / c.dx; c.rdy = 1 / c.dy; c.rdz = 1 / c.dz;
+    const uint32_t H = a.H, C = a.C;
+    c.rH = 1 / (float)H;
+    c.H3 = (float)(H * H * H);
+    c.halfH = 0.5f * (float)H;
+    c.Hm1 = (float)(H - 1);
+    c.Hf = (float)H;
+    c.Cf = (float)C;
+    c.dt_min = 2 * 1.7320508075688772f / a.max_steps;
+    c.dt_max = 2 * 1.7320508075688772f * (1 << (C - 1)) / H;
+    c.far = a.fars[index];
+    c.bmin0 = a.bbmin[0]; c.bmin1 = a.bbmin[1]; c.bmin2 = a.bbmin[2];
+    c.bmax0 = a.bbmax[0]; c.bmax1 = a.bbmax[1]; c.bmax2 = a.bbmax[2];
+    c.hi0 = (float)((double)c.bmax0 - 1e-6); c.hi1 = (float)((double)c.bmax1 - 1e-6); c.hi2 = (float)((double)c.bmax2 - 1e-6);
+    c.r0 = a.resolution[0]; c.r1 = a.resolution[1]; c.r2 = a.resolution[2];
+    c.rbound = 1 / a.bound;
+}
+
+// Trip prologue of one ray (raymarching.cu:1163-1172).  Returns false when the ray has nothing to march.
+// `resume` (may be null): t left by skip_empty_cells; `last_t` keeps the trip's start.
+__device__ __forceinline__ bool ray_start(const MarchParams& a, const RayConsts& c, int index, float noise, const float* resume, RayState& st) {
+    float t = a.rays_t[index];
+    t += clampf(t * a.dt_gamma, c.dt_min, c.dt_max) * noise;
+    st.last_t = t;
+    st.step = 0;
+    st.t = t;
+    if (!(t < c.far)) return false;
+    if (resume) st.t = *resume;
+    return true;
+}
+
+struct PointEval {
+    float x, y, z;  // sample position (warped when IPs were found)
+    float dt;       // step at this t
+    float tt;       // voxel exit target when the point is not emitted
+    bool emit;      // occupied && found
+    bool oob;       // search cell outside the spatial hash (error flag of the reference's printf branch)
+    unsigned n_cand, n_warp;
+};
+
+// The body of one marching iteration at ray parameter t, one lane.  Literal restatement of raymarching.cu:1190-1431.
+template <int K, bool MULTI>
+__device__ __forceinline__ void eval_point(const MarchParams& a, const March2Tables& tb, const RayConsts& c, float t, PointEval& r) {
+    bool found = false;
+    float x, y, z;
+    if (a.cut) {
+        x = clampf(c.ox + t * c.dx, -a.bound, a.bound);
+        y = clampf(c.oy + t * c.dy, -a.bound, a.bound);
+        z = clampf(c.oz + t * c.dz, -a.bound, a.bound);
+    } else {
+        x = clampf(c.ox + t * c.dx, c.bmin0, c.hi0);
+        y = clampf(c.oy + t * c.dy, c.bmin1, c.hi1);
+        z = clampf(c.oz + t * c.dz, c.bmin2, c.hi2);
+    }
+    bool in_cut = true;
+    if (a.cut) {
+        const float* cb = a.cut_bounds;  // `x < cb[3]` is the reference's own test (raymarching.cu:1210)
+        in_cut = (x > cb[0] && x < cb[1] && y > cb[2] && x < cb[3] && z > cb[4] && z < cb[5]);
+    }
+    r.oob = false;
+    r.n_cand = 0;
+    r.n_warp = 0;
+    if (in_cut) {
+        float x_map = 0.0f, y_map = 0.0f, z_map = 0.0f;
+        const int g0 = (int)floorf((x - c.bmin0) / a.hgs);
+        const int g1 = (int)floorf((y - c.bmin1) / a.hgs);
+        const int g2 = (int)floorf((z - c.bmin2) / a.hgs);
+        const bool oob = (g0 < 0 || g1 < 0 || g2 < 0 || g0 >= c.r0 || g1 >= c.r1 || g2 >= c.r2);
+        r.oob = oob;
+        int ord[3] = {-1, -1, -1};  // list positions of the selected candidates, nearest first
+        if (!oob) {
+            const int gid = g2 * c.r1 * c.r0 + g1 * c.r0 + g0;
+            const int b = tb.nb_bgn[gid], e = tb.nb_bgn[gid + 1];
+            r.n_cand = (unsigned)(e - b);
+            if (K == 1) {
+                // find_closest_IP (:986-1043): own cell first, the 26 neighbours only if that found nothing; `d < best` from 9999.9
+                const int own = a.pig_cnt[gid];
+                float best = (float)9999.9;
+                for (int j = b; j < b + own; j++) {
+                    const float4 v = tb.nb[j];
+                    const float ax = v.x - x, ay = v.y - y, az = v.z - z;
+                    const float d = ax * ax + ay * ay + az * az;
+                    if (d < best) { best = d; ord[0] = j; }
+                }
+                if (ord[0] == -1) {
+                    for (int j = b + own; j < e; j++) {
+                        const float4 v = tb.nb[j];
+                        const float ax = v.x - x, ay = v.y - y, az = v.z - z;
+                        const float d = ax * ax + ay * ay + az * az;
+                        if (d < best) { best = d; ord[0] = j; }
+                    }
+                }
+            } else {
+                // find_closest_IPs (:1045-1118): all 27 cells in visiting order (= list order), insertion on strict '<'
+                float d0 = FLT_MAX, d1 = FLT_MAX, d2 = FLT_MAX;
+                for (int j0 = b; j0 < e; j0 += 4) {  // four entries in flight per round trip
+                    float4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v[u] = tb.nb[min(j0 + u, e - 1)];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int j = j0 + u;
+                        const float ax = v[u].x - x, ay = v[u].y - y, az = v[u].z - z;
+                        const float d = ax * ax + ay * ay + az * az;
+                        if (j < e) {
+                            if (d < d0) {
+                                if (K > 2) { d2 = d1; ord[2] = ord[1]; }
+                                d1 = d0; ord[1] = ord[0];
+                                d0 = d; ord[0] = j;
+                            } else if (d < d1) {
+                                if (K > 2) { d2 = d1; ord[2] = ord[1]; }
+                                d1 = d; ord[1] = j;
+                            } else if (K > 2 && d < d2) {
+                                d2 = d; ord[2] = j;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        int n_IP = (ord[0] != -1) + (ord[1] != -1) + (ord[2] != -1);
+        found = n_IP > 0;
+        if (found) {
+            int ips[3] = {0, 0, 0};
+            // pre-filter (:1246-1251): `n_IP--` inside the loop it bounds, strict '<' on z only
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                if (k < n_IP) {
+                    const float4 cnd = tb.nb[ord[k]];
+                    ips[k] = __float_as_int(cnd.w);
+                    if (cnd.x <= c.bmin0 || cnd.y <= c.bmin1 || cnd.z < c.bmin2 || cnd.x >= c.bmax0 || cnd.y >= c.bmax1 || cnd.z >= c.bmax2) n_IP--;
+                }
+            }
+            if (n_IP <= 0) found = false;
+            if (found) {
+                float ps[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dk[3] = {0, 0, 0};
+                // per-IP Newton warp (:1262-1324): a rejected result still fills its slot and shrinks the bound
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    if (k < n_IP) {
+                        float pw[3];
+                        r.n_warp++;
+                        if (warp_record<MULTI>(tb.rec + (size_t)ips[k] * 11, a.max_iter_num, a.IP_dx, x, y, z, pw, &dk[k])) n_IP--;
+                        ps[3 * k] = pw[0]; ps[3 * k + 1] = pw[1]; ps[3 * k + 2] = pw[2];
+                    }
+                }
+                if (n_IP == 1) {
+                    x_map = ps[0]; y_map = ps[1]; z_map = ps[2];
+                } else if (n_IP == 2) {
+                    const float dist_sum = dk[0] + dk[1];
+                    const float w0 = dk[1] / dist_sum, w1 = dk[0] / dist_sum;
+                    x_map = w0 * ps[0] + w1 * ps[3];
+                    y_map = w0 * ps[1] + w1 * ps[4];
+                    z_map = w0 * ps[2] + w1 * ps[5];
+                } else if (n_IP == 3) {
+                    const float dist_sum = dk[0] * dk[1] + dk[1] * dk[2] + dk[2] * dk[0];
+                    const float w0 = dk[1] * dk[2] / dist_sum;
+                    const float w1 = dk[0] * dk[2] / dist_sum;
+                    const float w2 = dk[0] * dk[1] / dist_sum;
+                    x_map = w0 * ps[0] + w1 * ps[3] + w2 * ps[6];
+                    y_map = w0 * ps[1] + w1 * ps[4] + w2 * ps[7];
+                    z_map = w0 * ps[2] + w1 * ps[5] + w2 * ps[8];
+                }
+                x = x_map; y = y_map; z = z_map;  // n_IP == 0 here maps the sample to the origin (:1372-1374)
+            }
+        }
+    } else {
+        found = true;  // cut mode, outside the cut box: un-warped background sample (:1380-1383)
+    }
+
+    const float dt = dtf(a, c, t);
+    const int level = max(mip_from_pos(x, y, z, c.Cf), mip_from_dt(dt, c.Hf, c.Cf));
+    const float pw2 = scalbnf(1.0f, level);  // mip_bound = fminf(2^level, bound); 1 / 2^level is exact
+    const bool use_pw = pw2 <= a.bound;
+    const float mip_bound = use_pw ? pw2 : a.bound;
+    const float mip_rbound = use_pw ? scalbnf(1.0f, -level) : c.rbound;
+    // (float)(0.5 * (double)v * (double)H) == v * (0.5f * H): both round the exact product once (pn_march2.h)
+    const int nx = (int)clampf((x * mip_rbound + 1) * c.halfH, 0.0f, c.Hm1);
+    const int ny = (int)clampf((y * mip_rbound + 1) * c.halfH, 0.0f, c.Hm1);
+    const int nz = (int)clampf((z * mip_rbound + 1) * c.halfH, 0.0f, c.Hm1);
+    bool occ = false;
+    if (found) {  // the occupancy bit only matters when an IP was found (`occ && found`)
+        const uint32_t vox = (uint32_t)(level * c.H3 + (float)morton3D(nx, ny, nz));
+        occ = (bool)(a.grid[vox / 8] & (1 << (vox % 8)));
+    }
+    r.emit = occ && found;
+    r.x = x; r.y = y; r.z = z;
+    r.dt = dt;
+    const float tx = (((nx + 0.5f + 0.5f * signf(c.dx)) * c.rH * 2 - 1) * mip_bound - x) * c.rdx;
+    const float ty = (((ny + 0.5f + 0.5f * signf(c.dy)) * c.rH * 2 - 1) * mip_bound - y) * c.rdy;
+    const float tz = (((nz + 0.5f + 0.5f * signf(c.dz)) * c.rH * 2 - 1) * mip_bound - z) * c.rdz;
+    r.tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+}
+
+// Up to `max_rounds` windows of G sequence elements of one ray; the G lanes [gbase, gbase + G) run in lock step.
+// Returns true when the ray is done for this trip (t >= far, or n_step samples), false when the round budget ran out; `st` is
+// advanced either way (identically on all G lanes).  Samples go to xyzs/dirs/deltas[slot], slot = number emitted before.
+template <int K, bool MULTI, int G>
+__device__ inline bool march_window(const MarchParams& a, const March2Tables& tb, const RayConsts& c, uint32_t n_step, int sub, int gbase,
+                                    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, RayState& st, int max_rounds) {
+    float t = st.t, last_t = st.last_t;
+    uint32_t step = st.step;
+    const float far = c.far;
+    unsigned st_iter = 0, st_cand = 0, st_warp = 0;  // instrumentation (visited points only), reported when a.stats != nullptr
+    bool done = true;
+    int rounds = 0;
+    while (t < far && step < n_step) {
+        if (rounds == max_rounds) { done = false; break; }
+        rounds++;
+        // this lane's point s_sub and its successor
+        float s = t;
+        for (int j = 0; j < G - 1; j++)
+            if (j < sub) s += dtf(a, c, s);
+        const float nxt = s + dtf(a, c, s);
+        const bool active = s < far;
+        PointEval ev;
+        ev.emit = false; ev.oob = false; ev.tt = 0.f; ev.dt = 0.f; ev.x = ev.y = ev.z = 0.f; ev.n_cand = 0; ev.n_warp = 0;
+        if (active) eval_point<K, MULTI>(a, tb, c, s, ev);
+        // where the chain goes from this point: the next element (emitted) or the first element not below the voxel exit;
+        // G = first element of the next window, G + 1 = beyond it
+        int jump = sub + 1;
+        if (active && !ev.emit) {
+            float u = nxt;
+            int k = sub + 1;
+            while (k < G && u < ev.tt) { u += dtf(a, c, u); k++; }
+            jump = (k == G && u < ev.tt) ? G + 1 : k;
+        }
+        unsigned word = 0;
+        if (G == 8) {
+            word = (unsigned)jump << (4 * sub);
+            word |= dpp_u32<0xB1>(word);   // lane ^ 1
+            word |= dpp_u32<0x4E>(word);   // lane ^ 2
+            word |= dpp_u32<0x141>(word);  // lane <-> 7 - lane within each 8
+        }
+        const unsigned long long gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+        const unsigned long long emitm = (__ballot(ev.emit) >> gbase) & gmask;
+        const unsigned long long actm = (__ballot(active) >> gbase) & gmask;
+        // replay of the visit chain, identically on the G lanes
+        int cur = 0, prev_emit = -1, n_emit = 0, last_vis = 0;
+        int my_ord = -1, my_prev = -1;
+        bool visited = false, ended = false;
+        while (cur < G) {
+            if (!((actm >> cur) & 1ull)) { ended = true; break; }  // s_cur >= far: the march is over
+            if (cur == sub) { visited = true; my_ord = n_emit; my_prev = prev_emit; }
+            last_vis = cur;
+            const bool em = (emitm >> cur) & 1ull;
+            const int nx_idx = (G == 8) ? (int)((word >> (4 * cur)) & 0xFu) : __shfl(jump, gbase + cur);
+            if (em) {
+                prev_emit = cur;
+                n_emit++;
+                if (step + (uint32_t)n_emit == n_step) { ended = true; break; }
+            }
+            cur = nx_idx;
+        }
+        // emitted samples: slot = step + rank in the chain; deltas[1] = t_after - last_t (raymarching.cu:1395-1410)
+        const float prev_nxt = __shfl(nxt, gbase + max(my_prev, 0));
+        if (visited) {
+            st_iter++; st_cand += ev.n_cand; st_warp += ev.n_warp;
+            if (ev.oob && a.err_flag) atomicOr(a.err_flag, 1);
+            if (ev.emit) {
+                const uint32_t slot = step + (uint32_t)my_ord;
+                float* X = xyzs + (size_t)slot * 3;
+                float* D = dirs + (size_t)slot * 3;
+                float* L = deltas + (size_t)slot * 2;
+                X[0] = ev.x; X[1] = ev.y; X[2] = ev.z;
+                D[0] = c.dx; D[1] = c.dy; D[2] = c.dz;
+                L[0] = ev.dt;
+                L[1] = nxt - (my_prev >= 0 ? prev_nxt : last_t);
+            }
+        }
+        const float last_emit_nxt = __shfl(nxt, gbase + max(prev_emit, 0));
+        if (n_emit > 0) last_t = last_emit_nxt;
+        step += (uint32_t)n_emit;
+        // next window start: s_G, or further when the last visited point's voxel exit lies beyond the window
+        const float sG = __shfl(nxt, gbase + G - 1);
+        const float tt_last = __shfl(ev.tt, gbase + last_vis);
+        if (ended) break;  // done for this trip; t is not needed any more (composite tracks rays_t itself)
+        t = sG;
+        if (cur == G + 1)
+            while (t < tt_last) t += dtf(a, c, t);
+    }
+    if (a.stats) {
+        if (st_iter) { atomicAdd(a.stats, (unsigned long long)st_iter); atomicAdd(a.stats + 1, (unsigned long long)st_cand); }
+        if (st_warp) atomicAdd(a.stats + 2, (unsigned long long)st_warp);
+    }
+    st.t = t;
+    st.last_t = last_t;
+    st.step = step;
+    return done;
+}
+
+}  // namespace pnm3

@@ -2,7 +2,7 @@
 // Built with -ffp-contract=off (see pn_march.h).  Reference citations are relative to /root/reference.
 #include <float.h>
 
-#include "pn_march2.h"
+#include "pn_march3.h"
 
 thread_local char pn_err_buf[512] = {0};
 
@@ -301,6 +301,30 @@ struct MarchIO {
     // frame-driver mode (trip != nullptr): counts come from device memory, valid sample slots are appended to `list`
     PnTrip* trip;
     int* list;
+    float* t_resume;  // optional [n_alive]: written by k_march_skip, read by k_march (pn_march2.h: skip_empty_cells)
+    // optional tail pass: rays unfinished after `max_rounds` windows in k_march are appended here (count zeroed by the caller)
+    struct TailEntry* tail;
+    int* tail_count;
+    int max_rounds;
+};
+
+// One lane per ray slot: fast-forward over the leading run of IP-free search cells.
+__global__ void __launch_bounds__(256) k_march_skip(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
+    uint32_t n_alive = io.n_alive;
+    if (io.trip) n_alive = (uint32_t)io.trip->n_alive;
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= n_alive) return;
+    unsigned n_iter = 0;
+    io.t_resume[n] = pnm2::skip_empty_cells(a, tb, io.rays_alive[n], io.noises ? io.noises[n] : 0.0f, &n_iter);
+    if (a.stats && n_iter) atomicAdd(a.stats, (unsigned long long)n_iter);
+}
+
+// ---- the per-ray march (pn_march3.h): pass 1 = k_march (8 lanes per ray, bounded number of rounds), pass 2 = k_march_tail
+// (one wave per ray that pass 1 left unfinished).
+struct TailEntry {
+    int n;            // alive slot
+    float t, last_t;  // pnm3::RayState
+    int step;
 };
 
 // 8 lanes per ray, 32 rays per 256-thread block.
@@ -309,22 +333,38 @@ __global__ void __launch_bounds__(256, 4) k_march(pnm::MarchParams a, pnm2::Marc
     uint32_t n_alive = io.n_alive, n_step = io.n_step;
     if (io.trip) { n_alive = (uint32_t)io.trip->n_alive; n_step = (uint32_t)io.trip->n_step; }
     const int lane = threadIdx.x & 63, sub = lane & 7, gbase = lane & ~7;
+    const int budget = io.tail ? io.max_rounds : 0x7fffffff;
     // 32-ray chunks are dealt round-robin to a bounded grid: in frame mode the alive count is only known on the device, and a
     // grid sized for all N rays would push ~20 000 mostly empty workgroups through the dispatcher on every trip
     for (uint32_t chunk = blockIdx.x; chunk * 32u < n_alive; chunk += gridDim.x) {
         const uint32_t n = chunk * 32u + (threadIdx.x >> 3);
         uint32_t emitted = 0;
+        bool deferred = false;
         float* dl = nullptr;
         if (n < n_alive) {
             const int index = io.rays_alive[n];
             const float noise = io.noises ? io.noises[n] : 0.0f;
             dl = io.deltas + (size_t)n * n_step * 2;
-            emitted = pnm2::march_group<K, MULTI>(a, tb, index, noise, n_step, sub, gbase, io.xyzs + (size_t)n * n_step * 3,
-                                                  io.dirs + (size_t)n * n_step * 3, dl);
+            pnm3::RayConsts c;
+            pnm3::RayState st;
+            pnm3::ray_consts(a, index, c);
+            if (pnm3::ray_start(a, c, index, noise, io.t_resume ? io.t_resume + n : nullptr, st)) {
+                const bool done = pnm3::march_window<K, MULTI, 8>(a, tb, c, n_step, sub, gbase, io.xyzs + (size_t)n * n_step * 3,
+                                                                  io.dirs + (size_t)n * n_step * 3, dl, st, budget);
+                if (!done) {  // still marching after the round budget: continue with a whole wave (k_march_tail)
+                    deferred = true;
+                    if (sub == 0) {
+                        const int pos = atomicAdd(io.tail_count, 1);
+                        io.tail[pos] = TailEntry{(int)n, st.t, st.last_t, (int)st.step};
+                    }
+                }
+            }
+            emitted = deferred ? 0u : st.step;  // a deferred ray's samples are listed by the tail pass
+            if (a.stats && sub == 0 && emitted) atomicAdd(a.stats + 3, (unsigned long long)emitted);
         }
         if (io.trip) {
             // slots the ray did not fill end it in composite (delta == 0); the op-level wrapper zero-fills instead (raymarching.py:415-417)
-            if (dl)
+            if (dl && !deferred)
                 for (uint32_t s = emitted + sub; s < n_step; s += PN_G) { dl[2 * s] = 0.0f; dl[2 * s + 1] = 0.0f; }
             // wave-aggregated append of this wave's valid sample slots (one atomic per wave)
             int inc = (sub == 0) ? (int)emitted : 0;
@@ -343,11 +383,55 @@ __global__ void __launch_bounds__(256, 4) k_march(pnm::MarchParams a, pnm2::Marc
     }
 }
 
-static void launch_march(int K, uint32_t blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb, const MarchIO& io) {
+// One wave per unfinished ray: windows of 64 sequence elements until the ray is done for this trip.
+template <int K, bool MULTI>
+__global__ void __launch_bounds__(256, 4) k_march_tail(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
+    uint32_t n_step = io.n_step;
+    if (io.trip) n_step = (uint32_t)io.trip->n_step;
+    const int total = __hip_atomic_load(io.tail_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int lane = threadIdx.x & 63;
+    const int n_waves = (int)gridDim.x * 4;
+    for (int e = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); e < total; e += n_waves) {
+        const TailEntry te = io.tail[e];
+        const uint32_t n = (uint32_t)te.n;
+        const int index = io.rays_alive[n];
+        float* dl = io.deltas + (size_t)n * n_step * 2;
+        pnm3::RayConsts c;
+        pnm3::ray_consts(a, index, c);
+        pnm3::RayState st{te.t, te.last_t, (uint32_t)te.step};
+        pnm3::march_window<K, MULTI, 64>(a, tb, c, n_step, lane, 0, io.xyzs + (size_t)n * n_step * 3, io.dirs + (size_t)n * n_step * 3, dl, st,
+                                         0x7fffffff);
+        const uint32_t emitted = st.step;
+        if (a.stats && lane == 0 && emitted) atomicAdd(a.stats + 3, (unsigned long long)emitted);
+        if (io.trip) {
+            for (uint32_t s = emitted + lane; s < n_step; s += 64) { dl[2 * s] = 0.0f; dl[2 * s + 1] = 0.0f; }
+            int base = 0;
+            if (lane == 0 && emitted > 0) base = atomicAdd(&io.trip->n_samples, (int)emitted);
+            base = __shfl(base, 0);
+            for (uint32_t s = lane; s < emitted; s += 64) io.list[base + s] = (int)(n * n_step + s);
+        }
+    }
+}
+
+template <int K, bool MULTI>
+static void launch_march_km(uint32_t blocks, uint32_t tail_blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb, const MarchIO& io) {
+    k_march<K, MULTI><<<blocks, 256, 0, st>>>(a, tb, io);
+    if (io.tail) k_march_tail<K, MULTI><<<tail_blocks, 256, 0, st>>>(a, tb, io);
+}
+
+// pass 1 over `blocks` workgroups, then (io.tail != nullptr) the tail pass over `tail_blocks`
+static void launch_march(int K, uint32_t blocks, uint32_t tail_blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb,
+                         const MarchIO& io) {
     const bool multi = a.max_iter_num > 1;
-    if (K == 1) { if (multi) k_march<1, true><<<blocks, 256, 0, st>>>(a, tb, io); else k_march<1, false><<<blocks, 256, 0, st>>>(a, tb, io); }
-    else if (K == 2) { if (multi) k_march<2, true><<<blocks, 256, 0, st>>>(a, tb, io); else k_march<2, false><<<blocks, 256, 0, st>>>(a, tb, io); }
-    else { if (multi) k_march<3, true><<<blocks, 256, 0, st>>>(a, tb, io); else k_march<3, false><<<blocks, 256, 0, st>>>(a, tb, io); }
+    if (K == 1) { if (multi) launch_march_km<1, true>(blocks, tail_blocks, st, a, tb, io); else launch_march_km<1, false>(blocks, tail_blocks, st, a, tb, io); }
+    else if (K == 2) { if (multi) launch_march_km<2, true>(blocks, tail_blocks, st, a, tb, io); else launch_march_km<2, false>(blocks, tail_blocks, st, a, tb, io); }
+    else { if (multi) launch_march_km<3, true>(blocks, tail_blocks, st, a, tb, io); else launch_march_km<3, false>(blocks, tail_blocks, st, a, tb, io); }
+}
+
+// Rounds of 8 sequence elements a ray gets in k_march before it is handed to the wave-per-ray tail pass (PN_TAIL_ROUNDS overrides).
+static uint32_t march_tail_rounds() {
+    static const uint32_t r = pn_env_u32("PN_TAIL_ROUNDS", 4);  // measured on the chair: 2..4 within 1 % for latency, 4 best for throughput
+    return r;
 }
 
 static pnm::MarchParams make_march_params(const int* pig_cnt, const int* pig_bgn, const int* pig_idx, int n_vtx, int n_grid, const float* p_def,
@@ -388,7 +472,10 @@ extern "C" int pn_march_rays_quadratic_bending(const int* pig_cnt, const int* pi
     char* pool = nullptr;
     const size_t ints = ((size_t)n_grid + 1) * 3 * sizeof(int), nbb = (size_t)s.nb_capacity * sizeof(float4), recb = (size_t)n_vtx * 44 * sizeof(float);
     const size_t off_nb = (ints + 255) & ~(size_t)255, off_rec = (off_nb + nbb + 255) & ~(size_t)255;
-    PN_HIP_CHECK(hipMallocAsync((void**)&pool, off_rec + recb, st));
+    const size_t off_res = (off_rec + recb + 255) & ~(size_t)255;
+    const size_t off_tail = (off_res + (size_t)n_alive * sizeof(float) + 255) & ~(size_t)255;  // [tail counter | 16 B pad | tail entries]
+    PN_HIP_CHECK(hipMallocAsync((void**)&pool, off_tail + 16 + (size_t)n_alive * sizeof(TailEntry), st));
+    PN_HIP_CHECK(hipMemsetAsync(pool + off_tail, 0, 16, st));
     s.nb_cnt = (int*)pool; s.nb_bgn = s.nb_cnt + n_grid + 1; s.nb_cursor = s.nb_bgn + n_grid + 1;
     s.nb = (float4*)(pool + off_nb); s.rec = (float*)(pool + off_rec);
     int rc = march_side_build(s, n_vtx, n_grid, nullptr, resolution, pig_cnt, pig_bgn, pig_idx, p_def, p_ori, F_IP, dF_IP, num_seek_IP, err_flag, st);
@@ -397,8 +484,10 @@ extern "C" int pn_march_rays_quadratic_bending(const int* pig_cnt, const int* pi
                                                resolution, num_seek_IP, IP_dx, cut, cut_bounds, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps,
                                                C, H, grid, fars, err_flag);
         pnm2::March2Tables tb{s.nb_bgn, s.nb, (const float4*)s.rec};
-        MarchIO io{n_alive, n_step, rays_alive, xyzs, dirs, deltas, noises, nullptr, nullptr};
-        launch_march(num_seek_IP, pn_div_up(n_alive, 32), st, a, tb, io);
+        MarchIO io{n_alive, n_step, rays_alive, xyzs, dirs, deltas, noises, nullptr, nullptr, cut ? nullptr : (float*)(pool + off_res),
+                   (TailEntry*)(pool + off_tail + 16), (int*)(pool + off_tail), (int)march_tail_rounds()};
+        if (io.t_resume) k_march_skip<<<pn_div_up(n_alive, 256), 256, 0, st>>>(a, tb, io);
+        launch_march(num_seek_IP, pn_div_up(n_alive, 32), std::min(pn_div_up(n_alive, 4), 2048u), st, a, tb, io);
     }
     PN_HIP_CHECK(hipFreeAsync(pool, st));
     if (rc) return rc;
@@ -553,6 +642,8 @@ struct pn_frame {
     uint32_t max_rays, max_vtx, max_cells;
     float *nears, *fars, *rays_t, *xyzs, *dirs, *deltas, *sigmas, *rgbs;
     int *alive_a, *alive_b, *list, *chunk_counts;
+    TailEntry* tail;   // [max_rays] rays handed from k_march to k_march_tail
+    int* tail_counts;  // [PN_MAX_TRIPS + 2] one counter per trip, zeroed by k_frame_init
     int *pig_cnt, *pig_bgn, *pig_idx, *pig_cursor;
     MarchSide side;  // candidate lists + packed IP records of the cooperative march
     PnTrip* trips;  // [PN_MAX_TRIPS + 2]
@@ -607,7 +698,7 @@ __global__ void __launch_bounds__(1024) k_frame_bbox(const float* __restrict__ p
 
 // Per-frame initialisation done by kernels (not memset nodes): zeroed accumulators (renderer.py:807-809), rays_alive = arange(N)
 // (:828), zeroed trip records and trip 0 = (N rays, n_step 1).
-__global__ void __launch_bounds__(256) k_frame_init(PnTrip* trips, int n_trip_records, uint32_t N, int* alive, const PnFrameDev* dev,
+__global__ void __launch_bounds__(256) k_frame_init(PnTrip* trips, int* tail_counts, int n_trip_records, uint32_t N, int* alive, const PnFrameDev* dev,
                                                     float* __restrict__ weights_sum, float* __restrict__ depth_0, float* __restrict__ image) {
     const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
     if (i < N) {
@@ -621,6 +712,7 @@ __global__ void __launch_bounds__(256) k_frame_init(PnTrip* trips, int n_trip_re
             PnTrip r{0, 0, 0, 0};
             if (t == 0) { r.n_alive = dev->err ? 0 : (int)N; r.n_step = 1; }  // max(min(N // N, 8), 1)
             trips[t] = r;
+            tail_counts[t] = 0;
         }
     }
 }
@@ -654,6 +746,7 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
     PN_ALLOC(f->side.nb_cursor, ((size_t)max_grid_cells + 1) * 4);
     f->side.nb_capacity = 27 * (int)max_vtx;
     PN_ALLOC(f->side.nb, (size_t)f->side.nb_capacity * sizeof(float4)); PN_ALLOC(f->side.rec, (size_t)max_vtx * 44 * 4);
+    PN_ALLOC(f->tail, N * sizeof(TailEntry)); PN_ALLOC(f->tail_counts, sizeof(int) * (PN_MAX_TRIPS + 2));
     PN_ALLOC(f->trips, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)); PN_ALLOC(f->dev, sizeof(PnFrameDev)); PN_ALLOC(f->cut_bounds, 6 * 4);
 #undef PN_ALLOC
     PN_HIP_CHECK(hipMalloc((void**)&f->march_counters, 4 * sizeof(unsigned long long)));
@@ -667,7 +760,7 @@ extern "C" void pn_frame_destroy(pn_frame* f) {
     if (!f) return;
     void* ptrs[] = {f->nears, f->fars, f->rays_t, f->xyzs, f->dirs, f->deltas, f->sigmas, f->rgbs, f->alive_a, f->alive_b, f->list,
                     f->chunk_counts, f->pig_cnt, f->pig_bgn, f->pig_cursor, f->pig_idx, f->trips, f->dev, f->cut_bounds,
-                    f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, f->side.nb, f->side.rec, f->march_counters};
+                    f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, f->side.nb, f->side.rec, f->march_counters, f->tail, f->tail_counts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int t = 0; t < PN_TIMED_TRIPS; t++)
         for (int e = 0; e < 3; e++) if (f->ev[t][e]) (void)hipEventDestroy(f->ev[t][e]);
@@ -706,6 +799,8 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     // PN_MARCH_GRID / PN_TRIP_GRID override for experiments.
     static const uint32_t march_grid_cfg = pn_env_u32("PN_MARCH_GRID", 8192), trip_grid_cfg = pn_env_u32("PN_TRIP_GRID", 1024);
     const uint32_t march_grid = march_grid_cfg, trip_grid = std::min(nblk, trip_grid_cfg);
+    static const uint32_t tail_grid_cfg = pn_env_u32("PN_TAIL_GRID", 1024);  // x4 waves, one unfinished ray per wave at a time
+    const uint32_t tail_grid = std::min(pn_div_up(N, 4), tail_grid_cfg);
 
     if (!f->cut_bounds_valid || memcmp(f->cut_bounds_host, o->cut_bounds, sizeof(f->cut_bounds_host)) != 0) {  // uploaded only when it changes
         memcpy(f->cut_bounds_host, o->cut_bounds, sizeof(f->cut_bounds_host));
@@ -727,7 +822,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     if (rc) return rc;
     pnm2::March2Tables tb{f->side.nb_bgn, f->side.nb, (const float4*)f->side.rec};
     k_near_far<<<nblk, 256, 0, st>>>(rays_o, rays_d, f->dev->aabb, N, o->min_near, f->nears, f->fars, f->rays_t);
-    k_frame_init<<<nblk, 256, 0, st>>>(f->trips, PN_MAX_TRIPS + 2, N, f->alive_a, f->dev, weights_sum, depth_0, image);
+    k_frame_init<<<nblk, 256, 0, st>>>(f->trips, f->tail_counts, PN_MAX_TRIPS + 2, N, f->alive_a, f->dev, weights_sum, depth_0, image);
     PN_LAUNCH_CHECK();
 
     pnm::MarchParams mp = make_march_params(f->pig_cnt, f->pig_bgn, f->pig_idx, n_vtx, 0, p_def, p_ori, F_IP, dF_IP, o->max_iter_num, bbmin, bbmax,
@@ -741,14 +836,18 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
         for (int k = 0; k < batch; k++, t++) {
             int* cur = (t & 1) ? f->alive_b : f->alive_a;
             int* nxt = (t & 1) ? f->alive_a : f->alive_b;
-            MarchIO io{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + t, f->list};
+            // trip 0 (every ray, one sample each) is dominated by rays crossing IP-free cells: a one-lane-per-ray pre-pass
+            // fast-forwards them; its per-ray resume point lives in `sigmas`, which is not written before this trip's network launch
+            MarchIO io{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + t, f->list, (t == 0 && !o->cut) ? f->sigmas : nullptr,
+                       f->tail, f->tail_counts + t, (int)march_tail_rounds()};
             const bool timed = (f->march_counters_on & 2) && async_trips == 0 && t < PN_TIMED_TRIPS;
             if (timed) {  // measurement mode: HIP events around the two heavy launches of each trip, on the launch stream
                 for (int e = 0; e < 3; e++)
                     if (!f->ev[t][e]) PN_HIP_CHECK(hipEventCreate(&f->ev[t][e]));
                 PN_HIP_CHECK(hipEventRecord(f->ev[t][0], st));
             }
-            launch_march(o->num_seek_IP, std::min(pn_div_up(N, 32), march_grid), st, mp, tb, io);
+            if (io.t_resume) k_march_skip<<<nblk, 256, 0, st>>>(mp, tb, io);
+            launch_march(o->num_seek_IP, std::min(pn_div_up(N, 32), march_grid), tail_grid, st, mp, tb, io);
             if (timed) PN_HIP_CHECK(hipEventRecord(f->ev[t][1], st));
             rc = pn_nerf_forward_launch(net, f->xyzs, f->dirs, f->list, &f->trips[t].n_samples, N, o->density_scale, f->sigmas, f->rgbs, st);
             if (rc) return rc;

@@ -78,7 +78,9 @@ __device__ void svd3(const M3& F, M3& U, double* sig, M3& V) {
     for (int sweep = 0; sweep < 32; sweep++) {
         const double off = S.m[0][1] * S.m[0][1] + S.m[0][2] * S.m[0][2] + S.m[1][2] * S.m[1][2];
         const double dia = S.m[0][0] * S.m[0][0] + S.m[1][1] * S.m[1][1] + S.m[2][2] * S.m[2][2];
-        if (off <= 1e-34 * dia || off == 0.0) break;
+        // fp64 rounding leaves off ~ 1e-32 dia however long one sweeps (a 1e-34 test never fires and all 32 sweeps run);
+        // 1e-30 is reached one sweep after ~1e-15 (quadratic convergence) — same rule as the oracle
+        if (off <= 1e-30 * dia || off == 0.0) break;
         jacobi_rot<0, 1>(S, Q);
         jacobi_rot<0, 2>(S, Q);
         jacobi_rot<1, 2>(S, Q);
@@ -320,6 +322,60 @@ __global__ void __launch_bounds__(256) k_rhs_gather(int n_k, double dx3, const i
     }
 }
 
+// Step-driver form of the gather: one 256-thread workgroup per kernel over a CSR-ORDERED copy of dNx (dNx_csr[entry][c][x],
+// built once at initialisation), so the 240 B of every entry are read as one contiguous stream: thread (slot, q = c*10 + x)
+// walks entries slot, slot+8, ... and accumulates the three rows r of P[v][r][c] * dNx[c][x]; the 8 slots x 3 columns c are
+// then reduced through LDS in a fixed order.  out = momentum + sum - rhs_rest.
+__global__ void __launch_bounds__(256) k_rhs_gather_csr(int n_k, const int* __restrict__ csr_bg, const int* __restrict__ csr_cnt,
+                                                        const int* __restrict__ csr_buf, const double* __restrict__ dNx_csr,
+                                                        const double* __restrict__ P, const double* __restrict__ momentum,
+                                                        const double* __restrict__ rhs_rest, double* __restrict__ out) {
+    PN_SIM_PRIO();
+    __shared__ double red[8][30][3];
+    const int k = blockIdx.x;
+    const int t = threadIdx.x;
+    const int slot = t / 30, q = t - slot * 30, c = q / 10;
+    const int bg = csr_bg[k], cnt = csr_cnt[k];
+    if (t < 240) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        const double* __restrict__ g = dNx_csr + (size_t)bg * 30 + q;
+        int e = slot;
+        for (; e + 24 < cnt; e += 32) {  // four entries in flight
+            int v[4];
+            double gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { v[u] = csr_buf[bg + e + 8 * u] >> 3; gv[u] = g[(size_t)(e + 8 * u) * 30]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const double* __restrict__ Pv = P + (size_t)v[u] * 9 + c;
+                a0 += Pv[0] * gv[u];
+                a1 += Pv[3] * gv[u];
+                a2 += Pv[6] * gv[u];
+            }
+        }
+        for (; e < cnt; e += 8) {
+            const int v = csr_buf[bg + e] >> 3;
+            const double gv = g[(size_t)e * 30];
+            const double* __restrict__ Pv = P + (size_t)v * 9 + c;
+            a0 += Pv[0] * gv;
+            a1 += Pv[3] * gv;
+            a2 += Pv[6] * gv;
+        }
+        red[slot][q][0] = a0; red[slot][q][1] = a1; red[slot][q][2] = a2;
+    }
+    __syncthreads();
+    if (t < 30) {
+        const int x = t / 3, r = t - x * 3;  // output row x*3 + r of kernel k
+        double s = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < 8; sl++)
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) s += red[sl][cc * 10 + x][r];
+        const size_t o = (size_t)k * 30 + t;
+        out[o] = momentum[o] + s - rhs_rest[o];
+    }
+}
+
 extern "C" int pn_sim_collect_rhs(int n_k, double dx, const int* csr_bg, const int* csr_cnt, const int* csr_buf, const double* mu, const double* lam,
                                   const double* dNx, const double* RF, const double* VF, double* rhs, void* stream) {
     PN_REQUIRE(n_k > 0 && csr_bg && csr_cnt && csr_buf && mu && lam && dNx && RF && VF && rhs);
@@ -335,35 +391,53 @@ extern "C" int pn_sim_collect_rhs(int n_k, double dx, const int* csr_bg, const i
 __global__ void __launch_bounds__(256) k_matvec3(int n, const double* __restrict__ A, const double* __restrict__ X, double* __restrict__ Y, int mode,
                                                  const double* __restrict__ add1, const double* __restrict__ add2) {
     PN_SIM_PRIO();
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= n) return;
+    // two rows per wave: each X[j,:] fetched once serves both, and the four-deep unroll keeps 20 loads in flight per lane
+    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (i0 >= n) return;
+    const bool two = i0 + 1 < n;
     const int lane = threadIdx.x & 63;
-    const double* __restrict__ a = A + (size_t)i * n;
-    double s0 = 0, s1 = 0, s2 = 0;
-    for (int j = lane; j < n; j += 64) {
-        const double w = a[j];
-        s0 += w * X[j * 3];
-        s1 += w * X[j * 3 + 1];
-        s2 += w * X[j * 3 + 2];
+    const double* __restrict__ a = A + (size_t)i0 * n;
+    const double* __restrict__ b = A + (size_t)(two ? i0 + 1 : i0) * n;
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    int j = lane;
+    for (; j + 192 < n; j += 256) {
+        double wa[4], wb[4], x[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int jj = j + 64 * u;
+            wa[u] = a[jj]; wb[u] = b[jj];
+            x[u][0] = X[jj * 3]; x[u][1] = X[jj * 3 + 1]; x[u][2] = X[jj * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            s[0] += wa[u] * x[u][0]; s[1] += wa[u] * x[u][1]; s[2] += wa[u] * x[u][2];
+            s[3] += wb[u] * x[u][0]; s[4] += wb[u] * x[u][1]; s[5] += wb[u] * x[u][2];
+        }
+    }
+    for (; j < n; j += 64) {
+        const double wa = a[j], wb = b[j];
+        const double x0 = X[j * 3], x1 = X[j * 3 + 1], x2 = X[j * 3 + 2];
+        s[0] += wa * x0; s[1] += wa * x1; s[2] += wa * x2;
+        s[3] += wb * x0; s[4] += wb * x1; s[5] += wb * x2;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s0 += shfl_xor_d(s0, o);
-        s1 += shfl_xor_d(s1, o);
-        s2 += shfl_xor_d(s2, o);
-    }
-    if (lane < 3) {
-        double s = lane == 0 ? s0 : (lane == 1 ? s1 : s2);
-        const size_t o = (size_t)i * 3 + lane;
-        if (mode == 1) s = s + add1[o] + add2[o];
-        else if (mode == 2) s = add1[o] + s;
-        Y[o] = s;
+    for (int q = 0; q < 6; q++)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s[q] += shfl_xor_d(s[q], o);
+    if (lane < (two ? 6 : 3)) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) if (q == lane) v = s[q];
+        const size_t o = (size_t)i0 * 3 + lane;
+        if (mode == 1) v = v + add1[o] + add2[o];
+        else if (mode == 2) v = add1[o] + v;
+        Y[o] = v;
     }
 }
 
 extern "C" int pn_sim_matvec3(int n, const double* A, const double* X, double* Y, void* stream) {
     PN_REQUIRE(n > 0 && A && X && Y);
-    k_matvec3<<<pn_div_up(n, 4), 256, 0, (hipStream_t)stream>>>(n, A, X, Y, 0, nullptr, nullptr);
+    k_matvec3<<<pn_div_up(n, 8), 256, 0, (hipStream_t)stream>>>(n, A, X, Y, 0, nullptr, nullptr);
     PN_LAUNCH_CHECK();
     return PN_OK;
 }
@@ -389,9 +463,9 @@ __global__ void __launch_bounds__(256) k_step_end(int n3, double dt, const doubl
 extern "C" uint64_t pn_sim_work_doubles(int n_k, int n_IP) { return (uint64_t)n_k * 30 * 4 + (uint64_t)n_IP * 9; }
 
 extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, double dx, const int* topo, const int* csr_bg, const int* csr_cnt,
-                                  const int* csr_buf, const double* mu, const double* lam, const double* dNx, const double* Ainv,
-                                  const double* Mmat, const double* dof_rest, const double* rhs_rest, const double* rhs_gravity,
-                                  const double* dof_f, double* dof, double* dof_vel, double* work, void* stream) {
+                                  const int* csr_buf, const double* mu, const double* lam, const double* dNx, const double* dNx_csr,
+                                  const double* Ainv, const double* Mmat, const double* dof_rest, const double* rhs_rest,
+                                  const double* rhs_gravity, const double* dof_f, double* dof, double* dof_vel, double* work, void* stream) {
     PN_REQUIRE(n_k > 0 && n_IP > 0 && iters >= 0 && topo && csr_bg && csr_cnt && csr_buf && mu && lam && dNx && Ainv && Mmat);
     PN_REQUIRE(dof_rest && rhs_rest && rhs_gravity && dof_f && dof && dof_vel && work);
     hipStream_t st = (hipStream_t)stream;
@@ -403,11 +477,14 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
     double* P = work + 4 * (size_t)n3;
     const double dx3 = pow(dx, 3.0);
     k_step_begin<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, dt, dof, dof_vel, tilde, last);
-    k_matvec3<<<pn_div_up(n, 4), 256, 0, st>>>(n, Mmat, tilde, momentum, 1, dof_f, rhs_gravity);  // compute_momentum (:574-576)
+    k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Mmat, tilde, momentum, 1, dof_f, rhs_gravity);  // compute_momentum (:574-576)
     for (int it = 0; it < iters; it++) {
         k_elastic<<<pn_div_up((uint64_t)n_IP * 8, 256), 256, 0, st>>>(n_IP, topo, dNx, dof, nullptr, nullptr, nullptr, P, mu, lam, dx3);
-        k_rhs_gather<<<pn_div_up(n_k, 4), 256, 0, st>>>(n_k, dx3, csr_bg, csr_cnt, csr_buf, mu, lam, dNx, nullptr, nullptr, P, momentum, rhs_rest, tot);
-        k_matvec3<<<pn_div_up(n, 4), 256, 0, st>>>(n, Ainv, tot, dof, 2, dof_rest, nullptr);  // x = G @ rhs ; dof = dof_rest + x (:600-601)
+        if (dNx_csr)  // CSR-ordered copy of dNx available: the coalesced one-workgroup-per-kernel gather
+            k_rhs_gather_csr<<<n_k, 256, 0, st>>>(n_k, csr_bg, csr_cnt, csr_buf, dNx_csr, P, momentum, rhs_rest, tot);
+        else
+            k_rhs_gather<<<pn_div_up(n_k, 4), 256, 0, st>>>(n_k, dx3, csr_bg, csr_cnt, csr_buf, mu, lam, dNx, nullptr, nullptr, P, momentum, rhs_rest, tot);
+        k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Ainv, tot, dof, 2, dof_rest, nullptr);  // x = G @ rhs ; dof = dof_rest + x (:600-601)
     }
     k_step_end<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, dt, dof, last, dof_vel);
     PN_LAUNCH_CHECK();
@@ -441,5 +518,33 @@ extern "C" int pn_sim_update_force(int n_k, int vid, const double* f3_host, doub
 }
 
 // ------------------------------------------------------------------------------------------------ misc
+extern "C" int pn_device_cu_count(void) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    return n;
+}
+
+extern "C" int pn_stream_create_cu_mask(uint32_t total_cu, uint32_t first_cu, uint32_t n_cu, int invert, void** stream_out) {
+    PN_REQUIRE(stream_out && total_cu > 0 && total_cu <= 1024 && n_cu > 0 && first_cu + n_cu <= total_cu);
+    uint32_t mask[32];
+    const uint32_t words = (total_cu + 31) / 32;
+    for (uint32_t w = 0; w < words; w++) mask[w] = 0;
+    for (uint32_t i = 0; i < total_cu; i++) {
+        const bool in = i >= first_cu && i < first_cu + n_cu;
+        if (in != (invert != 0)) mask[i / 32] |= 1u << (i % 32);
+    }
+    hipStream_t s = nullptr;
+    PN_HIP_CHECK(hipExtStreamCreateWithCUMask(&s, words, mask));
+    *stream_out = (void*)s;
+    return PN_OK;
+}
+
+extern "C" int pn_stream_destroy(void* stream) {
+    PN_REQUIRE(stream);
+    PN_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+    return PN_OK;
+}
+
 extern "C" const char* pn_version(void) { return "pienerf_hip 0.1.0 gfx950"; }
 extern "C" const char* pn_last_error(void) { return pn_err_buf; }

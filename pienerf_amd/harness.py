@@ -168,7 +168,19 @@ class SimRenderHarness:
 
     # ------------------------------------------------------------------ several frames in flight on one GPU
     @torch.no_grad()
-    def capture_pipelined(self, lanes=2, n_trips=8, W=None, H=None, sim_ahead=None, sim_priority=0, _probe_no_substep=False):
+    def _cu_masked_stream(self, first_cu, n_cu, invert):
+        import ctypes
+
+        from ._lib import check, lib
+        total = lib().pn_device_cu_count()
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().pn_stream_create_cu_mask(total, first_cu, n_cu, int(invert), ctypes.byref(h)), "stream_create_cu_mask")
+        self._raw_streams = getattr(self, "_raw_streams", []) + [h.value]
+        return torch.cuda.ExternalStream(h.value, device=self.device)
+
+    @torch.no_grad()
+    def capture_pipelined(self, lanes=2, n_trips=8, W=None, H=None, sim_ahead=None, sim_priority=0, sim_cus=0, _probe_no_substep=False):
         """Throughput mode: `lanes` renders in flight on their own streams, the simulator running `sim_ahead` frames ahead.
 
         A render is a chain of short latency-bound launches whose tails leave most of the 256 CUs idle, and the substep is a
@@ -189,14 +201,20 @@ class SimRenderHarness:
                           keepalive=[], sim_next=0)
         p = self._pipe
         self._graph_pose = torch.from_numpy(np.asarray(self.pose, np.float32)).unsqueeze(0).to(dev)
-        p["sim_stream"] = torch.cuda.Stream(dev, priority=sim_priority)
+        if sim_cus > 0:
+            # compute-unit partition: the substep's ~30 small dependent launches get `sim_cus` CUs of their own (spread over the
+            # XCDs), the render lanes the rest, so a substep never waits for a render wave to release registers
+            p["sim_stream"] = self._cu_masked_stream(0, sim_cus, invert=False)
+            streams = [self._cu_masked_stream(0, sim_cus, invert=True) for _ in range(lanes)]
+        else:
+            p["sim_stream"] = torch.cuda.Stream(dev, priority=sim_priority)
+            streams = [torch.cuda.Stream(dev) for _ in range(lanes)]
         p["snap"] = [torch.empty_like(self.sim.dof) for _ in range(slots)]
         p["snap_ready"] = [torch.cuda.Event() for _ in range(slots)]
         keep = (self.sim.dof.clone(), self.sim.dof_vel.clone())
         kw = self.render_kwargs()
         kw["async_trips"] = n_trips
         main = torch.cuda.current_stream(dev)
-        streams = [torch.cuda.Stream(dev) for _ in range(lanes)]
         n_IP = self.sim.n_IP
         for lane in range(lanes):  # warm-up of every lane outside capture (creates the per-lane frame workspaces)
             s = streams[lane]

@@ -121,6 +121,9 @@ class Simulator:
         self.kernel_cnt = torch.bincount(keys, minlength=n_k).to(torch.int32).contiguous()
         self.kernel_bg = (torch.cumsum(self.kernel_cnt, dim=0, dtype=torch.int32) - self.kernel_cnt).contiguous()
         self.tot = int(self.kernel_cnt.sum())
+        # dNx rows in CSR order (6.9 MB on the chair): the step driver's collect_rhs then reads each kernel's entries as one
+        # contiguous stream instead of chasing `buffer` (pn_sim_stepforward, dNx_csr)
+        self.dNx_csr = self.IP_dNx.reshape(n_IP * 8, 30)[order].contiguous()
 
         m = (self.IP_rho * self.dx * self.dx * self.dx)                                      # collect_gravity, cuda_utils.py:262-279
         rg = torch.zeros((n_k * 10, 3), dtype=torchfloat, device=dev)
@@ -195,7 +198,7 @@ class Simulator:
 
     def stepforward(self):  # solver.py:595-602
         check(lib().pn_sim_stepforward(self.n_k, self.n_IP, int(self.iters), float(self.dt), float(self.dx), ptr(self.IP_kernel), ptr(self.kernel_bg),
-                                       ptr(self.kernel_cnt), ptr(self.buffer), ptr(self.IP_mu), ptr(self.IP_lam), ptr(self.IP_dNx), ptr(self.Ainv),
+                                       ptr(self.kernel_cnt), ptr(self.buffer), ptr(self.IP_mu), ptr(self.IP_lam), ptr(self.IP_dNx), ptr(self.dNx_csr), ptr(self.Ainv),
                                        ptr(self.Mmat), ptr(self.dof_rest), ptr(self.rhs_rest), ptr(self.rhs_gravity), ptr(self.dof_f), ptr(self.dof),
                                        ptr(self.dof_vel), ptr(self._work), stream_ptr()), "stepforward")
 

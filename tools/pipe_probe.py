@@ -21,6 +21,7 @@ ap.add_argument("--steps", type=int, default=300)
 ap.add_argument("--trips", type=int, default=8)
 ap.add_argument("--sim-priority", type=int, default=0)
 ap.add_argument("--no-substep", action="store_true")
+ap.add_argument("--sim-cus", type=int, default=0)
 args = ap.parse_args()
 opt = scene.default_opt()
 dev = torch.device("cuda:0")
@@ -39,7 +40,7 @@ for L in args.lanes:
     h = SimRenderHarness(opt, device=dev)
     for _ in range(20):
         h.sim.stepforward()
-    h.capture_pipelined(lanes=L, n_trips=args.trips, sim_priority=args.sim_priority, _probe_no_substep=args.no_substep)
+    h.capture_pipelined(lanes=L, n_trips=args.trips, sim_priority=args.sim_priority, sim_cus=args.sim_cus, _probe_no_substep=args.no_substep)
     p = h._pipe
     for _ in range(3 * L):
         h.step_pipelined()
