@@ -142,30 +142,41 @@ def kernel_report(h, opt, dev):
     net_tf = MLP_FLOP_PER_SAMPLE * B / (t_net * 1e-3) / 1e12
     # HBM traffic per launch from the committed PMC passes (profiles/pmc_traffic.json: FETCH_SIZE + WRITE_SIZE, KB, separate rocprofv3 runs);
     # the profile averaged over all enqueued trips, the empty ones move ~nothing, so scale to the real launches like `achieved`
-    traffic = None
+    traffic = {}
     pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         with open(pmc_path) as f:
-            pm = json.load(f)["k_march"]
-        frames = pm["dispatches"] / 8.0
-        traffic = int((pm["fetch_kb_per_launch"] + pm["write_kb_per_launch"]) * 1024 * pm["dispatches"] / (frames * pm["real_trips_per_frame"]))
+            pmc = json.load(f)
+        for kname in ("k_nerf_forward", "k_march"):
+            pm = pmc.get(kname)
+            if pm:
+                frames = pm["dispatches"] / float(pm.get("enqueued_trips_per_frame", 8))
+                traffic[kname] = int((pm["fetch_kb_per_launch"] + pm["write_kb_per_launch"]) * 1024 * pm["dispatches"] / (frames * pm["real_trips_per_frame"]))
+    # dominant kernel = the fused network kernel (largest single-kernel share of the step's GPU time, profiles/README.md): its launches in
+    # the render loop, HIP events on the launch stream around each of them (pn_frame_trip_times)
+    net_loop_ms = float(net_ms[:real].sum())
+    net_loop_gbs = FUSED_BYTES_PER_SAMPLE * st["samples"] / (net_loop_ms * 1e-3) / 1e9
     roofline = {
-        "kernel": "k_march<3,false> (ray march + inverse-GMLS warp; largest share of the step)", "bound": "hbm", "achieved": round(march_gbs, 1),
-        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(march_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
-        "traffic_note": "bytes per launch, FETCH_SIZE+WRITE_SIZE PMC passes (profiles/pmc_traffic.json); far below the algorithmic bytes because the "
-                        "candidate lists / IP records (~1 MB) stay L2/MALL resident - no wasted HBM re-reads",
-        "launch_ms": round(march_launch, 4), "launches_per_frame": real, "ms_per_frame": round(march_total, 4),
-        # rocprofv3 --stats averages over every enqueued launch, the empty tail trips (a few us each) included: this is the figure to compare
-        "launch_ms_incl_empty_trips": round(float(march_ms.mean()), 4), "launches_enqueued_per_frame": int(len(march_ms)),
-        "units_per_frame": cnt, "algorithmic_bytes_per_frame": int(march_bytes),
-        "note": "latency/divergence-bound pointer chase (<= 100 dependent iterations per ray, ~70k active rays), not a streaming kernel: "
-                "the HBM fraction is reported for completeness; see DESIGN.md §4",
+        "kernel": "k_nerf_forward<2,4> (hash-grid gather + SH + 5-layer MLP fused, f32 MFMA), launches inside the render loop",
+        "bound": "hbm", "achieved": round(net_loop_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(net_loop_gbs / HBM_PEAK_GBS, 4),
+        "traffic": traffic.get("k_nerf_forward"),
+        "traffic_note": "bytes per launch, FETCH_SIZE+WRITE_SIZE PMC passes (profiles/pmc_traffic.json); below the algorithmic bytes because the dense "
+                        "levels and part of the hashed tables are served by L2 / Infinity Cache",
+        "launch_ms": round(net_loop_ms / real, 4), "launches_per_frame": real, "ms_per_frame": round(net_loop_ms, 4),
+        "launch_ms_incl_empty_trips": round(float(net_ms.mean()), 4), "launches_enqueued_per_frame": int(len(net_ms)),
+        "bytes_per_sample": FUSED_BYTES_PER_SAMPLE, "samples_per_frame": st["samples"],
+        "algorithmic_bytes_per_launch": int(FUSED_BYTES_PER_SAMPLE * st["samples"] / real),
+        "mfma_tflops_in_loop": round(MLP_FLOP_PER_SAMPLE * st["samples"] / (net_loop_ms * 1e-3) / 1e12, 2),
+        "all_samples_one_launch": {"launch_ms": round(t_net, 4), "achieved_GBps": round(net_gbs, 1), "frac_of_hbm_peak": round(net_gbs / HBM_PEAK_GBS, 4),
+                                   "mfma_tflops": round(net_tf, 2), "frac_of_f32_mfma_peak": round(net_tf / F32_MFMA_PEAK_TF, 4)},
+        "note": "gather and MFMA phases of a wave are serial (each ~half of the time): both rooflines are reported; see DESIGN.md 4.2",
     }
     extra = {
-        "network": {"kernel": "k_nerf_forward<2,4> (hash-grid gather + SH + MLP fused, f32 MFMA)", "bound": "hbm", "achieved_GBps": round(net_gbs, 1),
-                    "frac_of_hbm_peak": round(net_gbs / HBM_PEAK_GBS, 4), "launch_ms_all_samples": round(t_net, 4), "samples": B,
-                    "mfma_tflops": round(net_tf, 2), "frac_of_f32_mfma_peak": round(net_tf / F32_MFMA_PEAK_TF, 4),
-                    "ms_per_frame_in_loop": round(float(net_ms[:real].sum()), 4), "bytes_per_sample": FUSED_BYTES_PER_SAMPLE},
+        "march": {"kernels": "k_march_skip + k_march<3,false> + k_march_tail<3,false> per loop trip (ray march + inverse-GMLS warp)",
+                  "ms_per_frame": round(march_total, 4), "launch_group_ms": round(march_launch, 4), "trips_per_frame": real,
+                  "units_per_frame": cnt, "algorithmic_bytes_per_frame": int(march_bytes), "achieved_GBps": round(march_gbs, 1),
+                  "frac_of_hbm_peak": round(march_gbs / HBM_PEAK_GBS, 5), "traffic_bytes_per_launch": traffic.get("k_march"),
+                  "note": "latency/divergence-bound pointer chase over ~1 MB of cache-resident tables, not a streaming kernel (DESIGN.md 4.1)"},
         "hash_lookup": {"kernel": "k_grid_encode<2> (stand-alone hash-grid lookup, output [L,B,C] like the reference kernel)",
                         "achieved_GBps": round(grid_gbs, 1), "frac_of_hbm_peak": round(grid_gbs / HBM_PEAK_GBS, 4), "launch_ms": round(t_grid, 4),
                         "bytes_per_sample": HASH_BYTES_PER_SAMPLE, "launch_ms_direct_BLC_output": round(t_grid_bl, 4)},

@@ -108,12 +108,10 @@ __global__ void __launch_bounds__(256) k_pig_count(int n_vtx, int n_grid_max, co
     else if (err_flag) atomicOr(err_flag, 2);
 }
 
-// pig_bgn = cumsum(cnt) - cnt (nerf/utils.py:369), one workgroup, 4 cells per thread per tile.
-__global__ void __launch_bounds__(1024) k_pig_scan(int n_grid_max, const int* __restrict__ n_grid_dev, const int* __restrict__ cnt,
-                                                   int* __restrict__ bgn, int* __restrict__ cursor) {
+// pig_bgn = cumsum(cnt) - cnt (nerf/utils.py:369), one workgroup of 1024 threads, 4 cells per thread per tile.
+__device__ __forceinline__ void block_scan_1024(int n_grid, const int* __restrict__ cnt, int* __restrict__ bgn, int* __restrict__ cursor) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
-    const int n_grid = n_grid_dev ? min(*n_grid_dev, n_grid_max) : n_grid_max;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
@@ -145,6 +143,11 @@ __global__ void __launch_bounds__(1024) k_pig_scan(int n_grid_max, const int* __
         if (threadIdx.x == 0) carry_s += total;
         __syncthreads();
     }
+}
+__global__ void __launch_bounds__(1024) k_pig_scan(int n_grid_max, const int* __restrict__ n_grid_dev, const int* __restrict__ cnt,
+                                                   int* __restrict__ bgn, int* __restrict__ cursor) {
+    const int n_grid = n_grid_dev ? min(*n_grid_dev, n_grid_max) : n_grid_max;
+    block_scan_1024(n_grid, cnt, bgn, cursor);
 }
 
 // get_pig_idx, nerf/utils.py:427-443 — slots claimed through a per-cell cursor ...
@@ -730,6 +733,249 @@ __global__ void __launch_bounds__(256) k_frame_finish(uint32_t N, float bg, cons
     depth[i] = fmaxf(depth_0[i] - nears[i], 0.0f) / (fars[i] - nears[i]);
 }
 
+// ---- fused frame prologue (3 launches instead of 13; every one of them was a few-microsecond kernel with a launch gap)
+// (1) k_frame_tables, ONE workgroup of 1024 threads: IP bounding box + spatial-hash resolution (k_frame_bbox), the spatial
+//     hash itself (count -> scan -> cursor fill -> per-cell sort, = k_pig_*) and the per-cell candidate-list offsets (k_nb_count
+//     + scan).  The phases talk through global memory (L2) with relaxed agent-scope atomic loads where a value was produced by
+//     an atomic or by another thread of the block, and __syncthreads() in between.
+__global__ void __launch_bounds__(1024) k_frame_tables(const float* __restrict__ p_def, int n_vtx, int cut, float bound, float hgs, int max_cells,
+                                                       PnFrameDev* dev, int* pig_cnt, int* pig_bgn, int* pig_idx, int* pig_cursor, int swap,
+                                                       int* nb_cnt, int* nb_bgn, int* nb_cursor) {
+    extern __shared__ unsigned cnt2[];  // per-cell point counts, two 16-bit counters per word (a cell never holds 65 536 IPs)
+    __shared__ float smin[3][16], smax[3][16];
+    __shared__ float sh_min[3];
+    __shared__ int sh_res[4];
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = threadIdx.x; i < n_vtx; i += blockDim.x)
+#pragma unroll
+        for (int c = 0; c < 3; c++) { const float v = p_def[i * 3 + c]; mn[c] = fminf(mn[c], v); mx[c] = fmaxf(mx[c], v); }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mn[c] = fminf(mn[c], __shfl_xor(mn[c], o)); mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o)); }
+        if (lane == 0) { smin[c][wid] = mn[c]; smax[c][wid] = mx[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // renderer.py:782-791
+        int ncell = 1;
+        for (int c = 0; c < 3; c++) {
+            float a = smin[c][0], b = smax[c][0];
+            for (int w = 1; w < 16; w++) { a = fminf(a, smin[c][w]); b = fmaxf(b, smax[c][w]); }
+            if (cut) { a = -bound; b = bound; }
+            const float lo = a - 1e-3f, hi = b + 1e-3f;
+            dev->aabb[c] = lo;
+            dev->aabb[3 + c] = hi;
+            sh_min[c] = lo;
+            const int r = (int)ceilf((hi - lo) / hgs);
+            dev->resolution[c] = r;
+            sh_res[c] = r;
+            ncell *= r;
+        }
+        int err = 0;
+        if (ncell > max_cells || ncell <= 0) { err = 4; ncell = 0; }
+        dev->resolution[3] = ncell;
+        dev->err = err;
+        sh_res[3] = ncell;
+        carry_s = 0;
+    }
+    __syncthreads();
+    const int n_grid = sh_res[3], r0 = sh_res[0], r1 = sh_res[1], r2 = sh_res[2];
+    const float b0 = sh_min[0], b1 = sh_min[1], b2 = sh_min[2];
+    if (n_grid == 0) { if (threadIdx.x == 0) nb_bgn[0] = 0; return; }
+    for (int g = threadIdx.x; g < (n_grid + 1) / 2; g += blockDim.x) cnt2[g] = 0u;
+    __syncthreads();
+    auto cell_of = [&](int p) {  // p2g, nerf/utils.py:389-407
+        const int g0 = (int)floorf((p_def[p * 3] - b0) / hgs);
+        const int g1 = (int)floorf((p_def[p * 3 + 1] - b1) / hgs);
+        const int g2 = (int)floorf((p_def[p * 3 + 2] - b2) / hgs);
+        const int gid = g2 * r1 * r0 + g1 * r0 + g0;
+        return (gid < 0 || gid >= n_grid) ? -1 : gid;
+    };
+    auto count_of = [&](int g) { return (int)((cnt2[g >> 1] >> (16 * (g & 1))) & 0xFFFFu); };
+    for (int p = threadIdx.x; p < n_vtx; p += blockDim.x) {
+        const int gid = cell_of(p);
+        if (gid >= 0) atomicAdd(&cnt2[gid >> 1], 1u << (16 * (gid & 1)));
+        else atomicOr(&dev->err, 2);
+    }
+    __syncthreads();
+    // exclusive scan of the counts -> pig_cnt / pig_bgn / pig_cursor, then of the 27-neighbourhood sums -> nb_cnt / nb_bgn / nb_cursor
+    for (int pass = 0; pass < 2; pass++) {
+        int* out_cnt = pass ? nb_cnt : pig_cnt;
+        int* out_bgn = pass ? nb_bgn : pig_bgn;
+        int* out_cur = pass ? nb_cursor : pig_cursor;
+        for (int base = 0; base < n_grid; base += 4096) {
+            const int i0 = base + threadIdx.x * 4;
+            int v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int c = i0 + k;
+                int val = 0;
+                if (c < n_grid) {
+                    val = count_of(c);
+                    if (pass) {  // k_nb_count: the cell and its 26 neighbours
+                        int g0, g1, g2;
+                        nb_cell_coords(c, r0, r1, g0, g1, g2);
+                        for (int q = 0; q < 26; q++) {
+                            const int nbc = nb_neighbour(q, swap, g0, g1, g2, r0, r1, r2);
+                            if (nbc >= 0) val += count_of(nbc);
+                        }
+                    }
+                    out_cnt[c] = val;
+                }
+                v[k] = val;
+            }
+            const int tsum = v[0] + v[1] + v[2] + v[3];
+            int inc = tsum;  // inclusive wave scan
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int u = __shfl_up(inc, o);
+                if (lane >= o) inc += u;
+            }
+            if (lane == 63) wsum[wid] = inc;
+            __syncthreads();
+            int woff = 0;
+            for (int w = 0; w < wid; w++) woff += wsum[w];
+            int total = 0;
+            for (int w = 0; w < 16; w++) total += wsum[w];
+            int run = carry_s + woff + inc - tsum;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (i0 + k < n_grid) { out_bgn[i0 + k] = run; out_cur[i0 + k] = run; }
+                run += v[k];
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) carry_s += total;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) carry_s = 0;
+        __syncthreads();
+    }
+    // cursor fill (get_pig_idx, nerf/utils.py:427-443): slots claimed through the per-cell cursor, entries staged in LDS ...
+    int* lidx = reinterpret_cast<int*>(cnt2 + (max_cells + 1) / 2);
+    for (int p = threadIdx.x; p < n_vtx; p += blockDim.x) {
+        const int gid = cell_of(p);
+        if (gid >= 0) lidx[atomicAdd(pig_cursor + gid, 1)] = p;
+    }
+    __syncthreads();
+    // ... then ascending point id inside each cell (k_pig_sort): the table does not depend on the order of the atomics
+    for (int g = threadIdx.x; g < n_grid; g += blockDim.x) {
+        const int c = count_of(g);
+        if (c < 2) continue;
+        int* a = lidx + __hip_atomic_load(pig_bgn + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 1; i < c; i++) {
+            const int v = a[i];
+            int j = i - 1;
+            while (j >= 0 && a[j] > v) { a[j + 1] = a[j]; j--; }
+            a[j + 1] = v;
+        }
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < n_vtx; p += blockDim.x) pig_idx[p] = lidx[p];
+}
+
+// (2) k_frame_lists: candidate lists with 8 lanes per cell (lane j copies neighbours j, j+8, j+16, j+24 of the 27 in visiting
+//     order, after summing the counts of the neighbours before its own) + the packed IP records (blocks >= list_blocks).
+__global__ void __launch_bounds__(256) k_frame_lists(int n_grid_max, const int* __restrict__ n_grid_dev, const int* __restrict__ res,
+                                                     const int* __restrict__ pig_cnt, const int* __restrict__ pig_bgn, const int* __restrict__ pig_idx,
+                                                     const float* __restrict__ p_def, int swap, const int* __restrict__ nb_cnt, int* __restrict__ nb_bgn,
+                                                     float4* __restrict__ nb, int nb_capacity, int* err_flag, int list_blocks, int n_vtx,
+                                                     const float* __restrict__ p_ori, const float* __restrict__ F_IP, const float* __restrict__ dF_IP,
+                                                     float* __restrict__ rec) {
+    if ((int)blockIdx.x >= list_blocks) {  // k_pack_ip
+        const int t = threadIdx.x + ((int)blockIdx.x - list_blocks) * 256;
+        const int ip = t / 44, j = t % 44;
+        if (ip >= n_vtx) return;
+        float v = 0.f;
+        if (j < 3) v = p_ori[ip * 3 + j];
+        else if (j < 6) v = p_def[ip * 3 + j - 3];
+        else if (j < 15) v = F_IP[ip * 9 + j - 6];
+        else if (j < 42) v = dF_IP[ip * 27 + j - 15];
+        rec[t] = v;
+        return;
+    }
+    const int n_grid = min(*n_grid_dev, n_grid_max);
+    const int r0 = res[0], r1 = res[1], r2 = res[2];
+    const int sub = threadIdx.x & 7;
+    for (int c = (threadIdx.x + blockIdx.x * 256) >> 3; c < n_grid; c += (list_blocks * 256) >> 3) {
+        const int w0 = nb_bgn[c], total = nb_cnt[c];
+        if (c == n_grid - 1 && sub == 0) nb_bgn[n_grid] = w0 + total;  // closing offset
+        if (total == 0) continue;
+        if (w0 + total > nb_capacity) { if (err_flag && sub == 0) atomicOr(err_flag, 8); continue; }
+        int g0, g1, g2;
+        nb_cell_coords(c, r0, r1, g0, g1, g2);
+        // visiting position q = 0 is the cell itself, q = 1..26 its neighbours k = q - 1
+        int before = 0;  // entries of the positions before this lane's first one
+        for (int q = 0; q < sub; q++) {
+            const int cell = (q == 0) ? c : nb_neighbour(q - 1, swap, g0, g1, g2, r0, r1, r2);
+            if (cell >= 0) before += pig_cnt[cell];
+        }
+        for (int q = sub; q < 27; q += 8) {
+            const int cell = (q == 0) ? c : nb_neighbour(q - 1, swap, g0, g1, g2, r0, r1, r2);
+            if (cell >= 0) {
+                const int n = pig_cnt[cell], b = pig_bgn[cell];
+                for (int i = 0; i < n; i++) {
+                    const int ip = pig_idx[b + i];
+                    nb[w0 + before + i] = make_float4(p_def[ip * 3], p_def[ip * 3 + 1], p_def[ip * 3 + 2], __int_as_float(ip));
+                }
+                before += n;
+            }
+            for (int q2 = q + 1; q2 < q + 8 && q2 < 27; q2++) {  // skip the 7 positions owned by the other lanes
+                const int cell2 = nb_neighbour(q2 - 1, swap, g0, g1, g2, r0, r1, r2);
+                if (cell2 >= 0) before += pig_cnt[cell2];
+            }
+        }
+    }
+}
+
+// (3) k_frame_rays: k_near_far + k_frame_init in one pass over the rays.
+__global__ void __launch_bounds__(256) k_frame_rays(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const PnFrameDev* dev, uint32_t N,
+                                                    float min_near, float* __restrict__ nears, float* __restrict__ fars, float* __restrict__ rays_t,
+                                                    PnTrip* trips, int* tail_counts, int n_trip_records, int* alive, float* __restrict__ weights_sum,
+                                                    float* __restrict__ depth_0, float* __restrict__ image) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (blockIdx.x == 0) {
+        for (int t = threadIdx.x; t < n_trip_records; t += blockDim.x) {
+            PnTrip r{0, 0, 0, 0};
+            if (t == 0) { r.n_alive = dev->err ? 0 : (int)N; r.n_step = 1; }  // max(min(N // N, 8), 1)
+            trips[t] = r;
+            tail_counts[t] = 0;
+        }
+    }
+    if (n >= N) return;
+    const float* aabb = dev->aabb;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx;
+    if (near > far) { float c = near; near = far; far = c; }
+    float near_y = (aabb[1] - oy) * rdy, far_y = (aabb[4] - oy) * rdy;
+    if (near_y > far_y) { float c = near_y; near_y = far_y; far_y = c; }
+    bool miss = (near > far_y || near_y > far);
+    if (!miss) {
+        if (near_y > near) near = near_y;
+        if (far_y < far) far = far_y;
+        float near_z = (aabb[2] - oz) * rdz, far_z = (aabb[5] - oz) * rdz;
+        if (near_z > far_z) { float c = near_z; near_z = far_z; far_z = c; }
+        miss = (near > far_z || near_z > far);
+        if (!miss) {
+            if (near_z > near) near = near_z;
+            if (far_z < far) far = far_z;
+            if (near < min_near) near = min_near;
+        }
+    }
+    if (miss) near = far = FLT_MAX;
+    nears[n] = near;
+    fars[n] = far;
+    rays_t[n] = near;  // rays_t = nears.clone() (renderer.py:829)
+    alive[n] = (int)n;
+    weights_sum[n] = 0.f;
+    depth_0[n] = 0.f;
+    image[n * 3] = 0.f; image[n * 3 + 1] = 0.f; image[n * 3 + 2] = 0.f;
+}
+
 extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_vtx, uint32_t max_grid_cells) {
     PN_REQUIRE(out && max_rays > 0 && max_vtx > 0 && max_grid_cells > 0);
     pn_frame* f = new pn_frame();
@@ -808,21 +1054,31 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
         f->cut_bounds_valid = 1;
     }
 
-    k_frame_bbox<<<1, 1024, 0, st>>>(p_def, n_vtx, o->cut, o->bound, o->hash_grid_size, (int)f->max_cells, f->dev);
     const float* bbmin = f->dev->aabb;  // device addresses of struct members
     const float* bbmax = f->dev->aabb + 3;
     const int* res = f->dev->resolution;
     const int* n_grid_dev = f->dev->resolution + 3;
     int* err = &f->dev->err;
-    int rc = pig_build(n_vtx, (int)f->max_cells, n_grid_dev, p_def, bbmin, o->hash_grid_size, res, f->pig_cnt, f->pig_bgn, f->pig_idx,
-                       f->pig_cursor, err, st);
-    if (rc) return rc;
-    rc = march_side_build(f->side, n_vtx, (int)f->max_cells, n_grid_dev, res, f->pig_cnt, f->pig_bgn, f->pig_idx, p_def, p_ori, F_IP, dF_IP,
-                          o->num_seek_IP, err, st);
-    if (rc) return rc;
+    int rc = PN_OK;
+    const int swap = (o->num_seek_IP == 1) ? 1 : 0;
+    // two 16-bit cell counters per LDS word + the staged point-index table
+    const size_t tables_lds = ((size_t)f->max_cells + 1) / 2 * sizeof(unsigned) + (size_t)f->max_vtx * sizeof(int);
+    PN_REQUIRE(tables_lds <= 150 * 1024);
+    static size_t tables_lds_set = 0;
+    if (tables_lds > tables_lds_set) {  // dynamic LDS above 64 KB has to be opted into (gfx950: 160 KB per workgroup)
+        PN_HIP_CHECK(hipFuncSetAttribute((const void*)k_frame_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tables_lds));
+        tables_lds_set = tables_lds;
+    }
+    k_frame_tables<<<1, 1024, tables_lds, st>>>(p_def, n_vtx, o->cut, o->bound, o->hash_grid_size, (int)f->max_cells, f->dev, f->pig_cnt, f->pig_bgn,
+                                       f->pig_idx, f->pig_cursor, swap, f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor);
+    const int list_blocks = (int)std::min(pn_div_up((uint64_t)f->max_cells * 8, 256), 2048u);
+    const int pack_blocks = (int)pn_div_up((uint64_t)n_vtx * 44, 256);
+    k_frame_lists<<<list_blocks + pack_blocks, 256, 0, st>>>((int)f->max_cells, n_grid_dev, res, f->pig_cnt, f->pig_bgn, f->pig_idx, p_def, swap,
+                                                             f->side.nb_cnt, f->side.nb_bgn, f->side.nb, f->side.nb_capacity, err, list_blocks, n_vtx,
+                                                             p_ori, F_IP, dF_IP, f->side.rec);
     pnm2::March2Tables tb{f->side.nb_bgn, f->side.nb, (const float4*)f->side.rec};
-    k_near_far<<<nblk, 256, 0, st>>>(rays_o, rays_d, f->dev->aabb, N, o->min_near, f->nears, f->fars, f->rays_t);
-    k_frame_init<<<nblk, 256, 0, st>>>(f->trips, f->tail_counts, PN_MAX_TRIPS + 2, N, f->alive_a, f->dev, weights_sum, depth_0, image);
+    k_frame_rays<<<nblk, 256, 0, st>>>(rays_o, rays_d, f->dev, N, o->min_near, f->nears, f->fars, f->rays_t, f->trips, f->tail_counts,
+                                       PN_MAX_TRIPS + 2, f->alive_a, weights_sum, depth_0, image);
     PN_LAUNCH_CHECK();
 
     pnm::MarchParams mp = make_march_params(f->pig_cnt, f->pig_bgn, f->pig_idx, n_vtx, 0, p_def, p_ori, F_IP, dF_IP, o->max_iter_num, bbmin, bbmax,
