@@ -226,20 +226,12 @@ struct MarchArgs {
 // ray-slot's first sample.
 // optional instrumentation (ORC_MARCH_STATS=1): loop iterations per call / max per ray / iterations with candidates
 static long long g_march_iters = 0, g_march_found = 0;
-static int g_march_max = 0, g_sp_max = 0;
-static long long g_sp_rounds = 0;
+static int g_march_max = 0;
 static std::vector<int> g_march_hist(16, 0);
 static const bool g_march_stats = getenv("ORC_MARCH_STATS") != nullptr;
-// study hooks (ORC_MARCH_STATS only): run ONE iteration from an arbitrary t and report where it leaves t
-static thread_local bool g_probe = false;
-static thread_local float g_probe_t = 0.0f;
-static long long g_merge_hit = 0, g_merge_all = 0;
-static std::vector<int> g_el_hist(16, 0);
 
 uint32_t march_one(const MarchArgs& a, int index, float noise, float* xyzs, float* dirs, float* deltas, int* oob_flag) {
     int iters = 0, iters_found = 0;
-    std::vector<float> visited_ts;
-    float first_found_t = -1.0f;
     const float* ro = a.rays_o + (size_t)index * 3;
     const float* rd = a.rays_d + (size_t)index * 3;
     const float ox = ro[0], oy = ro[1], oz = ro[2];
@@ -255,52 +247,13 @@ uint32_t march_one(const MarchArgs& a, int index, float noise, float* xyzs, floa
     uint32_t step = 0;
     t += clampf(t * a.dt_gamma, dt_min, dt_max) * noise;
     float last_t = t;
-    if (g_probe) t = g_probe_t;
     const float* bbmin = a.bbmin;
     const float* bbmax = a.bbmax;
     const float* cb = a.cut_bounds;
     const int* res = a.pg.res;
 
-    // ORC_MARCH_STATS only — study for the GPU kernel: if the next 7 visited t values are PREDICTED from the last visited point
-    // (warp ~ translation by that point's offset, or the constant origin; same emit/skip behaviour) and 8 points are evaluated per
-    // round, how many rounds does a ray need?  A round ends at the first visited t that was not predicted.
-    int sp_rounds = 0, sp_pos = 8, lv_kind = 0;
-    float sp_pred[8], lv_off[3] = {0, 0, 0};
-    bool lv_emit = false;
-    auto sp_predict = [&](float tp) {
-        if (lv_emit) return tp + clampf(tp * a.dt_gamma, dt_min, dt_max);
-        float px = clampf(ox + tp * dx, bbmin[0], (float)((double)bbmax[0] - 1e-6));
-        float py = clampf(oy + tp * dy, bbmin[1], (float)((double)bbmax[1] - 1e-6));
-        float pz = clampf(oz + tp * dz, bbmin[2], (float)((double)bbmax[2] - 1e-6));
-        if (lv_kind == 1) { px = py = pz = 0.0f; } else { px += lv_off[0]; py += lv_off[1]; pz += lv_off[2]; }
-        const float dtp = clampf(tp * a.dt_gamma, dt_min, dt_max);
-        const int lvl = std::max(mip_from_pos(px, py, pz, (float)C), mip_from_dt(dtp, (float)H, (float)C));
-        const float mb = fminf(scalbnf(1, lvl), a.bound), mrb = 1 / mb;
-        const int qx = (int)clampf((float)(0.5 * (double)(px * mrb + 1) * (double)H), 0.0f, (float)(H - 1));
-        const int qy = (int)clampf((float)(0.5 * (double)(py * mrb + 1) * (double)H), 0.0f, (float)(H - 1));
-        const int qz = (int)clampf((float)(0.5 * (double)(pz * mrb + 1) * (double)H), 0.0f, (float)(H - 1));
-        const float ux = (((qx + 0.5f + 0.5f * signf(dx)) * rH * 2 - 1) * mb - px) * rdx;
-        const float uy = (((qy + 0.5f + 0.5f * signf(dy)) * rH * 2 - 1) * mb - py) * rdy;
-        const float uz = (((qz + 0.5f + 0.5f * signf(dz)) * rH * 2 - 1) * mb - pz) * rdz;
-        const float tq = tp + fmaxf(0.0f, fminf(ux, fminf(uy, uz)));
-        float u = tp;
-        do { u += clampf(u * a.dt_gamma, dt_min, dt_max); } while (u < tq);
-        return u;
-    };
-
     while (t < far && step < a.n_step) {
         iters++;
-        if (g_probe && iters > 1) { g_probe_t = t; return 0; }
-        if (g_march_stats && !g_probe) visited_ts.push_back(t);
-        if (g_march_stats && !g_probe) {
-            if (sp_pos >= 8 || sp_pred[sp_pos] != t) {
-                sp_rounds++;
-                sp_pos = 0;
-                sp_pred[0] = t;
-                for (int j = 1; j < 8; j++) sp_pred[j] = sp_predict(sp_pred[j - 1]);
-            }
-            sp_pos++;
-        }
         bool found = false;
         float x, y, z;
         if (a.cut) {
@@ -312,7 +265,6 @@ uint32_t march_one(const MarchArgs& a, int index, float noise, float* xyzs, floa
             y = clampf(oy + t * dy, bbmin[1], (float)((double)bbmax[1] - 1e-6));
             z = clampf(oz + t * dz, bbmin[2], (float)((double)bbmax[2] - 1e-6));
         }
-        const float xu = x, yu = y, zu = z;
         // quirk R7q-i: `x < cut_bounds[3]` where y is meant (:1210)
         if (!a.cut || (x > cb[0] && x < cb[1] && y > cb[2] && x < cb[3] && z > cb[4] && z < cb[5])) {
             float x_map = 0.0f, y_map = 0.0f, z_map = 0.0f;
@@ -333,7 +285,6 @@ uint32_t march_one(const MarchArgs& a, int index, float noise, float* xyzs, floa
             }
             found = n_IP > 0;
             if (found) iters_found++;
-            if (found && first_found_t < 0) first_found_t = t;
             if (found) {
                 // quirks R7q-iii/iv: n_IP-- inside the loop it bounds; strict '<' on z only (:1246-1251)
                 for (int k = 0; k < n_IP; k++) {
@@ -397,11 +348,6 @@ uint32_t march_one(const MarchArgs& a, int index, float noise, float* xyzs, floa
         const int nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
         const uint32_t vox = (uint32_t)(level * H3 + (float)morton3D(nx, ny, nz));
         const bool occ = a.grid[vox / 8] & (1 << (vox % 8));
-        if (g_march_stats) {
-            lv_emit = occ && found;
-            lv_kind = (found && x == 0.0f && y == 0.0f && z == 0.0f) ? 1 : 0;
-            lv_off[0] = x - xu; lv_off[1] = y - yu; lv_off[2] = z - zu;
-        }
 
         if (occ && found) {
             xyzs[0] = x; xyzs[1] = y; xyzs[2] = z;
@@ -421,44 +367,13 @@ uint32_t march_one(const MarchArgs& a, int index, float noise, float* xyzs, floa
             do { t += clampf(t * a.dt_gamma, dt_min, dt_max); } while (t < tt);
         }
     }
-    if (g_probe) { g_probe_t = t; return 0; }
-    if (g_march_stats && iters >= 16) {
-        // merge study: start ONE iteration at every element of the t sequence between the first and last visited point; does it
-        // land on a point the real chain visits?  (chains that enter the same density voxel leave it at the same element)
-        float sx[3], sd[3], sl[2];
-        long long hit = 0, all = 0;
-        float u = visited_ts.front();
-        size_t vi = 0;
-        while (u < visited_ts.back()) {
-            while (vi < visited_ts.size() && visited_ts[vi] < u) vi++;
-            if (!(vi < visited_ts.size() && visited_ts[vi] == u)) {  // not on the chain itself
-                g_probe = true; g_probe_t = u;
-                march_one(a, index, noise, sx, sd, sl, nullptr);
-                g_probe = false;
-                const float land = g_probe_t;
-                all++;
-                if (std::binary_search(visited_ts.begin(), visited_ts.end(), land) || land > visited_ts.back()) hit++;
-            }
-            u += clampf(u * a.dt_gamma, dt_min, dt_max);
-        }
-#pragma omp critical
-        { g_merge_hit += hit; g_merge_all += all; }
-    }
     if (g_march_stats) {
 #pragma omp critical
         {
             g_march_iters += iters; g_march_found += iters_found;
             if (iters > g_march_max) g_march_max = iters;
-            if (sp_rounds > g_sp_max) g_sp_max = sp_rounds;
-            g_sp_rounds += sp_rounds;
             int b = 0; while ((1 << b) <= iters && b < 15) b++;
             g_march_hist[b]++;
-            if (first_found_t >= 0) {  // sequence elements from the first point with candidates to where the trip left the ray
-                int el = 0;
-                for (float u = first_found_t; u < t && el < 100000; u += clampf(u * a.dt_gamma, dt_min, dt_max)) el++;
-                int eb = 0; while ((1 << eb) <= el && eb < 15) eb++;
-                g_el_hist[eb]++;
-            }
         }
     }
     return step;
@@ -723,13 +638,6 @@ int orc_march_rays_quadratic_bending(const int* pig_cnt, const int* pig_bgn, con
     if (g_march_stats) {
         fprintf(stderr, "[march] n_alive=%u n_step=%u iters=%lld found=%lld max/ray=%d hist(log2):", n_alive, n_step, g_march_iters, g_march_found, g_march_max);
         for (int b = 0; b < 12; b++) fprintf(stderr, " %d", g_march_hist[b]);
-        fprintf(stderr, "  | predicted rounds of 8: total %lld, max/ray %d", g_sp_rounds, g_sp_max);
-        g_sp_rounds = 0; g_sp_max = 0;
-        fprintf(stderr, "  | one-hop merge onto the chain (rays with >= 16 iters): %lld / %lld", g_merge_hit, g_merge_all);
-        g_merge_hit = g_merge_all = 0;
-        fprintf(stderr, "  | elements after first candidate hist(log2):");
-        for (int b = 0; b < 12; b++) fprintf(stderr, " %d", g_el_hist[b]);
-        std::fill(g_el_hist.begin(), g_el_hist.end(), 0);
         fprintf(stderr, "\n");
         g_march_iters = g_march_found = 0; g_march_max = 0; std::fill(g_march_hist.begin(), g_march_hist.end(), 0);
     }

@@ -477,7 +477,8 @@ int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* di
     if (M_max == 0) return PN_OK;
     const uint32_t tiles = pn_div_up(M_max, 32);
     uint32_t blocks = pn_div_up(tiles, 4);
-    if (blocks > 768) blocks = 768;  // 3 workgroups per CU (48 KB LDS each) x 256 CUs; waves stride over tiles
+    static const uint32_t max_blocks = pn_env_u32("PN_NERF_BLOCKS", 768);  // 3 workgroups per CU (48 KB LDS each) x 256 CUs; waves stride over tiles
+    if (blocks > max_blocks) blocks = max_blocks;
     const size_t lds = sizeof(float) * PN_NET_MFMAS * 64;
     static int variant = -1;
     if (variant < 0) { const char* e = getenv("PN_NERF_VARIANT"); variant = e ? atoi(e) : 0; }
