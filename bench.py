@@ -208,11 +208,18 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # "nccl" IS RCCL on ROCm.  PN_DIST_BACKEND=gloo lets the N > 1 code path be exercised on a one-GPU box (ranks share cuda:0).
+        backend = os.environ.get("PN_DIST_BACKEND", "nccl")
+        dev_index = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
 
     from pienerf_amd import scene
     from pienerf_amd.harness import SimRenderHarness
@@ -241,29 +248,17 @@ def main():
             h.capture(n_trips=args.trips)
             run_steps = lambda n: [h.step_graph() for _ in range(n)]
     else:
-        # frame-parallel (pienerf_amd/frames.py): rank 0 owns the simulator and broadcasts dof[30 n_k] per frame over RCCL;
-        # frame f is rendered by rank f % world from the pre-step state.  `n` steps per rank = n * world frames in total.
-        from pienerf_amd.frames import FrameParallel, broadcast_tensors
-        from pienerf_amd.nerf.utils import get_rays
-        m, sim = h.model, h.sim
+        # frame-parallel (harness.capture_frame_parallel): rank 0 owns the simulator, runs it ahead on dof snapshots and
+        # broadcasts each snapshot (<= 82 KB) over RCCL on a communication stream; frame f is rendered by rank f % world on one of its
+        # `lanes` render streams.  `n` steps per rank = n * world frames in total.
+        from pienerf_amd.frames import broadcast_tensors
+        m = h.model
         broadcast_tensors([m.encoder.embeddings.data, m.density_bitfield] + [l.weight.data for l in list(m.sigma_net) + list(m.color_net)], src=0)
-        pose_t = torch.from_numpy(h.pose).unsqueeze(0).to(dev)
-        kw = h.render_kwargs()
-
-        def render(frame):
-            rays = get_rays(pose_t, h.intrinsics, opt["H"], opt["W"], -1)
-            m.p_def, m.IP_F, m.IP_dF = sim.get_IP_info()
-            return m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **kw)["image"]
-
-        def set_dof(t):
-            sim.dof.copy_(t)
-
-        fp = FrameParallel(sim.stepforward, lambda: sim.dof, set_dof, render)
-        counter = {"f": 0}
+        h.capture_frame_parallel(lanes=args.lanes, n_trips=args.trips)
 
         def run_steps(n):
-            fp.run(n * world, first_frame=counter["f"])
-            counter["f"] += n * world
+            for _ in range(n * world):
+                h.step_frame_parallel()
 
     with torch.no_grad():
         run_steps(args.warmup)
@@ -272,8 +267,8 @@ def main():
         run_steps(args.steps)
         barrier()
         elapsed = time.perf_counter() - t0
-        if world == 1 and not args.eager:  # the last replayed frame(s) must be complete too
-            if not args.single_graph:
+        if world > 1 or not args.eager:  # the last replayed frame(s) must be complete too
+            if world > 1 or not args.single_graph:
                 h.drain_pipeline()
             else:
                 h._check_previous_graph_frame()
@@ -292,7 +287,7 @@ def main():
             "config": {"workload": "configs[1]: synthetic chair 800x800, sim_dx=0.05, sim_iters=10, num_seek_IP=3, max_iter_num=1, fp32, "
                                    "1 sim+render step per frame", "rays": opt["W"] * opt["H"], "n_IP": h.sim.n_IP, "n_kernels": h.sim.n_k,
                        "samples_per_frame": st["samples"], "trips_per_frame": st["trips"],
-                       "launch": "eager" if (args.eager or world > 1) else (f"one hip graph per step, {args.trips} trips" if args.single_graph else
+                       "launch": "eager" if (args.eager and world == 1) else (f"one hip graph per step, {args.trips} trips" if args.single_graph else
                                                                                    f"hip graphs, {args.trips} trips, {args.lanes} render(s) in flight, simulator running ahead"),
                        "parallelism": f"frame-parallel x{world}, DOF broadcast over RCCL" if world > 1 else "single GPU"},
             "roofline": roofline,

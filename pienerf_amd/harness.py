@@ -180,7 +180,7 @@ class SimRenderHarness:
         return torch.cuda.ExternalStream(h.value, device=self.device)
 
     @torch.no_grad()
-    def capture_pipelined(self, lanes=2, n_trips=8, W=None, H=None, sim_ahead=None, sim_priority=0, sim_cus=0, _probe_no_substep=False):
+    def capture_pipelined(self, lanes=2, n_trips=8, W=None, H=None, sim_ahead=None, sim_priority=0, sim_cus=0, _probe_no_substep=False, _extra_slots=0):
         """Throughput mode: `lanes` renders in flight on their own streams, the simulator running `sim_ahead` frames ahead.
 
         A render is a chain of short latency-bound launches whose tails leave most of the 256 CUs idle, and the substep is a
@@ -196,7 +196,7 @@ class SimRenderHarness:
         o, m, dev = self.opt, self.model, self.device
         W, H = W or o["W"], H or o["H"]
         ahead = lanes if sim_ahead is None else int(sim_ahead)
-        slots = lanes + ahead + 1
+        slots = lanes + ahead + 1 + int(_extra_slots)
         self._pipe = dict(lanes=lanes, ahead=ahead, slots=slots, W=W, H=H, trips=n_trips, ren_graph=[], out=[], stream=[], done=[], pending=[], ip=[],
                           keepalive=[], sim_next=0)
         p = self._pipe
@@ -291,6 +291,82 @@ class SimRenderHarness:
         p["pending"][lane] = True
         self.frame += 1
         return p["out"][lane]
+
+    # ------------------------------------------------------------------ frame-parallel over the GPUs of a node
+    @torch.no_grad()
+    def capture_frame_parallel(self, lanes=3, n_trips=8, group=None, sim_owner=0):
+        """Multi-GPU form of capture_pipelined (BASELINE.json configs[3]): every rank calls step_frame_parallel()
+        once per GLOBAL frame f.  The sim owner advances the simulator (running ahead on dof snapshots, exactly as on one GPU)
+        and every snapshot is broadcast over `group` on a communication stream of its own — <= 82 KB per frame, the only
+        exchange; rank f % world renders frame f on its lane (f // world) % lanes from its copy of snapshot f.  Neither the
+        substeps nor the broadcasts ever wait for a render, so the ranks' renders overlap freely; the job is bounded by the
+        owner's substep rate (the simulator is time-sequential and does not shard)."""
+        import torch.distributed as dist
+        on = dist.is_available() and dist.is_initialized()
+        world = dist.get_world_size(group) if on else 1
+        rank = dist.get_rank(group) if on else 0
+        self.capture_pipelined(lanes=lanes, n_trips=n_trips, sim_ahead=world * lanes, _extra_slots=world * lanes)
+        p = self._pipe
+        S = p["slots"]
+        p.update(world=world, rank=rank, owner=sim_owner, group=group, bc_next=0, comm=torch.cuda.Stream(self.device),
+                 src=(dist.get_global_rank(group, sim_owner) if (on and group is not None) else sim_owner),
+                 bc_done=[torch.cuda.Event() for _ in range(S)], ip_done=[torch.cuda.Event() for _ in range(S)],
+                 bc_used=[False] * S, ip_used=[False] * S)
+        return self
+
+    @torch.no_grad()
+    def step_frame_parallel(self):
+        """One global frame.  Returns the lane's (static) outputs on the rank that renders it, None elsewhere."""
+        import torch.distributed as dist
+        p = self._pipe
+        f, world, rank, S = self.frame, p["world"], p["rank"], p["slots"]
+        mine = (f % world) == rank
+        lane = (f // world) % p["lanes"]
+        if mine and p["pending"][lane]:  # this rank's previous frame on the lane must have finished (outputs / IP buffers are reused)
+            p["done"][lane].synchronize()
+            st = self.model.render_status(synchronize=False, slot=lane)
+            if st["alive_at_exit"] > 0:
+                raise RuntimeError(f"frame-parallel step ran {p['trips']} render trips but {st['alive_at_exit']} rays were still alive")
+        sim_s, comm = p["sim_stream"], p["comm"]
+        if rank == p["owner"]:
+            with torch.cuda.stream(sim_s):
+                while p["sim_next"] <= f + p["ahead"]:
+                    slot = p["sim_next"] % S
+                    if p["bc_used"][slot]:
+                        sim_s.wait_event(p["bc_done"][slot])   # the slot's previous snapshot has been sent ...
+                    if p["ip_used"][slot]:
+                        sim_s.wait_event(p["ip_done"][slot])   # ... and consumed by this rank's own render
+                    p["snap"][slot].copy_(self.sim.dof)
+                    p["snap_ready"][slot].record(sim_s)
+                    p["sim_graph"].replay()
+                    p["sim_next"] += 1
+        if world > 1:
+            with torch.cuda.stream(comm):
+                while p["bc_next"] <= f + p["ahead"]:  # same order on every rank
+                    slot = p["bc_next"] % S
+                    if rank == p["owner"]:
+                        comm.wait_event(p["snap_ready"][slot])
+                    elif p["ip_used"][slot]:
+                        comm.wait_event(p["ip_done"][slot])    # this rank's render has read the slot's previous snapshot
+                    dist.broadcast(p["snap"][slot], src=p["src"], group=p["group"])
+                    p["bc_done"][slot].record(comm)
+                    p["bc_used"][slot] = True
+                    p["bc_next"] += 1
+        out = None
+        if mine:
+            slot = f % S
+            ren_s = p["stream"][lane]
+            ren_s.wait_event(p["bc_done"][slot] if world > 1 else p["snap_ready"][slot])
+            with torch.cuda.stream(ren_s):
+                self.sim.get_IP_info(dof=p["snap"][slot], out=p["ip"][lane])
+                p["ip_done"][slot].record(ren_s)
+                p["ip_used"][slot] = True
+                p["ren_graph"][lane].replay()
+                p["done"][lane].record(ren_s)
+            p["pending"][lane] = True
+            out = p["out"][lane]
+        self.frame += 1
+        return out
 
     @property
     def substeps_enqueued(self):
