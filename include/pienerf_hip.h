@@ -35,6 +35,10 @@ const char* pn_version(void);
  * (wrap it with torch.cuda.ExternalStream); destroy with pn_stream_destroy.  No reference counterpart. */
 int pn_stream_create_cu_mask(uint32_t total_cu, uint32_t first_cu, uint32_t n_cu, int invert, void** stream_out);
 int pn_stream_destroy(void* stream);
+/* Test / tuning hook: rounds (windows of 8 ray points) a ray gets in the first march launch before it is handed to the
+ * wave-per-ray tail launch; 0 restores the default (4).  The samples do not depend on it (bit for bit) — tests use 1 and a
+ * large value to push every ray through either launch.  Affects renders enqueued afterwards, process-wide. */
+int pn_march_set_tail_rounds(int rounds);
 /* Number of compute units of the current device. */
 int pn_device_cu_count(void);
 /* Text of the last PN_ERR_HIP on the calling thread ("" if none). */

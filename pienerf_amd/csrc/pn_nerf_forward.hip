@@ -119,6 +119,7 @@ __global__ void __launch_bounds__(256) k_grid_encode(const float* __restrict__ i
 extern "C" int pn_grid_encode_forward(const float* inputs, const float* embeddings, const int* offsets_host, float* outputs, uint32_t B, uint32_t D,
                                       uint32_t C, uint32_t L, float S, uint32_t H, const float* dy_dx, uint32_t gridtype, int align_corners,
                                       uint32_t interp, int out_bl_major, void* stream) {
+    if (B == 0) return PN_OK;  // empty tensors have null data pointers
     PN_REQUIRE(inputs && embeddings && offsets_host && outputs);
     PN_REQUIRE(D == 3);                                   // the reference also has D = 2,4,5 (gridencoder.cu:386-395); not on this path
     PN_REQUIRE(C == 1 || C == 2 || C == 4 || C == 8);     // gridencoder.cu:376-382
@@ -182,6 +183,7 @@ __global__ void __launch_bounds__(256) k_sh_encode(const float* __restrict__ inp
 }
 
 extern "C" int pn_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C, const float* dy_dx, void* stream) {
+    if (B == 0) return PN_OK;  // empty tensors have null data pointers
     PN_REQUIRE(inputs && outputs && D == 3 && C >= 1 && C <= 4 && dy_dx == nullptr);  // degrees 5-8 (shencoder.cu:70-122): not on this path
     if (B == 0) return PN_OK;
     k_sh_encode<<<pn_div_up(B, 256), 256, 0, (hipStream_t)stream>>>(inputs, outputs, B, C);
@@ -501,6 +503,7 @@ int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* di
 
 extern "C" int pn_nerf_forward(const pn_net* net, const float* xyzs, const float* dirs, uint32_t M, float density_scale, float* sigmas, float* rgbs,
                                void* stream) {
+    if (M == 0) return PN_OK;  // empty tensors have null data pointers
     PN_REQUIRE(net && xyzs && dirs && sigmas && rgbs);
     return pn_nerf_forward_launch(net, xyzs, dirs, nullptr, nullptr, M, density_scale, sigmas, rgbs, (hipStream_t)stream);
 }

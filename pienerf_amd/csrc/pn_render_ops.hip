@@ -49,8 +49,8 @@ __global__ void __launch_bounds__(256) k_near_far(const float* __restrict__ rays
 
 extern "C" int pn_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near, float* nears,
                                      float* fars, void* stream) {
+    if (N == 0) return PN_OK;  // empty tensors have null data pointers
     PN_REQUIRE(rays_o && rays_d && aabb && nears && fars);
-    if (N == 0) return PN_OK;
     k_near_far<<<pn_div_up(N, 256), 256, 0, (hipStream_t)stream>>>(rays_o, rays_d, aabb, N, min_near, nears, fars, nullptr);
     PN_LAUNCH_CHECK();
     return PN_OK;
@@ -432,9 +432,15 @@ static void launch_march(int K, uint32_t blocks, uint32_t tail_blocks, hipStream
 }
 
 // Rounds of 8 sequence elements a ray gets in k_march before it is handed to the wave-per-ray tail pass (PN_TAIL_ROUNDS overrides).
+static int g_tail_rounds_override = 0;  // pn_march_set_tail_rounds (tests): > 0 replaces the default below
 static uint32_t march_tail_rounds() {
     static const uint32_t r = pn_env_u32("PN_TAIL_ROUNDS", 4);  // measured on the chair: 2..4 within 1 % for latency, 4 best for throughput
-    return r;
+    return g_tail_rounds_override > 0 ? (uint32_t)g_tail_rounds_override : r;
+}
+extern "C" int pn_march_set_tail_rounds(int rounds) {
+    PN_REQUIRE(rounds >= 0);
+    g_tail_rounds_override = rounds;
+    return PN_OK;
 }
 
 static pnm::MarchParams make_march_params(const int* pig_cnt, const int* pig_bgn, const int* pig_idx, int n_vtx, int n_grid, const float* p_def,
@@ -553,8 +559,8 @@ __global__ void __launch_bounds__(256) k_composite(uint32_t n_alive_arg, uint32_
 
 extern "C" int pn_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int* rays_alive, float* rays_t, const float* sigmas,
                                  const float* rgbs, const float* deltas, float* weights_sum, float* depth, float* image, void* stream) {
+    if (n_alive == 0) return PN_OK;  // empty tensors have null data pointers
     PN_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image && n_step >= 1);
-    if (n_alive == 0) return PN_OK;
     k_composite<<<pn_div_up(n_alive, 256), 256, 0, (hipStream_t)stream>>>(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas,
                                                                          weights_sum, depth, image, nullptr, nullptr);
     PN_LAUNCH_CHECK();
@@ -618,10 +624,10 @@ __global__ void __launch_bounds__(256) k_compact(const int* __restrict__ in, uin
 extern "C" uint32_t pn_compact_scratch_ints(uint32_t n) { return pn_div_up(n, 256) + 1; }
 
 extern "C" int pn_compact_rays(const int* rays_alive, uint32_t n, int* out, int* n_out, int* scratch, void* stream) {
-    PN_REQUIRE(out && n_out && scratch);
+    PN_REQUIRE(n_out);
     hipStream_t st = (hipStream_t)stream;
-    if (n == 0) { PN_HIP_CHECK(hipMemsetAsync(n_out, 0, sizeof(int), st)); return PN_OK; }
-    PN_REQUIRE(rays_alive);
+    if (n == 0) { PN_HIP_CHECK(hipMemsetAsync(n_out, 0, sizeof(int), st)); return PN_OK; }  // empty tensors have null data pointers
+    PN_REQUIRE(rays_alive && out && scratch);
     const uint32_t chunks = pn_div_up(n, 256);
     k_chunk_count<<<chunks, 256, 0, st>>>(rays_alive, n, scratch);
     k_compact<<<chunks, 256, 0, st>>>(rays_alive, n, scratch, out, n_out, nullptr, nullptr, 0, 0);

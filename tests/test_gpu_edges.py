@@ -1,0 +1,142 @@
+"""GPU edge cases of the render path: empty and ragged inputs, rays that all miss, a whole frame in --cut mode, and the two
+march launches pushed to their extremes (every ray through the 8-lane launch / through the wave-per-ray tail launch) — the
+samples must not depend on that split, bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from pienerf_amd import scene
+from test_gpu_parity import DEV, T, _march_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(ckpt, ip):
+    from pienerf_amd.nerf.network import NeRFNetwork
+    net = NeRFNetwork(encoding="hashgrid", bound=1.0, cuda_ray=True).to(DEV).load_checkpoint_dict(ckpt)
+    net.p_def, net.p_ori, net.IP_F, net.IP_dF, net.IP_dx = T(ip["p_def"]), T(ip["p_ori"]), T(ip["F"]), T(ip["dF"]), ip["IP_dx"]
+    return net
+
+
+@pytest.fixture
+def tail_rounds():
+    from pienerf_amd._lib import check, lib
+
+    def set_rounds(r):
+        check(lib().pn_march_set_tail_rounds(int(r)), "set_tail_rounds")
+    yield set_rounds
+    set_rounds(0)
+
+
+def test_empty_inputs_are_no_ops(ckpt):
+    from pienerf_amd import raymarching
+    from pienerf_amd.gridencoder import GridEncoder
+    from pienerf_amd.shencoder import SHEncoder
+    z3 = torch.zeros(0, 3, device=DEV)
+    n, f = raymarching.near_far_from_aabb(z3, z3, T(np.array([-1, -1, -1, 1, 1, 1], np.float32)), 0.2)
+    assert n.numel() == 0 and f.numel() == 0
+    out = raymarching.compact_rays(torch.zeros(0, dtype=torch.int32, device=DEV))
+    assert out.numel() == 0
+    assert raymarching.compact_rays(torch.full((300,), -1, dtype=torch.int32, device=DEV)).numel() == 0  # nothing survives
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048).to(DEV)
+    assert enc(z3, bound=1.0).shape == (0, 32)
+    assert SHEncoder(input_dim=3, degree=4).to(DEV)(z3).shape == (0, 16)
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (33, 7), (257, 3)])
+def test_ragged_ray_counts(W, H):
+    from pienerf_amd import raymarching
+    from pienerf_amd.nerf.utils import get_rays
+    pose = scene.orbit_pose(4.0, 40.0, -10.0)
+    intr = scene.orbit_intrinsics(W, H, 50.0)
+    o_ref, d_ref = oracle.get_rays(pose, intr, H, W)
+    r = get_rays(T(pose[None]), intr, H, W)
+    assert np.array_equal(r["rays_o"][0].cpu().numpy(), o_ref) and np.array_equal(r["rays_d"][0].cpu().numpy(), d_ref)
+    aabb = np.array([-0.5, -0.5, -0.5, 0.5, 0.5, 0.5], np.float32)
+    n_ref, f_ref = oracle.near_far_from_aabb(o_ref, d_ref, aabb, 0.2)
+    n, f = raymarching.near_far_from_aabb(r["rays_o"][0], r["rays_d"][0], T(aabb), 0.2)
+    assert np.array_equal(n.cpu().numpy(), n_ref) and np.array_equal(f.cpu().numpy(), f_ref)
+
+
+def test_frame_whose_rays_all_miss(deformed_ip_state, small_opt, ckpt):
+    """Camera looking away from the object: no ray enters the IP box, the loop ends after trip 0 with zero samples."""
+    W = 40
+    pose = scene.orbit_pose(5.0, 20.0, -15.0)
+    pose[:3, :3] = -pose[:3, :3]  # turn the camera around
+    o, d = oracle.get_rays(pose, scene.orbit_intrinsics(W, W, 50.0), W, W)
+    ref = oracle.render_deformed(o, d, deformed_ip_state, ckpt, small_opt)
+    net = _net(ckpt, deformed_ip_state)
+    with torch.no_grad():
+        out = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **small_opt)
+    st = dict(net.last_stats)
+    assert ref["samples"] == 0 and st["samples"] == 0 and st["alive_at_exit"] == 0 and st["err"] == 0
+    assert np.array_equal(out["image"][0].cpu().numpy(), ref["image"])  # pure background
+    dep = out["depth"][0].cpu().numpy()
+    assert np.array_equal(np.isfinite(dep), np.isfinite(ref["depth"]))   # NaN wherever nears == fars == FLT_MAX (renderer.py:898)
+    assert np.isnan(dep).sum() > 0.8 * dep.size                          # most rays miss the IP box altogether
+    assert np.array_equal(dep[np.isfinite(dep)], ref["depth"][np.isfinite(dep)])  # a grazing ray without samples has depth 0
+
+
+@pytest.mark.parametrize("num_seek_IP", [1, 3])
+def test_frame_in_cut_mode(deformed_ip_state, small_opt, ckpt, num_seek_IP):
+    """--cut through the fused frame driver: bbox = +-bound, samples outside cut_bounds are un-warped background."""
+    W = 56
+    opt = dict(small_opt, cut=True, cut_bounds=[-0.3, 0.9, -0.9, 0.5, -0.9, 0.9], num_seek_IP=num_seek_IP, max_steps=256)
+    pose = scene.orbit_pose(4.0, 10.0, -5.0)
+    o, d = oracle.get_rays(pose, scene.orbit_intrinsics(W, W, 50.0), W, W)
+    ref = oracle.render_deformed(o, d, deformed_ip_state, ckpt, opt)
+    net = _net(ckpt, deformed_ip_state)
+    with torch.no_grad():
+        out = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **opt)
+    st = dict(net.last_stats)
+    assert ref["samples"] > 1000
+    assert st["trips"] == ref["trips"] and st["samples"] == ref["samples"] and st["err"] == 0 and st["alive_at_exit"] == 0
+    assert np.abs(out["image"][0].cpu().numpy() - ref["image"]).max() < 1e-4
+    assert np.abs(out["weights_sum"].cpu().numpy() - ref["weights_sum"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("num_seek_IP,max_iter_num,n_step,rounds", [(3, 1, 8, 1), (3, 1, 8, 1000), (2, 4, 64, 1), (1, 1, 64, 1), (3, 2, 200, 2)])
+def test_march_split_between_the_two_launches_does_not_matter(deformed_ip_state, small_opt, ckpt, tail_rounds, num_seek_IP, max_iter_num, n_step,
+                                                             rounds):
+    """rounds = 1: every ray that needs more than one window of 8 points finishes in the wave-per-ray launch (windows of 64);
+    rounds = 1000: no ray ever reaches it.  n_step = 64 / 200 marches whole rays in one call (many windows per ray)."""
+    from pienerf_amd import raymarching
+    ip, ck = deformed_ip_state, ckpt
+    m = _march_inputs(ip, small_opt, ck, W=48)
+    alive = np.nonzero(m["nears"] < 1e30)[0].astype(np.int32)
+    n_alive = len(alive)
+    cb = np.zeros(6, np.float32)
+    args = (len(ip["p_def"]), m["n_grid"])
+    ref = oracle.march_rays_quadratic_bending(*m["pig"], *args, ip["p_def"], ip["p_ori"], ip["F"], ip["dF"], max_iter_num, m["bbmin"], m["bbmax"],
+                                              m["hgs"], m["res"], num_seek_IP, np.float32(ip["IP_dx"]), False, cb, n_alive, n_step, alive, m["nears"],
+                                              m["o"], m["d"], 1.0, ck["density_bitfield"], ck["cascade"], ck["grid_size"], m["nears"], m["fars"], 128,
+                                              False, 0.0, 1024)
+    tail_rounds(rounds)
+    got = raymarching.march_rays_quadratic_bending(*[T(a) for a in m["pig"]], *args, T(ip["p_def"]), T(ip["p_ori"]), T(ip["F"]), T(ip["dF"]),
+                                                   max_iter_num, T(m["bbmin"]), T(m["bbmax"]), float(m["hgs"]), T(m["res"]), num_seek_IP,
+                                                   float(ip["IP_dx"]), False, T(cb), n_alive, n_step, T(alive), T(m["nears"]), T(m["o"]), T(m["d"]),
+                                                   1.0, T(ck["density_bitfield"]), ck["cascade"], ck["grid_size"], T(m["nears"]), T(m["fars"]), 128,
+                                                   False, 0.0, 1024)
+    assert (ref[2][:, 0] != 0).sum() > 500
+    for name, a, b in zip(("xyzs", "dirs", "deltas"), got, ref):
+        a = a.cpu().numpy()
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{name}: {np.sum(a != b)} of {a.size} values differ"
+
+
+@pytest.mark.parametrize("rounds", [1, 1000])
+def test_frame_independent_of_tail_rounds(deformed_ip_state, small_opt, ckpt, tail_rounds, rounds):
+    W = 64
+    pose = scene.orbit_pose(5.0, 20.0, -15.0)
+    o, d = oracle.get_rays(pose, scene.orbit_intrinsics(W, W, 50.0), W, W)
+    net = _net(ckpt, deformed_ip_state)
+    with torch.no_grad():
+        base = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **small_opt)
+        st0 = dict(net.last_stats)
+        img0, d0 = base["image"].clone(), base["depth_0"].clone()
+        tail_rounds(rounds)
+        alt = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **small_opt)
+        st1 = dict(net.last_stats)
+    assert st0["samples"] == st1["samples"] > 2000 and st0["trips"] == st1["trips"]
+    # same samples, but the sample LIST order (the order the network kernel visits them in) differs: per-ray compositing is unchanged
+    assert torch.equal(alt["image"], img0) and torch.equal(alt["depth_0"], d0)
