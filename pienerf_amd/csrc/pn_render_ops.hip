@@ -652,7 +652,7 @@ struct pn_frame {
     float *nears, *fars, *rays_t, *xyzs, *dirs, *deltas, *sigmas, *rgbs;
     int *alive_a, *alive_b, *list, *chunk_counts;
     TailEntry* tail;   // [max_rays] rays handed from k_march to k_march_tail
-    int* tail_counts;  // [PN_MAX_TRIPS + 2] one counter per trip, zeroed by k_frame_init
+    int* tail_counts;  // [PN_MAX_TRIPS + 2] one counter per trip, zeroed by k_frame_rays
     int *pig_cnt, *pig_bgn, *pig_idx, *pig_cursor;
     MarchSide side;  // candidate lists + packed IP records of the cooperative march
     PnTrip* trips;  // [PN_MAX_TRIPS + 2]
@@ -669,63 +669,6 @@ struct pn_frame {
     int timed_trips;
 };
 
-// bbox of the deformed IPs +-1e-3 and the spatial-hash resolution (nerf/renderer.py:782-791), one workgroup.
-__global__ void __launch_bounds__(1024) k_frame_bbox(const float* __restrict__ p_def, int n_vtx, int cut, float bound, float hgs, int max_cells,
-                                                     PnFrameDev* dev) {
-    __shared__ float smin[3][16], smax[3][16];
-    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (int i = threadIdx.x; i < n_vtx; i += blockDim.x)
-#pragma unroll
-        for (int c = 0; c < 3; c++) { const float v = p_def[i * 3 + c]; mn[c] = fminf(mn[c], v); mx[c] = fmaxf(mx[c], v); }
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { mn[c] = fminf(mn[c], __shfl_xor(mn[c], o)); mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o)); }
-        if (lane == 0) { smin[c][wid] = mn[c]; smax[c][wid] = mx[c]; }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int ncell = 1;
-        for (int c = 0; c < 3; c++) {
-            float a = smin[c][0], b = smax[c][0];
-            for (int w = 1; w < 16; w++) { a = fminf(a, smin[c][w]); b = fmaxf(b, smax[c][w]); }
-            if (cut) { a = -bound; b = bound; }
-            const float lo = a - 1e-3f, hi = b + 1e-3f;
-            dev->aabb[c] = lo;
-            dev->aabb[3 + c] = hi;
-            const int r = (int)ceilf((hi - lo) / hgs);
-            dev->resolution[c] = r;
-            ncell *= r;
-        }
-        int err = 0;
-        if (ncell > max_cells || ncell <= 0) { err = 4; ncell = 0; }
-        dev->resolution[3] = ncell;
-        dev->err = err;
-    }
-}
-
-// Per-frame initialisation done by kernels (not memset nodes): zeroed accumulators (renderer.py:807-809), rays_alive = arange(N)
-// (:828), zeroed trip records and trip 0 = (N rays, n_step 1).
-__global__ void __launch_bounds__(256) k_frame_init(PnTrip* trips, int* tail_counts, int n_trip_records, uint32_t N, int* alive, const PnFrameDev* dev,
-                                                    float* __restrict__ weights_sum, float* __restrict__ depth_0, float* __restrict__ image) {
-    const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-    if (i < N) {
-        alive[i] = (int)i;
-        weights_sum[i] = 0.f;
-        depth_0[i] = 0.f;
-        image[i * 3] = 0.f; image[i * 3 + 1] = 0.f; image[i * 3 + 2] = 0.f;
-    }
-    if (blockIdx.x == 0) {
-        for (int t = threadIdx.x; t < n_trip_records; t += blockDim.x) {
-            PnTrip r{0, 0, 0, 0};
-            if (t == 0) { r.n_alive = dev->err ? 0 : (int)N; r.n_step = 1; }  // max(min(N // N, 8), 1)
-            trips[t] = r;
-            tail_counts[t] = 0;
-        }
-    }
-}
-
 // image += (1 - weights_sum) * bg ; depth = clamp(depth - nears, 0) / (fars - nears) (renderer.py:896-899)
 __global__ void __launch_bounds__(256) k_frame_finish(uint32_t N, float bg, const float* __restrict__ nears, const float* __restrict__ fars,
                                                       const float* __restrict__ weights_sum, const float* __restrict__ depth_0,
@@ -740,7 +683,7 @@ __global__ void __launch_bounds__(256) k_frame_finish(uint32_t N, float bg, cons
 }
 
 // ---- fused frame prologue (3 launches instead of 13; every one of them was a few-microsecond kernel with a launch gap)
-// (1) k_frame_tables, ONE workgroup of 1024 threads: IP bounding box + spatial-hash resolution (k_frame_bbox), the spatial
+// (1) k_frame_tables, ONE workgroup of 1024 threads: IP bounding box +-1e-3 and spatial-hash resolution (nerf/renderer.py:782-791), the spatial
 //     hash itself (count -> scan -> cursor fill -> per-cell sort, = k_pig_*) and the per-cell candidate-list offsets (k_nb_count
 //     + scan).  The phases talk through global memory (L2) with relaxed agent-scope atomic loads where a value was produced by
 //     an atomic or by another thread of the block, and __syncthreads() in between.
@@ -936,7 +879,8 @@ __global__ void __launch_bounds__(256) k_frame_lists(int n_grid_max, const int* 
     }
 }
 
-// (3) k_frame_rays: k_near_far + k_frame_init in one pass over the rays.
+// (3) k_frame_rays: k_near_far + the per-frame initialisation in one pass over the rays — zeroed accumulators (renderer.py:807-809),
+//     rays_alive = arange(N) (:828), rays_t = nears (:829), zeroed trip records and tail counters, trip 0 = (N rays, n_step 1).
 __global__ void __launch_bounds__(256) k_frame_rays(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const PnFrameDev* dev, uint32_t N,
                                                     float min_near, float* __restrict__ nears, float* __restrict__ fars, float* __restrict__ rays_t,
                                                     PnTrip* trips, int* tail_counts, int n_trip_records, int* alive, float* __restrict__ weights_sum,
