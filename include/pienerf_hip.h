@@ -193,11 +193,14 @@ int pn_sim_matvec3(int n, const double* A, const double* X, double* Y, void* str
 /* Simulator.stepforward (simulator/solver.py:595-602) incl. compute_momentum (:574-576) and build_rhs (:541-571).
  * All vectors [10 n_k,3] fp64.  dof and dof_vel are updated in place.  work: >= pn_sim_work_doubles(n_k, n_IP) doubles. */
 int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, double dx, const int* topo, const int* csr_bg, const int* csr_cnt,
-                       const int* csr_buf, const double* mu, const double* lam, const double* dNx, const double* dNx_csr, const double* Ainv,
+                       const int* csr_buf, const double* mu, const double* lam, const double* dNx, const double* dNx_csr, const int* csr_pos,
+                       const double* Ainv,
                        const double* Mmat, const double* dof_rest, const double* rhs_rest, const double* rhs_gravity, const double* dof_f,
                        double* dof, double* dof_vel, double* work, void* stream);
 /* dNx_csr (may be NULL): dNx rows gathered in CSR order, dNx_csr[e] = dNx[csr_buf[e]] (30 doubles each), built once at
- * initialisation; with it collect_rhs streams contiguous memory (one workgroup per kernel) instead of chasing csr_buf. */
+ * initialisation; with it collect_rhs streams contiguous memory (one workgroup per kernel) instead of chasing csr_buf.
+ * csr_pos (may be NULL; needs dNx_csr): inverse of csr_buf, csr_pos[csr_buf[e]] = e; calc_elastic then also writes P once per
+ * neighbour slot in CSR order and the gather has no index left to follow. */
 uint64_t pn_sim_work_doubles(int n_k, int n_IP);
 
 /* Simulator.update_force (simulator/solver.py:578-588): dof_f [10 n_k,3] is overwritten with the pick force of IP `vid`. */

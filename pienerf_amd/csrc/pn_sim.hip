@@ -37,14 +37,36 @@ __device__ __forceinline__ double det33(const M3& a) {
            a.m[0][2] * (a.m[1][0] * a.m[2][1] - a.m[1][1] * a.m[2][0]);
 }
 
+// v_rcp_f64 / v_rsq_f64 (~26 good bits) + two Newton steps: ~1 ulp, a third of the dependent-instruction count of the IEEE
+// divide / sqrt expansions.  The SVD below is one long fp64 dependency chain per IP (k_elastic is latency-bound on it), and its
+// results are compared with the oracle by tolerance, not bit for bit.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ double fast_rsq(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-x * y, y, 1.0);
+    return fma(0.5 * y, e, y);
+}
+
 // One Jacobi rotation zeroing S[p][q] of the symmetric S, accumulated into Q (columns = eigenvectors).
 template <int p, int q>
 __device__ __forceinline__ void jacobi_rot(M3& S, M3& Q) {
     const double spq = S.m[p][q];
     if (spq == 0.0) return;
-    const double theta = (S.m[q][q] - S.m[p][p]) / (2.0 * spq);
-    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+    const double theta = (S.m[q][q] - S.m[p][p]) * fast_rcp(2.0 * spq);
+    double t;
+    if (fabs(theta) > 1e100) {
+        t = 0.5 * fast_rcp(theta);  // theta^2 would overflow; t = 1 / (2 theta) to full precision there
+    } else {
+        const double h = fma(theta, theta, 1.0);
+        t = (theta >= 0 ? 1.0 : -1.0) * fast_rcp(fabs(theta) + h * fast_rsq(h));
+    }
+    const double c = fast_rsq(fma(t, t, 1.0)), s = t * c;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const double a = S.m[k][p], b = S.m[k][q];
@@ -105,16 +127,21 @@ __device__ void svd3(const M3& F, M3& U, double* sig, M3& V) {
         for (int i = 0; i < 3; i++) { Q.m[i][2] = -Q.m[i][2]; B.m[i][2] = -B.m[i][2]; }
     }
     double u0[3], u1[3], u2[3];
-    const double l0 = sqrt(n0);
-    if (l0 > 0) { u0[0] = B.m[0][0] / l0; u0[1] = B.m[1][0] / l0; u0[2] = B.m[2][0] / l0; }
-    else { u0[0] = 1; u0[1] = 0; u0[2] = 0; }
+    double l0 = 0.0;
+    if (n0 > 0) {
+        const double il0 = fast_rsq(n0);
+        l0 = n0 * il0;
+        u0[0] = B.m[0][0] * il0; u0[1] = B.m[1][0] * il0; u0[2] = B.m[2][0] * il0;
+    } else { u0[0] = 1; u0[1] = 0; u0[2] = 0; }
     const double d01 = u0[0] * B.m[0][1] + u0[1] * B.m[1][1] + u0[2] * B.m[2][1];
 #pragma unroll
     for (int i = 0; i < 3; i++) u1[i] = B.m[i][1] - d01 * u0[i];
-    double l1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+    const double q1 = u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2];
+    double l1 = 0.0, il1 = 0.0;
+    if (q1 > 1e-290) { il1 = fast_rsq(q1); l1 = q1 * il1; }
     if (l1 > 1e-300 && l1 > 1e-14 * l0) {
 #pragma unroll
-        for (int i = 0; i < 3; i++) u1[i] /= l1;
+        for (int i = 0; i < 3; i++) u1[i] *= il1;
     } else {  // rank <= 1: any unit vector orthogonal to u0
         const double a0 = fabs(u0[0]), a1 = fabs(u0[1]), a2 = fabs(u0[2]);
         const int k = a0 < a1 ? (a0 < a2 ? 0 : 2) : (a1 < a2 ? 1 : 2);
@@ -143,7 +170,7 @@ __device__ __forceinline__ void volume_invariant_project(const double* sig, doub
         const double a = sig[0] + D0, b = sig[1] + D1, c = sig[2] + D2;
         const double C = a * b * c - 1.0;
         const double g0 = b * c, g1 = a * c, g2 = a * b;
-        const double coef = ((g0 * D0 + g1 * D1 + g2 * D2) - C) / (g0 * g0 + g1 * g1 + g2 * g2);
+        const double coef = ((g0 * D0 + g1 * D1 + g2 * D2) - C) * fast_rcp(g0 * g0 + g1 * g1 + g2 * g2);
         D0 = coef * g0; D1 = coef * g1; D2 = coef * g2;
     }
     out[0] = sig[0] + D0; out[1] = sig[1] + D1; out[2] = sig[2] + D2;
@@ -207,7 +234,8 @@ extern "C" int pn_sim_update_F(int n_IP, const int* topo, const double* dof, con
 // 8 lanes per IP.  Writes RF/VF/FF (op-level, any may be NULL) and/or P = dx^3 (mu R + lam V) (step driver).
 __global__ void __launch_bounds__(256) k_elastic(int n_IP, const int* __restrict__ topo, const double* __restrict__ dNx, const double* __restrict__ dof,
                                                  double* __restrict__ RF, double* __restrict__ VF, double* __restrict__ FF, double* __restrict__ P,
-                                                 const double* __restrict__ mu, const double* __restrict__ lam, double dx3) {
+                                                 const double* __restrict__ mu, const double* __restrict__ lam, double dx3,
+                                                 const int* __restrict__ csr_pos = nullptr, double* __restrict__ P_csr = nullptr) {
     PN_SIM_PRIO();
     const int tid = threadIdx.x + blockIdx.x * blockDim.x;
     const int v = tid >> 3, i = tid & 7;
@@ -243,23 +271,40 @@ __global__ void __launch_bounds__(256) k_elastic(int n_IP, const int* __restrict
             s += shfl_xor_d(s, 4);
             Fm.m[r][c] = s;
         }
-    if (!live || i != 0) return;
-    M3 U, V;
-    double sig[3], sp[3];
-    svd3(Fm, U, sig, V);
-    volume_invariant_project(sig, sp);
-    const double m_ = mu ? mu[v] : 0.0, l_ = lam ? lam[v] : 0.0;
+    if (!live) return;  // the 8 lanes of an IP share v: whole groups leave together
+    double Pm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (i == 0) {
+        M3 U, V;
+        double sig[3], sp[3];
+        svd3(Fm, U, sig, V);
+        volume_invariant_project(sig, sp);
+        const double m_ = mu ? mu[v] : 0.0, l_ = lam ? lam[v] : 0.0;
 #pragma unroll
-    for (int r = 0; r < 3; r++)
+        for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const double R = U.m[r][0] * V.m[c][0] + U.m[r][1] * V.m[c][1] + U.m[r][2] * V.m[c][2];
-            const double Vv = U.m[r][0] * sp[0] * V.m[c][0] + U.m[r][1] * sp[1] * V.m[c][1] + U.m[r][2] * sp[2] * V.m[c][2];
-            if (RF) RF[(size_t)v * 9 + r * 3 + c] = R;
-            if (VF) VF[(size_t)v * 9 + r * 3 + c] = Vv;
-            if (FF) FF[(size_t)v * 9 + r * 3 + c] = U.m[r][0] * sig[0] * V.m[c][0] + U.m[r][1] * sig[1] * V.m[c][1] + U.m[r][2] * sig[2] * V.m[c][2];
-            if (P) P[(size_t)v * 9 + r * 3 + c] = dx3 * (m_ * R + l_ * Vv);
+            for (int c = 0; c < 3; c++) {
+                const double R = U.m[r][0] * V.m[c][0] + U.m[r][1] * V.m[c][1] + U.m[r][2] * V.m[c][2];
+                const double Vv = U.m[r][0] * sp[0] * V.m[c][0] + U.m[r][1] * sp[1] * V.m[c][1] + U.m[r][2] * sp[2] * V.m[c][2];
+                if (RF) RF[(size_t)v * 9 + r * 3 + c] = R;
+                if (VF) VF[(size_t)v * 9 + r * 3 + c] = Vv;
+                if (FF) FF[(size_t)v * 9 + r * 3 + c] = U.m[r][0] * sig[0] * V.m[c][0] + U.m[r][1] * sig[1] * V.m[c][1] + U.m[r][2] * sig[2] * V.m[c][2];
+                Pm[r * 3 + c] = dx3 * (m_ * R + l_ * Vv);
+                if (P) P[(size_t)v * 9 + r * 3 + c] = Pm[r * 3 + c];
+            }
+    }
+    if (P_csr) {
+        // step driver: P also goes, once per neighbour slot, to that slot's position in its kernel's CSR list, so that the
+        // gather (k_rhs_gather_csr) reads P and dNx as two contiguous streams with no index to chase
+        const int src = (threadIdx.x & 63) & ~7;
+        double* __restrict__ dst = P_csr + (size_t)csr_pos[v * 8 + i] * 9;
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            int2 t = *reinterpret_cast<int2*>(&Pm[q]);
+            t.x = __shfl(t.x, src);
+            t.y = __shfl(t.y, src);
+            dst[q] = *reinterpret_cast<double*>(&t);
         }
+    }
 }
 
 extern "C" int pn_sim_calc_elastic(int n_IP, const int* topo, const double* dNx, const double* dof, double* RF, double* VF, double* FF,
@@ -322,44 +367,56 @@ __global__ void __launch_bounds__(256) k_rhs_gather(int n_k, double dx3, const i
     }
 }
 
-// Step-driver form of the gather: one 256-thread workgroup per kernel over a CSR-ORDERED copy of dNx (dNx_csr[entry][c][x],
-// built once at initialisation), so the 240 B of every entry are read as one contiguous stream: thread (slot, q = c*10 + x)
-// walks entries slot, slot+8, ... and accumulates the three rows r of P[v][r][c] * dNx[c][x]; the 8 slots x 3 columns c are
-// then reduced through LDS in a fixed order.  out = momentum + sum - rhs_rest.
-__global__ void __launch_bounds__(256) k_rhs_gather_csr(int n_k, const int* __restrict__ csr_bg, const int* __restrict__ csr_cnt,
-                                                        const int* __restrict__ csr_buf, const double* __restrict__ dNx_csr,
-                                                        const double* __restrict__ P, const double* __restrict__ momentum,
-                                                        const double* __restrict__ rhs_rest, double* __restrict__ out) {
+// Step-driver form of the gather: one 1024-thread workgroup per kernel over CSR-ORDERED copies of dNx (dNx_csr[entry][c][x],
+// built once at initialisation) and, when calc_elastic wrote it, of P (P_csr[entry][r][c]): the 240 B + 72 B of every entry are
+// read as contiguous streams with no index to follow.  Thread (slot, q = c*10 + x) walks entries slot, slot+32, ... and
+// accumulates the three rows r of P[r][c] * dNx[c][x]; the 32 slots x 3 columns c are then reduced through LDS in a fixed
+// order (bit-reproducible run to run).  out = momentum + sum - rhs_rest.
+#define PN_GATHER_SLOTS 32
+__global__ void __launch_bounds__(1024) k_rhs_gather_csr(int n_k, const int* __restrict__ csr_bg, const int* __restrict__ csr_cnt,
+                                                         const int* __restrict__ csr_buf, const double* __restrict__ dNx_csr,
+                                                         const double* __restrict__ P, const double* __restrict__ P_csr,
+                                                         const double* __restrict__ momentum,
+                                                         const double* __restrict__ rhs_rest, double* __restrict__ out) {
     PN_SIM_PRIO();
-    __shared__ double red[8][30][3];
+    constexpr int NS = PN_GATHER_SLOTS;
+    __shared__ double red[NS][30][3];
     const int k = blockIdx.x;
     const int t = threadIdx.x;
     const int slot = t / 30, q = t - slot * 30, c = q / 10;
     const int bg = csr_bg[k], cnt = csr_cnt[k];
-    if (t < 240) {
+    if (t < NS * 30) {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
         const double* __restrict__ g = dNx_csr + (size_t)bg * 30 + q;
         int e = slot;
-        for (; e + 24 < cnt; e += 32) {  // four entries in flight
-            int v[4];
-            double gv[4];
+        if (P_csr) {  // every load is independent of every other
+            const double* __restrict__ pc = P_csr + (size_t)bg * 9 + c;
+            for (; e + 3 * NS < cnt; e += 4 * NS) {  // four entries in flight
+                double gv[4], p0[4], p1[4], p2[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { v[u] = csr_buf[bg + e + 8 * u] >> 3; gv[u] = g[(size_t)(e + 8 * u) * 30]; }
+                for (int u = 0; u < 4; u++) {
+                    const size_t ee = (size_t)(e + NS * u);
+                    gv[u] = g[ee * 30];
+                    p0[u] = pc[ee * 9]; p1[u] = pc[ee * 9 + 3]; p2[u] = pc[ee * 9 + 6];
+                }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const double* __restrict__ Pv = P + (size_t)v[u] * 9 + c;
-                a0 += Pv[0] * gv[u];
-                a1 += Pv[3] * gv[u];
-                a2 += Pv[6] * gv[u];
+                for (int u = 0; u < 4; u++) { a0 += p0[u] * gv[u]; a1 += p1[u] * gv[u]; a2 += p2[u] * gv[u]; }
             }
-        }
-        for (; e < cnt; e += 8) {
-            const int v = csr_buf[bg + e] >> 3;
-            const double gv = g[(size_t)e * 30];
-            const double* __restrict__ Pv = P + (size_t)v * 9 + c;
-            a0 += Pv[0] * gv;
-            a1 += Pv[3] * gv;
-            a2 += Pv[6] * gv;
+            for (; e < cnt; e += NS) {
+                const double gv = g[(size_t)e * 30];
+                a0 += pc[(size_t)e * 9] * gv;
+                a1 += pc[(size_t)e * 9 + 3] * gv;
+                a2 += pc[(size_t)e * 9 + 6] * gv;
+            }
+        } else {
+            for (; e < cnt; e += NS) {
+                const int v = csr_buf[bg + e] >> 3;
+                const double gv = g[(size_t)e * 30];
+                const double* __restrict__ Pv = P + (size_t)v * 9 + c;
+                a0 += Pv[0] * gv;
+                a1 += Pv[3] * gv;
+                a2 += Pv[6] * gv;
+            }
         }
         red[slot][q][0] = a0; red[slot][q][1] = a1; red[slot][q][2] = a2;
     }
@@ -367,8 +424,7 @@ __global__ void __launch_bounds__(256) k_rhs_gather_csr(int n_k, const int* __re
     if (t < 30) {
         const int x = t / 3, r = t - x * 3;  // output row x*3 + r of kernel k
         double s = 0.0;
-#pragma unroll
-        for (int sl = 0; sl < 8; sl++)
+        for (int sl = 0; sl < NS; sl++)
 #pragma unroll
             for (int cc = 0; cc < 3; cc++) s += red[sl][cc * 10 + x][r];
         const size_t o = (size_t)k * 30 + t;
@@ -460,11 +516,11 @@ __global__ void __launch_bounds__(256) k_step_end(int n3, double dt, const doubl
     vel[i] = (dof[i] - last[i]) / dt * 0.998;  // solver.py:602
 }
 
-extern "C" uint64_t pn_sim_work_doubles(int n_k, int n_IP) { return (uint64_t)n_k * 30 * 4 + (uint64_t)n_IP * 9; }
+extern "C" uint64_t pn_sim_work_doubles(int n_k, int n_IP) { return (uint64_t)n_k * 30 * 4 + (uint64_t)n_IP * 9 + (uint64_t)n_IP * 8 * 9; }
 
 extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, double dx, const int* topo, const int* csr_bg, const int* csr_cnt,
                                   const int* csr_buf, const double* mu, const double* lam, const double* dNx, const double* dNx_csr,
-                                  const double* Ainv, const double* Mmat, const double* dof_rest, const double* rhs_rest,
+                                  const int* csr_pos, const double* Ainv, const double* Mmat, const double* dof_rest, const double* rhs_rest,
                                   const double* rhs_gravity, const double* dof_f, double* dof, double* dof_vel, double* work, void* stream) {
     PN_REQUIRE(n_k > 0 && n_IP > 0 && iters >= 0 && topo && csr_bg && csr_cnt && csr_buf && mu && lam && dNx && Ainv && Mmat);
     PN_REQUIRE(dof_rest && rhs_rest && rhs_gravity && dof_f && dof && dof_vel && work);
@@ -475,13 +531,16 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
     double* momentum = work + 2 * (size_t)n3;
     double* tot = work + 3 * (size_t)n3;
     double* P = work + 4 * (size_t)n3;
+    double* P_csr = P + (size_t)n_IP * 9;
     const double dx3 = pow(dx, 3.0);
     k_step_begin<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, dt, dof, dof_vel, tilde, last);
     k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Mmat, tilde, momentum, 1, dof_f, rhs_gravity);  // compute_momentum (:574-576)
     for (int it = 0; it < iters; it++) {
-        k_elastic<<<pn_div_up((uint64_t)n_IP * 8, 256), 256, 0, st>>>(n_IP, topo, dNx, dof, nullptr, nullptr, nullptr, P, mu, lam, dx3);
+        const bool pcsr = dNx_csr && csr_pos;
+        k_elastic<<<pn_div_up((uint64_t)n_IP * 8, 256), 256, 0, st>>>(n_IP, topo, dNx, dof, nullptr, nullptr, nullptr, pcsr ? nullptr : P, mu, lam, dx3,
+                                                                      pcsr ? csr_pos : nullptr, pcsr ? P_csr : nullptr);
         if (dNx_csr)  // CSR-ordered copy of dNx available: the coalesced one-workgroup-per-kernel gather
-            k_rhs_gather_csr<<<n_k, 256, 0, st>>>(n_k, csr_bg, csr_cnt, csr_buf, dNx_csr, P, momentum, rhs_rest, tot);
+            k_rhs_gather_csr<<<n_k, 1024, 0, st>>>(n_k, csr_bg, csr_cnt, csr_buf, dNx_csr, P, pcsr ? P_csr : nullptr, momentum, rhs_rest, tot);
         else
             k_rhs_gather<<<pn_div_up(n_k, 4), 256, 0, st>>>(n_k, dx3, csr_bg, csr_cnt, csr_buf, mu, lam, dNx, nullptr, nullptr, P, momentum, rhs_rest, tot);
         k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Ainv, tot, dof, 2, dof_rest, nullptr);  // x = G @ rhs ; dof = dof_rest + x (:600-601)

@@ -124,6 +124,8 @@ class Simulator:
         # dNx rows in CSR order (6.9 MB on the chair): the step driver's collect_rhs then reads each kernel's entries as one
         # contiguous stream instead of chasing `buffer` (pn_sim_stepforward, dNx_csr)
         self.dNx_csr = self.IP_dNx.reshape(n_IP * 8, 30)[order].contiguous()
+        self.csr_pos = torch.empty_like(self.buffer)
+        self.csr_pos[order] = torch.arange(order.numel(), dtype=torch.int32, device=dev)   # inverse of `buffer`
 
         m = (self.IP_rho * self.dx * self.dx * self.dx)                                      # collect_gravity, cuda_utils.py:262-279
         rg = torch.zeros((n_k * 10, 3), dtype=torchfloat, device=dev)
@@ -198,7 +200,7 @@ class Simulator:
 
     def stepforward(self):  # solver.py:595-602
         check(lib().pn_sim_stepforward(self.n_k, self.n_IP, int(self.iters), float(self.dt), float(self.dx), ptr(self.IP_kernel), ptr(self.kernel_bg),
-                                       ptr(self.kernel_cnt), ptr(self.buffer), ptr(self.IP_mu), ptr(self.IP_lam), ptr(self.IP_dNx), ptr(self.dNx_csr), ptr(self.Ainv),
+                                       ptr(self.kernel_cnt), ptr(self.buffer), ptr(self.IP_mu), ptr(self.IP_lam), ptr(self.IP_dNx), ptr(self.dNx_csr), ptr(self.csr_pos), ptr(self.Ainv),
                                        ptr(self.Mmat), ptr(self.dof_rest), ptr(self.rhs_rest), ptr(self.rhs_gravity), ptr(self.dof_f), ptr(self.dof),
                                        ptr(self.dof_vel), ptr(self._work), stream_ptr()), "stepforward")
 

@@ -382,6 +382,7 @@ def test_pipelined_frames_equal_eager_steps(small_cloud, small_opt, ckpt, lanes,
         out = pipe.step_pipelined()
         pipe._pipe["done"][f % lanes].synchronize()  # the lane's buffers are reused `lanes` frames later: read them before that
         got.append(out["image"].clone())
+        torch.cuda.current_stream().synchronize()    # the copy runs on this (other) stream: finish it before the lane is reused
     pipe.drain_pipeline()
     for f in range(n_frames):
         assert (want[f] - got[f]).abs().max() < 1e-5, f
