@@ -5,10 +5,12 @@
 
 A step = one GUI-frame equivalent (nerf/gui.py:588-603 / nerf/trainer.py:300-318 of the reference):
 get_rays -> get_IP_info -> stepforward(iters=10) -> render_deformed at 800x800, inputs resident in HBM, outputs left in HBM.
-N = 1 replays the whole step as one captured HIP graph (--eager launches kernel by kernel instead).
-N > 1 is frame-parallel (BASELINE.json configs[3]): rank 0 owns the simulator and broadcasts the DOF
-state (<= 82 KB) per frame over RCCL; every rank holds the checkpoint and renders frames f = rank (mod N).  K steps per
-rank = K*N frames in total (weak scaling); value = frames all ranks completed / max-over-ranks time.
+N = 1 replays captured HIP graphs: `--lanes` renders in flight on their own streams, the simulator running ahead on dof snapshots
+(harness.capture_pipelined; --single-graph: one graph per step, one frame at a time; --eager: kernel by kernel).
+N > 1 is frame-parallel (BASELINE.json configs[3]): rank 0 owns the simulator and broadcasts every dof snapshot
+(<= 82 KB per frame) over RCCL; every rank holds the checkpoint and renders frames f = rank (mod N) on its own lanes
+(harness.capture_frame_parallel).  K steps per rank = K*N frames in total (weak scaling); value = frames all ranks completed /
+max-over-ranks time.
 """
 import argparse
 import json
@@ -156,20 +158,24 @@ def kernel_report(h, opt, dev):
     # the render loop, HIP events on the launch stream around each of them (pn_frame_trip_times)
     net_loop_ms = float(net_ms[:real].sum())
     net_loop_gbs = FUSED_BYTES_PER_SAMPLE * st["samples"] / (net_loop_ms * 1e-3) / 1e9
+    net_loop_tf = MLP_FLOP_PER_SAMPLE * st["samples"] / (net_loop_ms * 1e-3) / 1e12
     roofline = {
         "kernel": "k_nerf_forward<2,4> (hash-grid gather + SH + 5-layer MLP fused, f32 MFMA), launches inside the render loop",
-        "bound": "hbm", "achieved": round(net_loop_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(net_loop_gbs / HBM_PEAK_GBS, 4),
+        # PMC: the SIMD matrix pipe is busy 59 % of the kernel's time, waves wait on memory 12 % of theirs -> MFMA is the bound
+        "bound": "mfma", "achieved": round(net_loop_tf, 2), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(net_loop_tf / F32_MFMA_PEAK_TF, 4),
+        "flop_per_sample": MLP_FLOP_PER_SAMPLE, "flop_per_sample_issued": 24576,
         "traffic": traffic.get("k_nerf_forward"),
-        "traffic_note": "bytes per launch, FETCH_SIZE+WRITE_SIZE PMC passes (profiles/pmc_traffic.json); below the algorithmic bytes because the dense "
-                        "levels and part of the hashed tables are served by L2 / Infinity Cache",
+        "traffic_note": "HBM bytes per launch, FETCH_SIZE+WRITE_SIZE PMC passes (profiles/pmc_traffic.json); below the algorithmic bytes because the "
+                        "dense levels and part of the hashed tables are served by L2 / Infinity Cache",
         "launch_ms": round(net_loop_ms / real, 4), "launches_per_frame": real, "ms_per_frame": round(net_loop_ms, 4),
         "launch_ms_incl_empty_trips": round(float(net_ms.mean()), 4), "launches_enqueued_per_frame": int(len(net_ms)),
-        "bytes_per_sample": FUSED_BYTES_PER_SAMPLE, "samples_per_frame": st["samples"],
-        "algorithmic_bytes_per_launch": int(FUSED_BYTES_PER_SAMPLE * st["samples"] / real),
-        "mfma_tflops_in_loop": round(MLP_FLOP_PER_SAMPLE * st["samples"] / (net_loop_ms * 1e-3) / 1e12, 2),
-        "all_samples_one_launch": {"launch_ms": round(t_net, 4), "achieved_GBps": round(net_gbs, 1), "frac_of_hbm_peak": round(net_gbs / HBM_PEAK_GBS, 4),
-                                   "mfma_tflops": round(net_tf, 2), "frac_of_f32_mfma_peak": round(net_tf / F32_MFMA_PEAK_TF, 4)},
-        "note": "gather and MFMA phases of a wave are serial (each ~half of the time): both rooflines are reported; see DESIGN.md 4.2",
+        "samples_per_frame": st["samples"], "algorithmic_flop_per_launch": int(MLP_FLOP_PER_SAMPLE * st["samples"] / real),
+        "hbm_view": {"bytes_per_sample": FUSED_BYTES_PER_SAMPLE, "algorithmic_bytes_per_launch": int(FUSED_BYTES_PER_SAMPLE * st["samples"] / real),
+                     "achieved_GBps": round(net_loop_gbs, 1), "frac_of_hbm_peak": round(net_loop_gbs / HBM_PEAK_GBS, 4)},
+        "all_samples_one_launch": {"launch_ms": round(t_net, 4), "mfma_tflops": round(net_tf, 2), "frac_of_f32_mfma_peak": round(net_tf / F32_MFMA_PEAK_TF, 4),
+                                   "achieved_GBps": round(net_gbs, 1), "frac_of_hbm_peak": round(net_gbs / HBM_PEAK_GBS, 4)},
+        "note": "peak = 157.3 TFLOP/s, the dense f32-input MFMA rate of MI355X_MICROARCH.md (= the fp32 vector rate; no xf32 on gfx950); "
+                "achieved counts the network's 18 688 useful FLOP per sample, not the 24 576 issued with row padding",
     }
     extra = {
         "march": {"kernels": "k_march_skip + k_march<3,false> + k_march_tail<3,false> per loop trip (ray march + inverse-GMLS warp)",

@@ -31,8 +31,11 @@ struct March2Tables {
 // Newton inverse warp through one packed IP record (raymarching.cu:1262-1324).  Returns the reject flag.
 // MULTI = false is the max_iter_num <= 1 build (the chair / trex demo setting, README.md:123,134): no dF, far fewer registers.
 template <bool MULTI>
-__device__ inline bool warp_record(const float4* __restrict__ r, int max_iter_num, float IP_dx, float x, float y, float z, float* p_out, float* dist_out) {
-    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+// `h` = the record's first four float4 (p_ori, p_def, F), already loaded by the caller; `r` = the record (dF is read from it
+// only if a second Newton step runs).
+__device__ inline bool warp_record(const float4 (&h)[4], const float4* __restrict__ r, int max_iter_num, float IP_dx, float x, float y, float z,
+                                   float* p_out, float* dist_out) {
+    const float4 r0 = h[0], r1 = h[1], r2 = h[2], r3 = h[3];
     const float pk0 = r0.x, pk1 = r0.y, pk2 = r0.z;          // p_ori
     const float pd0 = r0.w, pd1 = r1.x, pd2 = r1.y;          // p_def
     const float Fk[9] = {r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z};

@@ -27,6 +27,10 @@ using namespace pnm;
 using pnm2::March2Tables;
 using pnm2::warp_record;
 
+#ifndef PN_CAND_FLIGHT
+#define PN_CAND_FLIGHT 8  // candidate-list entries a lane has in flight per memory round trip
+#endif
+
 struct RayConsts {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
     float bmin0, bmin1, bmin2, bmax0, bmax1, bmax2, hi0, hi1, hi2;
@@ -145,12 +149,12 @@ __device__ __forceinline__ void eval_point(const MarchParams& a, const March2Tab
             } else {
                 // find_closest_IPs (:1045-1118): all 27 cells in visiting order (= list order), insertion on strict '<'
                 float d0 = FLT_MAX, d1 = FLT_MAX, d2 = FLT_MAX;
-                for (int j0 = b; j0 < e; j0 += 4) {  // four entries in flight per round trip
-                    float4 v[4];
+                for (int j0 = b; j0 < e; j0 += PN_CAND_FLIGHT) {  // entries in flight per round trip
+                    float4 v[PN_CAND_FLIGHT];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) v[u] = tb.nb[min(j0 + u, e - 1)];
+                    for (int u = 0; u < PN_CAND_FLIGHT; u++) v[u] = tb.nb[min(j0 + u, e - 1)];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < PN_CAND_FLIGHT; u++) {
                         const int j = j0 + u;
                         const float ax = v[u].x - x, ay = v[u].y - y, az = v[u].z - z;
                         const float d = ax * ax + ay * ay + az * az;
@@ -173,14 +177,30 @@ __device__ __forceinline__ void eval_point(const MarchParams& a, const March2Tab
         int n_IP = (ord[0] != -1) + (ord[1] != -1) + (ord[2] != -1);
         found = n_IP > 0;
         if (found) {
-            int ips[3] = {0, 0, 0};
+            // the selected candidates' entries and the heads of their IP records are fetched for all K at once (two memory round
+            // trips for the whole point) — the loops below, whose bounds shrink as they run, then work on registers
+            float4 cnd[3];
+            int ips[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                cnd[k] = tb.nb[(k < K && ord[k] >= 0) ? ord[k] : ord[0]];
+                ips[k] = __float_as_int(cnd[k].w);
+            }
+            float4 rh[3][4];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (k < K) {
+                    const float4* __restrict__ rp = tb.rec + (size_t)ips[k] * 11;
+                    rh[k][0] = rp[0]; rh[k][1] = rp[1]; rh[k][2] = rp[2]; rh[k][3] = rp[3];
+                }
+            }
             // pre-filter (:1246-1251): `n_IP--` inside the loop it bounds, strict '<' on z only
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 if (k < n_IP) {
-                    const float4 cnd = tb.nb[ord[k]];
-                    ips[k] = __float_as_int(cnd.w);
-                    if (cnd.x <= c.bmin0 || cnd.y <= c.bmin1 || cnd.z < c.bmin2 || cnd.x >= c.bmax0 || cnd.y >= c.bmax1 || cnd.z >= c.bmax2) n_IP--;
+                    if (cnd[k].x <= c.bmin0 || cnd[k].y <= c.bmin1 || cnd[k].z < c.bmin2 || cnd[k].x >= c.bmax0 || cnd[k].y >= c.bmax1 ||
+                        cnd[k].z >= c.bmax2)
+                        n_IP--;
                 }
             }
             if (n_IP <= 0) found = false;
@@ -192,7 +212,7 @@ __device__ __forceinline__ void eval_point(const MarchParams& a, const March2Tab
                     if (k < n_IP) {
                         float pw[3];
                         r.n_warp++;
-                        if (warp_record<MULTI>(tb.rec + (size_t)ips[k] * 11, a.max_iter_num, a.IP_dx, x, y, z, pw, &dk[k])) n_IP--;
+                        if (warp_record<MULTI>(rh[k], tb.rec + (size_t)ips[k] * 11, a.max_iter_num, a.IP_dx, x, y, z, pw, &dk[k])) n_IP--;
                         ps[3 * k] = pw[0]; ps[3 * k + 1] = pw[1]; ps[3 * k + 2] = pw[2];
                     }
                 }

@@ -330,9 +330,13 @@ struct TailEntry {
     int step;
 };
 
+// waves per SIMD the march kernels are compiled for: 3 leaves 170 VGPRs, which holds the K prefetched IP-record heads and 8
+// candidate entries in flight without spilling (4 -> 128 VGPRs spills 64 B per lane); the kernels wait on memory, not on occupancy
+#define PN_MARCH_WAVES 3
+
 // 8 lanes per ray, 32 rays per 256-thread block.
 template <int K, bool MULTI>
-__global__ void __launch_bounds__(256, 4) k_march(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
+__global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
     uint32_t n_alive = io.n_alive, n_step = io.n_step;
     if (io.trip) { n_alive = (uint32_t)io.trip->n_alive; n_step = (uint32_t)io.trip->n_step; }
     const int lane = threadIdx.x & 63, sub = lane & 7, gbase = lane & ~7;
@@ -388,7 +392,7 @@ __global__ void __launch_bounds__(256, 4) k_march(pnm::MarchParams a, pnm2::Marc
 
 // One wave per unfinished ray: windows of 64 sequence elements until the ray is done for this trip.
 template <int K, bool MULTI>
-__global__ void __launch_bounds__(256, 4) k_march_tail(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
+__global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march_tail(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
     uint32_t n_step = io.n_step;
     if (io.trip) n_step = (uint32_t)io.trip->n_step;
     const int total = __hip_atomic_load(io.tail_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
