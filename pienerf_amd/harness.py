@@ -135,7 +135,7 @@ class SimRenderHarness:
         torch.cuda.current_stream(self.device).wait_stream(warm)
         torch.cuda.synchronize(self.device)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
             self._graph_out = self._step_body(n_trips, W, H)
         self.sim.dof.copy_(keep[0])       # warm-up advanced the simulator; capture itself executes nothing
         self.sim.dof_vel.copy_(keep[1])
@@ -229,8 +229,10 @@ class SimRenderHarness:
                     rays = get_rays(self._graph_pose, self.intrinsics, H, W, -1)
                     m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **dict(kw, frame_slot=lane))
             torch.cuda.synchronize(dev)
+        # capture_error_mode="thread_local": with a process group alive, RCCL's watchdog thread queries events while we capture;
+        # in the default "global" mode any HIP call from another thread invalidates the capture
         gs = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gs, stream=p["sim_stream"]):
+        with torch.cuda.graph(gs, stream=p["sim_stream"], capture_error_mode="thread_local"):
             if not _probe_no_substep:
                 self.sim.stepforward()
             else:
@@ -241,7 +243,7 @@ class SimRenderHarness:
             s = streams[lane]
             m.p_def, m.IP_F, m.IP_dF = p["ip"][lane]  # the render graph of this lane reads the lane's own IP buffers
             gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr, stream=s):
+            with torch.cuda.graph(gr, stream=s, capture_error_mode="thread_local"):
                 rays = get_rays(self._graph_pose, self.intrinsics, H, W, -1)
                 out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **kw_l)
             p["ren_graph"].append(gr)
