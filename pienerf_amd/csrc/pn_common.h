@@ -71,6 +71,7 @@ struct pn_net {
     float bound;
 };
 #define PN_NET_MFMAS 192
+#define PN_NET_VALU_OFF (160 * 64)  // float offset, inside the image, of the VALU output layer's 192 weights (slots of MFMAs 160..191)
 
 // internal launcher shared by pn_nerf_forward and the frame driver: evaluates the network on the `count` samples whose
 // slot ids are list[0..count) (list == NULL: slots 0..M-1); when ctl_count != NULL the count is read from device memory.

@@ -242,6 +242,18 @@ extern "C" int pn_net_create(pn_net** out, const float* embeddings, const int* o
     float* img = new float[PN_NET_MFMAS * 64];
     for (int m = 0; m < PN_NET_MFMAS; m++)
         for (int l = 0; l < 64; l++) img[((m >> 2) * 64 + l) * 4 + (m & 3)] = host[m * 64 + l];
+    // The 64 -> 3 output layer runs on the vector ALU (k_nerf_forward: 96 FMAs per lane on the D layout instead of 32 MFMAs that
+    // are 29/32 row padding — f32 MFMA and VALU share the fp32 ALUs), so the image slots of MFMAs 160..191 hold
+    // its weights instead: wlast[h][q][o] = W4[o][krow(q, h)], q = tile*16 + register index of the D layout.
+    {
+        float* wlast = img + PN_NET_VALU_OFF;
+        for (int h = 0; h < 2; h++)
+            for (int q = 0; q < 32; q++)
+                for (int o = 0; o < 3; o++) {
+                    const int t = q >> 4, r = q & 15;
+                    wlast[(h * 32 + q) * 3 + o] = W4[o * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+                }
+    }
     hipError_t e = hipMalloc((void**)&n->wpack, sizeof(float) * PN_NET_MFMAS * 64);
     if (e == hipSuccess) e = hipMalloc((void**)&n->fused_levels, sizeof(fl));
     if (e == hipSuccess) e = hipMemcpyAsync(n->fused_levels, fl, sizeof(fl), hipMemcpyHostToDevice, (hipStream_t)stream);
@@ -453,17 +465,25 @@ __global__ void __launch_bounds__(256, MINW) k_nerf_forward(const PnFusedLevel* 
         d0 = relu16(d0);
         d1 = relu16(d1);
         __builtin_amdgcn_sched_barrier(0);  // keep the next layer's LDS weight reads from being hoisted (register pressure)
-        // ---- colour layer 2: 64 -> 3
-        f32x16 e = {0};
+        // ---- colour layer 2: 64 -> 3 on the vector ALU: this lane holds 32 of the 64 hidden values of its sample (D layout), its
+        // partner lane (l ^ 32) the other 32; 3 x 32 FMAs with broadcast LDS weights, then one cross-half add per output
+        float e[3] = {0.f, 0.f, 0.f};
+        {
+            const float* __restrict__ wlast = reinterpret_cast<const float*>(wlds) + PN_NET_VALU_OFF + half * 96;
 #pragma unroll
-        for (int g = 0; g < 8; g++) {
-            const float4 w = wl[(40 + g) * 64];
-            const f32x16& src = (g < 4) ? d0 : d1;
-            const int r = (g & 3) * 4;
-            e = PN_MFMA(w.x, src[r + 0], e);
-            e = PN_MFMA(w.y, src[r + 1], e);
-            e = PN_MFMA(w.z, src[r + 2], e);
-            e = PN_MFMA(w.w, src[r + 3], e);
+            for (int q4 = 0; q4 < 8; q4++) {  // 4 hidden values x 3 outputs = 12 weights = 3 ds_read_b128
+                const float4 wa = *reinterpret_cast<const float4*>(wlast + q4 * 12);
+                const float4 wb = *reinterpret_cast<const float4*>(wlast + q4 * 12 + 4);
+                const float4 wc = *reinterpret_cast<const float4*>(wlast + q4 * 12 + 8);
+                const f32x16& src = (q4 < 4) ? d0 : d1;
+                const int r = (q4 & 3) * 4;
+                e[0] = fmaf(wa.x, src[r], e[0]); e[1] = fmaf(wa.y, src[r], e[1]); e[2] = fmaf(wa.z, src[r], e[2]);
+                e[0] = fmaf(wa.w, src[r + 1], e[0]); e[1] = fmaf(wb.x, src[r + 1], e[1]); e[2] = fmaf(wb.y, src[r + 1], e[2]);
+                e[0] = fmaf(wb.z, src[r + 2], e[0]); e[1] = fmaf(wb.w, src[r + 2], e[1]); e[2] = fmaf(wc.x, src[r + 2], e[2]);
+                e[0] = fmaf(wc.y, src[r + 3], e[0]); e[1] = fmaf(wc.z, src[r + 3], e[1]); e[2] = fmaf(wc.w, src[r + 3], e[2]);
+            }
+#pragma unroll
+            for (int o = 0; o < 3; o++) e[o] += __shfl_xor(e[o], 32);
         }
         if (valid && half == 0) {
             sigmas[slot] = density_scale * expf(sigma_logit);           // trunc_exp forward = exp (nerf/activation.py:8-10)
