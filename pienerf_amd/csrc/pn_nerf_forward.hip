@@ -325,7 +325,7 @@ __device__ __forceinline__ void encode8(const PnFusedLevel* __restrict__ lv, con
 
 __device__ __forceinline__ f32x16 relu16(f32x16 v) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = fmaxf(v[r], 0.0f);
+    for (int r = 0; r < 16; r++) v[r] = __int_as_float(max(__float_as_int(v[r]), 0));  // ReLU as ONE v_max_i32 (fmaxf: two v_max_f32, NaN canonicalisation)
     return v;
 }
 
@@ -412,12 +412,19 @@ __global__ void __launch_bounds__(256, MINW) k_nerf_forward(const PnFusedLevel* 
         float sh[16];
         sh16(dx, dy, dz, sh);
         float v[16];
+        // `half ? arr[i] : arr[j]` is rewritten by the compiler into arr[half ? i : j], a dynamic register index that it then lowers
+        // to a 16-way compare + v_cndmask chain (~200 VALU instructions per tile, in a kernel bound by ALU issue); the empty asm
+        // pins both operands in registers so that each select stays one v_cndmask
+        auto pick = [half](float a, float b) {
+            asm volatile("" : "+v"(a), "+v"(b));
+            return half ? a : b;
+        };
 #pragma unroll
-        for (int k = 0; k < 7; k++) v[k] = half ? h2[k] : h2[k + 1];
-        v[7] = half ? h2[7] : sh[0];
+        for (int k = 0; k < 7; k++) v[k] = pick(h2[k], h2[k + 1]);
+        v[7] = pick(h2[7], sh[0]);
 #pragma unroll
-        for (int k = 8; k < 15; k++) v[k] = half ? sh[k + 1] : sh[k - 7];
-        v[15] = half ? 0.0f : sh[8];
+        for (int k = 8; k < 15; k++) v[k] = pick(sh[k + 1], sh[k - 7]);
+        v[15] = pick(0.0f, sh[8]);
         __builtin_amdgcn_sched_barrier(0);  // keep the next layer's LDS weight reads from being hoisted (register pressure)
         // ---- colour layer 0: 31 -> 64, ReLU
         f32x16 c0 = {0}, c1 = {0};
