@@ -256,6 +256,7 @@ class SimRenderHarness:
             ev = torch.cuda.Event()
             ev.record(main)
             p["done"].append(ev)
+            p.setdefault("done_spare", []).append(torch.cuda.Event())
             p["pending"].append(False)
         torch.cuda.synchronize(dev)
         self.sim.dof.copy_(keep[0])
@@ -269,14 +270,9 @@ class SimRenderHarness:
         `done` event has fired (synchronize() / the next use of the lane)."""
         p = self._pipe
         lane = self.frame % p["lanes"]
-        if p["pending"][lane]:  # the lane's previous frame: finished?  (host runs at most `lanes` frames ahead)
-            p["done"][lane].synchronize()
-            st = self.model.render_status(synchronize=False, slot=lane)
-            if st["alive_at_exit"] > 0:
-                raise RuntimeError(f"pipelined step ran {p['trips']} render trips but {st['alive_at_exit']} rays were still alive")
         sim_s, ren_s = p["sim_stream"], p["stream"][lane]
-        # simulator: substeps up to frame + ahead.  Snapshot slot g % slots was last read by frame g - slots <= frame - lanes - 1,
-        # which the host has already seen complete (above), so the simulator stream waits for nothing.
+        # simulator: substeps up to frame + ahead.  Snapshot slot g % slots was last read by frame g - slots = frame - lanes - 1,
+        # which the host saw complete at the end of the previous call, so the simulator stream waits for nothing.
         with torch.cuda.stream(sim_s):
             while p["sim_next"] <= self.frame + p["ahead"]:
                 slot = p["sim_next"] % p["slots"]
@@ -284,7 +280,12 @@ class SimRenderHarness:
                 p["snap_ready"][slot].record(sim_s)
                 p["sim_graph"].replay()
                 p["sim_next"] += 1
+        # this frame goes onto its lane BEFORE the host waits for the lane's previous frame (stream order keeps them apart on
+        # the GPU): the ~0.15 ms the host needs to wake up and enqueue ~100 launches is then hidden behind that frame's tail
+        # instead of leaving the lane empty
         slot = self.frame % p["slots"]
+        prev_done, had_prev = p["done"][lane], p["pending"][lane]
+        p["done"][lane], p["done_spare"][lane] = p["done_spare"][lane], prev_done
         ren_s.wait_event(p["snap_ready"][slot])
         with torch.cuda.stream(ren_s):
             self.sim.get_IP_info(dof=p["snap"][slot], out=p["ip"][lane])
@@ -292,6 +293,13 @@ class SimRenderHarness:
             p["done"][lane].record(ren_s)
         p["pending"][lane] = True
         self.frame += 1
+        if had_prev:  # the host runs at most `lanes` completed-or-running frames plus one queued frame per lane ahead
+            prev_done.synchronize()
+            # the status words of the previous frame are read microseconds after it completed; the frame just enqueued overwrites
+            # them only at ITS end, a render later
+            st = self.model.render_status(synchronize=False, slot=lane)
+            if st["alive_at_exit"] > 0:
+                raise RuntimeError(f"pipelined step ran {p['trips']} render trips but {st['alive_at_exit']} rays were still alive")
         return p["out"][lane]
 
     # ------------------------------------------------------------------ frame-parallel over the GPUs of a node
