@@ -332,11 +332,6 @@ class SimRenderHarness:
         f, world, rank, S = self.frame, p["world"], p["rank"], p["slots"]
         mine = (f % world) == rank
         lane = (f // world) % p["lanes"]
-        if mine and p["pending"][lane]:  # this rank's previous frame on the lane must have finished (outputs / IP buffers are reused)
-            p["done"][lane].synchronize()
-            st = self.model.render_status(synchronize=False, slot=lane)
-            if st["alive_at_exit"] > 0:
-                raise RuntimeError(f"frame-parallel step ran {p['trips']} render trips but {st['alive_at_exit']} rays were still alive")
         sim_s, comm = p["sim_stream"], p["comm"]
         if rank == p["owner"]:
             with torch.cuda.stream(sim_s):
@@ -366,8 +361,10 @@ class SimRenderHarness:
         if mine:
             slot = f % S
             ren_s = p["stream"][lane]
+            prev_done, had_prev = p["done"][lane], p["pending"][lane]
+            p["done"][lane], p["done_spare"][lane] = p["done_spare"][lane], prev_done
             ren_s.wait_event(p["bc_done"][slot] if world > 1 else p["snap_ready"][slot])
-            with torch.cuda.stream(ren_s):
+            with torch.cuda.stream(ren_s):  # enqueued before the host waits for the lane's previous frame (see step_pipelined)
                 self.sim.get_IP_info(dof=p["snap"][slot], out=p["ip"][lane])
                 p["ip_done"][slot].record(ren_s)
                 p["ip_used"][slot] = True
@@ -375,6 +372,11 @@ class SimRenderHarness:
                 p["done"][lane].record(ren_s)
             p["pending"][lane] = True
             out = p["out"][lane]
+            if had_prev:
+                prev_done.synchronize()
+                st = self.model.render_status(synchronize=False, slot=lane)
+                if st["alive_at_exit"] > 0:
+                    raise RuntimeError(f"frame-parallel step ran {p['trips']} render trips but {st['alive_at_exit']} rays were still alive")
         self.frame += 1
         return out
 
