@@ -28,7 +28,7 @@ using pnm2::March2Tables;
 using pnm2::warp_record;
 
 #ifndef PN_CAND_FLIGHT
-#define PN_CAND_FLIGHT 8  // candidate-list entries a lane has in flight per memory round trip
+#define PN_CAND_FLIGHT 4  // candidate-list entries a lane has in flight per memory round trip (8: +16 VGPRs, no measurable gain)
 #endif
 
 struct RayConsts {
@@ -177,22 +177,14 @@ __device__ __forceinline__ void eval_point(const MarchParams& a, const March2Tab
         int n_IP = (ord[0] != -1) + (ord[1] != -1) + (ord[2] != -1);
         found = n_IP > 0;
         if (found) {
-            // the selected candidates' entries and the heads of their IP records are fetched for all K at once (two memory round
-            // trips for the whole point) — the loops below, whose bounds shrink as they run, then work on registers
+            // the selected candidates' entries are fetched for all K at once — the pre-filter loop below, whose bound shrinks as it
+            // runs, then works on registers
             float4 cnd[3];
             int ips[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 cnd[k] = tb.nb[(k < K && ord[k] >= 0) ? ord[k] : ord[0]];
                 ips[k] = __float_as_int(cnd[k].w);
-            }
-            float4 rh[3][4];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                if (k < K) {
-                    const float4* __restrict__ rp = tb.rec + (size_t)ips[k] * 11;
-                    rh[k][0] = rp[0]; rh[k][1] = rp[1]; rh[k][2] = rp[2]; rh[k][3] = rp[3];
-                }
             }
             // pre-filter (:1246-1251): `n_IP--` inside the loop it bounds, strict '<' on z only
 #pragma unroll
@@ -212,7 +204,9 @@ __device__ __forceinline__ void eval_point(const MarchParams& a, const March2Tab
                     if (k < n_IP) {
                         float pw[3];
                         r.n_warp++;
-                        if (warp_record<MULTI>(rh[k], tb.rec + (size_t)ips[k] * 11, a.max_iter_num, a.IP_dx, x, y, z, pw, &dk[k])) n_IP--;
+                        const float4* __restrict__ rp = tb.rec + (size_t)ips[k] * 11;
+                        const float4 rh[4] = {rp[0], rp[1], rp[2], rp[3]};  // loaded per IP: prefetching all K heads costs 48 VGPRs
+                        if (warp_record<MULTI>(rh, rp, a.max_iter_num, a.IP_dx, x, y, z, pw, &dk[k])) n_IP--;
                         ps[3 * k] = pw[0]; ps[3 * k + 1] = pw[1]; ps[3 * k + 2] = pw[2];
                     }
                 }

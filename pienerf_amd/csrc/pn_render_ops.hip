@@ -330,9 +330,11 @@ struct TailEntry {
     int step;
 };
 
-// waves per SIMD the march kernels are compiled for: 3 leaves 170 VGPRs, which holds the K prefetched IP-record heads and 8
-// candidate entries in flight without spilling (4 -> 128 VGPRs spills 64 B per lane); the kernels wait on memory, not on occupancy
-#define PN_MARCH_WAVES 3
+// waves per SIMD the march kernels are compiled for: 4 -> at most 128 VGPRs.  The kernels wait on memory rather than on
+// occupancy, but their register footprint decides what else fits beside them: with 3 waves x 146 VGPRs a SIMD had no room left
+// for a wave of the simulator's kernels (k_elastic: 94), and the substep running concurrently on its own stream cost the
+// pipelined step 5 % more than it does now (measured)
+#define PN_MARCH_WAVES 4
 
 // 8 lanes per ray, 32 rays per 256-thread block.
 template <int K, bool MULTI>
