@@ -160,22 +160,24 @@ def kernel_report(h, opt, dev):
     net_loop_gbs = FUSED_BYTES_PER_SAMPLE * st["samples"] / (net_loop_ms * 1e-3) / 1e9
     net_loop_tf = MLP_FLOP_PER_SAMPLE * st["samples"] / (net_loop_ms * 1e-3) / 1e12
     roofline = {
-        "kernel": "k_nerf_forward<2,4> (hash-grid gather + SH + 5-layer MLP fused, f32 MFMA), launches inside the render loop",
-        # PMC: the SIMD matrix pipe is busy 59 % of the kernel's time, waves wait on memory 12 % of theirs -> MFMA is the bound
-        "bound": "mfma", "achieved": round(net_loop_tf, 2), "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": round(net_loop_tf / F32_MFMA_PEAK_TF, 4),
-        "flop_per_sample": MLP_FLOP_PER_SAMPLE, "flop_per_sample_issued": 24576,
+        "kernel": "k_nerf_forward<2,4> (hash-grid gather + SH + 5-layer MLP fused; dense layers as three-way bf16-split MFMA at fp32 accuracy), "
+                  "launches inside the render loop",
+        # cutting the matrix time by 2.7x (f32-input MFMA -> bf16 split) left the stand-alone kernel time unchanged, the
+        # gather-only variant of the kernel takes 69 % of its time, the MLP-only variant 55 %: the bound is the gather path
+        "bound": "hbm", "achieved": round(net_loop_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(net_loop_gbs / HBM_PEAK_GBS, 4),
+        "bytes_per_sample": FUSED_BYTES_PER_SAMPLE, "algorithmic_bytes_per_launch": int(FUSED_BYTES_PER_SAMPLE * st["samples"] / real),
         "traffic": traffic.get("k_nerf_forward"),
         "traffic_note": "HBM bytes per launch, FETCH_SIZE+WRITE_SIZE PMC passes (profiles/pmc_traffic.json); below the algorithmic bytes because the "
                         "dense levels and part of the hashed tables are served by L2 / Infinity Cache",
         "launch_ms": round(net_loop_ms / real, 4), "launches_per_frame": real, "ms_per_frame": round(net_loop_ms, 4),
         "launch_ms_incl_empty_trips": round(float(net_ms.mean()), 4), "launches_enqueued_per_frame": int(len(net_ms)),
-        "samples_per_frame": st["samples"], "algorithmic_flop_per_launch": int(MLP_FLOP_PER_SAMPLE * st["samples"] / real),
-        "hbm_view": {"bytes_per_sample": FUSED_BYTES_PER_SAMPLE, "algorithmic_bytes_per_launch": int(FUSED_BYTES_PER_SAMPLE * st["samples"] / real),
-                     "achieved_GBps": round(net_loop_gbs, 1), "frac_of_hbm_peak": round(net_loop_gbs / HBM_PEAK_GBS, 4)},
-        "all_samples_one_launch": {"launch_ms": round(t_net, 4), "mfma_tflops": round(net_tf, 2), "frac_of_f32_mfma_peak": round(net_tf / F32_MFMA_PEAK_TF, 4),
-                                   "achieved_GBps": round(net_gbs, 1), "frac_of_hbm_peak": round(net_gbs / HBM_PEAK_GBS, 4)},
-        "note": "peak = 157.3 TFLOP/s, the dense f32-input MFMA rate of MI355X_MICROARCH.md (= the fp32 vector rate; no xf32 on gfx950); "
-                "achieved counts the network's 18 688 useful FLOP per sample, not the 24 576 issued with row padding",
+        "samples_per_frame": st["samples"],
+        "mfma_view": {"flop_per_sample_fp32_equivalent": MLP_FLOP_PER_SAMPLE, "bf16_mfma_flop_per_sample_issued": 6 * 20 * 32768 // 32,
+                      "fp32_equivalent_TFLOPs": round(net_loop_tf, 2), "frac_of_f32_mfma_peak": round(net_loop_tf / F32_MFMA_PEAK_TF, 4)},
+        "all_samples_one_launch": {"launch_ms": round(t_net, 4), "achieved_GBps": round(net_gbs, 1), "frac_of_hbm_peak": round(net_gbs / HBM_PEAK_GBS, 4),
+                                   "fp32_equivalent_TFLOPs": round(net_tf, 2)},
+        "note": "achieved = 1 068 algorithmic bytes per sample (16 levels x 8 corners x 8 B gathered + 4 B slot id + 24 B xyz/dir in + 16 B sigma/rgb "
+                "out) x samples of the launch / HIP-event time of the launch; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md)",
     }
     extra = {
         "march": {"kernels": "k_march_skip + k_march<3,false> + k_march_tail<3,false> per loop trip (ray march + inverse-GMLS warp)",

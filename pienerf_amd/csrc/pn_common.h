@@ -66,12 +66,15 @@ int pn_fill_grid_levels(PnGridLevels* g, const int* offsets_host, uint32_t L, ui
 struct pn_net {
     PnGridLevels levels;
     const float* embeddings;  // device, not owned
-    float* wpack;             // device, owned: MFMA A-operand stream, [PN_NET_MFMAS][64]
+    void* wsplit;             // device, owned: the kernel's LDS weight image, PN_NET_SPLIT_BYTES (pn_nerf_forward.hip)
     void* fused_levels;       // device, owned: PnFusedLevel[16] (pn_nerf_forward.hip)
     float bound;
 };
-#define PN_NET_MFMAS 192
-#define PN_NET_VALU_OFF (160 * 64)  // float offset, inside the image, of the VALU output layer's 192 weights (slots of MFMAs 160..191)
+
+// weight image: [20 MFMA operand groups][3 bf16 pieces hi/mid/lo][64 lanes][8 bf16], then the VALU output layer's 192 fp32 weights
+#define PN_NET_GROUPS 20
+#define PN_NET_SPLIT_W_BYTES (PN_NET_GROUPS * 3 * 64 * 16)
+#define PN_NET_SPLIT_BYTES (PN_NET_SPLIT_W_BYTES + 192 * 4)
 
 // internal launcher shared by pn_nerf_forward and the frame driver: evaluates the network on the `count` samples whose
 // slot ids are list[0..count) (list == NULL: slots 0..M-1); when ctl_count != NULL the count is read from device memory.

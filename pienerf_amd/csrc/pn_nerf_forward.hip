@@ -5,12 +5,13 @@
 //
 // Fused kernel layout (one wave = 32 samples, two lanes per sample):
 //   lane l: sample s = l & 31, half h = l >> 5.  Half h gathers hash levels [8h, 8h+8) -> 16 features per lane.
-//   Every dense layer is a chain of v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, D = W·X^T):
-//     A operand (lane l) = W[out = tile*32 + (l&31)][k(h)]   — pre-permuted on the host, streamed from LDS
-//     B operand (lane l) = this lane's own activation register — k(0) comes from the low half, k(1) from the high half
+//   Every dense layer is D = W·X^T on v_mfma_f32_32x32x16_bf16 at fp32 accuracy (three-way bf16 split, see k_nerf_forward):
+//     A operand (lane l) = 8 K-elements of W[out = tile*32 + (l&31)][.] — pre-permuted and pre-split on the host, streamed from LDS
+//     B operand (lane l) = 8 of this lane's own activation registers, split in registers
 //     D layout: lane l holds out-rows (r&3) + 8*(r>>2) + 4h, r = 0..15, of column s.
-//   The D layout of one layer is exactly the B layout of the next (rows i and i+4 pair up), so activations never
-//   leave registers; the only LDS traffic is the 48 KB weight stream shared by all waves of a workgroup.
+//   The K index of (chunk kc, lane half h, element e) is whatever feature that lane holds in register 8 kc + e, so the D layout of
+//   one layer is directly the B layout of the next: activations never leave registers; the only LDS traffic is the 61 KB weight
+//   image shared by all waves of a workgroup.
 #include <math.h>
 #include <stdlib.h>
 
@@ -196,8 +197,9 @@ extern "C" int pn_sh_encode_forward(const float* inputs, float* outputs, uint32_
 static const int PN_MAPL[16] = {16, 17, 18, 23, 24, 25, 26, 0, 1, 2, 3, 4, 5, 6, 7, 8};
 static const int PN_MAPU[16] = {19, 20, 21, 22, 27, 28, 29, 30, 9, 10, 11, 12, 13, 14, 15, 31};
 
-// Host: A-operand stream, wpack[m][lane], in MFMA issue order (see header comment).
-static void pack_weights(const float* W0, const float* W1, const float* W2, const float* W3, const float* W4, float* wp) {
+// Host: wp[m][lane] = the weight that multiplies activation register m (numbered through the four MFMA layers: 2 x 16, 32, 2 x 16,
+// 2 x 32) of lane half lane >> 5, for output row lane & 31 of that layer's tile (see header comment).
+static void pack_weights(const float* W0, const float* W1, const float* W2, const float* W3, float* wp) {
     auto krow = [](int q, int h) { const int t = q >> 4, r = q & 15; return t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h; };
     int m = 0;
     for (int t = 0; t < 2; t++)  // layer 0: 32 -> 64
@@ -214,8 +216,6 @@ static void pack_weights(const float* W0, const float* W1, const float* W2, cons
     for (int t = 0; t < 2; t++)  // layer 3: 64 -> 64
         for (int q = 0; q < 32; q++, m++)
             for (int l = 0; l < 64; l++) wp[m * 64 + l] = W3[(t * 32 + (l & 31)) * 64 + krow(q, l >> 5)];
-    for (int q = 0; q < 32; q++, m++)  // layer 4: 64 -> 3 (rows 3..31 zero)
-        for (int l = 0; l < 64; l++) wp[m * 64 + l] = ((l & 31) < 3) ? W4[(l & 31) * 64 + krow(q, l >> 5)] : 0.0f;
 }
 
 extern "C" int pn_net_create(pn_net** out, const float* embeddings, const int* offsets_host, uint32_t L, uint32_t C, float per_level_scale_log2,
@@ -236,17 +236,38 @@ extern "C" int pn_net_create(pn_net** out, const float* embeddings, const int* o
     }
     n->embeddings = embeddings;
     n->bound = bound;
-    float* host = new float[PN_NET_MFMAS * 64];
-    pack_weights(W0, W1, W2, W3, W4, host);
-    // LDS image: [m/4][lane][4] so that one ds_read_b128 fetches the A operands of 4 consecutive MFMAs
-    float* img = new float[PN_NET_MFMAS * 64];
-    for (int m = 0; m < PN_NET_MFMAS; m++)
-        for (int l = 0; l < 64; l++) img[((m >> 2) * 64 + l) * 4 + (m & 3)] = host[m * 64 + l];
-    // The 64 -> 3 output layer runs on the vector ALU (k_nerf_forward: 96 FMAs per lane on the D layout instead of 32 MFMAs that
-    // are 29/32 row padding — f32 MFMA and VALU share the fp32 ALUs), so the image slots of MFMAs 160..191 hold
-    // its weights instead: wlast[h][q][o] = W4[o][krow(q, h)], q = tile*16 + register index of the D layout.
+    float* host = new float[160 * 64];
+    pack_weights(W0, W1, W2, W3, host);
+    // LDS image for v_mfma_f32_32x32x16_bf16: operand group (layer, out tile t, K chunk kc) takes the 8 consecutive activation
+    // registers m0 + 8 kc + e (e = 0..7) of the stream above as the 8 K-elements of its lane, each weight cut into three bf16
+    // pieces w = hi + mid + lo (truncation splits: exact, 8 + 8 + 8 significant bits).
+    unsigned char* simg = new unsigned char[PN_NET_SPLIT_BYTES];
     {
-        float* wlast = img + PN_NET_VALU_OFF;
+        uint16_t* s16 = reinterpret_cast<uint16_t*>(simg);
+        int G = 0;
+        auto emit = [&](int m0) {
+            for (int l = 0; l < 64; l++)
+                for (int e2 = 0; e2 < 8; e2++) {
+                    float v = host[(m0 + e2) * 64 + l];
+                    for (int p = 0; p < 3; p++) {
+                        uint32_t u;
+                        memcpy(&u, &v, 4);
+                        u &= 0xffff0000u;
+                        float h;
+                        memcpy(&h, &u, 4);
+                        s16[((size_t)(G * 3 + p) * 64 + l) * 8 + e2] = (uint16_t)(u >> 16);
+                        v -= h;
+                    }
+                }
+            G++;
+        };
+        for (int t = 0; t < 2; t++) for (int kc = 0; kc < 2; kc++) emit(0 + t * 16 + 8 * kc);    // layer 0: groups 0..3
+        for (int kc = 0; kc < 4; kc++) emit(32 + 8 * kc);                                         // layer 1: groups 4..7
+        for (int t = 0; t < 2; t++) for (int kc = 0; kc < 2; kc++) emit(64 + t * 16 + 8 * kc);   // layer 2: groups 8..11
+        for (int t = 0; t < 2; t++) for (int kc = 0; kc < 4; kc++) emit(96 + t * 32 + 8 * kc);   // layer 3: groups 12..19
+        // The 64 -> 3 output layer runs on the vector ALU (96 FMAs per lane on the D layout; an MFMA tile would be 29/32 row padding):
+        // wlast[h][q][o] = W4[o][krow(q, h)], q = tile*16 + register index of the D layout.
+        float* wlast = reinterpret_cast<float*>(simg + PN_NET_SPLIT_W_BYTES);
         for (int h = 0; h < 2; h++)
             for (int q = 0; q < 32; q++)
                 for (int o = 0; o < 3; o++) {
@@ -254,13 +275,13 @@ extern "C" int pn_net_create(pn_net** out, const float* embeddings, const int* o
                     wlast[(h * 32 + q) * 3 + o] = W4[o * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
                 }
     }
-    hipError_t e = hipMalloc((void**)&n->wpack, sizeof(float) * PN_NET_MFMAS * 64);
+    hipError_t e = hipMalloc((void**)&n->wsplit, PN_NET_SPLIT_BYTES);
+    if (e == hipSuccess) e = hipMemcpyAsync(n->wsplit, simg, PN_NET_SPLIT_BYTES, hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e == hipSuccess) e = hipMalloc((void**)&n->fused_levels, sizeof(fl));
     if (e == hipSuccess) e = hipMemcpyAsync(n->fused_levels, fl, sizeof(fl), hipMemcpyHostToDevice, (hipStream_t)stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(n->wpack, img, sizeof(float) * PN_NET_MFMAS * 64, hipMemcpyHostToDevice, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     delete[] host;
-    delete[] img;
+    delete[] simg;
     if (e != hipSuccess) {
         snprintf(pn_err_buf, sizeof(pn_err_buf), "pn_net_create: %s", hipGetErrorString(e));
         delete n;
@@ -272,7 +293,7 @@ extern "C" int pn_net_create(pn_net** out, const float* embeddings, const int* o
 
 extern "C" void pn_net_destroy(pn_net* n) {
     if (!n) return;
-    if (n->wpack) (void)hipFree(n->wpack);
+    if (n->wsplit) (void)hipFree(n->wsplit);
     if (n->fused_levels) (void)hipFree(n->fused_levels);
     delete n;
 }
@@ -321,35 +342,78 @@ __device__ __forceinline__ void encode8(const PnFusedLevel* __restrict__ lv, con
     }
 }
 
-#define PN_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-
 __device__ __forceinline__ f32x16 relu16(f32x16 v) {
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = __int_as_float(max(__float_as_int(v[r]), 0));  // ReLU as ONE v_max_i32 (fmaxf: two v_max_f32, NaN canonicalisation)
     return v;
 }
 
-// Workgroup = 4 waves; LDS = the 48 KB packed weight image.  MINW = waves per SIMD the register allocator must leave room
-// for; LU = how many hash levels' gathers are in flight per lane at once.
+// ------------------------------------------------------------------------------------------------ fused kernel
+// The dense layers run on the bf16 matrix pipe at fp32 accuracy.  An fp32 value is cut, by truncation, into three bf16 pieces
+// x = hi + mid + lo (8 + 8 + 8 significant bits, exact), weights likewise on the host; a product x*w is the six partial
+// products whose weight is >= 2^-16 (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi; the dropped mid*lo, lo*mid, lo*lo are
+// <= 2^-23 |x*w|, the size of fp32's own product rounding), accumulated in the fp32 accumulator of
+// v_mfma_f32_32x32x16_bf16.  Six bf16 MFMAs of 32 cycles do the work of sixteen v_mfma_f32_32x32x2_f32 of 64 cycles, and — unlike
+// the f32-input MFMA, which occupies the fp32 vector ALUs — they run beside the VALU work of the SIMD's other waves.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct Split8 { uint4 hi, mid, lo; };
+
+__device__ __forceinline__ uint32_t hi_pair(float a, float b) {  // bf16 (truncated) of a in the low half, of b in the high half
+    return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+__device__ __forceinline__ float drop_hi(float x) { return x - __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+__device__ __forceinline__ Split8 split8(float x0, float x1, float x2, float x3, float x4, float x5, float x6, float x7) {
+    Split8 o;
+    o.hi = make_uint4(hi_pair(x0, x1), hi_pair(x2, x3), hi_pair(x4, x5), hi_pair(x6, x7));
+    x0 = drop_hi(x0); x1 = drop_hi(x1); x2 = drop_hi(x2); x3 = drop_hi(x3);
+    x4 = drop_hi(x4); x5 = drop_hi(x5); x6 = drop_hi(x6); x7 = drop_hi(x7);
+    o.mid = make_uint4(hi_pair(x0, x1), hi_pair(x2, x3), hi_pair(x4, x5), hi_pair(x6, x7));
+    x0 = drop_hi(x0); x1 = drop_hi(x1); x2 = drop_hi(x2); x3 = drop_hi(x3);
+    x4 = drop_hi(x4); x5 = drop_hi(x5); x6 = drop_hi(x6); x7 = drop_hi(x7);
+    o.lo = make_uint4(hi_pair(x0, x1), hi_pair(x2, x3), hi_pair(x4, x5), hi_pair(x6, x7));
+    return o;
+}
+#define PN_BMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
+// acc += W(group G) · x for one K chunk: the six partial products.  The first MFMA of a chain (acc = literal 0) gets a freshly
+// allocated destination, and hipcc (ROCm 7.2) does not treat the destination of v_mfma_f32_32x32x16_bf16 as early-clobber: an A or
+// B operand that dies in that instruction may be given the same registers, and the hardware then reads sources it has already
+// begun to overwrite (observed: 16-sample blocks wrong by ~1e-2, run-to-run).  Leading with hi*hi, both of whose operands are
+// used again below, keeps every source of a first MFMA live and therefore disjoint from its destination.
+__device__ __forceinline__ f32x16 split_mac(const uint4* __restrict__ wl, int G, const Split8& x, f32x16 acc) {
+    const uint4 wh = wl[(G * 3 + 0) * 64], wm = wl[(G * 3 + 1) * 64], wo = wl[(G * 3 + 2) * 64];
+    acc = PN_BMFMA(wh, x.hi, acc);
+    acc = PN_BMFMA(wh, x.mid, acc);
+    acc = PN_BMFMA(wm, x.hi, acc);
+    acc = PN_BMFMA(wm, x.mid, acc);
+    acc = PN_BMFMA(wh, x.lo, acc);
+    acc = PN_BMFMA(wo, x.hi, acc);
+    return acc;
+}
+__device__ __forceinline__ Split8 split8_of(const f32x16& v, int r0) {
+    return split8(v[r0], v[r0 + 1], v[r0 + 2], v[r0 + 3], v[r0 + 4], v[r0 + 5], v[r0 + 6], v[r0 + 7]);
+}
+
+// Workgroup = 6 waves sharing the 61 KB LDS weight image: 2 workgroups per CU = 3 waves per SIMD.  MINW = waves per SIMD the
+// register allocator must leave room for; LU = how many hash levels' gathers are in flight per lane at once.
+#define PN_BF_WAVES 6
 template <int MINW, int LU>
-__global__ void __launch_bounds__(256, MINW) k_nerf_forward(const PnFusedLevel* __restrict__ lv, const float* __restrict__ emb, const float* __restrict__ wpack, float bound,
-                                                      const float* __restrict__ xyzs, const float* __restrict__ dirs, const int* __restrict__ list,
-                                                      const int* __restrict__ count_dev, uint32_t M_arg, float density_scale,
-                                                      float* __restrict__ sigmas, float* __restrict__ rgbs) {
-    extern __shared__ __attribute__((aligned(16))) float4 wlds[];  // [48][64] float4
+__global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const PnFusedLevel* __restrict__ lv, const float* __restrict__ emb,
+                                                                          const uint4* __restrict__ wsplit, float bound, const float* __restrict__ xyzs,
+                                                                          const float* __restrict__ dirs, const int* __restrict__ list,
+                                                                          const int* __restrict__ count_dev, uint32_t M_arg, float density_scale,
+                                                                          float* __restrict__ sigmas, float* __restrict__ rgbs) {
+    extern __shared__ __attribute__((aligned(16))) uint4 wimg[];  // PN_NET_SPLIT_BYTES
     const uint32_t M = count_dev ? (uint32_t)*count_dev : M_arg;
     const uint32_t n_tiles = (M + 31) / 32;
-    const uint32_t waves_total = gridDim.x * 4;
-    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blockIdx.x * 4 >= n_tiles) return;  // no tile for any wave of this block
-    {
-        const float4* __restrict__ src = reinterpret_cast<const float4*>(wpack);
-        for (int i = threadIdx.x; i < PN_NET_MFMAS * 16; i += 256) wlds[i] = src[i];
-    }
+    const uint32_t waves_total = gridDim.x * PN_BF_WAVES;
+    const uint32_t wave = blockIdx.x * PN_BF_WAVES + (threadIdx.x >> 6);
+    if (blockIdx.x * PN_BF_WAVES >= n_tiles) return;  // no tile for any wave of this block
+    for (int i = threadIdx.x; i < PN_NET_SPLIT_BYTES / 16; i += PN_BF_WAVES * 64) wimg[i] = wsplit[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int s = lane & 31, half = lane >> 5;
-    const float4* __restrict__ wl = wlds + lane;
+    const uint4* __restrict__ wl = wimg + lane;
 
     for (uint32_t tile = wave; tile < n_tiles; tile += waves_total) {
         const uint32_t li = tile * 32 + s;
@@ -365,56 +429,32 @@ __global__ void __launch_bounds__(256, MINW) k_nerf_forward(const PnFusedLevel* 
         const bool oob = (u0 < 0 || u0 > 1 || u1 < 0 || u1 > 1 || u2 < 0 || u2 > 1);
         float feat[16];
         encode8<LU>(lv, emb, half, oob ? 0.f : u0, oob ? 0.f : u1, oob ? 0.f : u2, oob, feat);
-
         __builtin_amdgcn_sched_barrier(0);  // keep the next layer's LDS weight reads from being hoisted (register pressure)
-        // ---- sigma net layer 0: 32 -> 64, ReLU
+        // ---- sigma net layer 0: 32 -> 64, ReLU   (groups 0..3 = tile*2 + chunk)
         f32x16 a0 = {0}, a1 = {0};
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const float4 w = wl[(0 + g) * 64];
-            a0 = PN_MFMA(w.x, feat[4 * g + 0], a0);
-            a0 = PN_MFMA(w.y, feat[4 * g + 1], a0);
-            a0 = PN_MFMA(w.z, feat[4 * g + 2], a0);
-            a0 = PN_MFMA(w.w, feat[4 * g + 3], a0);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const float4 w = wl[(4 + g) * 64];
-            a1 = PN_MFMA(w.x, feat[4 * g + 0], a1);
-            a1 = PN_MFMA(w.y, feat[4 * g + 1], a1);
-            a1 = PN_MFMA(w.z, feat[4 * g + 2], a1);
-            a1 = PN_MFMA(w.w, feat[4 * g + 3], a1);
+        for (int kc = 0; kc < 2; kc++) {
+            const Split8 b = split8(feat[8 * kc], feat[8 * kc + 1], feat[8 * kc + 2], feat[8 * kc + 3], feat[8 * kc + 4], feat[8 * kc + 5],
+                                    feat[8 * kc + 6], feat[8 * kc + 7]);
+            a0 = split_mac(wl, 0 + kc, b, a0);
+            a1 = split_mac(wl, 2 + kc, b, a1);
         }
         a0 = relu16(a0);
         a1 = relu16(a1);
-        __builtin_amdgcn_sched_barrier(0);  // keep the next layer's LDS weight reads from being hoisted (register pressure)
-        // ---- sigma net layer 1: 64 -> 16
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- sigma net layer 1: 64 -> 16   (groups 4..7)
         f32x16 h2 = {0};
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const float4 w = wl[(8 + g) * 64];
-            h2 = PN_MFMA(w.x, a0[4 * g + 0], h2);
-            h2 = PN_MFMA(w.y, a0[4 * g + 1], h2);
-            h2 = PN_MFMA(w.z, a0[4 * g + 2], h2);
-            h2 = PN_MFMA(w.w, a0[4 * g + 3], h2);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const float4 w = wl[(12 + g) * 64];
-            h2 = PN_MFMA(w.x, a1[4 * g + 0], h2);
-            h2 = PN_MFMA(w.y, a1[4 * g + 1], h2);
-            h2 = PN_MFMA(w.z, a1[4 * g + 2], h2);
-            h2 = PN_MFMA(w.w, a1[4 * g + 3], h2);
-        }
+        for (int kc = 0; kc < 4; kc++) h2 = split_mac(wl, 4 + kc, split8_of(kc < 2 ? a0 : a1, (kc & 1) * 8), h2);
         const float sigma_logit = h2[0];  // row 0 lives in the low half's register 0
-        __builtin_amdgcn_sched_barrier(0);  // keep the next layer's LDS weight reads from being hoisted (register pressure)
+        __builtin_amdgcn_sched_barrier(0);
         // ---- colour net input: 16 values per lane (see PN_MAPL / PN_MAPU)
         float sh[16];
         sh16(dx, dy, dz, sh);
         float v[16];
         // `half ? arr[i] : arr[j]` is rewritten by the compiler into arr[half ? i : j], a dynamic register index that it then lowers
-        // to a 16-way compare + v_cndmask chain (~200 VALU instructions per tile, in a kernel bound by ALU issue); the empty asm
-        // pins both operands in registers so that each select stays one v_cndmask
+        // to a 16-way compare + v_cndmask chain (~200 VALU instructions per tile); the empty asm pins both operands in registers
+        // so that each select stays one v_cndmask
         auto pick = [half](float a, float b) {
             asm volatile("" : "+v"(a), "+v"(b));
             return half ? a : b;
@@ -425,60 +465,36 @@ __global__ void __launch_bounds__(256, MINW) k_nerf_forward(const PnFusedLevel* 
 #pragma unroll
         for (int k = 8; k < 15; k++) v[k] = pick(sh[k + 1], sh[k - 7]);
         v[15] = pick(0.0f, sh[8]);
-        __builtin_amdgcn_sched_barrier(0);  // keep the next layer's LDS weight reads from being hoisted (register pressure)
-        // ---- colour layer 0: 31 -> 64, ReLU
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- colour layer 0: 31 -> 64, ReLU   (groups 8..11)
         f32x16 c0 = {0}, c1 = {0};
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const float4 w = wl[(16 + g) * 64];
-            c0 = PN_MFMA(w.x, v[4 * g + 0], c0);
-            c0 = PN_MFMA(w.y, v[4 * g + 1], c0);
-            c0 = PN_MFMA(w.z, v[4 * g + 2], c0);
-            c0 = PN_MFMA(w.w, v[4 * g + 3], c0);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const float4 w = wl[(20 + g) * 64];
-            c1 = PN_MFMA(w.x, v[4 * g + 0], c1);
-            c1 = PN_MFMA(w.y, v[4 * g + 1], c1);
-            c1 = PN_MFMA(w.z, v[4 * g + 2], c1);
-            c1 = PN_MFMA(w.w, v[4 * g + 3], c1);
+        for (int kc = 0; kc < 2; kc++) {
+            const Split8 b = split8(v[8 * kc], v[8 * kc + 1], v[8 * kc + 2], v[8 * kc + 3], v[8 * kc + 4], v[8 * kc + 5], v[8 * kc + 6], v[8 * kc + 7]);
+            c0 = split_mac(wl, 8 + kc, b, c0);
+            c1 = split_mac(wl, 10 + kc, b, c1);
         }
         c0 = relu16(c0);
         c1 = relu16(c1);
-        __builtin_amdgcn_sched_barrier(0);  // keep the next layer's LDS weight reads from being hoisted (register pressure)
-        // ---- colour layer 1: 64 -> 64, ReLU
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- colour layer 1: 64 -> 64, ReLU   (groups 12..19 = tile*4 + chunk)
         f32x16 d0 = {0}, d1 = {0};
 #pragma unroll
-        for (int t2 = 0; t2 < 2; t2++) {
-#pragma unroll
-            for (int g = 0; g < 8; g++) {
-                const float4 w = wl[(24 + t2 * 8 + g) * 64];
-                const f32x16& src = (g < 4) ? c0 : c1;
-                const int r = (g & 3) * 4;
-                if (t2 == 0) {
-                    d0 = PN_MFMA(w.x, src[r + 0], d0);
-                    d0 = PN_MFMA(w.y, src[r + 1], d0);
-                    d0 = PN_MFMA(w.z, src[r + 2], d0);
-                    d0 = PN_MFMA(w.w, src[r + 3], d0);
-                } else {
-                    d1 = PN_MFMA(w.x, src[r + 0], d1);
-                    d1 = PN_MFMA(w.y, src[r + 1], d1);
-                    d1 = PN_MFMA(w.z, src[r + 2], d1);
-                    d1 = PN_MFMA(w.w, src[r + 3], d1);
-                }
-            }
+        for (int kc = 0; kc < 4; kc++) {
+            const Split8 b = split8_of(kc < 2 ? c0 : c1, (kc & 1) * 8);
+            d0 = split_mac(wl, 12 + kc, b, d0);
+            d1 = split_mac(wl, 16 + kc, b, d1);
         }
         d0 = relu16(d0);
         d1 = relu16(d1);
-        __builtin_amdgcn_sched_barrier(0);  // keep the next layer's LDS weight reads from being hoisted (register pressure)
+        __builtin_amdgcn_sched_barrier(0);
         // ---- colour layer 2: 64 -> 3 on the vector ALU: this lane holds 32 of the 64 hidden values of its sample (D layout), its
         // partner lane (l ^ 32) the other 32; 3 x 32 FMAs with broadcast LDS weights, then one cross-half add per output
         float e[3] = {0.f, 0.f, 0.f};
         {
-            const float* __restrict__ wlast = reinterpret_cast<const float*>(wlds) + PN_NET_VALU_OFF + half * 96;
+            const float* __restrict__ wlast = reinterpret_cast<const float*>(wimg) + PN_NET_SPLIT_W_BYTES / 4 + half * 96;
 #pragma unroll
-            for (int q4 = 0; q4 < 8; q4++) {  // 4 hidden values x 3 outputs = 12 weights = 3 ds_read_b128
+            for (int q4 = 0; q4 < 8; q4++) {
                 const float4 wa = *reinterpret_cast<const float4*>(wlast + q4 * 12);
                 const float4 wb = *reinterpret_cast<const float4*>(wlast + q4 * 12 + 4);
                 const float4 wc = *reinterpret_cast<const float4*>(wlast + q4 * 12 + 8);
@@ -505,25 +521,12 @@ int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* di
                            float density_scale, float* sigmas, float* rgbs, hipStream_t stream) {
     if (M_max == 0) return PN_OK;
     const uint32_t tiles = pn_div_up(M_max, 32);
-    uint32_t blocks = pn_div_up(tiles, 4);
-    static const uint32_t max_blocks = pn_env_u32("PN_NERF_BLOCKS", 768);  // 3 workgroups per CU (48 KB LDS each) x 256 CUs; waves stride over tiles
+    static const uint32_t max_blocks = pn_env_u32("PN_NERF_BLOCKS", 512);  // 2 workgroups per CU x 256 CUs; waves stride over tiles
+    uint32_t blocks = pn_div_up(tiles, PN_BF_WAVES);
     if (blocks > max_blocks) blocks = max_blocks;
-    const size_t lds = sizeof(float) * PN_NET_MFMAS * 64;
-    static int variant = -1;
-    if (variant < 0) { const char* e = getenv("PN_NERF_VARIANT"); variant = e ? atoi(e) : 0; }
-#define PN_NF_LAUNCH(MINW, LU) k_nerf_forward<MINW, LU><<<blocks, 256, lds, stream>>>((const PnFusedLevel*)net->fused_levels, net->embeddings, net->wpack, net->bound, xyzs, dirs, \
-                                                                                       list, ctl_count, M_max, density_scale, sigmas, rgbs)
-    switch (variant) {
-        case 1: PN_NF_LAUNCH(1, 8); break;
-        case 2: PN_NF_LAUNCH(2, 8); break;
-        case 3: PN_NF_LAUNCH(2, 4); break;
-        case 4: PN_NF_LAUNCH(3, 4); break;
-        case 5: PN_NF_LAUNCH(3, 2); break;
-        case 6: PN_NF_LAUNCH(4, 2); break;
-        case 7: PN_NF_LAUNCH(4, 1); break;
-        default: PN_NF_LAUNCH(2, 4); break;
-    }
-#undef PN_NF_LAUNCH
+    k_nerf_forward<2, 4><<<blocks, PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES, stream>>>((const PnFusedLevel*)net->fused_levels, net->embeddings,
+                                                                                  (const uint4*)net->wsplit, net->bound, xyzs, dirs, list, ctl_count,
+                                                                                  M_max, density_scale, sigmas, rgbs);
     PN_LAUNCH_CHECK();
     return PN_OK;
 }

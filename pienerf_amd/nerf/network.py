@@ -1,6 +1,6 @@
 """NeRFNetwork with the reference's constructor, state-dict keys and forward (nerf/network.py:14-127).
 
-``forward(x, d)`` runs the fused HIP kernel (hash grid + SH + both MLPs on f32 MFMA); ``forward_ops`` is the same
+``forward(x, d)`` runs the fused HIP kernel (hash grid + SH + both MLPs on the matrix cores, bf16 three-way split at fp32 accuracy); ``forward_ops`` is the same
 computation op by op (grid_encode -> torch Linear -> sh_encode -> ...) like the reference, kept for parity tests.
 """
 import ctypes as C

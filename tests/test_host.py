@@ -30,6 +30,46 @@ def test_library_exports_every_declared_symbol():
     assert h.pn_compact_scratch_ints(1000) >= 4 and h.pn_sim_work_doubles(10, 20) >= 10 * 30 * 4
 
 
+def test_no_mfma_overwrites_its_own_sources(tmp_path):
+    """hipcc (ROCm 7.2) does not mark the destination of v_mfma_f32_32x32x16_bf16 early-clobber; when a source dies in the first MFMA
+    of an accumulator chain the allocator may hand its registers to the destination, and on gfx950 that corrupts 16-lane blocks
+    run to run (pn_nerf_forward.hip, split_mac).  Disassemble the shipped device code and check no MFMA has such an overlap."""
+    import shutil
+    import subprocess
+    from pienerf_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    so = tmp_path / "lib.so"
+    shutil.copy(_lib.LIB_PATH, so)
+    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, capture_output=True)
+    images = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert images
+    pat = re.compile(r"v_mfma\S*\s+[av]\[(\d+):(\d+)\], ([av]\[\d+:\d+\]|[av]\d+), ([av]\[\d+:\d+\]|[av]\d+),")
+    n = 0
+
+    def span(tok):
+        m = re.match(r"[av]\[(\d+):(\d+)\]", tok)
+        if m:
+            return int(m.group(1)), int(m.group(2))
+        r = int(tok[1:])
+        return r, r
+    for img in images:
+        dis = subprocess.run([objdump, "-d", str(tmp_path / img)], check=True, capture_output=True, text=True).stdout
+        for line in dis.splitlines():
+            m = pat.search(line)
+            if not m:
+                continue
+            n += 1
+            d0, d1 = int(m.group(1)), int(m.group(2))
+            for tok in (m.group(3), m.group(4)):
+                if tok[0] != line[m.start(1) - 2]:  # VGPR vs AGPR files do not alias
+                    continue
+                s0, s1 = span(tok)
+                assert s1 < d0 or s0 > d1, line.strip()
+    assert n >= 120  # the fused network kernel alone carries 120
+
+
 def test_ops_fail_loudly_without_gpu_tensors():
     from pienerf_amd import gridencoder, raymarching, shencoder
     with pytest.raises(RuntimeError, match="GPU only"):
