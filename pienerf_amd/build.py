@@ -16,8 +16,14 @@ OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libpienerf_hip.so")
 ARCH = "gfx950"
 
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function",
-          "-Wno-unused-variable"]
+# -fno-slp-vectorize: no packed-fp32 VALU (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) anywhere in the library.  On gfx950 a wave
+# issuing them while ANOTHER wave of the same SIMD has a v_mfma_f32_32x32x16_bf16 in flight corrupts columns 16..31 of that MFMA's
+# result (measured: 16-sample blocks of the network output off by ~1e-2, run to run; inputs, LDS operands and split pieces verified
+# bit-stable, isolating the MFMA groups with barriers and 64-cycle s_nop changes nothing, removing the packed ops removes every
+# error in 300 x 1M-sample launches — DESIGN.md 4.2).  Every kernel here can be co-resident with the network kernel (render lanes,
+# simulator stream), so the flag is library-wide; tests/test_host.py checks the shipped ISA for it.
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-Wall",
+          "-Wno-unused-function", "-Wno-unused-variable"]
 # per-translation-unit flags: the ray-side kernels round every operation once, in source order (bit-exact integer
 # decisions vs the CPU oracle); the encoder/MLP and the fp64 simulator let the compiler contract to FMA.
 UNITS = {

@@ -112,6 +112,19 @@ def _init_GMLS_chunk(r, pos, topo, kernel_pos):
     return Nx, dNx, ddNx
 
 
+def index_add_ordered(dst, index, src):
+    """dst.index_add_(0, index, src) with a summation order that does not depend on the race of fp64 atomics (torch's sort-based
+    path), so that two initialisations of the same scene produce bit-identical matrices (the reference's Warp kernels add in race
+    order, cuda_utils.py:22-81; an initialisation-time cost only)."""
+    prev, warn = torch.are_deterministic_algorithms_enabled(), torch.is_deterministic_algorithms_warn_only_enabled()
+    torch.use_deterministic_algorithms(True)
+    try:
+        dst.index_add_(0, index, src)
+    finally:
+        torch.use_deterministic_algorithms(prev, warn_only=warn)
+    return dst
+
+
 def assemble_IP_matrix(dim, dx, dt, topo, mu, lam, rho, Nx, dNx, ddNx, chunk=512):
     """System matrix [dim,dim] (dim = 10 n_k) of build_IP_global (cuda_utils.py:22-55): per IP the 80x80 block
     Z^T diag(c) Z with Z = [N; dN_p; ddN_pq] (13 x 80)."""
@@ -130,7 +143,7 @@ def assemble_IP_matrix(dim, dx, dt, topo, mu, lam, rho, Nx, dNx, ddNx, chunk=512
         blocks = torch.einsum("vr,vra,vrb->vab", coef, Z, Z)                                            # [m,80,80]
         rows = (topo[sl].long()[:, :, None] * 10 + ar10[None, None, :]).reshape(m, 80)
         flat = rows[:, :, None] * dim + rows[:, None, :]
-        mat.index_add_(0, flat.reshape(-1), blocks.reshape(-1))
+        index_add_ordered(mat, flat.reshape(-1), blocks.reshape(-1))
     return mat.view(dim, dim)
 
 
@@ -143,7 +156,7 @@ def add_pin_penalty(mat, stiff, pin_ids, pts_topo, pts_Nx):
     nv = pts_Nx[pin_ids].reshape(-1, 80)
     rows = (pts_topo[pin_ids].long()[:, :, None] * 10 + torch.arange(10, device=dev)[None, None, :]).reshape(-1, 80)
     flat = rows[:, :, None] * dim + rows[:, None, :]
-    mat.view(-1).index_add_(0, flat.reshape(-1), (stiff * nv[:, :, None] * nv[:, None, :]).reshape(-1))
+    index_add_ordered(mat.view(-1), flat.reshape(-1), (stiff * nv[:, :, None] * nv[:, None, :]).reshape(-1))
     return mat
 
 

@@ -130,15 +130,15 @@ class Simulator:
         m = (self.IP_rho * self.dx * self.dx * self.dx)                                      # collect_gravity, cuda_utils.py:262-279
         rg = torch.zeros((n_k * 10, 3), dtype=torchfloat, device=dev)
         rows = (self.IP_kernel.long()[:, :, None] * 10 + torch.arange(10, device=dev)[None, None, :]).reshape(-1)
-        rg.index_add_(0, rows, (m[:, None, None] * self.IP_Nx).reshape(-1)[:, None] * self.gravity[None, :])
+        gmls.index_add_ordered(rg, rows, (m[:, None, None] * self.IP_Nx).reshape(-1)[:, None] * self.gravity[None, :])
         self.rhs_gravity = rg.reshape(-1).contiguous()
 
     def collect_IP(self):  # solver.py:427-450
         n_IP, idx = self.n_IP, self.pts_IP.long()
         z = torch.zeros(n_IP, dtype=torchfloat, device=self.device)
-        s_mu = z.clone().index_add_(0, idx, self.mu * self.mass)
-        s_lam = z.clone().index_add_(0, idx, self.lam * self.mass)
-        s_m = z.clone().index_add_(0, idx, self.mass)
+        s_mu = gmls.index_add_ordered(z.clone(), idx, self.mu * self.mass)
+        s_lam = gmls.index_add_ordered(z.clone(), idx, self.lam * self.mass)
+        s_m = gmls.index_add_ordered(z.clone(), idx, self.mass)
         return (s_mu / s_m).contiguous(), (s_lam / s_m).contiguous(), (s_m / (self.dx ** 3)).contiguous()
 
     def build_global(self):  # solver.py:453-538

@@ -208,6 +208,23 @@ def test_nerf_forward_fused_vs_oracle_and_ops(ckpt):
     assert 20 < np.median(s_ref) < 200  # the synthetic checkpoint's density calibration
 
 
+def test_nerf_forward_is_bit_reproducible(ckpt):
+    """The same launch repeated gives the same bits (guards the gfx950 packed-fp32-VALU x bf16-MFMA corruption, DESIGN.md 4.2:
+    with v_pk_*_f32 in the kernel, 16-sample blocks of ~20 % of 1M-sample launches came out ~1e-2 off)."""
+    from pienerf_amd.nerf.network import NeRFNetwork
+    rng = np.random.default_rng(11)
+    M = 600_001
+    x = T((rng.random((M, 3)).astype(np.float32) * 2 - 1) * 0.9)
+    d = rng.standard_normal((M, 3)).astype(np.float32)
+    d = T(d / np.linalg.norm(d, axis=-1, keepdims=True))
+    net = NeRFNetwork(encoding="hashgrid", bound=1.0, cuda_ray=True).to(DEV).load_checkpoint_dict(ckpt)
+    with torch.no_grad():
+        s0, c0 = net(x, d)
+        for _ in range(40):
+            s, c = net(x, d)
+            assert torch.equal(s, s0) and torch.equal(c, c0)
+
+
 # ------------------------------------------------------------------------------------------------ composite / compaction
 def test_composite_and_compaction(ckpt):
     from pienerf_amd import raymarching

@@ -70,6 +70,27 @@ def test_no_mfma_overwrites_its_own_sources(tmp_path):
     assert n >= 120  # the fused network kernel alone carries 120
 
 
+def test_no_packed_fp32_valu_in_shipped_code(tmp_path):
+    """Packed-fp32 VALU instructions issued by one wave corrupt a v_mfma_f32_32x32x16_bf16 another wave of the same SIMD has in
+    flight (gfx950, measured — pienerf_amd/build.py); every kernel of the library can be co-resident with the
+    network kernel, so none may contain them (-fno-slp-vectorize)."""
+    import shutil
+    import subprocess
+    from pienerf_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    so = tmp_path / "lib.so"
+    shutil.copy(_lib.LIB_PATH, so)
+    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, capture_output=True)
+    images = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert images
+    for img in images:
+        dis = subprocess.run([objdump, "-d", str(tmp_path / img)], check=True, capture_output=True, text=True).stdout
+        bad = [ln.strip() for ln in dis.splitlines() if re.search(r"\bv_pk_(mul|add|fma)_f32\b", ln)]
+        assert not bad, bad[:5]
+
+
 def test_ops_fail_loudly_without_gpu_tensors():
     from pienerf_amd import gridencoder, raymarching, shencoder
     with pytest.raises(RuntimeError, match="GPU only"):
