@@ -377,9 +377,10 @@ __device__ __forceinline__ Split8 split8(float x0, float x1, float x2, float x3,
 
 // acc += W(group G) · x for one K chunk: the six partial products.  The first MFMA of a chain (acc = literal 0) gets a freshly
 // allocated destination, and hipcc (ROCm 7.2) does not treat the destination of v_mfma_f32_32x32x16_bf16 as early-clobber: an A or
-// B operand that dies in that instruction may be given the same registers, and the hardware then reads sources it has already
-// begun to overwrite (observed: 16-sample blocks wrong by ~1e-2, run-to-run).  Leading with hi*hi, both of whose operands are
-// used again below, keeps every source of a first MFMA live and therefore disjoint from its destination.
+// B operand that dies in that instruction may be given the same registers (seen in the ISA of an earlier ordering).  Leading with
+// hi*hi, both of whose operands are used again below, keeps every source of a first MFMA live and therefore disjoint from its
+// destination; tests/test_host.py scans the shipped ISA for such overlaps.  (The run-to-run corruption first blamed on this turned
+// out to come from packed-fp32 VALU of co-resident waves — see build.py; the ordering stays as a precaution.)
 __device__ __forceinline__ f32x16 split_mac(const uint4* __restrict__ wl, int G, const Split8& x, f32x16 acc) {
     const uint4 wh = wl[(G * 3 + 0) * 64], wm = wl[(G * 3 + 1) * 64], wo = wl[(G * 3 + 2) * 64];
     acc = PN_BMFMA(wh, x.hi, acc);

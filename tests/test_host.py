@@ -32,8 +32,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_no_mfma_overwrites_its_own_sources(tmp_path):
     """hipcc (ROCm 7.2) does not mark the destination of v_mfma_f32_32x32x16_bf16 early-clobber; when a source dies in the first MFMA
-    of an accumulator chain the allocator may hand its registers to the destination, and on gfx950 that corrupts 16-lane blocks
-    run to run (pn_nerf_forward.hip, split_mac).  Disassemble the shipped device code and check no MFMA has such an overlap."""
+    of an accumulator chain the allocator may hand its registers to the destination (pn_nerf_forward.hip, split_mac orders the
+    products so that it cannot).  Precaution: disassemble the shipped device code and check no MFMA has such an overlap."""
     import shutil
     import subprocess
     from pienerf_amd import _lib
