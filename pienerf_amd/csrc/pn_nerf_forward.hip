@@ -395,9 +395,10 @@ __device__ __forceinline__ Split8 split8_of(const f32x16& v, int r0) {
     return split8(v[r0], v[r0 + 1], v[r0 + 2], v[r0 + 3], v[r0 + 4], v[r0 + 5], v[r0 + 6], v[r0 + 7]);
 }
 
-// Workgroup = 6 waves sharing the 61 KB LDS weight image: 2 workgroups per CU = 3 waves per SIMD.  MINW = waves per SIMD the
-// register allocator must leave room for; LU = how many hash levels' gathers are in flight per lane at once.
-#define PN_BF_WAVES 6
+// Workgroup = 4 waves sharing the 61 KB LDS weight image: 2 workgroups per CU = 2 waves per SIMD (measured: 5 or 6 waves per
+// workgroup are no faster stand-alone and slower beside the other render lanes' march kernels, which want the wave slots).
+// MINW = waves per SIMD the register allocator must leave room for; LU = how many hash levels' gathers are in flight per lane.
+#define PN_BF_WAVES 4
 template <int MINW, int LU>
 __global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const PnFusedLevel* __restrict__ lv, const float* __restrict__ emb,
                                                                           const uint4* __restrict__ wsplit, float bound, const float* __restrict__ xyzs,
