@@ -149,17 +149,19 @@ def kernel_report(h, opt, dev):
     if os.path.exists(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)
-        for kname in ("k_nerf_forward", "k_march"):
+        for kname in ("k_nerf_forward", "k_march", "k_march_tail", "k_march_skip"):
             pm = pmc.get(kname)
-            if pm:
+            if pm:  # bytes per FRAME of this kernel / real trips per frame
                 frames = pm["dispatches"] / float(pm.get("enqueued_trips_per_frame", 8))
                 traffic[kname] = int((pm["fetch_kb_per_launch"] + pm["write_kb_per_launch"]) * 1024 * pm["dispatches"] / (frames * pm["real_trips_per_frame"]))
+        if all(k in traffic for k in ("k_march", "k_march_tail", "k_march_skip")):  # one launch group = one trip; the skip pre-pass runs once per frame
+            traffic["march_group"] = traffic["k_march"] + traffic["k_march_tail"] + traffic["k_march_skip"] // real
     # dominant kernel = the fused network kernel (largest single-kernel share of the step's GPU time, profiles/README.md): its launches in
     # the render loop, HIP events on the launch stream around each of them (pn_frame_trip_times)
     net_loop_ms = float(net_ms[:real].sum())
     net_loop_gbs = FUSED_BYTES_PER_SAMPLE * st["samples"] / (net_loop_ms * 1e-3) / 1e9
     net_loop_tf = MLP_FLOP_PER_SAMPLE * st["samples"] / (net_loop_ms * 1e-3) / 1e12
-    roofline = {
+    network = {
         "kernel": "k_nerf_forward<2,4> (hash-grid gather + SH + 5-layer MLP fused; dense layers as three-way bf16-split MFMA at fp32 accuracy), "
                   "launches inside the render loop",
         # cutting the matrix time by 2.7x (f32-input MFMA -> bf16 split) left the stand-alone kernel time unchanged, the
@@ -179,12 +181,26 @@ def kernel_report(h, opt, dev):
         "note": "achieved = 1 068 algorithmic bytes per sample (16 levels x 8 corners x 8 B gathered + 4 B slot id + 24 B xyz/dir in + 16 B sigma/rgb "
                 "out) x samples of the launch / HIP-event time of the launch; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md)",
     }
+    # dominant kernel = the ray march (k_march 19.4 % + k_march_tail 18.5 % + k_march_skip 4.4 % of the step's GPU time in
+    # profiles/r01_final_kernel_stats.csv; the network kernel is 15.8 %): one algorithm in two passes per trip plus the trip-0 pre-pass,
+    # timed as one launch group by HIP events on the launch stream (pn_frame_trip_times)
+    roofline = {
+        "kernel": "ray march + inverse-GMLS warp: k_march<3,false> + k_march_tail<3,false> per loop trip (+ k_march_skip on trip 0), one launch group",
+        "bound": "hbm", "achieved": round(march_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(march_gbs / HBM_PEAK_GBS, 4),
+        "traffic": traffic.get("march_group"),
+        "traffic_note": "HBM bytes per launch group, FETCH_SIZE+WRITE_SIZE PMC passes (profiles/pmc_traffic.json): far below the algorithmic bytes "
+                        "because the candidate lists and IP records (~1 MB per frame) are re-read from L2",
+        "launch_ms": round(march_launch, 4), "launches_per_frame": real, "ms_per_frame": round(march_total, 4),
+        "launch_ms_incl_empty_trips": round(float(march_ms.mean()), 4), "launches_enqueued_per_frame": int(len(march_ms)),
+        "units_per_frame": cnt, "algorithmic_bytes_per_frame": int(march_bytes), "algorithmic_bytes_per_launch": int(march_bytes / real),
+        "bytes_per_unit": MARCH_BYTES,
+        "note": "achieved = algorithmic bytes (8 B per marched ray point, 16 B per candidate-list entry, 64 B per warped IP record head, 36 B per "
+                "emitted sample, 40 B of ray state per ray and trip) / HIP-event time of the launch group.  The kernel is a divergent pointer chase "
+                "over cache-resident tables: latency-bound, not a streaming kernel, so the HBM roofline is an upper bound it cannot approach "
+                "(DESIGN.md 4.1)",
+    }
     extra = {
-        "march": {"kernels": "k_march_skip + k_march<3,false> + k_march_tail<3,false> per loop trip (ray march + inverse-GMLS warp)",
-                  "ms_per_frame": round(march_total, 4), "launch_group_ms": round(march_launch, 4), "trips_per_frame": real,
-                  "units_per_frame": cnt, "algorithmic_bytes_per_frame": int(march_bytes), "achieved_GBps": round(march_gbs, 1),
-                  "frac_of_hbm_peak": round(march_gbs / HBM_PEAK_GBS, 5), "traffic_bytes_per_launch": traffic.get("k_march"),
-                  "note": "latency/divergence-bound pointer chase over ~1 MB of cache-resident tables, not a streaming kernel (DESIGN.md 4.1)"},
+        "network": network,
         "hash_lookup": {"kernel": "k_grid_encode<2> (stand-alone hash-grid lookup, output [L,B,C] like the reference kernel)",
                         "achieved_GBps": round(grid_gbs, 1), "frac_of_hbm_peak": round(grid_gbs / HBM_PEAK_GBS, 4), "launch_ms": round(t_grid, 4),
                         "bytes_per_sample": HASH_BYTES_PER_SAMPLE, "launch_ms_direct_BLC_output": round(t_grid_bl, 4)},
