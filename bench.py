@@ -224,6 +224,8 @@ def main():
                          "compute pipes of an XCD, more streams only time-slice)")
     ap.add_argument("--single-graph", action="store_true", help="whole step as ONE captured graph (sim on a forked stream), one frame at a time")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--force", type=float, nargs=3, default=None, metavar=("FX", "FY", "FZ"),
+                    help="constant update_force on the middle integration point (SURVEY 8d, config 2 second pass); default: gravity only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -252,6 +254,8 @@ def main():
     cloud = scene.make_chair_points(hgs=opt["hash_grid_size"])
     ckpt = scene.make_checkpoint(bound=opt["bound"], seed=0)
     h = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device=dev)
+    if args.force is not None and (world == 1 or rank == 0):  # Simulator.update_force (solver.py:578-588): the dragged-point load of the GUI
+        h.sim.update_force(h.sim.n_IP // 2, np.asarray(args.force, dtype=np.float64))
 
     def barrier():
         if world > 1:
@@ -309,7 +313,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 render / f64 sim", "data": "synthetic",
             "config": {"workload": "configs[1]: synthetic chair 800x800, sim_dx=0.05, sim_iters=10, num_seek_IP=3, max_iter_num=1, fp32, "
-                                   "1 sim+render step per frame", "rays": opt["W"] * opt["H"], "n_IP": h.sim.n_IP, "n_kernels": h.sim.n_k,
+                                   "1 sim+render step per frame" + (f", constant force {args.force} on IP {h.sim.n_IP // 2}" if args.force is not None else ", gravity only"),
+                       "rays": opt["W"] * opt["H"], "n_IP": h.sim.n_IP, "n_kernels": h.sim.n_k,
                        "samples_per_frame": st["samples"], "trips_per_frame": st["trips"],
                        "launch": "eager" if (args.eager and world == 1) else (f"one hip graph per step, {args.trips} trips" if args.single_graph else
                                                                                    f"hip graphs, {args.trips} trips, {args.lanes} render(s) in flight, simulator running ahead"),

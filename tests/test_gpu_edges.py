@@ -96,6 +96,33 @@ def test_frame_in_cut_mode(deformed_ip_state, small_opt, ckpt, num_seek_IP):
     assert np.abs(out["weights_sum"].cpu().numpy() - ref["weights_sum"]).max() < 1e-4
 
 
+def test_frame_in_trex_configuration(deformed_ip_state):
+    """The option set of BASELINE config 3 (README.md:134 of the reference) at test size: bound 2 -> two density cascades and the
+    4096-resolution hash grid, dt_gamma = 1/128 (step length grows along the ray), --cut with cut_bounds (static background rendered
+    un-warped, spatial hash over +-bound), max_steps 300, T_thresh 5e-2, num_seek_IP 1, a 4:3 image."""
+    from pienerf_amd.nerf.network import NeRFNetwork
+    ck = scene.make_checkpoint(bound=2.0, seed=3)
+    assert ck["cascade"] == 2
+    W, H = 84, 63
+    opt = scene.default_opt(bound=2.0, scale=0.33, dt_gamma=1.0 / 128, max_steps=300, T_thresh=5e-2, num_seek_IP=1, max_iter_num=1, cut=True,
+                            cut_bounds=[-0.62, 1.0, -0.82, 0.42, -0.52, 0.28], sim_dx=0.1, W=W, H=H)
+    pose = scene.orbit_pose(4.5, 25.0, -10.0)
+    o, d = oracle.get_rays(pose, scene.orbit_intrinsics(W, H, 50.0), W, H)
+    ref = oracle.render_deformed(o, d, deformed_ip_state, ck, opt)
+    ip = deformed_ip_state
+    net = NeRFNetwork(encoding="hashgrid", bound=2.0, cuda_ray=True).to(DEV).load_checkpoint_dict(ck)
+    net.p_def, net.p_ori, net.IP_F, net.IP_dF, net.IP_dx = T(ip["p_def"]), T(ip["p_ori"]), T(ip["F"]), T(ip["dF"]), ip["IP_dx"]
+    with torch.no_grad():
+        out = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **opt)
+    st = dict(net.last_stats)
+    assert ref["samples"] > 1000 and ref["trips"] >= 2
+    assert st["trips"] == ref["trips"] and st["samples"] == ref["samples"] and st["err"] == 0 and st["alive_at_exit"] == 0
+    assert np.abs(out["image"][0].cpu().numpy() - ref["image"]).max() < 1e-4
+    assert np.abs(out["weights_sum"].cpu().numpy() - ref["weights_sum"]).max() < 1e-4
+    dep, rd = out["depth"][0].cpu().numpy(), ref["depth"]
+    assert np.array_equal(np.isfinite(dep), np.isfinite(rd)) and np.abs(dep[np.isfinite(dep)] - rd[np.isfinite(rd)]).max() < 1e-4
+
+
 @pytest.mark.parametrize("num_seek_IP,max_iter_num,n_step,rounds", [(3, 1, 8, 1), (3, 1, 8, 1000), (2, 4, 64, 1), (1, 1, 64, 1), (3, 2, 200, 2)])
 def test_march_split_between_the_two_launches_does_not_matter(deformed_ip_state, small_opt, ckpt, tail_rounds, num_seek_IP, max_iter_num, n_step,
                                                              rounds):
