@@ -282,6 +282,9 @@ def main():
         from pienerf_amd.frames import broadcast_tensors
         m = h.model
         broadcast_tensors([m.encoder.embeddings.data, m.density_bitfield] + [l.weight.data for l in list(m.sigma_net) + list(m.color_net)], src=0)
+        # ROCm time-slices badly once more than 4 hardware queues are busy (launch structure): with the simulator stream
+        # and the RCCL communication stream that leaves 2 render lanes per rank; a rank renders only every world-th frame anyway
+        args.lanes = min(args.lanes, 2)
         h.capture_frame_parallel(lanes=args.lanes, n_trips=args.trips)
 
         def run_steps(n):
