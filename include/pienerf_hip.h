@@ -113,6 +113,9 @@ void pn_net_destroy(pn_net* net);
 /* sigmas[M], rgbs[M,3] for xyzs[M,3] in [-bound,bound], dirs[M,3] unit.  density_scale multiplies sigma (renderer.py:875). */
 int pn_nerf_forward(const pn_net* net, const float* xyzs, const float* dirs, uint32_t M, float density_scale, float* sigmas, float* rgbs,
                     void* stream);
+/* NeRFNetwork.density (nerf/network.py:129-146): sigma = trunc_exp(h[0]) (no density_scale), geo_feat = h[1:16]; the same fused
+ * kernel stopped after the sigma net.  Used off the hot path (point sampling, main_sample.py:164-168).  sigmas [M], geo_feat [M,15]. */
+int pn_nerf_density(const pn_net* net, const float* xyzs, uint32_t M, float* sigmas, float* geo_feat, void* stream);
 
 /* ------------------------------------------------------------------ whole frame ---- */
 

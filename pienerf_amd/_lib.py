@@ -41,6 +41,7 @@ SIGNATURES = {
     "pn_net_create": (i32, [C.POINTER(P), P, P, u32, u32, f32, u32, f32, P, P, P, P, P, P]),
     "pn_net_destroy": (None, [P]),
     "pn_nerf_forward": (i32, [P, P, P, u32, f32, P, P, P]),
+    "pn_nerf_density": (i32, [P, P, u32, P, P, P]),
     "pn_frame_create": (i32, [C.POINTER(P), u32, u32, u32]),
     "pn_frame_destroy": (None, [P]),
     "pn_render_deformed": (i32, [P, P, C.POINTER(RenderOpts), P, P, u32, P, P, P, P, i32, P, P, P, P, P, P, P]),

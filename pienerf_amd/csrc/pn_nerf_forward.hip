@@ -404,7 +404,8 @@ __global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const P
                                                                           const uint4* __restrict__ wsplit, float bound, const float* __restrict__ xyzs,
                                                                           const float* __restrict__ dirs, const int* __restrict__ list,
                                                                           const int* __restrict__ count_dev, uint32_t M_arg, float density_scale,
-                                                                          float* __restrict__ sigmas, float* __restrict__ rgbs) {
+                                                                          float* __restrict__ sigmas, float* __restrict__ rgbs,
+                                                                          float* __restrict__ geo) {
     extern __shared__ __attribute__((aligned(16))) uint4 wimg[];  // PN_NET_SPLIT_BYTES
     const uint32_t M = count_dev ? (uint32_t)*count_dev : M_arg;
     const uint32_t n_tiles = (M + 31) / 32;
@@ -449,6 +450,18 @@ __global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const P
 #pragma unroll
         for (int kc = 0; kc < 4; kc++) h2 = split_mac(wl, 4 + kc, split8_of(kc < 2 ? a0 : a1, (kc & 1) * 8), h2);
         const float sigma_logit = h2[0];  // row 0 lives in the low half's register 0
+        if (geo) {  // NeRFNetwork.density (network.py:129-146): sigma = exp(h[0]), geo_feat = h[1:16]; no colour net (kernel-uniform)
+            if (valid) {
+                if (half == 0) sigmas[slot] = density_scale * expf(sigma_logit);
+                float* __restrict__ g = geo + (size_t)slot * 15;
+#pragma unroll
+                for (int r = 0; r < 8; r++) {  // this lane's rows (r&3) + 8*(r>>2) + 4*half of the 16 outputs
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row >= 1) g[row - 1] = h2[r];
+                }
+            }
+            continue;
+        }
         __builtin_amdgcn_sched_barrier(0);
         // ---- colour net input: 16 values per lane (see PN_MAPL / PN_MAPU)
         float sh[16];
@@ -528,7 +541,21 @@ int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* di
     if (blocks > max_blocks) blocks = max_blocks;
     k_nerf_forward<2, 4><<<blocks, PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES, stream>>>((const PnFusedLevel*)net->fused_levels, net->embeddings,
                                                                                   (const uint4*)net->wsplit, net->bound, xyzs, dirs, list, ctl_count,
-                                                                                  M_max, density_scale, sigmas, rgbs);
+                                                                                  M_max, density_scale, sigmas, rgbs, nullptr);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+extern "C" int pn_nerf_density(const pn_net* net, const float* xyzs, uint32_t M, float* sigmas, float* geo_feat, void* stream) {
+    if (M == 0) return PN_OK;  // empty tensors have null data pointers
+    PN_REQUIRE(net && xyzs && sigmas && geo_feat);
+    const uint32_t tiles = pn_div_up(M, 32);
+    uint32_t blocks = pn_div_up(tiles, PN_BF_WAVES);
+    if (blocks > 512) blocks = 512;
+    // dirs is only read by the colour net, which this mode never reaches: any readable buffer of >= 3 M floats will do
+    k_nerf_forward<2, 4><<<blocks, PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES, (hipStream_t)stream>>>((const PnFusedLevel*)net->fused_levels, net->embeddings,
+                                                                                               (const uint4*)net->wsplit, net->bound, xyzs, xyzs, nullptr,
+                                                                                               nullptr, M, 1.0f, sigmas, nullptr, geo_feat);
     PN_LAUNCH_CHECK();
     return PN_OK;
 }

@@ -69,6 +69,17 @@ class NeRFNetwork(NeRFRenderer):
         check(lib().pn_nerf_forward(self._net_handle(), ptr(x), ptr(d), M, 1.0, ptr(sigma), ptr(color), stream_ptr()), "nerf_forward")
         return sigma, color
 
+    def density(self, x):
+        """x [N,3] in [-bound,bound] -> {'sigma': [N], 'geo_feat': [N,15]} (network.py:129-146), the fused kernel stopped after the
+        sigma net."""
+        x = x.to(torch.float32).contiguous().view(-1, 3)
+        require_gpu(x)
+        M = x.shape[0]
+        sigma = torch.empty(M, dtype=torch.float32, device=x.device)
+        geo = torch.empty(M, 15, dtype=torch.float32, device=x.device)
+        check(lib().pn_nerf_density(self._net_handle(), ptr(x), M, ptr(sigma), ptr(geo), stream_ptr()), "nerf_density")
+        return {"sigma": sigma, "geo_feat": geo}
+
     def forward_ops(self, x, d):
         """The reference's op sequence: GridEncoder -> Linear/ReLU -> exp | SHEncoder, cat -> Linear/ReLU x3 -> sigmoid."""
         h = self.encoder(x, bound=self.bound)

@@ -173,12 +173,16 @@ def make_density_bitfield(bound=1.0, grid_size=128, solid=chair_solid):
     return bits, cascade
 
 
-def make_checkpoint(bound=1.0, seed=0, sigma_target=60.0, grid_size=128, solid=chair_solid):
+def make_checkpoint(bound=1.0, seed=0, sigma_target=60.0, grid_size=128, solid=chair_solid, shaped=False, sigma_outside=0.02):
     """Random-init network of the reference architecture with an analytically calibrated density:
 
     feature 0 (level 0, channel 0) is the constant 0.5 (level 0 is dense, so trilinear interpolation
     returns it everywhere), hidden unit 0 = ReLU(2 * 0.5) = 1 and sigma_net[1].weight[0,0] = ln(sigma_target),
     so sigma = sigma_target * exp(small random term) — median ~ sigma_target without a forward pass.
+
+    shaped=True (point sampling, pienerf_amd/sampling.py): the density FIELD itself has the solid's shape, not only the bitfield —
+    channel 0 of the finest dense level holds the solid's vertex occupancy, hidden unit 1 = its trilinear interpolation, and
+    sigma = sigma_outside * (sigma_target / sigma_outside)^occupancy * exp(small random term).
     """
     rng = np.random.default_rng(seed)
     offsets, pls = hashgrid_offsets(bound)
@@ -194,6 +198,19 @@ def make_checkpoint(bound=1.0, seed=0, sigma_target=60.0, grid_size=128, solid=c
     W0[0, 0] = 2.0
     W1[0, :] *= 0.25
     W1[0, 0] = math.log(sigma_target)
+    if shaped:
+        S = np.float32(np.log2(pls))
+        lvl = max(l for l in range(16) if (int(np.ceil(np.float32(np.exp2(np.float32(l) * S) * 16 - 1))) + 2) ** 3 <= offsets[l + 1] - offsets[l])
+        scale = np.float32(np.exp2(np.float32(lvl) * S) * 16 - 1)                    # gridencoder.cu:133
+        r1 = int(np.ceil(scale)) + 2                                                 # resolution + 1 vertices per axis (:134, :75)
+        gidx = np.arange(r1)
+        X, Y, Z = np.meshgrid(gidx, gidx, gidx, indexing="ij")
+        P = (np.stack([X, Y, Z], -1) - 0.5) / float(scale) * (2 * bound) - bound     # vertex g sits at u = (g - 0.5) / scale
+        emb[offsets[lvl] + (X + Y * r1 + Z * r1 * r1).reshape(-1), 0] = solid(P.reshape(-1, 3)).astype(np.float32)
+        W0[1, :] = 0.0
+        W0[1, 2 * lvl] = 1.0
+        W1[0, 0] = math.log(sigma_outside)
+        W1[0, 1] = math.log(sigma_target / sigma_outside)
     bits, cascade = make_density_bitfield(bound, grid_size, solid)
     return dict(embeddings=emb, offsets=offsets, per_level_scale=pls, base_resolution=16, W0=W0, W1=W1, W2=W2, W3=W3, W4=W4,
                 density_bitfield=bits, cascade=cascade, grid_size=grid_size, bound=float(bound), min_near=0.2, density_scale=1.0)
