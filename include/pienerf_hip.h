@@ -99,6 +99,20 @@ int pn_grid_encode_forward(const float* inputs, const float* embeddings, const i
 /* shencoder/src/shencoder.h:9 sh_encode_forward (kernel shencoder.cu:27-123), D=3, degree C in [1,4], dy_dx NULL. */
 int pn_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C, const float* dy_dx, void* stream);
 
+/* ------------------------------------------------------------------ static inference ops (off the hot path) */
+
+/* march_rays (raymarching/src/raymarching.cu:703-824, wrapper raymarching.py:327-360): the undeformed march against the density
+ * bitfield, up to n_step samples per alive ray.  xyzs/dirs [n_alive*n_step,3], deltas [..,2] zero-filled by the caller; noises
+ * [n_alive] or NULL (= 0). */
+int pn_march_rays(uint32_t n_alive, uint32_t n_step, const int* rays_alive, const float* rays_t, const float* rays_o, const float* rays_d,
+                  float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid, const float* nears,
+                  const float* fars, float* xyzs, float* dirs, float* deltas, const float* noises, void* stream);
+/* packbits (raymarching.cu:270-303): bitfield[n] bit i = grid[8n+i] > density_thresh; N = number of bytes. */
+int pn_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, void* stream);
+/* morton3D / morton3D_invert (raymarching.cu:217-263): coords [N,3] int32 <-> indices [N] int32. */
+int pn_morton3D(const int* coords, uint32_t N, int* indices, void* stream);
+int pn_morton3D_invert(const int* indices, uint32_t N, int* coords, void* stream);
+
 /* ------------------------------------------------------------------ network -------- */
 
 /* NeRFNetwork.forward (nerf/network.py:98-127): hash grid (16x2) -> 32->64->16 -> exp | SH(16)+15 -> 31->64->64->3 -> sigmoid,

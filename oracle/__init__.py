@@ -120,6 +120,43 @@ def warp_point(x, p_ori, p_def, F9, dF27, max_iter_num, IP_dx):
     return out, bool(rej)
 
 
+def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, Cc, H, near, far, align=-1, noises=None,
+               dt_gamma=0.0, max_steps=1024):
+    """raymarching.march_rays (raymarching.py:306-358 / raymarching.cu:703-824).  Returns zero-initialised xyzs, dirs, deltas."""
+    rays_o, rays_d = _f32(rays_o).reshape(-1, 3), _f32(rays_d).reshape(-1, 3)
+    M = int(n_alive) * int(n_step)
+    if align > 0:
+        M += align - (M % align)
+    xyzs, dirs, deltas = np.zeros((M, 3), np.float32), np.zeros((M, 3), np.float32), np.zeros((M, 2), np.float32)
+    noises = np.zeros(int(n_alive), np.float32) if noises is None else _f32(noises)
+    alive, rt, far = _i32(rays_alive), _f32(rays_t), _f32(far)
+    grid = np.ascontiguousarray(density_bitfield, np.uint8)
+    lib().orc_march_rays(C.c_uint32(int(n_alive)), C.c_uint32(int(n_step)), _p(alive, I), _p(rt, F), _p(rays_o, F), _p(rays_d, F), F(bound),
+                         F(dt_gamma), C.c_uint32(int(max_steps)), C.c_uint32(int(Cc)), C.c_uint32(int(H)), _p(grid, U8), _p(far, F), _p(xyzs, F), _p(dirs, F), _p(deltas, F), _p(noises, F))
+    return xyzs, dirs, deltas
+
+
+def packbits(grid, thresh):
+    g = _f32(grid).reshape(-1)
+    out = np.empty(g.size // 8, np.uint8)
+    lib().orc_packbits(_p(g, F), C.c_uint32(out.size), F(thresh), _p(out, U8))
+    return out
+
+
+def morton3D(coords):
+    c = _i32(coords).reshape(-1, 3)
+    out = np.empty(c.shape[0], np.int32)
+    lib().orc_morton3D(_p(c, I), C.c_uint32(c.shape[0]), _p(out, I))
+    return out
+
+
+def morton3D_invert(indices):
+    i = _i32(indices).reshape(-1)
+    out = np.empty((i.size, 3), np.int32)
+    lib().orc_morton3D_invert(_p(i, I), C.c_uint32(i.size), _p(out, I))
+    return out
+
+
 def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh=1e-2):
     """In place on rays_alive, rays_t, weights_sum, depth, image (all must be contiguous numpy arrays of the right dtype)."""
     for a, ty in ((rays_alive, np.int32), (rays_t, np.float32), (weights_sum, np.float32), (depth, np.float32), (image, np.float32)):
@@ -234,6 +271,41 @@ def render_deformed(rays_o, rays_d, ip_state, ckpt, opt, bg_color=1.0, bbox=None
 
 
 # ----------------------------------------------------------------------------- sim
+def render_static(rays_o, rays_d, ckpt, opt, bg_color=1.0):
+    """NeRFRenderer.run_cuda, inference branch (nerf/renderer.py:267-387), perturb=False, op by op on the CPU."""
+    rays_o, rays_d = _f32(rays_o).reshape(-1, 3), _f32(rays_d).reshape(-1, 3)
+    N = rays_o.shape[0]
+    bound = float(ckpt["bound"])
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)                       # renderer.py:33-36
+    nears, fars = near_far_from_aabb(rays_o, rays_d, aabb, ckpt.get("min_near", 0.2))
+    ws, depth, image = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+    alive = np.arange(N, dtype=np.int32)
+    rays_t = nears.copy()
+    step, trips, samples = 0, 0, 0
+    max_steps = int(opt["max_steps"])
+    while step < max_steps:
+        n_alive = alive.shape[0]
+        if n_alive <= 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        xyzs, dirs, deltas = march_rays(n_alive, n_step, alive, rays_t, rays_o, rays_d, bound, ckpt["density_bitfield"], ckpt["cascade"],
+                                        ckpt["grid_size"], nears, fars, 128, None, float(opt["dt_gamma"]), max_steps)
+        live = deltas[:, 0] != 0
+        sig, rgb = np.zeros(len(xyzs), np.float32), np.zeros((len(xyzs), 3), np.float32)
+        if live.any():                                                              # slots with delta 0 are never read by composite
+            sig[live], rgb[live] = nerf_forward(xyzs[live], dirs[live], ckpt, bound)
+        sig = np.float32(ckpt.get("density_scale", 1.0)) * sig
+        composite_rays(n_alive, n_step, alive, rays_t, sig, rgb, deltas, ws, depth, image, float(opt["T_thresh"]))
+        alive = compact_rays(alive)
+        samples += int(live.sum())
+        step += n_step
+        trips += 1
+    image = image + (1 - ws)[:, None] * np.float32(bg_color)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        depth = np.maximum(depth - nears, 0) / (fars - nears)
+    return dict(image=image.astype(np.float32), depth=depth.astype(np.float32), weights_sum=ws, trips=trips, samples=samples)
+
+
 def svd3(Fm):
     Fm = _f64(Fm).reshape(3, 3)
     U, s, V = np.empty((3, 3)), np.empty(3), np.empty((3, 3))

@@ -645,6 +645,88 @@ int orc_march_rays_quadratic_bending(const int* pig_cnt, const int* pig_bgn, con
 }
 
 // raymarching.cu:925-932 (host) + 827-923 (kernel)
+// march_rays (raymarching.cu:703-824): the undeformed march.  Same loop as march_one without the search / warp.
+void orc_march_rays(uint32_t n_alive, uint32_t n_step, const int* rays_alive, const float* rays_t, const float* rays_o, const float* rays_d,
+                    float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid, const float* fars, float* xyzs_,
+                    float* dirs_, float* deltas_, const float* noises) {
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t n = 0; n < (int64_t)n_alive; n++) {
+        const int index = rays_alive[n];
+        const float noise = noises ? noises[n] : 0.0f;
+        const float* ro = rays_o + (size_t)index * 3;
+        const float* rd = rays_d + (size_t)index * 3;
+        float* xyzs = xyzs_ + (size_t)n * n_step * 3;
+        float* dirs = dirs_ + (size_t)n * n_step * 3;
+        float* deltas = deltas_ + (size_t)n * n_step * 2;
+        const float ox = ro[0], oy = ro[1], oz = ro[2];
+        const float dx = rd[0], dy = rd[1], dz = rd[2];
+        const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+        const float rH = 1 / (float)H;
+        const float H3 = (float)(H * H * H);
+        float t = rays_t[index];
+        const float far = fars[index];
+        const float dt_min = 2 * 1.73205080757f / max_steps;
+        const float dt_max = 2 * 1.73205080757f * (1 << (C - 1)) / H;
+        uint32_t step = 0;
+        t += clampf(t * dt_gamma, dt_min, dt_max) * noise;
+        float last_t = t;
+        while (t < far && step < n_step) {
+            const float x = clampf(ox + t * dx, -bound, bound);
+            const float y = clampf(oy + t * dy, -bound, bound);
+            const float z = clampf(oz + t * dz, -bound, bound);
+            const float dt = clampf(t * dt_gamma, dt_min, dt_max);
+            const int level = std::max(mip_from_pos(x, y, z, (float)C), mip_from_dt(dt, (float)H, (float)C));
+            const float mip_bound = fminf(scalbnf(1, level), bound);
+            const float mip_rbound = 1 / mip_bound;
+            const int nx = (int)clampf((float)(0.5 * (double)(x * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+            const int ny = (int)clampf((float)(0.5 * (double)(y * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+            const int nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+            const uint32_t vox = (uint32_t)(level * H3 + (float)morton3D(nx, ny, nz));
+            const bool occ = grid[vox / 8] & (1 << (vox % 8));
+            if (occ) {
+                xyzs[0] = x; xyzs[1] = y; xyzs[2] = z;
+                dirs[0] = dx; dirs[1] = dy; dirs[2] = dz;
+                t += dt;
+                deltas[0] = dt;
+                deltas[1] = t - last_t;
+                last_t = t;
+                xyzs += 3; dirs += 3; deltas += 2;
+                step++;
+            } else {
+                const float tx = (((nx + 0.5f + 0.5f * signf(dx)) * rH * 2 - 1) * mip_bound - x) * rdx;
+                const float ty = (((ny + 0.5f + 0.5f * signf(dy)) * rH * 2 - 1) * mip_bound - y) * rdy;
+                const float tz = (((nz + 0.5f + 0.5f * signf(dz)) * rH * 2 - 1) * mip_bound - z) * rdz;
+                const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+                do { t += clampf(t * dt_gamma, dt_min, dt_max); } while (t < tt);
+            }
+        }
+    }
+}
+
+// packbits (raymarching.cu:270-303), morton3D / morton3D_invert (:60-81,217-263)
+void orc_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield) {
+    for (uint32_t n = 0; n < N; n++) {
+        uint8_t bits = 0;
+        for (int i = 0; i < 8; i++) bits |= (grid[(size_t)n * 8 + i] > density_thresh) ? (uint8_t)(1u << i) : 0;
+        bitfield[n] = bits;
+    }
+}
+void orc_morton3D(const int* coords, uint32_t N, int* indices) {
+    for (uint32_t n = 0; n < N; n++) indices[n] = (int)morton3D((uint32_t)coords[n * 3], (uint32_t)coords[n * 3 + 1], (uint32_t)coords[n * 3 + 2]);
+}
+void orc_morton3D_invert(const int* indices, uint32_t N, int* coords) {
+    for (uint32_t n = 0; n < N; n++)
+        for (int a = 0; a < 3; a++) {
+            uint32_t x = (uint32_t)(indices[n] >> a);
+            x = x & 0x49249249u;
+            x = (x | (x >> 2)) & 0xc30c30c3u;
+            x = (x | (x >> 4)) & 0x0f00f00fu;
+            x = (x | (x >> 8)) & 0xff0000ffu;
+            x = (x | (x >> 16)) & 0x0000ffffu;
+            coords[n * 3 + a] = (int)x;
+        }
+}
+
 void orc_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int* rays_alive, float* rays_t, const float* sigmas, const float* rgbs,
                         const float* deltas, float* weights_sum, float* depth, float* image) {
 #pragma omp parallel for schedule(static)

@@ -40,6 +40,10 @@ SIGNATURES = {
     "pn_sh_encode_forward": (i32, [P, P, u32, u32, u32, P, P]),
     "pn_net_create": (i32, [C.POINTER(P), P, P, u32, u32, f32, u32, f32, P, P, P, P, P, P]),
     "pn_net_destroy": (None, [P]),
+    "pn_march_rays": (i32, [u32, u32, P, P, P, P, f32, f32, u32, u32, u32, P, P, P, P, P, P, P, P]),
+    "pn_packbits": (i32, [P, u32, f32, P, P]),
+    "pn_morton3D": (i32, [P, u32, P, P]),
+    "pn_morton3D_invert": (i32, [P, u32, P, P]),
     "pn_nerf_forward": (i32, [P, P, P, u32, f32, P, P, P]),
     "pn_nerf_density": (i32, [P, P, u32, P, P, P]),
     "pn_frame_create": (i32, [C.POINTER(P), u32, u32, u32]),

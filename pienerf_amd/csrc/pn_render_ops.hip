@@ -573,6 +573,143 @@ extern "C" int pn_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thre
     return PN_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ static (undeformed) inference ops
+// SURVEY 8(f) rank 3, inference side: kernel_march_rays (raymarching.cu:703-810), kernel_packbits (:270-292), kernel_morton3D /
+// kernel_morton3D_invert (:217-258).  Off the simulate-and-render hot path (the deformed march above replaces kernel_march_rays
+// there): one lane per ray / byte / index like the reference, arithmetic restated literally (this file is compiled with
+// -ffp-contract=off) so that samples are bit-identical to the oracle.
+__global__ void __launch_bounds__(128) k_march_rays_static(uint32_t n_alive, uint32_t n_step, const int* __restrict__ rays_alive,
+                                                           const float* __restrict__ rays_t, const float* __restrict__ rays_o,
+                                                           const float* __restrict__ rays_d, float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
+                                                           uint32_t H, const uint8_t* __restrict__ grid, const float* __restrict__ fars,
+                                                           float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
+                                                           const float* __restrict__ noises) {
+    using namespace pnm;
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    const float noise = noises ? noises[n] : 0.0f;
+    rays_o += (size_t)index * 3;
+    rays_d += (size_t)index * 3;
+    xyzs += (size_t)n * n_step * 3;
+    dirs += (size_t)n * n_step * 3;
+    deltas += (size_t)n * n_step * 2;
+    const float ox = rays_o[0], oy = rays_o[1], oz = rays_o[2];
+    const float dx = rays_d[0], dy = rays_d[1], dz = rays_d[2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    const float rH = 1 / (float)H;
+    const float H3 = (float)(H * H * H);
+    float t = rays_t[index];
+    const float far = fars[index];
+    const float dt_min = 2 * 1.73205080757f / max_steps;
+    const float dt_max = 2 * 1.73205080757f * (1 << (C - 1)) / H;
+    uint32_t step = 0;
+    t += clampf(t * dt_gamma, dt_min, dt_max) * noise;
+    float last_t = t;
+    while (t < far && step < n_step) {
+        const float x = clampf(ox + t * dx, -bound, bound);
+        const float y = clampf(oy + t * dy, -bound, bound);
+        const float z = clampf(oz + t * dz, -bound, bound);
+        const float dt = clampf(t * dt_gamma, dt_min, dt_max);
+        const int level = max(mip_from_pos(x, y, z, (float)C), mip_from_dt(dt, (float)H, (float)C));
+        const float mip_bound = fminf(scalbnf(1, level), bound);
+        const float mip_rbound = 1 / mip_bound;
+        // `0.5 * (x * mip_rbound + 1) * H` is a double product in the reference; (float)(0.5 * (double)v * (double)H) == v * (0.5f * H)
+        // for every float v and power-of-two-free H < 2^24 only when the product is exact, so it is kept in double here (cold path)
+        const int nx = (int)clampf((float)(0.5 * (double)(x * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+        const int ny = (int)clampf((float)(0.5 * (double)(y * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+        const int nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+        const uint32_t vox = (uint32_t)(level * H3 + (float)morton3D(nx, ny, nz));
+        const bool occ = grid[vox / 8] & (1 << (vox % 8));
+        if (occ) {
+            xyzs[0] = x; xyzs[1] = y; xyzs[2] = z;
+            dirs[0] = dx; dirs[1] = dy; dirs[2] = dz;
+            t += dt;
+            deltas[0] = dt;
+            deltas[1] = t - last_t;
+            last_t = t;
+            xyzs += 3; dirs += 3; deltas += 2;
+            step++;
+        } else {
+            const float tx = (((nx + 0.5f + 0.5f * signf(dx)) * rH * 2 - 1) * mip_bound - x) * rdx;
+            const float ty = (((ny + 0.5f + 0.5f * signf(dy)) * rH * 2 - 1) * mip_bound - y) * rdy;
+            const float tz = (((nz + 0.5f + 0.5f * signf(dz)) * rH * 2 - 1) * mip_bound - z) * rdz;
+            const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+            do { t += clampf(t * dt_gamma, dt_min, dt_max); } while (t < tt);
+        }
+    }
+}
+
+extern "C" int pn_march_rays(uint32_t n_alive, uint32_t n_step, const int* rays_alive, const float* rays_t, const float* rays_o, const float* rays_d,
+                             float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid, const float* nears,
+                             const float* fars, float* xyzs, float* dirs, float* deltas, const float* noises, void* stream) {
+    (void)nears;
+    if (n_alive == 0) return PN_OK;
+    PN_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas);
+    PN_REQUIRE(C >= 1 && C <= 8 && H > 0 && n_step >= 1 && max_steps > 0);
+    k_march_rays_static<<<pn_div_up(n_alive, 128), 128, 0, (hipStream_t)stream>>>(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma,
+                                                                                 max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+__global__ void __launch_bounds__(256) k_packbits(const float* __restrict__ grid, uint32_t N, float density_thresh, uint8_t* __restrict__ bitfield) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const float4 a = reinterpret_cast<const float4*>(grid)[2 * (size_t)n], b = reinterpret_cast<const float4*>(grid)[2 * (size_t)n + 1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) bits |= (v[i] > density_thresh) ? (1u << i) : 0u;
+    bitfield[n] = (uint8_t)bits;
+}
+
+extern "C" int pn_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, void* stream) {
+    if (N == 0) return PN_OK;
+    PN_REQUIRE(grid && bitfield && ((uintptr_t)grid & 15) == 0);
+    k_packbits<<<pn_div_up(N, 256), 256, 0, (hipStream_t)stream>>>(grid, N, density_thresh, bitfield);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+__device__ __forceinline__ uint32_t morton3D_invert1(uint32_t x) {  // raymarching.cu:73-81
+    x = x & 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return x;
+}
+__global__ void __launch_bounds__(256) k_morton3D(const int* __restrict__ coords, uint32_t N, int* __restrict__ indices, int invert) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    if (!invert) {
+        indices[n] = (int)pnm::morton3D((uint32_t)coords[n * 3], (uint32_t)coords[n * 3 + 1], (uint32_t)coords[n * 3 + 2]);
+    } else {  // `coords` is the output here
+        const int ind = indices[n];
+        int* c = const_cast<int*>(coords) + (size_t)n * 3;
+        c[0] = (int)morton3D_invert1((uint32_t)(ind >> 0));
+        c[1] = (int)morton3D_invert1((uint32_t)(ind >> 1));
+        c[2] = (int)morton3D_invert1((uint32_t)(ind >> 2));
+    }
+}
+
+extern "C" int pn_morton3D(const int* coords, uint32_t N, int* indices, void* stream) {
+    if (N == 0) return PN_OK;
+    PN_REQUIRE(coords && indices);
+    k_morton3D<<<pn_div_up(N, 256), 256, 0, (hipStream_t)stream>>>(coords, N, indices, 0);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+extern "C" int pn_morton3D_invert(const int* indices, uint32_t N, int* coords, void* stream) {
+    if (N == 0) return PN_OK;
+    PN_REQUIRE(coords && indices);
+    k_morton3D<<<pn_div_up(N, 256), 256, 0, (hipStream_t)stream>>>(coords, N, const_cast<int*>(indices), 1);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ stable compaction
 __global__ void __launch_bounds__(256) k_chunk_count(const int* __restrict__ rays_alive, uint32_t n, int* chunk_counts) {
     const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;

@@ -165,6 +165,46 @@ class NeRFRenderer(nn.Module):
         return self.last_stats
 
     # ------------------------------------------------------------------ op-by-op loop (reference structure, renderer.py:755-907)
+    @torch.no_grad()
+    def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024, T_thresh=1e-2, **kwargs):
+        """NeRFRenderer.run_cuda, inference branch (nerf/renderer.py:267-387): the static, undeformed render — near/far from
+        aabb_infer, then trips of march_rays -> network -> composite_rays -> compaction (op by op like the reference,
+        the fused frame driver exists only for the deformed hot path).  The training branch is not built."""
+        assert not self.training, "run_cuda: only the inference branch is built (SURVEY 8f rank 3)"
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        N, device = rays_o.shape[0], rays_o.device
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
+        if bg_color is None:
+            bg_color = 1
+        dtype = torch.float32
+        weights_sum = torch.zeros(N, dtype=dtype, device=device)
+        depth = torch.zeros(N, dtype=dtype, device=device)
+        image = torch.zeros(N, 3, dtype=dtype, device=device)
+        rays_alive = torch.arange(N, dtype=torch.int32, device=device)
+        rays_t = nears.clone()
+        step, trips, samples = 0, 0, 0
+        while step < max_steps:
+            n_alive = rays_alive.shape[0]
+            if n_alive <= 0:
+                break
+            n_step = max(min(N // n_alive, 8), 1)
+            xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield,
+                                                        self.cascade, self.grid_size, nears, fars, 128, perturb if step == 0 else False, dt_gamma,
+                                                        max_steps)
+            sigmas, rgbs = self(xyzs, dirs)
+            sigmas = self.density_scale * sigmas
+            raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh)
+            rays_alive = raymarching.compact_rays(rays_alive)  # == rays_alive[rays_alive >= 0]
+            samples += int((deltas[:, 0] != 0).sum())
+            step += n_step
+            trips += 1
+        self.last_stats = dict(trips=trips, samples=samples, err=0, alive_at_exit=int(rays_alive.shape[0]))
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "weights_sum": weights_sum}
+
     def rund_cuda_ops(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-2, **kwargs):
         dtype = torch.float32
         prefix = rays_o.shape[:-1]

@@ -9,7 +9,8 @@ import torch
 
 from .._lib import check, lib, ptr, require_gpu, stream_ptr
 
-__all__ = ["near_far_from_aabb", "march_rays_quadratic_bending", "composite_rays", "compact_rays"]
+__all__ = ["near_far_from_aabb", "march_rays_quadratic_bending", "march_rays", "composite_rays", "compact_rays", "morton3D", "morton3D_invert",
+           "packbits"]
 
 
 def _f32(t):
@@ -66,6 +67,68 @@ def march_rays_quadratic_bending(pig_cnt, pig_bgn, pig_idx, n_vtx, n_grid, p_def
         ptr(rays_t), ptr(rays_o), ptr(rays_d), float(bound), float(dt_gamma), int(max_steps), int(C), int(H), ptr(density_bitfield), ptr(near),
         ptr(far), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(noises), None, stream_ptr()), "march_rays_quadratic_bending")
     return xyzs, dirs, deltas
+
+
+def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far, align=-1, perturb=False, dt_gamma=0,
+               max_steps=1024):
+    """raymarching/raymarching.py:306-358: the undeformed march (static inference).  Returns zero-initialised
+    xyzs [M,3], dirs [M,3], deltas [M,2]."""
+    if not rays_o.is_cuda:
+        rays_o = rays_o.cuda()
+    if not rays_d.is_cuda:
+        rays_d = rays_d.cuda()
+    rays_o = _f32(rays_o).view(-1, 3)
+    rays_d = _f32(rays_d).view(-1, 3)
+    n_alive, n_step = int(n_alive), int(n_step)
+    M = n_alive * n_step
+    if align > 0:
+        M += align - (M % align)
+    dev = rays_o.device
+    xyzs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
+    dirs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
+    deltas = torch.zeros(M, 2, dtype=rays_o.dtype, device=dev)
+    noises = torch.rand(n_alive, dtype=rays_o.dtype, device=dev) if perturb else torch.zeros(n_alive, dtype=rays_o.dtype, device=dev)
+    require_gpu(rays_alive, rays_t, density_bitfield, near, far)
+    rays_t, near, far = _f32(rays_t), _f32(near), _f32(far)
+    check(lib().pn_march_rays(n_alive, n_step, ptr(rays_alive), ptr(rays_t), ptr(rays_o), ptr(rays_d), float(bound), float(dt_gamma), int(max_steps),
+                              int(C), int(H), ptr(density_bitfield), ptr(near), ptr(far), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(noises),
+                              stream_ptr()), "march_rays")
+    return xyzs, dirs, deltas
+
+
+def morton3D(coords):
+    """raymarching.py:85-106: coords [N,3] int32 in [0,128) -> indices [N] int32."""
+    if not coords.is_cuda:
+        coords = coords.cuda()
+    coords = coords.int().contiguous()
+    N = coords.shape[0]
+    indices = torch.empty(N, dtype=torch.int32, device=coords.device)
+    check(lib().pn_morton3D(ptr(coords), N, ptr(indices), stream_ptr()), "morton3D")
+    return indices
+
+
+def morton3D_invert(indices):
+    """raymarching.py:108-128: indices [N] int32 -> coords [N,3] int32."""
+    if not indices.is_cuda:
+        indices = indices.cuda()
+    indices = indices.int().contiguous()
+    N = indices.shape[0]
+    coords = torch.empty(N, 3, dtype=torch.int32, device=indices.device)
+    check(lib().pn_morton3D_invert(ptr(indices), N, ptr(coords), stream_ptr()), "morton3D_invert")
+    return coords
+
+
+def packbits(grid, thresh, bitfield=None):
+    """raymarching.py:131-157: grid float [C, H^3] -> bitfield uint8 [C*H^3/8], bit i of byte n = grid[8n+i] > thresh."""
+    if not grid.is_cuda:
+        grid = grid.cuda()
+    grid = _f32(grid)
+    N = grid.shape[0] * grid.shape[1] // 8
+    if bitfield is None:
+        bitfield = torch.empty(N, dtype=torch.uint8, device=grid.device)
+    require_gpu(bitfield)
+    check(lib().pn_packbits(ptr(grid), N, float(thresh), ptr(bitfield), stream_ptr()), "packbits")
+    return bitfield
 
 
 def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh=1e-2):

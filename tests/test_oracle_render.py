@@ -304,3 +304,73 @@ def test_get_rays_matches_reference_formulation():
     # default OrbitCamera: at +z looking down -z, y up (nerf/gui.py:13-44)
     p0 = scene.orbit_pose(5.0)
     assert np.allclose(p0[:3, 3], [0, 0, 5]) and np.allclose(p0[:3, :3], np.diag([1, -1, -1]))
+
+
+# ----------------------------------------------------------------------------- static inference ops
+def test_packbits_and_morton_invert_vs_numpy():
+    rng = np.random.default_rng(11)
+    grid = rng.random((2, 32 ** 3)).astype(np.float32)
+    grid[1, :9] = 0.25  # ties: strict > (raymarching.cu:291)
+    bits = oracle.packbits(grid, 0.25)
+    assert np.array_equal(bits, np.packbits((grid > 0.25).reshape(-1), bitorder="little"))
+    c = rng.integers(0, 1024, size=(3000, 3)).astype(np.int32)
+    idx = oracle.morton3D(c)
+    assert np.array_equal(idx.astype(np.uint32), scene.morton3D(c[:, 0], c[:, 1], c[:, 2]))
+    assert np.array_equal(oracle.morton3D_invert(idx), c)
+
+
+@pytest.mark.parametrize("dt_gamma,cascade", [(0.0, 1), (1.0 / 128, 2)])
+def test_static_march_properties(dt_gamma, cascade):
+    """Independent route: emitted points lie on the (clamped) ray inside occupied voxels of the level the kernel picks, dt follows
+    clamp(t*dt_gamma), deltas[1] telescopes to the distance marched, and rays end with zero rows."""
+    bound = float(2 ** (cascade - 1))
+    ck = scene.make_checkpoint(bound=bound, seed=3)
+    assert ck["cascade"] == cascade
+    H, max_steps, n_step, W = ck["grid_size"], 512, 16, 36
+    o, d = oracle.get_rays(scene.orbit_pose(3.2 * bound, 20.0, -25.0), scene.orbit_intrinsics(W, W, 50.0), W, W)
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    alive = np.arange(W * W, dtype=np.int32)[::2].copy()
+    xyz, dirs, deltas = oracle.march_rays(len(alive), n_step, alive, nears, o, d, bound, ck["density_bitfield"], cascade, H, nears, fars, 128, None,
+                                          dt_gamma, max_steps)
+    M = len(alive) * n_step
+    assert xyz.shape[0] % 128 == 0 and xyz.shape[0] > M and not xyz[M:].any() and not deltas[M:].any()
+    xyz, dirs, deltas = xyz[:M].reshape(-1, n_step, 3), dirs[:M].reshape(-1, n_step, 3), deltas[:M].reshape(-1, n_step, 2)
+    em = deltas[..., 0] != 0
+    assert em.sum() > 200
+    # emitted rows are a prefix of each ray's slots
+    assert np.all(em[:, :-1] >= em[:, 1:])
+    dt_min, dt_max = 2 * np.sqrt(3) / max_steps, 2 * np.sqrt(3) * 2 ** (cascade - 1) / H
+    # sample parameter: t_k = near + sum_{j<=k} deltas[j,1] - deltas[k,0]
+    t = nears[alive][:, None] + np.cumsum(deltas[..., 1].astype(np.float64), axis=1) - deltas[..., 0]
+    want_dt = np.clip(t * dt_gamma, dt_min, dt_max)
+    assert np.allclose(deltas[..., 0][em], want_dt[em], rtol=1e-5)
+    on_ray = np.clip(o[alive][:, None, :] + t[..., None] * d[alive][:, None, :], -bound, bound)
+    assert np.abs(xyz - on_ray)[em].max() < 2e-5
+    assert np.array_equal(dirs[em], np.broadcast_to(d[alive][:, None, :], dirs.shape)[em])
+    # occupancy at the level max(mip_from_pos, mip_from_dt) (raymarching.cu:38-57)
+    p = xyz[em].astype(np.float64)
+    mx = np.abs(p).max(1)
+    lvl_pos = np.clip(np.ceil(np.log2(np.maximum(mx, 1e-30))), 0, cascade - 1).astype(np.int64)
+    lvl_dt = np.clip(np.ceil(np.log2(np.maximum(deltas[..., 0][em].astype(np.float64) * H * 0.5, 1e-30))), 0, cascade - 1).astype(np.int64)
+    lvl = np.maximum(lvl_pos, lvl_dt)
+    mb = np.minimum(2.0 ** lvl, bound)
+    n = np.clip((0.5 * (p / mb[:, None] + 1) * H).astype(np.int64), 0, H - 1)
+    m = lvl * H ** 3 + scene.morton3D(n[:, 0], n[:, 1], n[:, 2]).astype(np.int64)
+    occ = (ck["density_bitfield"][m // 8] >> (m % 8)) & 1
+    assert occ.mean() > 0.999  # a point within an ulp of a level / voxel boundary may round the other way in float64
+    # rays that miss the box emit nothing
+    assert not em[nears[alive] > 1e30].any()
+
+
+def test_render_static_properties():
+    ck = scene.make_checkpoint(bound=1.0, seed=0, shaped=True)
+    opt = scene.default_opt(W=40, H=40)
+    o, d = oracle.get_rays(scene.orbit_pose(4.0, 40.0, -20.0), scene.orbit_intrinsics(40, 40, 50.0), 40, 40)
+    r1, r2 = oracle.render_static(o, d, ck, opt), oracle.render_static(o, d, ck, opt)
+    assert np.array_equal(r1["image"], r2["image"])
+    ws = r1["weights_sum"]
+    assert np.all(ws >= 0) and np.all(ws <= 1 + 1e-5) and r1["trips"] >= 2 and r1["samples"] > 500
+    assert np.all(r1["image"][ws == 0] == 1.0) and (ws > 0.9).sum() > 20
+    nears, _ = oracle.near_far_from_aabb(o, d, np.array([-1, -1, -1, 1, 1, 1], np.float32), 0.2)
+    assert np.array_equal(np.isnan(r1["depth"]), nears > 1e30)  # 0/0 exactly where the ray misses the +-bound box (renderer.py:384)
