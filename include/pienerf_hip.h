@@ -85,19 +85,20 @@ int pn_get_rays(const float* pose, float fx, float fy, float cx, float cy, int H
 
 /* ------------------------------------------------------------------ gridencoder ---- */
 
-/* gridencoder/src/gridencoder.h:11 grid_encode_forward (kernel gridencoder.cu:87-245, D=3, C in {1,2,4,8}, fp32,
- * dy_dx must be NULL).  offsets_host [host]: the L+1 int32 level offsets (the reference passes a device tensor; the
+/* gridencoder/src/gridencoder.h:12 grid_encode_forward (kernel gridencoder.cu:87-245, D=3, C in {1,2,4,8}, fp32).
+ * dy_dx: NULL, or [B, L, 3, C] (the `calc_grad_inputs` branch, :199-243; training side).  offsets_host [host]: the L+1 int32 level offsets (the reference passes a device tensor; the
  * launcher derives per-level scale / resolution / table size on the host with the reference's formulas :132-134 and
  * hands them to the kernel by value).  outputs [L,B,C] exactly like the reference kernel; with out_bl_major != 0 the
  * kernel writes [B, L*C] directly (what grid.py:57 produces by permute+reshape). */
 int pn_grid_encode_forward(const float* inputs, const float* embeddings, const int* offsets_host, float* outputs, uint32_t B, uint32_t D,
-                           uint32_t C, uint32_t L, float S, uint32_t H, const float* dy_dx, uint32_t gridtype, int align_corners,
+                           uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype, int align_corners,
                            uint32_t interp, int out_bl_major, void* stream);
 
 /* ------------------------------------------------------------------ shencoder ---- */
 
-/* shencoder/src/shencoder.h:9 sh_encode_forward (kernel shencoder.cu:27-123), D=3, degree C in [1,4], dy_dx NULL. */
-int pn_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C, const float* dy_dx, void* stream);
+/* shencoder/src/shencoder.h:9 sh_encode_forward (kernel shencoder.cu:27-123), D=3, degree C in [1,4]; dy_dx NULL or [B, 3, C*C]
+ * (:125-355). */
+int pn_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C, float* dy_dx, void* stream);
 
 /* ------------------------------------------------------------------ static inference ops (off the hot path) */
 
@@ -112,6 +113,34 @@ int pn_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bi
 /* morton3D / morton3D_invert (raymarching.cu:217-263): coords [N,3] int32 <-> indices [N] int32. */
 int pn_morton3D(const int* coords, uint32_t N, int* indices, void* stream);
 int pn_morton3D_invert(const int* indices, uint32_t N, int* coords, void* stream);
+
+/* ------------------------------------------------------------------ training ops (off the hot path) */
+
+/* march_rays_train (raymarching/src/raymarching.h:13, kernel raymarching.cu:314-483, wrapper raymarching.py:163-236).  xyzs/dirs [M,3],
+ * deltas [M,2] zero-filled by the caller; rays [N,3] = (ray id, point offset, point count); counter[2] += (points demanded, N).
+ * DIFFERENCE (documented): the reference hands out offsets and ray rows with atomicAdd (race order); here row n is ray n
+ * and offsets are the exclusive prefix sum of the counts (count -> single-workgroup scan -> write), so the output is reproducible.
+ * Rays whose range passes M are dropped like the reference's (:415).  noises [N] or NULL. */
+int pn_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma, uint32_t max_steps, uint32_t N,
+                        uint32_t C, uint32_t H, uint32_t M, const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas, int* rays,
+                        int* counter, const float* noises, void* stream);
+/* composite_rays_train_forward / _backward (raymarching.h:14-15, kernels raymarching.cu:503-581,604-686). */
+int pn_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int* rays, uint32_t M, uint32_t N, float T_thresh,
+                                    float* weights_sum, float* depth, float* image, void* stream);
+int pn_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas, const float* rgbs,
+                                     const float* deltas, const int* rays, const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                     float T_thresh, float* grad_sigmas, float* grad_rgbs, void* stream);
+/* grid_encode_backward (gridencoder.h:13, kernels gridencoder.cu:248-369): grad [L,B,C]; grad_embeddings [sO,C] zero-filled by the
+ * caller, accumulated with hardware fp32 atomics; dy_dx / grad_inputs [B,3] both NULL or both given. */
+int pn_grid_encode_backward(const float* grad, const float* inputs, const float* embeddings, const int* offsets_host, float* grad_embeddings,
+                            uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float* dy_dx, float* grad_inputs,
+                            uint32_t gridtype, int align_corners, uint32_t interp, void* stream);
+/* grad_total_variation (gridencoder.h:15, kernel gridencoder.cu:506-611): grad [sO,C] += TV gradient at the cells of `inputs` [B,3] in [0,1]. */
+int pn_grad_total_variation(const float* inputs, const float* embeddings, float* grad, const int* offsets_host, float weight, uint32_t B, uint32_t D,
+                            uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, void* stream);
+/* sh_encode_backward (shencoder.h:10, kernel shencoder.cu:358-383): grad_inputs [B,3] += grad [B,C*C] . dy_dx [B,3,C*C]. */
+int pn_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C, const float* dy_dx, float* grad_inputs,
+                          void* stream);
 
 /* ------------------------------------------------------------------ network -------- */
 

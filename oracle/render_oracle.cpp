@@ -881,3 +881,335 @@ int orc_num_threads(void) {
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// Training-side ops — same status as everything above: test infrastructure, parity unpinned.
+// =====================================================================================================================
+namespace {
+
+// The loop shared by kernel_march_rays_train's two passes (raymarching.cu:357-401 counts, :420-480 writes).  WRITE = false:
+// returns the number of occupied steps up to `limit`; WRITE = true: also stores xyzs / dirs / deltas.
+template <bool WRITE>
+uint32_t train_march_pass(const float* ro, const float* rd, float t0, float far, uint32_t limit, float bound, float dt_gamma, uint32_t max_steps,
+                          uint32_t C, uint32_t H, const uint8_t* grid, float* xyzs, float* dirs, float* deltas) {
+    const float ox = ro[0], oy = ro[1], oz = ro[2];
+    const float dx = rd[0], dy = rd[1], dz = rd[2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    const float rH = 1 / (float)H;
+    const float H3 = (float)(H * H * H);
+    const float dt_min = 2 * 1.73205080757f / max_steps;
+    const float dt_max = 2 * 1.73205080757f * (1 << (C - 1)) / H;
+    float t = t0, last_t = t0;
+    uint32_t step = 0;
+    while (t < far && step < limit) {
+        const float x = clampf(ox + t * dx, -bound, bound);
+        const float y = clampf(oy + t * dy, -bound, bound);
+        const float z = clampf(oz + t * dz, -bound, bound);
+        const float dt = clampf(t * dt_gamma, dt_min, dt_max);
+        const int level = std::max(mip_from_pos(x, y, z, (float)C), mip_from_dt(dt, (float)H, (float)C));
+        const float mip_bound = fminf(scalbnf(1.0f, level), bound);
+        const float mip_rbound = 1 / mip_bound;
+        const int nx = (int)clampf((float)(0.5 * (double)(x * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+        const int ny = (int)clampf((float)(0.5 * (double)(y * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+        const int nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+        const uint32_t vox = (uint32_t)(level * H3 + (float)morton3D(nx, ny, nz));
+        const bool occ = grid[vox / 8] & (1 << (vox % 8));
+        if (occ) {
+            if (WRITE) {
+                xyzs[0] = x; xyzs[1] = y; xyzs[2] = z;
+                dirs[0] = dx; dirs[1] = dy; dirs[2] = dz;
+            }
+            t += dt;
+            if (WRITE) {
+                deltas[0] = dt;
+                deltas[1] = t - last_t;
+                last_t = t;
+                xyzs += 3; dirs += 3; deltas += 2;
+            }
+            step++;
+        } else {
+            const float tx = (((nx + 0.5f + 0.5f * signf(dx)) * rH * 2 - 1) * mip_bound - x) * rdx;
+            const float ty = (((ny + 0.5f + 0.5f * signf(dy)) * rH * 2 - 1) * mip_bound - y) * rdy;
+            const float tz = (((nz + 0.5f + 0.5f * signf(dz)) * rH * 2 - 1) * mip_bound - z) * rdz;
+            const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+            do { t += clampf(t * dt_gamma, dt_min, dt_max); } while (t < tt);
+        }
+    }
+    return step;
+}
+
+// first-order terms of sh_one (d/dx, d/dy, d/dz of the same polynomials; shencoder.cu:125-355 tabulates the same derivatives)
+void sh_one_grad(const float* in, uint32_t C, float* gx, float* gy, float* gz) {
+    static const double PI_ = 3.14159265358979323846;  // the same closed forms as sh_one
+    static const float c1 = (float)(std::sqrt(3.0) / (2.0 * std::sqrt(PI_)));
+    static const float c2a = (float)(std::sqrt(15.0) / (2.0 * std::sqrt(PI_)));
+    static const float c2b = (float)(3.0 * std::sqrt(5.0) / (4.0 * std::sqrt(PI_)));
+    static const float c2d = (float)(std::sqrt(15.0) / (4.0 * std::sqrt(PI_)));
+    static const float c3a = (float)(std::sqrt(70.0) / (8.0 * std::sqrt(PI_)));
+    static const float c3b = (float)(std::sqrt(105.0) / (2.0 * std::sqrt(PI_)));
+    static const float c3c = (float)(std::sqrt(42.0) / (8.0 * std::sqrt(PI_)));
+    static const float c3d = (float)(std::sqrt(7.0) / (4.0 * std::sqrt(PI_)));
+    static const float c3e = (float)(std::sqrt(105.0) / (4.0 * std::sqrt(PI_)));
+    const float x = in[0], y = in[1], z = in[2];
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    const uint32_t C2 = C * C;
+    for (uint32_t i = 0; i < C2; i++) gx[i] = gy[i] = gz[i] = 0.0f;
+    if (C <= 1) return;
+    gy[1] = -c1; gz[2] = c1; gx[3] = -c1;
+    if (C <= 2) return;
+    gx[4] = c2a * y; gy[4] = c2a * x;
+    gy[5] = -c2a * z; gz[5] = -c2a * y;
+    gz[6] = 2.0f * c2b * z;
+    gx[7] = -c2a * z; gz[7] = -c2a * x;
+    gx[8] = 2.0f * c2d * x; gy[8] = -2.0f * c2d * y;
+    if (C <= 3) return;
+    gx[9] = -6.0f * c3a * xy; gy[9] = c3a * (-3.0f * x2 + 3.0f * y2);
+    gx[10] = c3b * yz; gy[10] = c3b * xz; gz[10] = c3b * xy;
+    gy[11] = c3c * (1.0f - 5.0f * z2); gz[11] = -10.0f * c3c * yz;
+    gz[12] = c3d * (15.0f * z2 - 3.0f);
+    gx[13] = c3c * (1.0f - 5.0f * z2); gz[13] = -10.0f * c3c * xz;
+    gx[14] = 2.0f * c3e * xz; gy[14] = -2.0f * c3e * yz; gz[14] = c3e * (x2 - y2);
+    gx[15] = c3a * (-3.0f * x2 + 3.0f * y2); gy[15] = 6.0f * c3a * xy;
+}
+
+}  // namespace
+
+extern "C" {
+
+// march_rays_train (raymarching.cu:314-497).  The reference hands out point ranges and ray rows with two atomicAdd counters, so
+// its ray order is a race; here (and in the HIP path) rays keep their own order: rays[n] = (n, exclusive prefix of the counts, count),
+// counter += (total points, N).  Rays whose range would pass M are dropped exactly like the reference's (:415).
+void orc_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma, uint32_t max_steps, uint32_t N,
+                          uint32_t C, uint32_t H, uint32_t M, const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                          int* rays, int* counter, const float* noises) {
+    const float dt_min = 2 * 1.73205080757f / max_steps;
+    const float dt_max = 2 * 1.73205080757f * (1 << (C - 1)) / H;
+    std::vector<uint32_t> cnt(N);
+    std::vector<float> t0s(N);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t n = 0; n < (int64_t)N; n++) {
+        float t0 = nears[n];
+        t0 += clampf(t0 * dt_gamma, dt_min, dt_max) * (noises ? noises[n] : 0.0f);
+        t0s[n] = t0;
+        cnt[n] = train_march_pass<false>(rays_o + n * 3, rays_d + n * 3, t0, fars[n], max_steps, bound, dt_gamma, max_steps, C, H, grid, nullptr, nullptr,
+                                         nullptr);
+    }
+    uint32_t point = (uint32_t)counter[0];
+    const uint32_t ray0 = (uint32_t)counter[1];
+    for (uint32_t n = 0; n < N; n++) {
+        rays[(size_t)(ray0 + n) * 3] = (int)n;
+        rays[(size_t)(ray0 + n) * 3 + 1] = (int)point;
+        rays[(size_t)(ray0 + n) * 3 + 2] = (int)cnt[n];
+        point += cnt[n];
+    }
+    counter[0] = (int)point;
+    counter[1] = (int)(ray0 + N);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t n = 0; n < (int64_t)N; n++) {
+        const uint32_t off = (uint32_t)rays[(size_t)(ray0 + n) * 3 + 1];
+        if (cnt[n] == 0 || off + cnt[n] > M) continue;
+        train_march_pass<true>(rays_o + n * 3, rays_d + n * 3, t0s[n], fars[n], cnt[n], bound, dt_gamma, max_steps, C, H, grid, xyzs + (size_t)off * 3,
+                               dirs + (size_t)off * 3, deltas + (size_t)off * 2);
+    }
+}
+
+// composite_rays_train_forward (raymarching.cu:503-581)
+void orc_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int* rays, uint32_t M, uint32_t N,
+                                      float T_thresh, float* weights_sum, float* depth, float* image) {
+    for (uint32_t n = 0; n < N; n++) {
+        const uint32_t index = rays[n * 3], offset = rays[n * 3 + 1], num_steps = rays[n * 3 + 2];
+        if (num_steps == 0 || offset + num_steps > M) {
+            weights_sum[index] = 0; depth[index] = 0;
+            image[index * 3] = image[index * 3 + 1] = image[index * 3 + 2] = 0;
+            continue;
+        }
+        const float* s = sigmas + offset; const float* c = rgbs + (size_t)offset * 3; const float* dl = deltas + (size_t)offset * 2;
+        uint32_t step = 0;
+        float T = 1.0f, r = 0, g = 0, b = 0, ws = 0, t = 0, d = 0;
+        while (step < num_steps) {
+            const float alpha = 1.0f - expf(-s[0] * dl[0]);
+            const float weight = alpha * T;
+            r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
+            t += dl[1];
+            d += weight * t;
+            ws += weight;
+            T *= 1.0f - alpha;
+            if (T < T_thresh) break;
+            s++; c += 3; dl += 2; step++;
+        }
+        weights_sum[index] = ws; depth[index] = d;
+        image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+    }
+}
+
+// composite_rays_train_backward (raymarching.cu:604-686); grad_sigmas / grad_rgbs zero-filled by the caller
+void orc_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas, const float* rgbs,
+                                       const float* deltas, const int* rays, const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                       float T_thresh, float* grad_sigmas, float* grad_rgbs) {
+    for (uint32_t n = 0; n < N; n++) {
+        const uint32_t index = rays[n * 3], offset = rays[n * 3 + 1], num_steps = rays[n * 3 + 2];
+        if (num_steps == 0 || offset + num_steps > M) continue;
+        const float gws = grad_weights_sum[index];
+        const float* gi = grad_image + (size_t)index * 3;
+        const float r_final = image[index * 3], g_final = image[index * 3 + 1], b_final = image[index * 3 + 2], ws_final = weights_sum[index];
+        const float* s = sigmas + offset; const float* c = rgbs + (size_t)offset * 3; const float* dl = deltas + (size_t)offset * 2;
+        float* gs = grad_sigmas + offset; float* gc = grad_rgbs + (size_t)offset * 3;
+        uint32_t step = 0;
+        float T = 1.0f, r = 0, g = 0, b = 0, ws = 0;
+        while (step < num_steps) {
+            const float alpha = 1.0f - expf(-s[0] * dl[0]);
+            const float weight = alpha * T;
+            r += weight * c[0]; g += weight * c[1]; b += weight * c[2];
+            ws += weight;
+            T *= 1.0f - alpha;
+            gc[0] = gi[0] * weight; gc[1] = gi[1] * weight; gc[2] = gi[2] * weight;
+            gs[0] = dl[0] * (gi[0] * (T * c[0] - (r_final - r)) + gi[1] * (T * c[1] - (g_final - g)) + gi[2] * (T * c[2] - (b_final - b)) +
+                             gws * (1 - ws_final));
+            if (T < T_thresh) break;
+            s++; c += 3; dl += 2; gs++; gc += 3; step++;
+        }
+    }
+}
+
+// kernel_grid's dy_dx branch (gridencoder.cu:199-243): dy_dx [B, L, 3, C]
+void orc_grid_encode_dy_dx(const float* inputs, const float* embeddings, const int* offsets, float* dy_dx, uint32_t B, uint32_t C, uint32_t L, float S,
+                           uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp) {
+    for (uint32_t l = 0; l < L; l++) {
+        float scale; uint32_t res;
+        level_params(l, S, H, &scale, &res);
+        const uint32_t hs = (uint32_t)(offsets[l + 1] - offsets[l]);
+        const float* table = embeddings + (size_t)(uint32_t)offsets[l] * C;
+        for (uint32_t b = 0; b < B; b++) {
+            const float* in3 = inputs + (size_t)b * 3;
+            float* out = dy_dx + ((size_t)b * L + l) * 3 * C;
+            bool oob = false;
+            for (int d = 0; d < 3; d++) if (in3[d] < 0 || in3[d] > 1) oob = true;
+            if (oob) { for (uint32_t i = 0; i < 3 * C; i++) out[i] = 0; continue; }  // gridencoder.cu:115-125
+            float pos[3], deriv[3];
+            uint32_t pg[3];
+            for (int d = 0; d < 3; d++) {
+                pos[d] = fmaf(in3[d], scale, align_corners ? 0.0f : 0.5f);
+                pg[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pg[d];
+                if (interp == 1) { deriv[d] = 6 * pos[d] * (1 - pos[d]); pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]); }
+                else deriv[d] = 1.0f;
+            }
+            for (uint32_t gd = 0; gd < 3; gd++) {
+                float rg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (uint32_t idx = 0; idx < 4; idx++) {
+                    float w = scale;
+                    uint32_t pl[3];
+                    for (uint32_t nd = 0; nd < 2; nd++) {
+                        const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+                        if ((idx & (1u << nd)) == 0) { w *= 1 - pos[d]; pl[d] = pg[d]; }
+                        else { w *= pos[d]; pl[d] = pg[d] + 1; }
+                    }
+                    pl[gd] = pg[gd];
+                    const uint32_t il = grid_index(gridtype, align_corners != 0, C, hs, res, pl);
+                    pl[gd] = pg[gd] + 1;
+                    const uint32_t ir = grid_index(gridtype, align_corners != 0, C, hs, res, pl);
+                    for (uint32_t c = 0; c < C; c++) rg[c] += w * (table[ir + c] - table[il + c]) * deriv[gd];
+                }
+                for (uint32_t c = 0; c < C; c++) out[gd * C + c] = rg[c];
+            }
+        }
+    }
+}
+
+// kernel_grid_backward (gridencoder.cu:248-340) + kernel_input_backward (:343-369).  grad [L,B,C]; grad_embeddings zero-filled by the
+// caller and accumulated here in sample order (the reference's atomicAdd order is a race); grad_inputs may be NULL.
+void orc_grid_encode_backward(const float* grad, const float* inputs, const int* offsets, float* grad_embeddings, uint32_t B, uint32_t C, uint32_t L,
+                              float S, uint32_t H, const float* dy_dx, float* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp) {
+    for (uint32_t l = 0; l < L; l++) {
+        float scale; uint32_t res;
+        level_params(l, S, H, &scale, &res);
+        const uint32_t hs = (uint32_t)(offsets[l + 1] - offsets[l]);
+        float* gt = grad_embeddings + (size_t)(uint32_t)offsets[l] * C;
+        for (uint32_t b = 0; b < B; b++) {
+            const float* in3 = inputs + (size_t)b * 3;
+            bool oob = false;
+            for (int d = 0; d < 3; d++) if (in3[d] < 0 || in3[d] > 1) oob = true;
+            if (oob) continue;
+            float pos[3];
+            uint32_t pg[3];
+            for (int d = 0; d < 3; d++) {
+                pos[d] = fmaf(in3[d], scale, align_corners ? 0.0f : 0.5f);
+                pg[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pg[d];
+                if (interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+            }
+            const float* g = grad + ((size_t)l * B + b) * C;
+            for (uint32_t idx = 0; idx < 8; idx++) {
+                float w = 1;
+                uint32_t pl[3];
+                for (int d = 0; d < 3; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pg[d]; }
+                    else { w *= pos[d]; pl[d] = pg[d] + 1; }
+                }
+                const uint32_t index = grid_index(gridtype, align_corners != 0, C, hs, res, pl);
+                for (uint32_t c = 0; c < C; c++) gt[index + c] += w * g[c];
+            }
+        }
+    }
+    if (dy_dx && grad_inputs)
+        for (uint32_t b = 0; b < B; b++)
+            for (uint32_t d = 0; d < 3; d++) {
+                float result = 0;
+                for (uint32_t l = 0; l < L; l++)
+                    for (uint32_t c = 0; c < C; c++) result += grad[((size_t)l * B + b) * C + c] * dy_dx[(((size_t)b * L + l) * 3 + d) * C + c];
+                grad_inputs[(size_t)b * 3 + d] = result;
+            }
+}
+
+// kernel_grad_tv (gridencoder.cu:506-611): accumulates into grad (sample order instead of the reference's atomic race order)
+void orc_grad_total_variation(const float* inputs, const float* embeddings, float* grad, const int* offsets, float weight, uint32_t B, uint32_t C,
+                              uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners) {
+    for (uint32_t l = 0; l < L; l++) {
+        float scale; uint32_t res;
+        level_params(l, S, H, &scale, &res);
+        const uint32_t hs = (uint32_t)(offsets[l + 1] - offsets[l]);
+        const float* table = embeddings + (size_t)(uint32_t)offsets[l] * C;
+        float* gt = grad + (size_t)(uint32_t)offsets[l] * C;
+        for (uint32_t b = 0; b < B; b++) {
+            const float* in3 = inputs + (size_t)b * 3;
+            bool oob = false;
+            for (int d = 0; d < 3; d++) if (in3[d] < 0 || in3[d] > 1) oob = true;
+            if (oob) continue;
+            uint32_t pg[3];
+            for (int d = 0; d < 3; d++) pg[d] = (uint32_t)floorf(fmaf(in3[d], scale, align_corners ? 0.0f : 0.5f));
+            float results[8] = {0, 0, 0, 0, 0, 0, 0, 0}, idelta[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const uint32_t index = grid_index(gridtype, align_corners != 0, C, hs, res, pg);
+            const float w = weight / (2 * 3);
+            for (int d = 0; d < 3; d++) {
+                const uint32_t cur = pg[d];
+                if (cur < res) {
+                    pg[d] = cur + 1;
+                    const uint32_t ir = grid_index(gridtype, align_corners != 0, C, hs, res, pg);
+                    for (uint32_t c = 0; c < C; c++) { const float gv = table[index + c] - table[ir + c]; results[c] += gv; idelta[c] += gv * gv; }
+                }
+                if (cur > 0) {
+                    pg[d] = cur - 1;
+                    const uint32_t il = grid_index(gridtype, align_corners != 0, C, hs, res, pg);
+                    for (uint32_t c = 0; c < C; c++) { const float gv = table[index + c] - table[il + c]; results[c] += gv; idelta[c] += gv * gv; }
+                }
+                pg[d] = cur;
+            }
+            for (uint32_t c = 0; c < C; c++) gt[index + c] += w * results[c] * (1.0f / sqrtf(idelta[c] + 1e-9f));
+        }
+    }
+}
+
+// kernel_sh's dy_dx branch (shencoder.cu:125-355, degree <= 4): dy_dx [B, 3, C*C]; kernel_sh_backward (:358-383): grad_inputs +=
+void orc_sh_encode_dy_dx(const float* inputs, float* dy_dx, uint32_t B, uint32_t C) {
+    const uint32_t C2 = C * C;
+    for (uint32_t b = 0; b < B; b++) sh_one_grad(inputs + (size_t)b * 3, C, dy_dx + (size_t)b * 3 * C2, dy_dx + (size_t)b * 3 * C2 + C2, dy_dx + (size_t)b * 3 * C2 + 2 * C2);
+}
+void orc_sh_encode_backward(const float* grad, uint32_t B, uint32_t C, const float* dy_dx, float* grad_inputs) {
+    const uint32_t C2 = C * C;
+    for (uint32_t t = 0; t < B * 3; t++) {
+        const uint32_t b = t / 3, d = t - b * 3;
+        for (uint32_t ch = 0; ch < C2; ch++) grad_inputs[t] += grad[(size_t)b * C2 + ch] * dy_dx[((size_t)b * 3 + d) * C2 + ch];
+    }
+}
+
+}  // extern "C"

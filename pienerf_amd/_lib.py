@@ -40,6 +40,12 @@ SIGNATURES = {
     "pn_sh_encode_forward": (i32, [P, P, u32, u32, u32, P, P]),
     "pn_net_create": (i32, [C.POINTER(P), P, P, u32, u32, f32, u32, f32, P, P, P, P, P, P]),
     "pn_net_destroy": (None, [P]),
+    "pn_march_rays_train": (i32, [P, P, P, f32, f32, u32, u32, u32, u32, u32, P, P, P, P, P, P, P, P, P]),
+    "pn_composite_rays_train_forward": (i32, [P, P, P, P, u32, u32, f32, P, P, P, P]),
+    "pn_composite_rays_train_backward": (i32, [P, P, P, P, P, P, P, P, u32, u32, f32, P, P, P]),
+    "pn_grid_encode_backward": (i32, [P, P, P, P, P, u32, u32, u32, u32, f32, u32, P, P, u32, i32, u32, P]),
+    "pn_grad_total_variation": (i32, [P, P, P, P, f32, u32, u32, u32, u32, f32, u32, u32, i32, P]),
+    "pn_sh_encode_backward": (i32, [P, P, u32, u32, u32, P, P, P]),
     "pn_march_rays": (i32, [u32, u32, P, P, P, P, f32, f32, u32, u32, u32, P, P, P, P, P, P, P, P]),
     "pn_packbits": (i32, [P, u32, f32, P, P]),
     "pn_morton3D": (i32, [P, u32, P, P]),

@@ -28,7 +28,9 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-co
 # decisions vs the CPU oracle); the encoder/MLP and the fp64 simulator let the compiler contract to FMA.
 UNITS = {
     "pn_render_ops.hip": ["-ffp-contract=off"],
+    "pn_train_ops.hip": ["-ffp-contract=off"],
     "pn_nerf_forward.hip": ["-ffp-contract=fast"],
+    "pn_encoder_grad.hip": ["-ffp-contract=fast"],
     "pn_sim.hip": ["-ffp-contract=fast"],
 }
 

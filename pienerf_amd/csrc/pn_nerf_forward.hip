@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "pn_common.h"
+#include "pn_encoders.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -44,21 +45,6 @@ int pn_fill_grid_levels(PnGridLevels* g, const int* offsets_host, uint32_t L, ui
         g->nomod[l] = (!hashed && dims == 3 && !align_corners && gridtype == 0) ? 1u : 0u;
     }
     return PN_OK;
-}
-
-// get_grid_index for D = 3 (gridencoder.cu:65-84); `dense` = 0 -> fast_hash, else number of strided dims.
-struct LevelIdx { uint32_t dense, hs, mask, nomod, stride1; };
-__device__ __forceinline__ LevelIdx level_idx(const PnGridLevels& lv, uint32_t level, int align_corners) {
-    return LevelIdx{lv.dense[level], lv.hashmap_size[level], lv.mask[level], lv.nomod[level],
-                    align_corners ? lv.resolution[level] : lv.resolution[level] + 1};
-}
-__device__ __forceinline__ uint32_t grid_index3(const LevelIdx& L, uint32_t g0, uint32_t g1, uint32_t g2) {
-    if (L.dense == 0) {
-        const uint32_t index = g0 ^ (g1 * 2654435761u) ^ (g2 * 805459861u);
-        return L.mask ? (index & L.mask) : (index % L.hs);
-    }
-    const uint32_t index = g0 + (L.dense > 1 ? g1 * L.stride1 : 0u) + (L.dense > 2 ? g2 * L.stride1 * L.stride1 : 0u);
-    return L.nomod ? index : (index % L.hs);
 }
 
 // ------------------------------------------------------------------------------------------------ op-level grid encoder
@@ -118,13 +104,13 @@ __global__ void __launch_bounds__(256) k_grid_encode(const float* __restrict__ i
 }
 
 extern "C" int pn_grid_encode_forward(const float* inputs, const float* embeddings, const int* offsets_host, float* outputs, uint32_t B, uint32_t D,
-                                      uint32_t C, uint32_t L, float S, uint32_t H, const float* dy_dx, uint32_t gridtype, int align_corners,
+                                      uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype, int align_corners,
                                       uint32_t interp, int out_bl_major, void* stream) {
     if (B == 0) return PN_OK;  // empty tensors have null data pointers
     PN_REQUIRE(inputs && embeddings && offsets_host && outputs);
     PN_REQUIRE(D == 3);                                   // the reference also has D = 2,4,5 (gridencoder.cu:386-395); not on this path
     PN_REQUIRE(C == 1 || C == 2 || C == 4 || C == 8);     // gridencoder.cu:376-382
-    PN_REQUIRE(dy_dx == nullptr && gridtype <= 1 && interp <= 1);
+    PN_REQUIRE(gridtype <= 1 && interp <= 1);
     if (B == 0) return PN_OK;
     PnGridLevels lv;
     if (pn_fill_grid_levels(&lv, offsets_host, L, C, S, H, gridtype, align_corners)) { PN_REQUIRE(L >= 1 && L <= PN_MAX_LEVELS); }
@@ -137,23 +123,11 @@ extern "C" int pn_grid_encode_forward(const float* inputs, const float* embeddin
         default: k_grid_encode<8><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
     }
     PN_LAUNCH_CHECK();
+    if (dy_dx) return pn_grid_dy_dx_launch(inputs, embeddings, lv, B, C, align_corners, interp, dy_dx, st);  // training side (pn_encoder_grad.hip)
     return PN_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ SH (degree <= 4)
-// Real SH basis in the reference's sign convention (shencoder.cu:50-68); constants are the closed forms of its comments.
-#define SH_C0 0.28209479177387814f   /* 1/(2 sqrt(pi)) */
-#define SH_C1 0.48860251190291992f   /* sqrt(3)/(2 sqrt(pi)) */
-#define SH_C2A 1.0925484305920792f   /* sqrt(15)/(2 sqrt(pi)) */
-#define SH_C2B 0.94617469575755997f  /* 3 sqrt(5)/(4 sqrt(pi)) */
-#define SH_C2C 0.31539156525251999f  /* sqrt(5)/(4 sqrt(pi)) */
-#define SH_C2D 0.54627421529603959f  /* sqrt(15)/(4 sqrt(pi)) */
-#define SH_C3A 0.59004358992664352f  /* sqrt(70)/(8 sqrt(pi)) */
-#define SH_C3B 2.8906114426405538f   /* sqrt(105)/(2 sqrt(pi)) */
-#define SH_C3C 0.45704579946446572f  /* sqrt(42)/(8 sqrt(pi)) */
-#define SH_C3D 0.3731763325901154f   /* sqrt(7)/(4 sqrt(pi)) */
-#define SH_C3E 1.4453057213202769f   /* sqrt(105)/(4 sqrt(pi)) */
-
 __device__ __forceinline__ void sh16(float x, float y, float z, float* o) {
     const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
     o[0] = SH_C0;
@@ -183,12 +157,13 @@ __global__ void __launch_bounds__(256) k_sh_encode(const float* __restrict__ inp
     for (uint32_t i = 0; i < C2; i++) outputs[(size_t)b * C2 + i] = o[i];
 }
 
-extern "C" int pn_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C, const float* dy_dx, void* stream) {
+extern "C" int pn_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C, float* dy_dx, void* stream) {
     if (B == 0) return PN_OK;  // empty tensors have null data pointers
-    PN_REQUIRE(inputs && outputs && D == 3 && C >= 1 && C <= 4 && dy_dx == nullptr);  // degrees 5-8 (shencoder.cu:70-122): not on this path
+    PN_REQUIRE(inputs && outputs && D == 3 && C >= 1 && C <= 4);  // degrees 5-8 (shencoder.cu:70-122): not on this path
     if (B == 0) return PN_OK;
     k_sh_encode<<<pn_div_up(B, 256), 256, 0, (hipStream_t)stream>>>(inputs, outputs, B, C);
     PN_LAUNCH_CHECK();
+    if (dy_dx) return pn_sh_dy_dx_launch(inputs, dy_dx, B, C, (hipStream_t)stream);  // training side (pn_encoder_grad.hip)
     return PN_OK;
 }
 

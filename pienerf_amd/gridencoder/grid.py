@@ -1,9 +1,9 @@
-"""Mirror of the reference's ``gridencoder`` package surface (inference only).
+"""Mirror of the reference's ``gridencoder`` package surface.
 
 Interface replaced: /root/reference/gridencoder/grid.py:24-63 (``_grid_encode.forward``) and
 :96-161 (``GridEncoder``): same call signatures, same module attributes / state-dict keys
-(``offsets`` buffer, ``embeddings`` parameter).  Backward, total-variation and fp16 tables are
-training-side and not part of the simulate-and-render path.
+(``offsets`` buffer, ``embeddings`` parameter).  Forward is on the simulate-and-render path; backward, dy_dx and
+``grad_total_variation`` (:65-92,168-190) are the training side.  fp16 tables are not built.
 """
 import math
 
@@ -28,26 +28,54 @@ def level_table_offsets(input_dim, num_levels, per_level_scale, base_resolution,
     return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
 
 
+class _grid_encode(torch.autograd.Function):
+    """gridencoder/grid.py:24-92.  Forward: one HIP launch writes [B, L*C] directly (the reference writes [L,B,C] and permutes,
+    grid.py:47,57), plus the dy_dx launch when ``calc_grad_inputs``.  Backward (training side): scatter-add into
+    grad_embeddings with hardware fp32 atomics and, with dy_dx, the chain rule to the inputs.  fp32 tables only (the reference's
+    autocast/half branch, grid.py:43-44, is not built)."""
+
+    @staticmethod
+    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0, align_corners=False,
+                interpolation=0, offsets_host=None):
+        x = inputs.to(torch.float32).contiguous()
+        table = embeddings.to(torch.float32).contiguous()
+        require_gpu(x, table)
+        B, D = x.shape
+        n_levels = offsets.shape[0] - 1
+        C = table.shape[1]
+        if offsets_host is None:
+            offsets_host = offsets.detach().to("cpu", torch.int32).contiguous()
+        feats = torch.empty(B, n_levels * C, device=x.device, dtype=torch.float32)
+        dy_dx = torch.empty(B, n_levels * D * C, device=x.device, dtype=torch.float32) if calc_grad_inputs else None
+        log2_scale = float(np.float32(np.log2(per_level_scale)))  # the reference passes S = log2(per_level_scale) as a float (grid.py:37)
+        rc = lib().pn_grid_encode_forward(ptr(x), ptr(table), offsets_host.data_ptr(), ptr(feats), B, D, C, n_levels, log2_scale, int(base_resolution),
+                                          ptr(dy_dx), int(gridtype), int(bool(align_corners)), int(interpolation), 1, stream_ptr())
+        check(rc, "grid_encode_forward")
+        ctx.save_for_backward(x, table, dy_dx)
+        ctx.dims = [B, D, C, n_levels, log2_scale, int(base_resolution), int(gridtype), int(interpolation)]
+        ctx.align_corners = bool(align_corners)
+        ctx.offsets_host = offsets_host
+        return feats
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, table, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H, gridtype, interpolation = ctx.dims
+        grad = grad.to(torch.float32).view(B, L, C).permute(1, 0, 2).contiguous()  # [B, L*C] -> [L, B, C] (grid.py:73)
+        grad_embeddings = torch.zeros_like(table)
+        grad_inputs = torch.zeros_like(x) if dy_dx is not None else None
+        rc = lib().pn_grid_encode_backward(ptr(grad), ptr(x), ptr(table), ctx.offsets_host.data_ptr(), ptr(grad_embeddings), B, D, C, L, S, H, ptr(dy_dx),
+                                           ptr(grad_inputs), gridtype, int(ctx.align_corners), interpolation, stream_ptr())
+        check(rc, "grid_encode_backward")
+        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None, None
+
+
 def grid_encode(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0, align_corners=False,
                 interpolation=0, offsets_host=None):
-    """inputs [B,D] in [0,1], embeddings [sO,C], offsets [L+1] -> features [B, L*C] fp32.
-
-    One HIP launch writes [B, L*C] directly; the reference writes [L,B,C] and permutes (grid.py:47,57)."""
-    if calc_grad_inputs:
-        raise RuntimeError("grid_encode: dy_dx / backward are not part of the inference path")
-    x = inputs.to(torch.float32).contiguous()
-    table = embeddings.to(torch.float32).contiguous()
-    require_gpu(x, table)
-    n_levels = offsets.shape[0] - 1
-    if offsets_host is None:
-        offsets_host = offsets.detach().to("cpu", torch.int32).contiguous()
-    feats = torch.empty(x.shape[0], n_levels * table.shape[1], device=x.device, dtype=torch.float32)
-    log2_scale = float(np.float32(np.log2(per_level_scale)))  # the reference passes S = log2(per_level_scale) as a float (grid.py:37)
-    rc = lib().pn_grid_encode_forward(ptr(x), ptr(table), offsets_host.data_ptr(), ptr(feats), x.shape[0], x.shape[1], table.shape[1], n_levels,
-                                      log2_scale, int(base_resolution), None, int(gridtype), int(bool(align_corners)), int(interpolation), 1,
-                                      stream_ptr())
-    check(rc, "grid_encode_forward")
-    return feats
+    """inputs [B,D] in [0,1], embeddings [sO,C], offsets [L+1] -> features [B, L*C] fp32 (differentiable w.r.t. embeddings, and w.r.t.
+    inputs when ``calc_grad_inputs``)."""
+    return _grid_encode.apply(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs, gridtype, align_corners, interpolation,
+                              offsets_host)
 
 
 class GridEncoder(nn.Module):
@@ -79,3 +107,23 @@ class GridEncoder(nn.Module):
         feats = grid_encode(unit.view(-1, self.input_dim), self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
                             unit.requires_grad, self.gridtype_id, self.align_corners, self.interp_id, offsets_host=self._offsets_host)
         return feats.view(lead + [self.output_dim])
+
+    @torch.no_grad()
+    def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):
+        """gridencoder/grid.py:168-190: adds the total-variation gradient at the cells of ``inputs`` (or of B uniform random points)
+        to ``self.embeddings.grad``; call between ``loss.backward()`` and ``optimizer.step()``."""
+        if inputs is None:
+            inputs = torch.rand(B, self.input_dim, device=self.embeddings.device)
+        else:
+            inputs = ((inputs + bound) / (2 * bound)).view(-1, self.input_dim)
+            B = inputs.shape[0]
+        if self.embeddings.grad is None:
+            raise ValueError("grad is None, should be called after loss.backward() and before optimizer.step()!")
+        inputs = inputs.to(torch.float32).contiguous()
+        table, grad = self.embeddings.detach(), self.embeddings.grad
+        require_gpu(inputs, table, grad)
+        assert table.is_contiguous() and grad.is_contiguous() and grad.dtype == torch.float32
+        rc = lib().pn_grad_total_variation(ptr(inputs), ptr(table), ptr(grad), self._offsets_host.data_ptr(), float(weight), B, self.input_dim,
+                                           self.level_dim, self.num_levels, float(np.float32(np.log2(self.per_level_scale))), int(self.base_resolution),
+                                           self.gridtype_id, int(bool(self.align_corners)), stream_ptr())
+        check(rc, "grad_total_variation")

@@ -10,7 +10,7 @@ import torch
 from .._lib import check, lib, ptr, require_gpu, stream_ptr
 
 __all__ = ["near_far_from_aabb", "march_rays_quadratic_bending", "march_rays", "composite_rays", "compact_rays", "morton3D", "morton3D_invert",
-           "packbits"]
+           "packbits", "march_rays_train", "composite_rays_train"]
 
 
 def _f32(t):
@@ -149,3 +149,86 @@ def compact_rays(rays_alive):
     scratch = torch.empty(int(lib().pn_compact_scratch_ints(n)), dtype=torch.int32, device=rays_alive.device)
     check(lib().pn_compact_rays(ptr(rays_alive), n, ptr(out), ptr(n_out), ptr(scratch), stream_ptr()), "compact_rays")
     return out[: int(n_out.item())]  # the .item() is the same D2H sync the reference's boolean mask implies
+
+
+# ----------------------------------------------------------------------------- training ops
+class _march_rays_train(torch.autograd.Function):
+    """raymarching/raymarching.py:163-236 (forward only, like the reference).  Ray rows keep ray order and point ranges are the
+    exclusive prefix sum of the per-ray counts (the reference's atomicAdd order is a race; include/pienerf_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1, perturb=False, align=-1,
+                force_all_rays=False, dt_gamma=0, max_steps=1024):
+        if not rays_o.is_cuda:
+            rays_o = rays_o.cuda()
+        if not rays_d.is_cuda:
+            rays_d = rays_d.cuda()
+        if not density_bitfield.is_cuda:
+            density_bitfield = density_bitfield.cuda()
+        rays_o = _f32(rays_o).view(-1, 3)
+        rays_d = _f32(rays_d).view(-1, 3)
+        density_bitfield = density_bitfield.contiguous()
+        nears, fars = _f32(nears), _f32(fars)
+        require_gpu(nears, fars, step_counter)
+        N = rays_o.shape[0]
+        M = N * int(max_steps)
+        if not force_all_rays and mean_count > 0:
+            if align > 0:
+                mean_count += align - mean_count % align
+            M = int(mean_count)
+        dev = rays_o.device
+        xyzs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
+        dirs = torch.zeros(M, 3, dtype=rays_o.dtype, device=dev)
+        deltas = torch.zeros(M, 2, dtype=rays_o.dtype, device=dev)
+        rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+        if step_counter is None:
+            step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        noises = torch.rand(N, dtype=rays_o.dtype, device=dev) if perturb else torch.zeros(N, dtype=rays_o.dtype, device=dev)
+        check(lib().pn_march_rays_train(ptr(rays_o), ptr(rays_d), ptr(density_bitfield), float(bound), float(dt_gamma), int(max_steps), N, int(C), int(H), M,
+                                        ptr(nears), ptr(fars), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays), ptr(step_counter), ptr(noises), stream_ptr()),
+              "march_rays_train")
+        if force_all_rays or mean_count <= 0:
+            m = int(step_counter[0].item())  # D2H copy, as in the reference (raymarching.py:224-231)
+            if align > 0:
+                m += align - m % align
+            xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
+        return xyzs, dirs, deltas, rays
+
+
+march_rays_train = _march_rays_train.apply
+
+
+class _composite_rays_train(torch.autograd.Function):
+    """raymarching/raymarching.py:241-289: weights_sum [N], depth [N], image [N,3]; backward to sigmas and rgbs (grad_depth is not
+    propagated, as in the reference)."""
+
+    @staticmethod
+    def forward(ctx, sigmas, rgbs, deltas, rays, T_thresh=1e-4):
+        sigmas, rgbs, deltas = _f32(sigmas), _f32(rgbs), _f32(deltas)
+        rays = rays.contiguous()
+        require_gpu(sigmas, rgbs, deltas, rays)
+        M, N = sigmas.shape[0], rays.shape[0]
+        weights_sum = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
+        depth = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
+        image = torch.empty(N, 3, dtype=sigmas.dtype, device=sigmas.device)
+        check(lib().pn_composite_rays_train_forward(ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), M, N, float(T_thresh), ptr(weights_sum), ptr(depth),
+                                                    ptr(image), stream_ptr()), "composite_rays_train_forward")
+        ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, depth, image)
+        ctx.dims = [M, N, T_thresh]
+        return weights_sum, depth, image
+
+    @staticmethod
+    def backward(ctx, grad_weights_sum, grad_depth, grad_image):
+        grad_weights_sum = _f32(grad_weights_sum)
+        grad_image = _f32(grad_image)
+        sigmas, rgbs, deltas, rays, weights_sum, depth, image = ctx.saved_tensors
+        M, N, T_thresh = ctx.dims
+        grad_sigmas = torch.zeros_like(sigmas)
+        grad_rgbs = torch.zeros_like(rgbs)
+        check(lib().pn_composite_rays_train_backward(ptr(grad_weights_sum), ptr(grad_image), ptr(sigmas), ptr(rgbs), ptr(deltas), ptr(rays), ptr(weights_sum),
+                                                     ptr(image), M, N, float(T_thresh), ptr(grad_sigmas), ptr(grad_rgbs), stream_ptr()),
+              "composite_rays_train_backward")
+        return grad_sigmas, grad_rgbs, None, None, None
+
+
+composite_rays_train = _composite_rays_train.apply

@@ -1,4 +1,4 @@
-"""Drop-in mirror of the reference's ``shencoder`` package (forward only, degree <= 4).
+"""Drop-in mirror of the reference's ``shencoder`` package (degree <= 4; forward on the render path, dy_dx / backward for training).
 
 /root/reference/shencoder/sphere_harmonics.py:14-37 (``_sh_encoder.forward``), :60-87 (``SHEncoder``).
 """
@@ -8,16 +8,37 @@ import torch.nn as nn
 from .._lib import check, lib, ptr, require_gpu, stream_ptr
 
 
+class _sh_encoder(torch.autograd.Function):
+    """shencoder/sphere_harmonics.py:14-56: forward [B,3] -> [B, degree^2]; with ``calc_grad_inputs`` also dy_dx [B, 3*degree^2] and a
+    backward to the directions (training side)."""
+
+    @staticmethod
+    def forward(ctx, inputs, degree, calc_grad_inputs=False):
+        inputs = inputs.to(torch.float32).contiguous()  # custom_fwd(cast_inputs=torch.float32)
+        require_gpu(inputs)
+        B, input_dim = inputs.shape
+        outputs = torch.empty(B, degree ** 2, dtype=inputs.dtype, device=inputs.device)
+        dy_dx = torch.empty(B, input_dim * degree ** 2, dtype=inputs.dtype, device=inputs.device) if calc_grad_inputs else None
+        check(lib().pn_sh_encode_forward(ptr(inputs), ptr(outputs), B, input_dim, int(degree), ptr(dy_dx), stream_ptr()), "sh_encode_forward")
+        ctx.save_for_backward(inputs, dy_dx)
+        ctx.dims = [B, input_dim, int(degree)]
+        return outputs
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, dy_dx = ctx.saved_tensors
+        if dy_dx is None:
+            return None, None, None
+        B, input_dim, degree = ctx.dims
+        grad = grad.to(torch.float32).contiguous()
+        grad_inputs = torch.zeros_like(inputs)
+        check(lib().pn_sh_encode_backward(ptr(grad), ptr(inputs), B, input_dim, degree, ptr(dy_dx), ptr(grad_inputs), stream_ptr()), "sh_encode_backward")
+        return grad_inputs, None, None
+
+
 def sh_encode(inputs, degree, calc_grad_inputs=False):
-    """sphere_harmonics.py:14-37: inputs [B,3] in [-1,1] -> [B, degree^2] fp32."""
-    if calc_grad_inputs:
-        raise RuntimeError("sh_encode: dy_dx / backward are not part of the inference path")
-    inputs = inputs.to(torch.float32).contiguous()  # custom_fwd(cast_inputs=torch.float32)
-    require_gpu(inputs)
-    B, input_dim = inputs.shape
-    outputs = torch.empty(B, degree ** 2, dtype=inputs.dtype, device=inputs.device)
-    check(lib().pn_sh_encode_forward(ptr(inputs), ptr(outputs), B, input_dim, int(degree), None, stream_ptr()), "sh_encode_forward")
-    return outputs
+    """sphere_harmonics.py:58: inputs [B,3] in [-1,1] -> [B, degree^2] fp32."""
+    return _sh_encoder.apply(inputs, degree, calc_grad_inputs)
 
 
 class SHEncoder(nn.Module):
