@@ -1,7 +1,8 @@
 """NeRFNetwork with the reference's constructor, state-dict keys and forward (nerf/network.py:14-127).
 
 ``forward(x, d)`` runs the fused HIP kernel (hash grid + SH + both MLPs on the matrix cores, bf16 three-way split at fp32 accuracy); ``forward_ops`` is the same
-computation op by op (grid_encode -> torch Linear -> sh_encode -> ...) like the reference, kept for parity tests.
+computation op by op (grid_encode -> torch Linear -> sh_encode -> ...) like the reference: the parity tests use it, and it is the differentiable path
+``forward`` takes in train() mode.
 """
 import ctypes as C
 
@@ -11,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .._lib import check, lib, ptr, require_gpu, stream_ptr
+from .activation import trunc_exp
 from .encoding import get_encoder
 from .renderer import NeRFRenderer
 
@@ -58,8 +60,17 @@ class NeRFNetwork(NeRFRenderer):
             self._net, self._net_sig = h, sig
         return self._net
 
+    def _wants_grad(self, *inputs):
+        """Differentiable path only in train() mode with autograd recording (Trainer.train_one_epoch calls model.train(), evaluate /
+        test call model.eval(): trainer.py:655,747); everything else — the simulate-and-render path — takes the fused kernel."""
+        return self.training and torch.is_grad_enabled()
+
     def forward(self, x, d):
-        """x [N,3] in [-bound,bound], d [N,3] unit -> sigma [N], color [N,3] (network.py:98-127), one fused launch."""
+        """x [N,3] in [-bound,bound], d [N,3] unit -> sigma [N], color [N,3] (network.py:98-127).  Inference (no_grad, the
+        simulate-and-render path): one fused launch.  With autograd recording (training): the differentiable op
+        sequence of ``forward_ops`` — HIP encoders with their backward kernels, rocBLAS for the five small GEMMs."""
+        if self._wants_grad(x, d):
+            return self.forward_ops(x, d)
         x = x.to(torch.float32).contiguous().view(-1, 3)
         d = d.to(torch.float32).contiguous().view(-1, 3)
         require_gpu(x, d)
@@ -72,6 +83,13 @@ class NeRFNetwork(NeRFRenderer):
     def density(self, x):
         """x [N,3] in [-bound,bound] -> {'sigma': [N], 'geo_feat': [N,15]} (network.py:129-146), the fused kernel stopped after the
         sigma net."""
+        if self._wants_grad(x):
+            h = self.encoder(x, bound=self.bound)
+            for i, layer in enumerate(self.sigma_net):
+                h = layer(h)
+                if i != self.num_layers - 1:
+                    h = F.relu(h, inplace=True)
+            return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
         x = x.to(torch.float32).contiguous().view(-1, 3)
         require_gpu(x)
         M = x.shape[0]
@@ -87,13 +105,18 @@ class NeRFNetwork(NeRFRenderer):
             h = layer(h)
             if i != self.num_layers - 1:
                 h = F.relu(h, inplace=True)
-        sigma = torch.exp(h[..., 0])  # trunc_exp forward (nerf/activation.py:8-10)
+        sigma = trunc_exp(h[..., 0])  # nerf/activation.py:5-18
         h = torch.cat([self.encoder_dir(d), h[..., 1:]], dim=-1)
         for i, layer in enumerate(self.color_net):
             h = layer(h)
             if i != self.num_layers_color - 1:
                 h = F.relu(h, inplace=True)
         return sigma, torch.sigmoid(h)
+
+    def get_params(self, lr):
+        """network.py:196-207: optimizer parameter groups."""
+        return [{"params": self.encoder.parameters(), "lr": lr}, {"params": self.sigma_net.parameters(), "lr": lr},
+                {"params": self.encoder_dir.parameters(), "lr": lr}, {"params": self.color_net.parameters(), "lr": lr}]
 
     def load_checkpoint_dict(self, ck):
         """Loads the synthetic checkpoint dict of pienerf_amd.scene.make_checkpoint (same tensors as the reference's
@@ -106,4 +129,4 @@ class NeRFNetwork(NeRFRenderer):
                 layer.weight.copy_(torch.from_numpy(ck[key]).to(dev))
             self.density_bitfield.copy_(torch.from_numpy(ck["density_bitfield"]).to(dev))
         self._net_sig = None
-        return self
+        return self.eval()  # a loaded checkpoint is used for inference; training code calls .train() itself

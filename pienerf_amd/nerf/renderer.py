@@ -164,47 +164,173 @@ class NeRFRenderer(nn.Module):
         self._set_stats(stats)
         return self.last_stats
 
-    # ------------------------------------------------------------------ op-by-op loop (reference structure, renderer.py:755-907)
-    @torch.no_grad()
+    # ------------------------------------------------------------------ static render + training state
+    def reset_extra_state(self):
+        """renderer.py:125-135."""
+        if not self.cuda_ray:
+            return
+        self.density_grid.zero_()
+        self.mean_density = 0
+        self.iter_density = 0
+        self.step_counter.zero_()
+        self.mean_count = 0
+        self.local_step = 0
+
     def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024, T_thresh=1e-2, **kwargs):
-        """NeRFRenderer.run_cuda, inference branch (nerf/renderer.py:267-387): the static, undeformed render — near/far from
-        aabb_infer, then trips of march_rays -> network -> composite_rays -> compaction (op by op like the reference,
-        the fused frame driver exists only for the deformed hot path).  The training branch is not built."""
-        assert not self.training, "run_cuda: only the inference branch is built (SURVEY 8f rank 3)"
+        """NeRFRenderer.run_cuda (nerf/renderer.py:267-387), the static / undeformed render.  train() mode: march_rays_train ->
+        network (differentiable) -> composite_rays_train, with the step counter feeding ``mean_count``.  eval() mode: near/far from
+        aabb_infer, then trips of march_rays -> network -> composite_rays -> compaction (op by op like the reference; the fused frame
+        driver exists only for the deformed hot path)."""
         prefix = rays_o.shape[:-1]
         rays_o = rays_o.contiguous().view(-1, 3)
         rays_d = rays_d.contiguous().view(-1, 3)
         N, device = rays_o.shape[0], rays_o.device
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_infer, self.min_near)
+        aabb = self.aabb_train if self.training else self.aabb_infer
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
+        if self.bg_radius > 0:
+            raise RuntimeError("background model (bg_radius > 0) is not built")
         if bg_color is None:
             bg_color = 1
-        dtype = torch.float32
-        weights_sum = torch.zeros(N, dtype=dtype, device=device)
-        depth = torch.zeros(N, dtype=dtype, device=device)
-        image = torch.zeros(N, 3, dtype=dtype, device=device)
-        rays_alive = torch.arange(N, dtype=torch.int32, device=device)
-        rays_t = nears.clone()
-        step, trips, samples = 0, 0, 0
-        while step < max_steps:
-            n_alive = rays_alive.shape[0]
-            if n_alive <= 0:
-                break
-            n_step = max(min(N // n_alive, 8), 1)
-            xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield,
-                                                        self.cascade, self.grid_size, nears, fars, 128, perturb if step == 0 else False, dt_gamma,
-                                                        max_steps)
+        if self.training:
+            counter = self.step_counter[self.local_step % 16]
+            counter.zero_()
+            self.local_step += 1
+            xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears,
+                                                                    fars, counter, self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps)
             sigmas, rgbs = self(xyzs, dirs)
             sigmas = self.density_scale * sigmas
-            raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh)
-            rays_alive = raymarching.compact_rays(rays_alive)  # == rays_alive[rays_alive >= 0]
-            samples += int((deltas[:, 0] != 0).sum())
-            step += n_step
-            trips += 1
-        self.last_stats = dict(trips=trips, samples=samples, err=0, alive_at_exit=int(rays_alive.shape[0]))
-        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+            weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+            self.last_stats = dict(trips=1, samples=int(xyzs.shape[0]), err=0, alive_at_exit=0)
+            return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "weights_sum": weights_sum}
+        with torch.no_grad():
+            dtype = torch.float32
+            weights_sum = torch.zeros(N, dtype=dtype, device=device)
+            depth = torch.zeros(N, dtype=dtype, device=device)
+            image = torch.zeros(N, 3, dtype=dtype, device=device)
+            rays_alive = torch.arange(N, dtype=torch.int32, device=device)
+            rays_t = nears.clone()
+            step, trips, samples = 0, 0, 0
+            while step < max_steps:
+                n_alive = rays_alive.shape[0]
+                if n_alive <= 0:
+                    break
+                n_step = max(min(N // n_alive, 8), 1)
+                xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield,
+                                                            self.cascade, self.grid_size, nears, fars, 128, perturb if step == 0 else False, dt_gamma,
+                                                            max_steps)
+                sigmas, rgbs = self(xyzs, dirs)
+                sigmas = self.density_scale * sigmas
+                raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh)
+                rays_alive = raymarching.compact_rays(rays_alive)  # == rays_alive[rays_alive >= 0]
+                samples += int((deltas[:, 0] != 0).sum())
+                step += n_step
+                trips += 1
+            self.last_stats = dict(trips=trips, samples=samples, err=0, alive_at_exit=int(rays_alive.shape[0]))
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
         return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "weights_sum": weights_sum}
 
+    def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
+        """renderer.py:552-585 (cuda_ray never stages)."""
+        if not self.cuda_ray:
+            raise RuntimeError("render: only the cuda_ray path is built")
+        return self.run_cuda(rays_o, rays_d, **kwargs)
+
+    @torch.no_grad()
+    def mark_untrained_grid(self, poses, intrinsic, S=64):
+        """renderer.py:390-452: density-grid cells no training camera sees get density -1 (never sampled, never updated)."""
+        if not self.cuda_ray:
+            return
+        if not torch.is_tensor(poses):
+            poses = torch.from_numpy(poses)
+        B = poses.shape[0]
+        fx, fy, cx, cy = intrinsic
+        dev = self.density_bitfield.device
+        axis = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
+        count = torch.zeros_like(self.density_grid)
+        poses = poses.to(device=dev, dtype=torch.float32)
+        for xs in axis:
+            for ys in axis:
+                for zs in axis:
+                    xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                    coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
+                    indices = raymarching.morton3D(coords).long()
+                    world_xyzs = (2 * coords.float() / (self.grid_size - 1) - 1).unsqueeze(0)
+                    for cas in range(self.cascade):
+                        bound = min(2 ** cas, self.bound)
+                        half_grid_size = bound / self.grid_size
+                        cas_world_xyzs = world_xyzs * (bound - half_grid_size)
+                        head = 0
+                        while head < B:
+                            tail = min(head + S, B)
+                            cam_xyzs = cas_world_xyzs - poses[head:tail, :3, 3].unsqueeze(1)
+                            cam_xyzs = cam_xyzs @ poses[head:tail, :3, :3]
+                            mask_z = cam_xyzs[:, :, 2] > 0
+                            mask_x = torch.abs(cam_xyzs[:, :, 0]) < cx / fx * cam_xyzs[:, :, 2] + half_grid_size * 2
+                            mask_y = torch.abs(cam_xyzs[:, :, 1]) < cy / fy * cam_xyzs[:, :, 2] + half_grid_size * 2
+                            mask = (mask_z & mask_x & mask_y).sum(0).reshape(-1)
+                            count[cas, indices] += mask
+                            head += S
+        self.density_grid[count == 0] = -1
+        return int((count == 0).sum())
+
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, S=128):
+        """renderer.py:454-549: refresh the density grid (full sweep for the first 16 calls, then N = H^3/4 uniform + N occupied cells per
+        cascade), EMA-max with the old grid, re-pack the bitfield at min(mean density, density_thresh), and turn the step counters
+        into ``mean_count``."""
+        if not self.cuda_ray:
+            return
+        dev = self.density_bitfield.device
+        tmp_grid = -torch.ones_like(self.density_grid)
+        if self.iter_density < 16:
+            axis = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
+            for xs in axis:
+                for ys in axis:
+                    for zs in axis:
+                        xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
+                        coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
+                        indices = raymarching.morton3D(coords).long()
+                        xyzs = 2 * coords.float() / (self.grid_size - 1) - 1
+                        for cas in range(self.cascade):
+                            tmp_grid[cas, indices] = self._cell_density(xyzs, cas)
+        else:
+            N = self.grid_size ** 3 // 4
+            for cas in range(self.cascade):
+                coords = torch.randint(0, self.grid_size, (N, 3), device=dev)
+                indices = raymarching.morton3D(coords).long()
+                occ_indices = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
+                if occ_indices.shape[0] > 0:
+                    rand_mask = torch.randint(0, occ_indices.shape[0], [N], dtype=torch.long, device=dev)
+                    occ_indices = occ_indices[rand_mask]
+                    occ_coords = raymarching.morton3D_invert(occ_indices)
+                    indices = torch.cat([indices, occ_indices], dim=0)
+                    coords = torch.cat([coords, occ_coords.to(coords.dtype)], dim=0)
+                xyzs = 2 * coords.float() / (self.grid_size - 1) - 1
+                tmp_grid[cas, indices] = self._cell_density(xyzs, cas)
+        valid_mask = (self.density_grid >= 0) & (tmp_grid >= 0)
+        self.density_grid[valid_mask] = torch.maximum(self.density_grid[valid_mask] * decay, tmp_grid[valid_mask])
+        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+        self.iter_density += 1
+        density_thresh = min(self.mean_density, self.density_thresh)
+        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
+        total_step = min(16, self.local_step)
+        if total_step > 0:
+            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+        self.local_step = 0
+
+    def _cell_density(self, xyzs, cas):
+        """density_scale * sigma at jittered cell centres of cascade `cas` (renderer.py:488-499); xyzs in [-1, 1]."""
+        bound = min(2 ** cas, self.bound)
+        half_grid_size = bound / self.grid_size
+        cas_xyzs = xyzs * (bound - half_grid_size)
+        cas_xyzs += (torch.rand_like(cas_xyzs) * 2 - 1) * half_grid_size
+        sigmas = self.density(cas_xyzs)["sigma"].reshape(-1).detach()
+        return sigmas * self.density_scale
+
+    # ------------------------------------------------------------------ op-by-op loop (reference structure, renderer.py:755-907)
     def rund_cuda_ops(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-2, **kwargs):
         dtype = torch.float32
         prefix = rays_o.shape[:-1]

@@ -1,0 +1,121 @@
+"""NeRFRenderer.run_cuda's training branch, update_extra_state / mark_untrained_grid and a short training run on
+the HIP ops (pienerf_amd/training.py): a fresh network is fitted to images rendered from the synthetic chair checkpoint."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import training as otr
+from pienerf_amd import raymarching, scene
+from pienerf_amd.nerf.network import NeRFNetwork
+from pienerf_amd.training import RayImageSet, Trainer
+from test_gpu_parity import DEV, T
+
+pytestmark = pytest.mark.gpu
+
+
+def _teacher():
+    ck = scene.make_checkpoint(bound=1.0, seed=0, shaped=True)
+    return ck, NeRFNetwork(encoding="hashgrid", bound=1.0, cuda_ray=True).to(DEV).load_checkpoint_dict(ck)
+
+
+def test_run_cuda_training_branch_matches_oracle_composition():
+    ck, net = _teacher()
+    opt = scene.default_opt(W=40, H=40)
+    o, d = oracle.get_rays(scene.orbit_pose(4.0, 40.0, -20.0), scene.orbit_intrinsics(40, 40, 50.0), 40, 40)
+    nears, fars = oracle.near_far_from_aabb(o, d, np.array([-1, -1, -1, 1, 1, 1], np.float32), 0.2)
+    xyzs, dirs, deltas, rays = otr.march_rays_train(o, d, 1.0, ck["density_bitfield"], 1, 128, nears, fars, None, -1, None, 128, False, 0.0, 1024)
+    sig, rgb = oracle.nerf_forward(xyzs, dirs, ck, 1.0)
+    ws, depth, image = otr.composite_rays_train_forward(sig, rgb, deltas, rays, 1e-2)
+    image = image + (1 - ws)[:, None]
+    net.train()
+    out = net.run_cuda(T(o)[None], T(d)[None], dt_gamma=0, perturb=False, max_steps=1024, T_thresh=1e-2)
+    assert out["image"].requires_grad and net.local_step == 1
+    assert int(net.step_counter[0, 0]) == int(rays[:, 2].sum()) and int(net.step_counter[0, 1]) == len(o)
+    assert np.abs(out["image"][0].detach().cpu().numpy() - image).max() < 1e-4
+    assert np.abs(out["weights_sum"].detach().cpu().numpy() - ws).max() < 1e-4
+    # directional derivative of a scalar loss along a random direction in weight space vs autograd
+    w = net.color_net[2].weight
+    target = torch.rand_like(out["image"])
+    loss = ((out["image"] - target) ** 2).mean()
+    loss.backward()
+    assert net.encoder.embeddings.grad is not None and net.encoder.embeddings.grad.abs().max() > 0
+    direction = torch.randn_like(w)
+    analytic = float((w.grad * direction).sum())
+    eps = 1e-2
+    vals = []
+    for sgn in (1, -1):
+        with torch.no_grad():
+            w.add_(sgn * eps * direction)
+        vals.append(float(((net.run_cuda(T(o)[None], T(d)[None], perturb=False, T_thresh=1e-2)["image"].detach() - target) ** 2).mean()))
+        with torch.no_grad():
+            w.sub_(sgn * eps * direction)
+    numeric = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(numeric - analytic) < 0.05 * abs(analytic) + 1e-6, (numeric, analytic)
+
+
+def test_update_extra_state_and_mark_untrained_grid():
+    ck, net = _teacher()
+    net.reset_extra_state()
+    assert not net.density_grid.any() and net.mean_count == 0
+    poses = np.stack([scene.orbit_pose(2.5, a, -20.0) for a in (0.0, 40.0)])    # two nearby narrow cameras: part of the volume is never seen
+    n_unseen = net.mark_untrained_grid(poses, scene.orbit_intrinsics(64, 64, 25.0))
+    assert 0 < n_unseen < 128 ** 3 and int((net.density_grid == -1).sum()) == n_unseen
+    torch.manual_seed(0)
+    net.local_step = 3
+    net.step_counter[:3, 0] = torch.tensor([100, 200, 600], dtype=torch.int32)
+    net.update_extra_state()
+    grid = net.density_grid.cpu().numpy()
+    assert (grid[0] == -1).sum() == n_unseen                       # unseen cells stay unseen
+    assert net.iter_density == 1 and net.mean_count == 300 and net.local_step == 0
+    seen = grid[0] >= 0
+    # the grid now holds density_scale * sigma at jittered cell centres: the oracle's sigma at the exact centres agrees in the bulk
+    idx = np.flatnonzero(seen)[::997]
+    coords = oracle.morton3D_invert(idx.astype(np.int32))
+    centres = (2 * coords.astype(np.float32) / 127 - 1) * np.float32(1 - 1 / 128)
+    sig, _ = oracle.nerf_forward(centres, np.tile(np.float32([0, 0, 1]), (len(idx), 1)), ck, 1.0)
+    inside = sig > 30
+    assert inside.sum() > 20 and (grid[0][idx][inside] > 5).mean() > 0.9
+    # bitfield == packbits(grid > min(mean, density_thresh)), bit for bit
+    thresh = min(net.mean_density, net.density_thresh)
+    assert np.array_equal(net.density_bitfield.cpu().numpy(), oracle.packbits(grid, thresh))
+    # the EMA-max rule: a second update never lowers a seen cell below decay * old
+    old = net.density_grid.clone()
+    net.update_extra_state(decay=0.95)
+    new = net.density_grid
+    ok = old >= 0
+    assert bool((new[ok] >= 0.95 * old[ok] - 1e-6).all()) and bool((new[~ok] == -1).all())
+    # partial-update branch (iter_density >= 16)
+    net.iter_density = 16
+    net.update_extra_state()
+    assert net.iter_density == 17 and bool((net.density_grid[~ok] == -1).all())
+
+
+def test_training_fits_the_teacher_images():
+    ck, teacher = _teacher()
+    Wd = 64
+    intr = scene.orbit_intrinsics(Wd, Wd, 50.0)
+    poses = np.stack([scene.orbit_pose(4.0, a, e) for a in (0.0, 60.0, 120.0, 180.0, 240.0, 300.0) for e in (-20.0, -50.0)]).astype(np.float32)
+    from pienerf_amd.nerf.utils import get_rays
+    images = []
+    with torch.no_grad():
+        for p in poses:
+            r = get_rays(T(p[None]), intr, Wd, Wd)
+            out = teacher.run_cuda(r["rays_o"], r["rays_d"], bg_color=1, max_steps=1024, T_thresh=1e-2)
+            images.append(out["image"].view(Wd, Wd, 3))
+    images = torch.stack(images)
+    assert float(images.std()) > 0.05
+    torch.manual_seed(1)
+    student = NeRFNetwork(encoding="hashgrid", bound=1.0, cuda_ray=True, density_thresh=10).to(DEV)
+    data = RayImageSet(T(poses), intr, images, generator=torch.Generator().manual_seed(2))
+    tr = Trainer(student, dict(dt_gamma=0, max_steps=512, T_thresh=1e-2), lr=1e-2, iters=400, num_rays=2048)
+    psnr0, _ = tr.evaluate(data, 0)
+    losses = tr.train(data, 400)
+    psnr1, out = tr.evaluate(data, 0)
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-20:]) < 0.25 * np.mean(losses[:5]), (losses[:5], losses[-20:])
+    assert psnr1 > psnr0 + 5 and psnr1 > 20, (psnr0, psnr1)
+    assert student.mean_count > 0 and student.iter_density == 25
+    # the trained bitfield keeps the object and drops most of the empty space
+    occ = np.unpackbits(student.density_bitfield.cpu().numpy()).mean()
+    assert 0.001 < occ < 0.6
