@@ -1,0 +1,100 @@
+"""Headless front end IO: reference-format checkpoints, PNG frames, poses.  CPU tests + one GPU end-to-end run."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from pienerf_amd import io, scene
+
+
+def _model(**kw):
+    from pienerf_amd.nerf.network import NeRFNetwork
+    return NeRFNetwork(encoding="hashgrid", bound=1.0, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1, **kw)
+
+
+def test_checkpoint_round_trip_in_reference_layout(tmp_path, ckpt):
+    a = _model()
+    a.load_checkpoint_dict(ckpt)
+    a.mean_count, a.mean_density = 4321, 0.125
+    a.density_grid.uniform_(-1, 5)
+    opt = torch.optim.Adam(a.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda it: 0.1 ** min(it / 100, 1))
+    p = io.save_checkpoint(a, str(tmp_path / "checkpoints" / "ngp_ep0007.pth"), epoch=7, global_step=700, optimizer=opt, lr_scheduler=sched, full=True)
+    raw = torch.load(p, weights_only=False)
+    # the keys Trainer.load_checkpoint reads (trainer.py:866-916)
+    assert {"epoch", "global_step", "stats", "mean_count", "mean_density", "model", "optimizer", "lr_scheduler"} <= set(raw)
+    assert {"encoder.embeddings", "encoder.offsets", "sigma_net.0.weight", "sigma_net.1.weight", "color_net.0.weight", "color_net.1.weight",
+            "color_net.2.weight", "density_grid", "density_bitfield", "step_counter", "aabb_train", "aabb_infer"} == set(raw["model"])
+    assert io.latest_checkpoint(str(tmp_path / "checkpoints")) == p and io.latest_checkpoint(str(tmp_path)) is None
+    b = _model()
+    info = io.load_checkpoint(b, p, model_only=False)
+    assert info["missing_keys"] == [] and info["unexpected_keys"] == [] and info["epoch"] == 7 and info["global_step"] == 700
+    assert b.mean_count == 4321 and b.mean_density == 0.125 and not b.training
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    # a bare state dict and a "best" checkpoint without density_grid (trainer.py:842-844) load too
+    torch.save(a.state_dict(), str(tmp_path / "bare.pth"))
+    io.load_checkpoint(_model(), str(tmp_path / "bare.pth"))
+    del raw["model"]["density_grid"]
+    torch.save(raw, str(tmp_path / "best.pth"))
+    assert io.load_checkpoint(_model(), str(tmp_path / "best.pth"))["missing_keys"] == ["density_grid"]
+
+
+def test_save_image_and_poses(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    img = rng.uniform(-0.2, 1.2, (6 * 5, 3)).astype(np.float32)
+    data = io.save_image(img, str(tmp_path / "o" / "img_0.png"), 5, 6)
+    back = np.asarray(Image.open(tmp_path / "o" / "img_0.png"))
+    assert back.shape == (6, 5, 3) and np.array_equal(back, data)
+    assert np.array_equal(data.reshape(-1, 3), (np.clip(img, 0, 1) * 255).astype(np.uint8))  # truncation, like main_render.py:16-17
+    # nerf_matrix_to_ngp: rows permuted (y, z, x), columns 1,2 negated, translation scaled + offset
+    P = rng.standard_normal((4, 4)).astype(np.float32)
+    Q = io.nerf_matrix_to_ngp(P, scale=0.8, offset=[0.1, 0.2, 0.3])
+    perm = [1, 2, 0]
+    assert np.allclose(Q[:3, 0], P[perm, 0]) and np.allclose(Q[:3, 1], -P[perm, 1]) and np.allclose(Q[:3, 2], -P[perm, 2])
+    assert np.allclose(Q[:3, 3], P[perm, 3] * 0.8 + np.float32([0.1, 0.2, 0.3])) and np.array_equal(Q[3], [0, 0, 0, 1])
+    d = tmp_path / "data"
+    d.mkdir()
+    assert io.get_pose(str(d), "0057") is None
+    frames = [{"file_path": f"./train/r_{i:04d}", "transform_matrix": (np.eye(4) * i).tolist()} for i in (56, 57)]
+    (d / "transforms.json").write_text(json.dumps({"frames": frames}))
+    assert np.array_equal(io.get_pose(str(d), "0057"), np.eye(4, dtype=np.float32) * 57) and io.get_pose(str(d), "0099") is None
+    (d / "transforms_train.json").write_text(json.dumps({"frames": frames[:1]}))
+    assert io.get_pose(str(d), "0057") is None  # transforms_train.json wins when present (main_render.py:29-33)
+
+
+@pytest.mark.gpu
+def test_main_render_end_to_end(tmp_path):
+    """PLY + .pth in, PNG frames out: the files equal what the harness renders from the in-memory synthetic assets."""
+    from PIL import Image
+    from pienerf_amd import main_render
+    from pienerf_amd.harness import SimRenderHarness
+    from pienerf_amd.nerf.network import NeRFNetwork
+    hgs = 1.2 * 0.1
+    cloud = scene.make_chair_points(sub_res=30, hgs=hgs)
+    scene.write_ply(str(tmp_path / "chair.ply"), cloud)
+    ck = scene.make_checkpoint(bound=1.0, seed=0)
+    net = NeRFNetwork(encoding="hashgrid", bound=1.0, cuda_ray=True, density_thresh=10).to("cuda").load_checkpoint_dict(ck)
+    io.save_checkpoint(net, str(tmp_path / "ws" / "checkpoints" / "ngp_ep0300.pth"), epoch=300)
+    args = main_render.parser().parse_args(["--ply", str(tmp_path / "chair.ply"), "--ckpt", str(tmp_path / "ws" / "checkpoints"), "--out",
+                                            str(tmp_path / "out"), "--frames", "3", "--W", "64", "--H", "48", "--sim_dx", "0.1", "--sim_iters", "4",
+                                            "--azimuth", "30", "--elevation", "-20", "--save_ply", "--save_ip_state", "--quiet"])
+    files = main_render.run(args)
+    assert [os.path.basename(f) for f in files] == ["img_0.png", "img_1.png", "img_2.png"]
+    opt = scene.default_opt(W=64, H=48, sim_dx=0.1, sim_iters=4)
+    ref = SimRenderHarness(opt, cloud=scene.cloud_from_ply(str(tmp_path / "chair.ply")), ckpt=ck, device="cuda:0")
+    pose = scene.orbit_pose(5.0, 30.0, -20.0)
+    for f in range(3):
+        out = ref.to_host(ref.step(pose=pose))
+        want = (np.clip(out["image"], 0, 1) * 255).astype(np.uint8)
+        got = np.asarray(Image.open(files[f]))
+        assert got.shape == (48, 64, 3) and np.array_equal(got, want)
+        assert np.array_equal(np.load(tmp_path / "out" / f"ip_pos_{f}.npy"), ref.model.p_def.cpu().numpy())
+    assert (want != 255).any()                                      # not an empty frame
+    pts = scene.read_ply(str(tmp_path / "out" / "points_2.ply"))
+    assert len(pts["x"]) == len(cloud["pos"])
+    moved = np.abs(np.stack([pts["x"], pts["y"], pts["z"]], 1) - cloud["pos"]).max()
+    assert 0 < moved < 0.05                                        # three substeps under gravity
