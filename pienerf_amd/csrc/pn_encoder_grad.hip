@@ -75,20 +75,27 @@ __global__ void __launch_bounds__(256) k_grid_dy_dx(const float* __restrict__ in
     }
 }
 
-// grad_embeddings += w * grad (gridencoder.cu:248-340); grad [L, B, C]
+// grad_embeddings += w * grad (gridencoder.cu:248-340); grad [L, B, C].
+// Device-scope fp32 atomics execute at the memory side on gfx950 (the per-XCD L2s are not coherent), ~10 ns each when they pile up
+// on one address, and that is exactly what the coarse levels do: samples arrive in ray order (pn_march_rays_train keeps them so), so
+// neighbouring lanes sit in the same cell of a 16..100-cell-wide level and hit the same 8 corners.  Each wave therefore folds runs of
+// equal target rows before touching memory: a lane starts a run when its row differs from the previous lane's, run ids come from a
+// ballot + prefix popcount, a 6-step shuffle tree adds a lane's partial to the lane `off` below it while both carry the same run id
+// (ids are monotonic, so equal ids = one contiguous run), and only run heads issue the atomic.  Fine hashed levels (no sharing)
+// degenerate to one atomic per lane, as before; coarse levels drop to one per cell crossing.
 template <uint32_t C>
 __global__ void __launch_bounds__(256) k_grid_backward(const float* __restrict__ grad, const float* __restrict__ inputs, PnGridLevels lv, uint32_t B,
                                                        int align_corners, uint32_t interp, float* __restrict__ grad_emb) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
     const uint32_t level = blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63;
     Cell c;
-    if (!locate(inputs + (size_t)b * 3, lv.scale[level], align_corners, interp, c)) return;
+    const bool valid = b < B && locate(inputs + (size_t)b * 3, lv.scale[level], align_corners, interp, c);
     float* __restrict__ gt = grad_emb + (size_t)lv.offset[level] * C;
     const LevelIdx LI = level_idx(lv, level, align_corners);
     float g[C];
 #pragma unroll
-    for (uint32_t ch = 0; ch < C; ch++) g[ch] = grad[((size_t)level * B + b) * C + ch];
+    for (uint32_t ch = 0; ch < C; ch++) g[ch] = valid ? grad[((size_t)level * B + b) * C + ch] : 0.0f;
 #pragma unroll
     for (uint32_t idx = 0; idx < 8; idx++) {
         float w = 1;
@@ -98,9 +105,28 @@ __global__ void __launch_bounds__(256) k_grid_backward(const float* __restrict__
             if ((idx & (1u << d)) == 0) { w *= 1 - c.pos[d]; pl[d] = c.pg[d]; }
             else { w *= c.pos[d]; pl[d] = c.pg[d] + 1; }
         }
-        const uint32_t index = grid_index3(LI, pl[0], pl[1], pl[2]) * C;
+        const uint32_t row = valid ? grid_index3(LI, pl[0], pl[1], pl[2]) : 0xFFFFFFFFu;
+        float v[C];
 #pragma unroll
-        for (uint32_t ch = 0; ch < C; ch++) unsafeAtomicAdd(gt + index + ch, w * g[ch]);
+        for (uint32_t ch = 0; ch < C; ch++) v[ch] = valid ? w * g[ch] : 0.0f;
+        const uint32_t prev = __shfl_up(row, 1, 64);
+        const bool head = lane == 0 || prev != row;
+        const unsigned long long heads = __ballot(head);
+        const uint32_t run = __popcll(heads & ((2ull << lane) - 1ull));  // number of heads at or below this lane: monotonic run id
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t run2 = __shfl_down(run, off, 64);
+            const bool take = lane + off < 64 && run2 == run;
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) {
+                const float o = __shfl_down(v[ch], off, 64);
+                if (take) v[ch] += o;
+            }
+        }
+        if (head && row != 0xFFFFFFFFu) {
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) unsafeAtomicAdd(gt + (size_t)row * C + ch, v[ch]);
+        }
     }
 }
 

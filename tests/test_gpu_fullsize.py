@@ -111,3 +111,45 @@ def test_full_size_substeps_match_the_oracle(full):
     p1, F1, dF1 = (t.cpu().numpy() for t in h.sim.get_IP_info())
     p2, F2, dF2 = ref.get_IP_info()
     assert np.abs(p1 - p2).max() < 1e-5 and np.abs(F1 - F2).max() < 1e-4
+
+
+def test_stress_configuration_dense_cloud_staged_batches():
+    """BASELINE configs[4]: the sub_res = 180 cloud (268 k points feeding the same 0.05 simulation grid), max_iter_num = 5 Newton steps,
+    num_seek_IP = 3, the 800x800 frame rendered in staged batches of 4096 rays (renderer.py:569-576's batching).  Rays are independent,
+    so the staged batches must reproduce the one-shot frame bit for bit; a strided subset is checked against the oracle."""
+    from pienerf_amd.harness import SimRenderHarness
+    opt = scene.default_opt(max_iter_num=5, num_seek_IP=3)
+    cloud = scene.make_chair_points(sub_res=180, hgs=opt["hash_grid_size"])
+    assert len(cloud["pos"]) > 250000
+    ckpt = scene.make_checkpoint(bound=opt["bound"], seed=0)
+    h = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device=DEV)
+    assert h.sim.n_IP > 3000
+    h.sim.update_force(h.sim.n_IP // 2, np.array([400.0, -150.0, 250.0]))
+    for _ in range(12):
+        h.sim.stepforward()
+    with torch.no_grad():
+        out = h.step(simulate=True, collect_stats=True)
+        torch.cuda.synchronize()
+        st = dict(h.model.last_stats)
+        assert st["err"] == 0 and st["alive_at_exit"] == 0 and st["samples"] > 500000
+        m = h.model
+        disp = (m.p_def - m.p_ori).abs().max().item()
+        assert 1e-3 < disp < 0.3                                     # visibly deformed, not blown up
+        o, d = out["rays_o"][0], out["rays_d"][0]
+        N = o.shape[0]
+        img = torch.empty(N, 3, device=DEV)
+        dep = torch.empty(N, device=DEV)
+        total = 0
+        for head in range(0, N, 4096):
+            r = m.render_deformed(o[None, head:head + 4096], d[None, head:head + 4096], collect_stats=True, frame_slot=1, **h.render_kwargs())
+            img[head:head + 4096], dep[head:head + 4096] = r["image"][0], r["depth_0"][0]
+            total += m.last_stats["samples"]
+    # n_step = clamp(N // n_alive, 1, 8) depends on the batch, so batches march a few more slots past a ray's T_thresh exit than the
+    # one-shot frame does (renderer.py:846); the composited pixels cannot depend on that
+    assert 0.95 * st["samples"] < total < 1.1 * st["samples"]
+    assert torch.equal(img, out["image"].reshape(-1, 3)) and torch.equal(dep, out["depth_0"].reshape(-1))
+    sel = np.arange(97, N, 211)
+    ip = dict(p_def=m.p_def.cpu().numpy(), p_ori=m.p_ori.cpu().numpy(), F=m.IP_F.cpu().numpy(), dF=m.IP_dF.cpu().numpy(), IP_dx=m.IP_dx)
+    ref = oracle.render_deformed(o.cpu().numpy()[sel], d.cpu().numpy()[sel], ip, ckpt, opt)
+    assert ref["samples"] > 2000
+    assert np.abs(out["image"].reshape(-1, 3)[sel].cpu().numpy() - ref["image"]).max() < 1e-4
