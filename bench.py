@@ -325,7 +325,7 @@ def main():
             "roofline": roofline,
         }
         res.update(extra)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # a reported baseline, timed on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(opt, cloud, ckpt, args.cpu_budget)
         print(json.dumps(res))
     if world > 1:
