@@ -224,6 +224,8 @@ def main():
                          "compute pipes of an XCD, more streams only time-slice)")
     ap.add_argument("--single-graph", action="store_true", help="whole step as ONE captured graph (sim on a forked stream), one frame at a time")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--dedicated-sim", choices=("auto", "on", "off"), default="auto",
+                    help="N > 1: the sim owner only simulates and broadcasts, the other ranks render (auto: from 3 ranks on, frames.dedicated_sim_default)")
     ap.add_argument("--force", type=float, nargs=3, default=None, metavar=("FX", "FY", "FZ"),
                     help="constant update_force on the middle integration point (SURVEY 8d, config 2 second pass); default: gravity only")
     args = ap.parse_args()
@@ -285,7 +287,8 @@ def main():
         # ROCm time-slices badly once more than 4 hardware queues are busy (launch structure): with the simulator stream
         # and the RCCL communication stream that leaves 2 render lanes per rank; a rank renders only every world-th frame anyway
         args.lanes = min(args.lanes, 2)
-        h.capture_frame_parallel(lanes=args.lanes, n_trips=args.trips)
+        dedicated = {"auto": None, "on": True, "off": False}[args.dedicated_sim]
+        h.capture_frame_parallel(lanes=args.lanes, n_trips=args.trips, dedicated_sim=dedicated)
 
         def run_steps(n):
             for _ in range(n * world):
@@ -321,7 +324,9 @@ def main():
                        "samples_per_frame": st["samples"], "trips_per_frame": st["trips"],
                        "launch": "eager" if (args.eager and world == 1) else (f"one hip graph per step, {args.trips} trips" if args.single_graph else
                                                                                    f"hip graphs, {args.trips} trips, {args.lanes} render(s) in flight, simulator running ahead"),
-                       "parallelism": f"frame-parallel x{world}, DOF broadcast over RCCL" if world > 1 else "single GPU"},
+                       "parallelism": (f"frame-parallel x{world}, DOF broadcast over RCCL, " + ("rank 0 simulates only, frames round-robin over the other ranks"
+                                                                                                if h._pipe["dedicated"] else "frames round-robin over all ranks"))
+                       if world > 1 else "single GPU"},
             "roofline": roofline,
         }
         res.update(extra)

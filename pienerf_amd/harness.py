@@ -304,11 +304,12 @@ class SimRenderHarness:
 
     # ------------------------------------------------------------------ frame-parallel over the GPUs of a node
     @torch.no_grad()
-    def capture_frame_parallel(self, lanes=3, n_trips=8, group=None, sim_owner=0):
+    def capture_frame_parallel(self, lanes=3, n_trips=8, group=None, sim_owner=0, dedicated_sim=None):
         """Multi-GPU form of capture_pipelined (BASELINE.json configs[3]): every rank calls step_frame_parallel()
         once per GLOBAL frame f.  The sim owner advances the simulator (running ahead on dof snapshots, exactly as on one GPU)
         and every snapshot is broadcast over `group` on a communication stream of its own — <= 82 KB per frame, the only
-        exchange; rank f % world renders frame f on its lane (f // world) % lanes from its copy of snapshot f.  Neither the
+        exchange; rank frames.frame_owner(f) renders frame f on one of its lanes from its copy of snapshot f (round-robin over all
+        ranks; with `dedicated_sim` — default from 3 ranks on — over every rank but the owner, which then only simulates).  Neither the
         substeps nor the broadcasts ever wait for a render, so the ranks' renders overlap freely; the job is bounded by the
         owner's substep rate (the simulator is time-sequential and does not shard)."""
         import torch.distributed as dist
@@ -318,7 +319,10 @@ class SimRenderHarness:
         self.capture_pipelined(lanes=lanes, n_trips=n_trips, sim_ahead=world * lanes, _extra_slots=world * lanes)
         p = self._pipe
         S = p["slots"]
-        p.update(world=world, rank=rank, owner=sim_owner, group=group, bc_next=0, comm=torch.cuda.Stream(self.device),
+        from .frames import dedicated_sim_default
+        dedicated = dedicated_sim_default(world) if dedicated_sim is None else bool(dedicated_sim and world > 1)
+        p.update(world=world, rank=rank, owner=sim_owner, group=group, bc_next=0, comm=torch.cuda.Stream(self.device), dedicated=dedicated,
+                 renderers=(world - 1 if dedicated else world), my_frames=0,
                  src=(dist.get_global_rank(group, sim_owner) if (on and group is not None) else sim_owner),
                  bc_done=[torch.cuda.Event() for _ in range(S)], ip_done=[torch.cuda.Event() for _ in range(S)],
                  bc_used=[False] * S, ip_used=[False] * S)
@@ -329,9 +333,10 @@ class SimRenderHarness:
         """One global frame.  Returns the lane's (static) outputs on the rank that renders it, None elsewhere."""
         import torch.distributed as dist
         p = self._pipe
+        from .frames import frame_owner
         f, world, rank, S = self.frame, p["world"], p["rank"], p["slots"]
-        mine = (f % world) == rank
-        lane = (f // world) % p["lanes"]
+        mine = frame_owner(f, world, p["owner"], p["dedicated"]) == rank
+        lane = p["my_frames"] % p["lanes"]
         sim_s, comm = p["sim_stream"], p["comm"]
         if rank == p["owner"]:
             with torch.cuda.stream(sim_s):
@@ -371,12 +376,17 @@ class SimRenderHarness:
                 p["ren_graph"][lane].replay()
                 p["done"][lane].record(ren_s)
             p["pending"][lane] = True
+            p["my_frames"] += 1
             out = p["out"][lane]
             if had_prev:
                 prev_done.synchronize()
                 st = self.model.render_status(synchronize=False, slot=lane)
                 if st["alive_at_exit"] > 0:
                     raise RuntimeError(f"frame-parallel step ran {p['trips']} render trips but {st['alive_at_exit']} rays were still alive")
+        elif p["dedicated"] and rank == p["owner"] and world > 1:
+            # a rank that never renders has nothing that paces its host: wait until this frame's snapshot has been delivered, so that
+            # the owner stays at most `ahead` frames in front of the slowest receiver instead of enqueueing the whole job at once
+            p["bc_done"][f % S].synchronize()
         self.frame += 1
         return out
 

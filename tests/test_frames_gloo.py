@@ -17,7 +17,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_frames, out_dir):
+def _worker(rank, world, port, n_frames, out_dir, dedicated=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -38,13 +38,16 @@ def _worker(rank, world, port, n_frames, out_dir):
     broadcast_tensors(ckpt, src=0)
     assert all(float(t.flatten()[0]) in (0.0, 10.0) for t in ckpt)  # every rank now holds rank 0's "checkpoint"
 
-    fp = FrameParallel(sim_step, lambda: state["dof"], lambda t: state.__setitem__("dof", t.clone()), render)
+    fp = FrameParallel(sim_step, lambda: state["dof"], lambda t: state.__setitem__("dof", t.clone()), render, dedicated_sim=dedicated)
     res = fp.run(n_frames)
     ids = fp.gather_frame_ids(res)
-    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([[f, v] for f, v in sorted(res.items())]))
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([[f, v] for f, v in sorted(res.items())]).reshape(-1, 2))
     if rank == 0:
         assert state["steps"] == n_frames
-        assert ids == [list(range(0, n_frames, 2)), list(range(1, n_frames, 2))]
+        if fp.dedicated_sim:  # the owner renders nothing; frames go round-robin over the other ranks
+            assert ids == [[]] + [list(range(r - 1, n_frames, world - 1)) for r in range(1, world)]
+        else:
+            assert ids == [list(range(r, n_frames, world)) for r in range(world)]
     else:
         assert state["steps"] == 0
     dist.barrier()
@@ -59,6 +62,26 @@ def test_frame_parallel_two_ranks(tmp_path):
     got = got[np.argsort(got[:, 0])]
     assert list(got[:, 0].astype(int)) == list(range(n_frames))
     # serial reference: frame f sees the state before substep f
+    dof = np.arange(30 * 7, dtype=np.float64)
+    want = []
+    for f in range(n_frames):
+        want.append(dof.sum())
+        dof = dof * 1.01 + 0.5
+    assert np.allclose(got[:, 1], want, rtol=0, atol=1e-9)
+
+
+def test_frame_parallel_three_ranks_dedicated_sim_owner(tmp_path):
+    """From 3 ranks on the sim owner only simulates and broadcasts (frames.dedicated_sim_default); the frames are the serial sequence."""
+    from pienerf_amd.frames import dedicated_sim_default, frame_owner
+    assert [dedicated_sim_default(w) for w in (1, 2, 3, 8)] == [False, False, True, True]
+    assert [frame_owner(f, 4, 0, True) for f in range(7)] == [1, 2, 3, 1, 2, 3, 1]
+    assert [frame_owner(f, 4, 2, True) for f in range(7)] == [0, 1, 3, 0, 1, 3, 0]
+    assert [frame_owner(f, 4, 0, False) for f in range(5)] == [0, 1, 2, 3, 0]
+    n_frames = 8
+    mp.spawn(_worker, args=(3, _free_port(), n_frames, str(tmp_path)), nprocs=3, join=True)
+    got = np.concatenate([np.load(tmp_path / f"r{r}.npy") for r in range(3)])
+    got = got[np.argsort(got[:, 0])]
+    assert list(got[:, 0].astype(int)) == list(range(n_frames)) and len(np.load(tmp_path / "r0.npy")) == 0
     dof = np.arange(30 * 7, dtype=np.float64)
     want = []
     for f in range(n_frames):

@@ -30,22 +30,23 @@ def _scene():
     return opt, cloud, ckpt
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, dedicated=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pienerf_amd.harness import SimRenderHarness
     opt, cloud, ckpt = _scene()
-    h = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device="cuda:0").capture_frame_parallel(lanes=2, n_trips=8)
+    from pienerf_amd.frames import frame_owner
+    h = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device="cuda:0").capture_frame_parallel(lanes=2, n_trips=8, dedicated_sim=dedicated)
     p = h._pipe
-    assert (p["world"], p["rank"]) == (world, rank)
+    assert (p["world"], p["rank"]) == (world, rank) and p["dedicated"] == bool(dedicated)
     got = {}
     for f in range(N_FRAMES):
         out = h.step_frame_parallel()
-        assert (out is not None) == (f % world == rank)
+        assert (out is not None) == (frame_owner(f, world, 0, bool(dedicated)) == rank)
         if out is not None:
-            p["done"][(f // world) % 2].synchronize()  # the lane's buffers are reused two of this rank's frames later
+            p["done"][len(got) % 2].synchronize()  # the lane's buffers are reused two of this rank's frames later
             got[f] = out["image"].clone().cpu().numpy()
     h.drain_pipeline()
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), **{str(k): v for k, v in got.items()})
@@ -57,7 +58,9 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_frame_parallel_two_ranks_on_gpu(tmp_path):
+@pytest.mark.parametrize("dedicated", [False, True])
+def test_frame_parallel_two_ranks_on_gpu(tmp_path, dedicated):
+    """dedicated = True forces the >= 3-rank policy onto two ranks: rank 0 only simulates and broadcasts, rank 1 renders every frame."""
     import torch.multiprocessing as mp
     from pienerf_amd.harness import SimRenderHarness
     opt, cloud, ckpt = _scene()
@@ -66,10 +69,11 @@ def test_frame_parallel_two_ranks_on_gpu(tmp_path):
     eager.synchronize()
     del eager
     torch.cuda.empty_cache()
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), dedicated), nprocs=2, join=True)
     got = {}
     for r in range(2):
         with np.load(tmp_path / f"r{r}.npz") as z:
+            assert not (dedicated and r == 0 and z.files)
             got.update({int(k): z[k] for k in z.files})
     assert sorted(got) == list(range(N_FRAMES))
     for f in range(N_FRAMES):
