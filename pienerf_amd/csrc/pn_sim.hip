@@ -432,6 +432,80 @@ __global__ void __launch_bounds__(1024) k_rhs_gather_csr(int n_k, const int* __r
     }
 }
 
+// Balanced form of the gather used by the step driver.  One workgroup per kernel leaves the launch as long as its longest list (chair:
+// 770 entries against a mean of 206, and only 139 of 256 CUs busy), so the lists are cut into chunks of PN_GCH entries, one
+// workgroup per chunk, each writing its 30 partial sums; the chunk sums of a kernel are added in ascending chunk order by the
+// consumer (k_matvec3_gathered builds its X operand from them in LDS), so the result is still reproducible bit for bit.
+// k_gather_plan (once per substep, one workgroup) lays the chunks out: kc_bg[k] = first chunk of kernel k, chunk[b] = (first entry, count).
+#define PN_GCH 128
+__global__ void __launch_bounds__(512) k_gather_plan(int n_k, int chunks_max, const int* __restrict__ csr_bg, const int* __restrict__ csr_cnt,
+                                                     int* __restrict__ kc_bg, int2* __restrict__ chunk) {
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int k = 0; k < n_k; k++) { kc_bg[k] = acc; acc += (csr_cnt[k] + PN_GCH - 1) / PN_GCH; }
+        kc_bg[n_k] = acc;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n_k; k += blockDim.x)  // chunk[b] = (first entry, entry count): one load tells a workgroup its work
+        for (int b = kc_bg[k]; b < kc_bg[k + 1]; b++) {
+            const int first = (b - kc_bg[k]) * PN_GCH;
+            chunk[b] = make_int2(csr_bg[k] + first, min(PN_GCH, csr_cnt[k] - first));
+        }
+    for (int b = kc_bg[n_k] + threadIdx.x; b < chunks_max; b += blockDim.x) chunk[b] = make_int2(0, 0);  // unused tail of the grid
+}
+
+__global__ void __launch_bounds__(1024) k_rhs_gather_chunk(const int2* __restrict__ chunk, const double* __restrict__ dNx_csr,
+                                                           const double* __restrict__ P_csr, double* __restrict__ part) {
+    PN_SIM_PRIO();
+    constexpr int NS = PN_GATHER_SLOTS;
+    __shared__ double red[NS][30][3];
+    const int b = blockIdx.x;
+    const int2 ch = chunk[b];
+    const int bg = ch.x, cnt = ch.y;
+    if (cnt == 0) return;  // the grid is the host-side upper bound 8 n_IP / PN_GCH + n_k
+    const int t = threadIdx.x;
+    const int slot = t / 30, q = t - slot * 30, c = q / 10;
+    if (t < NS * 30) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        const double* __restrict__ g = dNx_csr + (size_t)bg * 30 + q;
+        const double* __restrict__ pc = P_csr + (size_t)bg * 9 + c;
+        double gv[4], p0[4], p1[4], p2[4];  // PN_GCH / NS = 4 entries per slot, all loads independent
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = slot + NS * u;
+            const bool on = e < cnt;
+            const size_t ee = on ? (size_t)e : 0;
+            gv[u] = on ? g[ee * 30] : 0.0;
+            p0[u] = pc[ee * 9]; p1[u] = pc[ee * 9 + 3]; p2[u] = pc[ee * 9 + 6];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a0 += p0[u] * gv[u]; a1 += p1[u] * gv[u]; a2 += p2[u] * gv[u]; }
+        red[slot][q][0] = a0; red[slot][q][1] = a1; red[slot][q][2] = a2;
+    }
+    __syncthreads();
+    if (t < 30) {
+        const int x = t / 3, r = t - x * 3;
+        double s = 0.0;
+        for (int sl = 0; sl < NS; sl++)
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) s += red[sl][cc * 10 + x][r];
+        part[(size_t)b * 30 + t] = s;
+    }
+}
+
+// out = momentum + (chunk sums of the row's kernel, ascending chunk order) - rhs_rest: one thread per output row
+__global__ void __launch_bounds__(256) k_gather_sum(int n30, const int* __restrict__ kc_bg, const double* __restrict__ part,
+                                                    const double* __restrict__ momentum, const double* __restrict__ rhs_rest, double* __restrict__ out) {
+    PN_SIM_PRIO();
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n30) return;
+    const int k = o / 30, q = o - k * 30;
+    const int b0 = kc_bg[k], b1 = kc_bg[k + 1];
+    double sum = 0.0;
+    for (int b = b0; b < b1; b++) sum += part[(size_t)b * 30 + q];
+    out[o] = momentum[o] + sum - rhs_rest[o];
+}
+
 extern "C" int pn_sim_collect_rhs(int n_k, double dx, const int* csr_bg, const int* csr_cnt, const int* csr_buf, const double* mu, const double* lam,
                                   const double* dNx, const double* RF, const double* VF, double* rhs, void* stream) {
     PN_REQUIRE(n_k > 0 && csr_bg && csr_cnt && csr_buf && mu && lam && dNx && RF && VF && rhs);
@@ -491,6 +565,60 @@ __global__ void __launch_bounds__(256) k_matvec3(int n, const double* __restrict
     }
 }
 
+// dof = dof_rest + Ainv @ (momentum + gathered - rhs_rest) with the right-hand side assembled in LDS from the chunk sums of
+// k_rhs_gather_chunk (ascending chunk order per kernel: a fixed summation tree).  The matrix rows stream from L2 exactly as in
+// k_matvec3; X comes from LDS instead of four L2 reads of the whole vector per workgroup.
+__global__ void __launch_bounds__(256) k_matvec3_gathered(int n, const double* __restrict__ A, double* __restrict__ Y, const double* __restrict__ add1,
+                                                          const double* __restrict__ momentum, const double* __restrict__ rhs_rest,
+                                                          const double* __restrict__ part, const int* __restrict__ kc_bg) {
+    PN_SIM_PRIO();
+    extern __shared__ double xs[];  // [n * 3]
+    for (int o = threadIdx.x; o < n * 3; o += 256) {
+        const int k = o / 30, q = o - k * 30;
+        double sum = 0.0;
+        for (int b = kc_bg[k]; b < kc_bg[k + 1]; b++) sum += part[(size_t)b * 30 + q];
+        xs[o] = momentum[o] + sum - rhs_rest[o];
+    }
+    __syncthreads();
+    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (i0 >= n) return;
+    const bool two = i0 + 1 < n;
+    const int lane = threadIdx.x & 63;
+    const double* __restrict__ a = A + (size_t)i0 * n;
+    const double* __restrict__ b = A + (size_t)(two ? i0 + 1 : i0) * n;
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    int j = lane;
+    for (; j + 192 < n; j += 256) {
+        double wa[4], wb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { wa[u] = a[j + 64 * u]; wb[u] = b[j + 64 * u]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int jj = j + 64 * u;
+            const double x0 = xs[jj * 3], x1 = xs[jj * 3 + 1], x2 = xs[jj * 3 + 2];
+            s[0] += wa[u] * x0; s[1] += wa[u] * x1; s[2] += wa[u] * x2;
+            s[3] += wb[u] * x0; s[4] += wb[u] * x1; s[5] += wb[u] * x2;
+        }
+    }
+    for (; j < n; j += 64) {
+        const double wa = a[j], wb = b[j];
+        const double x0 = xs[j * 3], x1 = xs[j * 3 + 1], x2 = xs[j * 3 + 2];
+        s[0] += wa * x0; s[1] += wa * x1; s[2] += wa * x2;
+        s[3] += wb * x0; s[4] += wb * x1; s[5] += wb * x2;
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s[q] += shfl_xor_d(s[q], o);
+    if (lane < (two ? 6 : 3)) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) if (q == lane) v = s[q];
+        const size_t o = (size_t)i0 * 3 + lane;
+        Y[o] = add1[o] + v;
+    }
+}
+
 extern "C" int pn_sim_matvec3(int n, const double* A, const double* X, double* Y, void* stream) {
     PN_REQUIRE(n > 0 && A && X && Y);
     k_matvec3<<<pn_div_up(n, 8), 256, 0, (hipStream_t)stream>>>(n, A, X, Y, 0, nullptr, nullptr);
@@ -516,7 +644,12 @@ __global__ void __launch_bounds__(256) k_step_end(int n3, double dt, const doubl
     vel[i] = (dof[i] - last[i]) / dt * 0.998;  // solver.py:602
 }
 
-extern "C" uint64_t pn_sim_work_doubles(int n_k, int n_IP) { return (uint64_t)n_k * 30 * 4 + (uint64_t)n_IP * 9 + (uint64_t)n_IP * 8 * 9; }
+static inline uint64_t pn_gather_chunks_max(int n_k, int n_IP) { return (uint64_t)n_IP * 8 / PN_GCH + (uint64_t)n_k; }
+// tilde, last, momentum, tot [n_k*30 each] | P [n_IP*9] | P_csr [n_IP*8*9] | chunk sums [chunks_max*30] | plan: kc_bg [n_k+1] ints + chunk [chunks_max] int2
+extern "C" uint64_t pn_sim_work_doubles(int n_k, int n_IP) {
+    const uint64_t ch = pn_gather_chunks_max(n_k, n_IP);
+    return (uint64_t)n_k * 30 * 4 + (uint64_t)n_IP * 9 + (uint64_t)n_IP * 8 * 9 + ch * 30 + ((uint64_t)n_k + 2) / 2 + 1 + ch + 1;
+}
 
 extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, double dx, const int* topo, const int* csr_bg, const int* csr_cnt,
                                   const int* csr_buf, const double* mu, const double* lam, const double* dNx, const double* dNx_csr,
@@ -532,13 +665,42 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
     double* tot = work + 3 * (size_t)n3;
     double* P = work + 4 * (size_t)n3;
     double* P_csr = P + (size_t)n_IP * 9;
+    const uint64_t chunks_max = pn_gather_chunks_max(n_k, n_IP);
+    double* part = P_csr + (size_t)n_IP * 8 * 9;
+    int* kc_bg = reinterpret_cast<int*>(part + chunks_max * 30);
+    int2* chunk = reinterpret_cast<int2*>(kc_bg + ((n_k + 2) & ~1));
     const double dx3 = pow(dx, 3.0);
+    const bool pcsr = dNx_csr && csr_pos;
+    // balanced gather (chunked lists + right-hand side assembled inside the matvec); PN_SIM_GATHER=kernel keeps one workgroup per kernel
+    static const bool chunked_ok = [] { const char* v = getenv("PN_SIM_GATHER"); return !(v && strcmp(v, "kernel") == 0); }();
+    static const bool fused_x = [] { const char* v = getenv("PN_SIM_GATHER"); return v && strcmp(v, "fused") == 0; }();
+    const size_t xs_bytes = (size_t)n3 * sizeof(double);
+    const bool chunked = pcsr && chunked_ok && xs_bytes <= 160 * 1024 - 1024;
+    if (chunked) {
+        if (xs_bytes > 48 * 1024) {
+            static size_t granted = 0;
+            if (xs_bytes > granted) {
+                PN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_matvec3_gathered), hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_bytes));
+                granted = xs_bytes;
+            }
+        }
+        k_gather_plan<<<1, 512, 0, st>>>(n_k, (int)chunks_max, csr_bg, csr_cnt, kc_bg, chunk);
+    }
     k_step_begin<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, dt, dof, dof_vel, tilde, last);
     k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Mmat, tilde, momentum, 1, dof_f, rhs_gravity);  // compute_momentum (:574-576)
     for (int it = 0; it < iters; it++) {
-        const bool pcsr = dNx_csr && csr_pos;
         k_elastic<<<pn_div_up((uint64_t)n_IP * 8, 256), 256, 0, st>>>(n_IP, topo, dNx, dof, nullptr, nullptr, nullptr, pcsr ? nullptr : P, mu, lam, dx3,
                                                                       pcsr ? csr_pos : nullptr, pcsr ? P_csr : nullptr);
+        if (chunked) {
+            k_rhs_gather_chunk<<<(uint32_t)chunks_max, 1024, 0, st>>>(chunk, dNx_csr, P_csr, part);
+            if (fused_x) {
+                k_matvec3_gathered<<<pn_div_up(n, 8), 256, xs_bytes, st>>>(n, Ainv, dof, dof_rest, momentum, rhs_rest, part, kc_bg);
+            } else {
+                k_gather_sum<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, kc_bg, part, momentum, rhs_rest, tot);
+                k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Ainv, tot, dof, 2, dof_rest, nullptr);
+            }
+            continue;
+        }
         if (dNx_csr)  // CSR-ordered copy of dNx available: the coalesced one-workgroup-per-kernel gather
             k_rhs_gather_csr<<<n_k, 1024, 0, st>>>(n_k, csr_bg, csr_cnt, csr_buf, dNx_csr, P, pcsr ? P_csr : nullptr, momentum, rhs_rest, tot);
         else
