@@ -830,6 +830,11 @@ __global__ void __launch_bounds__(256) k_frame_finish(uint32_t N, float bg, cons
 //     hash itself (count -> scan -> cursor fill -> per-cell sort, = k_pig_*) and the per-cell candidate-list offsets (k_nb_count
 //     + scan).  The phases talk through global memory (L2) with relaxed agent-scope atomic loads where a value was produced by
 //     an atomic or by another thread of the block, and __syncthreads() in between.
+//     LARGE = false: everything in this one workgroup, per-cell counters in LDS (two 16-bit counters per word: up to ~290 k cells minus the
+//     staged index table fit the 160 KB).  LARGE = true: the grid is too large for that (bound 2 with --cut: the spatial hash spans +-bound,
+//     67^3 = 300 k cells at hgs 0.06) — this kernel only does the bounding box / resolution part and the tables are built by the
+//     multi-workgroup kernels of get_pnts_in_grids (k_pig_*) + k_nb_count + a second scan; same tables, bit for bit.
+template <bool LARGE>
 __global__ void __launch_bounds__(1024) k_frame_tables(const float* __restrict__ p_def, int n_vtx, int cut, float bound, float hgs, int max_cells,
                                                        PnFrameDev* dev, int* pig_cnt, int* pig_bgn, int* pig_idx, int* pig_cursor, int swap,
                                                        int* nb_cnt, int* nb_bgn, int* nb_cursor) {
@@ -877,6 +882,7 @@ __global__ void __launch_bounds__(1024) k_frame_tables(const float* __restrict__
     const int n_grid = sh_res[3], r0 = sh_res[0], r1 = sh_res[1], r2 = sh_res[2];
     const float b0 = sh_min[0], b1 = sh_min[1], b2 = sh_min[2];
     if (n_grid == 0) { if (threadIdx.x == 0) nb_bgn[0] = 0; return; }
+    if (LARGE) return;  // the tables themselves are built by the multi-workgroup kernels (pn_frame_prologue)
     for (int g = threadIdx.x; g < (n_grid + 1) / 2; g += blockDim.x) cnt2[g] = 0u;
     __syncthreads();
     auto cell_of = [&](int p) {  // p2g, nerf/utils.py:389-407
@@ -1156,14 +1162,24 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     const int swap = (o->num_seek_IP == 1) ? 1 : 0;
     // two 16-bit cell counters per LDS word + the staged point-index table
     const size_t tables_lds = ((size_t)f->max_cells + 1) / 2 * sizeof(unsigned) + (size_t)f->max_vtx * sizeof(int);
-    PN_REQUIRE(tables_lds <= 150 * 1024);
-    static size_t tables_lds_set = 0;
-    if (tables_lds > tables_lds_set) {  // dynamic LDS above 64 KB has to be opted into (gfx950: 160 KB per workgroup)
-        PN_HIP_CHECK(hipFuncSetAttribute((const void*)k_frame_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tables_lds));
-        tables_lds_set = tables_lds;
+    const bool large = tables_lds > 150 * 1024;  // grid too large for the one-workgroup LDS build
+    if (!large) {
+        static size_t tables_lds_set = 0;
+        if (tables_lds > tables_lds_set) {  // dynamic LDS above 64 KB has to be opted into (gfx950: 160 KB per workgroup)
+            PN_HIP_CHECK(hipFuncSetAttribute((const void*)k_frame_tables<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tables_lds));
+            tables_lds_set = tables_lds;
+        }
+        k_frame_tables<false><<<1, 1024, tables_lds, st>>>(p_def, n_vtx, o->cut, o->bound, o->hash_grid_size, (int)f->max_cells, f->dev, f->pig_cnt,
+                                                           f->pig_bgn, f->pig_idx, f->pig_cursor, swap, f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor);
+    } else {
+        k_frame_tables<true><<<1, 1024, 0, st>>>(p_def, n_vtx, o->cut, o->bound, o->hash_grid_size, (int)f->max_cells, f->dev, f->pig_cnt, f->pig_bgn,
+                                                 f->pig_idx, f->pig_cursor, swap, f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor);
+        rc = pig_build(n_vtx, (int)f->max_cells, n_grid_dev, p_def, bbmin, o->hash_grid_size, res, f->pig_cnt, f->pig_bgn, f->pig_idx, f->pig_cursor, err, st);
+        if (rc) return rc;
+        const int gz = (int)std::min(pn_div_up(f->max_cells, 256), 1024u);
+        k_nb_count<<<gz, 256, 0, st>>>((int)f->max_cells, n_grid_dev, res, f->pig_cnt, swap, f->side.nb_cnt);
+        k_pig_scan<<<1, 1024, 0, st>>>((int)f->max_cells, n_grid_dev, f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor);
     }
-    k_frame_tables<<<1, 1024, tables_lds, st>>>(p_def, n_vtx, o->cut, o->bound, o->hash_grid_size, (int)f->max_cells, f->dev, f->pig_cnt, f->pig_bgn,
-                                       f->pig_idx, f->pig_cursor, swap, f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor);
     const int list_blocks = (int)std::min(pn_div_up((uint64_t)f->max_cells * 8, 256), 2048u);
     const int pack_blocks = (int)pn_div_up((uint64_t)n_vtx * 44, 256);
     k_frame_lists<<<list_blocks + pack_blocks, 256, 0, st>>>((int)f->max_cells, n_grid_dev, res, f->pig_cnt, f->pig_bgn, f->pig_idx, p_def, swap,

@@ -153,3 +153,44 @@ def test_stress_configuration_dense_cloud_staged_batches():
     ref = oracle.render_deformed(o.cpu().numpy()[sel], d.cpu().numpy()[sel], ip, ckpt, opt)
     assert ref["samples"] > 2000
     assert np.abs(out["image"].reshape(-1, 3)[sel].cpu().numpy() - ref["image"]).max() < 1e-4
+
+
+def test_trex_configuration_full_size():
+    """BASELINE configs[2] at its full size: 1008x756 (762 048 rays), bound 2 (two density cascades, 4096-resolution hash grid),
+    dt_gamma 1/128, --cut with the README's cut_bounds (samples outside are rendered un-warped as static background), max_steps 300,
+    T_thresh 5e-2, num_seek_IP 1, max_iter_num 1, sim_dx 0.05 (README.md:134 of the reference; synthetic assets, orbit pose).  Parity through
+    the oracle on a strided ray subset, the subset rendered alone == the full frame's pixels bit for bit, and compositing invariants."""
+    from pienerf_amd.harness import SimRenderHarness
+    W, H = 1008, 756
+    opt = scene.default_opt(bound=2.0, scale=0.33, dt_gamma=1.0 / 128, max_steps=300, T_thresh=5e-2, num_seek_IP=1, max_iter_num=1, cut=True,
+                            cut_bounds=[-0.62, 1.0, -0.82, 0.42, -0.52, 0.28], sim_dx=0.05, W=W, H=H, radius=4.5)
+    cloud = scene.make_chair_points(hgs=opt["hash_grid_size"], bound=opt["bound"])
+    ckpt = scene.make_checkpoint(bound=2.0, seed=3)
+    assert ckpt["cascade"] == 2
+    h = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device=DEV)
+    h.sim.update_force(h.sim.n_IP // 2, np.array([250.0, 120.0, -180.0]))
+    for _ in range(10):
+        h.sim.stepforward()
+    pose = scene.orbit_pose(4.5, 25.0, -10.0)
+    with torch.no_grad():
+        out = h.step(pose=pose, intrinsics=scene.orbit_intrinsics(W, H, 50.0), W=W, H=H, simulate=True, collect_stats=True)
+        torch.cuda.synchronize()
+    st = dict(h.model.last_stats)
+    N = W * H
+    assert out["image"].shape == (1, H, W, 3) and st["err"] == 0 and st["alive_at_exit"] == 0 and st["samples"] > 100000 and st["trips"] >= 2
+    m = h.model
+    ip = dict(p_def=m.p_def.cpu().numpy(), p_ori=m.p_ori.cpu().numpy(), F=m.IP_F.cpu().numpy(), dF=m.IP_dF.cpu().numpy(), IP_dx=m.IP_dx)
+    assert 1e-3 < np.abs(ip["p_def"] - ip["p_ori"]).max() < 0.3
+    sel = np.arange(11, N, 251)
+    o, d = out["rays_o"].reshape(N, 3)[sel].cpu().numpy(), out["rays_d"].reshape(N, 3)[sel].cpu().numpy()
+    ref = oracle.render_deformed(o, d, ip, ckpt, opt)
+    img = out["image"].reshape(N, 3)[sel].cpu().numpy()
+    assert ref["samples"] > 500
+    assert np.abs(img - ref["image"]).max() < 1e-4
+    with torch.no_grad():
+        sub = m.render_deformed(T(o)[None], T(d)[None], staged=True, bg_color=None, perturb=False, frame_slot=1, **h.render_kwargs())
+    assert np.array_equal(sub["image"].reshape(-1, 3).cpu().numpy(), img)
+    ws = sub["weights_sum"].cpu().numpy()
+    assert ws.min() >= 0.0 and ws.max() <= 1.0 + 1e-5 and np.abs(ws - ref["weights_sum"]).max() < 1e-4
+    full_img = out["image"].reshape(N, 3)
+    assert float(full_img.min()) >= 0.0 and float(full_img.max()) <= 1.0 + 1e-5
