@@ -194,3 +194,40 @@ def test_trex_configuration_full_size():
     assert ws.min() >= 0.0 and ws.max() <= 1.0 + 1e-5 and np.abs(ws - ref["weights_sum"]).max() < 1e-4
     full_img = out["image"].reshape(N, 3)
     assert float(full_img.min()) >= 0.0 and float(full_img.max()) <= 1.0 + 1e-5
+
+
+def test_full_kernel_grid_scene():
+    """The largest simulator the chair options allow: a solid block filling the box -> all 7^3 = 343 GMLS kernels (10 290 DOFs, the SURVEY §8
+    upper bound), 39 k integration points (11x the chair), 314 k cloud points.  No oracle at this size (its dense CPU initialisation takes
+    minutes); size-independent properties instead: finite bounded motion, no device error flags, staged ray batches == the one-shot frame
+    bit for bit, two harnesses built from scratch agree bit for bit."""
+    from pienerf_amd.harness import SimRenderHarness
+    boxes = np.array([(-0.85, 0.85, -0.85, 0.85, -0.85, 0.85)])
+    opt = scene.default_opt(W=320, H=320)
+    cloud = scene.make_chair_points(sub_res=80, hgs=opt["hash_grid_size"], boxes=boxes)
+    ck = scene.make_checkpoint(bound=1.0, seed=0, solid=lambda p, margin=0.0: scene.chair_solid(p, margin, boxes=boxes))
+    outs = []
+    for _ in range(2):
+        h = SimRenderHarness(opt, cloud=cloud, ckpt=ck, device=DEV)
+        assert h.sim.n_k == 343 and h.sim.n_IP > 35000
+        h.sim.update_force(h.sim.n_IP // 2, np.array([3000.0, 1000.0, -2000.0]))
+        with torch.no_grad():
+            for _ in range(4):
+                out = h.step(collect_stats=True)
+            torch.cuda.synchronize()
+        st = dict(h.model.last_stats)
+        assert st["err"] == 0 and st["alive_at_exit"] == 0 and st["samples"] > 100000
+        assert bool(torch.isfinite(h.sim.dof).all())
+        disp = (h.model.p_def - h.model.p_ori).abs().max().item()
+        assert 1e-4 < disp < 0.2
+        outs.append((out["image"].clone(), h.sim.dof.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    with torch.no_grad():
+        o, d = out["rays_o"][0], out["rays_d"][0]
+        full = h.step(simulate=False)
+        img = torch.empty_like(full["image"].reshape(-1, 3))
+        for head in range(0, o.shape[0], 30000):
+            r = h.model.render_deformed(o[None, head:head + 30000], d[None, head:head + 30000], frame_slot=1, **h.render_kwargs())
+            img[head:head + 30000] = r["image"][0]
+    assert torch.equal(img, full["image"].reshape(-1, 3))
+    assert 0.0 <= float(img.min()) and float(img.max()) <= 1.0 + 1e-5 and float(img.min()) < 0.9
