@@ -437,7 +437,9 @@ __global__ void __launch_bounds__(1024) k_rhs_gather_csr(int n_k, const int* __r
 // workgroup per chunk, each writing its 30 partial sums; the chunk sums of a kernel are added in ascending chunk order by the
 // consumer (k_matvec3_gathered builds its X operand from them in LDS), so the result is still reproducible bit for bit.
 // k_gather_plan (once per substep, one workgroup) lays the chunks out: kc_bg[k] = first chunk of kernel k, chunk[b] = (first entry, count).
-#define PN_GCH 128
+#ifndef PN_GCH
+#define PN_GCH 128  // entries per chunk; the chunk kernel runs PN_GCH / 4 slots x 30 threads
+#endif
 __global__ void __launch_bounds__(512) k_gather_plan(int n_k, int chunks_max, const int* __restrict__ csr_bg, const int* __restrict__ csr_cnt,
                                                      int* __restrict__ kc_bg, int2* __restrict__ chunk) {
     if (threadIdx.x == 0) {
@@ -454,10 +456,10 @@ __global__ void __launch_bounds__(512) k_gather_plan(int n_k, int chunks_max, co
     for (int b = kc_bg[n_k] + threadIdx.x; b < chunks_max; b += blockDim.x) chunk[b] = make_int2(0, 0);  // unused tail of the grid
 }
 
-__global__ void __launch_bounds__(1024) k_rhs_gather_chunk(const int2* __restrict__ chunk, const double* __restrict__ dNx_csr,
-                                                           const double* __restrict__ P_csr, double* __restrict__ part) {
+__global__ void __launch_bounds__(PN_GCH * 8) k_rhs_gather_chunk(const int2* __restrict__ chunk, const double* __restrict__ dNx_csr,
+                                                                  const double* __restrict__ P_csr, double* __restrict__ part) {
     PN_SIM_PRIO();
-    constexpr int NS = PN_GATHER_SLOTS;
+    constexpr int NS = PN_GCH / 4;
     __shared__ double red[NS][30][3];
     const int b = blockIdx.x;
     const int2 ch = chunk[b];
@@ -692,7 +694,7 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
         k_elastic<<<pn_div_up((uint64_t)n_IP * 8, 256), 256, 0, st>>>(n_IP, topo, dNx, dof, nullptr, nullptr, nullptr, pcsr ? nullptr : P, mu, lam, dx3,
                                                                       pcsr ? csr_pos : nullptr, pcsr ? P_csr : nullptr);
         if (chunked) {
-            k_rhs_gather_chunk<<<(uint32_t)chunks_max, 1024, 0, st>>>(chunk, dNx_csr, P_csr, part);
+            k_rhs_gather_chunk<<<(uint32_t)chunks_max, PN_GCH * 8, 0, st>>>(chunk, dNx_csr, P_csr, part);
             if (fused_x) {
                 k_matvec3_gathered<<<pn_div_up(n, 8), 256, xs_bytes, st>>>(n, Ainv, dof, dof_rest, momentum, rhs_rest, part, kc_bg);
             } else {
