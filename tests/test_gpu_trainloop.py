@@ -119,3 +119,30 @@ def test_training_fits_the_teacher_images():
     # the trained bitfield keeps the object and drops most of the empty space
     occ = np.unpackbits(student.density_bitfield.cpu().numpy()).mean()
     assert 0.001 < occ < 0.6
+
+
+def test_training_state_with_two_cascades():
+    """bound = 2 (the trex option set): two density cascades, 4096-resolution hash grid — density-grid sweep, partial update, one training step
+    with gradients through march_rays_train / composite_rays_train at dt_gamma = 1/128, and the eval render afterwards."""
+    ck = scene.make_checkpoint(bound=2.0, seed=3, shaped=True)
+    net = NeRFNetwork(encoding="hashgrid", bound=2.0, cuda_ray=True, density_thresh=10).to(DEV).load_checkpoint_dict(ck)
+    assert net.cascade == 2 and net.density_grid.shape == (2, 128 ** 3) and net.density_bitfield.shape[0] == 2 * 128 ** 3 // 8
+    net.reset_extra_state()
+    torch.manual_seed(0)
+    net.update_extra_state()
+    grid = net.density_grid.cpu().numpy()
+    assert (grid >= 0).all() and (grid[0] > 5).sum() > 1000 and (grid[1] > 5).sum() > 100      # the object shows in both cascades
+    assert np.array_equal(net.density_bitfield.cpu().numpy(), oracle.packbits(grid, min(net.mean_density, net.density_thresh)))
+    net.iter_density = 16
+    net.update_extra_state()
+    W = 48
+    o, d = oracle.get_rays(scene.orbit_pose(4.5, 25.0, -10.0), scene.orbit_intrinsics(W, W, 50.0), W, W)
+    net.train()
+    out = net.run_cuda(T(o)[None], T(d)[None], dt_gamma=1.0 / 128, perturb=True, max_steps=300, T_thresh=5e-2)
+    out["image"].sum().backward()
+    g = net.encoder.embeddings.grad
+    assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+    assert int(net.step_counter[0, 0]) > 500 and int(net.step_counter[0, 1]) == W * W
+    net.eval()
+    img = net.run_cuda(T(o)[None], T(d)[None], dt_gamma=1.0 / 128, max_steps=300, T_thresh=5e-2)["image"]
+    assert bool(torch.isfinite(img).all()) and float(img.min()) < 0.9
