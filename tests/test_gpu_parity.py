@@ -121,10 +121,17 @@ def test_march_bit_exact(deformed_ip_state, small_opt, ckpt, num_seek_IP, max_it
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{name}: {np.sum(a != b)} of {a.size} values differ"
 
 
-def test_march_cut_mode(deformed_ip_state, small_opt, ckpt):
-    """--cut: bbox = +-bound, samples outside cut_bounds are un-warped background (raymarching.cu:1195-1210,1380-1383)."""
+@pytest.mark.parametrize("background,num_seek_IP,n_step", [(False, 1, 6), (True, 1, 6), (True, 3, 2), (True, 2, 16)])
+def test_march_cut_mode(deformed_ip_state, small_opt, ckpt, background, num_seek_IP, n_step):
+    """--cut: bbox = +-bound, samples outside cut_bounds are un-warped background (raymarching.cu:1195-1210,1380-1383).  `background`
+    adds occupied density voxels outside the object (blobs of a random pattern), so that static samples are really emitted and the
+    lane-per-ray pre-pass (pn_march2.h: skip_empty_cells) has to hand over at the right sequence element."""
     from pienerf_amd import raymarching
-    ip, ck = deformed_ip_state, ckpt
+    ip, ck = deformed_ip_state, dict(ckpt)
+    if background:
+        rng = np.random.default_rng(5)
+        blobs = np.repeat(rng.random(len(ck["density_bitfield"]) // 64) < 0.04, 64)   # runs of 512 morton-consecutive voxels = 8^3 blocks
+        ck["density_bitfield"] = ck["density_bitfield"] | np.where(blobs, 0xFF, 0).astype(np.uint8)
     pose = scene.orbit_pose(4.0, 10.0, -5.0)
     W = 32
     o, d = oracle.get_rays(pose, scene.orbit_intrinsics(W, W, 50.0), W, W)
@@ -136,14 +143,17 @@ def test_march_cut_mode(deformed_ip_state, small_opt, ckpt):
     alive = np.arange(W * W, dtype=np.int32)
     cb = np.array([-0.3, 0.9, -0.9, 0.5, -0.9, 0.9], np.float32)
     common = (len(ip["p_def"]), n_grid)
-    ref = oracle.march_rays_quadratic_bending(*pig, *common, ip["p_def"], ip["p_ori"], ip["F"], ip["dF"], 1, bbmin, bbmax, hgs, res, 1,
-                                              np.float32(ip["IP_dx"]), True, cb, len(alive), 6, alive, nears, o, d, 1.0, ck["density_bitfield"],
+    ref = oracle.march_rays_quadratic_bending(*pig, *common, ip["p_def"], ip["p_ori"], ip["F"], ip["dF"], 1, bbmin, bbmax, hgs, res, num_seek_IP,
+                                              np.float32(ip["IP_dx"]), True, cb, len(alive), n_step, alive, nears, o, d, 1.0, ck["density_bitfield"],
                                               ck["cascade"], ck["grid_size"], nears, fars, 128, False, 1.0 / 128, 300)
     got = raymarching.march_rays_quadratic_bending(*[T(a) for a in pig], *common, T(ip["p_def"]), T(ip["p_ori"]), T(ip["F"]), T(ip["dF"]), 1, T(bbmin),
-                                                   T(bbmax), float(hgs), T(res), 1, float(ip["IP_dx"]), True, T(cb), len(alive), 6, T(alive), T(nears),
-                                                   T(o), T(d), 1.0, T(ck["density_bitfield"]), ck["cascade"], ck["grid_size"], T(nears), T(fars), 128,
-                                                   False, 1.0 / 128, 300)
-    assert (ref[2][:, 0] != 0).sum() > 100
+                                                   T(bbmax), float(hgs), T(res), num_seek_IP, float(ip["IP_dx"]), True, T(cb), len(alive), n_step, T(alive),
+                                                   T(nears), T(o), T(d), 1.0, T(ck["density_bitfield"]), ck["cascade"], ck["grid_size"], T(nears), T(fars),
+                                                   128, False, 1.0 / 128, 300)
+    emitted = ref[2][:len(alive) * n_step, 0].reshape(len(alive), n_step) != 0
+    assert emitted.sum() > 100
+    if background:  # many rays emit static samples; some only after a stretch of empty voxels, some not at all
+        assert emitted[:, 0].mean() > 0.1 and (~emitted[:, 0]).sum() > 20
     for a, b in zip(got, ref):
         assert np.array_equal(a.cpu().numpy().view(np.uint32), b.view(np.uint32))
 
