@@ -89,6 +89,134 @@ __global__ void __launch_bounds__(128) k_train_count(const float* __restrict__ r
     rays[(size_t)n * 3 + 2] = (int)cnt;
 }
 
+// ---- wave-per-ray form of the two passes.  4 096 training rays are 64 waves in the lane-per-ray form: one ray's whole march (hundreds of
+// dependent iterations) is the launch time, with 1/16 of the SIMDs busy.  Both branches of the reference loop advance t by the same recurrence
+// s_{k+1} = s_k + clamp(s_k * dt_gamma, dt_min, dt_max) ("emit" takes one step, "hop to the voxel exit" takes steps until t >= tt), so the
+// values a ray can visit are a fixed sequence and the evaluation at s_k is a pure function of s_k (the observation behind the hot path's
+// pn_march3.h).  Per round the 64 lanes evaluate s_0..s_63 of the current window — lane k replays k steps of the recurrence, so every value is
+// rounded exactly as in the sequential loop — each lane walks its own hop to the index it would land on, and the wave replays the visit chain
+// 0 -> jump[0] -> ... with uniform lane reads.  Samples, deltas and counts are bit-identical to the lane-per-ray kernels (and to the oracle).
+struct TrainEval { float x, y, z, dt, t_next; int jump; bool occ, valid; };
+
+__device__ __forceinline__ TrainEval train_eval(float ox, float oy, float oz, float dx, float dy, float dz, float rdx, float rdy, float rdz, float t,
+                                                float far, int lane, float bound, float dt_gamma, float dt_min, float dt_max, uint32_t C, uint32_t H,
+                                                const uint8_t* __restrict__ grid) {
+    TrainEval e;
+    e.valid = t < far;
+    e.x = clampf(ox + t * dx, -bound, bound);
+    e.y = clampf(oy + t * dy, -bound, bound);
+    e.z = clampf(oz + t * dz, -bound, bound);
+    e.dt = clampf(t * dt_gamma, dt_min, dt_max);
+    e.occ = false;
+    e.jump = lane + 1;
+    e.t_next = t + e.dt;
+    if (!e.valid) return e;
+    const float rH = 1 / (float)H;
+    const float H3 = (float)(H * H * H);
+    const int level = max(mip_from_pos(e.x, e.y, e.z, (float)C), mip_from_dt(e.dt, (float)H, (float)C));
+    const float mip_bound = fminf(scalbnf(1.0f, level), bound);
+    const float mip_rbound = 1 / mip_bound;
+    const int nx = (int)clampf((float)(0.5 * (double)(e.x * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+    const int ny = (int)clampf((float)(0.5 * (double)(e.y * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+    const int nz = (int)clampf((float)(0.5 * (double)(e.z * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+    const uint32_t vox = (uint32_t)(level * H3 + (float)morton3D(nx, ny, nz));
+    e.occ = grid[vox / 8] & (1 << (vox % 8));
+    if (!e.occ) {
+        const float tx = (((nx + 0.5f + 0.5f * signf(dx)) * rH * 2 - 1) * mip_bound - e.x) * rdx;
+        const float ty = (((ny + 0.5f + 0.5f * signf(dy)) * rH * 2 - 1) * mip_bound - e.y) * rdy;
+        const float tz = (((nz + 0.5f + 0.5f * signf(dz)) * rH * 2 - 1) * mip_bound - e.z) * rdz;
+        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        float u = t;
+        int m = 0;
+        do { u += clampf(u * dt_gamma, dt_min, dt_max); m++; } while (u < tt);
+        e.jump = lane + m;  // may lie beyond the window; t_next is then the next window's first element
+        e.t_next = u;
+    }
+    return e;
+}
+
+// One wave marches one ray from t0 until t >= far or `limit` occupied steps.  WRITE = false: returns the count.  WRITE = true: stores the samples.
+template <bool WRITE>
+__device__ __forceinline__ uint32_t train_march_wave(const float* __restrict__ ro, const float* __restrict__ rd, float t0, float far, uint32_t limit,
+                                                     float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                                                     const uint8_t* __restrict__ grid, float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                     float* __restrict__ deltas) {
+    const int lane = threadIdx.x & 63;
+    const float ox = ro[0], oy = ro[1], oz = ro[2];
+    const float dx = rd[0], dy = rd[1], dz = rd[2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    const float dt_min = 2 * 1.73205080757f / max_steps;
+    const float dt_max = 2 * 1.73205080757f * (1 << (C - 1)) / H;
+    float t_win = t0, last_t = t0;  // wave-uniform
+    uint32_t step = 0;
+    while (t_win < far && step < limit) {
+        float t = t_win;  // lane k: k steps of the recurrence from the window's first element
+        for (int j = 0; j < lane; j++) t += clampf(t * dt_gamma, dt_min, dt_max);
+        const TrainEval e = train_eval(ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, t, far, lane, bound, dt_gamma, dt_min, dt_max, C, H, grid);
+        // replay the visit chain (all operands wave-uniform)
+        int pos = 0;
+        bool done = false;
+        bool mine = false;
+        uint32_t my_slot = 0;
+        float my_last = 0.0f;
+        float t_exit = t_win;
+        while (pos < 64) {
+            const bool valid = __shfl((int)e.valid, pos) != 0;
+            if (!valid || step >= limit) { done = true; break; }
+            const bool occ = __shfl((int)e.occ, pos) != 0;
+            const float tn = __shfl(e.t_next, pos);
+            if (occ) {
+                if (lane == pos) { mine = true; my_slot = step; my_last = last_t; }
+                last_t = tn;
+                step++;
+            }
+            t_exit = tn;
+            pos = __shfl(e.jump, pos);
+        }
+        if (WRITE && mine) {
+            float* px = xyzs + (size_t)my_slot * 3;
+            float* pd = dirs + (size_t)my_slot * 3;
+            float* pl = deltas + (size_t)my_slot * 2;
+            px[0] = e.x; px[1] = e.y; px[2] = e.z;
+            pd[0] = dx; pd[1] = dy; pd[2] = dz;
+            pl[0] = e.dt;
+            pl[1] = e.t_next - my_last;
+        }
+        if (done) break;
+        t_win = t_exit;
+    }
+    return step;
+}
+
+__global__ void __launch_bounds__(256) k_train_count_w(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid,
+                                                       float bound, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                                       const float* __restrict__ nears, const float* __restrict__ fars, int* __restrict__ rays,
+                                                       const float* __restrict__ noises) {
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float t0 = train_t0(nears[n], noises ? noises[n] : 0.0f, dt_gamma, max_steps, C, H);
+    const uint32_t cnt = train_march_wave<false>(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, t0, fars[n], max_steps, bound, dt_gamma, max_steps, C, H, grid,
+                                                 nullptr, nullptr, nullptr);
+    if ((threadIdx.x & 63) == 0) {
+        rays[(size_t)n * 3] = (int)n;
+        rays[(size_t)n * 3 + 2] = (int)cnt;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_train_write_w(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid,
+                                                       float bound, float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                       const float* __restrict__ nears, const float* __restrict__ fars, float* __restrict__ xyzs,
+                                                       float* __restrict__ dirs, float* __restrict__ deltas, const int* __restrict__ rays,
+                                                       const float* __restrict__ noises) {
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const uint32_t off = (uint32_t)rays[(size_t)n * 3 + 1], cnt = (uint32_t)rays[(size_t)n * 3 + 2];
+    if (cnt == 0 || off + cnt > M) return;  // raymarching.cu:414-415
+    const float t0 = train_t0(nears[n], noises ? noises[n] : 0.0f, dt_gamma, max_steps, C, H);
+    train_march_wave<true>(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, t0, fars[n], cnt, bound, dt_gamma, max_steps, C, H, grid, xyzs + (size_t)off * 3,
+                           dirs + (size_t)off * 3, deltas + (size_t)off * 2);
+}
+
 __global__ void __launch_bounds__(1024) k_train_scan(int* __restrict__ rays, uint32_t N, int* __restrict__ counter) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry_s;
@@ -205,10 +333,20 @@ extern "C" int pn_march_rays_train(const float* rays_o, const float* rays_d, con
     PN_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && (M == 0 || (xyzs && dirs && deltas)));
     PN_REQUIRE(C >= 1 && C <= 8 && H > 0 && max_steps > 0);
     hipStream_t st = (hipStream_t)stream;
-    k_train_count<<<pn_div_up(N, 128), 128, 0, st>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, noises);
-    k_train_scan<<<1, 1024, 0, st>>>(rays, N, counter);
-    k_train_write<<<pn_div_up(N, 128), 128, 0, st>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays,
-                                                     noises);
+    // wave per ray while that still fits the chip in a few rounds (training batches); lane per ray for whole images (PN_TRAIN_MARCH=lane|wave forces one)
+    static const char* form = getenv("PN_TRAIN_MARCH");
+    const bool wave = form ? strcmp(form, "wave") == 0 : N <= 131072;
+    if (wave) {
+        k_train_count_w<<<pn_div_up(N, 4), 256, 0, st>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, noises);
+        k_train_scan<<<1, 1024, 0, st>>>(rays, N, counter);
+        k_train_write_w<<<pn_div_up(N, 4), 256, 0, st>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays,
+                                                         noises);
+    } else {
+        k_train_count<<<pn_div_up(N, 128), 128, 0, st>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, nears, fars, rays, noises);
+        k_train_scan<<<1, 1024, 0, st>>>(rays, N, counter);
+        k_train_write<<<pn_div_up(N, 128), 128, 0, st>>>(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays,
+                                                         noises);
+    }
     PN_LAUNCH_CHECK();
     return PN_OK;
 }
