@@ -80,3 +80,50 @@ def test_sim_kat_gpu(small_cloud, small_opt):
     p, F, dF = (t.cpu().numpy() for t in sim.get_IP_info())
     assert np.abs(p - k["p_def_12"]).max() < 1e-5 and np.abs(F - k["F_12"]).max() < 1e-4 and rel_err(dF, k["dF_12"]) < 1e-3
     assert rel_err(sim.dof_vel.cpu().numpy().reshape(-1, 3), k["dof_vel_12"]) < 1e-3
+
+
+def test_widened_ops_against_the_committed_fixture(ckpt):
+    """tests/golden/train_kat.npz (make_golden_train.py): the HIP path of the static march, march_rays_train, composite_rays_train fwd/bwd,
+    grid dy_dx / backward / TV, SH dy_dx / backward, packbits, morton3D against the committed vectors — index / sample work bit for bit,
+    floating-point reductions within 1e-4 relative."""
+    import os
+    from pienerf_amd import raymarching
+    from pienerf_amd._lib import check, lib, ptr, stream_ptr
+    from pienerf_amd.gridencoder.grid import grid_encode
+    from pienerf_amd.shencoder.sphere_harmonics import sh_encode
+    k = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_kat.npz"))
+    rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - b).max() / max(1e-30, np.abs(b).max()))
+    o, d, nears, fars = (T(k[n]) for n in ("rays_o", "rays_d", "nears", "fars"))
+    bits = T(ckpt["density_bitfield"])
+    # march_rays_train with the fixture's noise vector (C ABI: the wrapper draws its own)
+    N, M = k["rays_o"].shape[0], k["train_xyzs"].shape[0]
+    xyzs, dirs, deltas = (torch.zeros(M, c, device=DEV) for c in (3, 3, 2))
+    rays, counter, noise = torch.empty(N, 3, dtype=torch.int32, device=DEV), torch.zeros(2, dtype=torch.int32, device=DEV), T(k["noise"])
+    check(lib().pn_march_rays_train(ptr(o), ptr(d), ptr(bits), 1.0, 0.0, 256, N, 1, 128, M, ptr(nears), ptr(fars), ptr(xyzs), ptr(dirs), ptr(deltas), ptr(rays),
+                                    ptr(counter), ptr(noise), stream_ptr()))
+    assert np.array_equal(counter.cpu().numpy(), k["train_counter"]) and np.array_equal(rays.cpu().numpy(), k["train_rays"])
+    assert np.array_equal(xyzs.cpu().numpy(), k["train_xyzs"]) and np.array_equal(deltas.cpu().numpy(), k["train_deltas"])
+    alive = T(k["static_alive"])
+    sx, _, sl = raymarching.march_rays(len(k["static_alive"]), 8, alive, nears, o, d, 1.0, bits, 1, 128, nears, fars, 128, False, 0.0, 256)
+    assert np.array_equal(sx.cpu().numpy(), k["static_xyzs"]) and np.array_equal(sl.cpu().numpy(), k["static_deltas"])
+    Mv = int(k["train_counter"][0])
+    sig, rgb = T(k["sig"]).requires_grad_(True), T(k["rgb"]).requires_grad_(True)
+    ws, depth, image = raymarching.composite_rays_train(sig, rgb, deltas[:Mv], rays, 1e-2)
+    assert rel(ws.detach().cpu().numpy(), k["comp_ws"]) < 1e-5 and rel(depth.detach().cpu().numpy(), k["comp_depth"]) < 1e-5
+    assert rel(image.detach().cpu().numpy(), k["comp_image"]) < 1e-5
+    ((ws * T(k["gws"])).sum() + (image * T(k["gim"])).sum()).backward()
+    assert rel(sig.grad.cpu().numpy(), k["comp_gs"]) < 1e-4 and rel(rgb.grad.cpu().numpy(), k["comp_gc"]) < 1e-5
+    x, emb = T(k["grid_x"]).requires_grad_(True), T(k["grid_emb"]).requires_grad_(True)
+    grid_encode(x, emb, T(k["grid_offsets"]), 1.6, 8, True).backward(T(k["grid_grad"]))
+    assert rel(emb.grad.cpu().numpy(), k["grid_ge"]) < 1e-4 and rel(x.grad.cpu().numpy(), k["grid_gi"]) < 1e-4
+    g = torch.zeros_like(emb)
+    off_host = torch.from_numpy(k["grid_offsets"])
+    xd, ed = x.detach().contiguous(), emb.detach().contiguous()
+    check(lib().pn_grad_total_variation(ptr(xd), ptr(ed), ptr(g), off_host.data_ptr(), 0.3, xd.shape[0], 3, 2, 6, float(np.float32(np.log2(1.6))), 8, 0, 0,
+                                        stream_ptr()))
+    assert rel(g.cpu().numpy(), k["grid_tv"]) < 1e-4
+    sd = T(k["sh_dirs"]).requires_grad_(True)
+    sh_encode(sd, 4, True).backward(T(k["sh_grad"]))
+    assert rel(sd.grad.cpu().numpy(), k["sh_gi"]) < 1e-5
+    assert np.array_equal(raymarching.packbits(T(k["pack_grid"]), 0.5).cpu().numpy(), k["pack_bits"])
+    assert np.array_equal(raymarching.morton3D(T(k["mort_coords"])).cpu().numpy(), k["mort_idx"])
