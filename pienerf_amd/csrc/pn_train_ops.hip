@@ -324,6 +324,84 @@ __global__ void __launch_bounds__(128) k_composite_train_bwd(const float* __rest
     }
 }
 
+// ---- wave-per-ray composite (training batches: 4 096 rays are 64 waves in the lane-per-ray form, each walking ~17 samples one after the
+// other with dependent loads).  A wave takes its ray's samples 64 at a time: alpha in parallel (coalesced loads, one __expf per lane),
+// transmittance by an inclusive product scan, the early exit as a ballot over T < T_thresh, sums by shuffle trees.  Same formulas as the
+// reference kernels; the order of the fp32 products / sums differs from the sequential loop (1e-7 relative), which is why these kernels are
+// compared with the oracle to a tolerance like the rest of the composite.
+__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float u = __shfl_up(v, o); if (lane >= o) v *= u; }
+    return v;
+}
+__device__ __forceinline__ float wave_incl_sum(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float u = __shfl_up(v, o); if (lane >= o) v += u; }
+    return v;
+}
+template <bool BWD>
+__global__ void __launch_bounds__(256) k_composite_train_w(const float* __restrict__ grad_weights_sum, const float* __restrict__ grad_image,
+                                                           const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                           const float* __restrict__ deltas, const int* __restrict__ rays,
+                                                           const float* __restrict__ ws_in, const float* __restrict__ image_in, uint32_t M, uint32_t N,
+                                                           float T_thresh, float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                           float* __restrict__ image, float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs) {
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t index = (uint32_t)rays[(size_t)n * 3], offset = (uint32_t)rays[(size_t)n * 3 + 1], num_steps = (uint32_t)rays[(size_t)n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps > M) {
+        if (!BWD && lane == 0) {
+            weights_sum[index] = 0; depth[index] = 0;
+            image[(size_t)index * 3] = 0; image[(size_t)index * 3 + 1] = 0; image[(size_t)index * 3 + 2] = 0;
+        }
+        return;
+    }
+    float gws = 0, gi0 = 0, gi1 = 0, gi2 = 0, rf = 0, gf = 0, bf = 0, wsf = 0;
+    if (BWD) {
+        gws = grad_weights_sum[index];
+        gi0 = grad_image[(size_t)index * 3]; gi1 = grad_image[(size_t)index * 3 + 1]; gi2 = grad_image[(size_t)index * 3 + 2];
+        rf = image_in[(size_t)index * 3]; gf = image_in[(size_t)index * 3 + 1]; bf = image_in[(size_t)index * 3 + 2];
+        wsf = ws_in[index];
+    }
+    float T0 = 1.0f, r = 0, g = 0, b = 0, ws = 0, t0 = 0, d = 0;  // carried across windows (wave-uniform)
+    for (uint32_t base = 0; base < num_steps; base += 64) {
+        const uint32_t s = base + lane;
+        const bool on = s < num_steps;
+        const size_t m = (size_t)offset + (on ? s : 0);
+        const float sg = on ? sigmas[m] : 0.0f, d0 = on ? deltas[m * 2] : 0.0f, d1 = on ? deltas[m * 2 + 1] : 0.0f;
+        const float c0 = on ? rgbs[m * 3] : 0.0f, c1 = on ? rgbs[m * 3 + 1] : 0.0f, c2 = on ? rgbs[m * 3 + 2] : 0.0f;
+        const float alpha = on ? 1.0f - __expf(-sg * d0) : 0.0f;
+        const float Tafter = T0 * wave_incl_prod(1.0f - alpha, lane);  // transmittance after this sample
+        float Tbefore = __shfl_up(Tafter, 1);
+        if (lane == 0) Tbefore = T0;
+        // the sample at which T drops below the threshold is still accumulated, later ones are not (raymarching.cu:559-560)
+        const unsigned long long below = __ballot(on && Tafter < T_thresh);
+        const int last = below ? __ffsll((long long)below) - 1 : 63;
+        const bool use = on && lane <= last;
+        const float w = use ? alpha * Tbefore : 0.0f;
+        const float tcum = t0 + wave_incl_sum(on ? d1 : 0.0f, lane);
+        const float pr = r + wave_incl_sum(w * c0, lane), pg = g + wave_incl_sum(w * c1, lane), pb = b + wave_incl_sum(w * c2, lane);
+        if (BWD) {
+            if (use) {
+                grad_rgbs[m * 3] = gi0 * w; grad_rgbs[m * 3 + 1] = gi1 * w; grad_rgbs[m * 3 + 2] = gi2 * w;
+                grad_sigmas[m] = d0 * (gi0 * (Tafter * c0 - (rf - pr)) + gi1 * (Tafter * c1 - (gf - pg)) + gi2 * (Tafter * c2 - (bf - pb)) + gws * (1 - wsf));
+            }
+        } else {
+            ws += __shfl(wave_incl_sum(w, lane), 63);
+            d += __shfl(wave_incl_sum(w * tcum, lane), 63);
+        }
+        r = __shfl(pr, 63); g = __shfl(pg, 63); b = __shfl(pb, 63);
+        t0 = __shfl(tcum, 63);
+        T0 = __shfl(Tafter, 63);
+        if (below) break;
+    }
+    if (!BWD && lane == 0) {
+        weights_sum[index] = ws; depth[index] = d;
+        image[(size_t)index * 3] = r; image[(size_t)index * 3 + 1] = g; image[(size_t)index * 3 + 2] = b;
+    }
+}
+
 }  // namespace
 
 extern "C" int pn_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma, uint32_t max_steps,
@@ -355,7 +433,12 @@ extern "C" int pn_composite_rays_train_forward(const float* sigmas, const float*
                                                float T_thresh, float* weights_sum, float* depth, float* image, void* stream) {
     if (N == 0) return PN_OK;
     PN_REQUIRE(rays && weights_sum && depth && image && (M == 0 || (sigmas && rgbs && deltas)));
-    k_composite_train_fwd<<<pn_div_up(N, 128), 128, 0, (hipStream_t)stream>>>(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image);
+    static const char* form = getenv("PN_TRAIN_COMPOSITE");  // lane | wave; default: wave per ray for training batches, lane per ray for whole images
+    if (form ? strcmp(form, "wave") == 0 : N <= 131072)
+        k_composite_train_w<false><<<pn_div_up(N, 4), 256, 0, (hipStream_t)stream>>>(nullptr, nullptr, sigmas, rgbs, deltas, rays, nullptr, nullptr, M, N, T_thresh,
+                                                                                    weights_sum, depth, image, nullptr, nullptr);
+    else
+        k_composite_train_fwd<<<pn_div_up(N, 128), 128, 0, (hipStream_t)stream>>>(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image);
     PN_LAUNCH_CHECK();
     return PN_OK;
 }
@@ -365,8 +448,13 @@ extern "C" int pn_composite_rays_train_backward(const float* grad_weights_sum, c
                                                 uint32_t N, float T_thresh, float* grad_sigmas, float* grad_rgbs, void* stream) {
     if (N == 0 || M == 0) return PN_OK;
     PN_REQUIRE(grad_weights_sum && grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs);
-    k_composite_train_bwd<<<pn_div_up(N, 128), 128, 0, (hipStream_t)stream>>>(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image,
-                                                                            M, N, T_thresh, grad_sigmas, grad_rgbs);
+    static const char* form = getenv("PN_TRAIN_COMPOSITE");
+    if (form ? strcmp(form, "wave") == 0 : N <= 131072)
+        k_composite_train_w<true><<<pn_div_up(N, 4), 256, 0, (hipStream_t)stream>>>(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
+                                                                                   T_thresh, nullptr, nullptr, nullptr, grad_sigmas, grad_rgbs);
+    else
+        k_composite_train_bwd<<<pn_div_up(N, 128), 128, 0, (hipStream_t)stream>>>(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image,
+                                                                                M, N, T_thresh, grad_sigmas, grad_rgbs);
     PN_LAUNCH_CHECK();
     return PN_OK;
 }
