@@ -114,3 +114,15 @@ def sh_encode_backward(grad, dy_dx, degree=4):
     gi = np.zeros((B, 3), np.float32)
     lib().orc_sh_encode_backward(_p(grad, F), U32(B), U32(degree), _p(dy_dx, F), _p(gi, F))
     return gi
+
+
+def trunc_exp_forward(x):
+    """nerf/activation.py:8-10: exp of the float32-cast input."""
+    import torch
+    return torch.exp(torch.from_numpy(_f32(x))).numpy()
+
+
+def trunc_exp_backward(x, g):
+    """nerf/activation.py:14-16: g * exp(clamp(x, -15, 15))."""
+    import torch
+    return (torch.from_numpy(_f32(g)) * torch.exp(torch.from_numpy(_f32(x)).clamp(-15, 15))).numpy()

@@ -73,6 +73,16 @@ def save_image(image, path, W, H):
     return data
 
 
+def linear_to_srgb(x):
+    """nerf/utils.py:44-46 (applied to the prediction when opt.color_space == 'linear', trainer.py:583-584)."""
+    return torch.where(x < 0.0031308, 12.92 * x, 1.055 * x ** 0.41666 - 0.055)
+
+
+def srgb_to_linear(x):
+    """nerf/utils.py:49-51."""
+    return torch.where(x < 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4)
+
+
 def nerf_matrix_to_ngp(pose, scale=0.33, offset=(0, 0, 0)):
     """nerf/provider.py:19-27: blender / colmap cam2world -> the renderer's axis convention, translation scaled and offset."""
     pose = np.asarray(pose, np.float32)

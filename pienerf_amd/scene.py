@@ -232,6 +232,59 @@ def orbit_pose(radius=5.0, azimuth_deg=0.0, elevation_deg=0.0, center=(0.0, 0.0,
     return res.astype(np.float32)
 
 
+def _rotvec_matrix(v):
+    """Rotation matrix of the rotation vector v (Rodrigues) — what scipy's Rotation.from_rotvec(v).as_matrix() returns."""
+    v = np.asarray(v, np.float64)
+    th = float(np.linalg.norm(v))
+    if th < 1e-300:
+        return np.eye(3)
+    k = v / th
+    K = np.array([[0.0, -k[2], k[1]], [k[2], 0.0, -k[0]], [-k[1], k[0], 0.0]])
+    return np.eye(3) + math.sin(th) * K + (1.0 - math.cos(th)) * (K @ K)
+
+
+class OrbitCamera:
+    """The GUI camera of the reference (nerf/gui.py:13-61) without scipy: same state (rot, radius, center, up), same mouse-delta
+    conventions for orbit / scale / pan, same pose and intrinsics.  tests/test_golden_ref.py holds it to values returned by the
+    reference class itself."""
+
+    def __init__(self, W, H, r=2, fovy=60):
+        self.W, self.H = W, H
+        self.radius = r
+        self.fovy = fovy
+        self.center = np.array([0, 0, 0], dtype=np.float32)
+        self.rot = np.diag([1.0, -1.0, -1.0])  # R.from_quat([1, 0, 0, 0]): half a turn about x (ngp convention)
+        self.up = np.array([0, 1, 0], dtype=np.float32)
+
+    def pose_to_params(self, pose):
+        self.radius = -self.center[2] + pose[:3, 3][2]
+        self.rot = np.asarray(pose[:3, :3], np.float64)
+
+    @property
+    def pose(self):
+        res = np.eye(4, dtype=np.float32)
+        res[2, 3] -= self.radius
+        rot = np.eye(4, dtype=np.float32)
+        rot[:3, :3] = self.rot
+        res = rot @ res
+        res[:3, 3] -= self.center
+        return res
+
+    @property
+    def intrinsics(self):
+        return orbit_intrinsics(self.W, self.H, self.fovy)
+
+    def orbit(self, dx, dy):
+        side = self.rot[:3, 0]
+        self.rot = _rotvec_matrix(self.up * np.radians(-0.1 * dx)) @ _rotvec_matrix(side * np.radians(-0.1 * dy)) @ self.rot
+
+    def scale(self, delta):
+        self.radius *= 1.1 ** (-delta)
+
+    def pan(self, dx, dy, dz=0):
+        self.center += (0.0005 * self.rot[:3, :3] @ np.array([dx, dy, dz])).astype(np.float32)
+
+
 def orbit_intrinsics(W, H, fovy=50.0):
     """OrbitCamera.intrinsics (nerf/gui.py:41-44)."""
     focal = H / (2 * np.tan(np.radians(fovy) / 2))
@@ -248,3 +301,13 @@ def default_opt(**over):
     opt["hash_grid_size"] = 1.2 * opt["sim_dx"]
     opt["num_seek_IP"] = max(min(3, opt["num_seek_IP"]), 1)
     return opt
+
+
+def trex_opt(**over):
+    """The option set of the reference's second demo (README.md:134: trex, llff): bound 2 (get_opts default), scale 0.33, dt_gamma 1/128, two
+    cascades, --cut with its bounds, max_steps 300, T_thresh 5e-2, 1008 x 756, num_seek_IP 1.  tests/test_golden_ref.py compares it with the
+    namespace the reference's get_opts.py returns for that command line."""
+    opt = dict(bound=2.0, scale=0.33, dt_gamma=1.0 / 128, W=1008, H=756, max_steps=300, T_thresh=5e-2, num_seek_IP=1, max_iter_num=1, cut=True,
+               cut_bounds=[-0.62, 1.0, -0.82, 0.42, -0.52, 0.28], sim_dx=0.05)
+    opt.update(over)
+    return default_opt(**opt)

@@ -1,0 +1,117 @@
+"""The oracle and the product's host code against values RETURNED BY THE REFERENCE ITSELF (tests/golden/make_golden_ref.py ran the
+reference's own get_opts / trunc_exp / get_rays / OrbitCamera / nerf_matrix_to_ngp / GridEncoder.__init__ in the build container and
+stored inputs + outputs).  CPU only; the GPU side of the same vectors is in tests/test_gpu_golden.py."""
+import json
+import os
+
+import numpy as np
+import torch
+
+import oracle
+from pienerf_amd import scene
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+K = np.load(os.path.join(G, "ref_kat.npz"))
+
+
+def _opts(name):
+    with open(os.path.join(G, f"opts_{name}.json")) as f:
+        return json.load(f)["opt"]
+
+
+def _same(ours, ref):
+    for k, v in ours.items():
+        if k not in ref:
+            continue
+        r = ref[k]
+        if isinstance(v, (list, tuple)):
+            assert [float(x) for x in v] == [float(x) for x in r], k
+        elif isinstance(v, bool) or isinstance(r, bool):
+            assert bool(v) == bool(r), k
+        else:
+            assert float(v) == float(r), (k, v, r)
+
+
+def test_default_opt_equals_reference_get_opts_chair():
+    ref = _opts("chair")  # python main_gui.py --dataset_type synthetic ... -O --max_iter_num 1 --num_seek_IP 3 --sim_dx 0.05 (README.md:123)
+    ours = scene.default_opt()
+    shared = set(ours) & set(ref)
+    assert {"bound", "scale", "dt_gamma", "W", "H", "max_steps", "T_thresh", "min_near", "density_thresh", "bg_radius", "radius", "fovy", "max_iter_num",
+            "num_seek_IP", "sim_dt", "sim_dx", "sim_iters", "sim_stiff", "cut", "cut_bounds", "hash_grid_size", "timing_on"} <= shared
+    _same(ours, ref)
+    assert ref["fp16"] is True and ref["cuda_ray"] is True  # -O; main_gui.py:36 builds its Trainer without fp16=, so the GUI path runs fp32
+
+
+def test_trex_opt_equals_reference_get_opts_trex():
+    ref = _opts("trex")  # README.md:134
+    ours = scene.trex_opt()
+    _same(ours, ref)
+    assert ours["W"] == 1008 and ours["H"] == 756 and ours["cut"] is True and ours["bound"] == 2.0 and abs(ours["hash_grid_size"] - 0.06) < 1e-15
+    # clamping of num_seek_IP (get_opts.py:97,117-120) at both ends
+    assert scene.default_opt(num_seek_IP=7)["num_seek_IP"] == 3 and scene.default_opt(num_seek_IP=0)["num_seek_IP"] == 1
+
+
+def test_trunc_exp_forward_backward_equal_reference():
+    from pienerf_amd.nerf.activation import trunc_exp
+    x = torch.from_numpy(K["trunc_exp_x"]).requires_grad_(True)
+    y = trunc_exp(x)
+    y.backward(torch.from_numpy(K["trunc_exp_g"]))
+    assert np.array_equal(y.detach().numpy(), K["trunc_exp_y"])     # same torch.exp on the same floats
+    assert np.array_equal(x.grad.numpy(), K["trunc_exp_dx"])       # g * exp(clamp(x, -15, 15)): the clamp acts at |x| > 15 only
+    # the oracle's restatement (oracle/training.py) of the same pair
+    from oracle import training as otr
+    assert np.array_equal(otr.trunc_exp_forward(K["trunc_exp_x"]), K["trunc_exp_y"])
+    assert np.array_equal(otr.trunc_exp_backward(K["trunc_exp_x"], K["trunc_exp_g"]), K["trunc_exp_dx"])
+
+
+def test_get_rays_oracle_and_host_equal_reference():
+    from pienerf_amd.nerf.utils import get_rays
+    for tag in "abc":
+        pose, intr = K[f"rays_{tag}_pose"], K[f"rays_{tag}_intr"]
+        W, H = (int(v) for v in K[f"rays_{tag}_WH"])
+        o, d = oracle.get_rays(pose, intr, H, W)
+        if tag == "c":
+            idx = K["rays_c_idx"]
+            o, d = o[idx], d[idx]
+        assert np.array_equal(o, K[f"rays_{tag}_o"])
+        # the reference normalises with torch.norm and rotates with a batched matmul; the oracle (and the kernel) divide by sqrtf and sum
+        # three products in order: equal to within one or two float32 roundings of a unit vector
+        assert np.abs(d - K[f"rays_{tag}_d"]).max() < 2.5e-7
+        assert np.abs(np.linalg.norm(K[f"rays_{tag}_d"].astype(np.float64), axis=1) - 1).max() < 3e-7
+
+
+def test_orbit_camera_equals_reference():
+    cam = scene.OrbitCamera(800, 800, r=5, fovy=50)
+    assert np.array_equal(cam.pose, K["cam_pose_default"]) and np.array_equal(scene.orbit_pose(5.0), K["cam_pose_default"])
+    assert np.array_equal(np.asarray(cam.intrinsics, np.float64), K["cam_intrinsics_800"])
+    assert np.array_equal(scene.orbit_intrinsics(1008, 756, 50), K["cam_intrinsics_trex"])
+    cam.orbit(250.0, -120.0)
+    assert np.abs(cam.pose - K["cam_pose_orbit"]).max() < 1e-6
+    cam.scale(3.0)
+    cam.pan(12.0, -7.0, 2.0)
+    assert np.abs(cam.pose - K["cam_pose_orbit_scale_pan"]).max() < 1e-6
+    assert abs(cam.radius - float(K["cam_radius_after"])) < 1e-12 and np.abs(cam.center - K["cam_center_after"]).max() < 1e-7
+
+
+def test_nerf_matrix_to_ngp_equals_reference():
+    from pienerf_amd import io
+    assert np.array_equal(io.nerf_matrix_to_ngp(K["ngp_in"], scale=0.33, offset=[0, 0, 0]), K["ngp_out_033"])
+    assert np.array_equal(io.nerf_matrix_to_ngp(K["ngp_in"], scale=0.8, offset=[0.1, -0.2, 0.3]), K["ngp_out_08"])
+
+
+def test_hash_grid_layout_equals_reference():
+    from pienerf_amd.gridencoder import GridEncoder
+    for tag, bound in (("b1", 1.0), ("b2", 2.0)):
+        off, pls = scene.hashgrid_offsets(bound)
+        assert np.array_equal(np.asarray(off, np.int64), K[f"grid_{tag}_offsets"]) and float(pls) == float(K[f"grid_{tag}_per_level_scale"])
+        enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048 * bound)
+        assert np.array_equal(enc.offsets.numpy().astype(np.int64), K[f"grid_{tag}_offsets"])
+        assert float(enc.per_level_scale) == float(K[f"grid_{tag}_per_level_scale"])
+        assert enc.output_dim == int(K[f"grid_{tag}_output_dim"]) and enc.embeddings.shape[0] == int(K[f"grid_{tag}_n_embeddings"])
+
+
+def test_srgb_helpers_equal_reference():
+    from pienerf_amd import io
+    v = torch.from_numpy(K["srgb_in"])
+    assert np.allclose(io.linear_to_srgb(v).numpy(), K["srgb_lin2srgb"], rtol=0, atol=1e-7)
+    assert np.allclose(io.srgb_to_linear(v).numpy(), K["srgb_srgb2lin"], rtol=0, atol=1e-7)
