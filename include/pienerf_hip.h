@@ -250,7 +250,9 @@ int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, double dx, const
  * neighbour slot in CSR order and the gather has no index left to follow. */
 uint64_t pn_sim_work_doubles(int n_k, int n_IP);
 
-/* Simulator.update_force (simulator/solver.py:578-588): dof_f [10 n_k,3] is overwritten with the pick force of IP `vid`. */
+/* Simulator.update_force (simulator/solver.py:578-588): dof_f [10 n_k,3] is overwritten, in ONE launch, with the pick force f3 of IP `vid`
+ * (every other entry zero).  vid < 0: clear_force (:590-593), f3_host / topo / rho / Nx may then be NULL.  Enqueue it on the stream the
+ * substeps run on: stream order then decides which substep sees the change. */
 int pn_sim_update_force(int n_k, int vid, const double* f3_host, double dx, const int* topo, const double* rho, const double* Nx, double* dof_f,
                         void* stream);
 

@@ -11,6 +11,7 @@
 #include "../../include/pienerf_hip.h"
 
 #define PN_WAVE 64
+#define PN_MAX_DEVICES 64  // per-device caches of function attributes (hipFuncSetAttribute is per device)
 
 extern thread_local char pn_err_buf[512];
 

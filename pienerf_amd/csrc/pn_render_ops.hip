@@ -1256,10 +1256,13 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     const size_t tables_lds = ((size_t)f->max_cells + 1) / 2 * sizeof(unsigned) + (size_t)f->max_vtx * sizeof(int);
     const bool large = tables_lds > 150 * 1024;  // grid too large for the one-workgroup LDS build
     if (!large) {
-        static size_t tables_lds_set = 0;
-        if (tables_lds > tables_lds_set) {  // dynamic LDS above 64 KB has to be opted into (gfx950: 160 KB per workgroup)
+        // dynamic LDS above 64 KB has to be opted into (gfx950: 160 KB per workgroup); the attribute is per DEVICE, so the cache is too
+        static size_t tables_lds_set[PN_MAX_DEVICES] = {0};
+        int dev_id = 0;
+        PN_HIP_CHECK(hipGetDevice(&dev_id));
+        if (dev_id < 0 || dev_id >= PN_MAX_DEVICES || tables_lds > tables_lds_set[dev_id]) {
             PN_HIP_CHECK(hipFuncSetAttribute((const void*)k_frame_tables<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tables_lds));
-            tables_lds_set = tables_lds;
+            if (dev_id >= 0 && dev_id < PN_MAX_DEVICES) tables_lds_set[dev_id] = tables_lds;
         }
         k_frame_tables<false><<<1, 1024, tables_lds, st>>>(p_def, n_vtx, o->cut, o->bound, o->hash_grid_size, (int)f->max_cells, f->dev, f->pig_cnt,
                                                            f->pig_bgn, f->pig_idx, f->pig_cursor, swap, f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor);

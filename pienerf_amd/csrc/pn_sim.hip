@@ -679,11 +679,13 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
     const size_t xs_bytes = (size_t)n3 * sizeof(double);
     const bool chunked = pcsr && chunked_ok && xs_bytes <= 160 * 1024 - 1024;
     if (chunked) {
-        if (xs_bytes > 48 * 1024) {
-            static size_t granted = 0;
-            if (xs_bytes > granted) {
+        if (xs_bytes > 48 * 1024 && fused_x) {  // dynamic LDS above 48 KB is opted into per DEVICE, so the cache is per device too
+            static size_t granted[PN_MAX_DEVICES] = {0};
+            int dev_id = 0;
+            PN_HIP_CHECK(hipGetDevice(&dev_id));
+            if (dev_id < 0 || dev_id >= PN_MAX_DEVICES || xs_bytes > granted[dev_id]) {
                 PN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_matvec3_gathered), hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_bytes));
-                granted = xs_bytes;
+                if (dev_id >= 0 && dev_id < PN_MAX_DEVICES) granted[dev_id] = xs_bytes;
             }
         }
         k_gather_plan<<<1, 512, 0, st>>>(n_k, (int)chunks_max, csr_bg, csr_cnt, kc_bg, chunk);
@@ -715,27 +717,31 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
 }
 
 // ------------------------------------------------------------------------------------------------ update_force
-// Simulator.update_force (solver.py:578-588): 80 entries of dof_f for the picked IP; everything else zero.
-__global__ void k_update_force(int vid, double fx, double fy, double fz, double dx3, const int* __restrict__ topo, const double* __restrict__ rho,
-                               const double* __restrict__ Nx, double* __restrict__ dof_f) {
-    const int t = threadIdx.x;
-    if (t >= 80) return;
-    const int i = t / 10, j = t % 10;
-    const int kid = topo[vid * 8 + i];
-    const double m = rho[vid] * dx3;
-    const double w = m * Nx[((size_t)vid * 8 + i) * 10 + j];
-    // distinct (i,j) address distinct rows because an IP's 8 neighbour kernels are distinct
-    dof_f[((size_t)kid * 10 + j) * 3] += w * fx;
-    dof_f[((size_t)kid * 10 + j) * 3 + 1] += w * fy;
-    dof_f[((size_t)kid * 10 + j) * 3 + 2] += w * fz;
+// Simulator.update_force (solver.py:578-588): dof_f = the pick force of IP `vid` spread over its 8 kernels' 10 coefficients, zero
+// elsewhere.  ONE launch writes every entry of dof_f (the reference: zero_ + an 80-iteration loop of scalar ops), so the vector never
+// exists in a cleared-but-not-yet-filled state between two launches; vid < 0 = clear_force (:590-593).  The caller enqueues it on the
+// stream the substeps run on (Simulator.force_stream), which orders it between two substeps.
+__global__ void __launch_bounds__(256) k_update_force(int n30, int vid, double fx, double fy, double fz, double dx3, const int* __restrict__ topo,
+                                                      const double* __restrict__ rho, const double* __restrict__ Nx, double* __restrict__ dof_f) {
+    const int o = threadIdx.x + blockIdx.x * blockDim.x;
+    if (o >= n30) return;
+    double v = 0.0;
+    if (vid >= 0) {
+        const int row = o / 3, r = o - row * 3, kid = row / 10, j = row - kid * 10;
+        const double f = r == 0 ? fx : (r == 1 ? fy : fz);
+        const double m = rho[vid] * dx3;
+        // an IP's 8 neighbour kernels are distinct, so at most one slot matches; summing keeps the reference's `+=` semantics otherwise
+        for (int i = 0; i < 8; i++)
+            if (topo[vid * 8 + i] == kid) v += m * Nx[((size_t)vid * 8 + i) * 10 + j] * f;
+    }
+    dof_f[o] = v;
 }
 
 extern "C" int pn_sim_update_force(int n_k, int vid, const double* f3_host, double dx, const int* topo, const double* rho, const double* Nx,
                                    double* dof_f, void* stream) {
-    PN_REQUIRE(n_k > 0 && vid >= 0 && f3_host && topo && rho && Nx && dof_f);
-    hipStream_t st = (hipStream_t)stream;
-    PN_HIP_CHECK(hipMemsetAsync(dof_f, 0, sizeof(double) * (size_t)n_k * 30, st));
-    k_update_force<<<1, 128, 0, st>>>(vid, f3_host[0], f3_host[1], f3_host[2], pow(dx, 3.0), topo, rho, Nx, dof_f);
+    PN_REQUIRE(n_k > 0 && dof_f && (vid < 0 || (f3_host && topo && rho && Nx)));
+    const double fx = vid >= 0 ? f3_host[0] : 0.0, fy = vid >= 0 ? f3_host[1] : 0.0, fz = vid >= 0 ? f3_host[2] : 0.0;
+    k_update_force<<<pn_div_up((uint64_t)n_k * 30, 256), 256, 0, (hipStream_t)stream>>>(n_k * 30, vid, fx, fy, fz, pow(dx, 3.0), topo, rho, Nx, dof_f);
     PN_LAUNCH_CHECK();
     return PN_OK;
 }

@@ -52,6 +52,7 @@ class SimRenderHarness:
             self._ip_ready = torch.cuda.Event()
             self._sim_done = torch.cuda.Event()
             self._sim_done.record(torch.cuda.current_stream(self.device))
+            self.sim.force_stream = self._sim_stream  # update_force / clear_force are ordered between two substeps (solver.py:578-593)
 
     def synchronize(self):
         torch.cuda.synchronize(self.device)
@@ -209,6 +210,7 @@ class SimRenderHarness:
         else:
             p["sim_stream"] = torch.cuda.Stream(dev, priority=sim_priority)
             streams = [torch.cuda.Stream(dev) for _ in range(lanes)]
+        self.sim.force_stream = p["sim_stream"]  # a force change is enqueued between two substeps of the simulator stream
         p["snap"] = [torch.empty_like(self.sim.dof) for _ in range(slots)]
         p["snap_ready"] = [torch.cuda.Event() for _ in range(slots)]
         keep = (self.sim.dof.clone(), self.sim.dof_vel.clone())

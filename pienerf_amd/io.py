@@ -13,8 +13,9 @@ import numpy as np
 import torch
 
 
-def save_checkpoint(model, path, epoch=0, global_step=0, stats=None, optimizer=None, lr_scheduler=None, full=False):
-    """trainer.py:793-830 (the ``best=False`` branch): one ``.pth`` the reference's ``Trainer.load_checkpoint`` can read."""
+def save_checkpoint(model, path, epoch=0, global_step=0, stats=None, optimizer=None, lr_scheduler=None, full=False, ema=None, scaler=None):
+    """trainer.py:793-830 (the ``best=False`` branch): one ``.pth`` the reference's ``Trainer.load_checkpoint`` can read.  ``ema`` (an object
+    with state_dict(), training.ParamEMA) and ``scaler`` go under the reference's 'ema' / 'scaler' keys of a full checkpoint (:806-812)."""
     state = {"epoch": int(epoch), "global_step": int(global_step), "stats": stats if stats is not None else {"checkpoints": [], "results": []}}
     if getattr(model, "cuda_ray", False):
         state["mean_count"] = model.mean_count
@@ -24,6 +25,10 @@ def save_checkpoint(model, path, epoch=0, global_step=0, stats=None, optimizer=N
             state["optimizer"] = optimizer.state_dict()
         if lr_scheduler is not None:
             state["lr_scheduler"] = lr_scheduler.state_dict()
+        if scaler is not None:
+            state["scaler"] = scaler.state_dict()
+        if ema is not None:
+            state["ema"] = ema.state_dict()
     state["model"] = model.state_dict()
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     torch.save(state, path)
@@ -36,9 +41,31 @@ def latest_checkpoint(ckpt_dir, name="ngp"):
     return found[-1] if found else None
 
 
-def load_checkpoint(model, path, model_only=True, optimizer=None, lr_scheduler=None, map_location=None):
+def _safe_load(path, map_location, allow_pickle):
+    """torch.load restricted to tensors + plain python / numpy scalars (the reference's checkpoint layout holds nothing else).  A file that
+    needs arbitrary pickle globals is refused unless the caller opts in: a downloaded .pth must not be able to run code."""
+    try:
+        import numpy._core.multiarray as _ma  # numpy >= 2
+    except ImportError:  # numpy 1.x
+        import numpy.core.multiarray as _ma
+    safe = [np.dtype, np.ndarray, type(np.dtype(np.float64)), type(np.dtype(np.float32)), type(np.dtype(np.int64)), type(np.dtype(np.int32))]
+    for name in ("_reconstruct", "scalar"):
+        fn = getattr(_ma, name, None)
+        if fn is not None:
+            safe.append(fn)
+    try:
+        with torch.serialization.safe_globals(safe):
+            return torch.load(path, map_location=map_location, weights_only=True)
+    except Exception as e:  # noqa: BLE001 — pickle.UnpicklingError and friends
+        if not allow_pickle:
+            raise RuntimeError(f"{path}: not loadable with weights_only=True ({type(e).__name__}: {e}). If you trust the file, pass allow_pickle=True "
+                               "(main_render: --trust-ckpt)") from e
+        return torch.load(path, map_location=map_location, weights_only=False)
+
+
+def load_checkpoint(model, path, model_only=True, optimizer=None, lr_scheduler=None, map_location=None, ema=None, allow_pickle=False):
     """trainer.py:856-916.  Returns dict(missing_keys, unexpected_keys, epoch, global_step).  The model is left in eval() mode."""
-    ck = torch.load(path, map_location=map_location or next(model.parameters()).device, weights_only=False)
+    ck = _safe_load(path, map_location or next(model.parameters()).device, allow_pickle)
     info = dict(missing_keys=[], unexpected_keys=[], epoch=None, global_step=None)
     if "model" not in ck:  # a bare state dict
         model.load_state_dict(ck)
@@ -56,6 +83,8 @@ def load_checkpoint(model, path, model_only=True, optimizer=None, lr_scheduler=N
                 optimizer.load_state_dict(ck["optimizer"])
             if lr_scheduler is not None and "lr_scheduler" in ck:
                 lr_scheduler.load_state_dict(ck["lr_scheduler"])
+        if ema is not None and "ema" in ck:  # trainer.py:884-885 (loaded whenever present)
+            ema.load_state_dict(ck["ema"])
     if hasattr(model, "_net_sig"):
         model._net_sig = None  # the packed weight image of the fused kernel is rebuilt on next use
     model.eval()

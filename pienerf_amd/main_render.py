@@ -30,7 +30,7 @@ def build_harness(args):
         path = args.ckpt if os.path.isfile(args.ckpt) else io.latest_checkpoint(args.ckpt)
         if path is None:
             raise FileNotFoundError(f"no checkpoint under {args.ckpt}")
-        io.load_checkpoint(h.model, path, model_only=True)
+        io.load_checkpoint(h.model, path, model_only=True, allow_pickle=args.trust_ckpt)
     return h
 
 
@@ -63,6 +63,8 @@ def run(args):
 def parser():
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--ply", default=None, help="simulation point cloud (x,y,z,mass,mu,lam,pin vertex properties); default: synthetic chair")
+    ap.add_argument("--trust-ckpt", dest="trust_ckpt", action="store_true",
+                    help="allow a checkpoint that needs arbitrary pickle globals (runs code from the file; default: tensors and plain scalars only)")
     ap.add_argument("--ckpt", default=None, help="a reference-format .pth or a checkpoints directory; default: synthetic chair checkpoint")
     ap.add_argument("--out", default="output_img/run")
     ap.add_argument("--frames", type=int, default=10)

@@ -71,15 +71,17 @@ _PLY_NAMES = {"double": "f8", "float64": "f8", "float": "f4", "float32": "f4", "
               "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2", "uint": "u4", "uint32": "u4", "char": "i1", "int8": "i1"}
 
 
-def write_ply(path, cloud, binary=True):
-    """Vertex-only PLY with the simulator's attributes (solver.py:116-135)."""
+def write_ply(path, cloud, binary=True, props=None):
+    """Vertex-only PLY.  Default: the simulator's input attributes (solver.py:116-135); props=("x","y","z"): positions only, the
+    schema Simulator.OutputToPly writes (solver.py:109-113)."""
     n = len(cloud["pos"])
-    rec = np.zeros(n, dtype=[(k, "<" + t) for k, t in _PLY_PROPS])
+    sel = [(k, t) for k, t in _PLY_PROPS if props is None or k in props]
+    rec = np.zeros(n, dtype=[(k, "<" + t) for k, t in sel])
     rec["x"], rec["y"], rec["z"] = cloud["pos"][:, 0], cloud["pos"][:, 1], cloud["pos"][:, 2]
-    for k in ("mass", "mu", "lam", "pin"):
+    for k, _ in sel[3:]:
         rec[k] = cloud[k]
     hdr = ["ply", "format binary_little_endian 1.0" if binary else "format ascii 1.0", f"element vertex {n}"]
-    hdr += [f"property {_PLY_TYPES[t]} {k}" for k, t in _PLY_PROPS] + ["end_header"]
+    hdr += [f"property {_PLY_TYPES[t]} {k}" for k, t in sel] + ["end_header"]
     with open(path, "wb") as f:
         f.write(("\n".join(hdr) + "\n").encode())
         if binary:
@@ -121,6 +123,9 @@ def read_ply(path):
 
 def cloud_from_ply(path):
     c = read_ply(path)
+    missing = [k for k in ("mass", "mu", "lam", "pin") if k not in c]
+    if missing:
+        raise ValueError(f"{path}: not a simulator input PLY, vertex properties {missing} are missing (OutputToPly files hold x, y, z only)")
     return dict(pos=np.stack([c["x"], c["y"], c["z"]], 1).astype(np.float64), mass=c["mass"].astype(np.float64), mu=c["mu"].astype(np.float64),
                 lam=c["lam"].astype(np.float64), pin=c["pin"].astype(bool))
 

@@ -21,6 +21,14 @@ torchfloat = torch.float64
 npfloat = np.float64
 
 
+class _null_ctx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
 class Simulator:
     def __init__(self, dt=1e-2, iters=20, bbox=torch.tensor([1.0, 1.0, 1.0], dtype=torchfloat), kres=7, dx=1,
                  gravity=torch.tensor([0.0, -9.8, 0.0], dtype=torchfloat), stiff=1e5, base=torch.tensor([-0.5, -0.5, -0.5], dtype=torchfloat),
@@ -35,6 +43,10 @@ class Simulator:
         self.gravity = gravity.to(dtype=torchfloat).to(self.device)
         self.dof = None
         self._work = None
+        # stream on which update_force / clear_force are enqueued (None: the caller's current stream).  A harness that runs the substeps
+        # on a stream of their own (harness.py: overlap_sim, capture_pipelined) sets it to that stream, so that a force change is ordered
+        # BETWEEN two substeps instead of racing with one
+        self.force_stream = None
 
     # ------------------------------------------------------------------ IO (solver.py:109-137)
     def InitializeFromPly(self, path):
@@ -49,12 +61,14 @@ class Simulator:
         self.mu = torch.from_numpy(np.asarray(mu, npfloat)).to(dev)
         self.lam = torch.from_numpy(np.asarray(lam, npfloat)).to(dev)
         self.is_pin = torch.from_numpy(np.asarray(pin).astype(bool)).to(dev)
+        if not bool((self.mass > 0).all()):  # collect_IP divides by the summed mass of every occupied cell (solver.py:450)
+            raise ValueError("Simulator: every point needs mass > 0 (a PLY written by OutputToPly carries positions only)")
         self.initialize()
 
     def OutputToPly(self, path):
+        """solver.py:109-113: the deformed point positions as a vertex element with double x, y, z only."""
         p = self.update_pos().cpu().numpy().astype(np.float64)
-        n = p.shape[0]
-        scene.write_ply(path, dict(pos=p, mass=np.zeros(n), mu=np.zeros(n), lam=np.zeros(n), pin=np.zeros(n, np.int32)))
+        scene.write_ply(path, dict(pos=p), props=("x", "y", "z"))
 
     # ------------------------------------------------------------------ init (solver.py:139-331)
     def initialize(self):
@@ -206,13 +220,23 @@ class Simulator:
 
     step = stepforward  # BASELINE.json's name for the same entry point
 
+    def _force_launch(self, vid, f3):
+        st = self.force_stream
+        if st is not None:  # ordered between two substeps of the simulator's own stream, after whatever the caller has enqueued so far
+            st.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(st) if st is not None else _null_ctx():
+            check(lib().pn_sim_update_force(self.n_k, int(vid), f3.ctypes.data if f3 is not None else None, float(self.dx), ptr(self.IP_kernel),
+                                            ptr(self.IP_rho), ptr(self.IP_Nx), ptr(self.dof_f), stream_ptr()), "update_force")
+
     def update_force(self, vid, f):  # solver.py:578-588
+        """dof_f = the pick force `f` on IP `vid`, written whole by one launch on `force_stream` (or the current stream): it acts from the
+        next substep enqueued after this call."""
         f3 = np.ascontiguousarray(f.detach().cpu().numpy() if torch.is_tensor(f) else f, dtype=np.float64)
-        check(lib().pn_sim_update_force(self.n_k, int(vid), f3.ctypes.data, float(self.dx), ptr(self.IP_kernel), ptr(self.IP_rho), ptr(self.IP_Nx),
-                                        ptr(self.dof_f), stream_ptr()), "update_force")
+        assert 0 <= int(vid) < self.n_IP and f3.shape == (3,)
+        self._force_launch(vid, f3)
 
     def clear_force(self):  # solver.py:590-593
-        self.dof_f.zero_()
+        self._force_launch(-1, None)
 
     def update_pos(self):  # solver.py:604-617 (update_pos_kernel) — only used by OutputToPly
         d = self.dof.view(self.n_k, 10, 3)[self.pts_kernel.long()]

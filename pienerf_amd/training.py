@@ -31,14 +31,58 @@ class RayImageSet:
                 "index": v}
 
 
+class ParamEMA:
+    """Exponential moving average of the trainable parameters with torch_ema's interface subset the reference uses (trainer.py:86-89,
+    643-644, 751-753, 789-790: update / store / copy_to / restore / state_dict), including torch_ema's warm-up of the decay,
+    min(decay, (1 + n) / (10 + n))."""
+
+    def __init__(self, parameters, decay=0.95):
+        self.decay, self.num_updates = float(decay), 0
+        self.params = [p for p in parameters if p.requires_grad]
+        self.shadow = [p.detach().clone() for p in self.params]
+        self.stored = None
+
+    @torch.no_grad()
+    def update(self):
+        self.num_updates += 1
+        d = min(self.decay, (1 + self.num_updates) / (10 + self.num_updates))
+        for s, p in zip(self.shadow, self.params):
+            s.sub_((1.0 - d) * (s - p))
+
+    @torch.no_grad()
+    def store(self):
+        self.stored = [p.detach().clone() for p in self.params]
+
+    @torch.no_grad()
+    def copy_to(self):
+        for s, p in zip(self.shadow, self.params):
+            p.copy_(s)
+
+    @torch.no_grad()
+    def restore(self):
+        for s, p in zip(self.stored, self.params):
+            p.copy_(s)
+        self.stored = None
+
+    def state_dict(self):
+        return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": [s.clone() for s in self.shadow], "collected_params": None}
+
+    def load_state_dict(self, sd):
+        self.decay, self.num_updates = float(sd["decay"]), int(sd["num_updates"])
+        for s, v in zip(self.shadow, sd["shadow_params"]):
+            s.copy_(v.to(s.device))
+
+
 class Trainer:
-    def __init__(self, model, opt, lr=1e-2, iters=30000, update_extra_interval=16, num_rays=4096):
+    def __init__(self, model, opt, lr=1e-2, iters=30000, update_extra_interval=16, num_rays=4096, ema_decay=None):
+        """ema_decay: main_train.py:78 passes 0.95; None (default) trains without an average, like Trainer's own default (trainer.py:19)."""
         self.model, self.opt = model, dict(opt)
         self.optimizer = torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
         self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lambda it: 0.1 ** min(it / iters, 1))
         self.criterion = torch.nn.MSELoss(reduction="none")
         self.update_extra_interval, self.num_rays = update_extra_interval, num_rays
         self.global_step = 0
+        self.ema = ParamEMA(model.parameters(), ema_decay) if ema_decay is not None else None
 
     def _render_opts(self):
         keep = ("dt_gamma", "max_steps", "T_thresh")
@@ -72,6 +116,8 @@ class Trainer:
             loss.backward()
             self.optimizer.step()
             self.lr_scheduler.step()
+            if self.ema is not None:  # trainer.py:643-644
+                self.ema.update()
             losses.append(float(loss.detach()))
         return losses
 
@@ -79,8 +125,13 @@ class Trainer:
     def evaluate(self, dataset, view):
         """Full-image PSNR of one view (eval() mode: the inference loop of run_cuda)."""
         self.model.eval()
+        if self.ema is not None:  # evaluation runs on the averaged weights (trainer.py:751-753, 789-790)
+            self.ema.store()
+            self.ema.copy_to()
         rays = get_rays(dataset.poses[view:view + 1], dataset.intrinsics, dataset.H, dataset.W)
         out = self.model.render(rays["rays_o"], rays["rays_d"], bg_color=1, perturb=False, **self._render_opts())
+        if self.ema is not None:
+            self.ema.restore()
         img = dataset.images[view]
         gt = img[..., :3] * img[..., 3:] + (1 - img[..., 3:]) if img.shape[-1] == 4 else img
         mse = torch.mean((out["image"].view(dataset.H, dataset.W, 3) - gt) ** 2)

@@ -422,3 +422,54 @@ def test_pipelined_frames_equal_eager_steps(small_cloud, small_opt, ckpt, lanes,
         eager.sim.stepforward()
     assert rel_err((pipe.sim.dof - pipe.sim.dof_rest).cpu().numpy(), (eager.sim.dof - eager.sim.dof_rest).cpu().numpy()) < 1e-7
     assert (want[0] - want[4]).abs().max() > 1e-3  # the object really moved between frames
+
+
+def test_force_change_between_overlapped_steps_matches_oracle(small_cloud, small_opt, ckpt):
+    """update_force / clear_force while the substeps run on their own stream (harness.step with overlap_sim, and the pipelined form with
+    the simulator running ahead): the change is enqueued on the simulator's stream (Simulator.force_stream), so it lands between two
+    substeps — the trajectory equals the oracle's with the force switched at the same substep index (solver.py:578-593, the GUI's drag
+    and release).  Repeated to give a race a chance."""
+    from pienerf_amd.harness import SimRenderHarness
+    opt = dict(small_opt, W=32, H=32)
+    f1, f2 = np.array([300.0, 100.0, -200.0]), np.array([-150.0, 220.0, 90.0])
+    for rep in range(3):
+        h = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV)  # overlap_sim=True: substep on a side stream
+        assert h.sim.force_stream is h._sim_stream
+        ref = make_oracle_sim(small_cloud, opt)
+        vid = h.sim.n_IP // 2
+        plan = {1: ("set", vid, f1), 3: ("set", vid // 2, f2), 5: ("clear",), 6: ("set", vid, f2)}
+        for step in range(8):
+            if step in plan:
+                if plan[step][0] == "set":
+                    h.sim.update_force(plan[step][1], plan[step][2])
+                    ref.update_force(plan[step][1], plan[step][2])
+                else:
+                    h.sim.clear_force()
+                    ref.clear_force()
+            h.step()       # no synchronisation in between: the force launch must order itself against the running substep
+            ref.stepforward()
+        h.synchronize()
+        disp, want = h.sim.dof.cpu().numpy().reshape(-1, 3) - ref.dof_rest, ref.dof - ref.dof_rest
+        assert rel_err(disp, want) < 1e-6, (rep, rel_err(disp, want))
+        assert rel_err(h.sim.dof_f.cpu().numpy().reshape(-1, 3), ref.dof_f) < 1e-14
+    # pipelined: the simulator is `ahead` substeps in front; a force set now acts from substep `substeps_enqueued`
+    p = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture_pipelined(lanes=2, n_trips=8)
+    ref = make_oracle_sim(small_cloud, opt)
+    done = 0
+    for frame in range(9):
+        if frame in (2, 5):
+            while done < p.substeps_enqueued:
+                ref.stepforward()
+                done += 1
+            if frame == 2:
+                p.sim.update_force(p.sim.n_IP // 2, f1)
+                ref.update_force(p.sim.n_IP // 2, f1)
+            else:
+                p.sim.clear_force()
+                ref.clear_force()
+        p.step_pipelined()
+    p.drain_pipeline()
+    while done < p.substeps_enqueued:
+        ref.stepforward()
+        done += 1
+    assert rel_err(p.sim.dof.cpu().numpy().reshape(-1, 3) - ref.dof_rest, ref.dof - ref.dof_rest) < 1e-6
