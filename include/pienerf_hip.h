@@ -94,6 +94,12 @@ int pn_grid_encode_forward(const float* inputs, const float* embeddings, const i
                            uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype, int align_corners,
                            uint32_t interp, int out_bl_major, void* stream);
 
+/* grid_encode_forward on a half table (AT_DISPATCH_FLOATING_TYPES_AND_HALF, gridencoder.cu:448-471 -> kernel_grid<at::Half,3,C>): embeddings
+ * [sO,C] and outputs fp16 (bit patterns), inputs fp32; no dy_dx (inference).  What GridEncoder.forward launches under autocast. */
+int pn_grid_encode_forward_half(const float* inputs, const uint16_t* embeddings, const int* offsets_host, uint16_t* outputs, uint32_t B, uint32_t D,
+                                uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                int out_bl_major, void* stream);
+
 /* ------------------------------------------------------------------ shencoder ---- */
 
 /* shencoder/src/shencoder.h:9 sh_encode_forward (kernel shencoder.cu:27-123), D=3, degree C in [1,4]; dy_dx NULL or [B, 3, C*C]
@@ -153,12 +159,28 @@ int pn_net_create(pn_net** out, const float* embeddings /*device, [n,2]*/, const
                   float per_level_scale_log2, uint32_t base_resolution, float bound, const float* W0_host, const float* W1_host,
                   const float* W2_host, const float* W3_host, const float* W4_host, void* stream);
 void pn_net_destroy(pn_net* net);
+/* Refreshes the packed weights of an existing context in place after the parameters changed (training: every optimizer step invalidates
+ * them): host-side packing into the context's pinned staging buffer + two asynchronous uploads on `stream`.  No allocation, no stream
+ * synchronisation (it waits only for the previous refresh's own upload event).  `embeddings` replaces the table pointer; when the fp16
+ * tables exist they are re-rounded from it.  PN_ERR_ARG while `stream` is being captured (the packing cannot be replayed). */
+int pn_net_update(pn_net* net, const float* embeddings, const float* W0_host, const float* W1_host, const float* W2_host, const float* W3_host,
+                  const float* W4_host, void* stream);
+/* Creates the fp16 copy of the hash tables (`embeddings.to(torch.half)`, gridencoder/grid.py:43-44; round to nearest even) once; the fp16
+ * weight image always exists.  Call before the first *_half launch or fp16 render, outside stream capture. */
+int pn_net_enable_half(pn_net* net, void* stream);
 /* sigmas[M], rgbs[M,3] for xyzs[M,3] in [-bound,bound], dirs[M,3] unit.  density_scale multiplies sigma (renderer.py:875). */
 int pn_nerf_forward(const pn_net* net, const float* xyzs, const float* dirs, uint32_t M, float density_scale, float* sigmas, float* rgbs,
                     void* stream);
+/* The same under autocast (fp16 tables, half Linear layers on v_mfma_f32_32x32x16_f16, half activations): sigmas fp32 (trunc_exp casts to
+ * float, nerf/activation.py:7), rgbs fp32 holding the half-rounded sigmoid outputs. */
+int pn_nerf_forward_half(const pn_net* net, const float* xyzs, const float* dirs, uint32_t M, float density_scale, float* sigmas, float* rgbs,
+                         void* stream);
 /* NeRFNetwork.density (nerf/network.py:129-146): sigma = trunc_exp(h[0]) (no density_scale), geo_feat = h[1:16]; the same fused
  * kernel stopped after the sigma net.  Used off the hot path (point sampling, main_sample.py:164-168).  sigmas [M], geo_feat [M,15]. */
 int pn_nerf_density(const pn_net* net, const float* xyzs, uint32_t M, float* sigmas, float* geo_feat, void* stream);
+int pn_nerf_density_half(const pn_net* net, const float* xyzs, uint32_t M, float* sigmas, float* geo_feat, void* stream);
+/* [host] fp32 -> fp16 bit patterns, round to nearest even: the rounding the host side of pn_net_create applies to the weights. */
+int pn_host_float_to_half(const float* in_host, uint16_t* out_host, uint32_t n);
 
 /* ------------------------------------------------------------------ whole frame ---- */
 
@@ -183,6 +205,8 @@ typedef struct {
     uint32_t grid_size;   /* H = 128 */
     float density_scale;
     float bg_color;       /* scalar background (renderer.py:803-804: bg_color = 1) */
+    int fp16;             /* != 0: the network runs as under torch.cuda.amp.autocast (trainer.py:561, Trainer(fp16=True)): fp16 hash tables
+                             (gridencoder/grid.py:43-44), fp16 MFMA layers with half-rounded activations; needs pn_net_enable_half */
 } pn_render_opts;
 int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_vtx, uint32_t max_grid_cells);
 void pn_frame_destroy(pn_frame* f);

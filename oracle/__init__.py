@@ -213,6 +213,43 @@ def nerf_forward(xyzs, dirs, ckpt, bound):
     return sig, rgb
 
 
+class half_precision:
+    """Context manager: inside it ``nerf_forward`` and ``render_deformed`` restate the network as the reference runs it under
+    ``torch.cuda.amp.autocast`` with fp16 (trainer.py:561 with Trainer(fp16=True)): half hash tables with kernel_grid<at::Half>'s half
+    accumulation (gridencoder/grid.py:43-44, gridencoder.cu:184), half nn.Linear layers, half sigmoid (render_oracle.cpp: nerf_one)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        lib().orc_set_half.restype = I
+        self.prev = lib().orc_set_half(I(int(self.on)))
+        return self
+
+    def __exit__(self, *a):
+        lib().orc_set_half(I(self.prev))
+        return False
+
+
+def hround(a):
+    """a rounded to the nearest fp16 value (ties to even), as float32 — the oracle's software rounding."""
+    a = _f32(a)
+    out = np.empty_like(a)
+    lib().orc_hround(_p(a.reshape(-1), F), _p(out.reshape(-1), F), C.c_uint32(a.size))
+    return out
+
+
+def grid_encode_forward_half(inputs, embeddings, offsets, per_level_scale, base_resolution, gridtype=0, align_corners=False, interpolation=0):
+    """kernel_grid<at::Half> (the autocast branch of gridencoder/grid.py:24-63): [B, L*C] half values as float32."""
+    inputs, embeddings, offsets = _f32(inputs).reshape(-1, 3), _f32(embeddings), _i32(offsets)
+    B, L, Cf = inputs.shape[0], offsets.shape[0] - 1, embeddings.shape[1]
+    out = np.empty((L, B, Cf), np.float32)
+    lib().orc_grid_encode_forward_half(_p(inputs, F), _p(embeddings, F), _p(offsets, I), _p(out, F), C.c_uint32(B), C.c_uint32(Cf), C.c_uint32(L),
+                                       F(np.float32(np.log2(per_level_scale))), C.c_uint32(base_resolution), C.c_uint32(gridtype),
+                                       I(int(align_corners)), C.c_uint32(interpolation))
+    return np.ascontiguousarray(out.transpose(1, 0, 2).reshape(B, L * Cf))
+
+
 def get_rays(pose, intrinsics, H, W):
     pose = _f32(pose).reshape(4, 4)
     fx, fy, cx, cy = [float(np.float32(v)) for v in intrinsics]

@@ -422,9 +422,34 @@ inline uint32_t grid_index(uint32_t gridtype, bool align_corners, uint32_t C, ui
     return (index % hashmap_size) * C;
 }
 
-// kernel_grid<float,3,C> for one (sample, level), gridencoder.cu:87-197 (dy_dx == nullptr path)
+// ---- fp16 (the reference under torch.cuda.amp.autocast, trainer.py:561 with Trainer(fp16=True); BASELINE configs[4]) ----------------------
+// hround(x): x rounded to the nearest fp16 value (ties to even), returned as float — what `tensor.to(torch.half)`, c10::Half(float) and
+// __float2half do.  Software, so that the oracle does not depend on compiler / CPU fp16 support.
+static inline float hround(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = x & 0x80000000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return f;                                                   // inf / nan
+    if (x >= 0x477ff000u) { const uint32_t inf = sign | 0x7f800000u; float r; memcpy(&r, &inf, 4); return r; }  // >= 65520 -> inf
+    if (x < 0x33000001u) { float r; memcpy(&r, &sign, 4); return r; }                 // <= 2^-25 -> (signed) zero
+    const int e = (int)(x >> 23) - 127;
+    const int drop = (e < -14) ? (13 + (-14 - e)) : 13;                               // low significand bits that do not fit a half
+    const uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    uint32_t q = m >> drop;
+    const uint32_t rem = m & ((1u << drop) - 1u), halfway = 1u << (drop - 1);
+    if (rem > halfway || (rem == halfway && (q & 1u))) q++;
+    const float r = ldexpf((float)q, e - 23 + drop);                                   // exact: q < 2^12
+    return sign ? -r : r;
+}
+static int g_half = 0;  // orc_set_half: nerf_one / the render drivers restate the autocast arithmetic
+
+// kernel_grid<scalar_t,3,C> for one (sample, level), gridencoder.cu:87-197 (dy_dx == nullptr path).  half == false: scalar_t = float.
+// half == true: scalar_t = at::Half (gridencoder/grid.py:43-44 casts the table; `table` holds the half values as floats): positions and
+// weights stay float (:137-139), and `results[ch] += w * grid[index + ch]` (:184) is, with c10::Half's operators, Half(float * float(Half))
+// followed by Half + Half = Half(float + float): two roundings to half per corner.
 void grid_one(const float* in3, const float* table /*level base*/, uint32_t hashmap_size, float scale, uint32_t resolution, uint32_t C, uint32_t gridtype,
-              bool align_corners, uint32_t interp, float* out) {
+              bool align_corners, uint32_t interp, float* out, bool half = false) {
     bool oob = false;
     for (int d = 0; d < 3; d++) if (in3[d] < 0 || in3[d] > 1) oob = true;
     if (oob) { for (uint32_t c = 0; c < C; c++) out[c] = 0; return; }
@@ -448,7 +473,8 @@ void grid_one(const float* in3, const float* table /*level base*/, uint32_t hash
             else { w *= pos[d]; pl[d] = pg[d] + 1; }
         }
         const uint32_t index = grid_index(gridtype, align_corners, C, hashmap_size, resolution, pl);
-        for (uint32_t c = 0; c < C; c++) res[c] += w * table[index + c];
+        if (half) for (uint32_t c = 0; c < C; c++) res[c] = hround(res[c] + hround(w * table[index + c]));
+        else for (uint32_t c = 0; c < C; c++) res[c] += w * table[index + c];
     }
     for (uint32_t c = 0; c < C; c++) out[c] = res[c];
 }
@@ -503,11 +529,37 @@ struct Net {
     float S;
     float bound;
     const float *W0, *W1, *W2, *W3, *W4;  // [64,32] [16,64] [64,31] [64,64] [3,64] row-major (out,in), nerf/network.py:36-71
+    bool half = false;                    // autocast: embeddings / W* below are the half-rounded copies (HalfNet)
+};
+
+// The half-rounded copies autocast makes: embeddings.to(torch.half) (gridencoder/grid.py:44) and, inside every nn.Linear, weight.to(half).
+struct HalfNet {
+    std::vector<float> emb, W[5];
+    Net net;
+    HalfNet(const Net& src, size_t n_emb_floats) {
+        emb.resize(n_emb_floats);
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < (int64_t)n_emb_floats; i++) emb[i] = hround(src.embeddings[i]);
+        const float* w[5] = {src.W0, src.W1, src.W2, src.W3, src.W4};
+        const size_t n[5] = {64 * 32, 16 * 64, 64 * 31, 64 * 64, 3 * 64};
+        for (int k = 0; k < 5; k++) { W[k].resize(n[k]); for (size_t i = 0; i < n[k]; i++) W[k][i] = hround(w[k][i]); }
+        net = src;
+        net.embeddings = emb.data();
+        net.W0 = W[0].data(); net.W1 = W[1].data(); net.W2 = W[2].data(); net.W3 = W[3].data(); net.W4 = W[4].data();
+        net.half = true;
+    }
 };
 
 // NeRFNetwork.forward for one sample, nerf/network.py:98-127 + gridencoder/grid.py:145-161
 // (u = (x+bound)/(2*bound)) + shencoder/sphere_harmonics.py:75-87 (size = 1).
 void nerf_one(const Net& nt, const float* xyz, const float* dir, float* sigma, float* rgb) {
+    // nt.half (autocast, fp16): every nn.Linear takes half inputs and half weights, accumulates in float and returns half (one rounding per
+    // output; the accumulation ORDER inside cuBLAS is not knowable — sequential here); ReLU and the slices are exact in half; trunc_exp
+    // casts its input to float (activation.py:7); SHEncoder returns float (sphere_harmonics.py:16) and torch.cat([d, geo_feat]) promotes to
+    // float, so the SH values are rounded to half by the first colour Linear's input cast; torch.sigmoid of a half tensor computes in float
+    // and rounds to half.  H(x) is that rounding; the identity otherwise.
+    const bool hf = nt.half;
+    auto H = [hf](float v) { return hf ? hround(v) : v; };
     float u[3];
     for (int d = 0; d < 3; d++) u[d] = (xyz[d] + nt.bound) / (2 * nt.bound);
     float enc[64];
@@ -515,39 +567,44 @@ void nerf_one(const Net& nt, const float* xyz, const float* dir, float* sigma, f
         float scale; uint32_t res;
         level_params(l, nt.S, nt.Hbase, &scale, &res);
         const uint32_t hs = (uint32_t)(nt.offsets[l + 1] - nt.offsets[l]);
-        grid_one(u, nt.embeddings + (size_t)(uint32_t)nt.offsets[l] * nt.Cf, hs, scale, res, nt.Cf, 0, false, 0, enc + l * nt.Cf);
+        grid_one(u, nt.embeddings + (size_t)(uint32_t)nt.offsets[l] * nt.Cf, hs, scale, res, nt.Cf, 0, false, 0, enc + l * nt.Cf, hf);
     }
     const uint32_t in_dim = nt.L * nt.Cf;  // 32
     float h1[64], h2[16];
     for (int j = 0; j < 64; j++) {
         float s = 0;
         for (uint32_t k = 0; k < in_dim; k++) s += nt.W0[j * in_dim + k] * enc[k];
+        s = H(s);
         h1[j] = s > 0 ? s : 0;
     }
     for (int j = 0; j < 16; j++) {
         float s = 0;
         for (int k = 0; k < 64; k++) s += nt.W1[j * 64 + k] * h1[k];
-        h2[j] = s;
+        h2[j] = H(s);
     }
     *sigma = expf(h2[0]);  // trunc_exp forward, nerf/activation.py:8-10
     float cin[31];
     sh_one(dir, 4, cin);
+    for (int k = 0; k < 16; k++) cin[k] = H(cin[k]);
     for (int k = 0; k < 15; k++) cin[16 + k] = h2[1 + k];
     float c1[64], c2[64];
     for (int j = 0; j < 64; j++) {
         float s = 0;
         for (int k = 0; k < 31; k++) s += nt.W2[j * 31 + k] * cin[k];
+        s = H(s);
         c1[j] = s > 0 ? s : 0;
     }
     for (int j = 0; j < 64; j++) {
         float s = 0;
         for (int k = 0; k < 64; k++) s += nt.W3[j * 64 + k] * c1[k];
+        s = H(s);
         c2[j] = s > 0 ? s : 0;
     }
     for (int j = 0; j < 3; j++) {
         float s = 0;
         for (int k = 0; k < 64; k++) s += nt.W4[j * 64 + k] * c2[k];
-        rgb[j] = 1.0f / (1.0f + expf(-s));  // torch.sigmoid
+        s = H(s);
+        rgb[j] = H(1.0f / (1.0f + expf(-s)));  // torch.sigmoid
     }
 }
 
@@ -773,9 +830,36 @@ void orc_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint
 void orc_nerf_forward(const float* xyzs, const float* dirs, uint32_t M, float bound, const float* embeddings, const int* offsets, uint32_t L,
                       uint32_t Cf, float S, uint32_t Hbase, const float* W0, const float* W1, const float* W2, const float* W3, const float* W4,
                       float* sigmas, float* rgbs) {
-    Net nt{embeddings, offsets, L, Cf, Hbase, S, bound, W0, W1, W2, W3, W4};
+    Net base{embeddings, offsets, L, Cf, Hbase, S, bound, W0, W1, W2, W3, W4};
+    HalfNet* hn = g_half ? new HalfNet(base, (size_t)(uint32_t)offsets[L] * Cf) : nullptr;
+    const Net& nt = hn ? hn->net : base;
 #pragma omp parallel for schedule(static)
     for (int64_t m = 0; m < (int64_t)M; m++) nerf_one(nt, xyzs + m * 3, dirs + m * 3, sigmas + m, rgbs + m * 3);
+    delete hn;
+}
+
+// orc_set_half(1): orc_nerf_forward / orc_render_deformed restate the network as the reference runs it under autocast with fp16 (see
+// nerf_one / grid_one); returns the previous setting.
+int orc_set_half(int on) { const int prev = g_half; g_half = on ? 1 : 0; return prev; }
+
+// [host] test hook: out[i] = in[i] rounded to the nearest fp16 value
+void orc_hround(const float* in, float* out, uint32_t n) { for (uint32_t i = 0; i < n; i++) out[i] = hround(in[i]); }
+
+// kernel_grid<at::Half,3,C> over B samples: `embeddings` fp32 master (rounded to half here, grid.py:44), outputs [L,B,C] = half values as floats
+void orc_grid_encode_forward_half(const float* inputs, const float* embeddings, const int* offsets, float* outputs, uint32_t B, uint32_t C, uint32_t L,
+                                  float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp) {
+    if (C > 8) return;
+    std::vector<float> tab((size_t)(uint32_t)offsets[L] * C);
+    for (size_t i = 0; i < tab.size(); i++) tab[i] = hround(embeddings[i]);
+    for (uint32_t l = 0; l < L; l++) {
+        float scale; uint32_t res;
+        level_params(l, S, H, &scale, &res);
+        const uint32_t hs = (uint32_t)(offsets[l + 1] - offsets[l]);
+        const float* table = tab.data() + (size_t)(uint32_t)offsets[l] * C;
+#pragma omp parallel for schedule(static)
+        for (int64_t b = 0; b < (int64_t)B; b++)
+            grid_one(inputs + b * 3, table, hs, scale, res, C, gridtype, align_corners != 0, interp, outputs + ((size_t)l * B + b) * C, true);
+    }
 }
 
 // nerf/utils.py:54-138 (N = -1 path): pixel centres, row-major; d = normalize(...) @ R^T; o = t.
@@ -818,7 +902,9 @@ int orc_render_deformed(const float* rays_o, const float* rays_d, uint32_t N, co
     std::vector<int> alive(N), alive2(N);
     for (uint32_t i = 0; i < N; i++) alive[i] = (int)i;
     rays_t = nears;
-    Net nt{embeddings, offsets, L, Cf, Hbase, S, bound, W0, W1, W2, W3, W4};
+    Net base{embeddings, offsets, L, Cf, Hbase, S, bound, W0, W1, W2, W3, W4};
+    HalfNet* hn = g_half ? new HalfNet(base, (size_t)(uint32_t)offsets[L] * Cf) : nullptr;  // autocast: half tables / weights
+    const Net& nt = hn ? hn->net : base;
     uint32_t step = 0;
     int trips = 0;
     int64_t emitted = 0, slots = 0;
@@ -862,6 +948,7 @@ int orc_render_deformed(const float* rays_o, const float* rays_d, uint32_t N, co
         depth[i] = fmaxf(depth_0[i] - nears[i], 0.0f) / (fars[i] - nears[i]);
     }
     if (stats) { stats[0] = trips; stats[1] = emitted; stats[2] = slots; }
+    delete hn;
     return trips;
 }
 

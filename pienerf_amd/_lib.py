@@ -17,7 +17,7 @@ class RenderOpts(C.Structure):
     """pn_render_opts (include/pienerf_hip.h)."""
     _fields_ = [("max_iter_num", i32), ("hash_grid_size", f32), ("num_seek_IP", i32), ("IP_dx", f32), ("cut", i32), ("cut_bounds", f32 * 6),
                 ("bound", f32), ("min_near", f32), ("dt_gamma", f32), ("max_steps", u32), ("T_thresh", f32), ("cascade", u32), ("grid_size", u32),
-                ("density_scale", f32), ("bg_color", f32)]
+                ("density_scale", f32), ("bg_color", f32), ("fp16", i32)]
 
 
 # name -> (restype, argtypes); every function declared in include/pienerf_hip.h
@@ -40,6 +40,12 @@ SIGNATURES = {
     "pn_sh_encode_forward": (i32, [P, P, u32, u32, u32, P, P]),
     "pn_net_create": (i32, [C.POINTER(P), P, P, u32, u32, f32, u32, f32, P, P, P, P, P, P]),
     "pn_net_destroy": (None, [P]),
+    "pn_net_update": (i32, [P, P, P, P, P, P, P, P]),
+    "pn_net_enable_half": (i32, [P, P]),
+    "pn_nerf_forward_half": (i32, [P, P, P, u32, f32, P, P, P]),
+    "pn_nerf_density_half": (i32, [P, P, u32, P, P, P]),
+    "pn_host_float_to_half": (i32, [P, P, u32]),
+    "pn_grid_encode_forward_half": (i32, [P, P, P, P, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, P]),
     "pn_march_rays_train": (i32, [P, P, P, f32, f32, u32, u32, u32, u32, u32, P, P, P, P, P, P, P, P, P]),
     "pn_composite_rays_train_forward": (i32, [P, P, P, P, u32, u32, f32, P, P, P, P]),
     "pn_composite_rays_train_backward": (i32, [P, P, P, P, P, P, P, P, u32, u32, f32, P, P, P]),

@@ -67,17 +67,29 @@ int pn_fill_grid_levels(PnGridLevels* g, const int* offsets_host, uint32_t L, ui
 struct pn_net {
     PnGridLevels levels;
     const float* embeddings;  // device, not owned
-    void* wsplit;             // device, owned: the kernel's LDS weight image, PN_NET_SPLIT_BYTES (pn_nerf_forward.hip)
+    void* wsplit;             // device, owned: the fp32-accurate kernel's LDS weight image, PN_NET_SPLIT_BYTES (pn_nerf_forward.hip)
     void* fused_levels;       // device, owned: PnFusedLevel[16] (pn_nerf_forward.hip)
     float bound;
+    uint32_t n_entries;       // rows of `embeddings` (offsets[L])
+    // fp16 form (the reference under torch.cuda.amp.autocast: gridencoder/grid.py:43-44, nn.Linear in half): built on first use by
+    // pn_net_enable_half, refreshed by pn_net_update
+    void* emb_half;           // device, owned: embeddings rounded to fp16 (RNE), [n_entries, 2] halves
+    void* whalf;              // device, owned: the fp16 kernel's LDS weight image, PN_NET_HALF_BYTES
+    // staging for in-place weight refreshes (pn_net_update): pinned host images + the event of the last upload that read them
+    void* stage;              // host pinned, PN_NET_SPLIT_BYTES + PN_NET_HALF_BYTES
+    hipEvent_t stage_done;
 };
 
 // weight image: [20 MFMA operand groups][3 bf16 pieces hi/mid/lo][64 lanes][8 bf16], then the VALU output layer's 192 fp32 weights
 #define PN_NET_GROUPS 20
 #define PN_NET_SPLIT_W_BYTES (PN_NET_GROUPS * 3 * 64 * 16)
 #define PN_NET_SPLIT_BYTES (PN_NET_SPLIT_W_BYTES + 192 * 4)
+// fp16 weight image: [20 operand groups][64 lanes][8 fp16], then the output layer's 192 weights (fp16-rounded, stored as fp32)
+#define PN_NET_HALF_W_BYTES (PN_NET_GROUPS * 64 * 16)
+#define PN_NET_HALF_BYTES (PN_NET_HALF_W_BYTES + 192 * 4)
 
 // internal launcher shared by pn_nerf_forward and the frame driver: evaluates the network on the `count` samples whose
 // slot ids are list[0..count) (list == NULL: slots 0..M-1); when ctl_count != NULL the count is read from device memory.
+// half != 0: the fp16 form (fp16 tables, fp16 MFMA, half-rounded activations); requires pn_net_enable_half to have been called.
 int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* dirs, const int* list, const int* ctl_count, uint32_t M_max,
-                           float density_scale, float* sigmas, float* rgbs, hipStream_t stream);
+                           float density_scale, float* sigmas, float* rgbs, int half, hipStream_t stream);

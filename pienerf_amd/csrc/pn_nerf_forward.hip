@@ -49,20 +49,22 @@ int pn_fill_grid_levels(PnGridLevels* g, const int* offsets_host, uint32_t L, ui
 
 // ------------------------------------------------------------------------------------------------ op-level grid encoder
 // One thread per (sample, level); blockIdx.y = level keeps one level's table hot in the XCD L2s (gridencoder.cu:103,388).
-template <uint32_t C>
-__global__ void __launch_bounds__(256) k_grid_encode(const float* __restrict__ inputs, const float* __restrict__ emb, PnGridLevels lv, uint32_t B,
-                                                     int align_corners, uint32_t interp, int out_bl_major, float* __restrict__ outputs) {
+// T = float: kernel_grid<float,3,C>.  T = _Float16: kernel_grid<at::Half,3,C> — the table and the outputs are half, positions and weights
+// stay float, and `results[ch] += w * grid[index + ch]` rounds the float product to half and adds half + half (c10::Half operators).
+template <uint32_t C, typename T>
+__global__ void __launch_bounds__(256) k_grid_encode(const float* __restrict__ inputs, const T* __restrict__ emb, PnGridLevels lv, uint32_t B,
+                                                     int align_corners, uint32_t interp, int out_bl_major, T* __restrict__ outputs) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const uint32_t level = blockIdx.y;
-    float* out = out_bl_major ? outputs + ((size_t)b * lv.L + level) * C : outputs + ((size_t)level * B + b) * C;
+    T* out = out_bl_major ? outputs + ((size_t)b * lv.L + level) * C : outputs + ((size_t)level * B + b) * C;
     const float in0 = inputs[b * 3], in1 = inputs[b * 3 + 1], in2 = inputs[b * 3 + 2];
     if (in0 < 0 || in0 > 1 || in1 < 0 || in1 > 1 || in2 < 0 || in2 > 1) {
 #pragma unroll
-        for (uint32_t c = 0; c < C; c++) out[c] = 0;
+        for (uint32_t c = 0; c < C; c++) out[c] = (T)0.0f;
         return;
     }
-    const float* __restrict__ table = emb + (size_t)lv.offset[level] * C;
+    const T* __restrict__ table = emb + (size_t)lv.offset[level] * C;
     const LevelIdx LI = level_idx(lv, level, align_corners);
     const float scale = lv.scale[level];
     float pos[3] = {in0, in1, in2};
@@ -74,9 +76,9 @@ __global__ void __launch_bounds__(256) k_grid_encode(const float* __restrict__ i
         pos[d] -= (float)pg[d];
         if (interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
     }
-    float res[C];
+    T res[C];
 #pragma unroll
-    for (uint32_t c = 0; c < C; c++) res[c] = 0;
+    for (uint32_t c = 0; c < C; c++) res[c] = (T)0.0f;
 #pragma unroll
     for (uint32_t idx = 0; idx < 8; idx++) {
         float w = 1;
@@ -87,44 +89,59 @@ __global__ void __launch_bounds__(256) k_grid_encode(const float* __restrict__ i
             else { w *= pos[d]; pl[d] = pg[d] + 1; }
         }
         const uint32_t index = grid_index3(LI, pl[0], pl[1], pl[2]) * C;
-        if (C == 2) {
+        if (sizeof(T) == 4 && C == 2) {
             const float2 v = *reinterpret_cast<const float2*>(table + index);
-            res[0] += w * v.x;
-            res[1] += w * v.y;
+            res[0] += (T)(w * v.x);
+            res[1] += (T)(w * v.y);
         } else {
 #pragma unroll
-            for (uint32_t c = 0; c < C; c++) res[c] += w * table[index + c];
+            for (uint32_t c = 0; c < C; c++) res[c] = res[c] + (T)(w * (float)table[index + c]);
         }
     }
-    if (C == 2) *reinterpret_cast<float2*>(out) = make_float2(res[0], res[1]);
-    else {
 #pragma unroll
-        for (uint32_t c = 0; c < C; c++) out[c] = res[c];
+    for (uint32_t c = 0; c < C; c++) out[c] = res[c];
+}
+
+template <typename T>
+static int grid_encode_launch(const float* inputs, const T* embeddings, const int* offsets_host, T* outputs, uint32_t B, uint32_t D, uint32_t C,
+                              uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int out_bl_major,
+                              PnGridLevels* lv_out, hipStream_t st) {
+    PN_REQUIRE(inputs && embeddings && offsets_host && outputs);
+    PN_REQUIRE(D == 3);                                   // the reference also has D = 2,4,5 (gridencoder.cu:386-395); not on this path
+    PN_REQUIRE(C == 1 || C == 2 || C == 4 || C == 8);     // gridencoder.cu:376-382
+    PN_REQUIRE(gridtype <= 1 && interp <= 1);
+    PnGridLevels lv;
+    if (pn_fill_grid_levels(&lv, offsets_host, L, C, S, H, gridtype, align_corners)) { PN_REQUIRE(L >= 1 && L <= PN_MAX_LEVELS); }
+    dim3 grid(pn_div_up(B, 256), L, 1);
+    switch (C) {
+        case 1: k_grid_encode<1, T><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
+        case 2: k_grid_encode<2, T><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
+        case 4: k_grid_encode<4, T><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
+        default: k_grid_encode<8, T><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
     }
+    PN_LAUNCH_CHECK();
+    if (lv_out) *lv_out = lv;
+    return PN_OK;
 }
 
 extern "C" int pn_grid_encode_forward(const float* inputs, const float* embeddings, const int* offsets_host, float* outputs, uint32_t B, uint32_t D,
                                       uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype, int align_corners,
                                       uint32_t interp, int out_bl_major, void* stream) {
     if (B == 0) return PN_OK;  // empty tensors have null data pointers
-    PN_REQUIRE(inputs && embeddings && offsets_host && outputs);
-    PN_REQUIRE(D == 3);                                   // the reference also has D = 2,4,5 (gridencoder.cu:386-395); not on this path
-    PN_REQUIRE(C == 1 || C == 2 || C == 4 || C == 8);     // gridencoder.cu:376-382
-    PN_REQUIRE(gridtype <= 1 && interp <= 1);
-    if (B == 0) return PN_OK;
     PnGridLevels lv;
-    if (pn_fill_grid_levels(&lv, offsets_host, L, C, S, H, gridtype, align_corners)) { PN_REQUIRE(L >= 1 && L <= PN_MAX_LEVELS); }
-    dim3 grid(pn_div_up(B, 256), L, 1);
-    hipStream_t st = (hipStream_t)stream;
-    switch (C) {
-        case 1: k_grid_encode<1><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
-        case 2: k_grid_encode<2><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
-        case 4: k_grid_encode<4><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
-        default: k_grid_encode<8><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
-    }
-    PN_LAUNCH_CHECK();
-    if (dy_dx) return pn_grid_dy_dx_launch(inputs, embeddings, lv, B, C, align_corners, interp, dy_dx, st);  // training side (pn_encoder_grad.hip)
+    const int rc = grid_encode_launch<float>(inputs, embeddings, offsets_host, outputs, B, D, C, L, S, H, gridtype, align_corners, interp, out_bl_major,
+                                             &lv, (hipStream_t)stream);
+    if (rc) return rc;
+    if (dy_dx) return pn_grid_dy_dx_launch(inputs, embeddings, lv, B, C, align_corners, interp, dy_dx, (hipStream_t)stream);  // training side (pn_encoder_grad.hip)
     return PN_OK;
+}
+
+extern "C" int pn_grid_encode_forward_half(const float* inputs, const uint16_t* embeddings, const int* offsets_host, uint16_t* outputs, uint32_t B,
+                                           uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                           uint32_t interp, int out_bl_major, void* stream) {
+    if (B == 0) return PN_OK;
+    return grid_encode_launch<_Float16>(inputs, reinterpret_cast<const _Float16*>(embeddings), offsets_host, reinterpret_cast<_Float16*>(outputs), B, D,
+                                        C, L, S, H, gridtype, align_corners, interp, out_bl_major, nullptr, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------ SH (degree <= 4)
@@ -193,12 +210,116 @@ static void pack_weights(const float* W0, const float* W1, const float* W2, cons
             for (int l = 0; l < 64; l++) wp[m * 64 + l] = W3[(t * 32 + (l & 31)) * 64 + krow(q, l >> 5)];
 }
 
+// fp32 -> fp16, round to nearest even (what `tensor.to(torch.half)` and v_cvt_f16_f32 do), returned as the 16 payload bits
+static uint16_t pn_f2h_bits(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((x > 0x7f800000u) ? 0x200u : 0u));  // inf / nan
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                        // rounds to >= 65520 -> inf
+    if (x < 0x33000001u) return (uint16_t)sign;                                                     // <= 2^-25 -> 0 (ties to even)
+    int e = (int)(x >> 23) - 127;
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;  // 24-bit significand
+    int shift = (e < -14) ? (13 + (-14 - e)) : 13;  // bits dropped (subnormal halves drop more)
+    uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (q & 1u))) q++;
+    if (e < -14) return (uint16_t)(sign | q);  // subnormal (q may carry into the smallest normal: the encoding is continuous)
+    return (uint16_t)(sign | (((uint32_t)(e + 15) << 10) + (q - 0x400u)));  // mantissa carry rolls into the exponent
+}
+static float pn_h2f(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+    uint32_t x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { float v = (float)m * 5.9604644775390625e-8f; memcpy(&x, &v, 4); x |= sign; }  // m * 2^-24
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112u) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &x, 4);
+    return f;
+}
+
+// Both LDS weight images from the five row-major [out,in] matrices.
+//   simg (PN_NET_SPLIT_BYTES): operand group (layer, out tile t, K chunk kc) takes the 8 consecutive activation registers m0 + 8 kc + e
+//     (e = 0..7) of pack_weights' stream as the 8 K-elements of its lane, each weight cut into three bf16 pieces w = hi + mid + lo
+//     (truncation splits: exact, 8 + 8 + 8 significant bits); then the 64 -> 3 layer's fp32 weights for the vector ALU
+//     (wlast[h][q][o] = W4[o][krow(q, h)], q = tile*16 + register index of the D layout; an MFMA tile would be 29/32 row padding).
+//   himg (PN_NET_HALF_BYTES): the same groups with every weight rounded once to fp16 (autocast's `weight.to(half)`), one piece.
+static void build_weight_images(const float* W0, const float* W1, const float* W2, const float* W3, const float* W4, unsigned char* simg,
+                                unsigned char* himg) {
+    float* host = new float[160 * 64];
+    pack_weights(W0, W1, W2, W3, host);
+    uint16_t* s16 = reinterpret_cast<uint16_t*>(simg);
+    uint16_t* h16 = reinterpret_cast<uint16_t*>(himg);
+    int G = 0;
+    auto emit = [&](int m0) {
+        for (int l = 0; l < 64; l++)
+            for (int e2 = 0; e2 < 8; e2++) {
+                float v = host[(m0 + e2) * 64 + l];
+                h16[((size_t)G * 64 + l) * 8 + e2] = pn_f2h_bits(v);
+                for (int p = 0; p < 3; p++) {
+                    uint32_t u;
+                    memcpy(&u, &v, 4);
+                    u &= 0xffff0000u;
+                    float h;
+                    memcpy(&h, &u, 4);
+                    s16[((size_t)(G * 3 + p) * 64 + l) * 8 + e2] = (uint16_t)(u >> 16);
+                    v -= h;
+                }
+            }
+        G++;
+    };
+    for (int t = 0; t < 2; t++) for (int kc = 0; kc < 2; kc++) emit(0 + t * 16 + 8 * kc);    // layer 0: groups 0..3
+    for (int kc = 0; kc < 4; kc++) emit(32 + 8 * kc);                                         // layer 1: groups 4..7
+    for (int t = 0; t < 2; t++) for (int kc = 0; kc < 2; kc++) emit(64 + t * 16 + 8 * kc);   // layer 2: groups 8..11
+    for (int t = 0; t < 2; t++) for (int kc = 0; kc < 4; kc++) emit(96 + t * 32 + 8 * kc);   // layer 3: groups 12..19
+    float* wlast = reinterpret_cast<float*>(simg + PN_NET_SPLIT_W_BYTES);
+    float* wlast_h = reinterpret_cast<float*>(himg + PN_NET_HALF_W_BYTES);
+    for (int h = 0; h < 2; h++)
+        for (int q = 0; q < 32; q++)
+            for (int o = 0; o < 3; o++) {
+                const int t = q >> 4, r = q & 15;
+                const float w = W4[o * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+                wlast[(h * 32 + q) * 3 + o] = w;
+                wlast_h[(h * 32 + q) * 3 + o] = pn_h2f(pn_f2h_bits(w));
+            }
+    delete[] host;
+}
+
+static int net_fail(pn_net* n, hipError_t e, const char* what) {
+    snprintf(pn_err_buf, sizeof(pn_err_buf), "%s: %s", what, hipGetErrorString(e));
+    pn_net_destroy(n);
+    return PN_ERR_HIP;
+}
+
+// stages both images in pinned memory and uploads them behind whatever `stream` holds; no allocation, no stream synchronisation
+static int net_upload_weights(pn_net* n, const float* W0, const float* W1, const float* W2, const float* W3, const float* W4, hipStream_t st) {
+    PN_HIP_CHECK(hipEventSynchronize(n->stage_done));  // the previous upload has finished reading the staging buffer (normally long ago)
+    unsigned char* simg = reinterpret_cast<unsigned char*>(n->stage);
+    unsigned char* himg = simg + PN_NET_SPLIT_BYTES;
+    build_weight_images(W0, W1, W2, W3, W4, simg, himg);
+    PN_HIP_CHECK(hipMemcpyAsync(n->wsplit, simg, PN_NET_SPLIT_BYTES, hipMemcpyHostToDevice, st));
+    PN_HIP_CHECK(hipMemcpyAsync(n->whalf, himg, PN_NET_HALF_BYTES, hipMemcpyHostToDevice, st));
+    PN_HIP_CHECK(hipEventRecord(n->stage_done, st));
+    return PN_OK;
+}
+
+__global__ void __launch_bounds__(256) k_table_to_half(const float2* __restrict__ emb, uint32_t n, uint32_t* __restrict__ out) {
+    for (uint32_t i = threadIdx.x + blockIdx.x * blockDim.x; i < n; i += gridDim.x * blockDim.x) {
+        const float2 v = emb[i];
+        const _Float16 a = (_Float16)v.x, b = (_Float16)v.y;  // v_cvt_f16_f32: round to nearest even = tensor.to(torch.half)
+        out[i] = (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+    }
+}
+
 extern "C" int pn_net_create(pn_net** out, const float* embeddings, const int* offsets_host, uint32_t L, uint32_t C, float per_level_scale_log2,
                              uint32_t base_resolution, float bound, const float* W0, const float* W1, const float* W2, const float* W3,
                              const float* W4, void* stream) {
     PN_REQUIRE(out && embeddings && offsets_host && W0 && W1 && W2 && W3 && W4);
     PN_REQUIRE(L == 16 && C == 2);  // the architecture of nerf/network.py:14-95 / nerf/encoding.py:40-70
     pn_net* n = new pn_net();
+    memset(n, 0, sizeof(*n));
     if (pn_fill_grid_levels(&n->levels, offsets_host, L, C, per_level_scale_log2, base_resolution, 0, 0)) { delete n; return PN_ERR_ARG; }
     PnFusedLevel fl[16];
     for (uint32_t l = 0; l < L; l++) {
@@ -211,65 +332,69 @@ extern "C" int pn_net_create(pn_net** out, const float* embeddings, const int* o
     }
     n->embeddings = embeddings;
     n->bound = bound;
-    float* host = new float[160 * 64];
-    pack_weights(W0, W1, W2, W3, host);
-    // LDS image for v_mfma_f32_32x32x16_bf16: operand group (layer, out tile t, K chunk kc) takes the 8 consecutive activation
-    // registers m0 + 8 kc + e (e = 0..7) of the stream above as the 8 K-elements of its lane, each weight cut into three bf16
-    // pieces w = hi + mid + lo (truncation splits: exact, 8 + 8 + 8 significant bits).
-    unsigned char* simg = new unsigned char[PN_NET_SPLIT_BYTES];
-    {
-        uint16_t* s16 = reinterpret_cast<uint16_t*>(simg);
-        int G = 0;
-        auto emit = [&](int m0) {
-            for (int l = 0; l < 64; l++)
-                for (int e2 = 0; e2 < 8; e2++) {
-                    float v = host[(m0 + e2) * 64 + l];
-                    for (int p = 0; p < 3; p++) {
-                        uint32_t u;
-                        memcpy(&u, &v, 4);
-                        u &= 0xffff0000u;
-                        float h;
-                        memcpy(&h, &u, 4);
-                        s16[((size_t)(G * 3 + p) * 64 + l) * 8 + e2] = (uint16_t)(u >> 16);
-                        v -= h;
-                    }
-                }
-            G++;
-        };
-        for (int t = 0; t < 2; t++) for (int kc = 0; kc < 2; kc++) emit(0 + t * 16 + 8 * kc);    // layer 0: groups 0..3
-        for (int kc = 0; kc < 4; kc++) emit(32 + 8 * kc);                                         // layer 1: groups 4..7
-        for (int t = 0; t < 2; t++) for (int kc = 0; kc < 2; kc++) emit(64 + t * 16 + 8 * kc);   // layer 2: groups 8..11
-        for (int t = 0; t < 2; t++) for (int kc = 0; kc < 4; kc++) emit(96 + t * 32 + 8 * kc);   // layer 3: groups 12..19
-        // The 64 -> 3 output layer runs on the vector ALU (96 FMAs per lane on the D layout; an MFMA tile would be 29/32 row padding):
-        // wlast[h][q][o] = W4[o][krow(q, h)], q = tile*16 + register index of the D layout.
-        float* wlast = reinterpret_cast<float*>(simg + PN_NET_SPLIT_W_BYTES);
-        for (int h = 0; h < 2; h++)
-            for (int q = 0; q < 32; q++)
-                for (int o = 0; o < 3; o++) {
-                    const int t = q >> 4, r = q & 15;
-                    wlast[(h * 32 + q) * 3 + o] = W4[o * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
-                }
-    }
+    n->n_entries = (uint32_t)offsets_host[L];
+    hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMalloc((void**)&n->wsplit, PN_NET_SPLIT_BYTES);
-    if (e == hipSuccess) e = hipMemcpyAsync(n->wsplit, simg, PN_NET_SPLIT_BYTES, hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipMalloc((void**)&n->whalf, PN_NET_HALF_BYTES);
     if (e == hipSuccess) e = hipMalloc((void**)&n->fused_levels, sizeof(fl));
-    if (e == hipSuccess) e = hipMemcpyAsync(n->fused_levels, fl, sizeof(fl), hipMemcpyHostToDevice, (hipStream_t)stream);
-    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-    delete[] host;
-    delete[] simg;
-    if (e != hipSuccess) {
-        snprintf(pn_err_buf, sizeof(pn_err_buf), "pn_net_create: %s", hipGetErrorString(e));
-        delete n;
-        return PN_ERR_HIP;
-    }
+    if (e == hipSuccess) e = hipHostMalloc((void**)&n->stage, PN_NET_SPLIT_BYTES + PN_NET_HALF_BYTES);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&n->stage_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(n->stage_done, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(n->fused_levels, fl, sizeof(fl), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return net_fail(n, e, "pn_net_create");
+    const int rc = net_upload_weights(n, W0, W1, W2, W3, W4, st);
+    if (rc) { pn_net_destroy(n); return rc; }
+    e = hipStreamSynchronize(st);  // `fl` lives on this stack frame
+    if (e != hipSuccess) return net_fail(n, e, "pn_net_create");
     *out = n;
+    return PN_OK;
+}
+
+extern "C" int pn_net_update(pn_net* n, const float* embeddings, const float* W0, const float* W1, const float* W2, const float* W3,
+                             const float* W4, void* stream) {
+    PN_REQUIRE(n && embeddings && W0 && W1 && W2 && W3 && W4);
+    hipStream_t st = (hipStream_t)stream;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    PN_HIP_CHECK(hipStreamIsCapturing(st, &cs));
+    if (cs != hipStreamCaptureStatusNone) {  // the packing runs on the host and reads host weights: it cannot be part of a captured graph
+        snprintf(pn_err_buf, sizeof(pn_err_buf), "pn_net_update: called while the stream is being captured into a HIP graph; refresh the network "
+                                                 "weights before capture (a replay would re-upload the weights packed at capture time)");
+        return PN_ERR_ARG;
+    }
+    n->embeddings = embeddings;
+    const int rc = net_upload_weights(n, W0, W1, W2, W3, W4, st);
+    if (rc) return rc;
+    if (n->emb_half) {  // keep the fp16 copy of the tables in step with the fp32 master
+        k_table_to_half<<<1024, 256, 0, st>>>(reinterpret_cast<const float2*>(n->embeddings), n->n_entries, reinterpret_cast<uint32_t*>(n->emb_half));
+        PN_LAUNCH_CHECK();
+    }
+    return PN_OK;
+}
+
+extern "C" int pn_net_enable_half(pn_net* n, void* stream) {
+    PN_REQUIRE(n);
+    if (n->emb_half) return PN_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    PN_HIP_CHECK(hipStreamIsCapturing((hipStream_t)stream, &cs));
+    if (cs != hipStreamCaptureStatusNone) {
+        snprintf(pn_err_buf, sizeof(pn_err_buf), "pn_net_enable_half: the fp16 tables must be created before stream capture (render one frame under autocast first)");
+        return PN_ERR_ARG;
+    }
+    PN_HIP_CHECK(hipMalloc(&n->emb_half, (size_t)n->n_entries * 4));
+    k_table_to_half<<<1024, 256, 0, (hipStream_t)stream>>>(reinterpret_cast<const float2*>(n->embeddings), n->n_entries,
+                                                          reinterpret_cast<uint32_t*>(n->emb_half));
+    PN_LAUNCH_CHECK();
     return PN_OK;
 }
 
 extern "C" void pn_net_destroy(pn_net* n) {
     if (!n) return;
     if (n->wsplit) (void)hipFree(n->wsplit);
+    if (n->whalf) (void)hipFree(n->whalf);
+    if (n->emb_half) (void)hipFree(n->emb_half);
     if (n->fused_levels) (void)hipFree(n->fused_levels);
+    if (n->stage) (void)hipHostFree(n->stage);
+    if (n->stage_done) (void)hipEventDestroy(n->stage_done);
     delete n;
 }
 
@@ -507,10 +632,265 @@ __global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const P
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fp16 form of the fused kernel
+// NeRFNetwork.forward as the reference runs it under torch.cuda.amp.autocast (trainer.py:561 with fp16=True; BASELINE configs[4]):
+//   * gridencoder/grid.py:43-44: embeddings.to(torch.half); kernel_grid<at::Half,3,2> (gridencoder.cu:87-197) keeps positions and weights
+//     in float and accumulates `results[ch] += w * grid[index + ch]` in at::Half: the float product is rounded to half, the running sum is
+//     a half + half addition (c10::Half operators) — restated literally by encode8_h;
+//   * nn.Linear under autocast: half inputs x half weights, fp32 accumulation, half output -> v_mfma_f32_32x32x16_f16 and ONE rounding of
+//     the accumulator to fp16 per output (hi-precision accumulate order is the matrix core's, cuBLAS's in the reference: unpinnable, hence a
+//     tolerance of a few half ulps in the tests);
+//   * trunc_exp casts its half input to float (activation.py:7); SH stays float (sphere_harmonics.py:16) and is rounded to half when the
+//     concatenated colour-net input enters the first colour Linear; torch.sigmoid of a half tensor rounds its float result to half.
+// Same wave layout as k_nerf_forward (32 samples per wave, two lanes per sample, D layout of one layer = B layout of the next), no split:
+// 20 MFMAs per tile instead of 120, a 21 KB LDS weight image instead of 61 KB, 4-byte corner gathers instead of 8-byte ones.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#define PN_HMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+// levels J0 .. J0+NJ-1 of this lane's 8 (fully unrolled: every feat index is a compile-time constant, so feat stays in registers).
+// The table is read through a buffer resource (uniform base in SGPRs + one 32-bit byte offset per lane): a corner costs ONE address VGPR
+// and no 64-bit pointer arithmetic — with flat 64-bit addresses the 32 dword gathers in flight needed 64 address registers and the
+// allocator serialised them behind spills.
+typedef int pn_rsrc_t __attribute__((ext_vector_type(4)));
+template <int J0, int NJ>
+__device__ __forceinline__ void encode_levels_h(const PnFusedLevel* __restrict__ lv, __amdgpu_buffer_rsrc_t emb_rsrc, int half, float u0, float u1,
+                                                float u2, bool oob, _Float16* feat) {
+#pragma unroll
+    for (int j = J0; j < J0 + NJ; j++) {
+        const PnFusedLevel A = lv[j], B = lv[j + 8];  // wave-uniform
+        const float scale = half ? B.scale : A.scale;
+        const uint32_t m1 = half ? B.m1 : A.m1, m2 = half ? B.m2 : A.m2, mask = half ? B.mask : A.mask;
+        const bool dense = (half ? B.dense : A.dense) != 0;
+        const uint32_t base = half ? B.offset : A.offset;  // entries before this level
+        float p0 = fmaf(u0, scale, 0.5f), p1 = fmaf(u1, scale, 0.5f), p2 = fmaf(u2, scale, 0.5f);
+        const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+        p0 -= f0; p1 -= f1; p2 -= f2;
+        const uint32_t t0[2] = {(uint32_t)f0, (uint32_t)f0 + 1u};
+        const uint32_t t1a = (uint32_t)f1 * m1, t2a = (uint32_t)f2 * m2;
+        const uint32_t t1[2] = {t1a, t1a + m1}, t2[2] = {t2a, t2a + m2};
+        uint32_t v[8];
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+            const uint32_t a0 = t0[idx & 1], a1 = t1[(idx >> 1) & 1], a2 = t2[(idx >> 2) & 1];
+            const uint32_t index = dense ? (a0 + a1 + a2) : ((a0 ^ a1 ^ a2) & mask);
+            v[idx] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(emb_rsrc, (int)((base + index) << 2), 0, 0);
+        }
+        _Float16 r0 = (_Float16)0.0f, r1 = (_Float16)0.0f;
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+            float w = 1;
+            w *= (idx & 1) ? p0 : 1 - p0;
+            w *= (idx & 2) ? p1 : 1 - p1;
+            w *= (idx & 4) ? p2 : 1 - p2;
+            const f16x2 e = __builtin_bit_cast(f16x2, v[idx]);
+            r0 = r0 + (_Float16)(w * (float)e[0]);  // Half(float * Half) then Half + Half, gridencoder.cu:184
+            r1 = r1 + (_Float16)(w * (float)e[1]);
+        }
+        feat[2 * j] = oob ? (_Float16)0.0f : r0;
+        feat[2 * j + 1] = oob ? (_Float16)0.0f : r1;
+    }
+}
+// 8 hash levels of one lane, LU levels' gathers (8 x LU dword loads) in flight at a time
+template <int LU>
+__device__ __forceinline__ void encode8_h(const PnFusedLevel* __restrict__ lv, __amdgpu_buffer_rsrc_t emb_h, int half, float u0, float u1,
+                                          float u2, bool oob, _Float16* feat) {
+    static_assert(LU == 2 || LU == 4 || LU == 8, "LU");
+    if (LU == 8) { encode_levels_h<0, 8>(lv, emb_h, half, u0, u1, u2, oob, feat); return; }
+    if (LU == 4) {
+        encode_levels_h<0, 4>(lv, emb_h, half, u0, u1, u2, oob, feat);
+        __builtin_amdgcn_sched_barrier(0);
+        encode_levels_h<4, 4>(lv, emb_h, half, u0, u1, u2, oob, feat);
+        return;
+    }
+    encode_levels_h<0, 2>(lv, emb_h, half, u0, u1, u2, oob, feat);
+    __builtin_amdgcn_sched_barrier(0);
+    encode_levels_h<2, 2>(lv, emb_h, half, u0, u1, u2, oob, feat);
+    __builtin_amdgcn_sched_barrier(0);
+    encode_levels_h<4, 2>(lv, emb_h, half, u0, u1, u2, oob, feat);
+    __builtin_amdgcn_sched_barrier(0);
+    encode_levels_h<6, 2>(lv, emb_h, half, u0, u1, u2, oob, feat);
+}
+
+// fp32 accumulators of one layer -> that layer's half output, optionally through ReLU, as the next layer's B operands
+__device__ __forceinline__ f16x8 to_half8(const f32x16& v, int r0, bool relu) {
+    f16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        _Float16 h = (_Float16)v[r0 + i];
+        if (relu) h = h > (_Float16)0.0f ? h : (_Float16)0.0f;
+        o[i] = h;
+    }
+    return o;
+}
+
+#define PN_H_WAVES 4
+template <int MINW, int LU>
+__global__ void __launch_bounds__(PN_H_WAVES * 64, MINW) k_nerf_forward_h(const PnFusedLevel* __restrict__ lv, const uint32_t* __restrict__ emb_h,
+                                                                           const uint4* __restrict__ whalf, float bound, const float* __restrict__ xyzs,
+                                                                           const float* __restrict__ dirs, const int* __restrict__ list,
+                                                                           const int* __restrict__ count_dev, uint32_t M_arg, float density_scale,
+                                                                           float* __restrict__ sigmas, float* __restrict__ rgbs,
+                                                                           float* __restrict__ geo, uint32_t emb_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint4 wimg[];  // PN_NET_HALF_BYTES
+    // raw buffer over the whole fp16 table: stride 0, num_records = bytes (out-of-range offsets read 0), gfx9 dword-format flags
+    const __amdgpu_buffer_rsrc_t emb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(emb_h), 0, (int)emb_bytes, 0x00020000);
+    const uint32_t M = count_dev ? (uint32_t)*count_dev : M_arg;
+    const uint32_t n_tiles = (M + 31) / 32;
+    const uint32_t waves_total = gridDim.x * PN_H_WAVES;
+    const uint32_t wave = blockIdx.x * PN_H_WAVES + (threadIdx.x >> 6);
+    if (blockIdx.x * PN_H_WAVES >= n_tiles) return;
+    for (int i = threadIdx.x; i < PN_NET_HALF_BYTES / 16; i += PN_H_WAVES * 64) wimg[i] = whalf[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int s = lane & 31, half = lane >> 5;
+    const uint4* __restrict__ wl = wimg + lane;
+    auto W = [&](int G) { return __builtin_bit_cast(f16x8, wl[G * 64]); };
+    // Accumulator chains start from a zero held in REGISTERS (opaque to the optimiser), not from the literal 0: with a literal C operand
+    // hipcc (ROCm 7.2) gives the first MFMA of a chain a destination that overlaps its dying A / B operands (seen in this kernel's ISA:
+    // v_mfma_f32_32x32x16_f16 v[0:15], v[0:3], v[4:7], 0); with C in registers the destination is tied to C, which is live together with
+    // A and B.  Same precaution as split_mac's operand order above; tests/test_host.py scans the shipped ISA for such overlaps, and
+    // tools/repro_mfma_overlap.hip measures whether the overlap is actually harmful on gfx950 (16 v_mov per chain is the price).
+    auto zero16 = [] {
+        float z = 0.0f;
+        asm volatile("" : "+v"(z));
+        f32x16 v;
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = z;
+        return v;
+    };
+
+    for (uint32_t tile = wave; tile < n_tiles; tile += waves_total) {
+        const uint32_t li = tile * 32 + s;
+        const bool valid = li < M;
+        const uint32_t slot = valid ? (list ? (uint32_t)list[li] : li) : 0u;
+        float x = 0.f, y = 0.f, z = 0.f, dx = 0.f, dy = 0.f, dz = 1.f;
+        if (valid) {
+            x = xyzs[slot * 3]; y = xyzs[slot * 3 + 1]; z = xyzs[slot * 3 + 2];
+            dx = dirs[slot * 3]; dy = dirs[slot * 3 + 1]; dz = dirs[slot * 3 + 2];
+        }
+        const float u0 = (x + bound) / (2 * bound), u1 = (y + bound) / (2 * bound), u2 = (z + bound) / (2 * bound);
+        const bool oob = (u0 < 0 || u0 > 1 || u1 < 0 || u1 > 1 || u2 < 0 || u2 > 1);
+        _Float16 feat[16];
+        // the per-level constants are selected per lane half (`half ? B.x : A.x`): with every index a compile-time constant the compiler
+        // hoists all 8 x 6 selections out of the tile loop and then spills around the gathers; an opaque copy of `half` per tile keeps them
+        // inside the loop (48 v_cndmask per 32 samples)
+        int half_t = half;
+        asm volatile("" : "+v"(half_t));
+        encode8_h<LU>(lv, emb_rsrc, half_t, oob ? 0.f : u0, oob ? 0.f : u1, oob ? 0.f : u2, oob, feat);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- sigma net layer 0: 32 -> 64, ReLU
+        f32x16 a0 = zero16(), a1 = zero16();
+#pragma unroll
+        for (int kc = 0; kc < 2; kc++) {
+            f16x8 b;
+#pragma unroll
+            for (int i = 0; i < 8; i++) b[i] = feat[8 * kc + i];
+            a0 = PN_HMFMA(W(0 + kc), b, a0);
+            a1 = PN_HMFMA(W(2 + kc), b, a1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- sigma net layer 1: 64 -> 16
+        f32x16 h2 = zero16();
+#pragma unroll
+        for (int kc = 0; kc < 4; kc++) h2 = PN_HMFMA(W(4 + kc), to_half8(kc < 2 ? a0 : a1, (kc & 1) * 8, true), h2);
+        float g2[8];  // this lane's 8 of the 16 outputs, rounded to half: rows (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+        for (int r = 0; r < 8; r++) g2[r] = (float)(_Float16)h2[r];
+        const float sigma_logit = g2[0];  // row 0 lives in the low half's register 0; trunc_exp computes in float
+        if (geo) {  // NeRFNetwork.density
+            if (valid) {
+                if (half == 0) sigmas[slot] = density_scale * expf(sigma_logit);
+                float* __restrict__ g = geo + (size_t)slot * 15;
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row >= 1) g[row - 1] = g2[r];
+                }
+            }
+            continue;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- colour net input (PN_MAPL / PN_MAPU), rounded to half by the first colour Linear's input cast
+        float sh[16];
+        sh16(dx, dy, dz, sh);
+        auto pick = [half](float a, float b) {
+            asm volatile("" : "+v"(a), "+v"(b));
+            return half ? a : b;
+        };
+        f16x8 vb[2];
+#pragma unroll
+        for (int k = 0; k < 7; k++) vb[0][k] = (_Float16)pick(g2[k], g2[k + 1]);
+        vb[0][7] = (_Float16)pick(g2[7], sh[0]);
+#pragma unroll
+        for (int k = 8; k < 15; k++) vb[1][k - 8] = (_Float16)pick(sh[k + 1], sh[k - 7]);
+        vb[1][7] = (_Float16)pick(0.0f, sh[8]);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- colour layer 0: 31 -> 64, ReLU
+        f32x16 c0 = zero16(), c1 = zero16();
+#pragma unroll
+        for (int kc = 0; kc < 2; kc++) {
+            c0 = PN_HMFMA(W(8 + kc), vb[kc], c0);
+            c1 = PN_HMFMA(W(10 + kc), vb[kc], c1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- colour layer 1: 64 -> 64, ReLU
+        f32x16 d0 = zero16(), d1 = zero16();
+#pragma unroll
+        for (int kc = 0; kc < 4; kc++) {
+            const f16x8 b = to_half8(kc < 2 ? c0 : c1, (kc & 1) * 8, true);
+            d0 = PN_HMFMA(W(12 + kc), b, d0);
+            d1 = PN_HMFMA(W(16 + kc), b, d1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- colour layer 2: 64 -> 3 on the vector ALU: half-rounded weights and inputs, float accumulation (products of two halves are
+        // exact in float), ONE rounding of each output to half
+        float e[3] = {0.f, 0.f, 0.f};
+        {
+            const float* __restrict__ wlast = reinterpret_cast<const float*>(wimg) + PN_NET_HALF_W_BYTES / 4 + half * 96;
+#pragma unroll
+            for (int q4 = 0; q4 < 8; q4++) {
+                const float4 wa = *reinterpret_cast<const float4*>(wlast + q4 * 12);
+                const float4 wb = *reinterpret_cast<const float4*>(wlast + q4 * 12 + 4);
+                const float4 wc = *reinterpret_cast<const float4*>(wlast + q4 * 12 + 8);
+                const f32x16& src = (q4 < 4) ? d0 : d1;
+                const int r = (q4 & 3) * 4;
+                float hv[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) { const _Float16 h = (_Float16)src[r + i]; hv[i] = (float)(h > (_Float16)0.0f ? h : (_Float16)0.0f); }
+                e[0] = fmaf(wa.x, hv[0], e[0]); e[1] = fmaf(wa.y, hv[0], e[1]); e[2] = fmaf(wa.z, hv[0], e[2]);
+                e[0] = fmaf(wa.w, hv[1], e[0]); e[1] = fmaf(wb.x, hv[1], e[1]); e[2] = fmaf(wb.y, hv[1], e[2]);
+                e[0] = fmaf(wb.z, hv[2], e[0]); e[1] = fmaf(wb.w, hv[2], e[1]); e[2] = fmaf(wc.x, hv[2], e[2]);
+                e[0] = fmaf(wc.y, hv[3], e[0]); e[1] = fmaf(wc.z, hv[3], e[1]); e[2] = fmaf(wc.w, hv[3], e[2]);
+            }
+#pragma unroll
+            for (int o = 0; o < 3; o++) e[o] += __shfl_xor(e[o], 32);
+        }
+        if (valid && half == 0) {
+            sigmas[slot] = density_scale * expf(sigma_logit);
+#pragma unroll
+            for (int o = 0; o < 3; o++) {
+                const float logit = (float)(_Float16)e[o];                                  // the last Linear's half output
+                rgbs[slot * 3 + o] = (float)(_Float16)(1.0f / (1.0f + expf(-logit)));      // torch.sigmoid on a half tensor
+            }
+        }
+    }
+}
+
 int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* dirs, const int* list, const int* ctl_count, uint32_t M_max,
-                           float density_scale, float* sigmas, float* rgbs, hipStream_t stream) {
+                           float density_scale, float* sigmas, float* rgbs, int half, hipStream_t stream) {
     if (M_max == 0) return PN_OK;
     const uint32_t tiles = pn_div_up(M_max, 32);
+    if (half) {
+        PN_REQUIRE(net->emb_half);  // pn_net_enable_half first
+        static const uint32_t max_blocks_h = pn_env_u32("PN_NERF_BLOCKS_H", 1024);  // 4 workgroups per CU
+        uint32_t blocks = std::min(pn_div_up(tiles, PN_H_WAVES), max_blocks_h);
+        k_nerf_forward_h<4, 4><<<blocks, PN_H_WAVES * 64, PN_NET_HALF_BYTES, stream>>>((const PnFusedLevel*)net->fused_levels, (const uint32_t*)net->emb_half,
+                                                                                     (const uint4*)net->whalf, net->bound, xyzs, dirs, list, ctl_count,
+                                                                                     M_max, density_scale, sigmas, rgbs, nullptr, net->n_entries * 4u);
+        PN_LAUNCH_CHECK();
+        return PN_OK;
+    }
     static const uint32_t max_blocks = pn_env_u32("PN_NERF_BLOCKS", 512);  // 2 workgroups per CU x 256 CUs; waves stride over tiles
     uint32_t blocks = pn_div_up(tiles, PN_BF_WAVES);
     if (blocks > max_blocks) blocks = max_blocks;
@@ -521,23 +901,51 @@ int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* di
     return PN_OK;
 }
 
+static int density_launch(const pn_net* net, const float* xyzs, uint32_t M, float* sigmas, float* geo_feat, int half, hipStream_t st) {
+    const uint32_t tiles = pn_div_up(M, 32);
+    // dirs is only read by the colour net, which this mode never reaches: any readable buffer of >= 3 M floats will do
+    if (half) {
+        PN_REQUIRE(net->emb_half);
+        k_nerf_forward_h<4, 4><<<std::min(pn_div_up(tiles, PN_H_WAVES), 1024u), PN_H_WAVES * 64, PN_NET_HALF_BYTES, st>>>(
+            (const PnFusedLevel*)net->fused_levels, (const uint32_t*)net->emb_half, (const uint4*)net->whalf, net->bound, xyzs, xyzs, nullptr, nullptr, M, 1.0f,
+            sigmas, nullptr, geo_feat, net->n_entries * 4u);
+    } else {
+        k_nerf_forward<2, 4><<<std::min(pn_div_up(tiles, PN_BF_WAVES), 512u), PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES, st>>>(
+            (const PnFusedLevel*)net->fused_levels, net->embeddings, (const uint4*)net->wsplit, net->bound, xyzs, xyzs, nullptr, nullptr, M, 1.0f, sigmas,
+            nullptr, geo_feat);
+    }
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
 extern "C" int pn_nerf_density(const pn_net* net, const float* xyzs, uint32_t M, float* sigmas, float* geo_feat, void* stream) {
     if (M == 0) return PN_OK;  // empty tensors have null data pointers
     PN_REQUIRE(net && xyzs && sigmas && geo_feat);
-    const uint32_t tiles = pn_div_up(M, 32);
-    uint32_t blocks = pn_div_up(tiles, PN_BF_WAVES);
-    if (blocks > 512) blocks = 512;
-    // dirs is only read by the colour net, which this mode never reaches: any readable buffer of >= 3 M floats will do
-    k_nerf_forward<2, 4><<<blocks, PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES, (hipStream_t)stream>>>((const PnFusedLevel*)net->fused_levels, net->embeddings,
-                                                                                               (const uint4*)net->wsplit, net->bound, xyzs, xyzs, nullptr,
-                                                                                               nullptr, M, 1.0f, sigmas, nullptr, geo_feat);
-    PN_LAUNCH_CHECK();
-    return PN_OK;
+    return density_launch(net, xyzs, M, sigmas, geo_feat, 0, (hipStream_t)stream);
+}
+
+extern "C" int pn_nerf_density_half(const pn_net* net, const float* xyzs, uint32_t M, float* sigmas, float* geo_feat, void* stream) {
+    if (M == 0) return PN_OK;
+    PN_REQUIRE(net && xyzs && sigmas && geo_feat);
+    return density_launch(net, xyzs, M, sigmas, geo_feat, 1, (hipStream_t)stream);
 }
 
 extern "C" int pn_nerf_forward(const pn_net* net, const float* xyzs, const float* dirs, uint32_t M, float density_scale, float* sigmas, float* rgbs,
                                void* stream) {
     if (M == 0) return PN_OK;  // empty tensors have null data pointers
     PN_REQUIRE(net && xyzs && dirs && sigmas && rgbs);
-    return pn_nerf_forward_launch(net, xyzs, dirs, nullptr, nullptr, M, density_scale, sigmas, rgbs, (hipStream_t)stream);
+    return pn_nerf_forward_launch(net, xyzs, dirs, nullptr, nullptr, M, density_scale, sigmas, rgbs, 0, (hipStream_t)stream);
+}
+
+extern "C" int pn_nerf_forward_half(const pn_net* net, const float* xyzs, const float* dirs, uint32_t M, float density_scale, float* sigmas,
+                                    float* rgbs, void* stream) {
+    if (M == 0) return PN_OK;
+    PN_REQUIRE(net && xyzs && dirs && sigmas && rgbs);
+    return pn_nerf_forward_launch(net, xyzs, dirs, nullptr, nullptr, M, density_scale, sigmas, rgbs, 1, (hipStream_t)stream);
+}
+
+extern "C" int pn_host_float_to_half(const float* in_host, uint16_t* out_host, uint32_t n) {
+    PN_REQUIRE(in_host && out_host);
+    for (uint32_t i = 0; i < n; i++) out_host[i] = pn_f2h_bits(in_host[i]);
+    return PN_OK;
 }

@@ -1229,6 +1229,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     PN_REQUIRE(N > 0 && N <= f->max_rays && n_vtx > 0 && (uint32_t)n_vtx <= f->max_vtx);
     PN_REQUIRE(o->num_seek_IP >= 1 && o->num_seek_IP <= 3 && o->cascade >= 1 && o->cascade <= 8 && o->max_steps <= PN_MAX_TRIPS - PN_TRIP_BATCH);
     PN_REQUIRE(async_trips >= 0 && async_trips <= PN_MAX_TRIPS);
+    PN_REQUIRE(!o->fp16 || net->emb_half);  // pn_net_enable_half before an fp16 render
     hipStream_t st = (hipStream_t)stream;
     const uint32_t nblk = pn_div_up(N, 256);
     // per-trip launches use bounded grids with round-robin chunk loops (the alive count lives on the device): 32 march blocks and
@@ -1309,7 +1310,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             if (io.t_resume) k_march_skip<<<nblk, 256, 0, st>>>(mp, tb, io);
             launch_march(o->num_seek_IP, std::min(pn_div_up(N, 32), march_grid), tail_grid, st, mp, tb, io);
             if (timed) PN_HIP_CHECK(hipEventRecord(f->ev[t][1], st));
-            rc = pn_nerf_forward_launch(net, f->xyzs, f->dirs, f->list, &f->trips[t].n_samples, N, o->density_scale, f->sigmas, f->rgbs, st);
+            rc = pn_nerf_forward_launch(net, f->xyzs, f->dirs, f->list, &f->trips[t].n_samples, N, o->density_scale, f->sigmas, f->rgbs, o->fp16, st);
             if (rc) return rc;
             if (timed) { PN_HIP_CHECK(hipEventRecord(f->ev[t][2], st)); f->timed_trips = t + 1; }
             k_composite<<<trip_grid, 256, 0, st>>>(0, 0, o->T_thresh, cur, f->rays_t, f->sigmas, f->rgbs, f->deltas, weights_sum, depth_0, image,

@@ -3,7 +3,8 @@
 Interface replaced: /root/reference/gridencoder/grid.py:24-63 (``_grid_encode.forward``) and
 :96-161 (``GridEncoder``): same call signatures, same module attributes / state-dict keys
 (``offsets`` buffer, ``embeddings`` parameter).  Forward is on the simulate-and-render path; backward, dy_dx and
-``grad_total_variation`` (:65-92,168-190) are the training side.  fp16 tables are not built.
+``grad_total_variation`` (:65-92,168-190) are the training side.  Under autocast the forward runs on a half copy of the
+table (grid.py:43-44: ``embeddings.to(torch.half)``) and returns half features (inference only: the half backward is not built).
 """
 import math
 
@@ -31,23 +32,35 @@ def level_table_offsets(input_dim, num_levels, per_level_scale, base_resolution,
 class _grid_encode(torch.autograd.Function):
     """gridencoder/grid.py:24-92.  Forward: one HIP launch writes [B, L*C] directly (the reference writes [L,B,C] and permutes,
     grid.py:47,57), plus the dy_dx launch when ``calc_grad_inputs``.  Backward (training side): scatter-add into
-    grad_embeddings with hardware fp32 atomics and, with dy_dx, the chain rule to the inputs.  fp32 tables only (the reference's
-    autocast/half branch, grid.py:43-44, is not built)."""
+    grad_embeddings with hardware fp32 atomics and, with dy_dx, the chain rule to the inputs.  Autocast (grid.py:43-44): when
+    ``torch.is_autocast_enabled()`` and C is even, the table is cast to half, the kernel is kernel_grid<at::Half> and the features come
+    back in half — forward only (fp16 training is not built: it raises if a gradient is requested)."""
 
     @staticmethod
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0, align_corners=False,
                 interpolation=0, offsets_host=None):
         x = inputs.to(torch.float32).contiguous()
-        table = embeddings.to(torch.float32).contiguous()
-        require_gpu(x, table)
         B, D = x.shape
         n_levels = offsets.shape[0] - 1
-        C = table.shape[1]
+        C = embeddings.shape[1]
         if offsets_host is None:
             offsets_host = offsets.detach().to("cpu", torch.int32).contiguous()
+        log2_scale = float(np.float32(np.log2(per_level_scale)))  # the reference passes S = log2(per_level_scale) as a float (grid.py:37)
+        if (torch.is_autocast_enabled() and C % 2 == 0) or embeddings.dtype == torch.float16:  # grid.py:41-44
+            if calc_grad_inputs or (embeddings.requires_grad and torch.is_grad_enabled()):
+                raise RuntimeError("grid_encode: the half-precision path is inference-only (fp16 training is not built); disable autocast to train")
+            table = embeddings.detach().to(torch.float16).contiguous()
+            require_gpu(x, table)
+            feats = torch.empty(B, n_levels * C, device=x.device, dtype=torch.float16)
+            check(lib().pn_grid_encode_forward_half(ptr(x), ptr(table), offsets_host.data_ptr(), ptr(feats), B, D, C, n_levels, log2_scale,
+                                                    int(base_resolution), int(gridtype), int(bool(align_corners)), int(interpolation), 1, stream_ptr()),
+                  "grid_encode_forward_half")
+            ctx.mark_non_differentiable(feats)
+            return feats
+        table = embeddings.to(torch.float32).contiguous()
+        require_gpu(x, table)
         feats = torch.empty(B, n_levels * C, device=x.device, dtype=torch.float32)
         dy_dx = torch.empty(B, n_levels * D * C, device=x.device, dtype=torch.float32) if calc_grad_inputs else None
-        log2_scale = float(np.float32(np.log2(per_level_scale)))  # the reference passes S = log2(per_level_scale) as a float (grid.py:37)
         rc = lib().pn_grid_encode_forward(ptr(x), ptr(table), offsets_host.data_ptr(), ptr(feats), B, D, C, n_levels, log2_scale, int(base_resolution),
                                           ptr(dy_dx), int(gridtype), int(bool(align_corners)), int(interpolation), 1, stream_ptr())
         check(rc, "grid_encode_forward")

@@ -57,6 +57,12 @@ class SimRenderHarness:
     def synchronize(self):
         torch.cuda.synchronize(self.device)
 
+    def _amp(self):
+        """Trainer.test_gui renders inside ``torch.cuda.amp.autocast(enabled=self.fp16)`` (trainer.py:561).  main_gui.py builds its Trainer
+        without fp16 (fp32 render, the default here); opt['fp16'] = True is main_train.py's Trainer(fp16=opt.fp16) and BASELINE configs[4]:
+        fp16 hash tables + half Linear layers (renderer.rund_cuda reads the autocast state)."""
+        return torch.autocast("cuda", dtype=torch.float16, enabled=bool(self.opt.get("fp16", False)))
+
     def render_kwargs(self):
         """**vars(opt) as the reference passes it (trainer.py:318); renderer reads these by name."""
         return dict(self.opt)
@@ -91,10 +97,11 @@ class SimRenderHarness:
             self.frame += 1
         kw = self.render_kwargs()
         kw["collect_stats"] = collect_stats
-        if fused:
-            out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **kw)
-        else:
-            out = m.rund_cuda_ops(rays["rays_o"], rays["rays_d"], bg_color=None, perturb=False, **kw)
+        with self._amp():
+            if fused:
+                out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **kw)
+            else:
+                out = m.rund_cuda_ops(rays["rays_o"], rays["rays_d"], bg_color=None, perturb=False, **kw)
         return {"image": out["image"].reshape(-1, H, W, 3), "depth": out["depth"].reshape(-1, H, W), "depth_0": out["depth_0"].reshape(-1, H, W),
                 "rays_o": rays["rays_o"], "rays_d": rays["rays_d"]}
 
@@ -111,7 +118,8 @@ class SimRenderHarness:
             self.sim.stepforward()
         kw = self.render_kwargs()
         kw["async_trips"] = n_trips
-        out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **kw)
+        with self._amp():
+            out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **kw)
         main.wait_stream(self._sim_stream)
         # every tensor the graph touches is returned (and so stays referenced): memory freed after capture would go back to the
         # graph's pool and could be handed out again
@@ -229,7 +237,8 @@ class SimRenderHarness:
                     self.sim.stepforward()
                     m.p_def, m.IP_F, m.IP_dF = ip
                     rays = get_rays(self._graph_pose, self.intrinsics, H, W, -1)
-                    m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **dict(kw, frame_slot=lane))
+                    with self._amp():
+                        m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **dict(kw, frame_slot=lane))
             torch.cuda.synchronize(dev)
         # capture_error_mode="thread_local": with a process group alive, RCCL's watchdog thread queries events while we capture;
         # in the default "global" mode any HIP call from another thread invalidates the capture
@@ -247,7 +256,8 @@ class SimRenderHarness:
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr, stream=s, capture_error_mode="thread_local"):
                 rays = get_rays(self._graph_pose, self.intrinsics, H, W, -1)
-                out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **kw_l)
+                with self._amp():
+                    out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **kw_l)
             p["ren_graph"].append(gr)
             # every tensor the graphs touch stays referenced: a tensor freed after capture goes back to the graph's memory pool
             # and may be handed out again

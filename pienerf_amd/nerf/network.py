@@ -34,13 +34,18 @@ class NeRFNetwork(NeRFRenderer):
         self.bg_net = None
         self._net = None
         self._net_sig = None
+        self._net_dev = None
+        self._net_half = False
 
     # ---- packed device context for the fused kernel; rebuilt when the parameters change
     def _signature(self):
         ts = [self.encoder.embeddings] + [l.weight for l in self.sigma_net] + [l.weight for l in self.color_net]
         return tuple((t.data_ptr(), t._version, str(t.device)) for t in ts)
 
-    def _net_handle(self):
+    def _net_handle(self, half=False):
+        """The packed device context (pn_net).  Created once; when a parameter changed since (optimizer step, checkpoint load) the packed
+        weights are refreshed IN PLACE (pn_net_update: pinned staging + async upload, no allocation, no device synchronisation).
+        half=True additionally makes sure the fp16 tables exist (pn_net_enable_half)."""
         sig = self._signature()
         if self._net is None or sig != self._net_sig:
             if (self.num_layers, self.hidden_dim, self.geo_feat_dim, self.num_layers_color, self.hidden_dim_color) != (2, 64, 15, 3, 64):
@@ -49,16 +54,29 @@ class NeRFNetwork(NeRFRenderer):
             require_gpu(emb)
             assert emb.dtype == torch.float32 and emb.is_contiguous()
             Ws = [np.ascontiguousarray(l.weight.detach().cpu().numpy(), dtype=np.float32) for l in list(self.sigma_net) + list(self.color_net)]
-            off = self.encoder._offsets_host
-            if self._net is not None:
-                lib().pn_net_destroy(self._net)
-            h = C.c_void_p()
-            check(lib().pn_net_create(C.byref(h), ptr(emb), off.data_ptr(), self.encoder.num_levels, self.encoder.level_dim,
-                                      float(np.float32(np.log2(self.encoder.per_level_scale))), int(self.encoder.base_resolution), float(self.bound),
-                                      Ws[0].ctypes.data, Ws[1].ctypes.data, Ws[2].ctypes.data, Ws[3].ctypes.data, Ws[4].ctypes.data,
-                                      stream_ptr()), "net_create")
-            self._net, self._net_sig = h, sig
+            wp = [w.ctypes.data for w in Ws]
+            if self._net is None or self._net_dev != str(emb.device):
+                if self._net is not None:
+                    lib().pn_net_destroy(self._net)
+                off = self.encoder._offsets_host
+                h = C.c_void_p()
+                check(lib().pn_net_create(C.byref(h), ptr(emb), off.data_ptr(), self.encoder.num_levels, self.encoder.level_dim,
+                                          float(np.float32(np.log2(self.encoder.per_level_scale))), int(self.encoder.base_resolution), float(self.bound),
+                                          wp[0], wp[1], wp[2], wp[3], wp[4], stream_ptr()), "net_create")
+                self._net, self._net_dev, self._net_half = h, str(emb.device), False
+            else:
+                check(lib().pn_net_update(self._net, ptr(emb), wp[0], wp[1], wp[2], wp[3], wp[4], stream_ptr()), "net_update")
+            self._net_sig = sig
+        if half and not self._net_half:
+            check(lib().pn_net_enable_half(self._net, stream_ptr()), "net_enable_half")
+            self._net_half = True
         return self._net
+
+    @staticmethod
+    def _autocast_half():
+        """True when the caller runs under torch.cuda.amp.autocast with fp16 (trainer.py:561, Trainer(fp16=True)): the reference then casts
+        the hash table to half (gridencoder/grid.py:43-44) and every nn.Linear computes in half."""
+        return torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.float16
 
     def _wants_grad(self, *inputs):
         """Differentiable path only in train() mode with autograd recording (Trainer.train_one_epoch calls model.train(), evaluate /
@@ -77,6 +95,11 @@ class NeRFNetwork(NeRFRenderer):
         M = x.shape[0]
         sigma = torch.empty(M, dtype=torch.float32, device=x.device)
         color = torch.empty(M, 3, dtype=torch.float32, device=x.device)
+        if self._autocast_half():
+            # fp16 tables + fp16 MFMA layers with half-rounded activations; sigma stays float (trunc_exp casts, activation.py:7), the colour
+            # is a half tensor like the reference's sigmoid of a half input (the kernel writes the half values exactly representable in fp32)
+            check(lib().pn_nerf_forward_half(self._net_handle(half=True), ptr(x), ptr(d), M, 1.0, ptr(sigma), ptr(color), stream_ptr()), "nerf_forward_half")
+            return sigma, color.to(torch.float16)
         check(lib().pn_nerf_forward(self._net_handle(), ptr(x), ptr(d), M, 1.0, ptr(sigma), ptr(color), stream_ptr()), "nerf_forward")
         return sigma, color
 
@@ -95,6 +118,9 @@ class NeRFNetwork(NeRFRenderer):
         M = x.shape[0]
         sigma = torch.empty(M, dtype=torch.float32, device=x.device)
         geo = torch.empty(M, 15, dtype=torch.float32, device=x.device)
+        if self._autocast_half():
+            check(lib().pn_nerf_density_half(self._net_handle(half=True), ptr(x), M, ptr(sigma), ptr(geo), stream_ptr()), "nerf_density_half")
+            return {"sigma": sigma, "geo_feat": geo.to(torch.float16)}
         check(lib().pn_nerf_density(self._net_handle(), ptr(x), M, ptr(sigma), ptr(geo), stream_ptr()), "nerf_density")
         return {"sigma": sigma, "geo_feat": geo}
 

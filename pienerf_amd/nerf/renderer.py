@@ -50,8 +50,12 @@ class NeRFRenderer(nn.Module):
     def forward(self, x, d):
         raise NotImplementedError()
 
-    def _net_handle(self):
+    def _net_handle(self, half=False):
         raise NotImplementedError()
+
+    @staticmethod
+    def _autocast_half():
+        return False
 
     # ------------------------------------------------------------------ entry point (renderer.py:587-599)
     def render_deformed(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
@@ -117,12 +121,13 @@ class NeRFRenderer(nn.Module):
         o.grid_size = int(self.grid_size)
         o.density_scale = float(self.density_scale)
         o.bg_color = float(bg_color)
+        o.fp16 = int(self._autocast_half())  # Trainer.test_gui renders under autocast(enabled=self.fp16) (trainer.py:561)
         image = torch.empty(N, 3, dtype=torch.float32, device=device)
         depth = torch.empty(N, dtype=torch.float32, device=device)
         depth_0 = torch.empty(N, dtype=torch.float32, device=device)
         weights_sum = torch.empty(N, dtype=torch.float32, device=device)
         async_trips = int(kwargs.get("async_trips") or 0)
-        frame, net = self._frame_handle(N, n_vtx, hgs, int(kwargs.get("frame_slot") or 0)), self._net_handle()
+        frame, net = self._frame_handle(N, n_vtx, hgs, int(kwargs.get("frame_slot") or 0)), self._net_handle(half=bool(o.fp16))
         if async_trips > 0:
             # non-blocking: a fixed number of trips, no host synchronisation (legal under HIP-graph capture); completion is
             # checked later with render_status()

@@ -301,7 +301,8 @@ def default_opt(**over):
     """The option names render_deformed / Simulator read (get_opts.py), chair-demo values (README.md:123)."""
     opt = dict(bound=1.0, scale=0.8, dt_gamma=0.0, W=800, H=800, max_steps=1024, T_thresh=1e-2, min_near=0.2, density_thresh=10, bg_radius=-1,
                radius=5.0, fovy=50.0, max_iter_num=1, num_seek_IP=3, sim_dt=1e-2, sim_dx=0.05, sim_iters=10, sim_stiff=1e5, cut=False,
-               cut_bounds=[0.0, 2.0, -2.0, 1.0, -1.42, 0.92], timing_on=False)
+               cut_bounds=[0.0, 2.0, -2.0, 1.0, -1.42, 0.92], timing_on=False,
+               fp16=False)  # the GUI / main_render path renders in fp32: main_gui.py:36 builds its Trainer without fp16= although -O sets opt.fp16
     opt.update(over)
     opt["hash_grid_size"] = 1.2 * opt["sim_dx"]
     opt["num_seek_IP"] = max(min(3, opt["num_seek_IP"]), 1)
@@ -314,5 +315,14 @@ def trex_opt(**over):
     namespace the reference's get_opts.py returns for that command line."""
     opt = dict(bound=2.0, scale=0.33, dt_gamma=1.0 / 128, W=1008, H=756, max_steps=300, T_thresh=5e-2, num_seek_IP=1, max_iter_num=1, cut=True,
                cut_bounds=[-0.62, 1.0, -0.82, 0.42, -0.52, 0.28], sim_dx=0.05)
+    opt.update(over)
+    return default_opt(**opt)
+
+
+def stress_opt(**over):
+    """BASELINE.json configs[4] ("stress"): the dense sub_res = 180 point cloud, max_iter_num = 5 Newton iterations of the inverse warp,
+    num_seek_IP = 3, the 800 x 800 frame rendered in ray batches of 4096 (max_ray_batch, get_opts.py:24), and the network under autocast:
+    fp16 hash tables (gridencoder/grid.py:43-44) + fp16 MFMA layers (main_train.py:52's Trainer(fp16=opt.fp16))."""
+    opt = dict(max_iter_num=5, num_seek_IP=3, fp16=True, max_ray_batch=4096, sub_res=180)
     opt.update(over)
     return default_opt(**opt)

@@ -21,7 +21,9 @@ def _opts(name):
 
 def _same(ours, ref):
     for k, v in ours.items():
-        if k not in ref:
+        # 'fp16': get_opts sets opt.fp16 = True under -O, but main_gui.py:36 / main_render.py:64 never hand it to their Trainer, so the
+        # simulate-and-render path runs fp32; default_opt's 'fp16' is that Trainer argument (False), asserted separately below
+        if k not in ref or k == "fp16":
             continue
         r = ref[k]
         if isinstance(v, (list, tuple)):
@@ -40,6 +42,7 @@ def test_default_opt_equals_reference_get_opts_chair():
             "num_seek_IP", "sim_dt", "sim_dx", "sim_iters", "sim_stiff", "cut", "cut_bounds", "hash_grid_size", "timing_on"} <= shared
     _same(ours, ref)
     assert ref["fp16"] is True and ref["cuda_ray"] is True  # -O; main_gui.py:36 builds its Trainer without fp16=, so the GUI path runs fp32
+    assert ours["fp16"] is False and scene.stress_opt()["fp16"] is True and scene.stress_opt()["max_ray_batch"] == ref["max_ray_batch"] == 4096
 
 
 def test_trex_opt_equals_reference_get_opts_trex():

@@ -21,6 +21,8 @@ with torch.no_grad():
     m, enc = h.model, h.model.encoder
     B = xyz.shape[0]
     t_net = bench.cuda_time_ms(lambda: m(xyz, dirs), iters=30)
+    with torch.autocast("cuda", dtype=torch.float16):  # fp16 form: fp16 tables + fp16 MFMA (BASELINE configs[4])
+        t_half = bench.cuda_time_ms(lambda: m(xyz, dirs), iters=30)
     u = ((xyz + m.bound) / (2 * m.bound)).contiguous()
     res = {}
     for blm in (1, 0):
@@ -29,5 +31,6 @@ with torch.no_grad():
         f = lambda: check(lib().pn_grid_encode_forward(ptr(u), ptr(enc.embeddings), enc._offsets_host.data_ptr(), ptr(o), B, 3, 2, 16, S, 16, None, 0, 0, 0, blm,
                                                        stream_ptr()), "grid")
         res[blm] = bench.cuda_time_ms(f, iters=30)
+print(f"fp16 net {t_half*1e3:.1f} us ({(1068 - 512)*B/t_half/1e6:.0f} GB/s of 556 B/sample, {18688*B/t_half/1e9:.1f} TF)")
 print(f"variant={os.environ.get('PN_NERF_VARIANT','0')} B={B} net {t_net*1e3:.1f} us ({1076*B/t_net/1e6:.0f} GB/s, {18688*B/t_net/1e9:.1f} TF)  "
       f"grid[B,LC] {res[1]*1e3:.1f} us ({1164*B/res[1]/1e6:.0f} GB/s)  grid[L,B,C] {res[0]*1e3:.1f} us ({1164*B/res[0]/1e6:.0f} GB/s)")
