@@ -179,6 +179,9 @@ int pn_nerf_forward_half(const pn_net* net, const float* xyzs, const float* dirs
  * kernel stopped after the sigma net.  Used off the hot path (point sampling, main_sample.py:164-168).  sigmas [M], geo_feat [M,15]. */
 int pn_nerf_density(const pn_net* net, const float* xyzs, uint32_t M, float* sigmas, float* geo_feat, void* stream);
 int pn_nerf_density_half(const pn_net* net, const float* xyzs, uint32_t M, float* sigmas, float* geo_feat, void* stream);
+/* density_scale * sigma only (no geo_feat written): what update_extra_state needs from density() over 2-4 M cell samples
+ * (nerf/renderer.py:493-495); half != 0 selects the fp16 form. */
+int pn_nerf_sigma(const pn_net* net, const float* xyzs, uint32_t M, float density_scale, float* sigmas, int half, void* stream);
 /* [host] fp32 -> fp16 bit patterns, round to nearest even: the rounding the host side of pn_net_create applies to the weights. */
 int pn_host_float_to_half(const float* in_host, uint16_t* out_host, uint32_t n);
 
@@ -227,6 +230,41 @@ int pn_render_deformed_async(pn_frame* f, const pn_net* net, const pn_render_opt
 /* stats_host [host, int64[4]] = {trips with alive rays, emitted samples, error flags, rays alive at exit} of the last render on f.
  * synchronize != 0: waits for `stream` first; 0: the caller guarantees the render has completed (e.g. through an event). */
 int pn_render_status(pn_frame* f, int64_t* stats_host, int synchronize, void* stream);
+
+/* NeRFRenderer.run_cuda, eval branch (nerf/renderer.py:305-387): the undeformed render — near / far from `aabb_host` [host, 6 floats:
+ * aabb_infer], trips of { march_rays, network, composite_rays, compaction } with the same device-side trip record as pn_render_deformed, then
+ * image += (1 - weights_sum) * bg, depth = clamp(depth - nears, 0) / (fars - nears).  n_trips == 0: blocking form (batches of trips
+ * until no ray is alive); n_trips > 0: exactly that many trips, no host synchronisation (pn_render_status afterwards).  depth_0 receives the
+ * un-normalised depth (the reference discards it).  Off the simulate-and-render hot path. */
+int pn_render_static(pn_frame* f, const pn_net* net, const pn_render_opts* opts, const float* rays_o, const float* rays_d, uint32_t N,
+                     const float* aabb_host, const uint8_t* bitfield, float* image, float* depth, float* depth_0, float* weights_sum,
+                     int64_t* stats_host, int n_trips, void* stream);
+
+/* ------------------------------------------------------------------ density-grid state (off the hot path) */
+
+/* NeRFRenderer.mark_untrained_grid (nerf/renderer.py:390-452): density_grid [cascade, H^3] (morton order) gets -1 in every cell that no
+ * camera sees — cell centre (2c/(H-1) - 1)(bound_c - bound_c/H), cam = (centre - t) @ R, z > 0 and |x|, |y| inside the frustum padded by one
+ * cell.  poses [B,4,4] row-major cam2world on the device; *n_unseen (device int[1]) receives the number of such cells. */
+int pn_mark_untrained_grid(const float* poses, uint32_t B, float fx, float fy, float cx, float cy, uint32_t cascade, uint32_t H, float bound,
+                           float* density_grid, int* n_unseen, void* stream);
+/* update_extra_state, full sweep (renderer.py:466-497): xyzs [cascade*H^3, 3] = jittered centre of every cell, row = cascade*H^3 + morton
+ * index; noise [cascade*H^3, 3] uniform in [0,1) (torch.rand_like).  The caller evaluates sigma there (pn_nerf_density) and hands the result
+ * to pn_density_grid_update as tmp_grid. */
+int pn_density_cells_full(uint32_t cascade, uint32_t H, float bound, const float* noise, float* xyzs, void* stream);
+/* update_extra_state, partial sweep of one cascade (renderer.py:499-527): N cells from rand_coords [N,3] (torch.randint(0,H)) + N picks
+ * occ[floor(rand_pick * n_occ)] from the cascade's occupied cells (density_grid_cas > 0, compacted on the device: no host round trip);
+ * tmp_grid_cas [H^3] is set to -1; indices [2N] (-1 where the occupied list is empty) and jittered xyzs [2N,3] come back; noise [2N,3].
+ * scratch: >= pn_density_partial_scratch_ints(H) ints. */
+int pn_density_cells_partial(uint32_t cas, uint32_t H, float bound, uint32_t N, const int* rand_coords, const float* rand_pick, const float* noise,
+                             const float* density_grid_cas, float* tmp_grid_cas, int* scratch, int* indices, float* xyzs, void* stream);
+uint64_t pn_density_partial_scratch_ints(uint32_t H);
+/* tmp_grid_cas[indices[m]] = sigmas[m] for indices >= 0 (renderer.py:527). */
+int pn_density_scatter(uint32_t n, const int* indices, const float* sigmas, float* tmp_grid_cas, void* stream);
+/* renderer.py:535-543: density_grid = where(grid >= 0 & tmp >= 0, max(grid * decay, tmp), grid) over n = cascade*H^3 cells; mean_thresh
+ * (device float[2]) = { mean(clamp(grid, 0)), min(mean, density_thresh) } by a fixed-order reduction; bitfield = packbits(grid > threshold)
+ * with the threshold read from the device.  partial: >= ceil(n / 256) doubles of scratch. */
+int pn_density_grid_update(uint32_t n, float* density_grid, const float* tmp_grid, float decay, float density_thresh, uint8_t* bitfield,
+                           double* partial, float* mean_thresh, void* stream);
 
 /* Measurement hook (bench.py).  `enable` is a bitmask: bit 0 (1) — renders on f accumulate march work counters on the device,
  * {marching-loop iterations, candidate entries scanned, per-IP inverse warps, samples emitted}, the units behind the march

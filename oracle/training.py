@@ -126,3 +126,71 @@ def trunc_exp_backward(x, g):
     """nerf/activation.py:14-16: g * exp(clamp(x, -15, 15))."""
     import torch
     return (torch.from_numpy(_f32(g)) * torch.exp(torch.from_numpy(_f32(x)).clamp(-15, 15))).numpy()
+
+
+# ---------------------------------------------------------------------------------------------- density-grid state (renderer.py:390-549)
+def _morton_invert(idx):
+    def compact(x):
+        x = x & 0x49249249
+        x = (x | (x >> 2)) & 0xc30c30c3
+        x = (x | (x >> 4)) & 0x0f00f00f
+        x = (x | (x >> 8)) & 0xff0000ff
+        x = (x | (x >> 16)) & 0x0000ffff
+        return x
+    idx = np.asarray(idx, np.uint32)
+    return np.stack([compact(idx), compact(idx >> 1), compact(idx >> 2)], -1)
+
+
+def _cell_centres(cas, H, bound):
+    """Cascade-space centres of all H^3 cells in morton order: (2 c / (H - 1) - 1) * (bound_c - bound_c / H), float32 op by op
+    (renderer.py:420,425-428 / :481,486-489)."""
+    f = np.float32
+    c = _morton_invert(np.arange(H ** 3, dtype=np.uint32)).astype(f)
+    bnd = f(min(2 ** cas, bound))
+    half = f(bnd / f(H))
+    return (f(2.0) * c / f(H - 1) - f(1.0)) * f(bnd - half), half
+
+
+def mark_untrained_grid(poses, intrinsic, cascade, H, bound):
+    """NeRFRenderer.mark_untrained_grid (renderer.py:390-452): boolean [cascade, H^3] (morton order), True where no camera sees the cell.
+    float32 arithmetic in the order of the reference's tensor ops; the batched matmul `cam @ R` is summed over the three rows in order."""
+    f = np.float32
+    poses = np.asarray(poses, f).reshape(-1, 4, 4)
+    fx, fy, cx, cy = (float(v) for v in intrinsic)
+    cxfx, cyfy = f(cx / fx), f(cy / fy)
+    out = np.zeros((cascade, H ** 3), bool)
+    for cas in range(cascade):
+        w, half = _cell_centres(cas, H, bound)
+        pad = f(half * f(2.0))
+        count = np.zeros(H ** 3, np.int64)
+        for P in poses:
+            d = w - P[:3, 3][None, :]
+            cam = [f(0)] * 3
+            for j in range(3):
+                cam[j] = (d[:, 0] * P[0, j] + d[:, 1] * P[1, j]) + d[:, 2] * P[2, j]
+            count += (cam[2] > 0) & (np.abs(cam[0]) < cxfx * cam[2] + pad) & (np.abs(cam[1]) < cyfy * cam[2] + pad)
+        out[cas] = count == 0
+    return out
+
+
+def density_cells_full(cascade, H, bound, noise):
+    """The jittered cell samples of update_extra_state's full sweep (renderer.py:486-491): [cascade * H^3, 3], row = cas * H^3 + morton."""
+    f = np.float32
+    noise = np.asarray(noise, f).reshape(cascade, H ** 3, 3)
+    out = np.empty((cascade, H ** 3, 3), f)
+    for cas in range(cascade):
+        w, half = _cell_centres(cas, H, bound)
+        out[cas] = w + (noise[cas] * f(2.0) - f(1.0)) * half
+    return out.reshape(-1, 3)
+
+
+def density_grid_update(grid, tmp, decay, density_thresh):
+    """renderer.py:535-543: EMA-max where both are valid, mean of the clamped grid, threshold, bitfield."""
+    f = np.float32
+    grid, tmp = np.asarray(grid, f).copy(), np.asarray(tmp, f)
+    valid = (grid >= 0) & (tmp >= 0)
+    grid[valid] = np.maximum(grid[valid] * f(decay), tmp[valid])
+    mean = float(np.mean(np.maximum(grid, 0).astype(np.float64)))
+    thresh = min(mean, float(density_thresh))
+    bits = np.packbits((grid.reshape(-1) > f(thresh)).reshape(-1, 8), axis=1, bitorder="little").reshape(-1)  # bit i of byte n = cell 8n+i (raymarching.cu:270-292)
+    return grid, mean, bits

@@ -44,6 +44,7 @@ SIGNATURES = {
     "pn_net_enable_half": (i32, [P, P]),
     "pn_nerf_forward_half": (i32, [P, P, P, u32, f32, P, P, P]),
     "pn_nerf_density_half": (i32, [P, P, u32, P, P, P]),
+    "pn_nerf_sigma": (i32, [P, P, u32, f32, P, i32, P]),
     "pn_host_float_to_half": (i32, [P, P, u32]),
     "pn_grid_encode_forward_half": (i32, [P, P, P, P, u32, u32, u32, u32, f32, u32, u32, i32, u32, i32, P]),
     "pn_march_rays_train": (i32, [P, P, P, f32, f32, u32, u32, u32, u32, u32, P, P, P, P, P, P, P, P, P]),
@@ -63,6 +64,13 @@ SIGNATURES = {
     "pn_render_deformed": (i32, [P, P, C.POINTER(RenderOpts), P, P, u32, P, P, P, P, i32, P, P, P, P, P, P, P]),
     "pn_render_deformed_async": (i32, [P, P, C.POINTER(RenderOpts), P, P, u32, P, P, P, P, i32, P, P, P, P, P, i32, P]),
     "pn_render_status": (i32, [P, P, i32, P]),
+    "pn_render_static": (i32, [P, P, C.POINTER(RenderOpts), P, P, u32, P, P, P, P, P, P, P, i32, P]),
+    "pn_mark_untrained_grid": (i32, [P, u32, f32, f32, f32, f32, u32, u32, f32, P, P, P]),
+    "pn_density_cells_full": (i32, [u32, u32, f32, P, P, P]),
+    "pn_density_cells_partial": (i32, [u32, u32, f32, u32, P, P, P, P, P, P, P, P, P]),
+    "pn_density_partial_scratch_ints": (u64, [u32]),
+    "pn_density_scatter": (i32, [u32, P, P, P, P]),
+    "pn_density_grid_update": (i32, [u32, P, P, f32, f32, P, P, P, P]),
     "pn_frame_march_counters": (i32, [P, i32, P, P]),
     "pn_frame_trip_times": (i32, [P, P, P, i32, P, P]),
     "pn_sim_update_F": (i32, [i32, P, P, P, P, P, P, P, P, P]),

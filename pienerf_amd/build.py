@@ -29,6 +29,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-co
 UNITS = {
     "pn_render_ops.hip": ["-ffp-contract=off"],
     "pn_train_ops.hip": ["-ffp-contract=off"],
+    "pn_grid_state.hip": ["-ffp-contract=off"],
     "pn_nerf_forward.hip": ["-ffp-contract=fast"],
     "pn_encoder_grad.hip": ["-ffp-contract=fast"],
     "pn_sim.hip": ["-ffp-contract=fast"],

@@ -48,6 +48,22 @@ int pn_fill_grid_levels(PnGridLevels* g, const int* offsets_host, uint32_t L, ui
 }
 
 // ------------------------------------------------------------------------------------------------ op-level grid encoder
+// Half(w * float(v)) as c10::Half computes it: the float product is rounded to float FIRST and then to half (two roundings).  Written
+// naively, `(_Float16)(w * (float)v)` is fused by hipcc into v_fma_mixlo_f16, which rounds the exact product ONCE, straight to half — a
+// different result whenever the float rounding lands on a half tie (tests/test_gpu_half.py caught it: isolated features one half ulp off the oracle).
+// The empty asm keeps the float product a value of its own.
+__device__ __forceinline__ _Float16 half_of_product(float w, _Float16 v) {
+    float p = w * (float)v;
+    asm volatile("" : "+v"(p));
+    return (_Float16)p;
+}
+template <typename T>
+__device__ __forceinline__ T rounded_product(float w, T v);
+template <>
+__device__ __forceinline__ float rounded_product<float>(float w, float v) { return w * v; }
+template <>
+__device__ __forceinline__ _Float16 rounded_product<_Float16>(float w, _Float16 v) { return half_of_product(w, v); }
+
 // One thread per (sample, level); blockIdx.y = level keeps one level's table hot in the XCD L2s (gridencoder.cu:103,388).
 // T = float: kernel_grid<float,3,C>.  T = _Float16: kernel_grid<at::Half,3,C> — the table and the outputs are half, positions and weights
 // stay float, and `results[ch] += w * grid[index + ch]` rounds the float product to half and adds half + half (c10::Half operators).
@@ -95,7 +111,7 @@ __global__ void __launch_bounds__(256) k_grid_encode(const float* __restrict__ i
             res[1] += (T)(w * v.y);
         } else {
 #pragma unroll
-            for (uint32_t c = 0; c < C; c++) res[c] = res[c] + (T)(w * (float)table[index + c]);
+            for (uint32_t c = 0; c < C; c++) res[c] = res[c] + rounded_product<T>(w, table[index + c]);
         }
     }
 #pragma unroll
@@ -505,7 +521,7 @@ __global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const P
                                                                           const float* __restrict__ dirs, const int* __restrict__ list,
                                                                           const int* __restrict__ count_dev, uint32_t M_arg, float density_scale,
                                                                           float* __restrict__ sigmas, float* __restrict__ rgbs,
-                                                                          float* __restrict__ geo) {
+                                                                          float* __restrict__ geo, int sigma_only) {
     extern __shared__ __attribute__((aligned(16))) uint4 wimg[];  // PN_NET_SPLIT_BYTES
     const uint32_t M = count_dev ? (uint32_t)*count_dev : M_arg;
     const uint32_t n_tiles = (M + 31) / 32;
@@ -550,14 +566,16 @@ __global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const P
 #pragma unroll
         for (int kc = 0; kc < 4; kc++) h2 = split_mac(wl, 4 + kc, split8_of(kc < 2 ? a0 : a1, (kc & 1) * 8), h2);
         const float sigma_logit = h2[0];  // row 0 lives in the low half's register 0
-        if (geo) {  // NeRFNetwork.density (network.py:129-146): sigma = exp(h[0]), geo_feat = h[1:16]; no colour net (kernel-uniform)
+        if (geo || sigma_only) {  // NeRFNetwork.density (network.py:129-146): sigma = exp(h[0]), geo_feat = h[1:16]; no colour net (kernel-uniform)
             if (valid) {
                 if (half == 0) sigmas[slot] = density_scale * expf(sigma_logit);
-                float* __restrict__ g = geo + (size_t)slot * 15;
+                if (geo) {
+                    float* __restrict__ g = geo + (size_t)slot * 15;
 #pragma unroll
-                for (int r = 0; r < 8; r++) {  // this lane's rows (r&3) + 8*(r>>2) + 4*half of the 16 outputs
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (row >= 1) g[row - 1] = h2[r];
+                    for (int r = 0; r < 8; r++) {  // this lane's rows (r&3) + 8*(r>>2) + 4*half of the 16 outputs
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (row >= 1) g[row - 1] = h2[r];
+                    }
                 }
             }
             continue;
@@ -684,8 +702,8 @@ __device__ __forceinline__ void encode_levels_h(const PnFusedLevel* __restrict__
             w *= (idx & 2) ? p1 : 1 - p1;
             w *= (idx & 4) ? p2 : 1 - p2;
             const f16x2 e = __builtin_bit_cast(f16x2, v[idx]);
-            r0 = r0 + (_Float16)(w * (float)e[0]);  // Half(float * Half) then Half + Half, gridencoder.cu:184
-            r1 = r1 + (_Float16)(w * (float)e[1]);
+            r0 = r0 + half_of_product(w, e[0]);  // Half(float * Half) then Half + Half, gridencoder.cu:184
+            r1 = r1 + half_of_product(w, e[1]);
         }
         feat[2 * j] = oob ? (_Float16)0.0f : r0;
         feat[2 * j + 1] = oob ? (_Float16)0.0f : r1;
@@ -731,7 +749,7 @@ __global__ void __launch_bounds__(PN_H_WAVES * 64, MINW) k_nerf_forward_h(const 
                                                                            const float* __restrict__ dirs, const int* __restrict__ list,
                                                                            const int* __restrict__ count_dev, uint32_t M_arg, float density_scale,
                                                                            float* __restrict__ sigmas, float* __restrict__ rgbs,
-                                                                           float* __restrict__ geo, uint32_t emb_bytes) {
+                                                                           float* __restrict__ geo, uint32_t emb_bytes, int sigma_only) {
     extern __shared__ __attribute__((aligned(16))) uint4 wimg[];  // PN_NET_HALF_BYTES
     // raw buffer over the whole fp16 table: stride 0, num_records = bytes (out-of-range offsets read 0), gfx9 dword-format flags
     const __amdgpu_buffer_rsrc_t emb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(emb_h), 0, (int)emb_bytes, 0x00020000);
@@ -798,14 +816,16 @@ __global__ void __launch_bounds__(PN_H_WAVES * 64, MINW) k_nerf_forward_h(const 
 #pragma unroll
         for (int r = 0; r < 8; r++) g2[r] = (float)(_Float16)h2[r];
         const float sigma_logit = g2[0];  // row 0 lives in the low half's register 0; trunc_exp computes in float
-        if (geo) {  // NeRFNetwork.density
+        if (geo || sigma_only) {  // NeRFNetwork.density
             if (valid) {
                 if (half == 0) sigmas[slot] = density_scale * expf(sigma_logit);
-                float* __restrict__ g = geo + (size_t)slot * 15;
+                if (geo) {
+                    float* __restrict__ g = geo + (size_t)slot * 15;
 #pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (row >= 1) g[row - 1] = g2[r];
+                    for (int r = 0; r < 8; r++) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (row >= 1) g[row - 1] = g2[r];
+                    }
                 }
             }
             continue;
@@ -887,7 +907,7 @@ int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* di
         uint32_t blocks = std::min(pn_div_up(tiles, PN_H_WAVES), max_blocks_h);
         k_nerf_forward_h<4, 4><<<blocks, PN_H_WAVES * 64, PN_NET_HALF_BYTES, stream>>>((const PnFusedLevel*)net->fused_levels, (const uint32_t*)net->emb_half,
                                                                                      (const uint4*)net->whalf, net->bound, xyzs, dirs, list, ctl_count,
-                                                                                     M_max, density_scale, sigmas, rgbs, nullptr, net->n_entries * 4u);
+                                                                                     M_max, density_scale, sigmas, rgbs, nullptr, net->n_entries * 4u, 0);
         PN_LAUNCH_CHECK();
         return PN_OK;
     }
@@ -896,23 +916,24 @@ int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* di
     if (blocks > max_blocks) blocks = max_blocks;
     k_nerf_forward<2, 4><<<blocks, PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES, stream>>>((const PnFusedLevel*)net->fused_levels, net->embeddings,
                                                                                   (const uint4*)net->wsplit, net->bound, xyzs, dirs, list, ctl_count,
-                                                                                  M_max, density_scale, sigmas, rgbs, nullptr);
+                                                                                  M_max, density_scale, sigmas, rgbs, nullptr, 0);
     PN_LAUNCH_CHECK();
     return PN_OK;
 }
 
-static int density_launch(const pn_net* net, const float* xyzs, uint32_t M, float* sigmas, float* geo_feat, int half, hipStream_t st) {
+static int density_launch(const pn_net* net, const float* xyzs, uint32_t M, float scale, float* sigmas, float* geo_feat, int half, hipStream_t st) {
     const uint32_t tiles = pn_div_up(M, 32);
+    const int sigma_only = geo_feat == nullptr;
     // dirs is only read by the colour net, which this mode never reaches: any readable buffer of >= 3 M floats will do
     if (half) {
         PN_REQUIRE(net->emb_half);
         k_nerf_forward_h<4, 4><<<std::min(pn_div_up(tiles, PN_H_WAVES), 1024u), PN_H_WAVES * 64, PN_NET_HALF_BYTES, st>>>(
-            (const PnFusedLevel*)net->fused_levels, (const uint32_t*)net->emb_half, (const uint4*)net->whalf, net->bound, xyzs, xyzs, nullptr, nullptr, M, 1.0f,
-            sigmas, nullptr, geo_feat, net->n_entries * 4u);
+            (const PnFusedLevel*)net->fused_levels, (const uint32_t*)net->emb_half, (const uint4*)net->whalf, net->bound, xyzs, xyzs, nullptr, nullptr, M, scale,
+            sigmas, nullptr, geo_feat, net->n_entries * 4u, sigma_only);
     } else {
         k_nerf_forward<2, 4><<<std::min(pn_div_up(tiles, PN_BF_WAVES), 512u), PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES, st>>>(
-            (const PnFusedLevel*)net->fused_levels, net->embeddings, (const uint4*)net->wsplit, net->bound, xyzs, xyzs, nullptr, nullptr, M, 1.0f, sigmas,
-            nullptr, geo_feat);
+            (const PnFusedLevel*)net->fused_levels, net->embeddings, (const uint4*)net->wsplit, net->bound, xyzs, xyzs, nullptr, nullptr, M, scale, sigmas,
+            nullptr, geo_feat, sigma_only);
     }
     PN_LAUNCH_CHECK();
     return PN_OK;
@@ -921,13 +942,19 @@ static int density_launch(const pn_net* net, const float* xyzs, uint32_t M, floa
 extern "C" int pn_nerf_density(const pn_net* net, const float* xyzs, uint32_t M, float* sigmas, float* geo_feat, void* stream) {
     if (M == 0) return PN_OK;  // empty tensors have null data pointers
     PN_REQUIRE(net && xyzs && sigmas && geo_feat);
-    return density_launch(net, xyzs, M, sigmas, geo_feat, 0, (hipStream_t)stream);
+    return density_launch(net, xyzs, M, 1.0f, sigmas, geo_feat, 0, (hipStream_t)stream);
 }
 
 extern "C" int pn_nerf_density_half(const pn_net* net, const float* xyzs, uint32_t M, float* sigmas, float* geo_feat, void* stream) {
     if (M == 0) return PN_OK;
     PN_REQUIRE(net && xyzs && sigmas && geo_feat);
-    return density_launch(net, xyzs, M, sigmas, geo_feat, 1, (hipStream_t)stream);
+    return density_launch(net, xyzs, M, 1.0f, sigmas, geo_feat, 1, (hipStream_t)stream);
+}
+
+extern "C" int pn_nerf_sigma(const pn_net* net, const float* xyzs, uint32_t M, float density_scale, float* sigmas, int half, void* stream) {
+    if (M == 0) return PN_OK;
+    PN_REQUIRE(net && xyzs && sigmas);
+    return density_launch(net, xyzs, M, density_scale, sigmas, nullptr, half, (hipStream_t)stream);
 }
 
 extern "C" int pn_nerf_forward(const pn_net* net, const float* xyzs, const float* dirs, uint32_t M, float density_scale, float* sigmas, float* rgbs,

@@ -14,6 +14,14 @@ struct PnTrip {
     int n_samples;  // samples emitted by this trip's march (filled by atomics)
 };
 
+// Per-frame device record of the frame drivers (pn_render_deformed / pn_render_static).
+struct PnFrameDev {
+    float aabb[6];      // bbmin = aabb, bbmax = aabb + 3   (aabb = cat(bbmin, bbmax), renderer.py:796)
+    int resolution[4];  // [3] = n_grid
+    int err;
+    int pad;
+};
+
 // ------------------------------------------------------------------------------------------------ near/far
 // kernel_near_far_from_aabb, raymarching.cu:91-159
 __global__ void __launch_bounds__(256) k_near_far(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ aabb,
@@ -745,6 +753,98 @@ extern "C" int pn_march_rays(uint32_t n_alive, uint32_t n_step, const int* rays_
     return PN_OK;
 }
 
+// Frame-driver form of the static march (pn_render_static): counts come from the trip record, 256-ray chunks are dealt round-robin to a
+// bounded grid, unfilled slots are ended (delta = 0) and the valid sample slots are appended to `list` (one atomic per wave).
+__device__ __forceinline__ uint32_t march_static_one(uint32_t n, uint32_t n_step, const int* __restrict__ rays_alive, const float* __restrict__ rays_t,
+                                                     const float* __restrict__ rays_o, const float* __restrict__ rays_d, float bound, float dt_gamma,
+                                                     uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
+                                                     const float* __restrict__ fars, float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                     float* __restrict__ deltas) {
+    using namespace pnm;
+    const int index = rays_alive[n];
+    rays_o += (size_t)index * 3;
+    rays_d += (size_t)index * 3;
+    xyzs += (size_t)n * n_step * 3;
+    dirs += (size_t)n * n_step * 3;
+    deltas += (size_t)n * n_step * 2;
+    const float ox = rays_o[0], oy = rays_o[1], oz = rays_o[2];
+    const float dx = rays_d[0], dy = rays_d[1], dz = rays_d[2];
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    const float rH = 1 / (float)H;
+    const float H3 = (float)(H * H * H);
+    float t = rays_t[index];
+    const float far = fars[index];
+    const float dt_min = 2 * 1.73205080757f / max_steps;
+    const float dt_max = 2 * 1.73205080757f * (1 << (C - 1)) / H;
+    uint32_t step = 0;
+    float last_t = t;  // noise = 0 (perturb = False): `t += clamp(...) * noise` leaves t unchanged
+    while (t < far && step < n_step) {
+        const float x = clampf(ox + t * dx, -bound, bound);
+        const float y = clampf(oy + t * dy, -bound, bound);
+        const float z = clampf(oz + t * dz, -bound, bound);
+        const float dt = clampf(t * dt_gamma, dt_min, dt_max);
+        const int level = max(mip_from_pos(x, y, z, (float)C), mip_from_dt(dt, (float)H, (float)C));
+        const float mip_bound = fminf(scalbnf(1, level), bound);
+        const float mip_rbound = 1 / mip_bound;
+        const int nx = (int)clampf((float)(0.5 * (double)(x * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+        const int ny = (int)clampf((float)(0.5 * (double)(y * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+        const int nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1) * (double)H), 0.0f, (float)(H - 1));
+        const uint32_t vox = (uint32_t)(level * H3 + (float)morton3D(nx, ny, nz));
+        const bool occ = grid[vox / 8] & (1 << (vox % 8));
+        if (occ) {
+            xyzs[0] = x; xyzs[1] = y; xyzs[2] = z;
+            dirs[0] = dx; dirs[1] = dy; dirs[2] = dz;
+            t += dt;
+            deltas[0] = dt;
+            deltas[1] = t - last_t;
+            last_t = t;
+            xyzs += 3; dirs += 3; deltas += 2;
+            step++;
+        } else {
+            const float tx = (((nx + 0.5f + 0.5f * signf(dx)) * rH * 2 - 1) * mip_bound - x) * rdx;
+            const float ty = (((ny + 0.5f + 0.5f * signf(dy)) * rH * 2 - 1) * mip_bound - y) * rdy;
+            const float tz = (((nz + 0.5f + 0.5f * signf(dz)) * rH * 2 - 1) * mip_bound - z) * rdz;
+            const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+            do { t += clampf(t * dt_gamma, dt_min, dt_max); } while (t < tt);
+        }
+    }
+    for (uint32_t s = step; s < n_step; s++) { deltas[0] = 0.0f; deltas[1] = 0.0f; deltas += 2; }  // the op-level wrapper zero-fills instead
+    return step;
+}
+
+__global__ void __launch_bounds__(256) k_march_static_trip(PnTrip* trip, const int* __restrict__ rays_alive, const float* __restrict__ rays_t,
+                                                           const float* __restrict__ rays_o, const float* __restrict__ rays_d, float bound,
+                                                           float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                                                           const uint8_t* __restrict__ grid, const float* __restrict__ fars, float* __restrict__ xyzs,
+                                                           float* __restrict__ dirs, float* __restrict__ deltas, int* __restrict__ list) {
+    const uint32_t n_alive = (uint32_t)trip->n_alive, n_step = (uint32_t)trip->n_step;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t chunk = blockIdx.x; chunk * 256u < n_alive; chunk += gridDim.x) {
+        const uint32_t n = chunk * 256u + threadIdx.x;
+        const uint32_t emitted = n < n_alive ? march_static_one(n, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars,
+                                                                xyzs, dirs, deltas)
+                                             : 0u;
+        int inc = (int)emitted;  // inclusive wave scan of the sample counts, one atomic per wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        const int total = __shfl(inc, 63);
+        int base = 0;
+        if (lane == 63 && total > 0) base = atomicAdd(&trip->n_samples, total);
+        base = __shfl(base, 63);
+        const int first = base + inc - (int)emitted;
+        for (uint32_t s = 0; s < emitted; s++) list[first + s] = (int)(n * n_step + s);
+    }
+}
+
+__global__ void k_set_aabb(PnFrameDev* dev, float a0, float a1, float a2, float a3, float a4, float a5) {
+    dev->aabb[0] = a0; dev->aabb[1] = a1; dev->aabb[2] = a2; dev->aabb[3] = a3; dev->aabb[4] = a4; dev->aabb[5] = a5;
+    dev->resolution[0] = dev->resolution[1] = dev->resolution[2] = dev->resolution[3] = 0;
+    dev->err = 0;
+}
+
 __global__ void __launch_bounds__(256) k_packbits(const float* __restrict__ grid, uint32_t N, float density_thresh, uint8_t* __restrict__ bitfield) {
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
     if (n >= N) return;
@@ -871,12 +971,6 @@ extern "C" int pn_compact_rays(const int* rays_alive, uint32_t n, int* out, int*
 }
 
 // ------------------------------------------------------------------------------------------------ whole frame
-struct PnFrameDev {
-    float aabb[6];      // bbmin = aabb, bbmax = aabb + 3   (aabb = cat(bbmin, bbmax), renderer.py:796)
-    int resolution[4];  // [3] = n_grid
-    int err;
-    int pad;
-};
 
 #define PN_MAX_TRIPS 1100
 #define PN_TRIP_BATCH 8
@@ -1222,11 +1316,17 @@ static void frame_stats(pn_frame* f, int64_t* stats_host) {
 // async_trips == 0: blocking form (trips are enqueued in batches until a readback shows no ray alive).
 // async_trips  > 0: exactly that many trips are enqueued, then the epilogue and an async copy of the trip records to pinned
 //                   host memory; nothing blocks the host and every call is legal inside a HIP-graph stream capture.
+// aabb_static != nullptr: the undeformed render (NeRFRenderer.run_cuda, eval branch, renderer.py:267-387): no IP state, near / far from the
+// given box, kernel_march_rays instead of the bending march; everything else (trip records, network, composite, compaction, epilogue)
+// is the same driver.
 static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, const float* rays_o, const float* rays_d, uint32_t N,
                        const float* p_def, const float* p_ori, const float* F_IP, const float* dF_IP, int n_vtx, const uint8_t* bitfield, float* image,
-                       float* depth, float* depth_0, float* weights_sum, int64_t* stats_host, int async_trips, void* stream) {
-    PN_REQUIRE(f && net && o && rays_o && rays_d && p_def && p_ori && F_IP && dF_IP && bitfield && image && depth && depth_0 && weights_sum);
-    PN_REQUIRE(N > 0 && N <= f->max_rays && n_vtx > 0 && (uint32_t)n_vtx <= f->max_vtx);
+                       float* depth, float* depth_0, float* weights_sum, int64_t* stats_host, int async_trips, void* stream,
+                       const float* aabb_static = nullptr) {
+    const bool is_static = aabb_static != nullptr;
+    PN_REQUIRE(f && net && o && rays_o && rays_d && bitfield && image && depth && depth_0 && weights_sum);
+    PN_REQUIRE(is_static || (p_def && p_ori && F_IP && dF_IP && n_vtx > 0 && (uint32_t)n_vtx <= f->max_vtx));
+    PN_REQUIRE(N > 0 && N <= f->max_rays);
     PN_REQUIRE(o->num_seek_IP >= 1 && o->num_seek_IP <= 3 && o->cascade >= 1 && o->cascade <= 8 && o->max_steps <= PN_MAX_TRIPS - PN_TRIP_BATCH);
     PN_REQUIRE(async_trips >= 0 && async_trips <= PN_MAX_TRIPS);
     PN_REQUIRE(!o->fp16 || net->emb_half);  // pn_net_enable_half before an fp16 render
@@ -1256,7 +1356,9 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     // two 16-bit cell counters per LDS word + the staged point-index table
     const size_t tables_lds = ((size_t)f->max_cells + 1) / 2 * sizeof(unsigned) + (size_t)f->max_vtx * sizeof(int);
     const bool large = tables_lds > 150 * 1024;  // grid too large for the one-workgroup LDS build
-    if (!large) {
+    if (is_static) {
+        k_set_aabb<<<1, 1, 0, st>>>(f->dev, aabb_static[0], aabb_static[1], aabb_static[2], aabb_static[3], aabb_static[4], aabb_static[5]);
+    } else if (!large) {
         // dynamic LDS above 64 KB has to be opted into (gfx950: 160 KB per workgroup); the attribute is per DEVICE, so the cache is too
         static size_t tables_lds_set[PN_MAX_DEVICES] = {0};
         int dev_id = 0;
@@ -1276,11 +1378,13 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
         k_nb_count<<<gz, 256, 0, st>>>((int)f->max_cells, n_grid_dev, res, f->pig_cnt, swap, f->side.nb_cnt);
         launch_cell_scan((int)f->max_cells, n_grid_dev, f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, st);
     }
-    const int list_blocks = (int)std::min(pn_div_up((uint64_t)f->max_cells * 8, 256), 2048u);
-    const int pack_blocks = (int)pn_div_up((uint64_t)n_vtx * 44, 256);
-    k_frame_lists<<<list_blocks + pack_blocks, 256, 0, st>>>((int)f->max_cells, n_grid_dev, res, f->pig_cnt, f->pig_bgn, f->pig_idx, p_def, swap,
-                                                             f->side.nb_cnt, f->side.nb_bgn, f->side.nb, f->side.nb_capacity, err, list_blocks, n_vtx,
-                                                             p_ori, F_IP, dF_IP, f->side.rec);
+    if (!is_static) {
+        const int list_blocks = (int)std::min(pn_div_up((uint64_t)f->max_cells * 8, 256), 2048u);
+        const int pack_blocks = (int)pn_div_up((uint64_t)n_vtx * 44, 256);
+        k_frame_lists<<<list_blocks + pack_blocks, 256, 0, st>>>((int)f->max_cells, n_grid_dev, res, f->pig_cnt, f->pig_bgn, f->pig_idx, p_def, swap,
+                                                                 f->side.nb_cnt, f->side.nb_bgn, f->side.nb, f->side.nb_capacity, err, list_blocks, n_vtx,
+                                                                 p_ori, F_IP, dF_IP, f->side.rec);
+    }
     pnm2::March2Tables tb{f->side.nb_bgn, f->side.nb, (const float4*)f->side.rec};
     k_frame_rays<<<nblk, 256, 0, st>>>(rays_o, rays_d, f->dev, N, o->min_near, f->nears, f->fars, f->rays_t, f->trips, f->tail_counts,
                                        PN_MAX_TRIPS + 2, f->alive_a, weights_sum, depth_0, image);
@@ -1307,8 +1411,13 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                     if (!f->ev[t][e]) PN_HIP_CHECK(hipEventCreate(&f->ev[t][e]));
                 PN_HIP_CHECK(hipEventRecord(f->ev[t][0], st));
             }
-            if (io.t_resume) k_march_skip<<<nblk, 256, 0, st>>>(mp, tb, io);
-            launch_march(o->num_seek_IP, std::min(pn_div_up(N, 32), march_grid), tail_grid, st, mp, tb, io);
+            if (is_static) {
+                k_march_static_trip<<<trip_grid, 256, 0, st>>>(f->trips + t, cur, f->rays_t, rays_o, rays_d, o->bound, o->dt_gamma, o->max_steps, o->cascade,
+                                                               o->grid_size, bitfield, f->fars, f->xyzs, f->dirs, f->deltas, f->list);
+            } else {
+                if (io.t_resume) k_march_skip<<<nblk, 256, 0, st>>>(mp, tb, io);
+                launch_march(o->num_seek_IP, std::min(pn_div_up(N, 32), march_grid), tail_grid, st, mp, tb, io);
+            }
             if (timed) PN_HIP_CHECK(hipEventRecord(f->ev[t][1], st));
             rc = pn_nerf_forward_launch(net, f->xyzs, f->dirs, f->list, &f->trips[t].n_samples, N, o->density_scale, f->sigmas, f->rgbs, o->fp16, st);
             if (rc) return rc;
@@ -1352,6 +1461,14 @@ extern "C" int pn_render_deformed_async(pn_frame* f, const pn_net* net, const pn
     PN_REQUIRE(n_trips > 0);
     return render_impl(f, net, o, rays_o, rays_d, N, p_def, p_ori, F_IP, dF_IP, n_vtx, bitfield, image, depth, depth_0, weights_sum, nullptr, n_trips,
                        stream);
+}
+
+extern "C" int pn_render_static(pn_frame* f, const pn_net* net, const pn_render_opts* o, const float* rays_o, const float* rays_d, uint32_t N,
+                                const float* aabb_host, const uint8_t* bitfield, float* image, float* depth, float* depth_0, float* weights_sum,
+                                int64_t* stats_host, int n_trips, void* stream) {
+    PN_REQUIRE(aabb_host && n_trips >= 0);
+    return render_impl(f, net, o, rays_o, rays_d, N, nullptr, nullptr, nullptr, nullptr, 0, bitfield, image, depth, depth_0, weights_sum, stats_host, n_trips,
+                       stream, aabb_host);
 }
 
 extern "C" int pn_frame_march_counters(pn_frame* f, int enable, uint64_t* counters_host, void* stream) {

@@ -66,12 +66,12 @@ class NeRFRenderer(nn.Module):
     def _ip_state(self, device):
         return [t.to(device=device, dtype=torch.float32).contiguous() for t in (self.p_def, self.p_ori, self.IP_F, self.IP_dF)]
 
-    def _frame_handle(self, N, n_vtx, hgs, slot=0):
+    def _frame_handle(self, N, n_vtx, hgs, slot=0, cells=None):
         """Per-frame workspace (pn_frame).  `slot` selects one of several independent workspaces so that frames can be in
         flight concurrently on different streams (harness.capture_pipelined)."""
         # spatial-hash capacity: the IP cloud lives inside the simulation box (2.04*bound per side, solver.py:24-32); x2 margin per axis
         side = int(math.ceil(2.2 * float(self.bound) / hgs)) + 2
-        cells = side ** 3
+        cells = side ** 3 if cells is None else int(cells)
         key = (N, n_vtx, cells)
         cur = self._frames.get(slot)
         if cur is None or cur[1] != key:
@@ -182,60 +182,83 @@ class NeRFRenderer(nn.Module):
         self.local_step = 0
 
     def run_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024, T_thresh=1e-2, **kwargs):
-        """NeRFRenderer.run_cuda (nerf/renderer.py:267-387), the static / undeformed render.  train() mode: march_rays_train ->
-        network (differentiable) -> composite_rays_train, with the step counter feeding ``mean_count``.  eval() mode: near/far from
-        aabb_infer, then trips of march_rays -> network -> composite_rays -> compaction (op by op like the reference; the fused frame
-        driver exists only for the deformed hot path)."""
+        """NeRFRenderer.run_cuda (nerf/renderer.py:267-387), the static / undeformed render.
+
+        train():  march_rays_train -> network (differentiable) -> composite_rays_train, the step counter feeding ``mean_count`` (:293-341).
+        eval():   ONE call of the frame driver pn_render_static — near / far from aabb_infer, then trips of march / network / composite /
+                  stable compaction driven by a device-side trip record, with one 16-byte read-back per batch of 8 trips (the reference
+                  synchronises the host on every trip, :351-380).  Per-ray background colours and ``perturb`` take the op-by-op loop
+                  ``run_cuda_ops`` (same kernels, host-driven)."""
+        if not self.training and not perturb and not torch.is_tensor(bg_color):
+            return self._run_static_fused(rays_o, rays_d, dt_gamma, 1 if bg_color is None else bg_color, max_steps, T_thresh, **kwargs)
+        return self.run_cuda_ops(rays_o, rays_d, dt_gamma, bg_color, perturb, force_all_rays, max_steps, T_thresh, **kwargs)
+
+    def _run_static_fused(self, rays_o, rays_d, dt_gamma, bg_color, max_steps, T_thresh, **kwargs):
         prefix = rays_o.shape[:-1]
-        rays_o = rays_o.contiguous().view(-1, 3)
-        rays_d = rays_d.contiguous().view(-1, 3)
-        N, device = rays_o.shape[0], rays_o.device
-        aabb = self.aabb_train if self.training else self.aabb_infer
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
+        rays_o = rays_o.to(torch.float32).contiguous().view(-1, 3)
+        rays_d = rays_d.to(torch.float32).contiguous().view(-1, 3)
+        require_gpu(rays_o, rays_d)
         if self.bg_radius > 0:
             raise RuntimeError("background model (bg_radius > 0) is not built")
-        if bg_color is None:
-            bg_color = 1
+        N, device = rays_o.shape[0], rays_o.device
+        o = RenderOpts()
+        o.max_iter_num, o.hash_grid_size, o.num_seek_IP, o.IP_dx, o.cut = 1, 1.0, 1, 0.0, 0
+        o.bound, o.min_near, o.dt_gamma, o.max_steps, o.T_thresh = float(self.bound), float(self.min_near), float(dt_gamma), int(max_steps), float(T_thresh)
+        o.cascade, o.grid_size, o.density_scale, o.bg_color = int(self.cascade), int(self.grid_size), float(self.density_scale), float(bg_color)
+        o.fp16 = int(self._autocast_half())
+        aabb = (C.c_float * 6)(*[float(v) for v in self.aabb_infer.tolist()])
+        image, depth, depth_0, ws = (torch.empty(N, 3, dtype=torch.float32, device=device), torch.empty(N, dtype=torch.float32, device=device),
+                                     torch.empty(N, dtype=torch.float32, device=device), torch.empty(N, dtype=torch.float32, device=device))
+        frame = self._frame_handle(N, 1, 1.0, int(kwargs.get("frame_slot") or 0), cells=1)
+        async_trips = int(kwargs.get("async_trips") or 0)
+        stats = (C.c_int64 * 4)() if not async_trips else None
+        check(lib().pn_render_static(frame, self._net_handle(half=bool(o.fp16)), C.byref(o), ptr(rays_o), ptr(rays_d), N, aabb, ptr(self.density_bitfield),
+                                     ptr(image), ptr(depth), ptr(depth_0), ptr(ws), stats, async_trips, stream_ptr()), "render_static")
+        if stats is not None:
+            self._set_stats(stats)
+        return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "weights_sum": ws}
+
+    def run_cuda_ops(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024, T_thresh=1e-2, **kwargs):
+        """run_cuda op by op on the drop-in ops (the training branch; the eval branch with perturb / tensor backgrounds; parity tests)."""
+        shape = rays_o.shape[:-1]
+        o3, d3 = rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3)
+        nears, fars = raymarching.near_far_from_aabb(o3, d3, self.aabb_train if self.training else self.aabb_infer, self.min_near)
+        if self.bg_radius > 0:
+            raise RuntimeError("background model (bg_radius > 0) is not built")
+        bg = 1 if bg_color is None else bg_color
+
+        def shade(xyzs, dirs):
+            sig, rgb = self(xyzs, dirs)
+            return self.density_scale * sig, rgb
+
         if self.training:
-            counter = self.step_counter[self.local_step % 16]
-            counter.zero_()
+            slot = self.step_counter[self.local_step % 16]
+            slot.zero_()
             self.local_step += 1
-            xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears,
-                                                                    fars, counter, self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps)
-            sigmas, rgbs = self(xyzs, dirs)
-            sigmas = self.density_scale * sigmas
-            weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
-            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+            xyzs, dirs, deltas, rays = raymarching.march_rays_train(o3, d3, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars, slot,
+                                                                    self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps)
+            ws, depth, image = raymarching.composite_rays_train(*shade(xyzs, dirs), deltas, rays, T_thresh)
             self.last_stats = dict(trips=1, samples=int(xyzs.shape[0]), err=0, alive_at_exit=0)
-            return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "weights_sum": weights_sum}
-        with torch.no_grad():
-            dtype = torch.float32
-            weights_sum = torch.zeros(N, dtype=dtype, device=device)
-            depth = torch.zeros(N, dtype=dtype, device=device)
-            image = torch.zeros(N, 3, dtype=dtype, device=device)
-            rays_alive = torch.arange(N, dtype=torch.int32, device=device)
-            rays_t = nears.clone()
-            step, trips, samples = 0, 0, 0
-            while step < max_steps:
-                n_alive = rays_alive.shape[0]
-                if n_alive <= 0:
-                    break
-                n_step = max(min(N // n_alive, 8), 1)
-                xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield,
-                                                            self.cascade, self.grid_size, nears, fars, 128, perturb if step == 0 else False, dt_gamma,
-                                                            max_steps)
-                sigmas, rgbs = self(xyzs, dirs)
-                sigmas = self.density_scale * sigmas
-                raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh)
-                rays_alive = raymarching.compact_rays(rays_alive)  # == rays_alive[rays_alive >= 0]
-                samples += int((deltas[:, 0] != 0).sum())
-                step += n_step
-                trips += 1
-            self.last_stats = dict(trips=trips, samples=samples, err=0, alive_at_exit=int(rays_alive.shape[0]))
-            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-            depth = torch.clamp(depth - nears, min=0) / (fars - nears)
-        return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "weights_sum": weights_sum}
+        else:
+            with torch.no_grad():
+                n_rays, dev = o3.shape[0], o3.device
+                ws, depth, image = (torch.zeros(n_rays, device=dev), torch.zeros(n_rays, device=dev), torch.zeros(n_rays, 3, device=dev))
+                alive, t_now = torch.arange(n_rays, dtype=torch.int32, device=dev), nears.clone()
+                done_steps = trips = samples = 0
+                while done_steps < max_steps and alive.shape[0] > 0:
+                    k = alive.shape[0]
+                    per_ray = max(min(n_rays // k, 8), 1)
+                    xyzs, dirs, deltas = raymarching.march_rays(k, per_ray, alive, t_now, o3, d3, self.bound, self.density_bitfield, self.cascade,
+                                                                self.grid_size, nears, fars, 128, perturb if done_steps == 0 else False, dt_gamma, max_steps)
+                    raymarching.composite_rays(k, per_ray, alive, t_now, *shade(xyzs, dirs), deltas, ws, depth, image, T_thresh)
+                    alive = raymarching.compact_rays(alive)
+                    samples += int((deltas[:, 0] != 0).sum())
+                    done_steps += per_ray
+                    trips += 1
+                self.last_stats = dict(trips=trips, samples=samples, err=0, alive_at_exit=int(alive.shape[0]))
+        image = image + (1 - ws).unsqueeze(-1) * bg
+        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        return {"depth": depth.view(*shape), "image": image.view(*shape, 3), "weights_sum": ws}
 
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
         """renderer.py:552-585 (cuda_ray never stages)."""
@@ -243,97 +266,63 @@ class NeRFRenderer(nn.Module):
             raise RuntimeError("render: only the cuda_ray path is built")
         return self.run_cuda(rays_o, rays_d, **kwargs)
 
+    # ------------------------------------------------------------------ density-grid state on the device (pn_grid_state.hip)
     @torch.no_grad()
     def mark_untrained_grid(self, poses, intrinsic, S=64):
-        """renderer.py:390-452: density-grid cells no training camera sees get density -1 (never sampled, never updated)."""
+        """renderer.py:390-452: cells of the density grid that no training camera sees get density -1 (never sampled, never updated).
+        One launch — a lane per (cascade, cell) loops over the poses — instead of the reference's five nested Python loops; returns the
+        number of unseen cells (the reference prints it).  ``S`` (the reference's block / pose-batch size) has no role here."""
         if not self.cuda_ray:
             return
-        if not torch.is_tensor(poses):
-            poses = torch.from_numpy(poses)
-        B = poses.shape[0]
-        fx, fy, cx, cy = intrinsic
-        dev = self.density_bitfield.device
-        axis = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
-        count = torch.zeros_like(self.density_grid)
-        poses = poses.to(device=dev, dtype=torch.float32)
-        for xs in axis:
-            for ys in axis:
-                for zs in axis:
-                    xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
-                    coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
-                    indices = raymarching.morton3D(coords).long()
-                    world_xyzs = (2 * coords.float() / (self.grid_size - 1) - 1).unsqueeze(0)
-                    for cas in range(self.cascade):
-                        bound = min(2 ** cas, self.bound)
-                        half_grid_size = bound / self.grid_size
-                        cas_world_xyzs = world_xyzs * (bound - half_grid_size)
-                        head = 0
-                        while head < B:
-                            tail = min(head + S, B)
-                            cam_xyzs = cas_world_xyzs - poses[head:tail, :3, 3].unsqueeze(1)
-                            cam_xyzs = cam_xyzs @ poses[head:tail, :3, :3]
-                            mask_z = cam_xyzs[:, :, 2] > 0
-                            mask_x = torch.abs(cam_xyzs[:, :, 0]) < cx / fx * cam_xyzs[:, :, 2] + half_grid_size * 2
-                            mask_y = torch.abs(cam_xyzs[:, :, 1]) < cy / fy * cam_xyzs[:, :, 2] + half_grid_size * 2
-                            mask = (mask_z & mask_x & mask_y).sum(0).reshape(-1)
-                            count[cas, indices] += mask
-                            head += S
-        self.density_grid[count == 0] = -1
-        return int((count == 0).sum())
+        cams = torch.as_tensor(poses).to(device=self.density_grid.device, dtype=torch.float32).contiguous().view(-1, 4, 4)
+        require_gpu(cams, self.density_grid)
+        fx, fy, cx, cy = (float(v) for v in intrinsic)
+        n_unseen = torch.zeros(1, dtype=torch.int32, device=cams.device)
+        check(lib().pn_mark_untrained_grid(ptr(cams), cams.shape[0], fx, fy, cx, cy, self.cascade, self.grid_size, float(self.bound),
+                                           ptr(self.density_grid), ptr(n_unseen), stream_ptr()), "mark_untrained_grid")
+        return int(n_unseen.item())
 
     @torch.no_grad()
     def update_extra_state(self, decay=0.95, S=128):
-        """renderer.py:454-549: refresh the density grid (full sweep for the first 16 calls, then N = H^3/4 uniform + N occupied cells per
-        cascade), EMA-max with the old grid, re-pack the bitfield at min(mean density, density_thresh), and turn the step counters
-        into ``mean_count``."""
+        """renderer.py:454-549.  Density grid: sigma at one jittered sample per cell — every cell for the first 16 calls, afterwards H^3/4
+        uniform cells + H^3/4 draws from the occupied cells per cascade — EMA-max into the grid, mean of the non-negative part, bitfield at
+        min(mean, density_thresh); then ``mean_count`` from the step counters.  Everything runs on the device in a handful of launches
+        (pn_density_cells_* -> pn_nerf_sigma -> pn_density_grid_update); the only host read-back is the final mean (the reference's
+        ``.item()``), and the occupied-cell list of the partial sweep is compacted on the device instead of through torch.nonzero."""
         if not self.cuda_ray:
             return
-        dev = self.density_bitfield.device
-        tmp_grid = -torch.ones_like(self.density_grid)
+        grid = self.density_grid
+        dev, H, n_cas = grid.device, self.grid_size, self.cascade
+        require_gpu(grid)
+        cells = H ** 3
+        net, half = self._net_handle(half=self._autocast_half()), int(self._autocast_half())
+        tmp = torch.empty_like(grid)
         if self.iter_density < 16:
-            axis = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
-            for xs in axis:
-                for ys in axis:
-                    for zs in axis:
-                        xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing="ij")
-                        coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
-                        indices = raymarching.morton3D(coords).long()
-                        xyzs = 2 * coords.float() / (self.grid_size - 1) - 1
-                        for cas in range(self.cascade):
-                            tmp_grid[cas, indices] = self._cell_density(xyzs, cas)
+            pts = torch.empty(n_cas * cells, 3, dtype=torch.float32, device=dev)
+            check(lib().pn_density_cells_full(n_cas, H, float(self.bound), ptr(torch.rand(n_cas * cells, 3, device=dev)), ptr(pts), stream_ptr()), "density_cells_full")
+            check(lib().pn_nerf_sigma(net, ptr(pts), n_cas * cells, float(self.density_scale), ptr(tmp), half, stream_ptr()), "nerf_sigma")
         else:
-            N = self.grid_size ** 3 // 4
-            for cas in range(self.cascade):
-                coords = torch.randint(0, self.grid_size, (N, 3), device=dev)
-                indices = raymarching.morton3D(coords).long()
-                occ_indices = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
-                if occ_indices.shape[0] > 0:
-                    rand_mask = torch.randint(0, occ_indices.shape[0], [N], dtype=torch.long, device=dev)
-                    occ_indices = occ_indices[rand_mask]
-                    occ_coords = raymarching.morton3D_invert(occ_indices)
-                    indices = torch.cat([indices, occ_indices], dim=0)
-                    coords = torch.cat([coords, occ_coords.to(coords.dtype)], dim=0)
-                xyzs = 2 * coords.float() / (self.grid_size - 1) - 1
-                tmp_grid[cas, indices] = self._cell_density(xyzs, cas)
-        valid_mask = (self.density_grid >= 0) & (tmp_grid >= 0)
-        self.density_grid[valid_mask] = torch.maximum(self.density_grid[valid_mask] * decay, tmp_grid[valid_mask])
-        self.mean_density = torch.mean(self.density_grid.clamp(min=0)).item()
+            n = cells // 4
+            scratch = torch.empty(int(lib().pn_density_partial_scratch_ints(H)), dtype=torch.int32, device=dev)
+            pts = torch.empty(2 * n, 3, dtype=torch.float32, device=dev)
+            idx = torch.empty(2 * n, dtype=torch.int32, device=dev)
+            sig = torch.empty(2 * n, dtype=torch.float32, device=dev)
+            for cas in range(n_cas):
+                draws = torch.randint(0, H, (n, 3), device=dev, dtype=torch.int32)
+                check(lib().pn_density_cells_partial(cas, H, float(self.bound), n, ptr(draws), ptr(torch.rand(n, device=dev)), ptr(torch.rand(2 * n, 3, device=dev)),
+                                                     ptr(grid[cas]), ptr(tmp[cas]), ptr(scratch), ptr(idx), ptr(pts), stream_ptr()), "density_cells_partial")
+                check(lib().pn_nerf_sigma(net, ptr(pts), 2 * n, float(self.density_scale), ptr(sig), half, stream_ptr()), "nerf_sigma")
+                check(lib().pn_density_scatter(2 * n, ptr(idx), ptr(sig), ptr(tmp[cas]), stream_ptr()), "density_scatter")
+        partial = torch.empty((n_cas * cells + 255) // 256, dtype=torch.float64, device=dev)
+        mean_thresh = torch.empty(2, dtype=torch.float32, device=dev)
+        check(lib().pn_density_grid_update(n_cas * cells, ptr(grid), ptr(tmp), float(decay), float(self.density_thresh), ptr(self.density_bitfield),
+                                           ptr(partial), ptr(mean_thresh), stream_ptr()), "density_grid_update")
+        self.mean_density = float(mean_thresh[0].item())
         self.iter_density += 1
-        density_thresh = min(self.mean_density, self.density_thresh)
-        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
-        total_step = min(16, self.local_step)
-        if total_step > 0:
-            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+        counted = min(16, self.local_step)
+        if counted > 0:  # :545-547
+            self.mean_count = int(self.step_counter[:counted, 0].sum().item() / counted)
         self.local_step = 0
-
-    def _cell_density(self, xyzs, cas):
-        """density_scale * sigma at jittered cell centres of cascade `cas` (renderer.py:488-499); xyzs in [-1, 1]."""
-        bound = min(2 ** cas, self.bound)
-        half_grid_size = bound / self.grid_size
-        cas_xyzs = xyzs * (bound - half_grid_size)
-        cas_xyzs += (torch.rand_like(cas_xyzs) * 2 - 1) * half_grid_size
-        sigmas = self.density(cas_xyzs)["sigma"].reshape(-1).detach()
-        return sigmas * self.density_scale
 
     # ------------------------------------------------------------------ op-by-op loop (reference structure, renderer.py:755-907)
     def rund_cuda_ops(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-2, **kwargs):

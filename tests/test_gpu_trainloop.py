@@ -146,3 +146,87 @@ def test_training_state_with_two_cascades():
     net.eval()
     img = net.run_cuda(T(o)[None], T(d)[None], dt_gamma=1.0 / 128, max_steps=300, T_thresh=5e-2)["image"]
     assert bool(torch.isfinite(img).all()) and float(img.min()) < 0.9
+
+
+def test_grid_state_kernels_match_oracle_bit_for_bit():
+    """pn_grid_state.hip against the numpy restatement (oracle/training.py): the set of unseen cells of mark_untrained_grid, the jittered
+    cell samples of the full sweep, and the EMA-max / mean / bitfield update — integer and index work bit-exact, the mean to 1e-6."""
+    import ctypes as C
+    from pienerf_amd._lib import check, lib, ptr, stream_ptr
+    H, bound, cascade = 128, 2.0, 2
+    poses = np.stack([scene.orbit_pose(3.2, a, e) for a, e in ((0.0, -20.0), (35.0, -10.0), (200.0, -50.0))]).astype(np.float32)
+    intr = scene.orbit_intrinsics(64, 48, 30.0)
+    net = NeRFNetwork(encoding="hashgrid", bound=bound, cuda_ray=True).to(DEV)
+    net.reset_extra_state()
+    n = net.mark_untrained_grid(poses, intr)
+    want = otr.mark_untrained_grid(poses, intr, cascade, H, bound)
+    got = (net.density_grid == -1).cpu().numpy()
+    assert n == int(want.sum()) and 0 < n < cascade * H ** 3 and np.array_equal(got, want)
+    # full-sweep samples
+    noise = torch.rand(cascade * H ** 3, 3, device=DEV)
+    pts = torch.empty(cascade * H ** 3, 3, device=DEV)
+    check(lib().pn_density_cells_full(cascade, H, bound, ptr(noise), ptr(pts), stream_ptr()), "cells")
+    ref = otr.density_cells_full(cascade, H, bound, noise.cpu().numpy())
+    assert np.array_equal(pts.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    assert np.abs(ref[:H ** 3]).max() <= 1.0 and 1.5 < np.abs(ref[H ** 3:]).max() <= 2.0       # cascade 0 spans +-1, cascade 1 +-2
+    # update: EMA-max, mean, bitfield
+    rng = np.random.default_rng(0)
+    g0 = rng.uniform(-0.5, 30, (cascade, H ** 3)).astype(np.float32)
+    g0[g0 < 0] = -1
+    t0 = rng.uniform(-0.5, 30, (cascade, H ** 3)).astype(np.float32)
+    t0[t0 < 0] = -1
+    grid, tmp = T(g0), T(t0)
+    bits = torch.zeros(cascade * H ** 3 // 8, dtype=torch.uint8, device=DEV)
+    partial = torch.empty((cascade * H ** 3 + 255) // 256, dtype=torch.float64, device=DEV)
+    mt = torch.empty(2, device=DEV)
+    check(lib().pn_density_grid_update(cascade * H ** 3, ptr(grid), ptr(tmp), 0.95, 10.0, ptr(bits), ptr(partial), ptr(mt), stream_ptr()), "update")
+    g_ref, mean_ref, bits_ref = otr.density_grid_update(g0, t0, 0.95, 10.0)
+    assert np.array_equal(grid.cpu().numpy(), g_ref) and abs(float(mt[0]) - mean_ref) < 1e-6 * mean_ref
+    assert float(mt[1]) == min(float(mt[0]), 10.0) and np.array_equal(bits.cpu().numpy(), bits_ref)
+    # partial sweep: indices are morton codes of the drawn cells / of occupied cells, samples lie inside their cells
+    N = H ** 3 // 4
+    draws = torch.randint(0, H, (N, 3), device=DEV, dtype=torch.int32)
+    scratch = torch.empty(int(lib().pn_density_partial_scratch_ints(H)), dtype=torch.int32, device=DEV)
+    idx = torch.empty(2 * N, dtype=torch.int32, device=DEV)
+    pts = torch.empty(2 * N, 3, device=DEV)
+    tmpc = torch.zeros(H ** 3, device=DEV)
+    check(lib().pn_density_cells_partial(1, H, bound, N, ptr(draws), ptr(torch.rand(N, device=DEV)), ptr(torch.rand(2 * N, 3, device=DEV)), ptr(grid[1]),
+                                         ptr(tmpc), ptr(scratch), ptr(idx), ptr(pts), stream_ptr()), "partial")
+    idx_h, pts_h = idx.cpu().numpy(), pts.cpu().numpy()
+    assert bool((tmpc == -1).all())
+    assert np.array_equal(idx_h[:N], oracle.morton3D(draws.cpu().numpy()))
+    occ = g_ref[1] > 0
+    assert occ[idx_h[N:]].all() and len(np.unique(idx_h[N:])) > N // 4                 # draws from the occupied cells, well spread
+    centres, half = otr._cell_centres(1, H, bound)
+    assert np.abs(pts_h - centres[idx_h]).max() <= half * (1 + 1e-6)
+
+
+def test_run_cuda_eval_fused_equals_op_loop_and_oracle():
+    """NeRFRenderer.run_cuda in eval(): the device-driven frame (pn_render_static) reproduces the op-by-op loop bit for bit (same kernels on the
+    same samples) and the CPU oracle's static render within 1e-4; it also runs captured in a HIP graph (fixed trip count, no host sync)."""
+    ck, net = _teacher()
+    W = 72
+    o, d = oracle.get_rays(scene.orbit_pose(4.0, 30.0, -25.0), scene.orbit_intrinsics(W, W, 45.0), W, W)
+    opt = dict(dt_gamma=0.0, max_steps=1024, T_thresh=1e-2)
+    with torch.no_grad():
+        a = net.run_cuda(T(o)[None], T(d)[None], **opt)
+        sa = dict(net.last_stats)
+        b = net.run_cuda_ops(T(o)[None], T(d)[None], **opt)
+        sb = dict(net.last_stats)
+    assert sa["trips"] == sb["trips"] and sa["samples"] == sb["samples"] and sa["alive_at_exit"] == 0
+    assert torch.equal(a["image"], b["image"]) and torch.equal(a["weights_sum"], b["weights_sum"])
+    da, db = a["depth"], b["depth"]
+    assert torch.equal(torch.isnan(da), torch.isnan(db)) and torch.equal(da[~torch.isnan(da)], db[~torch.isnan(db)])
+    ref = oracle.render_static(o, d, ck, dict(opt))
+    assert ref["samples"] == sa["samples"] and np.abs(a["image"][0].cpu().numpy() - ref["image"]).max() < 1e-4
+    # captured: fixed number of trips, completion checked afterwards
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    ro, rd = T(o)[None], T(d)[None]
+    with torch.no_grad(), torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+        c = net.run_cuda(ro, rd, async_trips=sa["trips"] + 2, **opt)
+    g.replay()
+    torch.cuda.synchronize()
+    st = net.render_status()
+    assert st["alive_at_exit"] == 0 and st["samples"] == sa["samples"] and torch.equal(c["image"], a["image"])
