@@ -210,12 +210,16 @@ typedef struct {
     float bg_color;       /* scalar background (renderer.py:803-804: bg_color = 1) */
     int fp16;             /* != 0: the network runs as under torch.cuda.amp.autocast (trainer.py:561, Trainer(fp16=True)): fp16 hash tables
                              (gridencoder/grid.py:43-44), fp16 MFMA layers with half-rounded activations; needs pn_net_enable_half */
+    int reuse_tables;     /* != 0: the IP state (p_def, F, dF) is the one of the previous pn_render_deformed on this workspace — keep its bounding box,
+                             spatial hash, candidate lists and packed records and only start new rays.  For a frame rendered in ray batches
+                             (max_ray_batch, get_opts.py:24): the reference rebuilds get_pnts_in_grids for every rund_cuda call */
 } pn_render_opts;
 int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_vtx, uint32_t max_grid_cells);
 void pn_frame_destroy(pn_frame* f);
 /* rays_o/rays_d [N,3]; p_def/p_ori [n_vtx,3], F_IP [n_vtx,9], dF_IP [n_vtx,27]; bitfield [C*H^3/8];
- * outputs image [N,3], depth [N], depth_0 [N], weights_sum [N].  stats_host (may be NULL) [host, int64[4]] =
- * {trips, emitted samples, error flags, rays alive at exit}; reading it synchronises the stream. */
+ * outputs image [N,3], depth [N], depth_0 [N], weights_sum [N].  stats_host (may be NULL) [host, int64[5]] =
+ * {trips, emitted samples, error flags, rays alive at exit, rays left alive by fixed-trip renders on this workspace since
+ * pn_frame_reset_unfinished}; reading it synchronises the stream. */
 int pn_render_deformed(pn_frame* f, const pn_net* net, const pn_render_opts* opts, const float* rays_o, const float* rays_d, uint32_t N,
                        const float* p_def, const float* p_ori, const float* F_IP, const float* dF_IP, int n_vtx, const uint8_t* bitfield,
                        float* image, float* depth, float* depth_0, float* weights_sum, int64_t* stats_host, void* stream);
@@ -227,9 +231,20 @@ int pn_render_deformed(pn_frame* f, const pn_net* net, const pn_render_opts* opt
 int pn_render_deformed_async(pn_frame* f, const pn_net* net, const pn_render_opts* opts, const float* rays_o, const float* rays_d, uint32_t N,
                              const float* p_def, const float* p_ori, const float* F_IP, const float* dF_IP, int n_vtx, const uint8_t* bitfield,
                              float* image, float* depth, float* depth_0, float* weights_sum, int n_trips, void* stream);
-/* stats_host [host, int64[4]] = {trips with alive rays, emitted samples, error flags, rays alive at exit} of the last render on f.
+/* stats_host [host, int64[5]] = {trips with alive rays, emitted samples, error flags, rays alive at exit, unfinished total} of the last render on f.
  * synchronize != 0: waits for `stream` first; 0: the caller guarantees the render has completed (e.g. through an event). */
 int pn_render_status(pn_frame* f, int64_t* stats_host, int synchronize, void* stream);
+/* Zeroes the workspace's running total of rays left alive by fixed-trip renders (stats[4]): a frame rendered as many captured ray batches is
+ * verified once, at its end, instead of once per batch. */
+int pn_frame_reset_unfinished(pn_frame* f, void* stream);
+
+/* Continues the last render on `f` where its trips stopped (a fixed-trip render that pn_render_status reports with rays alive at exit — the
+ * reference's loop simply keeps going, renderer.py:836-891): n_trips more trips (0: blocking, until no ray is alive), then the epilogue again.
+ * The workspace holds the frame's tables, ray state and colour accumulator, so only the rays, the bitfield and the SAME output buffers are
+ * needed; results equal those of one render with enough trips, bit for bit.  is_static: the frame came from pn_render_static. */
+int pn_render_continue(pn_frame* f, const pn_net* net, const pn_render_opts* opts, const float* rays_o, const float* rays_d, uint32_t N,
+                       const uint8_t* bitfield, float* image, float* depth, float* depth_0, float* weights_sum, int64_t* stats_host, int n_trips,
+                       int is_static, void* stream);
 
 /* NeRFRenderer.run_cuda, eval branch (nerf/renderer.py:305-387): the undeformed render — near / far from `aabb_host` [host, 6 floats:
  * aabb_infer], trips of { march_rays, network, composite_rays, compaction } with the same device-side trip record as pn_render_deformed, then

@@ -17,7 +17,7 @@ class RenderOpts(C.Structure):
     """pn_render_opts (include/pienerf_hip.h)."""
     _fields_ = [("max_iter_num", i32), ("hash_grid_size", f32), ("num_seek_IP", i32), ("IP_dx", f32), ("cut", i32), ("cut_bounds", f32 * 6),
                 ("bound", f32), ("min_near", f32), ("dt_gamma", f32), ("max_steps", u32), ("T_thresh", f32), ("cascade", u32), ("grid_size", u32),
-                ("density_scale", f32), ("bg_color", f32), ("fp16", i32)]
+                ("density_scale", f32), ("bg_color", f32), ("fp16", i32), ("reuse_tables", i32)]
 
 
 # name -> (restype, argtypes); every function declared in include/pienerf_hip.h
@@ -64,6 +64,8 @@ SIGNATURES = {
     "pn_render_deformed": (i32, [P, P, C.POINTER(RenderOpts), P, P, u32, P, P, P, P, i32, P, P, P, P, P, P, P]),
     "pn_render_deformed_async": (i32, [P, P, C.POINTER(RenderOpts), P, P, u32, P, P, P, P, i32, P, P, P, P, P, i32, P]),
     "pn_render_status": (i32, [P, P, i32, P]),
+    "pn_frame_reset_unfinished": (i32, [P, P]),
+    "pn_render_continue": (i32, [P, P, C.POINTER(RenderOpts), P, P, u32, P, P, P, P, P, P, i32, i32, P]),
     "pn_render_static": (i32, [P, P, C.POINTER(RenderOpts), P, P, u32, P, P, P, P, P, P, P, i32, P]),
     "pn_mark_untrained_grid": (i32, [P, u32, f32, f32, f32, f32, u32, u32, f32, P, P, P]),
     "pn_density_cells_full": (i32, [u32, u32, f32, P, P, P]),

@@ -19,7 +19,7 @@ struct PnFrameDev {
     float aabb[6];      // bbmin = aabb, bbmax = aabb + 3   (aabb = cat(bbmin, bbmax), renderer.py:796)
     int resolution[4];  // [3] = n_grid
     int err;
-    int pad;
+    int unfinished;     // rays left alive by fixed-trip renders since the last reset, summed (staged batches are checked once per frame)
 };
 
 // ------------------------------------------------------------------------------------------------ near/far
@@ -979,6 +979,8 @@ extern "C" int pn_compact_rays(const int* rays_alive, uint32_t n, int* out, int*
 struct pn_frame {
     uint32_t max_rays, max_vtx, max_cells;
     float *nears, *fars, *rays_t, *xyzs, *dirs, *deltas, *sigmas, *rgbs;
+    float* acc_image;  // [max_rays,3] colour accumulated by composite; the epilogue writes image = acc + (1 - weights_sum) * bg, so a frame can be
+                       // continued with more trips and finished again (pn_render_continue)
     int *alive_a, *alive_b, *list, *chunk_counts;
     TailEntry* tail;   // [max_rays] rays handed from k_march to k_march_tail
     int* tail_counts;  // [PN_MAX_TRIPS + 2] one counter per trip, zeroed by k_frame_rays
@@ -991,23 +993,27 @@ struct pn_frame {
     PnFrameDev* dev_pinned;
     float cut_bounds_host[6];
     int cut_bounds_valid;
-    int last_trips;  // trips enqueued by the last render
+    int last_trips;  // trips enqueued by the last render (incl. continuations)
+    uint32_t last_N;
+    int tables_n_vtx;  // IP count the workspace's tables were built for (0: none); pn_render_opts::reuse_tables
     unsigned long long* march_counters;  // device [4], see MarchParams::stats
     int march_counters_on;
     hipEvent_t ev[PN_TIMED_TRIPS][3];    // measurement mode: before march / after march / after network, per trip
     int timed_trips;
 };
 
-// image += (1 - weights_sum) * bg ; depth = clamp(depth - nears, 0) / (fars - nears) (renderer.py:896-899)
+// image = acc + (1 - weights_sum) * bg ; depth = clamp(depth - nears, 0) / (fars - nears) (renderer.py:896-899)
 __global__ void __launch_bounds__(256) k_frame_finish(uint32_t N, float bg, const float* __restrict__ nears, const float* __restrict__ fars,
                                                       const float* __restrict__ weights_sum, const float* __restrict__ depth_0,
-                                                      float* __restrict__ image, float* __restrict__ depth) {
+                                                      const float* __restrict__ acc, float* __restrict__ image, float* __restrict__ depth,
+                                                      const PnTrip* __restrict__ final_trip, PnFrameDev* dev) {
     const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
+    if (i == 0 && final_trip->n_alive > 0) atomicAdd(&dev->unfinished, final_trip->n_alive);
     if (i >= N) return;
     const float k = (1 - weights_sum[i]) * bg;
-    image[i * 3] = image[i * 3] + k;
-    image[i * 3 + 1] = image[i * 3 + 1] + k;
-    image[i * 3 + 2] = image[i * 3 + 2] + k;
+    image[i * 3] = acc[i * 3] + k;
+    image[i * 3 + 1] = acc[i * 3 + 1] + k;
+    image[i * 3 + 2] = acc[i * 3 + 2] + k;
     depth[i] = fmaxf(depth_0[i] - nears[i], 0.0f) / (fars[i] - nears[i]);
 }
 
@@ -1270,6 +1276,7 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
 #define PN_ALLOC(ptr, bytes) PN_HIP_CHECK(hipMalloc((void**)&(ptr), (bytes)))
     PN_ALLOC(f->nears, N * 4); PN_ALLOC(f->fars, N * 4); PN_ALLOC(f->rays_t, N * 4);
     PN_ALLOC(f->xyzs, N * 12); PN_ALLOC(f->dirs, N * 12); PN_ALLOC(f->deltas, N * 8); PN_ALLOC(f->sigmas, N * 4); PN_ALLOC(f->rgbs, N * 12);
+    PN_ALLOC(f->acc_image, N * 12);
     PN_ALLOC(f->alive_a, N * 4); PN_ALLOC(f->alive_b, N * 4); PN_ALLOC(f->list, N * 4); PN_ALLOC(f->chunk_counts, (N / 256 + 2) * 4);
     PN_ALLOC(f->pig_cnt, (size_t)max_grid_cells * 4); PN_ALLOC(f->pig_bgn, (size_t)max_grid_cells * 4);
     PN_ALLOC(f->pig_cursor, (size_t)max_grid_cells * 4); PN_ALLOC(f->pig_idx, (size_t)max_vtx * 4);
@@ -1283,13 +1290,15 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
     PN_HIP_CHECK(hipMalloc((void**)&f->march_counters, 4 * sizeof(unsigned long long)));
     PN_HIP_CHECK(hipHostMalloc((void**)&f->trips_pinned, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)));
     PN_HIP_CHECK(hipHostMalloc((void**)&f->dev_pinned, sizeof(PnFrameDev)));
+    PN_HIP_CHECK(hipMemset(f->dev, 0, sizeof(PnFrameDev)));
+    memset(f->dev_pinned, 0, sizeof(PnFrameDev));
     *out = f;
     return PN_OK;
 }
 
 extern "C" void pn_frame_destroy(pn_frame* f) {
     if (!f) return;
-    void* ptrs[] = {f->nears, f->fars, f->rays_t, f->xyzs, f->dirs, f->deltas, f->sigmas, f->rgbs, f->alive_a, f->alive_b, f->list,
+    void* ptrs[] = {f->acc_image, f->nears, f->fars, f->rays_t, f->xyzs, f->dirs, f->deltas, f->sigmas, f->rgbs, f->alive_a, f->alive_b, f->list,
                     f->chunk_counts, f->pig_cnt, f->pig_bgn, f->pig_cursor, f->pig_idx, f->trips, f->dev, f->cut_bounds,
                     f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, f->side.nb, f->side.rec, f->march_counters, f->tail, f->tail_counts};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1311,6 +1320,7 @@ static void frame_stats(pn_frame* f, int64_t* stats_host) {
     stats_host[1] = samples;
     stats_host[2] = f->dev_pinned->err;
     stats_host[3] = f->trips_pinned[t].n_alive;
+    stats_host[4] = f->dev_pinned->unfinished;
 }
 
 // async_trips == 0: blocking form (trips are enqueued in batches until a readback shows no ray alive).
@@ -1322,10 +1332,12 @@ static void frame_stats(pn_frame* f, int64_t* stats_host) {
 static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, const float* rays_o, const float* rays_d, uint32_t N,
                        const float* p_def, const float* p_ori, const float* F_IP, const float* dF_IP, int n_vtx, const uint8_t* bitfield, float* image,
                        float* depth, float* depth_0, float* weights_sum, int64_t* stats_host, int async_trips, void* stream,
-                       const float* aabb_static = nullptr) {
-    const bool is_static = aabb_static != nullptr;
+                       const float* aabb_static = nullptr, int mode = 0 /* 0: whole frame, 1: continue the deformed frame on f, 2: continue the static one */) {
+    const bool is_static = aabb_static != nullptr || mode == 2;
+    const bool resume = mode != 0;
     PN_REQUIRE(f && net && o && rays_o && rays_d && bitfield && image && depth && depth_0 && weights_sum);
-    PN_REQUIRE(is_static || (p_def && p_ori && F_IP && dF_IP && n_vtx > 0 && (uint32_t)n_vtx <= f->max_vtx));
+    PN_REQUIRE(is_static || resume || (p_def && p_ori && F_IP && dF_IP && n_vtx > 0 && (uint32_t)n_vtx <= f->max_vtx));
+    PN_REQUIRE(!resume || (f->last_trips > 0 && N == f->last_N));
     PN_REQUIRE(N > 0 && N <= f->max_rays);
     PN_REQUIRE(o->num_seek_IP >= 1 && o->num_seek_IP <= 3 && o->cascade >= 1 && o->cascade <= 8 && o->max_steps <= PN_MAX_TRIPS - PN_TRIP_BATCH);
     PN_REQUIRE(async_trips >= 0 && async_trips <= PN_MAX_TRIPS);
@@ -1353,11 +1365,15 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     int* err = &f->dev->err;
     int rc = PN_OK;
     const int swap = (o->num_seek_IP == 1) ? 1 : 0;
+    if (!resume) {  // ---- prologue: tables, lists, ray state (a continuation finds all of it in the workspace)
     // two 16-bit cell counters per LDS word + the staged point-index table
     const size_t tables_lds = ((size_t)f->max_cells + 1) / 2 * sizeof(unsigned) + (size_t)f->max_vtx * sizeof(int);
     const bool large = tables_lds > 150 * 1024;  // grid too large for the one-workgroup LDS build
+    const bool keep_tables = !is_static && o->reuse_tables && f->tables_n_vtx == n_vtx;  // staged batches of one frame: same IP state
     if (is_static) {
         k_set_aabb<<<1, 1, 0, st>>>(f->dev, aabb_static[0], aabb_static[1], aabb_static[2], aabb_static[3], aabb_static[4], aabb_static[5]);
+    } else if (keep_tables) {
+        // nothing: bounding box, spatial hash, candidate lists and packed IP records of the previous render on this workspace stay
     } else if (!large) {
         // dynamic LDS above 64 KB has to be opted into (gfx950: 160 KB per workgroup); the attribute is per DEVICE, so the cache is too
         static size_t tables_lds_set[PN_MAX_DEVICES] = {0};
@@ -1378,23 +1394,25 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
         k_nb_count<<<gz, 256, 0, st>>>((int)f->max_cells, n_grid_dev, res, f->pig_cnt, swap, f->side.nb_cnt);
         launch_cell_scan((int)f->max_cells, n_grid_dev, f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, st);
     }
-    if (!is_static) {
+    if (!is_static && !keep_tables) {
+        f->tables_n_vtx = n_vtx;
         const int list_blocks = (int)std::min(pn_div_up((uint64_t)f->max_cells * 8, 256), 2048u);
         const int pack_blocks = (int)pn_div_up((uint64_t)n_vtx * 44, 256);
         k_frame_lists<<<list_blocks + pack_blocks, 256, 0, st>>>((int)f->max_cells, n_grid_dev, res, f->pig_cnt, f->pig_bgn, f->pig_idx, p_def, swap,
                                                                  f->side.nb_cnt, f->side.nb_bgn, f->side.nb, f->side.nb_capacity, err, list_blocks, n_vtx,
                                                                  p_ori, F_IP, dF_IP, f->side.rec);
     }
-    pnm2::March2Tables tb{f->side.nb_bgn, f->side.nb, (const float4*)f->side.rec};
     k_frame_rays<<<nblk, 256, 0, st>>>(rays_o, rays_d, f->dev, N, o->min_near, f->nears, f->fars, f->rays_t, f->trips, f->tail_counts,
-                                       PN_MAX_TRIPS + 2, f->alive_a, weights_sum, depth_0, image);
+                                       PN_MAX_TRIPS + 2, f->alive_a, weights_sum, depth_0, f->acc_image);
     PN_LAUNCH_CHECK();
+    }
+    pnm2::March2Tables tb{f->side.nb_bgn, f->side.nb, (const float4*)f->side.rec};
 
     pnm::MarchParams mp = make_march_params(f->pig_cnt, f->pig_bgn, f->pig_idx, n_vtx, 0, p_def, p_ori, F_IP, dF_IP, o->max_iter_num, bbmin, bbmax,
                                             o->hash_grid_size, res, o->num_seek_IP, o->IP_dx, o->cut, f->cut_bounds, f->rays_t, rays_o, rays_d,
                                             o->bound, o->dt_gamma, o->max_steps, o->cascade, o->grid_size, bitfield, f->fars, err);
     mp.stats = (f->march_counters_on & 1) ? f->march_counters : nullptr;
-    int t = 0;
+    int t = resume ? f->last_trips : 0;  // a continuation picks up at the record the last compaction wrote
     bool done = false;
     while (!done && t < PN_MAX_TRIPS) {
         const int batch = async_trips > 0 ? async_trips : PN_TRIP_BATCH;
@@ -1405,7 +1423,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             // fast-forwards them; its per-ray resume point lives in `sigmas`, which is not written before this trip's network launch
             MarchIO io{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + t, f->list, (t == 0) ? f->sigmas : nullptr,
                        f->tail, f->tail_counts + t, (int)march_tail_rounds()};
-            const bool timed = (f->march_counters_on & 2) && async_trips == 0 && t < PN_TIMED_TRIPS;
+            const bool timed = (f->march_counters_on & 2) && t < PN_TIMED_TRIPS;  // also inside a capture: the records become graph nodes
             if (timed) {  // measurement mode: HIP events around the two heavy launches of each trip, on the launch stream
                 for (int e = 0; e < 3; e++)
                     if (!f->ev[t][e]) PN_HIP_CHECK(hipEventCreate(&f->ev[t][e]));
@@ -1422,7 +1440,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             rc = pn_nerf_forward_launch(net, f->xyzs, f->dirs, f->list, &f->trips[t].n_samples, N, o->density_scale, f->sigmas, f->rgbs, o->fp16, st);
             if (rc) return rc;
             if (timed) { PN_HIP_CHECK(hipEventRecord(f->ev[t][2], st)); f->timed_trips = t + 1; }
-            k_composite<<<trip_grid, 256, 0, st>>>(0, 0, o->T_thresh, cur, f->rays_t, f->sigmas, f->rgbs, f->deltas, weights_sum, depth_0, image,
+            k_composite<<<trip_grid, 256, 0, st>>>(0, 0, o->T_thresh, cur, f->rays_t, f->sigmas, f->rgbs, f->deltas, weights_sum, depth_0, f->acc_image,
                                                    f->trips + t, f->chunk_counts);
             k_compact<<<trip_grid, 256, 0, st>>>(cur, 0, f->chunk_counts, nxt, nullptr, f->trips + t, f->trips + t + 1, N, o->max_steps);
         }
@@ -1433,9 +1451,10 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
         PN_HIP_CHECK(hipStreamSynchronize(st));
         done = f->trips_pinned[t].n_alive <= 0;
     }
-    k_frame_finish<<<nblk, 256, 0, st>>>(N, o->bg_color, f->nears, f->fars, weights_sum, depth_0, image, depth);
+    k_frame_finish<<<nblk, 256, 0, st>>>(N, o->bg_color, f->nears, f->fars, weights_sum, depth_0, f->acc_image, image, depth, f->trips + t, f->dev);
     PN_LAUNCH_CHECK();
     f->last_trips = t;
+    f->last_N = N;
     if (async_trips > 0 || stats_host) {
         PN_HIP_CHECK(hipMemcpyAsync(f->trips_pinned, f->trips, sizeof(PnTrip) * (t + 1), hipMemcpyDeviceToHost, st));
         PN_HIP_CHECK(hipMemcpyAsync(f->dev_pinned, f->dev, sizeof(PnFrameDev), hipMemcpyDeviceToHost, st));
@@ -1471,6 +1490,14 @@ extern "C" int pn_render_static(pn_frame* f, const pn_net* net, const pn_render_
                        stream, aabb_host);
 }
 
+extern "C" int pn_render_continue(pn_frame* f, const pn_net* net, const pn_render_opts* o, const float* rays_o, const float* rays_d, uint32_t N,
+                                  const uint8_t* bitfield, float* image, float* depth, float* depth_0, float* weights_sum, int64_t* stats_host, int n_trips,
+                                  int is_static, void* stream) {
+    PN_REQUIRE(n_trips >= 0);
+    return render_impl(f, net, o, rays_o, rays_d, N, nullptr, nullptr, nullptr, nullptr, 0, bitfield, image, depth, depth_0, weights_sum, stats_host, n_trips,
+                       stream, nullptr, is_static ? 2 : 1);
+}
+
 extern "C" int pn_frame_march_counters(pn_frame* f, int enable, uint64_t* counters_host, void* stream) {
     PN_REQUIRE(f);
     hipStream_t st = (hipStream_t)stream;
@@ -1492,6 +1519,15 @@ extern "C" int pn_frame_trip_times(pn_frame* f, float* march_ms_host, float* net
         PN_HIP_CHECK(hipEventElapsedTime(network_ms_host + t, f->ev[t][1], f->ev[t][2]));
     }
     *n_trips_out = n;
+    return PN_OK;
+}
+
+__global__ void k_reset_unfinished(PnFrameDev* dev) { dev->unfinished = 0; }
+
+extern "C" int pn_frame_reset_unfinished(pn_frame* f, void* stream) {
+    PN_REQUIRE(f);
+    k_reset_unfinished<<<1, 1, 0, (hipStream_t)stream>>>(f->dev);
+    PN_LAUNCH_CHECK();
     return PN_OK;
 }
 

@@ -1,24 +1,34 @@
-"""Frame-parallel simulate-and-render over the GPUs of one node (BASELINE.json configs[3]).
+"""Frame pipeline of the simulate-and-render path: several frames in flight on one GPU, and frame-parallel over the GPUs of a node
+(BASELINE.json configs[1] / configs[3]).
 
-The simulator is time-sequential and tiny (<= 10 290 fp64 DOFs); rendering is embarrassingly parallel over frames.
-So one rank (the *sim owner*) advances the elastodynamics and, per frame, broadcasts the kernel-DOF vector
-``dof[30 n_k]`` (<= 82 KB) — the only per-frame exchange — over RCCL (``torch.distributed`` backend "nccl" on ROCm;
-intra-node xGMI, one hop to every peer, so a direct broadcast, not a ring).  Every rank holds the checkpoint and the
-shape functions, rebuilds ``(p_def, F, dF)`` locally from the received DOFs (pn_sim_update_F) and renders the frames
-``f`` with ``frame_owner(f) == rank`` (round-robin over all ranks; from 3 ranks on, over every rank but the sim owner, which then
-only simulates and broadcasts: ``dedicated_sim_default``).  Start-up state is made identical by a one-off broadcast of the checkpoint tensors
-(or by deterministic re-initialisation on every rank).
+The simulator is time-sequential and tiny (<= 10 290 fp64 DOFs); a render is a chain of latency-bound launches that leaves most of the
+chip idle; rendering is embarrassingly parallel over frames.  So the step is software-pipelined:
 
-The scheduling / exchange logic is backend-agnostic and is exercised on CPU with gloo (tests/test_frames_gloo.py);
-the render and sim callables are injected.
+  * a *simulator stream* (on the sim owner) runs nothing but `snapshot[g % S] <- dof` + one substep, frame after frame, `ahead` frames in
+    front of the renders; frame g is rendered from snapshot g = the state BEFORE substep g (trainer.py:300-318);
+  * with more than one rank, every snapshot (<= 82 KB) is broadcast on a *communication stream* (RCCL; every peer is one xGMI hop) — the only
+    per-frame exchange; the checkpoint is broadcast once (``broadcast_tensors``);
+  * frame f is rendered by rank ``frame_owner(f)`` on render *lane* (stream) ``k % lanes`` and workspace ``(k // lanes) % depth`` of that
+    lane, k = the rank's own frame counter: update_F(snapshot f) -> the captured render graph -> D2H of image / depth / depth_0 into pinned
+    buffers on a copy stream (trainer.py:589-592).  A workspace is *retired* — host-waited, checked for rays still alive (then continued
+    with more trips, renderer.py:836-891), handed out — right before it is reused, `lanes * depth` of the rank's frames later, by which time
+    it has long completed: the host never waits for the GPU in steady state and never leaves a lane empty while it enqueues.
+
+``FramePipeline`` is that schedule and nothing else: every device action goes through a small *backend* (streams, events, and the five
+operations snapshot / substep / broadcast / render / copy-out).  ``pienerf_amd.harness`` supplies the HIP backend (torch streams, HIP
+graphs, RCCL); ``SimulatedBackend`` below executes the same enqueue sequence on CPU tensors with FIFO "streams" run in a randomised but
+dependency-respecting order and gloo broadcasts — what tests/test_frames_gloo.py uses to check, for 1-4 ranks, both placements and many
+more frames than snapshot slots, that no slot is overwritten before its readers ran and that every frame sees exactly its own state.
 """
+import random
+
 import torch
 import torch.distributed as dist
 
 
 def dedicated_sim_default(world_size):
     """Whether the sim owner should only simulate.  The job is bounded by the owner's substep rate (the simulator is time-sequential);
-    a substep that shares its GPU with renders runs ~1.8x slower than alone, so from 3 ranks on — where the other
+    a substep that shares its GPU with renders runs slower than alone, so from 3 ranks on — where the other
     ranks can absorb the owner's share of the frames — the owner renders nothing and the frames go round-robin over the rest."""
     return world_size >= 3
 
@@ -39,50 +49,280 @@ def broadcast_tensors(tensors, src=0, group=None):
         dist.broadcast(t, src=src, group=group)
 
 
-class FrameParallel:
-    """Drives `n_frames` of sim+render across the ranks of `group`.
+class FramePipeline:
+    """The enqueue schedule of the pipelined / frame-parallel step.  One instance per rank; every rank calls ``step()`` once per GLOBAL frame.
 
-    sim_step():          advance the simulator by one substep (called on the sim owner only)
-    get_dof() -> tensor: the owner's current DOF vector (flat fp64, on the communication device)
-    set_dof(tensor):     install a received DOF vector on this rank
-    render(frame):       render `frame` from this rank's current DOF state; the return value is collected
+    backend interface (all calls only ENQUEUE work, except the three marked host):
+        stream(name) -> s         named FIFO of device work: 'sim', 'comm', 'lane0'..., 'copy'
+        event() -> e              e.record(s): marks a point of stream s;  s.wait(e): s does not pass until that point has run
+        e.host_wait()             [host] blocks until the point has run
+        snapshot(s, slot)         snap[slot] <- dof               substep(s)          one Simulator.stepforward
+        broadcast(s, slot, src)   collective on snap[slot]
+        render(s, frame, ws, slot, pose)   update_F(snap[slot]) + the render of workspace `ws` = (lane, sub)
+        copy_out(s, ws)           D2H of the workspace's outputs
+        complete(ws) -> bool      [host] did the render finish inside its trips?      finish(ws): [host] continue it until no ray is alive
+        result(ws) -> object      [host] what step() hands back for a retired frame
     """
 
-    def __init__(self, sim_step, get_dof, set_dof, render, sim_owner=0, group=None, dedicated_sim=None):
-        self.sim_step, self.get_dof, self.set_dof, self.render = sim_step, get_dof, set_dof, render
-        self.sim_owner = sim_owner
-        self.group = group
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.dedicated_sim = dedicated_sim_default(self.world) if dedicated_sim is None else bool(dedicated_sim and self.world > 1)
-        self._buf = None
+    def __init__(self, backend, world=1, rank=0, lanes=2, depth=2, ahead=None, sim_owner=0, dedicated_sim=None, copy_out=True):
+        self.b, self.world, self.rank, self.lanes, self.depth, self.owner = backend, int(world), int(rank), int(lanes), int(depth), int(sim_owner)
+        self.dedicated = dedicated_sim_default(self.world) if dedicated_sim is None else bool(dedicated_sim and self.world > 1)
+        self.ahead = self.world * self.lanes * self.depth if ahead is None else int(ahead)
+        self.slots = self.ahead + self.world * self.lanes * self.depth + 1   # snapshot ring: reuse is guarded by events, the size only avoids stalls
+        self.copy_out = copy_out
+        b = backend
+        self.s_sim, self.s_comm, self.s_copy = b.stream("sim"), b.stream("comm"), b.stream("copy")
+        self.s_lane = [b.stream(f"lane{i}") for i in range(self.lanes)]
+        S = self.slots
+        self.snap_ready = [b.event() for _ in range(S)]      # owner: snapshot written (sim stream)
+        self.bc_done = [b.event() for _ in range(S)]         # broadcast of the slot finished (comm stream)
+        self.ip_done = [b.event() for _ in range(S)]         # this rank's render has consumed the slot (lane stream)
+        self.bc_used, self.ip_used = [False] * S, [False] * S
+        n_ws = self.lanes * self.depth
+        self.render_done = [b.event() for _ in range(n_ws)]
+        self.out_ready = [b.event() for _ in range(n_ws)]
+        self.pending = [None] * n_ws                          # global frame index occupying the workspace
+        self.frame = 0            # next global frame
+        self.my_frames = 0        # frames this rank has rendered
+        self.sim_next = 0         # next snapshot / substep the owner enqueues
+        self.bc_next = 0          # next broadcast this rank enqueues
+        self.retired = []         # (frame, result) of workspaces retired by the last step()
 
-    def run(self, n_frames, first_frame=0):
-        """Frame f is rendered from the state BEFORE substep f (the reference's GUI shows the pre-step state,
-        nerf/trainer.py:300-318).  Returns {frame: render result} for the frames this rank owns."""
-        results = {}
-        for f in range(first_frame, first_frame + n_frames):
-            if self.world > 1:
-                if self.rank == self.sim_owner:
-                    buf = self.get_dof()
-                else:
-                    if self._buf is None:
-                        self._buf = torch.empty_like(self.get_dof())
-                    buf = self._buf
-                dist.broadcast(buf, src=self.sim_owner, group=self.group)  # <= 82 KB: latency-bound, every peer is one xGMI hop
-                if self.rank != self.sim_owner:
-                    self.set_dof(buf)
-            if frame_owner(f, self.world, self.sim_owner, self.dedicated_sim) == self.rank:
-                results[f] = self.render(f)
-            if self.rank == self.sim_owner:
-                self.sim_step()
-        return results
+    # ------------------------------------------------------------------ per-frame
+    def _ws(self, k):
+        lane = k % self.lanes
+        return lane, lane * self.depth + (k // self.lanes) % self.depth
 
-    def gather_frame_ids(self, results):
-        """All-gather of which frames were rendered where (bookkeeping / tests)."""
-        mine = sorted(results.keys())
-        if self.world == 1:
-            return [mine]
-        out = [None] * self.world
-        dist.all_gather_object(out, mine, group=self.group)
+    def _advance_simulator(self, upto):
+        b, S = self.b, self.slots
+        while self.sim_next <= upto:
+            slot = self.sim_next % S
+            if self.bc_used[slot]:
+                self.s_sim.wait(self.bc_done[slot])    # the slot's previous snapshot has been sent ...
+            if self.ip_used[slot]:
+                self.s_sim.wait(self.ip_done[slot])    # ... and consumed by this rank's own render
+            b.snapshot(self.s_sim, slot)
+            self.snap_ready[slot].record(self.s_sim)
+            b.substep(self.s_sim)
+            self.sim_next += 1
+
+    def _broadcasts(self, upto):
+        b, S = self.b, self.slots
+        while self.bc_next <= upto:   # same order on every rank
+            slot = self.bc_next % S
+            if self.rank == self.owner:
+                self.s_comm.wait(self.snap_ready[slot])
+            elif self.ip_used[slot]:
+                self.s_comm.wait(self.ip_done[slot])   # this rank's render has read the slot's previous snapshot
+            b.broadcast(self.s_comm, slot, self.owner)
+            self.bc_done[slot].record(self.s_comm)
+            self.bc_used[slot] = True
+            self.bc_next += 1
+
+    def retire(self, ws):
+        """[host] Completes the frame occupying workspace `ws` (if any) and returns (frame, result)."""
+        f = self.pending[ws]
+        if f is None:
+            return None
+        b = self.b
+        (self.out_ready if self.copy_out else self.render_done)[ws].host_wait()
+        if not b.complete(ws):          # rays were still alive after the captured trips: keep going like the reference's loop
+            b.finish(ws)                # [host] blocking continuation on the workspace's lane + copy-out again
+        self.pending[ws] = None
+        return f, b.result(ws)
+
+    def step(self, pose=None):
+        """Enqueues global frame `self.frame`.  Returns the list of (frame, result) this call retired on this rank (a frame comes back
+        `lanes * depth` of the rank's frames after it was enqueued; ``drain()`` returns the rest)."""
+        b, f, S = self.b, self.frame, self.slots
+        self.retired = []
+        if self.rank == self.owner:
+            self._advance_simulator(f + self.ahead)
+        if self.world > 1:
+            self._broadcasts(f + self.ahead)
+        mine = frame_owner(f, self.world, self.owner, self.dedicated) == self.rank
+        if mine:
+            lane, ws = self._ws(self.my_frames)
+            done = self.retire(ws)     # the workspace's previous frame: enqueued lanes*depth frames ago, normally long complete
+            if done is not None:
+                self.retired.append(done)
+            slot = f % S
+            s = self.s_lane[lane]
+            s.wait(self.bc_done[slot] if self.world > 1 else self.snap_ready[slot])
+            b.render(s, f, ws, slot, pose)
+            self.ip_done[slot].record(s)     # recorded after the whole render: conservative (update_F alone reads the snapshot)
+            self.ip_used[slot] = True
+            self.render_done[ws].record(s)
+            if self.copy_out:
+                self.s_copy.wait(self.render_done[ws])
+                b.copy_out(self.s_copy, ws)
+                self.out_ready[ws].record(self.s_copy)
+            self.pending[ws] = f
+            self.my_frames += 1
+        elif self.dedicated and self.rank == self.owner and self.world > 1:
+            # a rank that never renders has nothing that paces its host: wait until this frame's snapshot has been delivered, so that the
+            # owner stays at most `ahead` frames in front of the slowest receiver instead of enqueueing the whole job at once
+            self.bc_done[f % S].host_wait()
+        self.frame += 1
+        return self.retired
+
+    def drain(self):
+        """[host] Retires every frame still in flight on this rank, in frame order."""
+        out = [self.retire(ws) for ws in range(self.lanes * self.depth)]
+        out = sorted(r for r in out if r is not None)
+        self.retired = out
         return out
+
+    @property
+    def substeps_enqueued(self):
+        return self.sim_next
+
+
+# ---------------------------------------------------------------------------------------------------- CPU stand-in of the device side
+class _SimEvent:
+    def __init__(self, be):
+        self.be, self.stream, self.pos = be, None, -1
+
+    def record(self, stream):
+        self.stream, self.pos = stream, len(stream.ops) + stream.base   # the point after everything enqueued so far
+        stream.ops.append(("record", self, None))
+
+    def host_wait(self):
+        self.be.run_until(self)
+
+
+class _SimStream:
+    def __init__(self, name):
+        self.name, self.ops, self.base, self.executed = name, [], 0, 0   # ops[i] has absolute index base + i; executed = absolute count run
+
+    def wait(self, event):
+        # like hipStreamWaitEvent: the wait refers to the event's record at THIS moment (a later re-record does not move it)
+        self.ops.append(("wait", (event.stream, event.pos), None))
+
+
+class SimulatedBackend:
+    """Deferred, dependency-respecting execution of the pipeline's enqueue sequence on CPU tensors (the stand-in for HIP streams).
+
+    Every stream is a FIFO; an operation runs only when the stream's earlier operations have run and the events it waits on have been
+    recorded.  ``run_until(event)`` executes what the event needs, plus — seeded randomness — any other operation that happens to be
+    ready, so different seeds exercise different legal interleavings.  The operations themselves check the pipeline's safety properties:
+    a snapshot slot tagged with frame g may only be overwritten once every consumer of g has run, and a render must find its own frame's
+    tag and data in the slot it reads."""
+
+    def __init__(self, world, rank, n_dof=64, owner=0, seed=0, needs_more_trips=lambda frame: False, group=None):
+        self.world, self.rank, self.owner, self.group = world, rank, owner, group
+        self.rng = random.Random(seed * 1000 + rank)
+        self.streams = {}
+        self.dof = torch.arange(n_dof, dtype=torch.float64) * (1.0 if rank == owner else -7.0)   # only the owner's copy is ever advanced
+        self.steps = 0
+        self.snap, self.snap_tag = {}, {}            # slot -> tensor, slot -> frame whose state it holds
+        self.readers_left = {}                       # (slot, frame) -> renders of that content enqueued but not yet run
+        self.ws_out, self.ws_host, self.ws_trips_short = {}, {}, {}
+        self.needs_more_trips = needs_more_trips
+        self.log = []
+
+    # ---- streams / events
+    def stream(self, name):
+        return self.streams.setdefault(name, _SimStream(name))
+
+    def event(self):
+        return _SimEvent(self)
+
+    def _enqueue(self, s, what, fn):
+        s.ops.append(("op", what, fn))
+
+    def _ready(self, s):
+        if not s.ops:
+            return False
+        kind, a, _ = s.ops[0]
+        return kind != "wait" or a[0] is None or a[0].executed > a[1]
+
+    def _run_one(self, s):
+        kind, a, fn = s.ops.pop(0)
+        s.base += 1
+        if kind == "op":
+            fn()
+        s.executed += 1
+
+    def run_until(self, event):
+        guard = 0
+        while not (event.stream is None or event.stream.executed > event.pos):
+            ready = [s for s in self.streams.values() if self._ready(s)]
+            assert ready, f"deadlock: nothing can run while waiting for a point of stream {event.stream.name}"
+            # bias towards the awaited stream, but let anything legal happen
+            pick = event.stream if (event.stream in ready and self.rng.random() < 0.5) else self.rng.choice(ready)
+            self._run_one(pick)
+            guard += 1
+            assert guard < 10_000_000
+
+    def flush(self):
+        while True:
+            ready = [s for s in self.streams.values() if self._ready(s)]
+            if not ready:
+                break
+            self._run_one(self.rng.choice(ready))
+        assert all(not s.ops for s in self.streams.values()), "operations left that can never run"
+
+    # ---- the five device operations
+    def snapshot(self, s, slot):
+        g = self._sim_enq = getattr(self, "_sim_enq", 0)
+        self._sim_enq += 1
+
+        def run():
+            prev = self.snap_tag.get(slot)
+            assert self.readers_left.get((slot, prev), 0) == 0, f"snapshot slot {slot} overwritten with frame {g} while frame {prev} still has readers"
+            self.snap[slot] = self.dof.clone()
+            self.snap_tag[slot] = g
+        self._enqueue(s, f"snapshot {g}", run)
+
+    def substep(self, s):
+        def run():
+            self.dof = self.dof * 1.01 + 0.5
+            self.steps += 1
+        self._enqueue(s, "substep", run)
+
+    def broadcast(self, s, slot, src):
+        g = self._bc_enq = getattr(self, "_bc_enq", 0)
+        self._bc_enq += 1
+
+        def run():
+            if self.rank == src:
+                assert self.snap_tag.get(slot) == g, f"broadcast of frame {g} finds frame {self.snap_tag.get(slot)} in slot {slot}"
+                buf = self.snap[slot]
+            else:
+                prev = self.snap_tag.get(slot)
+                assert self.readers_left.get((slot, prev), 0) == 0, f"slot {slot} received frame {g} while frame {prev} still has readers"
+                buf = self.snap.setdefault(slot, torch.empty_like(self.dof))
+            dist.broadcast(buf, src=src, group=self.group)   # gloo: blocks until every rank runs the same broadcast
+            self.snap_tag[slot] = g
+        self._enqueue(s, f"broadcast {g}", run)
+
+    def render(self, s, frame, ws, slot, pose):
+        key = (slot, frame)   # readers are counted per slot CONTENT: registered at enqueue time, released when the render has run
+        self.readers_left[key] = self.readers_left.get(key, 0) + 1
+
+        def run():
+            assert self.snap_tag.get(slot) == frame, f"frame {frame} rendered from slot {slot} holding frame {self.snap_tag.get(slot)}"
+            self.readers_left[key] -= 1
+            short = bool(self.needs_more_trips(frame))
+            self.ws_out[ws] = (frame, float(self.snap[slot].sum()), None if pose is None else float(pose), "partial" if short else "full")
+            self.ws_trips_short[ws] = short
+            self.log.append(frame)
+        self._enqueue(s, f"render {frame}", run)
+
+    def copy_out(self, s, ws):
+        def run():
+            self.ws_host[ws] = self.ws_out[ws]
+        self._enqueue(s, f"copy_out {ws}", run)
+
+    # ---- host side of a retired workspace
+    def complete(self, ws):
+        return not self.ws_trips_short[ws]
+
+    def finish(self, ws):
+        f, v, p, _ = self.ws_out[ws]
+        self.ws_out[ws] = self.ws_host[ws] = (f, v, p, "full")
+        self.ws_trips_short[ws] = False
+
+    def result(self, ws):
+        return self.ws_host.get(ws, self.ws_out.get(ws))

@@ -154,7 +154,8 @@ class SimRenderHarness:
 
     @torch.no_grad()
     def step_graph(self, pose=None):
-        """Replays the captured step.  Outputs are static tensors (overwritten by the next replay)."""
+        """Replays the captured step.  Outputs are static tensors (overwritten by the next replay); they are complete — including frames
+        that needed more trips than were captured — after the NEXT call or ``finish_graph_frame()``."""
         if getattr(self, "_graph", None) is None:
             self.capture()
         self._check_previous_graph_frame()
@@ -166,17 +167,25 @@ class SimRenderHarness:
         self.frame += 1
         return self._graph_out
 
+    def finish_graph_frame(self):
+        """Waits for the last replayed step and completes it; returns its outputs."""
+        self._check_previous_graph_frame()
+        return self._graph_out
+
     def _check_previous_graph_frame(self):
+        """The captured step bakes in a trip count; a frame that still had rays alive after them is finished here with further trips (the
+        reference's loop just keeps going, renderer.py:836-891) before its outputs are handed on."""
         if getattr(self, "_graph_done", None) is not None:
             self._graph_done.synchronize()  # normally long complete: the host only ever runs one frame ahead
             st = self.model.render_status(synchronize=False)
             self._graph_done = None
             if st["alive_at_exit"] > 0:
-                raise RuntimeError(f"captured step ran {self._graph_trips} render trips but {st['alive_at_exit']} rays were still alive: "
-                                   "re-capture with more trips (harness.capture(n_trips=...))")
+                g = self._graph_out
+                with self._amp():
+                    self.model.render_continue(0, g["rays_o"], g["rays_d"], g, bg_color=None, **self.render_kwargs())
+                self.graph_continued = getattr(self, "graph_continued", 0) + 1
 
-    # ------------------------------------------------------------------ several frames in flight on one GPU
-    @torch.no_grad()
+    # ------------------------------------------------------------------ several frames in flight (one GPU, or frame-parallel over a node)
     def _cu_masked_stream(self, first_cu, n_cu, invert):
         import ctypes
 
@@ -189,235 +198,346 @@ class SimRenderHarness:
         return torch.cuda.ExternalStream(h.value, device=self.device)
 
     @torch.no_grad()
-    def capture_pipelined(self, lanes=2, n_trips=8, W=None, H=None, sim_ahead=None, sim_priority=0, sim_cus=0, _probe_no_substep=False, _extra_slots=0):
-        """Throughput mode: `lanes` renders in flight on their own streams, the simulator running `sim_ahead` frames ahead.
+    def capture_pipelined(self, lanes=2, n_trips=8, W=None, H=None, sim_ahead=None, depth=2, sim_priority=0, sim_cus=0, copy_out=True, group=None,
+                          frame_parallel=False, sim_owner=0, dedicated_sim=None, _probe_no_substep=False):
+        """Throughput mode (pienerf_amd/frames.py: FramePipeline): `lanes` render streams with `depth` workspaces each, the simulator running
+        `sim_ahead` frames ahead on dof snapshots, every frame's image / depth / depth_0 copied to pinned host memory on a copy stream
+        (the reference's device->host boundary, trainer.py:589-592; copy_out=False leaves the results on the device).  Everything a frame
+        launches is captured in HIP graphs — one for the substep, one per workspace for get_rays + the render with `n_trips` loop trips
+        (None: measured on one eager frame, + 3); a frame that still has rays alive after its trips is continued when it is retired
+        (renderer.py:836-891).  frame_parallel=True (or ``capture_frame_parallel``): the same pipeline over the ranks of `group` — the sim
+        owner broadcasts every snapshot (<= 82 KB) over RCCL, rank frames.frame_owner(f) renders frame f.
 
-        A render is a chain of short latency-bound launches whose tails leave most of the 256 CUs idle, and the substep is a
-        serial chain of ~30 small launches; neither fills the GPU alone, so frames are software-pipelined:
-          * simulator stream: for frame g, `snap[g % slots] <- dof` (33 KB: the state frame g is rendered from), then the
-            captured substep graph.  It depends on nothing but itself, so it never waits for a render;
-          * lane stream l = f % lanes: update_F(snap[f % slots]) into the lane's IP buffers, then the lane's captured render
-            graph, after the snapshot's event.
-        The host enqueues frame f only after frame f - lanes completed (its outputs and buffers are reused), and keeps the
-        simulator `sim_ahead` (default: lanes) frames ahead of that.  Every frame is still rendered from the state before
-        its own substep (trainer.py:300-318); `self.sim.dof` is `sim_ahead + 1` substeps ahead of the last enqueued frame, and a
-        force set with update_force() acts from the next substep that is enqueued."""
-        o, m, dev = self.opt, self.model, self.device
-        W, H = W or o["W"], H or o["H"]
-        ahead = lanes if sim_ahead is None else int(sim_ahead)
-        slots = lanes + ahead + 1 + int(_extra_slots)
-        self._pipe = dict(lanes=lanes, ahead=ahead, slots=slots, W=W, H=H, trips=n_trips, ren_graph=[], out=[], stream=[], done=[], pending=[], ip=[],
-                          keepalive=[], sim_next=0)
-        p = self._pipe
-        self._graph_pose = torch.from_numpy(np.asarray(self.pose, np.float32)).unsqueeze(0).to(dev)
-        if sim_cus > 0:
-            # compute-unit partition: the substep's ~30 small dependent launches get `sim_cus` CUs of their own (spread over the
-            # XCDs), the render lanes the rest, so a substep never waits for a render wave to release registers
-            p["sim_stream"] = self._cu_masked_stream(0, sim_cus, invert=False)
-            streams = [self._cu_masked_stream(0, sim_cus, invert=True) for _ in range(lanes)]
-        else:
-            p["sim_stream"] = torch.cuda.Stream(dev, priority=sim_priority)
-            streams = [torch.cuda.Stream(dev) for _ in range(lanes)]
-        self.sim.force_stream = p["sim_stream"]  # a force change is enqueued between two substeps of the simulator stream
-        p["snap"] = [torch.empty_like(self.sim.dof) for _ in range(slots)]
-        p["snap_ready"] = [torch.cuda.Event() for _ in range(slots)]
-        keep = (self.sim.dof.clone(), self.sim.dof_vel.clone())
-        kw = self.render_kwargs()
-        kw["async_trips"] = n_trips
-        main = torch.cuda.current_stream(dev)
-        n_IP = self.sim.n_IP
-        for lane in range(lanes):  # warm-up of every lane outside capture (creates the per-lane frame workspaces)
-            s = streams[lane]
-            s.wait_stream(main)
-            ip = tuple(torch.empty((n_IP, c), dtype=torch.float32, device=dev) for c in (3, 9, 27))
-            p["ip"].append(ip)
-            with torch.cuda.stream(s):
-                for _ in range(2):
-                    self.sim.get_IP_info(out=ip)
-                    self.sim.stepforward()
-                    m.p_def, m.IP_F, m.IP_dF = ip
-                    rays = get_rays(self._graph_pose, self.intrinsics, H, W, -1)
-                    with self._amp():
-                        m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **dict(kw, frame_slot=lane))
-            torch.cuda.synchronize(dev)
-        # capture_error_mode="thread_local": with a process group alive, RCCL's watchdog thread queries events while we capture;
-        # in the default "global" mode any HIP call from another thread invalidates the capture
-        gs = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gs, stream=p["sim_stream"], capture_error_mode="thread_local"):
-            if not _probe_no_substep:
-                self.sim.stepforward()
-            else:
-                self.sim.dof_vel.mul_(1.0)
-        p["sim_graph"] = gs
-        for lane in range(lanes):
-            kw_l = dict(kw, frame_slot=lane)
-            s = streams[lane]
-            m.p_def, m.IP_F, m.IP_dF = p["ip"][lane]  # the render graph of this lane reads the lane's own IP buffers
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr, stream=s, capture_error_mode="thread_local"):
-                rays = get_rays(self._graph_pose, self.intrinsics, H, W, -1)
-                with self._amp():
-                    out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **kw_l)
-            p["ren_graph"].append(gr)
-            # every tensor the graphs touch stays referenced: a tensor freed after capture goes back to the graph's memory pool
-            # and may be handed out again
-            p["keepalive"].append((rays, out))
-            p["out"].append({"image": out["image"].reshape(-1, H, W, 3), "depth": out["depth"].reshape(-1, H, W),
-                             "depth_0": out["depth_0"].reshape(-1, H, W)})
-            p["stream"].append(s)
-            ev = torch.cuda.Event()
-            ev.record(main)
-            p["done"].append(ev)
-            p.setdefault("done_spare", []).append(torch.cuda.Event())
-            p["pending"].append(False)
-        torch.cuda.synchronize(dev)
-        self.sim.dof.copy_(keep[0])
-        self.sim.dof_vel.copy_(keep[1])
-        torch.cuda.synchronize(dev)
-        return self
-
-    @torch.no_grad()
-    def step_pipelined(self):
-        """Enqueues frame `self.frame` on its lane and returns that lane's (static) outputs; they are complete once the lane's
-        `done` event has fired (synchronize() / the next use of the lane)."""
-        p = self._pipe
-        lane = self.frame % p["lanes"]
-        sim_s, ren_s = p["sim_stream"], p["stream"][lane]
-        # simulator: substeps up to frame + ahead.  Snapshot slot g % slots was last read by frame g - slots = frame - lanes - 1,
-        # which the host saw complete at the end of the previous call, so the simulator stream waits for nothing.
-        with torch.cuda.stream(sim_s):
-            while p["sim_next"] <= self.frame + p["ahead"]:
-                slot = p["sim_next"] % p["slots"]
-                p["snap"][slot].copy_(self.sim.dof)
-                p["snap_ready"][slot].record(sim_s)
-                p["sim_graph"].replay()
-                p["sim_next"] += 1
-        # this frame goes onto its lane BEFORE the host waits for the lane's previous frame (stream order keeps them apart on
-        # the GPU): the ~0.15 ms the host needs to wake up and enqueue ~100 launches is then hidden behind that frame's tail
-        # instead of leaving the lane empty
-        slot = self.frame % p["slots"]
-        prev_done, had_prev = p["done"][lane], p["pending"][lane]
-        p["done"][lane], p["done_spare"][lane] = p["done_spare"][lane], prev_done
-        ren_s.wait_event(p["snap_ready"][slot])
-        with torch.cuda.stream(ren_s):
-            self.sim.get_IP_info(dof=p["snap"][slot], out=p["ip"][lane])
-            p["ren_graph"][lane].replay()
-            p["done"][lane].record(ren_s)
-        p["pending"][lane] = True
-        self.frame += 1
-        if had_prev:  # the host runs at most `lanes` completed-or-running frames plus one queued frame per lane ahead
-            prev_done.synchronize()
-            # the status words of the previous frame are read microseconds after it completed; the frame just enqueued overwrites
-            # them only at ITS end, a render later
-            st = self.model.render_status(synchronize=False, slot=lane)
-            if st["alive_at_exit"] > 0:
-                raise RuntimeError(f"pipelined step ran {p['trips']} render trips but {st['alive_at_exit']} rays were still alive")
-        return p["out"][lane]
-
-    # ------------------------------------------------------------------ frame-parallel over the GPUs of a node
-    @torch.no_grad()
-    def capture_frame_parallel(self, lanes=3, n_trips=8, group=None, sim_owner=0, dedicated_sim=None):
-        """Multi-GPU form of capture_pipelined (BASELINE.json configs[3]): every rank calls step_frame_parallel()
-        once per GLOBAL frame f.  The sim owner advances the simulator (running ahead on dof snapshots, exactly as on one GPU)
-        and every snapshot is broadcast over `group` on a communication stream of its own — <= 82 KB per frame, the only
-        exchange; rank frames.frame_owner(f) renders frame f on one of its lanes from its copy of snapshot f (round-robin over all
-        ranks; with `dedicated_sim` — default from 3 ranks on — over every rank but the owner, which then only simulates).  Neither the
-        substeps nor the broadcasts ever wait for a render, so the ranks' renders overlap freely; the job is bounded by the
-        owner's substep rate (the simulator is time-sequential and does not shard)."""
+        ``step_pipelined(pose=None)`` enqueues the next frame (with its own camera pose, trainer.py:541) and returns the frames it retired:
+        [(frame index, {'image','depth','depth_0': numpy views of the pinned buffers, 'device': the device tensors})]; a frame comes back
+        lanes*depth steps after it went in, ``drain_pipeline()`` returns the rest.  Every frame is rendered from the state before its own
+        substep (trainer.py:300-318); ``self.sim.dof`` is `sim_ahead + 1` substeps in front of the last enqueued frame, and a force set with
+        update_force() acts from the next substep that is enqueued (it is ordered on the simulator's stream)."""
         import torch.distributed as dist
-        on = dist.is_available() and dist.is_initialized()
+
+        from .frames import FramePipeline
+        o = self.opt
+        W, H = W or o["W"], H or o["H"]
+        on = bool(frame_parallel) and dist.is_available() and dist.is_initialized()
         world = dist.get_world_size(group) if on else 1
         rank = dist.get_rank(group) if on else 0
-        self.capture_pipelined(lanes=lanes, n_trips=n_trips, sim_ahead=world * lanes, _extra_slots=world * lanes)
-        p = self._pipe
-        S = p["slots"]
-        from .frames import dedicated_sim_default
-        dedicated = dedicated_sim_default(world) if dedicated_sim is None else bool(dedicated_sim and world > 1)
-        p.update(world=world, rank=rank, owner=sim_owner, group=group, bc_next=0, comm=torch.cuda.Stream(self.device), dedicated=dedicated,
-                 renderers=(world - 1 if dedicated else world), my_frames=0,
-                 src=(dist.get_global_rank(group, sim_owner) if (on and group is not None) else sim_owner),
-                 bc_done=[torch.cuda.Event() for _ in range(S)], ip_done=[torch.cuda.Event() for _ in range(S)],
-                 bc_used=[False] * S, ip_used=[False] * S)
+        if n_trips is None:  # calibrate: the trips one eager frame needs from the current state and pose, plus a margin
+            self.step(simulate=False, collect_stats=True, W=W, H=H)
+            n_trips = max(8, int(self.model.last_stats["trips"]) + 3)
+        be = _HipBackend(self, lanes, depth, int(n_trips), W, H, sim_priority, sim_cus, copy_out, group if on else None,
+                         (dist.get_global_rank(group, sim_owner) if (on and group is not None) else sim_owner), _probe_no_substep)
+        self._pipe = FramePipeline(be, world=world, rank=rank, lanes=lanes, depth=depth, ahead=(lanes if sim_ahead is None and world == 1 else sim_ahead),
+                                   sim_owner=sim_owner, dedicated_sim=dedicated_sim, copy_out=copy_out)
+        self._pipe_backend = be
         return self
 
+    def capture_frame_parallel(self, lanes=2, n_trips=8, group=None, sim_owner=0, dedicated_sim=None, **kw):
+        """Multi-GPU form (BASELINE.json configs[3]): every rank calls step_frame_parallel() once per GLOBAL frame."""
+        return self.capture_pipelined(lanes=lanes, n_trips=n_trips, group=group, frame_parallel=True, sim_owner=sim_owner, dedicated_sim=dedicated_sim, **kw)
+
     @torch.no_grad()
-    def step_frame_parallel(self):
-        """One global frame.  Returns the lane's (static) outputs on the rank that renders it, None elsewhere."""
-        import torch.distributed as dist
-        p = self._pipe
-        from .frames import frame_owner
-        f, world, rank, S = self.frame, p["world"], p["rank"], p["slots"]
-        mine = frame_owner(f, world, p["owner"], p["dedicated"]) == rank
-        lane = p["my_frames"] % p["lanes"]
-        sim_s, comm = p["sim_stream"], p["comm"]
-        if rank == p["owner"]:
-            with torch.cuda.stream(sim_s):
-                while p["sim_next"] <= f + p["ahead"]:
-                    slot = p["sim_next"] % S
-                    if p["bc_used"][slot]:
-                        sim_s.wait_event(p["bc_done"][slot])   # the slot's previous snapshot has been sent ...
-                    if p["ip_used"][slot]:
-                        sim_s.wait_event(p["ip_done"][slot])   # ... and consumed by this rank's own render
-                    p["snap"][slot].copy_(self.sim.dof)
-                    p["snap_ready"][slot].record(sim_s)
-                    p["sim_graph"].replay()
-                    p["sim_next"] += 1
-        if world > 1:
-            with torch.cuda.stream(comm):
-                while p["bc_next"] <= f + p["ahead"]:  # same order on every rank
-                    slot = p["bc_next"] % S
-                    if rank == p["owner"]:
-                        comm.wait_event(p["snap_ready"][slot])
-                    elif p["ip_used"][slot]:
-                        comm.wait_event(p["ip_done"][slot])    # this rank's render has read the slot's previous snapshot
-                    dist.broadcast(p["snap"][slot], src=p["src"], group=p["group"])
-                    p["bc_done"][slot].record(comm)
-                    p["bc_used"][slot] = True
-                    p["bc_next"] += 1
-        out = None
-        if mine:
-            slot = f % S
-            ren_s = p["stream"][lane]
-            prev_done, had_prev = p["done"][lane], p["pending"][lane]
-            p["done"][lane], p["done_spare"][lane] = p["done_spare"][lane], prev_done
-            ren_s.wait_event(p["bc_done"][slot] if world > 1 else p["snap_ready"][slot])
-            with torch.cuda.stream(ren_s):  # enqueued before the host waits for the lane's previous frame (see step_pipelined)
-                self.sim.get_IP_info(dof=p["snap"][slot], out=p["ip"][lane])
-                p["ip_done"][slot].record(ren_s)
-                p["ip_used"][slot] = True
-                p["ren_graph"][lane].replay()
-                p["done"][lane].record(ren_s)
-            p["pending"][lane] = True
-            p["my_frames"] += 1
-            out = p["out"][lane]
-            if had_prev:
-                prev_done.synchronize()
-                st = self.model.render_status(synchronize=False, slot=lane)
-                if st["alive_at_exit"] > 0:
-                    raise RuntimeError(f"frame-parallel step ran {p['trips']} render trips but {st['alive_at_exit']} rays were still alive")
-        elif p["dedicated"] and rank == p["owner"] and world > 1:
-            # a rank that never renders has nothing that paces its host: wait until this frame's snapshot has been delivered, so that
-            # the owner stays at most `ahead` frames in front of the slowest receiver instead of enqueueing the whole job at once
-            p["bc_done"][f % S].synchronize()
-        self.frame += 1
+    def step_pipelined(self, pose=None):
+        out = self._pipe.step(pose)
+        self.frame = self._pipe.frame
         return out
+
+    step_frame_parallel = step_pipelined
 
     @property
     def substeps_enqueued(self):
-        """Simulator substeps enqueued so far in pipelined mode (= frames rendered + sim_ahead + 1 once running)."""
-        return self._pipe["sim_next"]
+        """Simulator substeps enqueued so far in pipelined mode (= frames enqueued + sim_ahead once running)."""
+        return self._pipe.substeps_enqueued
 
+    @torch.no_grad()
     def drain_pipeline(self):
-        """Waits for every frame in flight and verifies each lane's last render completed."""
-        p = self._pipe
+        """Retires every frame in flight (continuing any that ran out of trips) and returns them; the device is idle afterwards."""
+        out = self._pipe.drain()
         torch.cuda.synchronize(self.device)
-        for lane in range(p["lanes"]):
-            if p["pending"][lane]:
-                st = self.model.render_status(synchronize=False, slot=lane)
-                p["pending"][lane] = False
-                if st["alive_at_exit"] > 0:
-                    raise RuntimeError(f"pipelined step ran {p['trips']} render trips but {st['alive_at_exit']} rays were still alive")
+        return out
+
+    # ------------------------------------------------------------------ a frame rendered in ray batches (BASELINE.json configs[4])
+    @torch.no_grad()
+    def capture_staged(self, batch=None, n_trips=None, W=None, H=None, copy_out=True):
+        """The frame rendered in ray batches of `batch` (opt max_ray_batch = 4096, get_opts.py:24; renderer.py:562-576's staging loop).  Rays are
+        independent, so the batches reproduce the one-shot frame bit for bit (tests/test_gpu_fullsize.py).  One batch = one captured HIP
+        graph replay on a 4096-ray workspace; the first batch of a frame builds the spatial hash / candidate lists of the frame's IP state,
+        the others keep them (pn_render_opts.reuse_tables — the reference would rebuild get_pnts_in_grids for every call).  The substep
+        runs on the simulator stream beside the batches; two frame buffers alternate so the D2H of frame f overlaps the batches of f + 1.
+        Batches that ran out of captured trips are counted on the device (render_status 'unfinished') and the frame is then redone with
+        the blocking driver."""
+        o, m, dev = self.opt, self.model, self.device
+        W, H = W or o["W"], H or o["H"]
+        N = W * H
+        B = int(batch or o.get("max_ray_batch", 4096))
+        if n_trips is None:
+            self.step(simulate=False, collect_stats=True, W=W, H=H)
+            n_trips = max(8, int(m.last_stats["trips"]) + 6)   # a 4096-ray batch thins out more slowly than the whole frame: generous margin
+        if not hasattr(self, "_sim_stream"):
+            self._sim_stream = torch.cuda.Stream(dev)
+        self.sim.force_stream = self._sim_stream
+        st = dict(B=B, N=N, W=W, H=H, trips=n_trips, stream=torch.cuda.Stream(dev), copy=torch.cuda.Stream(dev), k=0, redone=0)
+        st["pose"] = torch.from_numpy(np.asarray(self.pose, np.float32)).unsqueeze(0).to(dev)
+        st["ip"] = tuple(torch.empty((self.sim.n_IP, c), dtype=torch.float32, device=dev) for c in (3, 9, 27))
+        st["ro"], st["rd"] = torch.zeros(1, B, 3, device=dev), torch.zeros(1, B, 3, device=dev)
+        st["frames"] = [dict(image=torch.empty(N, 3, device=dev), depth=torch.empty(N, device=dev), depth_0=torch.empty(N, device=dev),
+                             host=({k: torch.empty(s_, dtype=torch.float32).pin_memory() for k, s_ in (("image", (H, W, 3)), ("depth", (H, W)), ("depth_0", (H, W)))}
+                                   if copy_out else None), done=torch.cuda.Event(), used=False) for _ in range(2)]
+        kw = dict(self.render_kwargs(), async_trips=n_trips)
+        m.p_def, m.IP_F, m.IP_dF = st["ip"]
+        keep = (self.sim.dof.clone(), self.sim.dof_vel.clone())
+        s = st["stream"]
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            self.sim.get_IP_info(out=st["ip"])
+            rays = get_rays(st["pose"], self.intrinsics, H, W, -1)
+            st["ro"].copy_(rays["rays_o"][:, :B]); st["rd"].copy_(rays["rays_d"][:, :B])
+            for slot in (900, 901):   # two batch workspaces alternate from frame to frame: each keeps its frame's status words
+                with self._amp():
+                    m.render_deformed(st["ro"], st["rd"], bg_color=None, perturb=False, frame_slot=slot, **kw)
+                    m.render_deformed(st["ro"], st["rd"], bg_color=None, perturb=False, reuse_tables=True, frame_slot=slot, **kw)
+        torch.cuda.synchronize(dev)
+        st["graph"], st["out"] = {}, {}
+        for slot in (900, 901):
+            for reuse in (False, True):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+                    with self._amp():
+                        out = m.render_deformed(st["ro"], st["rd"], bg_color=None, perturb=False, reuse_tables=reuse, frame_slot=slot, **kw)
+                st["graph"][slot, reuse] = g
+                st["out"][slot, reuse] = out
+        torch.cuda.synchronize(dev)
+        self.sim.dof.copy_(keep[0]); self.sim.dof_vel.copy_(keep[1])
+        st["sim_done"] = torch.cuda.Event()
+        st["sim_done"].record(torch.cuda.current_stream(dev))
+        st["kw"] = kw
+        self._staged = st
+        return self
+
+    @torch.no_grad()
+    def step_staged(self, pose=None):
+        """One sim+render step with the frame rendered in ray batches.  Enqueues this step and returns the PREVIOUS step's frame (complete,
+        checked; None on the first call); ``finish_staged()`` returns the last one."""
+        from ._lib import check, lib, stream_ptr
+        st, m, dev = self._staged, self.model, self.device
+        s, B, N, H, W = st["stream"], st["B"], st["N"], st["H"], st["W"]
+        k = st["k"]
+        fr, slot = st["frames"][k % 2], 900 + k % 2      # this buffer's previous frame (k - 2) was retired during the last call
+        with torch.cuda.stream(s):
+            if pose is not None:
+                st["pose"].copy_(torch.from_numpy(np.asarray(pose, np.float32)).view(1, 4, 4).to(dev))
+            s.wait_event(st["sim_done"])                                # the previous substep must have finished before dof is read
+            self.sim.get_IP_info(out=st["ip"])
+            ip_ready = torch.cuda.Event()
+            ip_ready.record(s)
+            rays = get_rays(st["pose"], self.intrinsics, H, W, -1)
+            fr["rays"] = rays
+            check(lib().pn_frame_reset_unfinished(m._frames[slot][0], stream_ptr()), "reset_unfinished")
+            for head in range(0, N, B):
+                n = min(B, N - head)
+                st["ro"][:, :n].copy_(rays["rays_o"][:, head:head + n])
+                st["rd"][:, :n].copy_(rays["rays_d"][:, head:head + n])
+                key = (slot, head != 0)                                 # the first batch of the frame builds the tables, the others keep them
+                st["graph"][key].replay()
+                out = st["out"][key]
+                fr["image"][head:head + n].copy_(out["image"].view(-1, 3)[:n])
+                fr["depth"][head:head + n].copy_(out["depth"].view(-1)[:n])
+                fr["depth_0"][head:head + n].copy_(out["depth_0"].view(-1)[:n])
+            ev = torch.cuda.Event()
+            ev.record(s)
+        self._sim_stream.wait_event(ip_ready)                           # the substep only feeds the NEXT frame: it runs beside the batches
+        with torch.cuda.stream(self._sim_stream):
+            self.sim.stepforward()
+            st["sim_done"].record(self._sim_stream)
+        if fr["host"] is not None:
+            st["copy"].wait_event(ev)
+            with torch.cuda.stream(st["copy"]):
+                for name in ("image", "depth", "depth_0"):
+                    fr["host"][name].copy_(fr[name].view(fr["host"][name].shape), non_blocking=True)
+                fr["done"] = torch.cuda.Event()
+                fr["done"].record(st["copy"])
+        else:
+            fr["done"] = ev
+        fr["used"], fr["slot"] = True, slot
+        st["k"] += 1
+        self.frame += 1
+        return self._retire_staged(st["frames"][(k + 1) % 2])           # frame k - 1: the GPU already has frame k queued behind it
+
+    def _retire_staged(self, fr):
+        if not fr["used"]:
+            return None
+        fr["done"].synchronize()
+        # one status read per frame: batches the captured trips did not finish were counted on the device (pn_frame_reset_unfinished)
+        stt = self.model.render_status(synchronize=False, slot=fr["slot"])
+        if stt["unfinished"] > 0:
+            raise RuntimeError(f"staged frame: {stt['unfinished']} rays were still alive after the {self._staged['trips']} captured trips of their batch; "
+                               "capture_staged(n_trips=...) with more trips")
+        fr["used"] = False
+        h = fr["host"]
+        dev = {name: fr[name] for name in ("image", "depth", "depth_0")}
+        return {"device": dev} if h is None else {"image": h["image"].numpy(), "depth": h["depth"].numpy(), "depth_0": h["depth_0"].numpy(), "device": dev}
+
+    def finish_staged(self):
+        """Waits for and returns the last enqueued staged frame."""
+        st = self._staged
+        out = self._retire_staged(st["frames"][(st["k"] + 1) % 2])
+        torch.cuda.synchronize(self.device)
+        return out
 
     def to_host(self, out):
         """The reference's device->host boundary (trainer.py:589-592)."""
         return {k: out[k][0].detach().cpu().numpy() for k in ("image", "depth", "depth_0")}
+
+
+class _HipStream:
+    def __init__(self, s):
+        self.s = s
+
+    def wait(self, ev):
+        self.s.wait_event(ev.e)
+
+
+class _HipEvent:
+    def __init__(self):
+        self.e = torch.cuda.Event()
+
+    def record(self, stream):
+        self.e.record(stream.s)
+
+    def host_wait(self):
+        self.e.synchronize()
+
+
+class _HipBackend:
+    """The device side of frames.FramePipeline on one MI355X: torch streams and events, the substep and one render per workspace captured
+    as HIP graphs, RCCL broadcasts of the dof snapshots, D2H into pinned buffers."""
+
+    def __init__(self, h, lanes, depth, n_trips, W, H, sim_priority, sim_cus, copy_out, group, src, probe_no_substep):
+        self.h, self.lanes, self.depth, self.trips, self.W, self.H, self.group, self.src = h, lanes, depth, n_trips, W, H, group, src
+        dev, m, sim = h.device, h.model, h.sim
+        self.continued = 0
+        if sim_cus > 0:
+            # compute-unit partition: the substep's chain of small dependent launches gets `sim_cus` CUs of its own (spread over the XCDs),
+            # the render lanes the rest, so a substep never waits for a render wave to release registers
+            self._streams = {"sim": h._cu_masked_stream(0, sim_cus, invert=False)}
+            lane_streams = [h._cu_masked_stream(0, sim_cus, invert=True) for _ in range(lanes)]
+        else:
+            self._streams = {"sim": torch.cuda.Stream(dev, priority=sim_priority)}
+            lane_streams = [torch.cuda.Stream(dev) for _ in range(lanes)]
+        for i, s in enumerate(lane_streams):
+            self._streams[f"lane{i}"] = s
+        self._streams["comm"], self._streams["copy"] = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        sim.force_stream = self._streams["sim"]   # a force change is enqueued between two substeps of the simulator stream
+        self.snap = {}
+        n_ws, n_IP = lanes * depth, sim.n_IP
+        kw = dict(h.render_kwargs(), async_trips=n_trips)
+        self.kw = kw
+        pose0 = torch.from_numpy(np.asarray(h.pose, np.float32)).unsqueeze(0)
+        self.pose_dev = [pose0.to(dev) for _ in range(n_ws)]
+        self.pose_pin = [pose0.clone().pin_memory() for _ in range(n_ws)]
+        self.ip = [tuple(torch.empty((n_IP, c), dtype=torch.float32, device=dev) for c in (3, 9, 27)) for _ in range(n_ws)]
+        keep = (sim.dof.clone(), sim.dof_vel.clone())
+        main = torch.cuda.current_stream(dev)
+        for ws in range(n_ws):  # warm-up of every workspace outside capture (creates the pn_frame workspaces, the fp16 tables, ...)
+            s = self._streams[f"lane{ws // depth}"]
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    sim.get_IP_info(out=self.ip[ws])
+                    sim.stepforward()
+                    m.p_def, m.IP_F, m.IP_dF = self.ip[ws]
+                    rays = get_rays(self.pose_dev[ws], h.intrinsics, H, W, -1)
+                    with h._amp():
+                        m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **dict(kw, frame_slot=ws))
+            torch.cuda.synchronize(dev)
+        # capture_error_mode="thread_local": with a process group alive, RCCL's watchdog thread queries events while we capture;
+        # in the default "global" mode any HIP call from another thread invalidates the capture
+        self.sim_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.sim_graph, stream=self._streams["sim"], capture_error_mode="thread_local"):
+            if not probe_no_substep:
+                sim.stepforward()
+            else:
+                sim.dof_vel.mul_(1.0)
+        self.graph, self.rays, self.out, self.host = [], [], [], []
+        for ws in range(n_ws):
+            s = self._streams[f"lane{ws // depth}"]
+            m.p_def, m.IP_F, m.IP_dF = self.ip[ws]  # the render graph of this workspace reads its own IP buffers
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+                rays = get_rays(self.pose_dev[ws], h.intrinsics, H, W, -1)
+                with h._amp():
+                    out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **dict(kw, frame_slot=ws))
+            self.graph.append(g)
+            # every tensor the graphs touch stays referenced: a tensor freed after capture goes back to the graph's memory pool
+            self.rays.append(rays)
+            self.out.append(out)
+            self.host.append({"image": torch.empty((H, W, 3), dtype=torch.float32).pin_memory(), "depth": torch.empty((H, W), dtype=torch.float32).pin_memory(),
+                              "depth_0": torch.empty((H, W), dtype=torch.float32).pin_memory()} if copy_out else None)
+        torch.cuda.synchronize(dev)
+        sim.dof.copy_(keep[0])      # warm-up advanced the simulator; capture itself executes nothing
+        sim.dof_vel.copy_(keep[1])
+        torch.cuda.synchronize(dev)
+
+    # ---- streams / events
+    def stream(self, name):
+        return _HipStream(self._streams[name])
+
+    def event(self):
+        return _HipEvent()
+
+    def _snap(self, slot):
+        if slot not in self.snap:
+            self.snap[slot] = torch.empty_like(self.h.sim.dof)
+        return self.snap[slot]
+
+    # ---- device operations
+    def snapshot(self, s, slot):
+        with torch.cuda.stream(s.s):
+            self._snap(slot).copy_(self.h.sim.dof)
+
+    def substep(self, s):
+        with torch.cuda.stream(s.s):
+            self.sim_graph.replay()
+
+    def broadcast(self, s, slot, src):
+        import torch.distributed as dist
+        with torch.cuda.stream(s.s):
+            dist.broadcast(self._snap(slot), src=self.src, group=self.group)
+
+    def render(self, s, frame, ws, slot, pose):
+        with torch.cuda.stream(s.s):
+            if pose is not None:  # a new camera per frame (trainer.py:541): staged in pinned memory, uploaded in stream order before the graph reads it
+                self.pose_pin[ws].copy_(torch.from_numpy(np.asarray(pose, np.float32)).view(1, 4, 4))
+                self.pose_dev[ws].copy_(self.pose_pin[ws], non_blocking=True)
+            self.h.sim.get_IP_info(dof=self._snap(slot), out=self.ip[ws])
+            self.graph[ws].replay()
+
+    def copy_out(self, s, ws):
+        o, hbuf = self.out[ws], self.host[ws]
+        with torch.cuda.stream(s.s):
+            hbuf["image"].copy_(o["image"].view(self.H, self.W, 3), non_blocking=True)
+            hbuf["depth"].copy_(o["depth"].view(self.H, self.W), non_blocking=True)
+            hbuf["depth_0"].copy_(o["depth_0"].view(self.H, self.W), non_blocking=True)
+
+    # ---- host side of a retired workspace
+    def complete(self, ws):
+        return self.h.model.render_status(synchronize=False, slot=ws)["alive_at_exit"] == 0
+
+    def finish(self, ws):
+        """The captured trips were not enough for this frame: keep going on the workspace's lane until no ray is alive (blocking), then copy
+        the finished frame out again."""
+        h, m = self.h, self.h.model
+        s = self._streams[f"lane{ws // self.depth}"]
+        with torch.cuda.stream(s):
+            with h._amp():
+                m.render_continue(ws, self.rays[ws]["rays_o"], self.rays[ws]["rays_d"], self.out[ws], bg_color=None, **self.kw)
+            if self.host[ws] is not None:
+                self.copy_out(_HipStream(s), ws)
+        s.synchronize()
+        self.continued += 1
+
+    def result(self, ws):
+        o, hbuf = self.out[ws], self.host[ws]
+        dev = {"image": o["image"].view(-1, self.H, self.W, 3), "depth": o["depth"].view(-1, self.H, self.W), "depth_0": o["depth_0"].view(-1, self.H, self.W)}
+        if hbuf is None:
+            return {"device": dev}
+        return {"image": hbuf["image"].numpy(), "depth": hbuf["depth"].numpy(), "depth_0": hbuf["depth_0"].numpy(), "device": dev}

@@ -59,6 +59,8 @@ class NeRFRenderer(nn.Module):
 
     # ------------------------------------------------------------------ entry point (renderer.py:587-599)
     def render_deformed(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
+        """renderer.py:587-599.  `staged` / `max_ray_batch` are accepted and unused exactly as in the reference, whose render_deformed calls
+        rund_cuda on the whole ray set whatever they say (only the non-cuda_ray `render` stages, :562-576)."""
         if not self.cuda_ray:
             raise RuntimeError("render_deformed: only the cuda_ray path (main_gui.py / main_render.py with -O) is implemented")
         return self.rund_cuda(rays_o, rays_d, **kwargs)
@@ -85,27 +87,10 @@ class NeRFRenderer(nn.Module):
         return self._frames[slot][0]
 
     # ------------------------------------------------------------------ fused loop
-    def rund_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-2, **kwargs):
-        if perturb:
-            return self.rund_cuda_ops(rays_o, rays_d, dt_gamma, bg_color, perturb, max_steps, T_thresh, **kwargs)
-        prefix = rays_o.shape[:-1]
-        rays_o = rays_o.to(torch.float32).contiguous().view(-1, 3)
-        rays_d = rays_d.to(torch.float32).contiguous().view(-1, 3)
-        require_gpu(rays_o, rays_d)
-        N, device = rays_o.shape[0], rays_o.device
-        if self.bg_radius > 0:
-            raise RuntimeError("background model (bg_radius > 0) is not on the simulate-and-render path")
-        if bg_color is None:
-            bg_color = 1
-        if torch.is_tensor(bg_color):
-            raise RuntimeError("rund_cuda: tensor bg_color is not supported by the fused path; use rund_cuda_ops")
-        p_def, p_ori, F_IP, dF_IP = self._ip_state(device)
-        assert p_def.shape == p_ori.shape and p_ori.shape[0] > 0  # renderer.py:816-817
-        n_vtx = p_ori.shape[0]
-        hgs = float(kwargs.get("hash_grid_size"))
+    def _deformed_opts(self, dt_gamma, bg_scalar, max_steps, T_thresh, kwargs):
         o = RenderOpts()
         o.max_iter_num = int(kwargs.get("max_iter_num"))
-        o.hash_grid_size = hgs
+        o.hash_grid_size = float(kwargs.get("hash_grid_size"))
         o.num_seek_IP = int(kwargs.get("num_seek_IP"))
         o.IP_dx = float(self.IP_dx)
         o.cut = int(bool(kwargs.get("cut")))
@@ -120,31 +105,82 @@ class NeRFRenderer(nn.Module):
         o.cascade = int(self.cascade)
         o.grid_size = int(self.grid_size)
         o.density_scale = float(self.density_scale)
-        o.bg_color = float(bg_color)
+        o.bg_color = float(bg_scalar)
         o.fp16 = int(self._autocast_half())  # Trainer.test_gui renders under autocast(enabled=self.fp16) (trainer.py:561)
+        o.reuse_tables = int(bool(kwargs.get("reuse_tables")))  # extension: later ray batches of the same frame keep the first batch's tables
+        return o
+
+    def rund_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-2, **kwargs):
+        if perturb:
+            return self.rund_cuda_ops(rays_o, rays_d, dt_gamma, bg_color, perturb, max_steps, T_thresh, **kwargs)
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.to(torch.float32).contiguous().view(-1, 3)
+        rays_d = rays_d.to(torch.float32).contiguous().view(-1, 3)
+        require_gpu(rays_o, rays_d)
+        N, device = rays_o.shape[0], rays_o.device
+        if self.bg_radius > 0:
+            raise RuntimeError("background model (bg_radius > 0) is not on the simulate-and-render path")
+        if bg_color is None:
+            bg_color = 1
+        # a tensor background ([3] or [N,3], e.g. the GUI's bg_color tensor, gui.py:590): the driver composites over 0 and the blend
+        # image + (1 - weights_sum) * bg (renderer.py:896) is applied afterwards with the same two roundings
+        bg_tensor = bg_color.to(device=device, dtype=torch.float32) if torch.is_tensor(bg_color) else None
+        p_def, p_ori, F_IP, dF_IP = self._ip_state(device)
+        assert p_def.shape == p_ori.shape and p_ori.shape[0] > 0  # renderer.py:816-817
+        n_vtx = p_ori.shape[0]
+        o = self._deformed_opts(dt_gamma, 0.0 if bg_tensor is not None else bg_color, max_steps, T_thresh, kwargs)
         image = torch.empty(N, 3, dtype=torch.float32, device=device)
         depth = torch.empty(N, dtype=torch.float32, device=device)
         depth_0 = torch.empty(N, dtype=torch.float32, device=device)
         weights_sum = torch.empty(N, dtype=torch.float32, device=device)
         async_trips = int(kwargs.get("async_trips") or 0)
-        frame, net = self._frame_handle(N, n_vtx, hgs, int(kwargs.get("frame_slot") or 0)), self._net_handle(half=bool(o.fp16))
+        frame, net = self._frame_handle(N, n_vtx, o.hash_grid_size, int(kwargs.get("frame_slot") or 0)), self._net_handle(half=bool(o.fp16))
         if async_trips > 0:
             # non-blocking: a fixed number of trips, no host synchronisation (legal under HIP-graph capture); completion is
-            # checked later with render_status()
+            # checked later with render_status(), a frame that ran out of trips is finished with render_continue()
             check(lib().pn_render_deformed_async(frame, net, C.byref(o), ptr(rays_o), ptr(rays_d), N, ptr(p_def), ptr(p_ori), ptr(F_IP), ptr(dF_IP),
                                                  n_vtx, ptr(self.density_bitfield), ptr(image), ptr(depth), ptr(depth_0), ptr(weights_sum),
                                                  async_trips, stream_ptr()), "render_deformed_async")
         else:
-            stats = (C.c_int64 * 4)() if kwargs.get("collect_stats") else None
+            stats = (C.c_int64 * 5)() if kwargs.get("collect_stats") else None
             check(lib().pn_render_deformed(frame, net, C.byref(o), ptr(rays_o), ptr(rays_d), N, ptr(p_def), ptr(p_ori), ptr(F_IP), ptr(dF_IP), n_vtx,
                                            ptr(self.density_bitfield), ptr(image), ptr(depth), ptr(depth_0), ptr(weights_sum), stats, stream_ptr()),
                   "render_deformed")
             if stats is not None:
                 self._set_stats(stats)
+        if bg_tensor is not None:
+            image = image + (1 - weights_sum).unsqueeze(-1) * bg_tensor
         return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "depth_0": depth_0.view(*prefix), "weights_sum": weights_sum}
 
+    def render_continue(self, slot, rays_o, rays_d, out, n_trips=0, dt_gamma=0, bg_color=None, max_steps=1024, T_thresh=1e-2, static=False, **kwargs):
+        """Finishes the frame last rendered on workspace `slot` with a fixed trip count that turned out too small (render_status reports
+        rays alive at exit): more trips of the same loop — n_trips of them, or (0) until no ray is alive — and the epilogue again, into the
+        SAME output tensors `out` (the dict the render returned).  The reference's loop has no trip limit but max_steps (renderer.py:836-891);
+        this is how the captured, fixed-length forms keep that semantics.  Blocking when n_trips == 0."""
+        rays_o = rays_o.to(torch.float32).contiguous().view(-1, 3)
+        rays_d = rays_d.to(torch.float32).contiguous().view(-1, 3)
+        N = rays_o.shape[0]
+        if static:
+            o = RenderOpts()
+            o.max_iter_num, o.hash_grid_size, o.num_seek_IP, o.IP_dx, o.cut = 1, 1.0, 1, 0.0, 0
+            o.bound, o.min_near, o.dt_gamma, o.max_steps, o.T_thresh = float(self.bound), float(self.min_near), float(dt_gamma), int(max_steps), float(T_thresh)
+            o.cascade, o.grid_size, o.density_scale, o.bg_color = int(self.cascade), int(self.grid_size), float(self.density_scale), float(1 if bg_color is None else bg_color)
+            o.fp16 = int(self._autocast_half())
+        else:
+            o = self._deformed_opts(dt_gamma, 1 if bg_color is None else bg_color, max_steps, T_thresh, kwargs)
+        image, depth, ws = out["image"].view(-1, 3), out["depth"].view(-1), out["weights_sum"].view(-1)
+        depth_0 = out["depth_0"].view(-1) if "depth_0" in out else torch.empty_like(depth)
+        assert image.is_contiguous() and image.shape[0] == N
+        stats = (C.c_int64 * 5)() if int(n_trips) == 0 else None
+        check(lib().pn_render_continue(self._frames[slot][0], self._net_handle(half=bool(o.fp16)), C.byref(o), ptr(rays_o), ptr(rays_d), N,
+                                       ptr(self.density_bitfield), ptr(image), ptr(depth), ptr(depth_0), ptr(ws), stats, int(n_trips), int(bool(static)),
+                                       stream_ptr()), "render_continue")
+        if stats is not None:
+            self._set_stats(stats)
+        return out
+
     def _set_stats(self, stats):
-        self.last_stats = dict(trips=int(stats[0]), samples=int(stats[1]), err=int(stats[2]), alive_at_exit=int(stats[3]))
+        self.last_stats = dict(trips=int(stats[0]), samples=int(stats[1]), err=int(stats[2]), alive_at_exit=int(stats[3]), unfinished=int(stats[4]))
         if stats[2]:
             raise RuntimeError(f"render_deformed: device error flags {int(stats[2])} (1: sample cell outside the spatial hash, "
                                "2: IP outside it, 4: spatial-hash capacity exceeded, 8: candidate-list capacity exceeded)")
@@ -164,7 +200,7 @@ class NeRFRenderer(nn.Module):
     def render_status(self, synchronize=True, slot=0):
         """Outcome of the last render on frame workspace `slot`: dict(trips, samples, err, alive_at_exit).
         After an async render, alive_at_exit > 0 means the enqueued trips were not enough."""
-        stats = (C.c_int64 * 4)()
+        stats = (C.c_int64 * 5)()
         check(lib().pn_render_status(self._frames[slot][0], stats, int(bool(synchronize)), stream_ptr()), "render_status")
         self._set_stats(stats)
         return self.last_stats
@@ -211,7 +247,7 @@ class NeRFRenderer(nn.Module):
                                      torch.empty(N, dtype=torch.float32, device=device), torch.empty(N, dtype=torch.float32, device=device))
         frame = self._frame_handle(N, 1, 1.0, int(kwargs.get("frame_slot") or 0), cells=1)
         async_trips = int(kwargs.get("async_trips") or 0)
-        stats = (C.c_int64 * 4)() if not async_trips else None
+        stats = (C.c_int64 * 5)() if not async_trips else None
         check(lib().pn_render_static(frame, self._net_handle(half=bool(o.fp16)), C.byref(o), ptr(rays_o), ptr(rays_d), N, aabb, ptr(self.density_bitfield),
                                      ptr(image), ptr(depth), ptr(depth_0), ptr(ws), stats, async_trips, stream_ptr()), "render_static")
         if stats is not None:

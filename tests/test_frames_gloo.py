@@ -1,9 +1,12 @@
-"""N > 1 path on CPU: world_size-2 gloo run of the frame-parallel driver (rank 0 simulates and broadcasts the DOF state,
-frames are rendered round-robin)."""
+"""The frame pipeline's schedule (pienerf_amd/frames.py: FramePipeline — the class the HIP harness and bench.py --gpus N run) on CPU:
+1-4 gloo ranks, both placements of the simulator, many more frames than snapshot slots, randomised legal interleavings of the simulated
+streams.  The simulated backend asserts the safety properties while it runs (no snapshot slot overwritten or received into while a reader
+is outstanding, every render finds its own frame's state); the tests check the results against the serial sequence."""
 import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -17,83 +20,103 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_frames, out_dir, dedicated=None):
+def _serial(n_frames, n_dof=64):
+    dof = np.arange(n_dof, dtype=np.float64)
+    want = []
+    for _ in range(n_frames):
+        want.append(dof.sum())
+        dof = dof * 1.01 + 0.5
+    return want
+
+
+def _run_rank(rank, world, n_frames, lanes, depth, dedicated, seed, ahead=None, short=()):
+    from pienerf_amd.frames import FramePipeline, SimulatedBackend
+    be = SimulatedBackend(world, rank, seed=seed, needs_more_trips=lambda f: f in short)
+    pipe = FramePipeline(be, world=world, rank=rank, lanes=lanes, depth=depth, dedicated_sim=dedicated, ahead=ahead)
+    got = []
+    for f in range(n_frames):
+        got += pipe.step(pose=float(f) * 0.25)    # a per-frame pose travels with the frame
+    got += pipe.drain()
+    be.flush()
+    return pipe, be, got
+
+
+def _worker(rank, world, port, n_frames, lanes, depth, dedicated, seed, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from pienerf_amd.frames import FrameParallel, broadcast_tensors
-
-    # stand-in simulator: a deterministic linear recurrence on a DOF vector; only rank 0's copy is ever advanced
-    n = 30 * 7
-    state = {"dof": torch.arange(n, dtype=torch.float64) * (1.0 if rank == 0 else -1.0), "steps": 0}
-
-    def sim_step():
-        state["dof"] = state["dof"] * 1.01 + 0.5
-        state["steps"] += 1
-
-    def render(frame):
-        return float(state["dof"].sum())  # "image" = a checksum of the state the frame was rendered from
-
+    from pienerf_amd.frames import broadcast_tensors, frame_owner
     ckpt = [torch.full((5,), float(rank)), torch.full((3, 3), float(rank) + 10)]
     broadcast_tensors(ckpt, src=0)
     assert all(float(t.flatten()[0]) in (0.0, 10.0) for t in ckpt)  # every rank now holds rank 0's "checkpoint"
-
-    fp = FrameParallel(sim_step, lambda: state["dof"], lambda t: state.__setitem__("dof", t.clone()), render, dedicated_sim=dedicated)
-    res = fp.run(n_frames)
-    ids = fp.gather_frame_ids(res)
-    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([[f, v] for f, v in sorted(res.items())]).reshape(-1, 2))
+    pipe, be, got = _run_rank(rank, world, n_frames, lanes, depth, dedicated, seed, short=(3, 10))
+    frames = [f for f, _ in got]
+    assert frames == sorted(frames) and frames == [f for f in range(n_frames) if frame_owner(f, world, 0, pipe.dedicated) == rank]
+    assert all(r[0] == f and r[2] == f * 0.25 and r[3] == "full" for f, r in got)      # own frame, own pose, continued to completion if short
     if rank == 0:
-        assert state["steps"] == n_frames
-        if fp.dedicated_sim:  # the owner renders nothing; frames go round-robin over the other ranks
-            assert ids == [[]] + [list(range(r - 1, n_frames, world - 1)) for r in range(1, world)]
-        else:
-            assert ids == [list(range(r, n_frames, world)) for r in range(world)]
+        assert be.steps == n_frames + pipe.ahead and pipe.substeps_enqueued == n_frames + pipe.ahead
     else:
-        assert state["steps"] == 0
+        assert be.steps == 0
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([[f, r[1]] for f, r in got]).reshape(-1, 2))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_frame_parallel_two_ranks(tmp_path):
-    n_frames = 7
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, n_frames, str(tmp_path)), nprocs=2, join=True)
-    got = np.concatenate([np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")])
+@pytest.mark.parametrize("world,lanes,depth,dedicated,seed", [(2, 2, 2, None, 0), (2, 1, 2, False, 1), (3, 2, 1, None, 2), (3, 2, 2, False, 3), (4, 2, 2, None, 4),
+                                                               (4, 3, 1, False, 5)])
+def test_frame_pipeline_multi_rank(tmp_path, world, lanes, depth, dedicated, seed):
+    n_frames = 61   # several times the snapshot ring (2 * world * lanes * depth + 1 slots)
+    mp.spawn(_worker, args=(world, _free_port(), n_frames, lanes, depth, dedicated, seed, str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f"r{r}.npy") for r in range(world)])
     got = got[np.argsort(got[:, 0])]
     assert list(got[:, 0].astype(int)) == list(range(n_frames))
-    # serial reference: frame f sees the state before substep f
-    dof = np.arange(30 * 7, dtype=np.float64)
-    want = []
-    for f in range(n_frames):
-        want.append(dof.sum())
-        dof = dof * 1.01 + 0.5
-    assert np.allclose(got[:, 1], want, rtol=0, atol=1e-9)
+    assert np.allclose(got[:, 1], _serial(n_frames), rtol=0, atol=1e-9)      # frame f sees the state before substep f
+    from pienerf_amd.frames import dedicated_sim_default
+    if dedicated is None and dedicated_sim_default(world):
+        assert len(np.load(tmp_path / "r0.npy")) == 0                        # the owner only simulates and broadcasts
 
 
-def test_frame_parallel_three_ranks_dedicated_sim_owner(tmp_path):
-    """From 3 ranks on the sim owner only simulates and broadcasts (frames.dedicated_sim_default); the frames are the serial sequence."""
+@pytest.mark.parametrize("lanes,depth,ahead,seed", [(1, 2, None, 0), (3, 2, None, 1), (2, 1, 1, 2), (1, 1, 0, 3), (3, 1, 7, 4)])
+def test_frame_pipeline_single_rank(lanes, depth, ahead, seed):
+    n_frames = 40
+    pipe, be, got = _run_rank(0, 1, n_frames, lanes, depth, None, seed, ahead=ahead, short=(5,))
+    assert [f for f, _ in got] == list(range(n_frames))
+    assert np.allclose([r[1] for _, r in got], _serial(n_frames), rtol=0, atol=1e-9)
+    assert all(r[3] == "full" for _, r in got) and sorted(be.log) == list(range(n_frames))
+    assert pipe.substeps_enqueued == n_frames + pipe.ahead
+    # frames come back lanes * depth frames late, in order, and drain() returns the rest
+    pipe2, _, _ = _run_rank(0, 1, 0, lanes, depth, None, seed, ahead=ahead)
+    assert pipe2.drain() == []
+
+
+def test_schedule_helpers():
     from pienerf_amd.frames import dedicated_sim_default, frame_owner
     assert [dedicated_sim_default(w) for w in (1, 2, 3, 8)] == [False, False, True, True]
     assert [frame_owner(f, 4, 0, True) for f in range(7)] == [1, 2, 3, 1, 2, 3, 1]
     assert [frame_owner(f, 4, 2, True) for f in range(7)] == [0, 1, 3, 0, 1, 3, 0]
     assert [frame_owner(f, 4, 0, False) for f in range(5)] == [0, 1, 2, 3, 0]
-    n_frames = 8
-    mp.spawn(_worker, args=(3, _free_port(), n_frames, str(tmp_path)), nprocs=3, join=True)
-    got = np.concatenate([np.load(tmp_path / f"r{r}.npy") for r in range(3)])
-    got = got[np.argsort(got[:, 0])]
-    assert list(got[:, 0].astype(int)) == list(range(n_frames)) and len(np.load(tmp_path / "r0.npy")) == 0
-    dof = np.arange(30 * 7, dtype=np.float64)
-    want = []
-    for f in range(n_frames):
-        want.append(dof.sum())
-        dof = dof * 1.01 + 0.5
-    assert np.allclose(got[:, 1], want, rtol=0, atol=1e-9)
-
-
-def test_single_process_fallthrough():
-    from pienerf_amd.frames import FrameParallel, frame_owner
-    log = []
-    fp = FrameParallel(lambda: log.append("s"), lambda: torch.zeros(3, dtype=torch.float64), lambda t: None, lambda f: log.append(f) or f)
-    res = fp.run(3)
-    assert res == {0: 0, 1: 1, 2: 2} and log == [0, "s", 1, "s", 2, "s"]
     assert [frame_owner(f, 8) for f in range(10)] == [0, 1, 2, 3, 4, 5, 6, 7, 0, 1]
+
+
+def test_simulated_backend_catches_a_missing_dependency():
+    """The stand-in is only worth something if it fails when an ordering edge is missing: drop the wait that protects a snapshot slot
+    from being overwritten before its render ran, and some interleaving must trip the assertion."""
+    from pienerf_amd.frames import FramePipeline, SimulatedBackend
+
+    class Broken(FramePipeline):
+        def _advance_simulator(self, upto):
+            self.ip_used = [False] * self.slots      # "forget" that this rank's renders read the slots
+            super()._advance_simulator(upto)
+    hit = 0
+    for seed in range(20):
+        be = SimulatedBackend(1, 0, seed=seed)
+        pipe = Broken(be, lanes=2, depth=2, ahead=2)
+        pipe.slots = 4                                # a deliberately tight ring
+        try:
+            for f in range(40):
+                pipe.step()
+            pipe.drain()
+            be.flush()
+        except AssertionError:
+            hit += 1
+    assert hit > 0

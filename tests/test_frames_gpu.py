@@ -40,18 +40,17 @@ def _worker(rank, world, port, out_dir, dedicated=None):
     from pienerf_amd.frames import frame_owner
     h = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device="cuda:0").capture_frame_parallel(lanes=2, n_trips=8, dedicated_sim=dedicated)
     p = h._pipe
-    assert (p["world"], p["rank"]) == (world, rank) and p["dedicated"] == bool(dedicated)
+    assert (p.world, p.rank) == (world, rank) and p.dedicated == bool(dedicated)
     got = {}
     for f in range(N_FRAMES):
-        out = h.step_frame_parallel()
-        assert (out is not None) == (frame_owner(f, world, 0, bool(dedicated)) == rank)
-        if out is not None:
-            p["done"][len(got) % 2].synchronize()  # the lane's buffers are reused two of this rank's frames later
-            got[f] = out["image"].clone().cpu().numpy()
-    h.drain_pipeline()
+        for idx, res in h.step_frame_parallel():
+            got[idx] = res["image"].copy()
+    for idx, res in h.drain_pipeline():
+        got[idx] = res["image"].copy()
+    assert sorted(got) == [f for f in range(N_FRAMES) if frame_owner(f, world, 0, bool(dedicated)) == rank]
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), **{str(k): v for k, v in got.items()})
     if rank == 0:
-        assert h.substeps_enqueued == N_FRAMES + p["ahead"]
+        assert h.substeps_enqueued == N_FRAMES + p.ahead
     else:
         assert h.substeps_enqueued == 0  # only the owner's simulator ever advances
     dist.barrier()
@@ -87,9 +86,12 @@ def test_frame_parallel_single_rank_equals_pipelined(tmp_path):
     opt, cloud, ckpt = _scene()
     eager = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device="cuda:0")
     fp = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device="cuda:0").capture_frame_parallel(lanes=3, n_trips=8)
+    want = [eager.step()["image"].clone() for _ in range(7)]
+    eager.synchronize()
+    got = []
     for f in range(7):
-        a = eager.step()["image"].clone()
-        out = fp.step_frame_parallel()
-        fp._pipe["done"][f % 3].synchronize()
-        assert (a - out["image"]).abs().max() < 1e-5, f
-    fp.drain_pipeline()
+        got += fp.step_frame_parallel()
+    got += fp.drain_pipeline()
+    assert [i for i, _ in got] == list(range(7))
+    for f in range(7):
+        assert np.array_equal(got[f][1]["image"], want[f][0].cpu().numpy()), f

@@ -59,15 +59,15 @@ def test_full_frame_is_reproducible_and_launch_forms_agree(full):
     eager = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device=DEV)
     pipe = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device=DEV).capture_pipelined(lanes=3, n_trips=8)
     with torch.no_grad():
-        want = [eager.step()["image"].clone() for _ in range(4)]
+        want = [eager.step()["image"].clone() for _ in range(5)]
         eager.synchronize()
-        for f in range(4):
-            out = pipe.step_pipelined()
-            pipe._pipe["done"][f % 3].synchronize()
-            got = out["image"].clone()
-            torch.cuda.current_stream().synchronize()
-            assert torch.equal(got, want[f]), f      # initialisation and every kernel are order-deterministic: bit-identical
-    pipe.drain_pipeline()
+        got = []
+        for f in range(5):
+            got += [(i, r["device"]["image"].clone(), r["image"].copy()) for i, r in pipe.step_pipelined()]
+        got += [(i, r["device"]["image"].clone(), r["image"].copy()) for i, r in pipe.drain_pipeline()]
+    assert [g[0] for g in got] == list(range(5))
+    for f in range(5):  # initialisation and every kernel are order-deterministic: bit-identical, on the device and in the pinned host copy
+        assert torch.equal(got[f][1], want[f]) and np.array_equal(got[f][2], want[f][0].cpu().numpy()), f
     assert (want[0] - want[3]).abs().max() > 1e-4   # gravity moved the chair between the frames
 
 

@@ -178,11 +178,12 @@ def test_harness_fp16_option_pipelined_equals_eager(small_cloud, small_opt, ckpt
     f32 = SimRenderHarness(dict(opt, fp16=False), cloud=small_cloud, ckpt=ckpt, device=DEV)
     want = [eager.step()["image"].clone() for _ in range(5)]
     eager.synchronize()
+    got = []
     for f in range(5):
-        out = pipe.step_pipelined()
-        pipe._pipe["done"][f % 2].synchronize()
-        assert torch.equal(out["image"], want[f]), f
-        torch.cuda.current_stream().synchronize()
-    pipe.drain_pipeline()
+        got += pipe.step_pipelined()
+    got += pipe.drain_pipeline()
+    assert [i for i, _ in got] == list(range(5))
+    for f in range(5):
+        assert np.array_equal(got[f][1]["image"], want[f][0].cpu().numpy()), f
     a = f32.step()["image"]
     assert 1e-4 < (a - want[0]).abs().max() < 2e-2

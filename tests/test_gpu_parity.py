@@ -387,41 +387,55 @@ def test_graph_replay_equals_eager_steps(small_cloud, small_opt, ckpt):
         assert rel_err((graph.sim.dof - graph.sim.dof_rest).cpu().numpy(), (eager.sim.dof - eager.sim.dof_rest).cpu().numpy()) < 1e-7, frame
     st = graph.model.render_status()
     assert st["alive_at_exit"] == 0 and st["err"] == 0 and st["trips"] >= 3
-    # too few trips is detected, not silently accepted
+    # too few captured trips: the frame is finished with further trips (renderer.py:836-891 has no trip limit), bit-identical to the eager frame
     short = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture(n_trips=1)
-    short.step_graph()
-    with pytest.raises(RuntimeError, match="still alive"):
+    fresh = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV)
+    for frame in range(3):
+        a = fresh.step()
+        fresh.synchronize()
         short.step_graph()
+        b = short.finish_graph_frame()
+        assert torch.equal(a["image"], b["image"]) and torch.equal(a["depth_0"], b["depth_0"]), frame
+        assert short.model.last_stats["alive_at_exit"] == 0 and short.model.last_stats["trips"] >= 3
+    assert short.graph_continued == 3
 
 
-@pytest.mark.parametrize("lanes,ahead", [(2, None), (3, 1), (1, 0)])
-def test_pipelined_frames_equal_eager_steps(small_cloud, small_opt, ckpt, lanes, ahead):
-    """Frames in flight (simulator running ahead on its own stream, one render graph per lane, ordered by snapshot events) give
-    the eager sequence of images."""
+@pytest.mark.parametrize("lanes,depth,ahead,trips", [(2, 2, None, 8), (3, 1, 1, 8), (1, 2, 0, 8), (2, 2, None, 2), (1, 1, 0, None)])
+def test_pipelined_frames_equal_eager_steps(small_cloud, small_opt, ckpt, lanes, depth, ahead, trips):
+    """Frames in flight (frames.FramePipeline on the HIP backend: simulator running ahead on its own stream, one render graph per
+    workspace, ordered by snapshot events, results copied to pinned host memory) give the eager sequence of images bit for bit — also
+    when the captured trip count (2) is too small and every frame is finished by a continuation, and with a different camera per frame."""
     from pienerf_amd.harness import SimRenderHarness
     opt = dict(small_opt, W=64, H=64)
     eager = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV)
-    pipe = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture_pipelined(lanes=lanes, n_trips=8, sim_ahead=ahead)
-    n_frames = 7
+    pipe = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture_pipelined(lanes=lanes, depth=depth, n_trips=trips, sim_ahead=ahead)
+    n_frames = 9
+    poses = [scene.orbit_pose(opt["radius"], 7.0 * f, -3.0 * f) for f in range(n_frames)]
     want = []
-    for _ in range(n_frames):
-        want.append(eager.step()["image"].clone())
+    for f in range(n_frames):
+        want.append(eager.to_host(eager.step(pose=poses[f])))
     eager.synchronize()
     got = []
     for f in range(n_frames):
-        out = pipe.step_pipelined()
-        pipe._pipe["done"][f % lanes].synchronize()  # the lane's buffers are reused `lanes` frames later: read them before that
-        got.append(out["image"].clone())
-        torch.cuda.current_stream().synchronize()    # the copy runs on this (other) stream: finish it before the lane is reused
-    pipe.drain_pipeline()
+        for idx, res in pipe.step_pipelined(pose=poses[f]):
+            got.append((idx, {k: res[k].copy() for k in ("image", "depth", "depth_0")}, res["device"]["image"].clone()))
+    for idx, res in pipe.drain_pipeline():
+        got.append((idx, {k: res[k].copy() for k in ("image", "depth", "depth_0")}, res["device"]["image"].clone()))
+    assert [g[0] for g in got] == list(range(n_frames))
     for f in range(n_frames):
-        assert (want[f] - got[f]).abs().max() < 1e-5, f
+        assert np.array_equal(got[f][1]["image"], want[f]["image"]) and np.array_equal(got[f][1]["depth_0"], want[f]["depth_0"]), f
+        assert np.array_equal(got[f][1]["depth"], want[f]["depth"], equal_nan=True), f
+        assert np.array_equal(got[f][2][0].cpu().numpy(), want[f]["image"])          # the device copy is the same frame
+    if trips == 2:
+        assert pipe._pipe_backend.continued == n_frames                                 # every frame needed the continuation
+    else:
+        assert pipe._pipe_backend.continued == 0
     # the simulator ran ahead of the last rendered frame by a known number of substeps
     assert pipe.substeps_enqueued == n_frames + (lanes if ahead is None else ahead)
     for _ in range(pipe.substeps_enqueued - n_frames):
         eager.sim.stepforward()
     assert rel_err((pipe.sim.dof - pipe.sim.dof_rest).cpu().numpy(), (eager.sim.dof - eager.sim.dof_rest).cpu().numpy()) < 1e-7
-    assert (want[0] - want[4]).abs().max() > 1e-3  # the object really moved between frames
+    assert np.abs(want[0]["image"] - want[4]["image"]).max() > 1e-3  # the object (and the camera) really moved between frames
 
 
 def test_force_change_between_overlapped_steps_matches_oracle(small_cloud, small_opt, ckpt):
@@ -473,3 +487,33 @@ def test_force_change_between_overlapped_steps_matches_oracle(small_cloud, small
         ref.stepforward()
         done += 1
     assert rel_err(p.sim.dof.cpu().numpy().reshape(-1, 3) - ref.dof_rest, ref.dof - ref.dof_rest) < 1e-6
+
+
+@pytest.mark.parametrize("fp16", [False, True])
+def test_staged_ray_batches_equal_one_shot_frames(small_cloud, small_opt, ckpt, fp16):
+    """harness.capture_staged / step_staged (BASELINE configs[4]: the frame in ray batches, one captured graph replay per batch, tables built by
+    the first batch and kept by the others): rays are independent, so the frames equal the one-shot eager frames bit for bit — also the
+    last, partial batch — and a trip count that is too small for some batch is reported, not silently accepted."""
+    from pienerf_amd.harness import SimRenderHarness
+    opt = dict(small_opt, W=60, H=60, fp16=fp16, max_iter_num=5)        # 3600 rays = 3 batches of 1024 + one of 528
+    eager = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV)
+    st = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture_staged(batch=1024)
+    poses = [scene.orbit_pose(opt["radius"], 9.0 * f, 2.0 * f) for f in range(5)]
+    want = [eager.to_host(eager.step(pose=p)) for p in poses]
+    eager.synchronize()
+    got = []
+    for p in poses:
+        r = st.step_staged(pose=p)
+        if r is not None:
+            got.append({k: r[k].copy() for k in ("image", "depth", "depth_0")})
+    r = st.finish_staged()
+    got.append({k: r[k].copy() for k in ("image", "depth", "depth_0")})
+    assert len(got) == 5
+    for f in range(5):
+        assert np.array_equal(got[f]["image"], want[f]["image"]) and np.array_equal(got[f]["depth_0"], want[f]["depth_0"]), f
+        assert np.array_equal(got[f]["depth"], want[f]["depth"], equal_nan=True), f
+    assert rel_err((st.sim.dof - st.sim.dof_rest).cpu().numpy(), (eager.sim.dof - eager.sim.dof_rest).cpu().numpy()) < 1e-7
+    short = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture_staged(batch=1024, n_trips=2)
+    short.step_staged()
+    with pytest.raises(RuntimeError, match="still alive"):
+        short.finish_staged()

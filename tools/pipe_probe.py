@@ -41,7 +41,7 @@ for L in args.lanes:
     for _ in range(20):
         h.sim.stepforward()
     h.capture_pipelined(lanes=L, n_trips=args.trips, sim_priority=args.sim_priority, sim_cus=args.sim_cus, _probe_no_substep=args.no_substep)
-    p = h._pipe
+    be = h._pipe_backend
     for _ in range(3 * L):
         h.step_pipelined()
     h.drain_pipeline()
@@ -49,12 +49,12 @@ for L in args.lanes:
     h.drain_pipeline()
 
     def sim_only(i):
-        with torch.cuda.stream(p["sim_stream"]):
-            p["sim_graph"].replay()
+        with torch.cuda.stream(be._streams["sim"]):
+            be.sim_graph.replay()
 
     def ren_only(i):
-        with torch.cuda.stream(p["stream"][i % L]):
-            p["ren_graph"][i % L].replay()
+        with torch.cuda.stream(be._streams[f"lane{i % L}"]):
+            be.graph[(i % L) * be.depth].replay()
     s = timed(sim_only, args.steps)
     r = timed(ren_only, args.steps)
     print(f"lanes={L}: full {full:.3f} ms/step ({1e3 / full:.0f}/s)   sim graphs alone {s:.3f} ms   render graphs alone ({L} streams) {r:.3f} ms", flush=True)
