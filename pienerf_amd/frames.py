@@ -64,12 +64,13 @@ class FramePipeline:
         result(ws) -> object      [host] what step() hands back for a retired frame
     """
 
-    def __init__(self, backend, world=1, rank=0, lanes=2, depth=2, ahead=None, sim_owner=0, dedicated_sim=None, copy_out=True):
+    def __init__(self, backend, world=1, rank=0, lanes=2, depth=2, ahead=None, sim_owner=0, dedicated_sim=None, copy_out=True, on_retire=None):
         self.b, self.world, self.rank, self.lanes, self.depth, self.owner = backend, int(world), int(rank), int(lanes), int(depth), int(sim_owner)
         self.dedicated = dedicated_sim_default(self.world) if dedicated_sim is None else bool(dedicated_sim and self.world > 1)
         self.ahead = self.world * self.lanes * self.depth if ahead is None else int(ahead)
         self.slots = self.ahead + self.world * self.lanes * self.depth + 1   # snapshot ring: reuse is guarded by events, the size only avoids stalls
         self.copy_out = copy_out
+        self.on_retire = on_retire   # called as on_retire(frame, result) the moment a frame is complete, BEFORE its workspace is reused
         b = backend
         self.s_sim, self.s_comm, self.s_copy = b.stream("sim"), b.stream("comm"), b.stream("copy")
         self.s_lane = [b.stream(f"lane{i}") for i in range(self.lanes)]
@@ -129,7 +130,10 @@ class FramePipeline:
         if not b.complete(ws):          # rays were still alive after the captured trips: keep going like the reference's loop
             b.finish(ws)                # [host] blocking continuation on the workspace's lane + copy-out again
         self.pending[ws] = None
-        return f, b.result(ws)
+        res = b.result(ws)
+        if self.on_retire is not None:
+            self.on_retire(f, res)
+        return f, res
 
     def step(self, pose=None):
         """Enqueues global frame `self.frame`.  Returns the list of (frame, result) this call retired on this rank (a frame comes back

@@ -199,7 +199,7 @@ class SimRenderHarness:
 
     @torch.no_grad()
     def capture_pipelined(self, lanes=2, n_trips=8, W=None, H=None, sim_ahead=None, depth=2, sim_priority=0, sim_cus=0, copy_out=True, group=None,
-                          frame_parallel=False, sim_owner=0, dedicated_sim=None, _probe_no_substep=False):
+                          frame_parallel=False, sim_owner=0, dedicated_sim=None, on_retire=None, _probe_no_substep=False):
         """Throughput mode (pienerf_amd/frames.py: FramePipeline): `lanes` render streams with `depth` workspaces each, the simulator running
         `sim_ahead` frames ahead on dof snapshots, every frame's image / depth / depth_0 copied to pinned host memory on a copy stream
         (the reference's device->host boundary, trainer.py:589-592; copy_out=False leaves the results on the device).  Everything a frame
@@ -210,7 +210,10 @@ class SimRenderHarness:
 
         ``step_pipelined(pose=None)`` enqueues the next frame (with its own camera pose, trainer.py:541) and returns the frames it retired:
         [(frame index, {'image','depth','depth_0': numpy views of the pinned buffers, 'device': the device tensors})]; a frame comes back
-        lanes*depth steps after it went in, ``drain_pipeline()`` returns the rest.  Every frame is rendered from the state before its own
+        lanes*depth steps after it went in, ``drain_pipeline()`` returns the rest.  The numpy arrays stay valid for another lanes*depth steps
+        (two pinned sets per workspace alternate); the device tensors are the graph's static outputs and are overwritten by the workspace's
+        next frame, i.e. any time after this call returns: a consumer of the device copy hooks in with on_retire(frame, result), which runs
+        when the frame is complete and before its workspace is handed to the next frame.  Every frame is rendered from the state before its own
         substep (trainer.py:300-318); ``self.sim.dof`` is `sim_ahead + 1` substeps in front of the last enqueued frame, and a force set with
         update_force() acts from the next substep that is enqueued (it is ordered on the simulator's stream)."""
         import torch.distributed as dist
@@ -227,7 +230,7 @@ class SimRenderHarness:
         be = _HipBackend(self, lanes, depth, int(n_trips), W, H, sim_priority, sim_cus, copy_out, group if on else None,
                          (dist.get_global_rank(group, sim_owner) if (on and group is not None) else sim_owner), _probe_no_substep)
         self._pipe = FramePipeline(be, world=world, rank=rank, lanes=lanes, depth=depth, ahead=(lanes if sim_ahead is None and world == 1 else sim_ahead),
-                                   sim_owner=sim_owner, dedicated_sim=dedicated_sim, copy_out=copy_out)
+                                   sim_owner=sim_owner, dedicated_sim=dedicated_sim, copy_out=copy_out, on_retire=on_retire)
         self._pipe_backend = be
         return self
 
@@ -470,8 +473,11 @@ class _HipBackend:
             # every tensor the graphs touch stays referenced: a tensor freed after capture goes back to the graph's memory pool
             self.rays.append(rays)
             self.out.append(out)
-            self.host.append({"image": torch.empty((H, W, 3), dtype=torch.float32).pin_memory(), "depth": torch.empty((H, W), dtype=torch.float32).pin_memory(),
-                              "depth_0": torch.empty((H, W), dtype=torch.float32).pin_memory()} if copy_out else None)
+            # two pinned sets per workspace, used alternately: the arrays handed out when a frame is retired stay valid until the workspace has
+            # been through another whole frame (the next frame's D2H goes into the other set)
+            self.host.append([{"image": torch.empty((H, W, 3), dtype=torch.float32).pin_memory(), "depth": torch.empty((H, W), dtype=torch.float32).pin_memory(),
+                               "depth_0": torch.empty((H, W), dtype=torch.float32).pin_memory()} for _ in range(2)] if copy_out else None)
+        self.host_gen = [0] * n_ws
         torch.cuda.synchronize(dev)
         sim.dof.copy_(keep[0])      # warm-up advanced the simulator; capture itself executes nothing
         sim.dof_vel.copy_(keep[1])
@@ -511,8 +517,10 @@ class _HipBackend:
             self.h.sim.get_IP_info(dof=self._snap(slot), out=self.ip[ws])
             self.graph[ws].replay()
 
-    def copy_out(self, s, ws):
-        o, hbuf = self.out[ws], self.host[ws]
+    def copy_out(self, s, ws, same_buffer=False):
+        if not same_buffer:
+            self.host_gen[ws] ^= 1
+        o, hbuf = self.out[ws], self.host[ws][self.host_gen[ws]]
         with torch.cuda.stream(s.s):
             hbuf["image"].copy_(o["image"].view(self.H, self.W, 3), non_blocking=True)
             hbuf["depth"].copy_(o["depth"].view(self.H, self.W), non_blocking=True)
@@ -531,12 +539,12 @@ class _HipBackend:
             with h._amp():
                 m.render_continue(ws, self.rays[ws]["rays_o"], self.rays[ws]["rays_d"], self.out[ws], bg_color=None, **self.kw)
             if self.host[ws] is not None:
-                self.copy_out(_HipStream(s), ws)
+                self.copy_out(_HipStream(s), ws, same_buffer=True)
         s.synchronize()
         self.continued += 1
 
     def result(self, ws):
-        o, hbuf = self.out[ws], self.host[ws]
+        o, hbuf = self.out[ws], (self.host[ws][self.host_gen[ws]] if self.host[ws] is not None else None)
         dev = {"image": o["image"].view(-1, self.H, self.W, 3), "depth": o["depth"].view(-1, self.H, self.W), "depth_0": o["depth_0"].view(-1, self.H, self.W)}
         if hbuf is None:
             return {"device": dev}

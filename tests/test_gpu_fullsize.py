@@ -63,11 +63,11 @@ def test_full_frame_is_reproducible_and_launch_forms_agree(full):
         eager.synchronize()
         got = []
         for f in range(5):
-            got += [(i, r["device"]["image"].clone(), r["image"].copy()) for i, r in pipe.step_pipelined()]
-        got += [(i, r["device"]["image"].clone(), r["image"].copy()) for i, r in pipe.drain_pipeline()]
+            got += [(i, r["image"].copy()) for i, r in pipe.step_pipelined()]
+        got += [(i, r["image"].copy()) for i, r in pipe.drain_pipeline()]
     assert [g[0] for g in got] == list(range(5))
-    for f in range(5):  # initialisation and every kernel are order-deterministic: bit-identical, on the device and in the pinned host copy
-        assert torch.equal(got[f][1], want[f]) and np.array_equal(got[f][2], want[f][0].cpu().numpy()), f
+    for f in range(5):  # initialisation and every kernel are order-deterministic: bit-identical (compared through the pinned host copy)
+        assert np.array_equal(got[f][1], want[f][0].cpu().numpy()), f
     assert (want[0] - want[3]).abs().max() > 1e-4   # gravity moved the chair between the frames
 
 

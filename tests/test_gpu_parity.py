@@ -408,7 +408,12 @@ def test_pipelined_frames_equal_eager_steps(small_cloud, small_opt, ckpt, lanes,
     from pienerf_amd.harness import SimRenderHarness
     opt = dict(small_opt, W=64, H=64)
     eager = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV)
-    pipe = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture_pipelined(lanes=lanes, depth=depth, n_trips=trips, sim_ahead=ahead)
+    dev_copies = {}
+
+    def keep_device_copy(frame, res):   # runs when the frame is complete, before its workspace is reused
+        dev_copies[frame] = res["device"]["image"].clone()
+    pipe = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture_pipelined(lanes=lanes, depth=depth, n_trips=trips, sim_ahead=ahead,
+                                                                                             on_retire=keep_device_copy)
     n_frames = 9
     poses = [scene.orbit_pose(opt["radius"], 7.0 * f, -3.0 * f) for f in range(n_frames)]
     want = []
@@ -418,14 +423,14 @@ def test_pipelined_frames_equal_eager_steps(small_cloud, small_opt, ckpt, lanes,
     got = []
     for f in range(n_frames):
         for idx, res in pipe.step_pipelined(pose=poses[f]):
-            got.append((idx, {k: res[k].copy() for k in ("image", "depth", "depth_0")}, res["device"]["image"].clone()))
+            got.append((idx, {k: res[k].copy() for k in ("image", "depth", "depth_0")}))
     for idx, res in pipe.drain_pipeline():
-        got.append((idx, {k: res[k].copy() for k in ("image", "depth", "depth_0")}, res["device"]["image"].clone()))
+        got.append((idx, {k: res[k].copy() for k in ("image", "depth", "depth_0")}))
     assert [g[0] for g in got] == list(range(n_frames))
     for f in range(n_frames):
         assert np.array_equal(got[f][1]["image"], want[f]["image"]) and np.array_equal(got[f][1]["depth_0"], want[f]["depth_0"]), f
         assert np.array_equal(got[f][1]["depth"], want[f]["depth"], equal_nan=True), f
-        assert np.array_equal(got[f][2][0].cpu().numpy(), want[f]["image"])          # the device copy is the same frame
+        assert np.array_equal(dev_copies[f][0].cpu().numpy(), want[f]["image"])       # the device copy is the same frame
     if trips == 2:
         assert pipe._pipe_backend.continued == n_frames                                 # every frame needed the continuation
     else:
