@@ -76,7 +76,7 @@ class NeRFNetwork(NeRFRenderer):
     def _autocast_half():
         """True when the caller runs under torch.cuda.amp.autocast with fp16 (trainer.py:561, Trainer(fp16=True)): the reference then casts
         the hash table to half (gridencoder/grid.py:43-44) and every nn.Linear computes in half."""
-        return torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.float16
+        return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16
 
     def _wants_grad(self, *inputs):
         """Differentiable path only in train() mode with autograd recording (Trainer.train_one_epoch calls model.train(), evaluate /

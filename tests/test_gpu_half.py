@@ -74,12 +74,13 @@ def test_nerf_forward_half_vs_oracle_and_ops(ckpt):
     assert c.dtype == torch.float16 and s.dtype == torch.float32 and c2.dtype == torch.float16
     s, c, s2, c2 = s.cpu().numpy(), c.float().cpu().numpy(), s2.float().cpu().numpy(), c2.float().cpu().numpy()
     assert np.all(np.isfinite(s)) and np.all(np.isfinite(c))
-    eq_s, eq_c = np.mean(s == s_ref), np.mean(c == c_ref)
-    print(f"fused fp16 vs oracle: sigma bitwise equal {eq_s:.4f}, max rel {np.abs(s / s_ref - 1).max():.2e}; rgb bitwise equal {eq_c:.4f}, "
-          f"max abs {np.abs(c - c_ref).max():.2e}; torch half ops vs oracle: sigma equal {np.mean(s2 == s_ref):.4f}, rgb equal {np.mean(c2 == c_ref):.4f}")
+    # sigma = expf(half logit) in float: the device's expf and glibc's differ in the last float bit, so "same logit" is |rel| < 1e-6
+    eq_s, eq_c = np.mean(np.abs(s / s_ref - 1) < 1e-6), np.mean(c == c_ref)
+    print(f"fused fp16 vs oracle: sigma same-logit {eq_s:.4f}, max rel {np.abs(s / s_ref - 1).max():.2e}; rgb bitwise equal {eq_c:.4f}, "
+          f"max abs {np.abs(c - c_ref).max():.2e}; torch half ops vs oracle: sigma equal {np.mean(np.abs(s2 / s_ref - 1) < 1e-6):.4f}, rgb equal {np.mean(c2 == c_ref):.4f}")
     assert eq_s > 0.97 and np.abs(s / s_ref - 1).max() < 1.2e-2        # <= 3 ulps of a half logit in [4, 8)
     assert eq_c > 0.97 and np.abs(c - c_ref).max() < 3e-3              # <= 3 half ulps at 0.5 .. 1
-    assert np.mean(s2 == s_ref) > 0.95 and np.abs(s2 / s_ref - 1).max() < 1.2e-2 and np.abs(c2 - c_ref).max() < 3e-3
+    assert np.mean(np.abs(s2 / s_ref - 1) < 1e-6) > 0.95 and np.abs(s2 / s_ref - 1).max() < 1.2e-2 and np.abs(c2 - c_ref).max() < 3e-3
     # density(): same sigma, and the 15 geometry features are half values
     assert np.array_equal(dn["sigma"].cpu().numpy(), s) and dn["geo_feat"].dtype == torch.float16
     # the flag is not a no-op: the fp32 path gives different (more accurate) numbers
