@@ -20,6 +20,9 @@ struct PnFrameDev {
     int resolution[4];  // [3] = n_grid
     int err;
     int unfinished;     // rays left alive by fixed-trip renders since the last reset, summed (staged batches are checked once per frame)
+    int trips_run;      // loop trips the last render (or continuation) on this workspace has enqueued: written by its epilogue, so that it is
+                        // also right after a HIP-graph REPLAY, which the host-side bookkeeping never sees
+    int pad[3];
 };
 
 // ------------------------------------------------------------------------------------------------ near/far
@@ -1006,9 +1009,12 @@ struct pn_frame {
 __global__ void __launch_bounds__(256) k_frame_finish(uint32_t N, float bg, const float* __restrict__ nears, const float* __restrict__ fars,
                                                       const float* __restrict__ weights_sum, const float* __restrict__ depth_0,
                                                       const float* __restrict__ acc, float* __restrict__ image, float* __restrict__ depth,
-                                                      const PnTrip* __restrict__ final_trip, PnFrameDev* dev) {
+                                                      const PnTrip* __restrict__ final_trip, PnFrameDev* dev, int trips_run) {
     const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-    if (i == 0 && final_trip->n_alive > 0) atomicAdd(&dev->unfinished, final_trip->n_alive);
+    if (i == 0) {
+        dev->trips_run = trips_run;
+        if (final_trip->n_alive > 0) atomicAdd(&dev->unfinished, final_trip->n_alive);
+    }
     if (i >= N) return;
     const float k = (1 - weights_sum[i]) * bg;
     image[i * 3] = acc[i * 3] + k;
@@ -1311,7 +1317,7 @@ extern "C" void pn_frame_destroy(pn_frame* f) {
 
 static void frame_stats(pn_frame* f, int64_t* stats_host) {
     int64_t trips = 0, samples = 0;
-    const int t = f->last_trips;
+    const int t = f->dev_pinned->trips_run;  // as the render itself recorded it (right after graph replays too)
     for (int k = 0; k < t; k++) {
         if (f->trips_pinned[k].n_alive > 0) trips++;
         samples += f->trips_pinned[k].n_samples;
@@ -1337,7 +1343,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     const bool resume = mode != 0;
     PN_REQUIRE(f && net && o && rays_o && rays_d && bitfield && image && depth && depth_0 && weights_sum);
     PN_REQUIRE(is_static || resume || (p_def && p_ori && F_IP && dF_IP && n_vtx > 0 && (uint32_t)n_vtx <= f->max_vtx));
-    PN_REQUIRE(!resume || (f->last_trips > 0 && N == f->last_N));
+    PN_REQUIRE(!resume || N == f->last_N);
     PN_REQUIRE(N > 0 && N <= f->max_rays);
     PN_REQUIRE(o->num_seek_IP >= 1 && o->num_seek_IP <= 3 && o->cascade >= 1 && o->cascade <= 8 && o->max_steps <= PN_MAX_TRIPS - PN_TRIP_BATCH);
     PN_REQUIRE(async_trips >= 0 && async_trips <= PN_MAX_TRIPS);
@@ -1412,7 +1418,10 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                                             o->hash_grid_size, res, o->num_seek_IP, o->IP_dx, o->cut, f->cut_bounds, f->rays_t, rays_o, rays_d,
                                             o->bound, o->dt_gamma, o->max_steps, o->cascade, o->grid_size, bitfield, f->fars, err);
     mp.stats = (f->march_counters_on & 1) ? f->march_counters : nullptr;
-    int t = resume ? f->last_trips : 0;  // a continuation picks up at the record the last compaction wrote
+    // a continuation picks up at the record the last compaction wrote; the trip count comes from the device (through the pinned copy the
+    // previous render made at its end), not from host bookkeeping: the previous render may have been a graph replay
+    int t = resume ? f->dev_pinned->trips_run : 0;
+    PN_REQUIRE(t >= 0 && t <= PN_MAX_TRIPS);
     bool done = false;
     while (!done && t < PN_MAX_TRIPS) {
         const int batch = async_trips > 0 ? async_trips : PN_TRIP_BATCH;
@@ -1451,14 +1460,14 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
         PN_HIP_CHECK(hipStreamSynchronize(st));
         done = f->trips_pinned[t].n_alive <= 0;
     }
-    k_frame_finish<<<nblk, 256, 0, st>>>(N, o->bg_color, f->nears, f->fars, weights_sum, depth_0, f->acc_image, image, depth, f->trips + t, f->dev);
+    k_frame_finish<<<nblk, 256, 0, st>>>(N, o->bg_color, f->nears, f->fars, weights_sum, depth_0, f->acc_image, image, depth, f->trips + t, f->dev, t);
     PN_LAUNCH_CHECK();
     f->last_trips = t;
     f->last_N = N;
-    if (async_trips > 0 || stats_host) {
-        PN_HIP_CHECK(hipMemcpyAsync(f->trips_pinned, f->trips, sizeof(PnTrip) * (t + 1), hipMemcpyDeviceToHost, st));
-        PN_HIP_CHECK(hipMemcpyAsync(f->dev_pinned, f->dev, sizeof(PnFrameDev), hipMemcpyDeviceToHost, st));
-    }
+    // the trip records and the frame record always travel to pinned host memory (two small async copies): pn_render_status /
+    // pn_render_continue read them once the caller knows the render has completed
+    PN_HIP_CHECK(hipMemcpyAsync(f->trips_pinned, f->trips, sizeof(PnTrip) * (t + 1), hipMemcpyDeviceToHost, st));
+    PN_HIP_CHECK(hipMemcpyAsync(f->dev_pinned, f->dev, sizeof(PnFrameDev), hipMemcpyDeviceToHost, st));
     if (async_trips == 0 && stats_host) {
         PN_HIP_CHECK(hipStreamSynchronize(st));
         frame_stats(f, stats_host);

@@ -48,6 +48,9 @@ class NeRFNetwork(NeRFRenderer):
         half=True additionally makes sure the fp16 tables exist (pn_net_enable_half)."""
         sig = self._signature()
         if self._net is None or sig != self._net_sig:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("the network's parameters changed and its packed weights cannot be refreshed while the stream is being captured into "
+                                   "a HIP graph (the packing reads them on the host); evaluate the network once before capture")
             if (self.num_layers, self.hidden_dim, self.geo_feat_dim, self.num_layers_color, self.hidden_dim_color) != (2, 64, 15, 3, 64):
                 raise RuntimeError("fused network kernel implements the reference architecture only (32->64->16 | 31->64->64->3)")
             emb = self.encoder.embeddings

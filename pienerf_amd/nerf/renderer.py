@@ -242,7 +242,7 @@ class NeRFRenderer(nn.Module):
         o.bound, o.min_near, o.dt_gamma, o.max_steps, o.T_thresh = float(self.bound), float(self.min_near), float(dt_gamma), int(max_steps), float(T_thresh)
         o.cascade, o.grid_size, o.density_scale, o.bg_color = int(self.cascade), int(self.grid_size), float(self.density_scale), float(bg_color)
         o.fp16 = int(self._autocast_half())
-        aabb = (C.c_float * 6)(*[float(v) for v in self.aabb_infer.tolist()])
+        aabb = (C.c_float * 6)(*self._aabb_infer_host())
         image, depth, depth_0, ws = (torch.empty(N, 3, dtype=torch.float32, device=device), torch.empty(N, dtype=torch.float32, device=device),
                                      torch.empty(N, dtype=torch.float32, device=device), torch.empty(N, dtype=torch.float32, device=device))
         frame = self._frame_handle(N, 1, 1.0, int(kwargs.get("frame_slot") or 0), cells=1)
@@ -253,6 +253,15 @@ class NeRFRenderer(nn.Module):
         if stats is not None:
             self._set_stats(stats)
         return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "weights_sum": ws}
+
+    def _aabb_infer_host(self):
+        """aabb_infer as six Python floats, read back from the device only when the buffer changed (never inside a stream capture)."""
+        key = (self.aabb_infer.data_ptr(), self.aabb_infer._version)
+        if getattr(self, "_aabb_cache", (None, None))[0] != key:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("aabb_infer changed: render one frame outside stream capture first")
+            self._aabb_cache = (key, [float(v) for v in self.aabb_infer.tolist()])
+        return self._aabb_cache[1]
 
     def run_cuda_ops(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, force_all_rays=False, max_steps=1024, T_thresh=1e-2, **kwargs):
         """run_cuda op by op on the drop-in ops (the training branch; the eval branch with perturb / tensor backgrounds; parity tests)."""
