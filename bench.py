@@ -1,16 +1,24 @@
 #!/usr/bin/env python
-"""sim+render steps/s at 800x800 on the synthetic chair (BASELINE.json configs[1]); one JSON line on rank 0.
+"""sim+render steps/s of the PIE-NeRF simulate-and-render step on MI355X; one JSON line on rank 0.
 
-    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N --steps K --warmup W] [--config chair|stress|trex]     (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A step = one GUI-frame equivalent (nerf/gui.py:588-603 / nerf/trainer.py:300-318 of the reference):
-get_rays -> get_IP_info -> stepforward(iters=10) -> render_deformed at 800x800, inputs resident in HBM, outputs left in HBM.
-N = 1 replays captured HIP graphs: `--lanes` renders in flight on their own streams, the simulator running ahead on dof snapshots
-(harness.capture_pipelined; --single-graph: one graph per step, one frame at a time; --eager: kernel by kernel).
-N > 1 is frame-parallel (BASELINE.json configs[3]): rank 0 owns the simulator and broadcasts every dof snapshot
-(<= 82 KB per frame) over RCCL; every rank holds the checkpoint and renders frames f = rank (mod N) on its own lanes
-(harness.capture_frame_parallel).  K steps per rank = K*N frames in total (weak scaling); value = frames all ranks completed /
-max-over-ranks time.
+A step = one GUI-frame equivalent of the reference (nerf/gui.py:588-603 / nerf/trainer.py:300-318, 531-602):
+get_rays(pose) -> get_IP_info -> stepforward(sim_iters) -> render_deformed -> image / depth / depth_0 copied to host memory.
+Inputs are resident in HBM when the timed region starts; `value` INCLUDES the device-to-host copy of the three outputs (12.8 MB per 800x800
+frame into pinned memory on a copy stream: it is part of the reference's step); the device-resident rate is reported beside it.
+
+  --config chair  (default)  BASELINE.json configs[1]: synthetic chair 800x800, sim_dx 0.05, 10 local/global iterations, num_seek_IP 3, max_iter_num 1, fp32.
+                             N = 1: frames.FramePipeline — `--lanes` render streams x `--depth` workspaces, simulator running ahead on dof snapshots,
+                             everything replayed from HIP graphs.  N > 1 (configs[3]): the same pipeline frame-parallel over the ranks, rank 0 simulates
+                             and broadcasts each dof snapshot (<= 82 KB) over RCCL, frames round-robin; K steps per rank = K*N frames (weak scaling).
+  --config stress            configs[4]: sub_res 180 point cloud, max_iter_num 5, num_seek_IP 3, the 800x800 frame in ray batches of 4096, network under
+                             autocast (fp16 hash tables + fp16 MFMA layers).  harness.capture_staged.
+  --config trex              configs[2]: 1008x756, bound 2 (two cascades), --cut, dt_gamma 1/128, max_steps 300, T_thresh 5e-2, num_seek_IP 1, a static
+                             background in 2 % of the density-grid blocks.
+After the timed region rank 0 measures (N = 1 only, each a fraction of a second): the device-resident rate, the one-frame-at-a-time latency,
+the dominant kernel's launch durations (HIP events on the launch stream: blocking render AND inside the pipelined graphs), the stand-alone hash-grid
+and network kernels, and the CPU oracle on the host cores.
 """
 import argparse
 import json
@@ -27,12 +35,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic bytes / flops per unit
-HASH_BYTES_PER_SAMPLE = 1164   # 16 levels x 8 corners x 8 B gathered + 12 B position in + 128 B features out
-FUSED_BYTES_PER_SAMPLE = 1068  # fused network kernel: 1024 B gathered + 4 B slot id + 24 B xyz/dir in + 16 B sigma/rgb out
+HASH_BYTES_PER_SAMPLE = 1164        # 16 levels x 8 corners x 8 B gathered + 12 B position in + 128 B features out
+FUSED_BYTES_PER_SAMPLE = 1068       # fused network kernel, fp32 tables: 1024 B gathered + 4 B slot id + 24 B xyz/dir in + 16 B sigma/rgb out
+FUSED_BYTES_PER_SAMPLE_FP16 = 556   # fp16 tables: 512 B gathered + 44 B
 MLP_FLOP_PER_SAMPLE = 18688
 MARCH_BYTES = dict(iteration=8, candidate=16, warp=64, sample=32 + 4, ray_trip=40)  # cell range / list entry / record head / outputs / ray state
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-F32_MFMA_PEAK_TF = 157.3       # dense fp32-input MFMA peak
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8 TB/s
+F32_MFMA_PEAK_TF = 157.3            # dense fp32-input MFMA peak
+F16_MFMA_PEAK_TF = 2500.0           # dense fp16 / bf16 MFMA peak
 
 
 def cuda_time_ms(fn, iters=20, warmup=3):
@@ -49,8 +59,36 @@ def cuda_time_ms(fn, iters=20, warmup=3):
     return e0.elapsed_time(e1) / iters
 
 
-def cpu_baseline(opt, cloud, ckpt, budget_s=20.0):
-    """The CPU oracle ("port") on this box's host cores: sim steps + full 800x800 renders for ~budget_s seconds."""
+def make_config(name, sigma_gain=1.0):
+    """(opt, cloud, ckpt, pose, force, description) of a BASELINE.json configuration on the synthetic assets."""
+    from pienerf_amd import scene
+    if name == "chair":
+        opt = scene.default_opt()  # README.md:123
+        cloud = scene.make_chair_points(hgs=opt["hash_grid_size"])
+        ckpt = scene.make_checkpoint(bound=opt["bound"], seed=0, sigma_target=60.0 * sigma_gain)
+        return opt, cloud, ckpt, scene.orbit_pose(opt["radius"]), None, ("configs[1]: synthetic chair 800x800, sim_dx=0.05, sim_iters=10, num_seek_IP=3, max_iter_num=1, "
+                                                                         "fp32, 1 sim+render step per frame incl. D2H of image/depth/depth_0")
+    if name == "stress":
+        opt = scene.stress_opt()
+        cloud = scene.make_chair_points(sub_res=opt["sub_res"], hgs=opt["hash_grid_size"])
+        ckpt = scene.make_checkpoint(bound=opt["bound"], seed=0, sigma_target=60.0 * sigma_gain)
+        return opt, cloud, ckpt, scene.orbit_pose(opt["radius"]), np.array([400.0, -150.0, 250.0]), (
+            "configs[4] stress: sub_res=180 point cloud (268 k points), 800x800 frame in ray batches of 4096, max_iter_num=5, num_seek_IP=3, fp16 hash "
+            "tables + fp16 MFMA MLP (autocast), sim_dx=0.05, sim_iters=10, incl. D2H")
+    if name == "trex":
+        opt = scene.trex_opt(radius=4.5)  # README.md:134
+        cloud = scene.make_chair_points(hgs=opt["hash_grid_size"], bound=opt["bound"])
+        ckpt = scene.make_checkpoint(bound=2.0, seed=3, sigma_target=60.0 * sigma_gain)
+        blobs = np.repeat(np.random.default_rng(5).random(len(ckpt["density_bitfield"]) // 64) < 0.02, 64)  # static background: 2 % of the 8^3-voxel blocks
+        ckpt["density_bitfield"] = ckpt["density_bitfield"] | np.where(blobs, 0xFF, 0).astype(np.uint8)
+        return opt, cloud, ckpt, scene.orbit_pose(4.5, 25.0, -10.0), np.array([250.0, 120.0, -180.0]), (
+            "configs[2] trex option set: 1008x756, bound 2 (2 cascades), --cut, dt_gamma 1/128, max_steps 300, T_thresh 5e-2, num_seek_IP 1, static "
+            "background in 2 % of the density blocks, synthetic assets, incl. D2H")
+    raise ValueError(name)
+
+
+def cpu_baseline(opt, cloud, ckpt, pose, force, budget_s=20.0):
+    """The CPU oracle ("port") on this box's host cores: sim steps + full-size renders for ~budget_s seconds."""
     import oracle
     from oracle.sim_init import OracleSimulator
     from pienerf_amd import scene
@@ -58,23 +96,28 @@ def cpu_baseline(opt, cloud, ckpt, budget_s=20.0):
     ref = OracleSimulator(dt=opt["sim_dt"], iters=opt["sim_iters"], bbox=torch.tensor([2.0 * opt["bound"]] * 3), dx=opt["sim_dx"],
                           stiff=opt["sim_stiff"], base=torch.tensor([-opt["bound"]] * 3))
     ref.InitializeFromArrays(cloud["pos"], cloud["mass"], cloud["mu"], cloud["lam"], cloud["pin"])
+    if force is not None:
+        ref.update_force(ref.n_IP // 2, force)
     init_s = time.time() - t0
     p_ori, _, _ = ref.get_IP_info()
-    pose, intr = scene.orbit_pose(opt["radius"]), scene.orbit_intrinsics(opt["W"], opt["H"], opt["fovy"])
+    intr = scene.orbit_intrinsics(opt["W"], opt["H"], opt["fovy"])
     times = []
     t_all = time.time()
-    while True:
-        t = time.time()
-        o, d = oracle.get_rays(pose, intr, opt["H"], opt["W"])
-        p_def, F, dF = ref.get_IP_info()
-        ref.stepforward()
-        oracle.render_deformed(o, d, dict(p_def=p_def, p_ori=p_ori, F=F, dF=dF, IP_dx=ref.dx * 1.05), ckpt, opt)
-        times.append(time.time() - t)
-        if len(times) >= 3 and (time.time() - t_all > budget_s or len(times) >= 12):
-            break
+    import contextlib
+    ctx = oracle.half_precision() if opt.get("fp16") else contextlib.nullcontext()
+    with ctx:
+        while True:
+            t = time.time()
+            o, d = oracle.get_rays(pose, intr, opt["H"], opt["W"])
+            p_def, F, dF = ref.get_IP_info()
+            ref.stepforward()
+            oracle.render_deformed(o, d, dict(p_def=p_def, p_ori=p_ori, F=F, dF=dF, IP_dx=ref.dx * 1.05), ckpt, opt)
+            times.append(time.time() - t)
+            if len(times) >= 3 and (time.time() - t_all > budget_s or len(times) >= 12):
+                break
     steady = times[1:]
     return {"value": round(1.0 / float(np.median(steady)), 4), "unit": "steps/s", "cores": oracle.num_threads(), "kind": "port",
-            "sample": f"{len(steady)} full 800x800 sim+render steps of the C++/OpenMP oracle (median; first step discarded; init {init_s:.1f}s untimed)"}
+            "sample": f"{len(steady)} full {opt['W']}x{opt['H']} sim+render steps of the C++/OpenMP oracle (median; first step discarded; init {init_s:.1f}s untimed)"}
 
 
 def collect_samples(m, rays_o, rays_d, kw):
@@ -97,12 +140,37 @@ def collect_samples(m, rays_o, rays_d, kw):
     return x[keep].contiguous(), d[keep].contiguous()
 
 
+def load_traffic(real_trips):
+    """HBM-side bytes per launch from the committed PMC passes — only when they were taken on THIS code (profiles/pmc_traffic.json is stamped with
+    pienerf_amd.build.source_hash by tools/pmc_traffic.py); a stale file gives null, never a number that belongs to other kernels."""
+    from pienerf_amd.build import source_hash
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return {}, "profiles/pmc_traffic.json not present"
+    with open(path) as f:
+        pmc = json.load(f)
+    if pmc.get("lib_hash") != source_hash():
+        return {}, f"profiles/pmc_traffic.json was measured on other kernel sources (stamp {str(pmc.get('lib_hash'))[:10]}, tree {source_hash()[:10]}): not reported"
+    out = {}
+    for k, v in pmc["kernels"].items():
+        out[k.split("<")[0]] = out.get(k.split("<")[0], 0) + v["fetch_bytes_per_frame"] + v["write_bytes_per_frame"]
+    per_launch = {k: int(v / max(real_trips, 1)) for k, v in out.items()}
+    if all(k in out for k in ("k_march", "k_march_tail", "k_march_skip")):
+        per_launch["march_group"] = int((out["k_march"] + out["k_march_tail"] + out["k_march_skip"]) / max(real_trips, 1))
+    return per_launch, "FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 PMC passes on the same kernels (tools/pmc_traffic.py); per real trip"
+
+
 def kernel_report(h, opt, dev):
     """Per-kernel figures on one real frame (HIP events on the launch stream) + the march kernel's work counters."""
     from pienerf_amd._lib import check, lib, ptr, stream_ptr
     m = h.model
+    fp16 = bool(opt.get("fp16"))
+    for _ in range(20):   # a deformed state like the ones the timed region rendered, not the rest pose
+        h.step()
+    h.synchronize()
     out = h.step(simulate=False, collect_stats=True)   # also makes sure the frame workspace exists
     st = dict(m.last_stats)
+    st["hit_rays"] = int((~torch.isnan(out["depth"])).sum())  # rays that meet the bounding box of the deformed IPs (miss: near = far = FLT_MAX -> NaN depth)
     # (1) work counters of the march kernel (separate pass: the counters add atomics)
     m.march_counters(1)
     h.step(simulate=False)
@@ -124,7 +192,8 @@ def kernel_report(h, opt, dev):
                    + cnt["samples"] * MARCH_BYTES["sample"] + opt["W"] * opt["H"] * MARCH_BYTES["ray_trip"])  # trip 0 touches every ray once
     march_gbs = march_bytes / (march_total * 1e-3) / 1e9
     # (3) stand-alone network / hash-grid kernels on the frame's real sample set
-    xyz, dirs = collect_samples(m, out["rays_o"], out["rays_d"], h.render_kwargs())
+    with h._amp():
+        xyz, dirs = collect_samples(m, out["rays_o"], out["rays_d"], h.render_kwargs())
     B = xyz.shape[0]
     u = ((xyz + m.bound) / (2 * m.bound)).contiguous()
     enc = m.encoder
@@ -137,67 +206,44 @@ def kernel_report(h, opt, dev):
     t_grid = cuda_time_ms(lambda: grid_launch(0))      # [L,B,C]: the reference kernel's own output layout (gridencoder.cu:105)
     t_grid_bl = cuda_time_ms(lambda: grid_launch(1))   # [B,L*C] written directly (what grid.py:57 obtains with an extra permute pass)
     t_net = cuda_time_ms(lambda: m(xyz, dirs))
+    with torch.autocast("cuda", dtype=torch.float16):
+        t_net_h = cuda_time_ms(lambda: m(xyz, dirs))
     t_sim = cuda_time_ms(lambda: h.sim.stepforward(), iters=10)
     t_frame = cuda_time_ms(lambda: h.step(simulate=False), iters=10)
     grid_gbs = HASH_BYTES_PER_SAMPLE * B / (t_grid * 1e-3) / 1e9
-    net_gbs = FUSED_BYTES_PER_SAMPLE * B / (t_net * 1e-3) / 1e9
-    net_tf = MLP_FLOP_PER_SAMPLE * B / (t_net * 1e-3) / 1e12
-    # HBM traffic per launch from the committed PMC passes (profiles/pmc_traffic.json: FETCH_SIZE + WRITE_SIZE, KB, separate rocprofv3 runs);
-    # the profile averaged over all enqueued trips, the empty ones move ~nothing, so scale to the real launches like `achieved`
-    traffic = {}
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        with open(pmc_path) as f:
-            pmc = json.load(f)
-        for kname in ("k_nerf_forward", "k_march", "k_march_tail", "k_march_skip"):
-            pm = pmc.get(kname)
-            if pm:  # bytes per FRAME of this kernel / real trips per frame
-                frames = pm["dispatches"] / float(pm.get("enqueued_trips_per_frame", 8))
-                traffic[kname] = int((pm["fetch_kb_per_launch"] + pm["write_kb_per_launch"]) * 1024 * pm["dispatches"] / (frames * pm["real_trips_per_frame"]))
-        if all(k in traffic for k in ("k_march", "k_march_tail", "k_march_skip")):  # one launch group = one trip; the skip pre-pass runs once per frame
-            traffic["march_group"] = traffic["k_march"] + traffic["k_march_tail"] + traffic["k_march_skip"] // real
-    # dominant kernel = the fused network kernel (largest single-kernel share of the step's GPU time, profiles/README.md): its launches in
-    # the render loop, HIP events on the launch stream around each of them (pn_frame_trip_times)
+    bps = FUSED_BYTES_PER_SAMPLE_FP16 if fp16 else FUSED_BYTES_PER_SAMPLE
+    t_used = t_net_h if fp16 else t_net
+    traffic, traffic_note = load_traffic(real)
     net_loop_ms = float(net_ms[:real].sum())
-    net_loop_gbs = FUSED_BYTES_PER_SAMPLE * st["samples"] / (net_loop_ms * 1e-3) / 1e9
+    net_loop_gbs = bps * st["samples"] / (net_loop_ms * 1e-3) / 1e9
     net_loop_tf = MLP_FLOP_PER_SAMPLE * st["samples"] / (net_loop_ms * 1e-3) / 1e12
+    kname = "k_nerf_forward_h" if fp16 else "k_nerf_forward"
     network = {
-        "kernel": "k_nerf_forward<2,4> (hash-grid gather + SH + 5-layer MLP fused; dense layers as three-way bf16-split MFMA at fp32 accuracy), "
-                  "launches inside the render loop",
-        # cutting the matrix time by 2.7x (f32-input MFMA -> bf16 split) left the stand-alone kernel time unchanged, the
-        # gather-only variant of the kernel takes 69 % of its time, the MLP-only variant 55 %: the bound is the gather path
+        "kernel": ("k_nerf_forward_h<4,4> (fp16 hash tables + SH + 5-layer MLP fused; dense layers on v_mfma_f32_32x32x16_f16, half activations)" if fp16 else
+                   "k_nerf_forward<2,4> (hash-grid gather + SH + 5-layer MLP fused; dense layers as three-way bf16-split MFMA at fp32 accuracy)")
+        + ", launches inside the render loop",
         "bound": "hbm", "achieved": round(net_loop_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(net_loop_gbs / HBM_PEAK_GBS, 4),
-        "bytes_per_sample": FUSED_BYTES_PER_SAMPLE, "algorithmic_bytes_per_launch": int(FUSED_BYTES_PER_SAMPLE * st["samples"] / real),
-        "traffic": traffic.get("k_nerf_forward"),
-        "traffic_note": "HBM bytes per launch, FETCH_SIZE+WRITE_SIZE PMC passes (profiles/pmc_traffic.json); below the algorithmic bytes because the "
-                        "dense levels and part of the hashed tables are served by L2 / Infinity Cache",
+        "bytes_per_sample": bps, "algorithmic_bytes_per_launch": int(bps * st["samples"] / real), "traffic": traffic.get(kname), "traffic_note": traffic_note,
         "launch_ms": round(net_loop_ms / real, 4), "launches_per_frame": real, "ms_per_frame": round(net_loop_ms, 4),
-        "launch_ms_incl_empty_trips": round(float(net_ms.mean()), 4), "launches_enqueued_per_frame": int(len(net_ms)),
         "samples_per_frame": st["samples"],
-        "mfma_view": {"flop_per_sample_fp32_equivalent": MLP_FLOP_PER_SAMPLE, "bf16_mfma_flop_per_sample_issued": 6 * 20 * 32768 // 32,
-                      "fp32_equivalent_TFLOPs": round(net_loop_tf, 2), "frac_of_f32_mfma_peak": round(net_loop_tf / F32_MFMA_PEAK_TF, 4)},
-        "all_samples_one_launch": {"launch_ms": round(t_net, 4), "achieved_GBps": round(net_gbs, 1), "frac_of_hbm_peak": round(net_gbs / HBM_PEAK_GBS, 4),
-                                   "fp32_equivalent_TFLOPs": round(net_tf, 2)},
-        "note": "achieved = 1 068 algorithmic bytes per sample (16 levels x 8 corners x 8 B gathered + 4 B slot id + 24 B xyz/dir in + 16 B sigma/rgb "
-                "out) x samples of the launch / HIP-event time of the launch; peak = 8 TB/s HBM3E (MI355X_MICROARCH.md)",
+        "mfma_view": {"flop_per_sample": MLP_FLOP_PER_SAMPLE, "TFLOPs": round(net_loop_tf, 2),
+                      "frac_of_mfma_peak": round(net_loop_tf / (F16_MFMA_PEAK_TF if fp16 else F32_MFMA_PEAK_TF), 4),
+                      "peak_used": "fp16 dense MFMA 2.5 PF" if fp16 else "fp32-input MFMA 157.3 TF (the kernel computes fp32-accurate products out of 6 bf16 MFMAs)"},
+        "all_samples_one_launch": {"launch_ms_fp32": round(t_net, 4), "launch_ms_fp16": round(t_net_h, 4), "achieved_GBps": round(bps * B / (t_used * 1e-3) / 1e9, 1),
+                                   "frac_of_hbm_peak": round(bps * B / (t_used * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
     }
-    # dominant kernel = the ray march (k_march 19.4 % + k_march_tail 18.5 % + k_march_skip 4.4 % of the step's GPU time in
-    # profiles/r01_final_kernel_stats.csv; the network kernel is 15.8 %): one algorithm in two passes per trip plus the trip-0 pre-pass,
-    # timed as one launch group by HIP events on the launch stream (pn_frame_trip_times)
     roofline = {
-        "kernel": "ray march + inverse-GMLS warp: k_march<3,false> + k_march_tail<3,false> per loop trip (+ k_march_skip on trip 0), one launch group",
+        "kernel": "ray march + inverse-GMLS warp: k_march + k_march_tail per loop trip (+ k_march_skip on trip 0), one launch group",
         "bound": "hbm", "achieved": round(march_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(march_gbs / HBM_PEAK_GBS, 4),
-        "traffic": traffic.get("march_group"),
-        "traffic_note": "HBM bytes per launch group, FETCH_SIZE+WRITE_SIZE PMC passes (profiles/pmc_traffic.json): far below the algorithmic bytes "
-                        "because the candidate lists and IP records (~1 MB per frame) are re-read from L2",
+        "traffic": traffic.get("march_group"), "traffic_note": traffic_note,
         "launch_ms": round(march_launch, 4), "launches_per_frame": real, "ms_per_frame": round(march_total, 4),
-        "launch_ms_incl_empty_trips": round(float(march_ms.mean()), 4), "launches_enqueued_per_frame": int(len(march_ms)),
+        "measured_in": "blocking single-frame render, HIP events on the launch stream around each trip's march launches (pn_frame_trip_times); the same "
+                       "events recorded inside the pipelined graphs are under 'pipelined_kernel_ms'",
         "units_per_frame": cnt, "algorithmic_bytes_per_frame": int(march_bytes), "algorithmic_bytes_per_launch": int(march_bytes / real),
         "bytes_per_unit": MARCH_BYTES,
-        "note": "achieved = algorithmic bytes (8 B per marched ray point, 16 B per candidate-list entry, 64 B per warped IP record head, 36 B per "
-                "emitted sample, 40 B of ray state per ray and trip) / HIP-event time of the launch group.  The kernel is a divergent pointer chase "
-                "over cache-resident tables: latency-bound, not a streaming kernel, so the HBM roofline is an upper bound it cannot approach "
-                "(DESIGN.md 4.1)",
+        "note": "achieved = algorithmic bytes (8 B per marched ray point, 16 B per candidate-list entry, 64 B per warped IP record head, 36 B per emitted sample, "
+                "40 B of ray state per ray and trip) / HIP-event time of the launch group.  A divergent pointer chase over cache-resident tables (SQ counters "
+                "in profiles/: waves parked on memory most of their cycles): latency-bound, the HBM roofline is an upper bound it cannot approach (DESIGN.md 4.1)",
     }
     extra = {
         "network": network,
@@ -211,28 +257,87 @@ def kernel_report(h, opt, dev):
     return st, roofline, extra
 
 
+def pipelined_extras(make_harness, args, steps):
+    """Short measurements beside the headline (N = 1): device-resident rate, one-frame-at-a-time latency, kernel durations inside the pipelined graphs."""
+    res = {}
+
+    def rate(h, n):
+        for _ in range(2 * args.lanes * args.depth + 4):
+            h.step_pipelined()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            h.step_pipelined()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        h.drain_pipeline()
+        return dt / n * 1e3
+    h = make_harness()
+    h.capture_pipelined(lanes=args.lanes, depth=args.depth, n_trips=args.trips, copy_out=False)
+    ms = rate(h, steps)
+    res["device_resident"] = {"steps_per_s": round(1e3 / ms, 2), "ms_per_step": round(ms, 4), "note": "same pipeline without the D2H of image/depth/depth_0"}
+    del h
+    torch.cuda.empty_cache()
+    h = make_harness()
+    h.capture_pipelined(lanes=1, depth=2, n_trips=args.trips, sim_ahead=1)
+    ms = rate(h, steps)
+    res["latency_ms_per_step"] = round(ms, 4)
+    res["latency_note"] = "lanes = 1: one render at a time (the next substep overlaps it), incl. D2H — the GUI-equivalent frame time"
+    del h
+    torch.cuda.empty_cache()
+    try:  # HIP events recorded inside the captured render graphs: the march / network launch durations of the mode that produced `value`
+        h = make_harness()
+        h.capture_pipelined(lanes=args.lanes, depth=args.depth, n_trips=args.trips, _time_trips=True)
+        for _ in range(3 * args.lanes * args.depth):
+            h.step_pipelined()
+        h.drain_pipeline()
+        m_all, n_all = [], []
+        for ws in range(args.lanes * args.depth):
+            a, b = h.model.trip_times(slot=ws)
+            m_all.append(a)
+            n_all.append(b)
+        st = h.model.render_status(synchronize=False, slot=0)
+        real = st["trips"]
+        mm, nn = np.median(np.array(m_all), axis=0), np.median(np.array(n_all), axis=0)
+        res["pipelined_kernel_ms"] = {"march_per_trip": [round(float(v), 4) for v in mm[:real]], "network_per_trip": [round(float(v), 4) for v in nn[:real]],
+                                      "march_ms_per_frame": round(float(mm[:real].sum()), 4), "network_ms_per_frame": round(float(nn[:real].sum()), 4),
+                                      "note": f"HIP events recorded inside the captured render graphs while {args.lanes} lanes + the simulator run concurrently: "
+                                              "durations include the slowdown from sharing the GPU"}
+        del h
+    except Exception as e:  # noqa: BLE001 — measurement only
+        res["pipelined_kernel_ms"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=("chair", "stress", "trex"), default="chair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying the captured HIP graph")
-    ap.add_argument("--trips", type=int, default=8, help="render-loop trips baked into the captured graph")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short additional measurements after the timed region")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying captured HIP graphs")
+    ap.add_argument("--trips", type=int, default=8, help="render-loop trips baked into the captured graphs (a frame that needs more is continued)")
     ap.add_argument("--lanes", type=int, default=3,
-                    help="renders in flight on the GPU (1 = strictly one frame after the other; 3 render streams + the simulator stream = the 4 "
-                         "compute pipes of an XCD, more streams only time-slice)")
+                    help="render streams (3 render streams + the simulator stream = the 4 compute pipes of an XCD, more streams only time-slice)")
+    ap.add_argument("--depth", type=int, default=2, help="workspaces per render stream")
     ap.add_argument("--single-graph", action="store_true", help="whole step as ONE captured graph (sim on a forked stream), one frame at a time")
+    ap.add_argument("--no-d2h", action="store_true", help="leave the outputs on the device (then `value` is the device-resident rate and says so)")
+    ap.add_argument("--whole-frame", action="store_true", help="--config stress: render the frame in one shot instead of ray batches of 4096")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--dedicated-sim", choices=("auto", "on", "off"), default="auto",
                     help="N > 1: the sim owner only simulates and broadcasts, the other ranks render (auto: from 3 ranks on, frames.dedicated_sim_default)")
     ap.add_argument("--force", type=float, nargs=3, default=None, metavar=("FX", "FY", "FZ"),
-                    help="constant update_force on the middle integration point (SURVEY 8d, config 2 second pass); default: gravity only")
+                    help="constant update_force on the middle integration point (SURVEY 8d, config 2 second pass); default: per config")
+    ap.add_argument("--sigma-gain", type=float, default=1.0, help="scales the synthetic checkpoint's density (samples per frame fall as it rises)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rccl_ranks = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -244,55 +349,75 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        rccl_ranks = dist.get_world_size()
     else:
         dev_index = 0
         torch.cuda.set_device(0)
     dev = torch.device("cuda", dev_index)
 
-    from pienerf_amd import scene
     from pienerf_amd.harness import SimRenderHarness
+    opt, cloud, ckpt, pose, force, workload = make_config(args.config, args.sigma_gain)
+    if args.force is not None:
+        force = np.asarray(args.force, dtype=np.float64)
 
-    opt = scene.default_opt()  # chair demo options (README.md:123): 800x800, bound 1, dt_gamma 0, num_seek_IP 3, max_iter_num 1, sim_dx 0.05, iters 10
-    cloud = scene.make_chair_points(hgs=opt["hash_grid_size"])
-    ckpt = scene.make_checkpoint(bound=opt["bound"], seed=0)
-    h = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device=dev)
-    if args.force is not None and (world == 1 or rank == 0):  # Simulator.update_force (solver.py:578-588): the dragged-point load of the GUI
-        h.sim.update_force(h.sim.n_IP // 2, np.asarray(args.force, dtype=np.float64))
+    def make_harness():
+        hh = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device=dev)
+        hh.pose = pose
+        if force is not None and (world == 1 or rank == 0):  # Simulator.update_force (solver.py:578-588): the dragged-point load of the GUI
+            hh.sim.update_force(hh.sim.n_IP // 2, force)
+        return hh
+    h = make_harness()
+    copy_out = not args.no_d2h
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    frames_done = [0]
+    staged = args.config == "stress" and not args.whole_frame and world == 1 and not args.eager and not args.single_graph
     if world == 1:
         if args.eager:
-            run_steps = lambda n: [h.step() for _ in range(n)]
-        elif not args.single_graph:
-            # `lanes` renders in flight on their own streams, the simulator running ahead on dof snapshots (harness.capture_pipelined);
-            # lanes = 1 is one render at a time with the next substep overlapping it
-            h.capture_pipelined(lanes=args.lanes, n_trips=args.trips)
-            run_steps = lambda n: [h.step_pipelined() for _ in range(n)]
-        else:
+            def run_steps(n):
+                for _ in range(n):
+                    o_ = h.step()
+                    if copy_out:
+                        h.to_host(o_)
+            launch = "eager (one kernel launch per host call)"
+        elif args.single_graph:
             # the whole step (get_rays, get_IP_info, stepforward on a forked stream, render prologue + loop trips + epilogue) is one
-            # captured HIP graph; each replay re-checks that the previous frame left no ray alive
+            # captured HIP graph; each replay first completes the previous frame (continuing it if it ran out of trips)
             h.capture(n_trips=args.trips)
-            run_steps = lambda n: [h.step_graph() for _ in range(n)]
+
+            def run_steps(n):
+                for _ in range(n):
+                    o_ = h.step_graph()
+                    if copy_out:
+                        h.to_host(o_)
+            launch = f"one hip graph per step, {args.trips} trips"
+        elif staged:
+            h.capture_staged(copy_out=copy_out)
+            run_steps = lambda n: [h.step_staged() for _ in range(n)]
+            launch = f"one captured graph replay per 4096-ray batch ({h._staged['trips']} trips each), tables built once per frame, substep on its own stream"
+        else:
+            h.capture_pipelined(lanes=args.lanes, depth=args.depth, n_trips=args.trips, copy_out=copy_out)
+            run_steps = lambda n: [h.step_pipelined() for _ in range(n)]
+            launch = f"hip graphs, {args.trips} trips, {args.lanes} render streams x {args.depth} workspaces, simulator running ahead"
     else:
-        # frame-parallel (harness.capture_frame_parallel): rank 0 owns the simulator, runs it ahead on dof snapshots and
-        # broadcasts each snapshot (<= 82 KB) over RCCL on a communication stream; frame f is rendered by rank f % world on one of its
-        # `lanes` render streams.  `n` steps per rank = n * world frames in total.
         from pienerf_amd.frames import broadcast_tensors
         m = h.model
         broadcast_tensors([m.encoder.embeddings.data, m.density_bitfield] + [l.weight.data for l in list(m.sigma_net) + list(m.color_net)], src=0)
+        m._net_sig = None
         # ROCm time-slices badly once more than 4 hardware queues are busy (launch structure): with the simulator stream
         # and the RCCL communication stream that leaves 2 render lanes per rank; a rank renders only every world-th frame anyway
         args.lanes = min(args.lanes, 2)
         dedicated = {"auto": None, "on": True, "off": False}[args.dedicated_sim]
-        h.capture_frame_parallel(lanes=args.lanes, n_trips=args.trips, dedicated_sim=dedicated)
+        h.capture_frame_parallel(lanes=args.lanes, depth=args.depth, n_trips=args.trips, dedicated_sim=dedicated, copy_out=copy_out)
 
         def run_steps(n):
             for _ in range(n * world):
-                h.step_frame_parallel()
+                frames_done[0] += len(h.step_frame_parallel())
+        launch = f"hip graphs, {args.trips} trips, {args.lanes} render streams x {args.depth} workspaces per rank"
 
     with torch.no_grad():
         run_steps(args.warmup)
@@ -301,37 +426,66 @@ def main():
         run_steps(args.steps)
         barrier()
         elapsed = time.perf_counter() - t0
-        if world > 1 or not args.eager:  # the last replayed frame(s) must be complete too
-            if world > 1 or not args.single_graph:
-                h.drain_pipeline()
-            else:
-                h._check_previous_graph_frame()
+        continued = 0
+        if world > 1 or not (args.eager or args.single_graph or staged):  # the last frames in flight are retired (and verified) here
+            frames_done[0] += len(h.drain_pipeline())
+            continued = h._pipe_backend.continued
+        elif staged:
+            h.finish_staged()
+        elif args.single_graph:
+            h._check_previous_graph_frame()
+            continued = getattr(h, "graph_continued", 0)
+    per_rank_frames = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+        fr = torch.zeros(world, dtype=torch.int64, device=dev)
+        fr[rank] = frames_done[0]
+        torch.distributed.all_reduce(fr)
+        per_rank_frames = [int(v) for v in fr.tolist()]
 
     if rank == 0:
+        del_h = h
         with torch.no_grad():
-            st, roofline, extra = kernel_report(h, opt, dev)
+            hk = make_harness() if (world > 1 or not args.eager) else h   # a fresh eager harness for the per-kernel report
+            st, roofline, extra = kernel_report(hk, opt, dev)
         res = {
-            "metric": "sim+render steps/s @800x800 chair", "value": round(args.steps * world / elapsed, 3), "unit": "steps/s", "n_gpus": world,
+            "metric": "sim+render steps/s @800x800 chair" if args.config == "chair" else f"sim+render steps/s, {args.config} configuration",
+            "value": round(args.steps * world / elapsed, 3), "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 render / f64 sim", "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic chair 800x800, sim_dx=0.05, sim_iters=10, num_seek_IP=3, max_iter_num=1, fp32, "
-                                   "1 sim+render step per frame" + (f", constant force {args.force} on IP {h.sim.n_IP // 2}" if args.force is not None else ", gravity only"),
-                       "rays": opt["W"] * opt["H"], "n_IP": h.sim.n_IP, "n_kernels": h.sim.n_k,
-                       "samples_per_frame": st["samples"], "trips_per_frame": st["trips"],
-                       "launch": "eager" if (args.eager and world == 1) else (f"one hip graph per step, {args.trips} trips" if args.single_graph else
-                                                                                   f"hip graphs, {args.trips} trips, {args.lanes} render(s) in flight, simulator running ahead"),
-                       "parallelism": (f"frame-parallel x{world}, DOF broadcast over RCCL, " + ("rank 0 simulates only, frames round-robin over the other ranks"
-                                                                                                if h._pipe["dedicated"] else "frames round-robin over all ranks"))
-                       if world > 1 else "single GPU"},
+            "scaling": "weak", "vs_baseline": None, "dtype": ("f16 tables+MLP / f32 march / f64 sim" if opt.get("fp16") else "f32 render / f64 sim"), "data": "synthetic",
+            "config": {"workload": workload + (f", constant force {[float(v) for v in force]} on IP {hk.sim.n_IP // 2}" if force is not None else ", gravity only")
+                       + ("" if copy_out else " [--no-d2h: outputs left on the device]"),
+                       "rays": opt["W"] * opt["H"], "n_IP": hk.sim.n_IP, "n_kernels": hk.sim.n_k, "n_points": int(len(cloud["pos"])),
+                       "samples_per_frame": st["samples"], "trips_per_frame": st["trips"], "d2h_bytes_per_step": (opt["W"] * opt["H"] * 20 if copy_out else 0),
+                       "frames_continued_past_captured_trips": continued, "launch": launch, "sigma_gain": args.sigma_gain,
+                       "hit_rays": st["hit_rays"], "mean_samples_per_hit_ray": round(st["samples"] / max(1, st["hit_rays"]), 2),
+                       "parallelism": (f"frame-parallel x{world} ({rccl_ranks} RCCL ranks), dof snapshots broadcast over RCCL, "
+                                       + ("rank 0 simulates only, frames round-robin over the other ranks" if del_h._pipe.dedicated else "frames round-robin over all ranks")
+                                       + f", frames per rank {per_rank_frames}") if world > 1 else "single GPU"},
             "roofline": roofline,
         }
         res.update(extra)
+        if world == 1 and not args.no_extras and not (args.eager or args.single_graph or staged):
+            with torch.no_grad():
+                res.update(pipelined_extras(make_harness, args, max(40, min(args.steps, 120))))
+        if staged and not args.no_extras:  # the same configuration with the frame rendered in one shot (what render_deformed does with these options in the reference)
+            with torch.no_grad():
+                hw = make_harness()
+                hw.capture_pipelined(lanes=args.lanes, depth=args.depth, n_trips=None, copy_out=copy_out)
+                for _ in range(12):
+                    hw.step_pipelined()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(60):
+                    hw.step_pipelined()
+                torch.cuda.synchronize()
+                res["whole_frame_pipelined"] = {"steps_per_s": round(60 / (time.perf_counter() - t1), 2), "trips_captured": hw._pipe_backend.trips,
+                                                "note": "same scene, options and precision with the 800x800 frame rendered in one shot by the frame pipeline"}
+                hw.drain_pipeline()
         if not args.no_cpu_baseline and world == 1:  # a reported baseline, timed on rank 0 at N = 1 only
-            res["cpu_baseline"] = cpu_baseline(opt, cloud, ckpt, args.cpu_budget)
+            res["cpu_baseline"] = cpu_baseline(opt, cloud, ckpt, pose, force, args.cpu_budget)
         print(json.dumps(res))
     if world > 1:
         torch.distributed.barrier()

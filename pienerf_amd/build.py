@@ -36,6 +36,22 @@ UNITS = {
 }
 
 
+def source_hash():
+    """SHA-1 over the kernel sources, headers and compile flags: identifies the code a measurement was taken on (profiles/pmc_traffic.json is
+    stamped with it; bench.py refuses a stamp that does not match the tree it runs from)."""
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) 
+    for f in files:
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(HERE, "..", "include", "pienerf_hip.h"), "rb") as fh:
+        h.update(fh.read())
+    h.update(repr((COMMON, sorted(UNITS.items()))).encode())
+    return h.hexdigest()
+
+
 def hipcc():
     for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):

@@ -199,7 +199,7 @@ class SimRenderHarness:
 
     @torch.no_grad()
     def capture_pipelined(self, lanes=2, n_trips=8, W=None, H=None, sim_ahead=None, depth=2, sim_priority=0, sim_cus=0, copy_out=True, group=None,
-                          frame_parallel=False, sim_owner=0, dedicated_sim=None, on_retire=None, _probe_no_substep=False):
+                          frame_parallel=False, sim_owner=0, dedicated_sim=None, on_retire=None, _probe_no_substep=False, _time_trips=False):
         """Throughput mode (pienerf_amd/frames.py: FramePipeline): `lanes` render streams with `depth` workspaces each, the simulator running
         `sim_ahead` frames ahead on dof snapshots, every frame's image / depth / depth_0 copied to pinned host memory on a copy stream
         (the reference's device->host boundary, trainer.py:589-592; copy_out=False leaves the results on the device).  Everything a frame
@@ -228,7 +228,7 @@ class SimRenderHarness:
             self.step(simulate=False, collect_stats=True, W=W, H=H)
             n_trips = max(8, int(self.model.last_stats["trips"]) + 3)
         be = _HipBackend(self, lanes, depth, int(n_trips), W, H, sim_priority, sim_cus, copy_out, group if on else None,
-                         (dist.get_global_rank(group, sim_owner) if (on and group is not None) else sim_owner), _probe_no_substep)
+                         (dist.get_global_rank(group, sim_owner) if (on and group is not None) else sim_owner), _probe_no_substep, _time_trips)
         self._pipe = FramePipeline(be, world=world, rank=rank, lanes=lanes, depth=depth, ahead=(lanes if sim_ahead is None and world == 1 else sim_ahead),
                                    sim_owner=sim_owner, dedicated_sim=dedicated_sim, copy_out=copy_out, on_retire=on_retire)
         self._pipe_backend = be
@@ -414,7 +414,7 @@ class _HipBackend:
     """The device side of frames.FramePipeline on one MI355X: torch streams and events, the substep and one render per workspace captured
     as HIP graphs, RCCL broadcasts of the dof snapshots, D2H into pinned buffers."""
 
-    def __init__(self, h, lanes, depth, n_trips, W, H, sim_priority, sim_cus, copy_out, group, src, probe_no_substep):
+    def __init__(self, h, lanes, depth, n_trips, W, H, sim_priority, sim_cus, copy_out, group, src, probe_no_substep, time_trips=False):
         self.h, self.lanes, self.depth, self.trips, self.W, self.H, self.group, self.src = h, lanes, depth, n_trips, W, H, group, src
         dev, m, sim = h.device, h.model, h.sim
         self.continued = 0
@@ -464,6 +464,8 @@ class _HipBackend:
         for ws in range(n_ws):
             s = self._streams[f"lane{ws // depth}"]
             m.p_def, m.IP_F, m.IP_dF = self.ip[ws]  # the render graph of this workspace reads its own IP buffers
+            if time_trips:  # measurement (bench.py): HIP events around each trip's march / network launches become nodes of the captured graph
+                m.march_counters(2, slot=ws)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                 rays = get_rays(self.pose_dev[ws], h.intrinsics, H, W, -1)

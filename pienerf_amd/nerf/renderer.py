@@ -185,16 +185,18 @@ class NeRFRenderer(nn.Module):
             raise RuntimeError(f"render_deformed: device error flags {int(stats[2])} (1: sample cell outside the spatial hash, "
                                "2: IP outside it, 4: spatial-hash capacity exceeded, 8: candidate-list capacity exceeded)")
 
-    def march_counters(self, enable, read=False):
-        """Measurement hook: device-side work counters of the march kernel (iterations, candidates, warps, samples)."""
+    def march_counters(self, enable, read=False, slot=0):
+        """Measurement hook on workspace `slot`: 1 = device-side work counters of the march kernel (iterations, candidates, warps, samples);
+        2 = HIP events around each trip's march and network launches (see trip_times)."""
         out = (C.c_uint64 * 4)() if read else None
-        check(lib().pn_frame_march_counters(self._frame, int(enable), out, stream_ptr()), "march_counters")  # 1: counters, 2: event timing
+        check(lib().pn_frame_march_counters(self._frames[slot][0], int(enable), out, stream_ptr()), "march_counters")
         return None if out is None else dict(iterations=int(out[0]), candidates=int(out[1]), warps=int(out[2]), samples=int(out[3]))
 
-    def trip_times(self):
-        """Per-trip (march_ms, network_ms) of the last blocking render made while march_counters were enabled (HIP events)."""
+    def trip_times(self, slot=0):
+        """Per-trip (march_ms, network_ms) of the last render on `slot` made while event timing was enabled (HIP events on the launch stream;
+        for a captured render: the records of the last replay)."""
         a, b, n = (C.c_float * 64)(), (C.c_float * 64)(), C.c_int(0)
-        check(lib().pn_frame_trip_times(self._frame, a, b, 64, C.byref(n), stream_ptr()), "trip_times")
+        check(lib().pn_frame_trip_times(self._frames[slot][0], a, b, 64, C.byref(n), stream_ptr()), "trip_times")
         return [float(a[i]) for i in range(n.value)], [float(b[i]) for i in range(n.value)]
 
     def render_status(self, synchronize=True, slot=0):
