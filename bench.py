@@ -279,7 +279,7 @@ def pipelined_extras(make_harness, args, steps):
     del h
     torch.cuda.empty_cache()
     h = make_harness()
-    h.capture_pipelined(lanes=1, depth=2, n_trips=args.trips, sim_ahead=1)
+    h.capture_pipelined(lanes=1, depth=2, n_trips=args.trips, sim_ahead=1, copy_on=args.copy_on)
     ms = rate(h, steps)
     res["latency_ms_per_step"] = round(ms, 4)
     res["latency_note"] = "lanes = 1: one render at a time (the next substep overlaps it), incl. D2H — the GUI-equivalent frame time"
@@ -287,7 +287,7 @@ def pipelined_extras(make_harness, args, steps):
     torch.cuda.empty_cache()
     try:  # HIP events recorded inside the captured render graphs: the march / network launch durations of the mode that produced `value`
         h = make_harness()
-        h.capture_pipelined(lanes=args.lanes, depth=args.depth, n_trips=args.trips, _time_trips=True)
+        h.capture_pipelined(lanes=args.lanes, depth=args.depth, n_trips=args.trips, _time_trips=True, copy_on=args.copy_on)
         for _ in range(3 * args.lanes * args.depth):
             h.step_pipelined()
         h.drain_pipeline()
@@ -301,8 +301,9 @@ def pipelined_extras(make_harness, args, steps):
         mm, nn = np.median(np.array(m_all), axis=0), np.median(np.array(n_all), axis=0)
         res["pipelined_kernel_ms"] = {"march_per_trip": [round(float(v), 4) for v in mm[:real]], "network_per_trip": [round(float(v), 4) for v in nn[:real]],
                                       "march_ms_per_frame": round(float(mm[:real].sum()), 4), "network_ms_per_frame": round(float(nn[:real].sum()), 4),
-                                      "note": f"HIP events recorded inside the captured render graphs while {args.lanes} lanes + the simulator run concurrently: "
-                                              "durations include the slowdown from sharing the GPU"}
+                                      "note": f"time stamps (one-lane kernels reading the 100 MHz clock) captured inside the render graphs around each trip's march and "
+                                              f"network launches, while {args.lanes} lanes, the simulator and the D2H run concurrently: the durations of the mode that "
+                                              "produced `value`, including the slowdown from sharing the GPU (HIP events recorded in a graph cannot be timed)"}
         del h
     except Exception as e:  # noqa: BLE001 — measurement only
         res["pipelined_kernel_ms"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
@@ -319,7 +320,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the short additional measurements after the timed region")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying captured HIP graphs")
-    ap.add_argument("--trips", type=int, default=8, help="render-loop trips baked into the captured graphs (a frame that needs more is continued)")
+    ap.add_argument("--trips", type=int, default=None, help="render-loop trips baked into the captured graphs (default: what one eager frame needs + 3; a frame "
+                    "that needs more is continued when it is retired)")
+    ap.add_argument("--copy-on", choices=("copy", "lane"), default="copy", help="stream of the per-frame D2H: a copy stream of its own, or the frame's render stream")
+    ap.add_argument("--staged-streams", type=int, default=3, help="--config stress: streams the 4096-ray batches of a frame are dealt to")
     ap.add_argument("--lanes", type=int, default=3,
                     help="render streams (3 render streams + the simulator stream = the 4 compute pipes of an XCD, more streams only time-slice)")
     ap.add_argument("--depth", type=int, default=2, help="workspaces per render stream")
@@ -387,22 +391,25 @@ def main():
         elif args.single_graph:
             # the whole step (get_rays, get_IP_info, stepforward on a forked stream, render prologue + loop trips + epilogue) is one
             # captured HIP graph; each replay first completes the previous frame (continuing it if it ran out of trips)
-            h.capture(n_trips=args.trips)
+            h.capture(n_trips=args.trips or 8)
 
             def run_steps(n):
                 for _ in range(n):
                     o_ = h.step_graph()
                     if copy_out:
                         h.to_host(o_)
-            launch = f"one hip graph per step, {args.trips} trips"
+            launch = f"one hip graph per step, {args.trips or 8} trips"
         elif staged:
-            h.capture_staged(copy_out=copy_out)
+            h.capture_staged(copy_out=copy_out, streams=args.staged_streams, n_trips=args.trips)
             run_steps = lambda n: [h.step_staged() for _ in range(n)]
-            launch = f"one captured graph replay per 4096-ray batch ({h._staged['trips']} trips each), tables built once per frame, substep on its own stream"
+            launch = (f"one captured graph replay per 4096-ray batch ({h._staged['trips']} trips each) dealt to {h._staged['L']} streams, tables built once per "
+                      "workspace and frame, substep on its own stream")
         else:
-            h.capture_pipelined(lanes=args.lanes, depth=args.depth, n_trips=args.trips, copy_out=copy_out)
+            h.capture_pipelined(lanes=args.lanes, depth=args.depth, n_trips=args.trips, copy_out=copy_out, copy_on=args.copy_on)
+            args.trips = h._pipe_backend.trips
             run_steps = lambda n: [h.step_pipelined() for _ in range(n)]
-            launch = f"hip graphs, {args.trips} trips, {args.lanes} render streams x {args.depth} workspaces, simulator running ahead"
+            launch = (f"hip graphs, {args.trips} trips, {args.lanes} render streams x {args.depth} workspaces, simulator running ahead, D2H on "
+                      + ("a copy stream" if args.copy_on == "copy" else "the render stream"))
     else:
         from pienerf_amd.frames import broadcast_tensors
         m = h.model
@@ -412,7 +419,8 @@ def main():
         # and the RCCL communication stream that leaves 2 render lanes per rank; a rank renders only every world-th frame anyway
         args.lanes = min(args.lanes, 2)
         dedicated = {"auto": None, "on": True, "off": False}[args.dedicated_sim]
-        h.capture_frame_parallel(lanes=args.lanes, depth=args.depth, n_trips=args.trips, dedicated_sim=dedicated, copy_out=copy_out)
+        h.capture_frame_parallel(lanes=args.lanes, depth=args.depth, n_trips=args.trips or 8, dedicated_sim=dedicated, copy_out=copy_out, copy_on=args.copy_on)
+        args.trips = h._pipe_backend.trips
 
         def run_steps(n):
             for _ in range(n * world):

@@ -1003,6 +1003,8 @@ struct pn_frame {
     int march_counters_on;
     hipEvent_t ev[PN_TIMED_TRIPS][3];    // measurement mode: before march / after march / after network, per trip
     int timed_trips;
+    unsigned long long* stamps;          // device [PN_TIMED_TRIPS][3]: the same three points as 100 MHz wall-clock stamps written by one-lane kernels
+    int stamped;                         // — the form that also works inside a captured graph (HIP events recorded in a graph cannot be timed)
 };
 
 // image = acc + (1 - weights_sum) * bg ; depth = clamp(depth - nears, 0) / (fars - nears) (renderer.py:896-899)
@@ -1022,6 +1024,9 @@ __global__ void __launch_bounds__(256) k_frame_finish(uint32_t N, float bg, cons
     image[i * 3 + 2] = acc[i * 3 + 2] + k;
     depth[i] = fmaxf(depth_0[i] - nears[i], 0.0f) / (fars[i] - nears[i]);
 }
+
+// measurement: a stream-ordered time stamp (constant 100 MHz clock) as an ordinary kernel node, so that it can live inside a captured graph
+__global__ void k_stamp(unsigned long long* slot) { *slot = __builtin_amdgcn_s_memrealtime(); }
 
 // ---- fused frame prologue (3 launches instead of 13; every one of them was a few-microsecond kernel with a launch gap)
 // (1) k_frame_tables, ONE workgroup of 1024 threads: IP bounding box +-1e-3 and spatial-hash resolution (nerf/renderer.py:782-791), the spatial
@@ -1294,6 +1299,7 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
     PN_ALLOC(f->trips, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)); PN_ALLOC(f->dev, sizeof(PnFrameDev)); PN_ALLOC(f->cut_bounds, 6 * 4);
 #undef PN_ALLOC
     PN_HIP_CHECK(hipMalloc((void**)&f->march_counters, 4 * sizeof(unsigned long long)));
+    PN_HIP_CHECK(hipMalloc((void**)&f->stamps, sizeof(unsigned long long) * PN_TIMED_TRIPS * 3));
     PN_HIP_CHECK(hipHostMalloc((void**)&f->trips_pinned, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)));
     PN_HIP_CHECK(hipHostMalloc((void**)&f->dev_pinned, sizeof(PnFrameDev)));
     PN_HIP_CHECK(hipMemset(f->dev, 0, sizeof(PnFrameDev)));
@@ -1306,7 +1312,7 @@ extern "C" void pn_frame_destroy(pn_frame* f) {
     if (!f) return;
     void* ptrs[] = {f->acc_image, f->nears, f->fars, f->rays_t, f->xyzs, f->dirs, f->deltas, f->sigmas, f->rgbs, f->alive_a, f->alive_b, f->list,
                     f->chunk_counts, f->pig_cnt, f->pig_bgn, f->pig_cursor, f->pig_idx, f->trips, f->dev, f->cut_bounds,
-                    f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, f->side.nb, f->side.rec, f->march_counters, f->tail, f->tail_counts};
+                    f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, f->side.nb, f->side.rec, f->march_counters, f->tail, f->tail_counts, f->stamps};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int t = 0; t < PN_TIMED_TRIPS; t++)
         for (int e = 0; e < 3; e++) if (f->ev[t][e]) (void)hipEventDestroy(f->ev[t][e]);
@@ -1432,11 +1438,20 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             // fast-forwards them; its per-ray resume point lives in `sigmas`, which is not written before this trip's network launch
             MarchIO io{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + t, f->list, (t == 0) ? f->sigmas : nullptr,
                        f->tail, f->tail_counts + t, (int)march_tail_rounds()};
-            const bool timed = (f->march_counters_on & 2) && t < PN_TIMED_TRIPS;  // also inside a capture: the records become graph nodes
-            if (timed) {  // measurement mode: HIP events around the two heavy launches of each trip, on the launch stream
-                for (int e = 0; e < 3; e++)
-                    if (!f->ev[t][e]) PN_HIP_CHECK(hipEventCreate(&f->ev[t][e]));
-                PN_HIP_CHECK(hipEventRecord(f->ev[t][0], st));
+            const bool timed = (f->march_counters_on & 2) && t < PN_TIMED_TRIPS;
+            bool stamp = false;
+            if (timed) {  // measurement mode: the two heavy launch groups of each trip are bracketed on the launch stream
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                PN_HIP_CHECK(hipStreamIsCapturing(st, &cs));
+                stamp = cs != hipStreamCaptureStatusNone;   // inside a capture: stamp kernels (events recorded in a graph cannot be timed)
+                f->stamped = stamp ? 1 : 0;
+                if (stamp) {
+                    k_stamp<<<1, 1, 0, st>>>(f->stamps + t * 3);
+                } else {
+                    for (int e = 0; e < 3; e++)
+                        if (!f->ev[t][e]) PN_HIP_CHECK(hipEventCreate(&f->ev[t][e]));
+                    PN_HIP_CHECK(hipEventRecord(f->ev[t][0], st));
+                }
             }
             if (is_static) {
                 k_march_static_trip<<<trip_grid, 256, 0, st>>>(f->trips + t, cur, f->rays_t, rays_o, rays_d, o->bound, o->dt_gamma, o->max_steps, o->cascade,
@@ -1445,10 +1460,15 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                 if (io.t_resume) k_march_skip<<<nblk, 256, 0, st>>>(mp, tb, io);
                 launch_march(o->num_seek_IP, std::min(pn_div_up(N, 32), march_grid), tail_grid, st, mp, tb, io);
             }
-            if (timed) PN_HIP_CHECK(hipEventRecord(f->ev[t][1], st));
+            if (timed && stamp) k_stamp<<<1, 1, 0, st>>>(f->stamps + t * 3 + 1);
+            else if (timed) PN_HIP_CHECK(hipEventRecord(f->ev[t][1], st));
             rc = pn_nerf_forward_launch(net, f->xyzs, f->dirs, f->list, &f->trips[t].n_samples, N, o->density_scale, f->sigmas, f->rgbs, o->fp16, st);
             if (rc) return rc;
-            if (timed) { PN_HIP_CHECK(hipEventRecord(f->ev[t][2], st)); f->timed_trips = t + 1; }
+            if (timed) {
+                if (stamp) k_stamp<<<1, 1, 0, st>>>(f->stamps + t * 3 + 2);
+                else PN_HIP_CHECK(hipEventRecord(f->ev[t][2], st));
+                f->timed_trips = t + 1;
+            }
             k_composite<<<trip_grid, 256, 0, st>>>(0, 0, o->T_thresh, cur, f->rays_t, f->sigmas, f->rgbs, f->deltas, weights_sum, depth_0, f->acc_image,
                                                    f->trips + t, f->chunk_counts);
             k_compact<<<trip_grid, 256, 0, st>>>(cur, 0, f->chunk_counts, nxt, nullptr, f->trips + t, f->trips + t + 1, N, o->max_steps);
@@ -1523,9 +1543,18 @@ extern "C" int pn_frame_trip_times(pn_frame* f, float* march_ms_host, float* net
     PN_REQUIRE(f && march_ms_host && network_ms_host && n_trips_out && max_trips >= 0);
     PN_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     const int n = f->timed_trips < max_trips ? f->timed_trips : max_trips;
-    for (int t = 0; t < n; t++) {
-        PN_HIP_CHECK(hipEventElapsedTime(march_ms_host + t, f->ev[t][0], f->ev[t][1]));
-        PN_HIP_CHECK(hipEventElapsedTime(network_ms_host + t, f->ev[t][1], f->ev[t][2]));
+    if (f->stamped) {
+        static unsigned long long host[PN_TIMED_TRIPS * 3];
+        PN_HIP_CHECK(hipMemcpy(host, f->stamps, sizeof(unsigned long long) * (size_t)n * 3, hipMemcpyDeviceToHost));
+        for (int t = 0; t < n; t++) {  // s_memrealtime ticks at 100 MHz: 1 tick = 1e-5 ms
+            march_ms_host[t] = (float)((double)(host[t * 3 + 1] - host[t * 3]) * 1e-5);
+            network_ms_host[t] = (float)((double)(host[t * 3 + 2] - host[t * 3 + 1]) * 1e-5);
+        }
+    } else {
+        for (int t = 0; t < n; t++) {
+            PN_HIP_CHECK(hipEventElapsedTime(march_ms_host + t, f->ev[t][0], f->ev[t][1]));
+            PN_HIP_CHECK(hipEventElapsedTime(network_ms_host + t, f->ev[t][1], f->ev[t][2]));
+        }
     }
     *n_trips_out = n;
     return PN_OK;

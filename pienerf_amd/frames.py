@@ -158,9 +158,13 @@ class FramePipeline:
             self.ip_used[slot] = True
             self.render_done[ws].record(s)
             if self.copy_out:
-                self.s_copy.wait(self.render_done[ws])
-                b.copy_out(self.s_copy, ws)
-                self.out_ready[ws].record(self.s_copy)
+                # on the copy stream (overlaps the lane's next frame) or, where a further busy hardware queue costs more than it brings, on the
+                # frame's own lane right behind the render (backend.copy_on == "lane")
+                sc = s if getattr(b, "copy_on", "copy") == "lane" else self.s_copy
+                if sc is not s:
+                    sc.wait(self.render_done[ws])
+                b.copy_out(sc, ws)
+                self.out_ready[ws].record(sc)
             self.pending[ws] = f
             self.my_frames += 1
         elif self.dedicated and self.rank == self.owner and self.world > 1:

@@ -199,7 +199,7 @@ class SimRenderHarness:
 
     @torch.no_grad()
     def capture_pipelined(self, lanes=2, n_trips=8, W=None, H=None, sim_ahead=None, depth=2, sim_priority=0, sim_cus=0, copy_out=True, group=None,
-                          frame_parallel=False, sim_owner=0, dedicated_sim=None, on_retire=None, _probe_no_substep=False, _time_trips=False):
+                          frame_parallel=False, sim_owner=0, dedicated_sim=None, on_retire=None, copy_on="copy", _probe_no_substep=False, _time_trips=False):
         """Throughput mode (pienerf_amd/frames.py: FramePipeline): `lanes` render streams with `depth` workspaces each, the simulator running
         `sim_ahead` frames ahead on dof snapshots, every frame's image / depth / depth_0 copied to pinned host memory on a copy stream
         (the reference's device->host boundary, trainer.py:589-592; copy_out=False leaves the results on the device).  Everything a frame
@@ -228,7 +228,7 @@ class SimRenderHarness:
             self.step(simulate=False, collect_stats=True, W=W, H=H)
             n_trips = max(8, int(self.model.last_stats["trips"]) + 3)
         be = _HipBackend(self, lanes, depth, int(n_trips), W, H, sim_priority, sim_cus, copy_out, group if on else None,
-                         (dist.get_global_rank(group, sim_owner) if (on and group is not None) else sim_owner), _probe_no_substep, _time_trips)
+                         (dist.get_global_rank(group, sim_owner) if (on and group is not None) else sim_owner), _probe_no_substep, _time_trips, copy_on)
         self._pipe = FramePipeline(be, world=world, rank=rank, lanes=lanes, depth=depth, ahead=(lanes if sim_ahead is None and world == 1 else sim_ahead),
                                    sim_owner=sim_owner, dedicated_sim=dedicated_sim, copy_out=copy_out, on_retire=on_retire)
         self._pipe_backend = be
@@ -260,59 +260,69 @@ class SimRenderHarness:
 
     # ------------------------------------------------------------------ a frame rendered in ray batches (BASELINE.json configs[4])
     @torch.no_grad()
-    def capture_staged(self, batch=None, n_trips=None, W=None, H=None, copy_out=True):
+    def capture_staged(self, batch=None, n_trips=None, W=None, H=None, copy_out=True, streams=3):
         """The frame rendered in ray batches of `batch` (opt max_ray_batch = 4096, get_opts.py:24; renderer.py:562-576's staging loop).  Rays are
-        independent, so the batches reproduce the one-shot frame bit for bit (tests/test_gpu_fullsize.py).  One batch = one captured HIP
-        graph replay on a 4096-ray workspace; the first batch of a frame builds the spatial hash / candidate lists of the frame's IP state,
-        the others keep them (pn_render_opts.reuse_tables — the reference would rebuild get_pnts_in_grids for every call).  The substep
-        runs on the simulator stream beside the batches; two frame buffers alternate so the D2H of frame f overlaps the batches of f + 1.
-        Batches that ran out of captured trips are counted on the device (render_status 'unfinished') and the frame is then redone with
-        the blocking driver."""
+        independent, so the batches reproduce the one-shot frame bit for bit (tests/test_gpu_parity.py, test_gpu_fullsize.py).  One batch = one
+        captured HIP-graph replay on a `batch`-ray workspace; a 4096-ray render is a chain of ~70 tiny dependent launches that leaves the chip
+        idle, so the batches of a frame go round-robin over `streams` streams, each with its own workspace.  The first batch a workspace sees in
+        a frame builds the spatial hash / candidate lists of the frame's IP state, its later batches keep them (pn_render_opts.reuse_tables —
+        the reference would rebuild get_pnts_in_grids for every call).  The substep runs on the simulator stream beside the batches; two
+        frame buffers alternate, so the D2H of frame f overlaps the batches of f + 1.  Batches that ran out of captured trips are counted on the
+        device (render_status 'unfinished') and reported when the frame is retired."""
         o, m, dev = self.opt, self.model, self.device
         W, H = W or o["W"], H or o["H"]
         N = W * H
         B = int(batch or o.get("max_ray_batch", 4096))
+        L = max(1, min(int(streams), (N + B - 1) // B))
         if n_trips is None:
             self.step(simulate=False, collect_stats=True, W=W, H=H)
             n_trips = max(8, int(m.last_stats["trips"]) + 6)   # a 4096-ray batch thins out more slowly than the whole frame: generous margin
         if not hasattr(self, "_sim_stream"):
             self._sim_stream = torch.cuda.Stream(dev)
         self.sim.force_stream = self._sim_stream
-        st = dict(B=B, N=N, W=W, H=H, trips=n_trips, stream=torch.cuda.Stream(dev), copy=torch.cuda.Stream(dev), k=0, redone=0)
+        st = dict(B=B, N=N, W=W, H=H, L=L, trips=n_trips, stream=[torch.cuda.Stream(dev) for _ in range(L)], copy=torch.cuda.Stream(dev), k=0)
         st["pose"] = torch.from_numpy(np.asarray(self.pose, np.float32)).unsqueeze(0).to(dev)
         st["ip"] = tuple(torch.empty((self.sim.n_IP, c), dtype=torch.float32, device=dev) for c in (3, 9, 27))
-        st["ro"], st["rd"] = torch.zeros(1, B, 3, device=dev), torch.zeros(1, B, 3, device=dev)
-        st["frames"] = [dict(image=torch.empty(N, 3, device=dev), depth=torch.empty(N, device=dev), depth_0=torch.empty(N, device=dev),
-                             host=({k: torch.empty(s_, dtype=torch.float32).pin_memory() for k, s_ in (("image", (H, W, 3)), ("depth", (H, W)), ("depth_0", (H, W)))}
-                                   if copy_out else None), done=torch.cuda.Event(), used=False) for _ in range(2)]
+        st["ro"] = [torch.zeros(1, B, 3, device=dev) for _ in range(L)]
+        st["rd"] = [torch.zeros(1, B, 3, device=dev) for _ in range(L)]
+        st["frames"] = []
+        for _ in range(2):
+            pk = torch.empty(N * 5, dtype=torch.float32, device=dev)   # image | depth | depth_0: one D2H per frame
+            st["frames"].append(dict(packed=pk, image=pk[:3 * N].view(N, 3), depth=pk[3 * N:4 * N], depth_0=pk[4 * N:],
+                                     host=(torch.empty(N * 5, dtype=torch.float32).pin_memory() if copy_out else None), done=torch.cuda.Event(), used=False))
         kw = dict(self.render_kwargs(), async_trips=n_trips)
         m.p_def, m.IP_F, m.IP_dF = st["ip"]
         keep = (self.sim.dof.clone(), self.sim.dof_vel.clone())
-        s = st["stream"]
-        s.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(s):
-            self.sim.get_IP_info(out=st["ip"])
-            rays = get_rays(st["pose"], self.intrinsics, H, W, -1)
-            st["ro"].copy_(rays["rays_o"][:, :B]); st["rd"].copy_(rays["rays_d"][:, :B])
-            for slot in (900, 901):   # two batch workspaces alternate from frame to frame: each keeps its frame's status words
-                with self._amp():
-                    m.render_deformed(st["ro"], st["rd"], bg_color=None, perturb=False, frame_slot=slot, **kw)
-                    m.render_deformed(st["ro"], st["rd"], bg_color=None, perturb=False, reuse_tables=True, frame_slot=slot, **kw)
+        main = torch.cuda.current_stream(dev)
+        self.sim.get_IP_info(out=st["ip"])
+        rays = get_rays(st["pose"], self.intrinsics, H, W, -1)
+        for j in range(L):
+            st["ro"][j].copy_(rays["rays_o"][:, :B])
+            st["rd"][j].copy_(rays["rays_d"][:, :B])
         torch.cuda.synchronize(dev)
         st["graph"], st["out"] = {}, {}
-        for slot in (900, 901):
-            for reuse in (False, True):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+        for par in range(2):          # two sets of batch workspaces alternate from frame to frame: each keeps its frame's status words
+            for j in range(L):
+                slot = 900 + par * L + j
+                s = st["stream"][j]
+                s.wait_stream(main)
+                with torch.cuda.stream(s):
                     with self._amp():
-                        out = m.render_deformed(st["ro"], st["rd"], bg_color=None, perturb=False, reuse_tables=reuse, frame_slot=slot, **kw)
-                st["graph"][slot, reuse] = g
-                st["out"][slot, reuse] = out
+                        m.render_deformed(st["ro"][j], st["rd"][j], bg_color=None, perturb=False, frame_slot=slot, **kw)
+                        m.render_deformed(st["ro"][j], st["rd"][j], bg_color=None, perturb=False, reuse_tables=True, frame_slot=slot, **kw)
+                torch.cuda.synchronize(dev)
+                for reuse in (False, True):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+                        with self._amp():
+                            out = m.render_deformed(st["ro"][j], st["rd"][j], bg_color=None, perturb=False, reuse_tables=reuse, frame_slot=slot, **kw)
+                    st["graph"][slot, reuse] = g
+                    st["out"][slot, reuse] = out
         torch.cuda.synchronize(dev)
-        self.sim.dof.copy_(keep[0]); self.sim.dof_vel.copy_(keep[1])
+        self.sim.dof.copy_(keep[0])
+        self.sim.dof_vel.copy_(keep[1])
         st["sim_done"] = torch.cuda.Event()
-        st["sim_done"].record(torch.cuda.current_stream(dev))
-        st["kw"] = kw
+        st["sim_done"].record(main)
         self._staged = st
         return self
 
@@ -322,45 +332,53 @@ class SimRenderHarness:
         checked; None on the first call); ``finish_staged()`` returns the last one."""
         from ._lib import check, lib, stream_ptr
         st, m, dev = self._staged, self.model, self.device
-        s, B, N, H, W = st["stream"], st["B"], st["N"], st["H"], st["W"]
+        B, N, H, W, L = st["B"], st["N"], st["H"], st["W"], st["L"]
         k = st["k"]
-        fr, slot = st["frames"][k % 2], 900 + k % 2      # this buffer's previous frame (k - 2) was retired during the last call
-        with torch.cuda.stream(s):
+        fr, par = st["frames"][k % 2], k % 2      # this buffer's previous frame (k - 2) was retired during the last call
+        s0 = st["stream"][0]
+        with torch.cuda.stream(s0):
             if pose is not None:
                 st["pose"].copy_(torch.from_numpy(np.asarray(pose, np.float32)).view(1, 4, 4).to(dev))
-            s.wait_event(st["sim_done"])                                # the previous substep must have finished before dof is read
+            s0.wait_event(st["sim_done"])                               # the previous substep must have finished before dof is read
+            for j in range(1, L):
+                s0.wait_stream(st["stream"][j])                         # ... and the previous frame's batches before the IP buffers are overwritten
             self.sim.get_IP_info(out=st["ip"])
-            ip_ready = torch.cuda.Event()
-            ip_ready.record(s)
             rays = get_rays(st["pose"], self.intrinsics, H, W, -1)
             fr["rays"] = rays
-            check(lib().pn_frame_reset_unfinished(m._frames[slot][0], stream_ptr()), "reset_unfinished")
-            for head in range(0, N, B):
-                n = min(B, N - head)
-                st["ro"][:, :n].copy_(rays["rays_o"][:, head:head + n])
-                st["rd"][:, :n].copy_(rays["rays_d"][:, head:head + n])
-                key = (slot, head != 0)                                 # the first batch of the frame builds the tables, the others keep them
+            ip_ready = torch.cuda.Event()
+            ip_ready.record(s0)
+        first = [True] * L
+        for b, head in enumerate(range(0, N, B)):
+            j = b % L
+            s, slot = st["stream"][j], 900 + par * L + j
+            n = min(B, N - head)
+            with torch.cuda.stream(s):
+                if first[j]:
+                    s.wait_event(ip_ready)
+                    check(lib().pn_frame_reset_unfinished(m._frames[slot][0], stream_ptr()), "reset_unfinished")
+                st["ro"][j][:, :n].copy_(rays["rays_o"][:, head:head + n])
+                st["rd"][j][:, :n].copy_(rays["rays_d"][:, head:head + n])
+                key = (slot, not first[j])                              # the workspace's first batch of the frame builds the tables, the others keep them
+                first[j] = False
                 st["graph"][key].replay()
                 out = st["out"][key]
                 fr["image"][head:head + n].copy_(out["image"].view(-1, 3)[:n])
                 fr["depth"][head:head + n].copy_(out["depth"].view(-1)[:n])
                 fr["depth_0"][head:head + n].copy_(out["depth_0"].view(-1)[:n])
-            ev = torch.cuda.Event()
-            ev.record(s)
         self._sim_stream.wait_event(ip_ready)                           # the substep only feeds the NEXT frame: it runs beside the batches
         with torch.cuda.stream(self._sim_stream):
             self.sim.stepforward()
             st["sim_done"].record(self._sim_stream)
-        if fr["host"] is not None:
-            st["copy"].wait_event(ev)
-            with torch.cuda.stream(st["copy"]):
-                for name in ("image", "depth", "depth_0"):
-                    fr["host"][name].copy_(fr[name].view(fr["host"][name].shape), non_blocking=True)
-                fr["done"] = torch.cuda.Event()
-                fr["done"].record(st["copy"])
-        else:
-            fr["done"] = ev
-        fr["used"], fr["slot"] = True, slot
+        tail = st["copy"] if fr["host"] is not None else s0
+        for j in range(L):
+            if st["stream"][j] is not tail:
+                tail.wait_stream(st["stream"][j])
+        with torch.cuda.stream(tail):
+            if fr["host"] is not None:
+                fr["host"].copy_(fr["packed"], non_blocking=True)
+            fr["done"] = torch.cuda.Event()
+            fr["done"].record(tail)
+        fr["used"], fr["par"] = True, par
         st["k"] += 1
         self.frame += 1
         return self._retire_staged(st["frames"][(k + 1) % 2])           # frame k - 1: the GPU already has frame k queued behind it
@@ -368,16 +386,20 @@ class SimRenderHarness:
     def _retire_staged(self, fr):
         if not fr["used"]:
             return None
+        st = self._staged
         fr["done"].synchronize()
-        # one status read per frame: batches the captured trips did not finish were counted on the device (pn_frame_reset_unfinished)
-        stt = self.model.render_status(synchronize=False, slot=fr["slot"])
-        if stt["unfinished"] > 0:
-            raise RuntimeError(f"staged frame: {stt['unfinished']} rays were still alive after the {self._staged['trips']} captured trips of their batch; "
+        # one status read per workspace and frame: batches the captured trips did not finish were counted on the device
+        unfinished = sum(self.model.render_status(synchronize=False, slot=900 + fr["par"] * st["L"] + j)["unfinished"] for j in range(st["L"]))
+        if unfinished > 0:
+            raise RuntimeError(f"staged frame: {unfinished} rays were still alive after the {st['trips']} captured trips of their batch; "
                                "capture_staged(n_trips=...) with more trips")
         fr["used"] = False
-        h = fr["host"]
+        H, W, N = st["H"], st["W"], st["N"]
         dev = {name: fr[name] for name in ("image", "depth", "depth_0")}
-        return {"device": dev} if h is None else {"image": h["image"].numpy(), "depth": h["depth"].numpy(), "depth_0": h["depth_0"].numpy(), "device": dev}
+        if fr["host"] is None:
+            return {"device": dev}
+        hb = fr["host"].numpy()
+        return {"image": hb[:3 * N].reshape(H, W, 3), "depth": hb[3 * N:4 * N].reshape(H, W), "depth_0": hb[4 * N:].reshape(H, W), "device": dev}
 
     def finish_staged(self):
         """Waits for and returns the last enqueued staged frame."""
@@ -414,7 +436,8 @@ class _HipBackend:
     """The device side of frames.FramePipeline on one MI355X: torch streams and events, the substep and one render per workspace captured
     as HIP graphs, RCCL broadcasts of the dof snapshots, D2H into pinned buffers."""
 
-    def __init__(self, h, lanes, depth, n_trips, W, H, sim_priority, sim_cus, copy_out, group, src, probe_no_substep, time_trips=False):
+    def __init__(self, h, lanes, depth, n_trips, W, H, sim_priority, sim_cus, copy_out, group, src, probe_no_substep, time_trips=False, copy_on="copy"):
+        self.copy_on = copy_on  # "copy": D2H on the copy stream; "lane": on the frame's own render stream (no fifth busy hardware queue)
         self.h, self.lanes, self.depth, self.trips, self.W, self.H, self.group, self.src = h, lanes, depth, n_trips, W, H, group, src
         dev, m, sim = h.device, h.model, h.sim
         self.continued = 0
@@ -460,25 +483,29 @@ class _HipBackend:
                 sim.stepforward()
             else:
                 sim.dof_vel.mul_(1.0)
-        self.graph, self.rays, self.out, self.host = [], [], [], []
+        self.graph, self.rays, self.out, self.host, self.packed = [], [], [], [], []
+        N = W * H
         for ws in range(n_ws):
             s = self._streams[f"lane{ws // depth}"]
             m.p_def, m.IP_F, m.IP_dF = self.ip[ws]  # the render graph of this workspace reads its own IP buffers
-            if time_trips:  # measurement (bench.py): HIP events around each trip's march / network launches become nodes of the captured graph
+            if time_trips:  # measurement (bench.py): time stamps around each trip's march / network launches become nodes of the captured graph
                 m.march_counters(2, slot=ws)
+            # image | depth | depth_0 packed in one device buffer -> ONE device-to-host copy per frame (20 B per pixel, trainer.py:589-592)
+            pk = torch.empty(N * 5, dtype=torch.float32, device=dev)
+            ob = {"image": pk[:3 * N].view(N, 3), "depth": pk[3 * N:4 * N], "depth_0": pk[4 * N:], "weights_sum": torch.empty(N, dtype=torch.float32, device=dev)}
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                 rays = get_rays(self.pose_dev[ws], h.intrinsics, H, W, -1)
                 with h._amp():
-                    out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **dict(kw, frame_slot=ws))
+                    out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, out_buffers=ob, **dict(kw, frame_slot=ws))
             self.graph.append(g)
             # every tensor the graphs touch stays referenced: a tensor freed after capture goes back to the graph's memory pool
             self.rays.append(rays)
             self.out.append(out)
+            self.packed.append(pk)
             # two pinned sets per workspace, used alternately: the arrays handed out when a frame is retired stay valid until the workspace has
             # been through another whole frame (the next frame's D2H goes into the other set)
-            self.host.append([{"image": torch.empty((H, W, 3), dtype=torch.float32).pin_memory(), "depth": torch.empty((H, W), dtype=torch.float32).pin_memory(),
-                               "depth_0": torch.empty((H, W), dtype=torch.float32).pin_memory()} for _ in range(2)] if copy_out else None)
+            self.host.append([torch.empty(N * 5, dtype=torch.float32).pin_memory() for _ in range(2)] if copy_out else None)
         self.host_gen = [0] * n_ws
         torch.cuda.synchronize(dev)
         sim.dof.copy_(keep[0])      # warm-up advanced the simulator; capture itself executes nothing
@@ -522,11 +549,8 @@ class _HipBackend:
     def copy_out(self, s, ws, same_buffer=False):
         if not same_buffer:
             self.host_gen[ws] ^= 1
-        o, hbuf = self.out[ws], self.host[ws][self.host_gen[ws]]
         with torch.cuda.stream(s.s):
-            hbuf["image"].copy_(o["image"].view(self.H, self.W, 3), non_blocking=True)
-            hbuf["depth"].copy_(o["depth"].view(self.H, self.W), non_blocking=True)
-            hbuf["depth_0"].copy_(o["depth_0"].view(self.H, self.W), non_blocking=True)
+            self.host[ws][self.host_gen[ws]].copy_(self.packed[ws], non_blocking=True)
 
     # ---- host side of a retired workspace
     def complete(self, ws):
@@ -546,8 +570,10 @@ class _HipBackend:
         self.continued += 1
 
     def result(self, ws):
-        o, hbuf = self.out[ws], (self.host[ws][self.host_gen[ws]] if self.host[ws] is not None else None)
-        dev = {"image": o["image"].view(-1, self.H, self.W, 3), "depth": o["depth"].view(-1, self.H, self.W), "depth_0": o["depth_0"].view(-1, self.H, self.W)}
-        if hbuf is None:
+        o = self.out[ws]
+        H, W, N = self.H, self.W, self.H * self.W
+        dev = {"image": o["image"].view(-1, H, W, 3), "depth": o["depth"].view(-1, H, W), "depth_0": o["depth_0"].view(-1, H, W)}
+        if self.host[ws] is None:
             return {"device": dev}
-        return {"image": hbuf["image"].numpy(), "depth": hbuf["depth"].numpy(), "depth_0": hbuf["depth_0"].numpy(), "device": dev}
+        hb = self.host[ws][self.host_gen[ws]].numpy()
+        return {"image": hb[:3 * N].reshape(H, W, 3), "depth": hb[3 * N:4 * N].reshape(H, W), "depth_0": hb[4 * N:].reshape(H, W), "device": dev}

@@ -129,10 +129,15 @@ class NeRFRenderer(nn.Module):
         assert p_def.shape == p_ori.shape and p_ori.shape[0] > 0  # renderer.py:816-817
         n_vtx = p_ori.shape[0]
         o = self._deformed_opts(dt_gamma, 0.0 if bg_tensor is not None else bg_color, max_steps, T_thresh, kwargs)
-        image = torch.empty(N, 3, dtype=torch.float32, device=device)
-        depth = torch.empty(N, dtype=torch.float32, device=device)
-        depth_0 = torch.empty(N, dtype=torch.float32, device=device)
-        weights_sum = torch.empty(N, dtype=torch.float32, device=device)
+        ob = kwargs.get("out_buffers")  # extension: caller-owned outputs (the frame pipeline packs image | depth | depth_0 into one buffer -> one D2H)
+        if ob is not None:
+            image, depth, depth_0, weights_sum = ob["image"], ob["depth"], ob["depth_0"], ob["weights_sum"]
+            assert image.shape == (N, 3) and depth.shape == (N,) and all(t.is_contiguous() and t.dtype == torch.float32 for t in (image, depth, depth_0, weights_sum))
+        else:
+            image = torch.empty(N, 3, dtype=torch.float32, device=device)
+            depth = torch.empty(N, dtype=torch.float32, device=device)
+            depth_0 = torch.empty(N, dtype=torch.float32, device=device)
+            weights_sum = torch.empty(N, dtype=torch.float32, device=device)
         async_trips = int(kwargs.get("async_trips") or 0)
         frame, net = self._frame_handle(N, n_vtx, o.hash_grid_size, int(kwargs.get("frame_slot") or 0)), self._net_handle(half=bool(o.fp16))
         if async_trips > 0:
