@@ -322,7 +322,7 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying captured HIP graphs")
     ap.add_argument("--trips", type=int, default=None, help="render-loop trips baked into the captured graphs (default: what one eager frame needs + 3; a frame "
                     "that needs more is continued when it is retired)")
-    ap.add_argument("--copy-on", choices=("copy", "lane"), default="copy", help="stream of the per-frame D2H: a copy stream of its own, or the frame's render stream")
+    ap.add_argument("--copy-on", choices=("copy", "lane", "sim"), default="lane", help="stream of the per-frame D2H: a copy stream of its own, or the frame's render stream")
     ap.add_argument("--staged-streams", type=int, default=3, help="--config stress: streams the 4096-ray batches of a frame are dealt to")
     ap.add_argument("--lanes", type=int, default=3,
                     help="render streams (3 render streams + the simulator stream = the 4 compute pipes of an XCD, more streams only time-slice)")
@@ -409,7 +409,7 @@ def main():
             args.trips = h._pipe_backend.trips
             run_steps = lambda n: [h.step_pipelined() for _ in range(n)]
             launch = (f"hip graphs, {args.trips} trips, {args.lanes} render streams x {args.depth} workspaces, simulator running ahead, D2H on "
-                      + ("a copy stream" if args.copy_on == "copy" else "the render stream"))
+                      + {"copy": "a copy stream", "lane": "the frame's render stream", "sim": "the simulator stream"}[args.copy_on])
     else:
         from pienerf_amd.frames import broadcast_tensors
         m = h.model

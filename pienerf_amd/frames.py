@@ -160,7 +160,8 @@ class FramePipeline:
             if self.copy_out:
                 # on the copy stream (overlaps the lane's next frame) or, where a further busy hardware queue costs more than it brings, on the
                 # frame's own lane right behind the render (backend.copy_on == "lane")
-                sc = s if getattr(b, "copy_on", "copy") == "lane" else self.s_copy
+                where = getattr(b, "copy_on", "copy")   # "sim": the simulator's stream has room (a substep is a third of a step) and is a queue that exists anyway
+                sc = s if where == "lane" else (self.s_sim if where == "sim" else self.s_copy)
                 if sc is not s:
                     sc.wait(self.render_done[ws])
                 b.copy_out(sc, ws)

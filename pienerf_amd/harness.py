@@ -199,7 +199,7 @@ class SimRenderHarness:
 
     @torch.no_grad()
     def capture_pipelined(self, lanes=2, n_trips=8, W=None, H=None, sim_ahead=None, depth=2, sim_priority=0, sim_cus=0, copy_out=True, group=None,
-                          frame_parallel=False, sim_owner=0, dedicated_sim=None, on_retire=None, copy_on="copy", _probe_no_substep=False, _time_trips=False):
+                          frame_parallel=False, sim_owner=0, dedicated_sim=None, on_retire=None, copy_on="lane", _probe_no_substep=False, _time_trips=False):
         """Throughput mode (pienerf_amd/frames.py: FramePipeline): `lanes` render streams with `depth` workspaces each, the simulator running
         `sim_ahead` frames ahead on dof snapshots, every frame's image / depth / depth_0 copied to pinned host memory on a copy stream
         (the reference's device->host boundary, trainer.py:589-592; copy_out=False leaves the results on the device).  Everything a frame
@@ -369,7 +369,7 @@ class SimRenderHarness:
         with torch.cuda.stream(self._sim_stream):
             self.sim.stepforward()
             st["sim_done"].record(self._sim_stream)
-        tail = st["copy"] if fr["host"] is not None else s0
+        tail = self._sim_stream if fr["host"] is not None else s0      # the D2H rides on the simulator stream (a 5th busy hardware queue would time-slice)
         for j in range(L):
             if st["stream"][j] is not tail:
                 tail.wait_stream(st["stream"][j])
@@ -436,8 +436,11 @@ class _HipBackend:
     """The device side of frames.FramePipeline on one MI355X: torch streams and events, the substep and one render per workspace captured
     as HIP graphs, RCCL broadcasts of the dof snapshots, D2H into pinned buffers."""
 
-    def __init__(self, h, lanes, depth, n_trips, W, H, sim_priority, sim_cus, copy_out, group, src, probe_no_substep, time_trips=False, copy_on="copy"):
-        self.copy_on = copy_on  # "copy": D2H on the copy stream; "lane": on the frame's own render stream (no fifth busy hardware queue)
+    def __init__(self, h, lanes, depth, n_trips, W, H, sim_priority, sim_cus, copy_out, group, src, probe_no_substep, time_trips=False, copy_on="lane"):
+        # stream of the per-frame D2H.  gfx950 runs 4 hardware queues concurrently and time-slices beyond that (DESIGN.md 4): with 3 render lanes +
+        # the simulator stream a copy stream of its own is a fifth busy queue (measured: 808 steps/s against 1016 with the copy on the frame's own
+        # lane).  "copy": a stream of its own; "lane": the frame's render stream; "sim": the simulator stream
+        self.copy_on = copy_on
         self.h, self.lanes, self.depth, self.trips, self.W, self.H, self.group, self.src = h, lanes, depth, n_trips, W, H, group, src
         dev, m, sim = h.device, h.model, h.sim
         self.continued = 0
