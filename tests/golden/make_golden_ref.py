@@ -137,6 +137,22 @@ def main():
                                   gridtype="hash", align_corners=False)
         out.update({f"grid_{tag}_offsets": enc.offsets.numpy().astype(np.int64), f"grid_{tag}_per_level_scale": np.float64(enc.per_level_scale),
                     f"grid_{tag}_output_dim": np.int64(enc.output_dim), f"grid_{tag}_n_embeddings": np.int64(enc.embeddings.shape[0])})
+    # ---- 7. names and arities of the three pybind backends (read from the reference's headers / bindings.cpp; data, not code)
+    import re
+    bind = {}
+    for mod, bfile, hfile in (("_raymarching", "raymarching/src/bindings.cpp", "raymarching/src/raymarching.h"),
+                              ("_gridencoder", "gridencoder/src/bindings.cpp", "gridencoder/src/gridencoder.h"),
+                              ("_shencoder", "shencoder/src/bindings.cpp", "shencoder/src/shencoder.h")):
+        names = re.findall(r'm\.def\("(\w+)"', open(os.path.join(REF, bfile)).read())
+        header = re.sub(r"//[^\n]*", "", open(os.path.join(REF, hfile)).read())
+        bind[mod] = {}
+        for n in names:
+            m = re.search(r"void\s+" + n + r"\s*\(([^;]*?)\)\s*;", header, re.S)
+            params = [p_.strip().split()[-1] for p_ in m.group(1).split(",") if p_.strip()]
+            bind[mod][n] = params
+    with open(os.path.join(HERE, "ref_bindings.json"), "w") as f:
+        json.dump(bind, f, indent=1, sort_keys=True)
+        f.write("\n")
     np.savez_compressed(os.path.join(HERE, "ref_kat.npz"), **out)
     print("wrote opts_chair.json, opts_trex.json, ref_kat.npz:", sorted(out))
 

@@ -2,6 +2,7 @@
 import hashlib
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -202,3 +203,32 @@ def test_simulator_precompute_matches_oracle_init(small_cloud, small_opt, oracle
     x = torch.randn(s.n_k * 30, dtype=torch.float64)
     assert torch.allclose(s.global_matrix @ x, (s.Ainv @ x.view(-1, 3)).reshape(-1), atol=1e-9 * float(s.Ainv.abs().max()) * 100)
     assert s.step == s.stepforward
+
+
+def test_shim_backends_match_the_reference_binding_signatures():
+    """shim/_raymarching.py, _gridencoder.py, _shencoder.py (the modules the reference's wrappers import as `_backend`) export every function of the
+    reference's pybind modules with the same parameter names in the same order — tests/golden/ref_bindings.json was read from the reference's own
+    headers by tests/golden/make_golden_ref.py."""
+    import importlib
+    import inspect
+    import json
+    shim = os.path.join(ROOT, "shim")
+    sys.path.insert(0, shim)
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "ref_bindings.json")) as f:
+            ref = json.load(f)
+        assert set(ref) == {"_raymarching", "_gridencoder", "_shencoder"}
+        for mod, fns in ref.items():
+            m = importlib.import_module(mod)
+            assert m.__file__.startswith(shim)
+            for name, params in fns.items():
+                got = list(inspect.signature(getattr(m, name)).parameters)
+                assert got == params, (mod, name, got, params)
+        # the wrapper packages resolve under the reference's names
+        for pkg, attr in (("raymarching", "march_rays_quadratic_bending"), ("gridencoder", "GridEncoder"), ("shencoder", "SHEncoder"), ("simulator.solver", "Simulator")):
+            mod = importlib.import_module(pkg)
+            assert mod.__file__.startswith(shim) and hasattr(mod, attr)
+    finally:
+        sys.path.remove(shim)
+        for k in [k for k in sys.modules if k.split(".")[0] in ("_raymarching", "_gridencoder", "_shencoder", "raymarching", "gridencoder", "shencoder", "simulator")]:
+            del sys.modules[k]
