@@ -49,6 +49,60 @@ def broadcast_tensors(tensors, src=0, group=None):
         dist.broadcast(t, src=src, group=group)
 
 
+def tile_partition(W, H, world, tile=8):
+    """Ray-tile-parallel split of ONE frame ("alternative for interactive latency"): the image is cut into tile x tile pixel
+    blocks, block b (row-major) goes to rank b % world, so that every rank gets an interleaved 1/world of the object and of the background.
+    Returns [world] int64 tensors of flat pixel (= ray) indices, each padded with -1 to the common length (all_gather needs equal sizes)."""
+    ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    block = (ys // tile) * ((W + tile - 1) // tile) + (xs // tile)
+    owner = (block % world).reshape(-1)
+    parts = [torch.nonzero(owner == r).reshape(-1) for r in range(world)]
+    n = max(p.numel() for p in parts)
+    return [torch.cat([p, torch.full((n - p.numel(),), -1, dtype=torch.int64)]) for p in parts]
+
+
+class TileParallel:
+    """One frame rendered by all ranks together: rank r renders the rays ``tile_partition(...)[r]`` and an all-gather hands every rank the
+    whole frame — latency scales down with the rank count, where the frame-parallel pipeline only scales throughput.  The sim owner broadcasts
+    the DOF snapshot (<= 82 KB) first so that every rank renders the same state.
+
+    render_subset(indices [n] int64, -1 = padding) -> float32 tensor [n, channels] on the communication device (image | depth | depth_0 = 5 channels)
+    get_dof() / set_dof(t): the owner's state / installing the received state;  sim_step(): one substep on the owner."""
+
+    def __init__(self, W, H, render_subset, get_dof, set_dof, sim_step, sim_owner=0, group=None, tile=8, device="cpu"):
+        on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        self.W, self.H, self.group, self.owner = W, H, group, sim_owner
+        self.src = dist.get_global_rank(group, sim_owner) if (on and group is not None) else sim_owner
+        self.parts = [p.to(device) for p in tile_partition(W, H, self.world, tile)]
+        self.render_subset, self.get_dof, self.set_dof, self.sim_step = render_subset, get_dof, set_dof, sim_step
+        self._recv = None
+
+    def step(self):
+        """Renders the current state (the state BEFORE this step's substep, trainer.py:300-318) and advances the simulator.  Returns the full
+        frame [H*W, channels] on every rank."""
+        if self.world > 1:
+            buf = self.get_dof() if self.rank == self.owner else (self._recv if self._recv is not None else torch.empty_like(self.get_dof()))
+            self._recv = None if self.rank == self.owner else buf
+            dist.broadcast(buf, src=self.src, group=self.group)
+            if self.rank != self.owner:
+                self.set_dof(buf)
+        mine = self.render_subset(self.parts[self.rank])
+        if self.world > 1:
+            gathered = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(gathered, mine.contiguous(), group=self.group)   # RCCL: one all-gather of 20 B x N / world per rank
+        else:
+            gathered = [mine]
+        full = torch.empty(self.W * self.H, mine.shape[1], dtype=mine.dtype, device=mine.device)
+        for part, data in zip(self.parts, gathered):
+            ok = part >= 0
+            full[part[ok]] = data[ok]
+        if self.rank == self.owner:
+            self.sim_step()
+        return full
+
+
 class FramePipeline:
     """The enqueue schedule of the pipelined / frame-parallel step.  One instance per rank; every rank calls ``step()`` once per GLOBAL frame.
 

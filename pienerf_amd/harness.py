@@ -258,6 +258,45 @@ class SimRenderHarness:
         torch.cuda.synchronize(self.device)
         return out
 
+    # ------------------------------------------------------------------ one frame split over the ranks (interactive latency)
+    @torch.no_grad()
+    def capture_tile_parallel(self, group=None, sim_owner=0, tile=8, W=None, H=None):
+        """Ray-tile-parallel form ("alternative for interactive latency"; frames.TileParallel): every rank renders an
+        interleaved 1/world of the 8 x 8 pixel tiles of the SAME frame from the sim owner's broadcast DOF snapshot, and one all-gather
+        (20 B x N / world per rank over RCCL) gives every rank the whole frame.  Unlike the frame-parallel pipeline, whose throughput is
+        capped by the time-sequential simulator, this divides the render LATENCY of a frame by the rank count.  Launches are eager."""
+        from .frames import TileParallel
+        o, m, dev = self.opt, self.model, self.device
+        W, H = W or o["W"], H or o["H"]
+        ip = tuple(torch.empty((self.sim.n_IP, c), dtype=torch.float32, device=dev) for c in (3, 9, 27))
+        self._tile_pose = torch.from_numpy(np.asarray(self.pose, np.float32)).unsqueeze(0).to(dev)
+
+        def render_subset(idx):
+            rays = get_rays(self._tile_pose, self.intrinsics, H, W, -1)
+            sel = idx.clamp(min=0)
+            self.sim.get_IP_info(out=ip)
+            m.p_def, m.IP_F, m.IP_dF = ip
+            with self._amp():
+                out = m.render_deformed(rays["rays_o"][:, sel].contiguous(), rays["rays_d"][:, sel].contiguous(), bg_color=None, perturb=False, frame_slot=800,
+                                        **self.render_kwargs())
+            return torch.cat([out["image"].view(-1, 3), out["depth"].view(-1, 1), out["depth_0"].view(-1, 1)], dim=1)
+
+        def set_dof(t):
+            self.sim.dof.copy_(t)
+        self._tile = TileParallel(W, H, render_subset, lambda: self.sim.dof, set_dof, self.sim.stepforward, sim_owner=sim_owner, group=group, tile=tile, device=dev)
+        self._tile_WH = (W, H)
+        return self
+
+    @torch.no_grad()
+    def step_tile_parallel(self, pose=None):
+        """One sim+render step; every rank gets the full frame: {'image' [1,H,W,3], 'depth' [1,H,W], 'depth_0' [1,H,W]} on the device."""
+        if pose is not None:
+            self._tile_pose.copy_(torch.from_numpy(np.asarray(pose, np.float32)).view(1, 4, 4).to(self.device))
+        full = self._tile.step()
+        W, H = self._tile_WH
+        self.frame += 1
+        return {"image": full[:, :3].reshape(1, H, W, 3), "depth": full[:, 3].reshape(1, H, W), "depth_0": full[:, 4].reshape(1, H, W)}
+
     # ------------------------------------------------------------------ a frame rendered in ray batches (BASELINE.json configs[4])
     @torch.no_grad()
     def capture_staged(self, batch=None, n_trips=None, W=None, H=None, copy_out=True, streams=3):

@@ -120,3 +120,45 @@ def test_simulated_backend_catches_a_missing_dependency():
         except AssertionError:
             hit += 1
     assert hit > 0
+
+
+def _tile_worker(rank, world, port, W, H, n_frames, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pienerf_amd.frames import TileParallel
+    state = {"dof": torch.arange(64, dtype=torch.float64) * (1.0 if rank == 0 else -3.0), "steps": 0}
+
+    def render_subset(idx):   # "pixel" = f(ray index, state): 5 channels like image | depth | depth_0
+        base = idx.clamp(min=0).to(torch.float32)[:, None] * torch.tensor([1.0, 2.0, 3.0, 0.5, 0.25])
+        return (base + float(state["dof"].sum()) * 1e-3).to(torch.float32)
+
+    def sim_step():
+        state["dof"] = state["dof"] * 1.01 + 0.5
+        state["steps"] += 1
+    tp = TileParallel(W, H, render_subset, lambda: state["dof"], lambda t: state.__setitem__("dof", t.clone()), sim_step)
+    frames = [tp.step().numpy().copy() for _ in range(n_frames)]
+    assert state["steps"] == (n_frames if rank == 0 else 0)
+    np.save(os.path.join(out_dir, f"t{rank}.npy"), np.stack(frames))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H", [(2, 40, 24), (4, 50, 30), (3, 17, 9)])
+def test_tile_parallel_frames(tmp_path, world, W, H):
+    """Ray-tile-parallel rendering of one frame: interleaved 8 x 8 tiles per rank, DOF broadcast, all-gather — every rank ends up
+    with the whole frame of the owner's state, also when the tile count does not divide evenly (padding)."""
+    from pienerf_amd.frames import tile_partition
+    parts = tile_partition(W, H, world)
+    flat = torch.cat([p[p >= 0] for p in parts])
+    assert sorted(flat.tolist()) == list(range(W * H)) and len({p.numel() for p in parts}) == 1
+    assert all((p[p >= 0] // W // 8 * ((W + 7) // 8) + p[p >= 0] % W // 8) .remainder(world).eq(r).all() for r, p in enumerate(parts))
+    n_frames = 4
+    mp.spawn(_tile_worker, args=(world, _free_port(), W, H, n_frames, str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(tmp_path / f"t{r}.npy") for r in range(world)]
+    dof = np.arange(64, dtype=np.float64)
+    for f in range(n_frames):
+        want = (np.arange(W * H, dtype=np.float32)[:, None] * np.float32([1.0, 2.0, 3.0, 0.5, 0.25]) + np.float32(dof.sum() * 1e-3)).astype(np.float32)
+        for r in range(world):
+            assert np.allclose(got[r][f], want, rtol=1e-6, atol=1e-4), (f, r)
+        dof = dof * 1.01 + 0.5

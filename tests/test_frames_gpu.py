@@ -95,3 +95,36 @@ def test_frame_parallel_single_rank_equals_pipelined(tmp_path):
     assert [i for i, _ in got] == list(range(7))
     for f in range(7):
         assert np.array_equal(got[f][1], want[f][0].cpu().numpy()), f
+
+
+def _tile_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pienerf_amd.harness import SimRenderHarness
+    opt, cloud, ckpt = _scene()
+    h = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device="cuda:0", overlap_sim=False).capture_tile_parallel()
+    frames = [h.step_tile_parallel()["image"][0].cpu().numpy() for _ in range(4)]
+    np.save(os.path.join(out_dir, f"t{rank}.npy"), np.stack(frames))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_parallel_two_ranks_on_gpu(tmp_path):
+    """Ray-tile-parallel rendering (harness.capture_tile_parallel): two gloo ranks on the one GPU each render half of the 8 x 8 tiles of every frame from
+    rank 0's broadcast DOFs; both end up with the whole frame, equal to the single-process eager frame bit for bit (rays are independent)."""
+    import torch.multiprocessing as mp
+    from pienerf_amd.harness import SimRenderHarness
+    opt, cloud, ckpt = _scene()
+    eager = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device="cuda:0")
+    want = [eager.step()["image"][0].clone().cpu().numpy() for _ in range(4)]
+    eager.synchronize()
+    del eager
+    torch.cuda.empty_cache()
+    mp.spawn(_tile_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = np.load(tmp_path / f"t{r}.npy")
+        for f in range(4):
+            assert np.array_equal(got[f], want[f]), (r, f)
+    assert np.abs(want[0] - want[3]).max() > 1e-4

@@ -167,3 +167,66 @@ def test_frame_independent_of_tail_rounds(deformed_ip_state, small_opt, ckpt, ta
     assert st0["samples"] == st1["samples"] > 2000 and st0["trips"] == st1["trips"]
     # same samples, but the sample LIST order (the order the network kernel visits them in) differs: per-ray compositing is unchanged
     assert torch.equal(alt["image"], img0) and torch.equal(alt["depth_0"], d0)
+
+
+def test_calc_elastic_on_adversarial_deformation_gradients():
+    """pn_sim_calc_elastic (k_elastic: cyclic-Jacobi SVD with rcp/rsq + Newton instead of IEEE div/sqrt, det-+1 contract of wp.svd3, volume
+    projection) on deformation gradients that decide R = U V^T: inverted (det < 0), rank 2, rank 1, zero, repeated singular values, pure
+    rotations, 1e-12- and 1e+8-scaled, plus random ones — against the CPU oracle (1e-9) and, where F is non-singular, against the polar
+    rotation of numpy.linalg.svd (cuda_utils.py:83-121)."""
+    import ctypes as C
+    from pienerf_amd._lib import check, lib, ptr, stream_ptr
+    rng = np.random.default_rng(0)
+
+    def rot(axis, ang):
+        axis = np.asarray(axis, float) / np.linalg.norm(axis)
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+    Q1, Q2 = rot([1, 2, 3], 0.7), rot([-2, 1, 0.5], 2.1)
+    mats = [np.eye(3) + 0.3 * rng.standard_normal((3, 3)) for _ in range(300)]
+    mats += [m @ np.diag([1, 1, -1]) for m in mats[:80]]                                       # inverted elements
+    mats += [Q1 @ np.diag(s) @ Q2.T for s in ([2.0, 2.0, 0.5], [1.5, 1.5, 1.5], [3.0, 1.0, 1.0], [1.0, 1.0, -1.0], [2.0, 2.0, -2.0])]  # repeated sigma
+    mats += [Q1, Q2, Q1 @ Q2, np.eye(3), -np.eye(3)]                                            # rotations, identity, full inversion
+    mats += [Q1 @ np.diag([2.0, 0.7, 0.0]) @ Q2.T, Q1 @ np.diag([1.3, 0.0, 0.0]) @ Q2.T, np.outer([1, 2, 3], [0.5, -1, 2.0]), np.zeros((3, 3))]  # rank 2 / 1 / 0
+    mats += [1e-12 * (np.eye(3) + 0.2 * rng.standard_normal((3, 3))), 1e8 * (np.eye(3) + 0.2 * rng.standard_normal((3, 3))),
+             Q1 @ np.diag([2.0, 0.5, 1e-9]) @ Q2.T, Q1 @ np.diag([1.0, 1.0 + 1e-13, 1.0 - 1e-13]) @ Q2.T]
+    Fs = np.stack(mats)
+    n = len(Fs)
+    # one kernel per IP slot whose affine DOF rows are the identity: F[r][c] = sum_i dNx[v, i, c, 1 + r]
+    topo = np.tile(np.arange(8, dtype=np.int32), (n, 1))
+    dof = np.zeros((8, 10, 3))
+    for j in range(3):
+        dof[:, 1 + j, j] = 1.0
+    dNx = np.zeros((n, 8, 3, 10))
+    part = rng.uniform(0.05, 1.0, (n, 8))
+    part /= part.sum(1, keepdims=True)                                                         # F split over the 8 neighbours (sums back to F)
+    for r in range(3):
+        for c in range(3):
+            dNx[:, :, c, 1 + r] = Fs[:, r, c][:, None] * part
+    RF_ref, VF_ref, FF_ref = oracle.calc_elastic(topo, dNx, dof.reshape(-1, 3))
+    RF, VF, FF = (torch.empty(n, 3, 3, dtype=torch.float64, device=DEV) for _ in range(3))
+    check(lib().pn_sim_calc_elastic(n, ptr(T(topo)), ptr(T(dNx)), ptr(T(dof.reshape(-1))), ptr(RF), ptr(VF), ptr(FF), stream_ptr()), "calc_elastic")
+    RF, VF, FF = RF.cpu().numpy(), VF.cpu().numpy(), FF.cpu().numpy()
+    assert np.all(np.isfinite(RF)) and np.all(np.isfinite(VF))
+    scale = np.maximum(1.0, np.abs(Fs).max(axis=(1, 2)))[:, None, None]
+    assert np.abs(FF - Fs).max() / 1.0 < 1e-9 * scale.max() and np.abs((FF - Fs) / scale).max() < 1e-12   # U diag(sigma) V^T reassembles F
+    dets = np.linalg.det(Fs)
+    well = np.abs(dets) > 1e-6 * scale[:, 0, 0] ** 3                                           # non-singular, sigma gaps irrelevant for R
+    # R is a proper rotation for EVERY input (the det-+1 contract), also the inverted / rank-deficient ones
+    assert np.abs(np.einsum("nij,nkj->nik", RF, RF) - np.eye(3)).max() < 1e-9 and np.abs(np.linalg.det(RF) - 1).max() < 1e-9
+    for i in np.flatnonzero(well):
+        U, s, Vt = np.linalg.svd(Fs[i])
+        if np.linalg.det(U @ Vt) < 0:
+            U[:, -1] *= -1
+        gap = s[1] - s[2] if dets[i] < 0 else 1.0                                              # an inverted F with sigma_2 = sigma_3 has no unique R
+        if gap > 1e-6 * s[0]:
+            assert np.abs(RF[i] - U @ Vt).max() < 1e-8, (i, np.abs(RF[i] - U @ Vt).max())
+    # against the oracle wherever the answer is unique (R for well-conditioned F; V F always up to the same uniqueness)
+    uniq = well.copy()
+    for i in np.flatnonzero(well):
+        s = np.linalg.svd(Fs[i], compute_uv=False)
+        if dets[i] < 0 and s[1] - s[2] < 1e-6 * s[0]:
+            uniq[i] = False
+    assert np.abs(RF[uniq] - RF_ref[uniq]).max() < 1e-9
+    assert np.abs((VF[uniq] - VF_ref[uniq]) / scale[uniq]).max() < 1e-9
+    assert uniq.sum() > 350 and (~well).sum() >= 5
