@@ -412,6 +412,10 @@ struct MarchIO {
     struct TailEntry* tail;
     int* tail_count;
     int max_rounds;
+    // optional (trip 0 of the frame driver): k_march_skip lists the alive slots that still have something to march — nine rays in ten miss the
+    // object's bounding box or run out of it inside the IP-free cells — and k_march walks that list instead of all n_alive slots
+    int* active;
+    int* active_count;
 };
 
 // One lane per ray slot: fast-forward over the leading run of IP-free search cells.
@@ -419,10 +423,28 @@ __global__ void __launch_bounds__(256) k_march_skip(pnm::MarchParams a, pnm2::Ma
     uint32_t n_alive = io.n_alive;
     if (io.trip) n_alive = (uint32_t)io.trip->n_alive;
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
-    if (n >= n_alive) return;
-    unsigned n_iter = 0;
-    io.t_resume[n] = pnm2::skip_empty_cells(a, tb, io.rays_alive[n], io.noises ? io.noises[n] : 0.0f, &n_iter);
-    if (a.stats && n_iter) atomicAdd(a.stats, (unsigned long long)n_iter);
+    bool work = false;
+    if (n < n_alive) {
+        unsigned n_iter = 0;
+        const int index = io.rays_alive[n];
+        const float t = pnm2::skip_empty_cells(a, tb, index, io.noises ? io.noises[n] : 0.0f, &n_iter);
+        io.t_resume[n] = t;
+        if (a.stats && n_iter) atomicAdd(a.stats, (unsigned long long)n_iter);
+        work = t < a.fars[index];
+        if (io.active && !work) {  // nothing left to march: k_march will not visit the slot, so its (single, n_step == 1) sample slot is ended here
+            const uint32_t n_step = (uint32_t)io.trip->n_step;
+            float* dl = io.deltas + (size_t)n * n_step * 2;
+            for (uint32_t s2 = 0; s2 < n_step; s2++) { dl[2 * s2] = 0.0f; dl[2 * s2 + 1] = 0.0f; }
+        }
+    }
+    if (io.active) {  // wave-aggregated append (order is irrelevant: every listed slot is processed independently)
+        const unsigned long long m = __ballot(work);
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(io.active_count, (int)__popcll(m));
+        base = __shfl(base, 0);
+        if (work) io.active[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int)n;
+    }
 }
 
 // ---- the per-ray march (pn_march3.h): pass 1 = k_march (8 lanes per ray, bounded number of rounds), pass 2 = k_march_tail
@@ -448,8 +470,10 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams 
     const int budget = io.tail ? io.max_rounds : 0x7fffffff;
     // 32-ray chunks are dealt round-robin to a bounded grid: in frame mode the alive count is only known on the device, and a
     // grid sized for all N rays would push ~20 000 mostly empty workgroups through the dispatcher on every trip
-    for (uint32_t chunk = blockIdx.x; chunk * 32u < n_alive; chunk += gridDim.x) {
-        const uint32_t n = chunk * 32u + (threadIdx.x >> 3);
+    const uint32_t n_work = io.active ? (uint32_t)__hip_atomic_load(io.active_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n_alive;
+    for (uint32_t chunk = blockIdx.x; chunk * 32u < n_work; chunk += gridDim.x) {
+        const uint32_t i_work = chunk * 32u + (threadIdx.x >> 3);
+        const uint32_t n = io.active ? (i_work < n_work ? (uint32_t)io.active[i_work] : 0xffffffffu) : i_work;
         uint32_t emitted = 0;
         bool deferred = false;
         float* dl = nullptr;
@@ -603,7 +627,7 @@ extern "C" int pn_march_rays_quadratic_bending(const int* pig_cnt, const int* pi
                                                C, H, grid, fars, err_flag);
         pnm2::March2Tables tb{s.nb_bgn, s.nb, (const float4*)s.rec};
         MarchIO io{n_alive, n_step, rays_alive, xyzs, dirs, deltas, noises, nullptr, nullptr, (float*)(pool + off_res),
-                   (TailEntry*)(pool + off_tail + 16), (int*)(pool + off_tail), (int)march_tail_rounds()};
+                   (TailEntry*)(pool + off_tail + 16), (int*)(pool + off_tail), (int)march_tail_rounds(), nullptr, nullptr};
         if (io.t_resume) k_march_skip<<<pn_div_up(n_alive, 256), 256, 0, st>>>(a, tb, io);
         launch_march(num_seek_IP, pn_div_up(n_alive, 32), std::min(pn_div_up(n_alive, 4), 2048u), st, a, tb, io);
     }
@@ -1436,8 +1460,10 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             int* nxt = (t & 1) ? f->alive_a : f->alive_b;
             // trip 0 (every ray, one sample each) is dominated by rays crossing IP-free cells: a one-lane-per-ray pre-pass
             // fast-forwards them; its per-ray resume point lives in `sigmas`, which is not written before this trip's network launch
+            // ... and lists the slots that still have work (in `nxt`, which nobody reads before this trip's compaction writes it; the counter is
+            // the spare last entry of the per-trip tail counters, zeroed by k_frame_rays)
             MarchIO io{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + t, f->list, (t == 0) ? f->sigmas : nullptr,
-                       f->tail, f->tail_counts + t, (int)march_tail_rounds()};
+                       f->tail, f->tail_counts + t, (int)march_tail_rounds(), (t == 0) ? nxt : nullptr, (t == 0) ? f->tail_counts + PN_MAX_TRIPS + 1 : nullptr};
             const bool timed = (f->march_counters_on & 2) && t < PN_TIMED_TRIPS;
             bool stamp = false;
             if (timed) {  // measurement mode: the two heavy launch groups of each trip are bracketed on the launch stream
