@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpienerf_hip.so")
+LIB_PATH = os.environ.get("PN_LIB_PATH") or os.path.join(_HERE, "lib", "libpienerf_hip.so")  # PN_LIB_PATH: tuning builds (tools/build_variant.py)
 
 P = C.c_void_p
 u32, i32, f32, f64, u64 = C.c_uint32, C.c_int, C.c_float, C.c_double, C.c_uint64

@@ -459,7 +459,9 @@ struct TailEntry {
 // occupancy, but their register footprint decides what else fits beside them: with 3 waves x 146 VGPRs a SIMD had no room left
 // for a wave of the simulator's kernels (k_elastic: 94), and the substep running concurrently on its own stream cost the
 // pipelined step 5 % more than it does now (measured)
+#ifndef PN_MARCH_WAVES
 #define PN_MARCH_WAVES 4
+#endif
 
 // 8 lanes per ray, 32 rays per 256-thread block.
 template <int K, bool MULTI>

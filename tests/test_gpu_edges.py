@@ -207,7 +207,10 @@ def test_calc_elastic_on_adversarial_deformation_gradients():
     RF, VF, FF = (torch.empty(n, 3, 3, dtype=torch.float64, device=DEV) for _ in range(3))
     check(lib().pn_sim_calc_elastic(n, ptr(T(topo)), ptr(T(dNx)), ptr(T(dof.reshape(-1))), ptr(RF), ptr(VF), ptr(FF), stream_ptr()), "calc_elastic")
     RF, VF, FF = RF.cpu().numpy(), VF.cpu().numpy(), FF.cpu().numpy()
-    assert np.all(np.isfinite(RF)) and np.all(np.isfinite(VF))
+    # R is finite for every input; V F is finite exactly where the oracle's (= the reference's arithmetic) is: for F = 0 volume_invariant_project
+    # divides 0 by |grad C|^2 = 0 (func_utils.py:21-40) and the reference itself produces NaN there
+    assert np.all(np.isfinite(RF)) and np.array_equal(np.isfinite(VF), np.isfinite(VF_ref))
+    assert np.isfinite(VF).all(axis=(1, 2)).sum() >= n - 1
     scale = np.maximum(1.0, np.abs(Fs).max(axis=(1, 2)))[:, None, None]
     assert np.abs(FF - Fs).max() / 1.0 < 1e-9 * scale.max() and np.abs((FF - Fs) / scale).max() < 1e-12   # U diag(sigma) V^T reassembles F
     dets = np.linalg.det(Fs)
