@@ -204,7 +204,7 @@ __device__ __forceinline__ void eval_point(const MarchParams& a, const March2Tab
                     if (k < n_IP) {
                         float pw[3];
                         r.n_warp++;
-                        const float4* __restrict__ rp = tb.rec + (size_t)ips[k] * 11;
+                        const float4* __restrict__ rp = tb.rec + (size_t)ips[k] * PN_REC_VEC4;
                         const float4 rh[4] = {rp[0], rp[1], rp[2], rp[3]};  // loaded per IP: prefetching all K heads costs 48 VGPRs
                         if (warp_record<MULTI>(rh, rp, a.max_iter_num, a.IP_dx, x, y, z, pw, &dk[k])) n_IP--;
                         ps[3 * k] = pw[0]; ps[3 * k + 1] = pw[1]; ps[3 * k + 2] = pw[2];

@@ -365,18 +365,13 @@ __global__ void __launch_bounds__(256) k_nb_fill(int n_grid_max, const int* __re
     }
 }
 
-// rec[ip] = p_ori(3) p_def(3) F(9) dF(27) pad(2)
+// rec[ip]: see pn_march2.h (pack_ip_float)
 __global__ void __launch_bounds__(256) k_pack_ip(int n_vtx, const float* __restrict__ p_ori, const float* __restrict__ p_def,
                                                  const float* __restrict__ F_IP, const float* __restrict__ dF_IP, float* __restrict__ rec) {
     const int t = threadIdx.x + blockIdx.x * blockDim.x;
-    const int ip = t / 44, j = t % 44;
+    const int ip = t / PN_REC_FLOATS, j = t % PN_REC_FLOATS;
     if (ip >= n_vtx) return;
-    float v = 0.f;
-    if (j < 3) v = p_ori[ip * 3 + j];
-    else if (j < 6) v = p_def[ip * 3 + j - 3];
-    else if (j < 15) v = F_IP[ip * 9 + j - 6];
-    else if (j < 42) v = dF_IP[ip * 27 + j - 15];
-    rec[t] = v;
+    rec[t] = pnm2::pack_ip_float(j, ip, p_ori, p_def, F_IP, dF_IP);
 }
 
 struct MarchSide {  // device buffers of the side tables
@@ -394,7 +389,7 @@ static int march_side_build(const MarchSide& s, int n_vtx, int n_grid_max, const
     k_nb_count<<<gz, 256, 0, st>>>(n_grid_max, n_grid_dev, res, pig_cnt, swap, s.nb_cnt);
     launch_cell_scan(n_grid_max, n_grid_dev, s.nb_cnt, s.nb_bgn, s.nb_cursor, st);
     k_nb_fill<<<gz, 256, 0, st>>>(n_grid_max, n_grid_dev, res, pig_cnt, pig_bgn, pig_idx, p_def, swap, s.nb_cnt, s.nb_bgn, s.nb, s.nb_capacity, err_flag);
-    k_pack_ip<<<pn_div_up((uint64_t)n_vtx * 44, 256), 256, 0, st>>>(n_vtx, p_ori, p_def, F_IP, dF_IP, s.rec);
+    k_pack_ip<<<pn_div_up((uint64_t)n_vtx * PN_REC_FLOATS, 256), 256, 0, st>>>(n_vtx, p_ori, p_def, F_IP, dF_IP, s.rec);
     PN_LAUNCH_CHECK();
     return PN_OK;
 }
@@ -614,7 +609,7 @@ extern "C" int pn_march_rays_quadratic_bending(const int* pig_cnt, const int* pi
     MarchSide s;
     s.nb_capacity = 27 * n_vtx;
     char* pool = nullptr;
-    const size_t ints = ((size_t)n_grid + 1) * 3 * sizeof(int), nbb = (size_t)s.nb_capacity * sizeof(float4), recb = (size_t)n_vtx * 44 * sizeof(float);
+    const size_t ints = ((size_t)n_grid + 1) * 3 * sizeof(int), nbb = (size_t)s.nb_capacity * sizeof(float4), recb = (size_t)n_vtx * PN_REC_FLOATS * sizeof(float);
     const size_t off_nb = (ints + 255) & ~(size_t)255, off_rec = (off_nb + nbb + 255) & ~(size_t)255;
     const size_t off_res = (off_rec + recb + 255) & ~(size_t)255;
     const size_t off_tail = (off_res + (size_t)n_alive * sizeof(float) + 255) & ~(size_t)255;  // [tail counter | 16 B pad | tail entries]
@@ -1213,14 +1208,9 @@ __global__ void __launch_bounds__(256) k_frame_lists(int n_grid_max, const int* 
                                                      float* __restrict__ rec) {
     if ((int)blockIdx.x >= list_blocks) {  // k_pack_ip
         const int t = threadIdx.x + ((int)blockIdx.x - list_blocks) * 256;
-        const int ip = t / 44, j = t % 44;
+        const int ip = t / PN_REC_FLOATS, j = t % PN_REC_FLOATS;
         if (ip >= n_vtx) return;
-        float v = 0.f;
-        if (j < 3) v = p_ori[ip * 3 + j];
-        else if (j < 6) v = p_def[ip * 3 + j - 3];
-        else if (j < 15) v = F_IP[ip * 9 + j - 6];
-        else if (j < 42) v = dF_IP[ip * 27 + j - 15];
-        rec[t] = v;
+        rec[t] = pnm2::pack_ip_float(j, ip, p_ori, p_def, F_IP, dF_IP);
         return;
     }
     const int n_grid = min(*n_grid_dev, n_grid_max);
@@ -1320,7 +1310,7 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
     PN_ALLOC(f->side.nb_cnt, ((size_t)max_grid_cells + 1) * 4); PN_ALLOC(f->side.nb_bgn, ((size_t)max_grid_cells + 1) * 4);
     PN_ALLOC(f->side.nb_cursor, ((size_t)max_grid_cells + 1) * 4);
     f->side.nb_capacity = 27 * (int)max_vtx;
-    PN_ALLOC(f->side.nb, (size_t)f->side.nb_capacity * sizeof(float4)); PN_ALLOC(f->side.rec, (size_t)max_vtx * 44 * 4);
+    PN_ALLOC(f->side.nb, (size_t)f->side.nb_capacity * sizeof(float4)); PN_ALLOC(f->side.rec, (size_t)max_vtx * PN_REC_FLOATS * 4);
     PN_ALLOC(f->tail, N * sizeof(TailEntry)); PN_ALLOC(f->tail_counts, sizeof(int) * (PN_MAX_TRIPS + 2));
     PN_ALLOC(f->trips, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)); PN_ALLOC(f->dev, sizeof(PnFrameDev)); PN_ALLOC(f->cut_bounds, 6 * 4);
 #undef PN_ALLOC
@@ -1435,7 +1425,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     if (!is_static && !keep_tables) {
         f->tables_n_vtx = n_vtx;
         const int list_blocks = (int)std::min(pn_div_up((uint64_t)f->max_cells * 8, 256), 2048u);
-        const int pack_blocks = (int)pn_div_up((uint64_t)n_vtx * 44, 256);
+        const int pack_blocks = (int)pn_div_up((uint64_t)n_vtx * PN_REC_FLOATS, 256);
         k_frame_lists<<<list_blocks + pack_blocks, 256, 0, st>>>((int)f->max_cells, n_grid_dev, res, f->pig_cnt, f->pig_bgn, f->pig_idx, p_def, swap,
                                                                  f->side.nb_cnt, f->side.nb_bgn, f->side.nb, f->side.nb_capacity, err, list_blocks, n_vtx,
                                                                  p_ori, F_IP, dF_IP, f->side.rec);

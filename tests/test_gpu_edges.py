@@ -205,7 +205,9 @@ def test_calc_elastic_on_adversarial_deformation_gradients():
             dNx[:, :, c, 1 + r] = Fs[:, r, c][:, None] * part
     RF_ref, VF_ref, FF_ref = oracle.calc_elastic(topo, dNx, dof.reshape(-1, 3))
     RF, VF, FF = (torch.empty(n, 3, 3, dtype=torch.float64, device=DEV) for _ in range(3))
-    check(lib().pn_sim_calc_elastic(n, ptr(T(topo)), ptr(T(dNx)), ptr(T(dof.reshape(-1))), ptr(RF), ptr(VF), ptr(FF), stream_ptr()), "calc_elastic")
+    topo_d, dNx_d, dof_d = T(topo), T(dNx), T(dof.reshape(-1))   # kept alive until the kernel has run
+    check(lib().pn_sim_calc_elastic(n, ptr(topo_d), ptr(dNx_d), ptr(dof_d), ptr(RF), ptr(VF), ptr(FF), stream_ptr()), "calc_elastic")
+    torch.cuda.synchronize()
     RF, VF, FF = RF.cpu().numpy(), VF.cpu().numpy(), FF.cpu().numpy()
     # R is finite for every input; V F is finite exactly where the oracle's (= the reference's arithmetic) is: for F = 0 volume_invariant_project
     # divides 0 by |grad C|^2 = 0 (func_utils.py:21-40) and the reference itself produces NaN there
