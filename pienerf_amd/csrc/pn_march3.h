@@ -123,7 +123,7 @@ __device__ __forceinline__ void eval_point(const MarchParams& a, const March2Tab
         const int g2 = (int)floorf((z - c.bmin2) / a.hgs);
         const bool oob = (g0 < 0 || g1 < 0 || g2 < 0 || g0 >= c.r0 || g1 >= c.r1 || g2 >= c.r2);
         r.oob = oob;
-        int ord[3] = {-1, -1, -1};  // list positions of the selected candidates, nearest first
+        int ips[3] = {-1, -1, -1};  // the selected IPs, nearest first
         if (!oob) {
             const int gid = g2 * c.r1 * c.r0 + g1 * c.r0 + g0;
             const int b = tb.nb_bgn[gid], e = tb.nb_bgn[gid + 1];
@@ -136,63 +136,75 @@ __device__ __forceinline__ void eval_point(const MarchParams& a, const March2Tab
                     const float4 v = tb.nb[j];
                     const float ax = v.x - x, ay = v.y - y, az = v.z - z;
                     const float d = ax * ax + ay * ay + az * az;
-                    if (d < best) { best = d; ord[0] = j; }
+                    if (d < best) { best = d; ips[0] = __float_as_int(v.w); }
                 }
-                if (ord[0] == -1) {
+                if (ips[0] == -1) {
                     for (int j = b + own; j < e; j++) {
                         const float4 v = tb.nb[j];
                         const float ax = v.x - x, ay = v.y - y, az = v.z - z;
                         const float d = ax * ax + ay * ay + az * az;
-                        if (d < best) { best = d; ord[0] = j; }
+                        if (d < best) { best = d; ips[0] = __float_as_int(v.w); }
                     }
                 }
             } else {
-                // find_closest_IPs (:1045-1118): all 27 cells in visiting order (= list order), insertion on strict '<'
+                // find_closest_IPs (:1045-1118): all 27 cells in visiting order (= list order), insertion on strict '<'.  Written as selects
+                // on the three comparisons (d0 <= d1 <= d2 always, so d < d0 implies d < d1 implies d < d2 and the reference's
+                // if / else-if chain is exactly this): the compiler's branchy form of the chain cost ~55 instructions and four
+                // exec-mask branches per candidate, this one 21 and none.  The IP id travels with the distance, so the selected
+                // entries need no second fetch.
                 float d0 = FLT_MAX, d1 = FLT_MAX, d2 = FLT_MAX;
-                for (int j0 = b; j0 < e; j0 += PN_CAND_FLIGHT) {  // entries in flight per round trip
+                auto insert = [&](const float4& v, bool valid) {
+                    const float ax = v.x - x, ay = v.y - y, az = v.z - z;
+                    const float d = ax * ax + ay * ay + az * az;
+                    const int id = __float_as_int(v.w);
+                    const bool c0 = valid && d < d0, c1 = valid && d < d1, c2 = valid && d < d2;
+                    if (K > 2) {
+                        ips[2] = c1 ? ips[1] : (c2 ? id : ips[2]);
+                        d2 = c1 ? d1 : (c2 ? d : d2);
+                    }
+                    ips[1] = c0 ? ips[0] : (c1 ? id : ips[1]);
+                    d1 = c0 ? d0 : (c1 ? d : d1);
+                    ips[0] = c0 ? id : ips[0];
+                    d0 = c0 ? d : d0;
+                };
+                int j0 = b;
+                for (; j0 + PN_CAND_FLIGHT <= e; j0 += PN_CAND_FLIGHT) {  // entries in flight per round trip
+                    const float4* __restrict__ q = tb.nb + j0;
                     float4 v[PN_CAND_FLIGHT];
 #pragma unroll
-                    for (int u = 0; u < PN_CAND_FLIGHT; u++) v[u] = tb.nb[min(j0 + u, e - 1)];
+                    for (int u = 0; u < PN_CAND_FLIGHT; u++) v[u] = q[u];
 #pragma unroll
-                    for (int u = 0; u < PN_CAND_FLIGHT; u++) {
-                        const int j = j0 + u;
-                        const float ax = v[u].x - x, ay = v[u].y - y, az = v[u].z - z;
-                        const float d = ax * ax + ay * ay + az * az;
-                        if (j < e) {
-                            if (d < d0) {
-                                if (K > 2) { d2 = d1; ord[2] = ord[1]; }
-                                d1 = d0; ord[1] = ord[0];
-                                d0 = d; ord[0] = j;
-                            } else if (d < d1) {
-                                if (K > 2) { d2 = d1; ord[2] = ord[1]; }
-                                d1 = d; ord[1] = j;
-                            } else if (K > 2 && d < d2) {
-                                d2 = d; ord[2] = j;
-                            }
-                        }
-                    }
+                    for (int u = 0; u < PN_CAND_FLIGHT; u++) insert(v[u], true);
+                }
+                if (j0 < e) {
+                    float4 v[PN_CAND_FLIGHT - 1];
+#pragma unroll
+                    for (int u = 0; u < PN_CAND_FLIGHT - 1; u++) v[u] = tb.nb[min(j0 + u, e - 1)];
+#pragma unroll
+                    for (int u = 0; u < PN_CAND_FLIGHT - 1; u++) insert(v[u], j0 + u < e);
                 }
             }
         }
-        int n_IP = (ord[0] != -1) + (ord[1] != -1) + (ord[2] != -1);
+        int n_IP = (ips[0] != -1) + (ips[1] != -1) + (ips[2] != -1);
         found = n_IP > 0;
         if (found) {
-            // the selected candidates' entries are fetched for all K at once — the pre-filter loop below, whose bound shrinks as it
-            // runs, then works on registers
-            float4 cnd[3];
-            int ips[3];
+            // the selected IPs' record heads (p_ori, p_def, F^-1: 64 B each) are fetched for all K at once — the pre-filter loop
+            // below, whose bound shrinks as it runs, and the first Newton step then work on registers
+            float4 rh[3][4];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                cnd[k] = tb.nb[(k < K && ord[k] >= 0) ? ord[k] : ord[0]];
-                ips[k] = __float_as_int(cnd[k].w);
+                if (k < K) {
+                    const float4* __restrict__ rp = tb.rec + (size_t)(ips[k] >= 0 ? ips[k] : ips[0]) * PN_REC_VEC4;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) rh[k][u] = rp[u];
+                }
             }
-            // pre-filter (:1246-1251): `n_IP--` inside the loop it bounds, strict '<' on z only
+            // pre-filter (:1246-1251) on the candidates' deformed positions: `n_IP--` inside the loop it bounds, strict '<' on z only
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 if (k < n_IP) {
-                    if (cnd[k].x <= c.bmin0 || cnd[k].y <= c.bmin1 || cnd[k].z < c.bmin2 || cnd[k].x >= c.bmax0 || cnd[k].y >= c.bmax1 ||
-                        cnd[k].z >= c.bmax2)
-                        n_IP--;
+                    const float cx = rh[k][0].w, cy = rh[k][1].x, cz = rh[k][1].y;  // p_def
+                    if (cx <= c.bmin0 || cy <= c.bmin1 || cz < c.bmin2 || cx >= c.bmax0 || cy >= c.bmax1 || cz >= c.bmax2) n_IP--;
                 }
             }
             if (n_IP <= 0) found = false;
@@ -205,8 +217,7 @@ __device__ __forceinline__ void eval_point(const MarchParams& a, const March2Tab
                         float pw[3];
                         r.n_warp++;
                         const float4* __restrict__ rp = tb.rec + (size_t)ips[k] * PN_REC_VEC4;
-                        const float4 rh[4] = {rp[0], rp[1], rp[2], rp[3]};  // loaded per IP: prefetching all K heads costs 48 VGPRs
-                        if (warp_record<MULTI>(rh, rp, a.max_iter_num, a.IP_dx, x, y, z, pw, &dk[k])) n_IP--;
+                        if (warp_record<MULTI>(rh[k], rp, a.max_iter_num, a.IP_dx, x, y, z, pw, &dk[k])) n_IP--;
                         ps[3 * k] = pw[0]; ps[3 * k + 1] = pw[1]; ps[3 * k + 2] = pw[2];
                     }
                 }
