@@ -16,12 +16,11 @@ OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libpienerf_hip.so")
 ARCH = "gfx950"
 
-# -fno-slp-vectorize: no packed-fp32 VALU (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) anywhere in the library.  On gfx950 a wave
-# issuing them while ANOTHER wave of the same SIMD has a v_mfma_f32_32x32x16_bf16 in flight corrupts columns 16..31 of that MFMA's
-# result (measured: 16-sample blocks of the network output off by ~1e-2, run to run; inputs, LDS operands and split pieces verified
-# bit-stable, isolating the MFMA groups with barriers and 64-cycle s_nop changes nothing, removing the packed ops removes every
-# error in 300 x 1M-sample launches — DESIGN.md 4.2).  Every kernel here can be co-resident with the network kernel (render lanes,
-# simulator stream), so the flag is library-wide; tests/test_host.py checks the shipped ISA for it.
+# -fno-slp-vectorize: -O3 does not pack adjacent scalar fp32 adds / multiplies into v_pk_{add,mul,fma}_f32 on its own.  Beside MFMA chains
+# (the network kernels) each packed op costs ~20 extra cycles (MI355X_MICROARCH.md, fillers beside MFMAs), and the bit-exact ray-side code
+# wants the operation order of its source.  (Packed fp32 written explicitly for the march's candidate scan — quads of candidates in SoA
+# form, two distances per instruction — was measured and is no faster: the padding it needs costs what the packing saves.)  Round 1 justified the flag with a suspected gfx950 erratum (packed VALU corrupting another wave's
+# bf16 MFMA); tools/repro_pk_mfma.hip did not reproduce it (profiles/r02_repro_pk_mfma.json) and the claim is withdrawn.
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-Wall",
           "-Wno-unused-function", "-Wno-unused-variable"]
 # per-translation-unit flags: the ray-side kernels round every operation once, in source order (bit-exact integer

@@ -46,6 +46,39 @@ struct RayState {
 
 __device__ __forceinline__ float dtf(const MarchParams& a, const RayConsts& c, float t) { return clampf(t * a.dt_gamma, c.dt_min, c.dt_max); }
 
+// Fixed-step lattice arithmetic.  With dt_gamma == 0 (the chair option set) every step adds the same float D, and inside one binade
+// [2^e, 2^(e+1)) — where every float is a multiple of u = 2^(e-23) — the rounded sum fl(s + D) is s + Dq with Dq = D rounded to the nearest
+// multiple of u, for EVERY s of the binade whose successor stays inside it (the exact sum is s + Dq + r, |r| < u/2, unless D sits exactly
+// half-way between two multiples: then round-to-even depends on s and `ok` is false).  So s_k = t + k * Dq, with the product and the sum
+// both exact (k * (Dq / u) < 2^24 is part of `ok`), replaces the k-step recurrence, and "first element >= tt" is a rounded quotient
+// corrected by two exact comparisons.  Anything else — a window that reaches the binade's top, a tie, dt_gamma != 0 — takes the
+// reference's own step-by-step loops.
+struct Binade {
+    float Dq, rDq, top;
+    bool ok;
+};
+template <int G>
+__device__ __forceinline__ Binade binade_of(float t, float D) {
+    Binade b;
+    const uint32_t bits = __float_as_uint(t);
+    const int E = (int)(bits >> 23);         // biased exponent; a negative t has the sign bit here and fails the range test
+    const float Ds = scalbnf(D, 150 - E);    // D in units of u: a power-of-two scaling, exact
+    const float nf = rintf(Ds);
+    b.ok = E > 30 && E < 250 && fabsf(Ds - nf) != 0.5f && nf >= 1.0f && nf * (float)(G + 2) < 16777216.0f;
+    b.Dq = scalbnf(nf, E - 150);
+    b.rDq = __builtin_amdgcn_rcpf(b.Dq);
+    b.top = __uint_as_float((uint32_t)(E + 1) << 23);
+    return b;
+}
+// First k >= k_min with t + k * Dq >= tt, or k_cap + 1 when there is none up to k_cap (all of t + k * Dq, k <= k_cap, lie inside the binade).
+__device__ __forceinline__ int lattice_first_at_least(const Binade& b, float t, float tt, int k_min, int k_cap) {
+    // NaN tt: fmaxf drops it -> k_min, as the reference's `u < tt` loop (false at once) does
+    int k = (int)fminf(fmaxf(ceilf((tt - t) * b.rDq), (float)k_min), (float)(k_cap + 1));
+    if (k > k_min && t + (float)(k - 1) * b.Dq >= tt) k--;  // the quotient is off by at most one either way
+    else if (k <= k_cap && t + (float)k * b.Dq < tt) k++;
+    return k;
+}
+
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
@@ -281,14 +314,28 @@ __device__ inline bool march_window(const MarchParams& a, const March2Tables& tb
     unsigned st_iter = 0, st_cand = 0, st_warp = 0;  // instrumentation (visited points only), reported when a.stats != nullptr
     bool done = true;
     int rounds = 0;
+    const bool fixed = a.dt_gamma == 0.0f;
+    const float D = clampf(0.0f, c.dt_min, c.dt_max);  // dtf() of any finite t when dt_gamma == 0
     while (t < far && step < n_step) {
         if (rounds == max_rounds) { done = false; break; }
         rounds++;
         // this lane's point s_sub and its successor
-        float s = t;
-        for (int j = 0; j < G - 1; j++)
-            if (j < sub) s += dtf(a, c, s);
-        const float nxt = s + dtf(a, c, s);
+        Binade bn;
+        bool fast = false;  // the whole window s_0 .. s_G lies inside t's binade: lattice arithmetic
+        if (fixed) {
+            bn = binade_of<G>(t, D);
+            fast = bn.ok && t + (float)G * bn.Dq < bn.top;
+        }
+        float s, nxt;
+        if (fast) {
+            s = t + (float)sub * bn.Dq;
+            nxt = t + (float)(sub + 1) * bn.Dq;
+        } else {
+            s = t;
+            for (int j = 0; j < G - 1; j++)
+                if (j < sub) s += dtf(a, c, s);
+            nxt = s + dtf(a, c, s);
+        }
         const bool active = s < far;
         PointEval ev;
         ev.emit = false; ev.oob = false; ev.tt = 0.f; ev.dt = 0.f; ev.x = ev.y = ev.z = 0.f; ev.n_cand = 0; ev.n_warp = 0;
@@ -297,10 +344,14 @@ __device__ inline bool march_window(const MarchParams& a, const March2Tables& tb
         // G = first element of the next window, G + 1 = beyond it
         int jump = sub + 1;
         if (active && !ev.emit) {
-            float u = nxt;
-            int k = sub + 1;
-            while (k < G && u < ev.tt) { u += dtf(a, c, u); k++; }
-            jump = (k == G && u < ev.tt) ? G + 1 : k;
+            if (fast) {
+                jump = lattice_first_at_least(bn, t, ev.tt, sub + 1, G);
+            } else {
+                float u = nxt;
+                int k = sub + 1;
+                while (k < G && u < ev.tt) { u += dtf(a, c, u); k++; }
+                jump = (k == G && u < ev.tt) ? G + 1 : k;
+            }
         }
         unsigned word = 0;
         if (G == 8) {

@@ -423,7 +423,7 @@ extern "C" void pn_net_destroy(pn_net* n) {
 template <int LU>
 __device__ __forceinline__ void encode8(const PnFusedLevel* __restrict__ lv, const float* __restrict__ emb, int half, float u0, float u1, float u2,
                                         bool oob, float* feat) {
-#pragma unroll(LU)
+#pragma unroll LU
     for (int j = 0; j < 8; j++) {
         const PnFusedLevel A = lv[j], B = lv[j + 8];  // wave-uniform
         const float scale = half ? B.scale : A.scale;

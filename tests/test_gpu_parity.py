@@ -219,8 +219,9 @@ def test_nerf_forward_fused_vs_oracle_and_ops(ckpt):
 
 
 def test_nerf_forward_is_bit_reproducible(ckpt):
-    """The same launch repeated gives the same bits (guards the gfx950 packed-fp32-VALU x bf16-MFMA corruption, DESIGN.md 4.2:
-    with v_pk_*_f32 in the kernel, 16-sample blocks of ~20 % of 1M-sample launches came out ~1e-2 off)."""
+    """The same launch repeated gives the same bits (round 1 saw 16-sample blocks of ~20 % of 1M-sample launches come out ~1e-2 off in an
+    earlier version of the kernel; the cause it named then — packed-fp32 VALU beside bf16 MFMAs — did not reproduce in isolation,
+    tools/repro_pk_mfma.hip, so this test is what guards the property itself)."""
     from pienerf_amd.nerf.network import NeRFNetwork
     rng = np.random.default_rng(11)
     M = 600_001

@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-O=gpurun_out/r02i
+O=gpurun_out/r02l
 mkdir -p $O
 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_edges.py tests/test_gpu_golden.py tests/test_gpu_fullsize.py tests/test_gpu_half.py -m gpu -q -x 2>&1 | tail -5
 python bench.py --no-cpu-baseline --no-extras --steps 150 > $O/bench.json 2> $O/e
@@ -12,10 +12,10 @@ try:
 except Exception as e:
     print('failed', e, open('$O/e').read()[-300:])
 PY
-cd /tmp && rocprofv3 --kernel-trace --stats -d $OLDPWD/$O/prof -o eager -- python $OLDPWD/tools/run_frames.py --frames 3 > $OLDPWD/$O/time_frame.txt 2>&1; cd $OLDPWD
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o eager -- python $OLDPWD/tools/run_frames.py --frames 3 > $OLDPWD/$O/time_frame.txt 2>&1; cd $OLDPWD
 python - <<PY
 import csv,glob,collections
-f=glob.glob('$O/prof/**/*kernel_trace.csv', recursive=True)
+f=glob.glob('/tmp/prof/**/*kernel_trace.csv', recursive=True)
 if f:
     rows=list(csv.DictReader(open(f[0])))
     d=collections.defaultdict(list)
