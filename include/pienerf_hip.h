@@ -290,6 +290,9 @@ int pn_density_grid_update(uint32_t n, float* density_grid, const float* tmp_gri
 int pn_frame_march_counters(pn_frame* f, int enable, uint64_t* counters_host, void* stream);
 /* With bit 1 of `enable` set: the per-trip durations (ms, HIP events on the launch stream) of the last blocking render:
  * *n_trips_out entries in each array. */
+/* Diagnostics: the device's per-trip records of the last render on `f` as int[max_trips][5] = (n_alive, n_step, step_base, n_samples, n_emitted; -1 on trips whose list is compacted)
+ * and the number of rays each trip handed to the wave-per-ray tail pass.  Synchronises the stream. */
+int pn_frame_trip_records(pn_frame* f, int* records_host, int* tail_counts_host, int max_trips, void* stream);
 int pn_frame_trip_times(pn_frame* f, float* march_ms_host, float* network_ms_host, int max_trips, int* n_trips_out, void* stream);
 
 /* ------------------------------------------------------------------ simulator ------ */

@@ -75,6 +75,7 @@ SIGNATURES = {
     "pn_density_grid_update": (i32, [u32, P, P, f32, f32, P, P, P, P]),
     "pn_frame_march_counters": (i32, [P, i32, P, P]),
     "pn_frame_trip_times": (i32, [P, P, P, i32, P, P]),
+    "pn_frame_trip_records": (i32, [P, P, P, i32, P]),
     "pn_sim_update_F": (i32, [i32, P, P, P, P, P, P, P, P, P]),
     "pn_sim_calc_elastic": (i32, [i32, P, P, P, P, P, P, P]),
     "pn_sim_collect_rhs": (i32, [i32, f64, P, P, P, P, P, P, P, P, P, P]),

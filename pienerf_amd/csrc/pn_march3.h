@@ -84,9 +84,15 @@ __device__ __forceinline__ unsigned dpp_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
 }
 
+// three floats moved by ONE 12-byte access (global_{load,store}_dwordx3 need dword alignment only).  The march kernels are bound by the number
+// of accesses the vector L1 processes (TCP_TOTAL_ACCESSES, ~2.2 cycles each per CU however many waves are resident), not by bytes
+struct __attribute__((packed, aligned(4))) Float3 {
+    float x, y, z;
+};
 __device__ __forceinline__ void ray_consts(const MarchParams& a, int index, RayConsts& c) {
-    c.ox = a.rays_o[index * 3]; c.oy = a.rays_o[index * 3 + 1]; c.oz = a.rays_o[index * 3 + 2];
-    c.dx = a.rays_d[index * 3]; c.dy = a.rays_d[index * 3 + 1]; c.dz = a.rays_d[index * 3 + 2];
+    const Float3 o = *reinterpret_cast<const Float3*>(a.rays_o + (size_t)index * 3), d = *reinterpret_cast<const Float3*>(a.rays_d + (size_t)index * 3);
+    c.ox = o.x; c.oy = o.y; c.oz = o.z;
+    c.dx = d.x; c.dy = d.y; c.dz = d.z;
     c.rdx = 1 / c.dx; c.rdy = 1 / c.dy; c.rdz = 1 / c.dz;
     const uint32_t H = a.H, C = a.C;
     c.rH = 1 / (float)H;
@@ -118,6 +124,31 @@ __device__ __forceinline__ bool ray_start(const MarchParams& a, const RayConsts&
     return true;
 }
 
+// Timing experiment (-DPN_DBG_PHASES=1 builds only, tools/build_variant.py): per-wave clocks of the phases of a march kernel, summed into
+// MarchParams::stats[4 + base ...].  Every phase boundary drains the memory counters, so the phases add up to the wave's lifetime.
+#if PN_DBG_PHASES
+#define PN_DBG_PHASES_ON 1
+struct PhaseClock {
+    unsigned long long t0, acc[6];
+};
+__device__ __forceinline__ unsigned long long dbg_clock() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    return __builtin_readcyclecounter();
+}
+#define PN_PHASE_DECL(pk) pnm3::PhaseClock pk; { for (int _i = 0; _i < 6; _i++) pk.acc[_i] = 0; pk.t0 = pnm3::dbg_clock(); }
+#define PN_PHASE(pk, i) do { const unsigned long long _n = pnm3::dbg_clock(); (pk).acc[i] += _n - (pk).t0; (pk).t0 = _n; } while (0)
+#define PN_PHASE_FLUSH(pk, stats, base, lane) do { if ((stats) && (lane) == 0) for (int _i = 0; _i < 6; _i++) atomicAdd((stats) + 4 + (base) + _i, (pk).acc[_i]); } while (0)
+#define PN_PHASE_ARG , pnm3::PhaseClock& pk
+#define PN_PHASE_PASS , pk
+#else
+#define PN_DBG_PHASES_ON 0
+#define PN_PHASE_DECL(pk)
+#define PN_PHASE(pk, i)
+#define PN_PHASE_FLUSH(pk, stats, base, lane)
+#define PN_PHASE_ARG
+#define PN_PHASE_PASS
+#endif
+
 struct PointEval {
     float x, y, z;  // sample position (warped when IPs were found)
     float dt;       // step at this t
@@ -127,58 +158,110 @@ struct PointEval {
     unsigned n_cand, n_warp;
 };
 
-// The body of one marching iteration at ray parameter t, one lane.  Literal restatement of raymarching.cu:1190-1431.
-template <int K, bool MULTI>
-__device__ __forceinline__ void eval_point(const MarchParams& a, const March2Tables& tb, const RayConsts& c, float t, PointEval& r) {
-    bool found = false;
+// First half of one marching iteration at ray parameter t (raymarching.cu:1190-1232): the sample position and the candidate range of
+// its search cell.  Split from the rest so that the lanes of a wave can stage the lists they are about to scan together.
+struct PointCell {
     float x, y, z;
+    bool in_cut, oob;
+    int gid, b, e;  // candidates of the search cell: nb[b .. e)  (b == e: none / not searched)
+};
+__device__ __forceinline__ void point_cell(const MarchParams& a, const March2Tables& tb, const RayConsts& c, float t, PointCell& p) {
     if (a.cut) {
-        x = clampf(c.ox + t * c.dx, -a.bound, a.bound);
-        y = clampf(c.oy + t * c.dy, -a.bound, a.bound);
-        z = clampf(c.oz + t * c.dz, -a.bound, a.bound);
+        p.x = clampf(c.ox + t * c.dx, -a.bound, a.bound);
+        p.y = clampf(c.oy + t * c.dy, -a.bound, a.bound);
+        p.z = clampf(c.oz + t * c.dz, -a.bound, a.bound);
     } else {
-        x = clampf(c.ox + t * c.dx, c.bmin0, c.hi0);
-        y = clampf(c.oy + t * c.dy, c.bmin1, c.hi1);
-        z = clampf(c.oz + t * c.dz, c.bmin2, c.hi2);
+        p.x = clampf(c.ox + t * c.dx, c.bmin0, c.hi0);
+        p.y = clampf(c.oy + t * c.dy, c.bmin1, c.hi1);
+        p.z = clampf(c.oz + t * c.dz, c.bmin2, c.hi2);
     }
-    bool in_cut = true;
+    p.in_cut = true;
     if (a.cut) {
         const float* cb = a.cut_bounds;  // `x < cb[3]` is the reference's own test (raymarching.cu:1210)
-        in_cut = (x > cb[0] && x < cb[1] && y > cb[2] && x < cb[3] && z > cb[4] && z < cb[5]);
+        p.in_cut = (p.x > cb[0] && p.x < cb[1] && p.y > cb[2] && p.x < cb[3] && p.z > cb[4] && p.z < cb[5]);
     }
-    r.oob = false;
-    r.n_cand = 0;
-    r.n_warp = 0;
-    if (in_cut) {
-        float x_map = 0.0f, y_map = 0.0f, z_map = 0.0f;
-        const int g0 = (int)floorf((x - c.bmin0) / a.hgs);
-        const int g1 = (int)floorf((y - c.bmin1) / a.hgs);
-        const int g2 = (int)floorf((z - c.bmin2) / a.hgs);
-        const bool oob = (g0 < 0 || g1 < 0 || g2 < 0 || g0 >= c.r0 || g1 >= c.r1 || g2 >= c.r2);
-        r.oob = oob;
-        int ips[3] = {-1, -1, -1};  // the selected IPs, nearest first
-        if (!oob) {
-            const int gid = g2 * c.r1 * c.r0 + g1 * c.r0 + g0;
-            const int b = tb.nb_bgn[gid], e = tb.nb_bgn[gid + 1];
-            r.n_cand = (unsigned)(e - b);
+    p.oob = false;
+    p.gid = -1;
+    p.b = p.e = 0;
+    if (p.in_cut) {
+        const int g0 = (int)floorf((p.x - c.bmin0) / a.hgs);
+        const int g1 = (int)floorf((p.y - c.bmin1) / a.hgs);
+        const int g2 = (int)floorf((p.z - c.bmin2) / a.hgs);
+        p.oob = (g0 < 0 || g1 < 0 || g2 < 0 || g0 >= c.r0 || g1 >= c.r1 || g2 >= c.r2);
+        if (!p.oob) {
+            p.gid = g2 * c.r1 * c.r0 + g1 * c.r0 + g0;
+            p.b = tb.nb_bgn[p.gid];
+            p.e = tb.nb_bgn[p.gid + 1];
+        }
+    }
+}
+
+// Wave-cooperative staging of candidate lists in LDS.  The lanes of a wave scan a handful of DISTINCT lists per round (the 8 lanes of a
+// ray sit in the same search cell or two; in the tail pass 64 points of one ray cross four or five cells), but every lane used to fetch
+// its list itself: ~30 of the ~58 vector-memory instructions of a wave-round, each a 64-lane x 16 B gather.  Measured (rocprofv3
+// VmemLatency): 2 400 cycles per vector-memory instruction with the chip full of march waves against 560 when nearly empty — the vector
+// L1 path was the bottleneck, not HBM and not the ALUs.  Here each distinct list is copied once, by all 64 lanes with coalesced 16-byte
+// LDS-DMA loads (global_load_lds_dwordx4: no staging registers, one wait for all lists), and the per-lane scans read LDS.
+// Must be called with all 64 lanes active (destination = wave-uniform base + lane * 16).  Returns this lane's list offset in `stage`
+// (entries), or -1 when the wave's lists did not all fit: those lanes scan from global memory as before.
+#ifndef PN_STAGE_CAP
+#define PN_STAGE_CAP 768  // entries per wave: 12 KB (the record heads of a round need 4 * 3 * 64); 4 waves per workgroup, 3 workgroups per CU -> 144 of the 160 KB
+#endif
+__device__ __forceinline__ void glds16(const float4* g, float4* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ int stage_lists(float4* stage, const float4* __restrict__ nb, int b, int len, int lane) {
+    int my_off = -1;
+    int cursor = 0;
+    unsigned long long todo = __ballot(len > 0);
+    while (todo) {  // one iteration per distinct list (lists are per cell: same start <=> same list)
+        const int leader = __builtin_ctzll(todo);
+        const int lb = __builtin_amdgcn_readlane(b, leader), ll = __builtin_amdgcn_readlane(len, leader);
+        const bool mine = len > 0 && b == lb;
+        todo &= ~__ballot(mine);
+        if (cursor + ll > PN_STAGE_CAP) continue;
+        if (mine) my_off = cursor;
+        for (int i0 = 0; i0 < ll; i0 += 64)
+            if (i0 + lane < ll) glds16(nb + lb + i0 + lane, stage + cursor + i0);
+        cursor += ll;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return my_off;
+}
+
+// Candidate search of one marching iteration, one lane (raymarching.cu:1232-1244 -> find_closest_IP(s)): the K nearest IPs of the point,
+// nearest first, -1 = none.  `stage` / `my_off`: this lane's candidate list in LDS (stage_lists), my_off < 0: read it from tb.nb.
+template <int K>
+__device__ __forceinline__ void eval_scan(const MarchParams& a, const March2Tables& tb, const PointCell& pc, const float4* stage, int my_off, int (&ips)[3],
+                                          unsigned& n_cand) {
+    const float x = pc.x, y = pc.y, z = pc.z;
+    ips[0] = ips[1] = ips[2] = -1;
+    n_cand = 0;
+    if (pc.in_cut && !pc.oob) {
+        {
+            const int n_list = pc.e - pc.b;
+            n_cand = (unsigned)n_list;
             if (K == 1) {
                 // find_closest_IP (:986-1043): own cell first, the 26 neighbours only if that found nothing; `d < best` from 9999.9
-                const int own = a.pig_cnt[gid];
+                const int own = a.pig_cnt[pc.gid];
                 float best = (float)9999.9;
-                for (int j = b; j < b + own; j++) {
-                    const float4 v = tb.nb[j];
-                    const float ax = v.x - x, ay = v.y - y, az = v.z - z;
-                    const float d = ax * ax + ay * ay + az * az;
-                    if (d < best) { best = d; ips[0] = __float_as_int(v.w); }
-                }
-                if (ips[0] == -1) {
-                    for (int j = b + own; j < e; j++) {
-                        const float4 v = tb.nb[j];
+                auto scan1 = [&](const float4* base) {
+                    for (int j = 0; j < own; j++) {
+                        const float4 v = base[j];
                         const float ax = v.x - x, ay = v.y - y, az = v.z - z;
                         const float d = ax * ax + ay * ay + az * az;
                         if (d < best) { best = d; ips[0] = __float_as_int(v.w); }
                     }
-                }
+                    if (ips[0] == -1) {
+                        for (int j = own; j < n_list; j++) {
+                            const float4 v = base[j];
+                            const float ax = v.x - x, ay = v.y - y, az = v.z - z;
+                            const float d = ax * ax + ay * ay + az * az;
+                            if (d < best) { best = d; ips[0] = __float_as_int(v.w); }
+                        }
+                    }
+                };
+                if (my_off >= 0) scan1(stage + my_off); else scan1(tb.nb + pc.b);
             } else {
                 // find_closest_IPs (:1045-1118): all 27 cells in visiting order (= list order), insertion on strict '<'.  Written as selects
                 // on the three comparisons (d0 <= d1 <= d2 always, so d < d0 implies d < d1 implies d < d2 and the reference's
@@ -200,38 +283,75 @@ __device__ __forceinline__ void eval_point(const MarchParams& a, const March2Tab
                     ips[0] = c0 ? id : ips[0];
                     d0 = c0 ? d : d0;
                 };
-                int j0 = b;
-                for (; j0 + PN_CAND_FLIGHT <= e; j0 += PN_CAND_FLIGHT) {  // entries in flight per round trip
-                    const float4* __restrict__ q = tb.nb + j0;
-                    float4 v[PN_CAND_FLIGHT];
+                auto scan = [&](const float4* base) {  // entries base[0 .. n_list)
+                    int j0 = 0;
+                    for (; j0 + PN_CAND_FLIGHT <= n_list; j0 += PN_CAND_FLIGHT) {  // entries in flight per round trip
+                        float4 v[PN_CAND_FLIGHT];
 #pragma unroll
-                    for (int u = 0; u < PN_CAND_FLIGHT; u++) v[u] = q[u];
+                        for (int u = 0; u < PN_CAND_FLIGHT; u++) v[u] = base[j0 + u];
 #pragma unroll
-                    for (int u = 0; u < PN_CAND_FLIGHT; u++) insert(v[u], true);
-                }
-                if (j0 < e) {
-                    float4 v[PN_CAND_FLIGHT - 1];
+                        for (int u = 0; u < PN_CAND_FLIGHT; u++) insert(v[u], true);
+                    }
+                    if (j0 < n_list) {
+                        float4 v[PN_CAND_FLIGHT - 1];
 #pragma unroll
-                    for (int u = 0; u < PN_CAND_FLIGHT - 1; u++) v[u] = tb.nb[min(j0 + u, e - 1)];
+                        for (int u = 0; u < PN_CAND_FLIGHT - 1; u++) v[u] = base[min(j0 + u, n_list - 1)];
 #pragma unroll
-                    for (int u = 0; u < PN_CAND_FLIGHT - 1; u++) insert(v[u], j0 + u < e);
-                }
+                        for (int u = 0; u < PN_CAND_FLIGHT - 1; u++) insert(v[u], j0 + u < n_list);
+                    }
+                };
+                if (my_off >= 0) scan(stage + my_off); else scan(tb.nb + pc.b);
             }
         }
+    }
+}
+
+// The selected IPs' record heads (p_ori, p_def, F^-1: 64 B each) for all 64 lanes at once.  Per lane they are three scattered 64-byte
+// records; fetched lane by lane (3 x 4 global_load_dwordx4) every instruction costs the vector L1 one access per LANE (~770 per wave-round,
+// a third of all the kernel's accesses, and the accesses are what bounds it).  Here the four lanes of a quad fetch each other's records:
+// instruction (k, j) has every lane load part (lane & 3) of the k-th record of lane j of its quad — one contiguous 64 B per quad, 16
+// accesses per instruction — by LDS-DMA into stage[(k * 4 + j) * 64 + lane]; lane (Q, j) then reads its four parts back from
+// stage[(k * 4 + j) * 64 + Q * 4 ...].  All 64 lanes must be active; lanes without an IP fetch record 0.  Needs 4 * K * 64 entries of `stage`
+// (the candidate lists staged there have been consumed by then).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int K>
+__device__ __forceinline__ void head_fetch(float4* stage, const float4* __restrict__ rec, const int (&ips)[3], int lane, float4 (&rh)[3][4]) {
+    const int q = lane & 3;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int ipk = ips[k] >= 0 ? ips[k] : (ips[0] >= 0 ? ips[0] : 0);
+        const int i0 = dpp_i32<0x00>(ipk), i1 = dpp_i32<0x55>(ipk), i2 = dpp_i32<0xAA>(ipk), i3 = dpp_i32<0xFF>(ipk);  // quad_perm broadcasts
+        glds16(rec + (size_t)i0 * PN_REC_VEC4 + q, stage + (k * 4 + 0) * 64);
+        glds16(rec + (size_t)i1 * PN_REC_VEC4 + q, stage + (k * 4 + 1) * 64);
+        glds16(rec + (size_t)i2 * PN_REC_VEC4 + q, stage + (k * 4 + 2) * 64);
+        glds16(rec + (size_t)i3 * PN_REC_VEC4 + q, stage + (k * 4 + 3) * 64);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const float4* h = stage + (k * 4 + q) * 64 + (lane & ~3);
+#pragma unroll
+        for (int u = 0; u < 4; u++) rh[k][u] = h[u];
+    }
+}
+
+// Rest of one marching iteration, one lane: pre-filter, inverse warps, blend, density bit, voxel exit (raymarching.cu:1246-1431).
+template <int K, bool MULTI>
+__device__ __forceinline__ void eval_point(const MarchParams& a, const March2Tables& tb, const RayConsts& c, float t, const PointCell& pc,
+                                           const int (&ips)[3], const float4 (&rh)[3][4], unsigned n_cand, PointEval& r) {
+    bool found = false;
+    float x = pc.x, y = pc.y, z = pc.z;
+    r.oob = pc.oob;
+    r.n_cand = n_cand;
+    r.n_warp = 0;
+    if (pc.in_cut) {
+        float x_map = 0.0f, y_map = 0.0f, z_map = 0.0f;
         int n_IP = (ips[0] != -1) + (ips[1] != -1) + (ips[2] != -1);
         found = n_IP > 0;
         if (found) {
-            // the selected IPs' record heads (p_ori, p_def, F^-1: 64 B each) are fetched for all K at once — the pre-filter loop
-            // below, whose bound shrinks as it runs, and the first Newton step then work on registers
-            float4 rh[3][4];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                if (k < K) {
-                    const float4* __restrict__ rp = tb.rec + (size_t)(ips[k] >= 0 ? ips[k] : ips[0]) * PN_REC_VEC4;
-#pragma unroll
-                    for (int u = 0; u < 4; u++) rh[k][u] = rp[u];
-                }
-            }
+            // the selected IPs' record heads (p_ori, p_def, F^-1: 64 B each) arrive in rh[][] (head_fetch below) — the pre-filter loop, whose
+            // bound shrinks as it runs, and the first Newton step work on registers
             // pre-filter (:1246-1251) on the candidates' deformed positions: `n_IP--` inside the loop it bounds, strict '<' on z only
 #pragma unroll
             for (int k = 0; k < K; k++) {
@@ -305,112 +425,142 @@ __device__ __forceinline__ void eval_point(const MarchParams& a, const March2Tab
 // Up to `max_rounds` windows of G sequence elements of one ray; the G lanes [gbase, gbase + G) run in lock step.
 // Returns true when the ray is done for this trip (t >= far, or n_step samples), false when the round budget ran out; `st` is
 // advanced either way (identically on all G lanes).  Samples go to xyzs/dirs/deltas[slot], slot = number emitted before.
+// Called by ALL 64 lanes of the wave (have_ray = false for the lanes of a group without a ray): the round loop is wave-uniform so that
+// the candidate lists of a round can be staged cooperatively (stage_lists) in `stage`, the wave's PN_STAGE_CAP entries of LDS.
 template <int K, bool MULTI, int G>
-__device__ inline bool march_window(const MarchParams& a, const March2Tables& tb, const RayConsts& c, uint32_t n_step, int sub, int gbase,
-                                    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, RayState& st, int max_rounds) {
+__device__ inline bool march_window(const MarchParams& a, const March2Tables& tb, const RayConsts& c, uint32_t n_step, int sub, int gbase, int lane,
+                                    float4* stage, float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, RayState& st,
+                                    int max_rounds, bool have_ray PN_PHASE_ARG) {
     float t = st.t, last_t = st.last_t;
     uint32_t step = st.step;
     const float far = c.far;
     unsigned st_iter = 0, st_cand = 0, st_warp = 0;  // instrumentation (visited points only), reported when a.stats != nullptr
     bool done = true;
+    bool running = have_ray;
     int rounds = 0;
     const bool fixed = a.dt_gamma == 0.0f;
     const float D = clampf(0.0f, c.dt_min, c.dt_max);  // dtf() of any finite t when dt_gamma == 0
-    while (t < far && step < n_step) {
-        if (rounds == max_rounds) { done = false; break; }
+    while (true) {
+        bool go = running && t < far && step < n_step;  // the same on the G lanes of a ray
+        if (go && rounds == max_rounds) { done = false; go = false; }
+        running = go;
+        if (!__any(go)) break;
         rounds++;
         // this lane's point s_sub and its successor
         Binade bn;
+        bn.Dq = bn.rDq = bn.top = 0.f; bn.ok = false;
         bool fast = false;  // the whole window s_0 .. s_G lies inside t's binade: lattice arithmetic
-        if (fixed) {
-            bn = binade_of<G>(t, D);
-            fast = bn.ok && t + (float)G * bn.Dq < bn.top;
+        float s = 0.f, nxt = 0.f;
+        bool active = false;
+        PointCell pc;
+        pc.x = pc.y = pc.z = 0.f; pc.in_cut = false; pc.oob = false; pc.gid = -1; pc.b = pc.e = 0;
+        if (go) {
+            if (fixed) {
+                bn = binade_of<G>(t, D);
+                fast = bn.ok && t + (float)G * bn.Dq < bn.top;
+            }
+            if (fast) {
+                s = t + (float)sub * bn.Dq;
+                nxt = t + (float)(sub + 1) * bn.Dq;
+            } else {
+                s = t;
+                for (int j = 0; j < G - 1; j++)
+                    if (j < sub) s += dtf(a, c, s);
+                nxt = s + dtf(a, c, s);
+            }
+            active = s < far;
+            if (active) point_cell(a, tb, c, s, pc);
         }
-        float s, nxt;
-        if (fast) {
-            s = t + (float)sub * bn.Dq;
-            nxt = t + (float)(sub + 1) * bn.Dq;
-        } else {
-            s = t;
-            for (int j = 0; j < G - 1; j++)
-                if (j < sub) s += dtf(a, c, s);
-            nxt = s + dtf(a, c, s);
-        }
-        const bool active = s < far;
+        PN_PHASE(pk, 1);
+        const int my_off = stage_lists(stage, tb.nb, pc.b, pc.e - pc.b, lane);
+        PN_PHASE(pk, 2);
         PointEval ev;
         ev.emit = false; ev.oob = false; ev.tt = 0.f; ev.dt = 0.f; ev.x = ev.y = ev.z = 0.f; ev.n_cand = 0; ev.n_warp = 0;
-        if (active) eval_point<K, MULTI>(a, tb, c, s, ev);
-        // where the chain goes from this point: the next element (emitted) or the first element not below the voxel exit;
-        // G = first element of the next window, G + 1 = beyond it
-        int jump = sub + 1;
-        if (active && !ev.emit) {
-            if (fast) {
-                jump = lattice_first_at_least(bn, t, ev.tt, sub + 1, G);
+        int ips[3] = {-1, -1, -1};
+        unsigned n_cand = 0;
+        if (go && active) eval_scan<K>(a, tb, pc, stage, my_off, ips, n_cand);
+        float4 rh[3][4];
+        head_fetch<K>(stage, tb.rec, ips, lane, rh);
+        if (go && active) eval_point<K, MULTI>(a, tb, c, s, pc, ips, rh, n_cand, ev);
+        PN_PHASE(pk, 3);
+        if (go) {
+            // where the chain goes from this point: the next element (emitted) or the first element not below the voxel exit;
+            // G = first element of the next window, G + 1 = beyond it
+            int jump = sub + 1;
+            if (active && !ev.emit) {
+                if (fast) {
+                    jump = lattice_first_at_least(bn, t, ev.tt, sub + 1, G);
+                } else {
+                    float u = nxt;
+                    int k = sub + 1;
+                    while (k < G && u < ev.tt) { u += dtf(a, c, u); k++; }
+                    jump = (k == G && u < ev.tt) ? G + 1 : k;
+                }
+            }
+            unsigned word = 0;
+            if (G == 8) {
+                word = (unsigned)jump << (4 * sub);
+                word |= dpp_u32<0xB1>(word);   // lane ^ 1
+                word |= dpp_u32<0x4E>(word);   // lane ^ 2
+                word |= dpp_u32<0x141>(word);  // lane <-> 7 - lane within each 8
+            }
+            const unsigned long long gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+            const unsigned long long emitm = (__ballot(ev.emit) >> gbase) & gmask;
+            const unsigned long long actm = (__ballot(active) >> gbase) & gmask;
+            // replay of the visit chain, identically on the G lanes
+            int cur = 0, prev_emit = -1, n_emit = 0, last_vis = 0;
+            int my_ord = -1, my_prev = -1;
+            bool visited = false, ended = false;
+            while (cur < G) {
+                if (!((actm >> cur) & 1ull)) { ended = true; break; }  // s_cur >= far: the march is over
+                if (cur == sub) { visited = true; my_ord = n_emit; my_prev = prev_emit; }
+                last_vis = cur;
+                const bool em = (emitm >> cur) & 1ull;
+                const int nx_idx = (G == 8) ? (int)((word >> (4 * cur)) & 0xFu) : __shfl(jump, gbase + cur);
+                if (em) {
+                    prev_emit = cur;
+                    n_emit++;
+                    if (step + (uint32_t)n_emit == n_step) { ended = true; break; }
+                }
+                cur = nx_idx;
+            }
+            // emitted samples: slot = step + rank in the chain; deltas[1] = t_after - last_t (raymarching.cu:1395-1410)
+            const float prev_nxt = __shfl(nxt, gbase + max(my_prev, 0));
+            if (visited) {
+                st_iter++; st_cand += ev.n_cand; st_warp += ev.n_warp;
+                if (ev.oob && a.err_flag) atomicOr(a.err_flag, 1);
+                if (ev.emit) {
+                    const uint32_t slot = step + (uint32_t)my_ord;
+                    float* X = xyzs + (size_t)slot * 3;
+                    float* Dd = dirs + (size_t)slot * 3;
+                    float* L = deltas + (size_t)slot * 2;
+                    *reinterpret_cast<Float3*>(X) = Float3{ev.x, ev.y, ev.z};
+                    *reinterpret_cast<Float3*>(Dd) = Float3{c.dx, c.dy, c.dz};
+                    *reinterpret_cast<float2*>(L) = make_float2(ev.dt, nxt - (my_prev >= 0 ? prev_nxt : last_t));
+                }
+            }
+            const float last_emit_nxt = __shfl(nxt, gbase + max(prev_emit, 0));
+            if (n_emit > 0) last_t = last_emit_nxt;
+            step += (uint32_t)n_emit;
+            // next window start: s_G, or further when the last visited point's voxel exit lies beyond the window
+            const float sG = __shfl(nxt, gbase + G - 1);
+            const float tt_last = __shfl(ev.tt, gbase + last_vis);
+            if (ended) {
+                running = false;  // done for this trip; t is not needed any more (composite tracks rays_t itself)
             } else {
-                float u = nxt;
-                int k = sub + 1;
-                while (k < G && u < ev.tt) { u += dtf(a, c, u); k++; }
-                jump = (k == G && u < ev.tt) ? G + 1 : k;
+                t = sG;
+                if (cur == G + 1)
+                    while (t < tt_last) t += dtf(a, c, t);
             }
         }
-        unsigned word = 0;
-        if (G == 8) {
-            word = (unsigned)jump << (4 * sub);
-            word |= dpp_u32<0xB1>(word);   // lane ^ 1
-            word |= dpp_u32<0x4E>(word);   // lane ^ 2
-            word |= dpp_u32<0x141>(word);  // lane <-> 7 - lane within each 8
-        }
-        const unsigned long long gmask = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
-        const unsigned long long emitm = (__ballot(ev.emit) >> gbase) & gmask;
-        const unsigned long long actm = (__ballot(active) >> gbase) & gmask;
-        // replay of the visit chain, identically on the G lanes
-        int cur = 0, prev_emit = -1, n_emit = 0, last_vis = 0;
-        int my_ord = -1, my_prev = -1;
-        bool visited = false, ended = false;
-        while (cur < G) {
-            if (!((actm >> cur) & 1ull)) { ended = true; break; }  // s_cur >= far: the march is over
-            if (cur == sub) { visited = true; my_ord = n_emit; my_prev = prev_emit; }
-            last_vis = cur;
-            const bool em = (emitm >> cur) & 1ull;
-            const int nx_idx = (G == 8) ? (int)((word >> (4 * cur)) & 0xFu) : __shfl(jump, gbase + cur);
-            if (em) {
-                prev_emit = cur;
-                n_emit++;
-                if (step + (uint32_t)n_emit == n_step) { ended = true; break; }
-            }
-            cur = nx_idx;
-        }
-        // emitted samples: slot = step + rank in the chain; deltas[1] = t_after - last_t (raymarching.cu:1395-1410)
-        const float prev_nxt = __shfl(nxt, gbase + max(my_prev, 0));
-        if (visited) {
-            st_iter++; st_cand += ev.n_cand; st_warp += ev.n_warp;
-            if (ev.oob && a.err_flag) atomicOr(a.err_flag, 1);
-            if (ev.emit) {
-                const uint32_t slot = step + (uint32_t)my_ord;
-                float* X = xyzs + (size_t)slot * 3;
-                float* D = dirs + (size_t)slot * 3;
-                float* L = deltas + (size_t)slot * 2;
-                X[0] = ev.x; X[1] = ev.y; X[2] = ev.z;
-                D[0] = c.dx; D[1] = c.dy; D[2] = c.dz;
-                L[0] = ev.dt;
-                L[1] = nxt - (my_prev >= 0 ? prev_nxt : last_t);
-            }
-        }
-        const float last_emit_nxt = __shfl(nxt, gbase + max(prev_emit, 0));
-        if (n_emit > 0) last_t = last_emit_nxt;
-        step += (uint32_t)n_emit;
-        // next window start: s_G, or further when the last visited point's voxel exit lies beyond the window
-        const float sG = __shfl(nxt, gbase + G - 1);
-        const float tt_last = __shfl(ev.tt, gbase + last_vis);
-        if (ended) break;  // done for this trip; t is not needed any more (composite tracks rays_t itself)
-        t = sG;
-        if (cur == G + 1)
-            while (t < tt_last) t += dtf(a, c, t);
+        PN_PHASE(pk, 4);
     }
+#if !PN_DBG_PHASES  // (the phase-clock build reuses the counter block and must not be disturbed by these atomics)
     if (a.stats) {
         if (st_iter) { atomicAdd(a.stats, (unsigned long long)st_iter); atomicAdd(a.stats + 1, (unsigned long long)st_cand); }
         if (st_warp) atomicAdd(a.stats + 2, (unsigned long long)st_warp);
     }
+#endif
     st.t = t;
     st.last_t = last_t;
     st.step = step;

@@ -8,11 +8,25 @@ thread_local char pn_err_buf[512] = {0};
 
 // Device-side record driving one loop trip of rund_cuda (nerf/renderer.py:836-891).
 struct PnTrip {
+    // written by the previous trip's compaction (trip 0: k_frame_rays), read-only while this trip's kernels run
     int n_alive;    // rays entering this trip
     int n_step;     // max(min(N // n_alive, 8), 1)
     int step_base;  // renderer's `step` before this trip
-    int n_samples;  // samples emitted by this trip's march (filled by atomics)
+    int dense;      // see below
+    int pad0[28];
+    // counters the march updates with atomics: a cache line of their own, so that the waves reading the fields above (every wave's first
+    // instruction) do not queue behind them
+    int n_samples;  // entries of the sample list the network kernel reads (list trips: filled by atomics; dense trips: n_alive * n_step)
+    int n_emitted;  // dense trips only: samples really emitted (statistics)
+    int pad1[30];
 };
+static_assert(sizeof(PnTrip) == 256, "two cache lines");
+// Dense trips (frame driver of the deformed render, n_step > 1): after the first trip nearly every alive ray fills all its n_step slots
+// (measured on the chair: 98-99 %), so the sample list is the identity over the n_alive * n_step slots — written by the march without the
+// returning atomic a compact list costs every wave (one more dependent memory round trip at the end of a latency-bound kernel: -24 % on
+// trip 0's k_march without it) — and the few unfilled slots are zero-filled and run through the network as well; composite never reads
+// them (their delta is 0).  The compaction kernel presets n_samples for such a trip.
+__device__ __forceinline__ bool trip_is_dense(const PnTrip* t) { return t->dense != 0; }
 
 // Per-frame device record of the frame drivers (pn_render_deformed / pn_render_static).
 struct PnFrameDev {
@@ -424,7 +438,7 @@ __global__ void __launch_bounds__(256) k_march_skip(pnm::MarchParams a, pnm2::Ma
         const int index = io.rays_alive[n];
         const float t = pnm2::skip_empty_cells(a, tb, index, io.noises ? io.noises[n] : 0.0f, &n_iter);
         io.t_resume[n] = t;
-        if (a.stats && n_iter) atomicAdd(a.stats, (unsigned long long)n_iter);
+        if (!PN_DBG_PHASES_ON && a.stats && n_iter) atomicAdd(a.stats, (unsigned long long)n_iter);
         work = t < a.fars[index];
         if (io.active && !work) {  // nothing left to march: k_march will not visit the slot, so its (single, n_step == 1) sample slot is ended here
             const uint32_t n_step = (uint32_t)io.trip->n_step;
@@ -462,43 +476,69 @@ struct TailEntry {
 template <int K, bool MULTI>
 __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
     uint32_t n_alive = io.n_alive, n_step = io.n_step;
-    if (io.trip) { n_alive = (uint32_t)io.trip->n_alive; n_step = (uint32_t)io.trip->n_step; }
+    bool dense = false;
+    if (io.trip) { n_alive = (uint32_t)io.trip->n_alive; n_step = (uint32_t)io.trip->n_step; dense = trip_is_dense(io.trip); }
     const int lane = threadIdx.x & 63, sub = lane & 7, gbase = lane & ~7;
     const int budget = io.tail ? io.max_rounds : 0x7fffffff;
+    __shared__ float4 stage_mem[4][PN_STAGE_CAP];
+    float4* stage = stage_mem[threadIdx.x >> 6];
     // 32-ray chunks are dealt round-robin to a bounded grid: in frame mode the alive count is only known on the device, and a
     // grid sized for all N rays would push ~20 000 mostly empty workgroups through the dispatcher on every trip
     const uint32_t n_work = io.active ? (uint32_t)__hip_atomic_load(io.active_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n_alive;
-    for (uint32_t chunk = blockIdx.x; chunk * 32u < n_work; chunk += gridDim.x) {
+    PN_PHASE_DECL(pk);
+    // Chunk -> workgroup mapping: workgroup b runs on XCD b % 8 (observed dispatch order, MI355X_MICROARCH.md) and each XCD has its own 4 MB L2;
+    // the alive list is in raster order, so XCD x takes the x-th contiguous eighth of the chunks — one band of the image, one slab of the object,
+    // one eighth of the candidate lists and IP records in its L2 instead of all of them in all eight (rocprofv3: > 50 % L2 misses before).
+    const uint32_t n_chunks = (n_work + 31u) / 32u;
+    const uint32_t xcd = blockIdx.x & 7u, per_xcd = (n_chunks + 7u) / 8u, wg_per_xcd = max(gridDim.x >> 3, 1u);
+    const bool xcd_map = (gridDim.x & 7u) == 0;
+    for (uint32_t k = xcd_map ? (blockIdx.x >> 3) : blockIdx.x; xcd_map ? (k < per_xcd) : (k < n_chunks); k += xcd_map ? wg_per_xcd : gridDim.x) {
+        const uint32_t chunk = xcd_map ? xcd * per_xcd + k : k;
+        if (chunk >= n_chunks) break;
         const uint32_t i_work = chunk * 32u + (threadIdx.x >> 3);
         const uint32_t n = io.active ? (i_work < n_work ? (uint32_t)io.active[i_work] : 0xffffffffu) : i_work;
         uint32_t emitted = 0;
-        bool deferred = false;
+        bool deferred = false, have = false;
         float* dl = nullptr;
+        pnm3::RayConsts c;
+        pnm3::RayState st{0.f, 0.f, 0u};
         if (n < n_alive) {
             const int index = io.rays_alive[n];
             const float noise = io.noises ? io.noises[n] : 0.0f;
             dl = io.deltas + (size_t)n * n_step * 2;
-            pnm3::RayConsts c;
-            pnm3::RayState st;
             pnm3::ray_consts(a, index, c);
-            if (pnm3::ray_start(a, c, index, noise, io.t_resume ? io.t_resume + n : nullptr, st)) {
-                const bool done = pnm3::march_window<K, MULTI, 8>(a, tb, c, n_step, sub, gbase, io.xyzs + (size_t)n * n_step * 3,
-                                                                  io.dirs + (size_t)n * n_step * 3, dl, st, budget);
-                if (!done) {  // still marching after the round budget: continue with a whole wave (k_march_tail)
-                    deferred = true;
-                    if (sub == 0) {
-                        const int pos = atomicAdd(io.tail_count, 1);
-                        io.tail[pos] = TailEntry{(int)n, st.t, st.last_t, (int)st.step};
-                    }
+            have = pnm3::ray_start(a, c, index, noise, io.t_resume ? io.t_resume + n : nullptr, st);
+        }
+        PN_PHASE(pk, 0);
+        // all 64 lanes enter (the round loop inside is wave-uniform, pn_march3.h); lanes without a ray idle through it
+        const bool done = pnm3::march_window<K, MULTI, 8>(a, tb, c, n_step, sub, gbase, lane, stage, io.xyzs + (size_t)n * n_step * 3,
+                                                          io.dirs + (size_t)n * n_step * 3, dl, st, budget, have PN_PHASE_PASS);
+        if (n < n_alive) {
+            if (have && !done) {  // still marching after the round budget: continue with a whole wave (k_march_tail)
+                deferred = true;
+                if (sub == 0) {
+                    const int pos = atomicAdd(io.tail_count, 1);
+                    io.tail[pos] = TailEntry{(int)n, st.t, st.last_t, (int)st.step};
                 }
             }
             emitted = deferred ? 0u : st.step;  // a deferred ray's samples are listed by the tail pass
-            if (a.stats && sub == 0 && emitted) atomicAdd(a.stats + 3, (unsigned long long)emitted);
+            if (!PN_DBG_PHASES_ON && a.stats && sub == 0 && emitted) atomicAdd(a.stats + 3, (unsigned long long)emitted);
         }
         if (io.trip) {
             // slots the ray did not fill end it in composite (delta == 0); the op-level wrapper zero-fills instead (raymarching.py:415-417)
             if (dl && !deferred)
                 for (uint32_t s = emitted + sub; s < n_step; s += PN_G) { dl[2 * s] = 0.0f; dl[2 * s + 1] = 0.0f; }
+            if (dense) {
+                if (dl && !deferred) {
+                    float* X = io.xyzs + (size_t)n * n_step * 3;
+                    float* Dd = io.dirs + (size_t)n * n_step * 3;
+                    for (uint32_t s = emitted + sub; s < n_step; s += PN_G) { X[3 * s] = X[3 * s + 1] = X[3 * s + 2] = 0.0f; Dd[3 * s] = Dd[3 * s + 1] = Dd[3 * s + 2] = 0.0f; }
+                    for (uint32_t s = sub; s < n_step; s += PN_G) io.list[n * n_step + s] = (int)(n * n_step + s);
+                }
+                int v = (sub == 0 && dl && !deferred) ? (int)emitted : 0;  // one counter update per wave, result unused: no wait
+                v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+                if (lane == 0 && v) atomicAdd(&io.trip->n_emitted, v);
+            } else {
             // wave-aggregated append of this wave's valid sample slots (one atomic per wave)
             int inc = (sub == 0) ? (int)emitted : 0;
 #pragma unroll
@@ -512,18 +552,25 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams 
             base = __shfl(base, 63);
             const int first = base + __shfl(inc, gbase) - (int)emitted;  // exclusive prefix of this group's first lane
             for (uint32_t s = sub; s < emitted; s += PN_G) io.list[first + s] = (int)(n * n_step + s);
+            }
         }
+        PN_PHASE(pk, 5);
     }
+    PN_PHASE_FLUSH(pk, a.stats, 0, lane);
 }
 
 // One wave per unfinished ray: windows of 64 sequence elements until the ray is done for this trip.
 template <int K, bool MULTI>
 __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march_tail(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
     uint32_t n_step = io.n_step;
-    if (io.trip) n_step = (uint32_t)io.trip->n_step;
+    bool dense = false;
+    if (io.trip) { n_step = (uint32_t)io.trip->n_step; dense = trip_is_dense(io.trip); }
     const int total = __hip_atomic_load(io.tail_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int lane = threadIdx.x & 63;
     const int n_waves = (int)gridDim.x * 4;
+    __shared__ float4 stage_mem[4][PN_STAGE_CAP];
+    float4* stage = stage_mem[threadIdx.x >> 6];
+    PN_PHASE_DECL(pk);
     for (int e = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); e < total; e += n_waves) {
         const TailEntry te = io.tail[e];
         const uint32_t n = (uint32_t)te.n;
@@ -532,18 +579,29 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march_tail(pnm::MarchPa
         pnm3::RayConsts c;
         pnm3::ray_consts(a, index, c);
         pnm3::RayState st{te.t, te.last_t, (uint32_t)te.step};
-        pnm3::march_window<K, MULTI, 64>(a, tb, c, n_step, lane, 0, io.xyzs + (size_t)n * n_step * 3, io.dirs + (size_t)n * n_step * 3, dl, st,
-                                         0x7fffffff);
+        PN_PHASE(pk, 0);
+        pnm3::march_window<K, MULTI, 64>(a, tb, c, n_step, lane, 0, lane, stage, io.xyzs + (size_t)n * n_step * 3, io.dirs + (size_t)n * n_step * 3,
+                                         dl, st, 0x7fffffff, true PN_PHASE_PASS);
         const uint32_t emitted = st.step;
-        if (a.stats && lane == 0 && emitted) atomicAdd(a.stats + 3, (unsigned long long)emitted);
+        if (!PN_DBG_PHASES_ON && a.stats && lane == 0 && emitted) atomicAdd(a.stats + 3, (unsigned long long)emitted);
         if (io.trip) {
             for (uint32_t s = emitted + lane; s < n_step; s += 64) { dl[2 * s] = 0.0f; dl[2 * s + 1] = 0.0f; }
-            int base = 0;
-            if (lane == 0 && emitted > 0) base = atomicAdd(&io.trip->n_samples, (int)emitted);
-            base = __shfl(base, 0);
-            for (uint32_t s = lane; s < emitted; s += 64) io.list[base + s] = (int)(n * n_step + s);
+            if (dense) {
+                float* X = io.xyzs + (size_t)n * n_step * 3;
+                float* Dd = io.dirs + (size_t)n * n_step * 3;
+                for (uint32_t s = emitted + lane; s < n_step; s += 64) { X[3 * s] = X[3 * s + 1] = X[3 * s + 2] = 0.0f; Dd[3 * s] = Dd[3 * s + 1] = Dd[3 * s + 2] = 0.0f; }
+                for (uint32_t s = lane; s < n_step; s += 64) io.list[n * n_step + s] = (int)(n * n_step + s);
+                if (lane == 0 && emitted) atomicAdd(&io.trip->n_emitted, (int)emitted);
+            } else {
+                int base = 0;
+                if (lane == 0 && emitted > 0) base = atomicAdd(&io.trip->n_samples, (int)emitted);
+                base = __shfl(base, 0);
+                for (uint32_t s = lane; s < emitted; s += 64) io.list[base + s] = (int)(n * n_step + s);
+            }
         }
+        PN_PHASE(pk, 5);
     }
+    PN_PHASE_FLUSH(pk, a.stats, 6, lane);
 }
 
 template <int K, bool MULTI>
@@ -937,7 +995,7 @@ __global__ void __launch_bounds__(256) k_chunk_count(const int* __restrict__ ray
 // Block 0 also publishes the total and, in frame-driver mode, the next trip's record (renderer.py:839-846,891).
 __global__ void __launch_bounds__(256) k_compact(const int* __restrict__ in, uint32_t n_arg, const int* __restrict__ chunk_counts,
                                                  int* __restrict__ out, int* n_out, const PnTrip* trip, PnTrip* next, uint32_t N_rays,
-                                                 uint32_t max_steps) {
+                                                 uint32_t max_steps, int dense_trips) {
     __shared__ int red[4];
     __shared__ int woff[4];
     const uint32_t n = trip ? (uint32_t)trip->n_alive : n_arg;
@@ -963,7 +1021,11 @@ __global__ void __launch_bounds__(256) k_compact(const int* __restrict__ in, uin
                 next->n_alive = done ? 0 : sum;
                 next->n_step = done ? 1 : max(min((int)(N_rays / (uint32_t)sum), 8), 1);
                 next->step_base = step;
-                next->n_samples = 0;
+                // dense trip (see trip_is_dense): the list is the identity over all slots; n_emitted = -1 marks a list trip
+                const bool dense = dense_trips && !done && next->n_step > 1;
+                next->dense = dense ? 1 : 0;
+                next->n_samples = dense ? sum * next->n_step : 0;
+                next->n_emitted = 0;
             }
         }
         const uint32_t i = c * 256 + threadIdx.x;
@@ -989,7 +1051,7 @@ extern "C" int pn_compact_rays(const int* rays_alive, uint32_t n, int* out, int*
     PN_REQUIRE(rays_alive && out && scratch);
     const uint32_t chunks = pn_div_up(n, 256);
     k_chunk_count<<<chunks, 256, 0, st>>>(rays_alive, n, scratch);
-    k_compact<<<chunks, 256, 0, st>>>(rays_alive, n, scratch, out, n_out, nullptr, nullptr, 0, 0);
+    k_compact<<<chunks, 256, 0, st>>>(rays_alive, n, scratch, out, n_out, nullptr, nullptr, 0, 0, 0);
     PN_LAUNCH_CHECK();
     return PN_OK;
 }
@@ -1256,7 +1318,8 @@ __global__ void __launch_bounds__(256) k_frame_rays(const float* __restrict__ ra
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
     if (blockIdx.x == 0) {
         for (int t = threadIdx.x; t < n_trip_records; t += blockDim.x) {
-            PnTrip r{0, 0, 0, 0};
+            PnTrip r;
+            memset(&r, 0, sizeof(r));  // trip 0 (n_step == 1) is a list trip
             if (t == 0) { r.n_alive = dev->err ? 0 : (int)N; r.n_step = 1; }  // max(min(N // N, 8), 1)
             trips[t] = r;
             tail_counts[t] = 0;
@@ -1314,7 +1377,7 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
     PN_ALLOC(f->tail, N * sizeof(TailEntry)); PN_ALLOC(f->tail_counts, sizeof(int) * (PN_MAX_TRIPS + 2));
     PN_ALLOC(f->trips, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)); PN_ALLOC(f->dev, sizeof(PnFrameDev)); PN_ALLOC(f->cut_bounds, 6 * 4);
 #undef PN_ALLOC
-    PN_HIP_CHECK(hipMalloc((void**)&f->march_counters, 4 * sizeof(unsigned long long)));
+    PN_HIP_CHECK(hipMalloc((void**)&f->march_counters, 16 * sizeof(unsigned long long)));  // [4..15]: debug phase clocks (PN_DBG_PHASES builds)
     PN_HIP_CHECK(hipMalloc((void**)&f->stamps, sizeof(unsigned long long) * PN_TIMED_TRIPS * 3));
     PN_HIP_CHECK(hipHostMalloc((void**)&f->trips_pinned, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)));
     PN_HIP_CHECK(hipHostMalloc((void**)&f->dev_pinned, sizeof(PnFrameDev)));
@@ -1342,7 +1405,7 @@ static void frame_stats(pn_frame* f, int64_t* stats_host) {
     const int t = f->dev_pinned->trips_run;  // as the render itself recorded it (right after graph replays too)
     for (int k = 0; k < t; k++) {
         if (f->trips_pinned[k].n_alive > 0) trips++;
-        samples += f->trips_pinned[k].n_samples;
+        samples += f->trips_pinned[k].dense ? f->trips_pinned[k].n_emitted : f->trips_pinned[k].n_samples;
     }
     stats_host[0] = trips;
     stats_host[1] = samples;
@@ -1489,7 +1552,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             }
             k_composite<<<trip_grid, 256, 0, st>>>(0, 0, o->T_thresh, cur, f->rays_t, f->sigmas, f->rgbs, f->deltas, weights_sum, depth_0, f->acc_image,
                                                    f->trips + t, f->chunk_counts);
-            k_compact<<<trip_grid, 256, 0, st>>>(cur, 0, f->chunk_counts, nxt, nullptr, f->trips + t, f->trips + t + 1, N, o->max_steps);
+            k_compact<<<trip_grid, 256, 0, st>>>(cur, 0, f->chunk_counts, nxt, nullptr, f->trips + t, f->trips + t + 1, N, o->max_steps, is_static ? 0 : 1);
         }
         PN_LAUNCH_CHECK();
         if (async_trips > 0) break;
@@ -1550,9 +1613,18 @@ extern "C" int pn_frame_march_counters(pn_frame* f, int enable, uint64_t* counte
     hipStream_t st = (hipStream_t)stream;
     if (counters_host) {
         PN_HIP_CHECK(hipMemcpyAsync(counters_host, f->march_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+#if PN_DBG_PHASES
+        {
+            unsigned long long ph[16];
+            PN_HIP_CHECK(hipMemcpy(ph, f->march_counters, sizeof(ph), hipMemcpyDeviceToHost));
+            fprintf(stderr, "phases:");
+            for (int i = 4; i < 16; i++) fprintf(stderr, " %llu", ph[i]);
+            fprintf(stderr, "\n");
+        }
+#endif
         PN_HIP_CHECK(hipStreamSynchronize(st));
     }
-    if ((enable & 1) && !(f->march_counters_on & 1)) PN_HIP_CHECK(hipMemsetAsync(f->march_counters, 0, 4 * sizeof(unsigned long long), st));
+    if ((enable & 1) && !(f->march_counters_on & 1)) PN_HIP_CHECK(hipMemsetAsync(f->march_counters, 0, 16 * sizeof(unsigned long long), st));
     f->march_counters_on = enable & 3;  // bit 0: work counters, bit 1: per-trip event timing
     return PN_OK;
 }
@@ -1575,6 +1647,20 @@ extern "C" int pn_frame_trip_times(pn_frame* f, float* march_ms_host, float* net
         }
     }
     *n_trips_out = n;
+    return PN_OK;
+}
+
+extern "C" int pn_frame_trip_records(pn_frame* f, int* records_host, int* tail_counts_host, int max_trips, void* stream) {
+    PN_REQUIRE(f && records_host && tail_counts_host && max_trips >= 0);
+    PN_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    const int n = max_trips < PN_MAX_TRIPS ? max_trips : PN_MAX_TRIPS;
+    std::vector<PnTrip> rec((size_t)n);
+    PN_HIP_CHECK(hipMemcpy(rec.data(), f->trips, sizeof(PnTrip) * (size_t)n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+        int* r = records_host + 5 * i;
+        r[0] = rec[i].n_alive; r[1] = rec[i].n_step; r[2] = rec[i].step_base; r[3] = rec[i].n_samples; r[4] = rec[i].dense ? rec[i].n_emitted : -1;
+    }
+    PN_HIP_CHECK(hipMemcpy(tail_counts_host, f->tail_counts, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
     return PN_OK;
 }
 

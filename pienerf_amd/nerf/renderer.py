@@ -197,6 +197,12 @@ class NeRFRenderer(nn.Module):
         check(lib().pn_frame_march_counters(self._frames[slot][0], int(enable), out, stream_ptr()), "march_counters")
         return None if out is None else dict(iterations=int(out[0]), candidates=int(out[1]), warps=int(out[2]), samples=int(out[3]))
 
+    def trip_records(self, slot=0, max_trips=16):
+        """Diagnostics: [(n_alive, n_step, step_base, n_samples, n_emitted, n_tail)] per trip of the last render on `slot`."""
+        rec, tail = (C.c_int * (5 * max_trips))(), (C.c_int * max_trips)()
+        check(lib().pn_frame_trip_records(self._frames[slot][0], rec, tail, max_trips, stream_ptr()), "trip_records")
+        return [tuple(rec[5 * i:5 * i + 5]) + (tail[i],) for i in range(max_trips) if rec[5 * i] > 0]
+
     def trip_times(self, slot=0):
         """Per-trip (march_ms, network_ms) of the last render on `slot` made while event timing was enabled (HIP events on the launch stream;
         for a captured render: the records of the last replay)."""

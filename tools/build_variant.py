@@ -15,7 +15,12 @@ out_dir = os.path.join(b.HERE, "lib", "variants")
 obj_dir = os.path.join(out_dir, "obj_" + name)
 os.makedirs(obj_dir, exist_ok=True)
 objs = []
+only = os.environ.get("PN_VARIANT_UNITS", "pn_render_ops.hip").split(",")  # the other units are taken from the base build
+b.build()
 for src, extra in b.UNITS.items():
+    if src not in only:
+        objs.append(os.path.join(b.OBJ, src.replace(".hip", ".o")))
+        continue
     o = os.path.join(obj_dir, src.replace(".hip", ".o"))
     objs.append(o)
     subprocess.run([b.hipcc()] + b.COMMON + extra + flags + ["-c", os.path.join(b.CSRC, src), "-o", o], check=True)

@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-O=gpurun_out/r02l
+O=gpurun_out/r02v
 mkdir -p $O
 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_edges.py tests/test_gpu_golden.py tests/test_gpu_fullsize.py tests/test_gpu_half.py -m gpu -q -x 2>&1 | tail -5
 python bench.py --no-cpu-baseline --no-extras --steps 150 > $O/bench.json 2> $O/e

@@ -35,3 +35,7 @@ else:
         h.step(simulate=not args.no_sim, collect_stats=True)
     torch.cuda.synchronize()
     print(h.model.last_stats)
+    h.model.march_counters(1)
+    h.step(simulate=False, collect_stats=True)
+    print("counters", h.model.march_counters(1, read=True))
+    print("trips (n_alive, n_step, step_base, n_samples, n_tail)", h.model.trip_records())
