@@ -89,11 +89,8 @@ __device__ __forceinline__ unsigned dpp_u32(unsigned v) {
 struct __attribute__((packed, aligned(4))) Float3 {
     float x, y, z;
 };
-__device__ __forceinline__ void ray_consts(const MarchParams& a, int index, RayConsts& c) {
-    const Float3 o = *reinterpret_cast<const Float3*>(a.rays_o + (size_t)index * 3), d = *reinterpret_cast<const Float3*>(a.rays_d + (size_t)index * 3);
-    c.ox = o.x; c.oy = o.y; c.oz = o.z;
-    c.dx = d.x; c.dy = d.y; c.dz = d.z;
-    c.rdx = 1 / c.dx; c.rdy = 1 / c.dy; c.rdz = 1 / c.dz;
+// the part of RayConsts that does not depend on the ray
+__device__ __forceinline__ void frame_consts(const MarchParams& a, RayConsts& c) {
     const uint32_t H = a.H, C = a.C;
     c.rH = 1 / (float)H;
     c.H3 = (float)(H * H * H);
@@ -103,12 +100,19 @@ __device__ __forceinline__ void ray_consts(const MarchParams& a, int index, RayC
     c.Cf = (float)C;
     c.dt_min = 2 * 1.7320508075688772f / a.max_steps;
     c.dt_max = 2 * 1.7320508075688772f * (1 << (C - 1)) / H;
-    c.far = a.fars[index];
     c.bmin0 = a.bbmin[0]; c.bmin1 = a.bbmin[1]; c.bmin2 = a.bbmin[2];
     c.bmax0 = a.bbmax[0]; c.bmax1 = a.bbmax[1]; c.bmax2 = a.bbmax[2];
     c.hi0 = (float)((double)c.bmax0 - 1e-6); c.hi1 = (float)((double)c.bmax1 - 1e-6); c.hi2 = (float)((double)c.bmax2 - 1e-6);
     c.r0 = a.resolution[0]; c.r1 = a.resolution[1]; c.r2 = a.resolution[2];
     c.rbound = 1 / a.bound;
+}
+__device__ __forceinline__ void ray_consts(const MarchParams& a, int index, RayConsts& c) {
+    const Float3 o = *reinterpret_cast<const Float3*>(a.rays_o + (size_t)index * 3), d = *reinterpret_cast<const Float3*>(a.rays_d + (size_t)index * 3);
+    c.ox = o.x; c.oy = o.y; c.oz = o.z;
+    c.dx = d.x; c.dy = d.y; c.dz = d.z;
+    c.rdx = 1 / c.dx; c.rdy = 1 / c.dy; c.rdz = 1 / c.dz;
+    c.far = a.fars[index];
+    frame_consts(a, c);
 }
 
 // Trip prologue of one ray (raymarching.cu:1163-1172).  Returns false when the ray has nothing to march.

@@ -417,15 +417,38 @@ struct MarchIO {
     PnTrip* trip;
     int* list;
     float* t_resume;  // optional [n_alive]: written by k_march_skip, read by k_march (pn_march2.h: skip_empty_cells)
-    // optional tail pass: rays unfinished after `max_rounds` windows in k_march are appended here (count zeroed by the caller)
+    // optional tail pass: rays unfinished after `max_rounds` windows in k_march are appended here (counters zeroed by the caller)
     struct TailEntry* tail;
-    int* tail_count;
+    int* tail_counts;   // segmented (see PN_SEGS)
+    int tail_seg_cap;
     int max_rounds;
     // optional (trip 0 of the frame driver): k_march_skip lists the alive slots that still have something to march — nine rays in ten miss the
     // object's bounding box or run out of it inside the IP-free cells — and k_march walks that list instead of all n_alive slots
     int* active;
-    int* active_count;
+    int* active_counts;  // segmented
+    int active_seg_cap;
+    // frame-driver mode, list trips: the sample list is appended in segments (list_seg, samp_counts) and packed into `list` by k_list_pack;
+    // dense trips: emit_parts collects the number of samples really emitted
+    int* list_seg;
+    int* samp_counts;
+    int list_seg_cap;
+    int* emit_parts;
 };
+
+// Append lists are SEGMENTED: PN_SEGS independent (counter, region) pairs, every counter on a cache line of its own, the producer picking
+// its segment from its workgroup / wave id.  Atomics on ONE address are served one at a time by the memory side — measured 11.4 ns each on
+// gfx950, returning or not, however many waves issue them (tools/calib_atomic.hip: 5 000 waves x 1 atomic = +50 us) — and the march used one
+// per wave (sample list) or per ray (tail list): that serialisation, not ALU work or memory latency, was 50-120 us of every march launch.
+// Consumers need no prefix over the segments: workgroup b (wave w) takes segment b % PN_SEGS (w % PN_SEGS) and strides over its entries.
+#define PN_SEGS 64
+#define PN_SEG_STRIDE 32  // ints between counters: 128 B
+__device__ __forceinline__ int seg_count(const int* counts, int seg) {
+    return __hip_atomic_load(counts + seg * PN_SEG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// entries a segment must hold when its producers are the workgroups (32 rays each) / waves (64 rays) with id % PN_SEGS == segment
+// workers (workgroups or waves) whose id % PN_SEGS == seg, out of `total` (launches of segment consumers have at least PN_SEGS workers)
+__device__ __forceinline__ int seg_workers(int total, int seg) { return max((total - seg + PN_SEGS - 1) / PN_SEGS, 1); }
+static uint32_t seg_cap_for(uint32_t n_rays) { return (uint32_t)((pn_div_up(pn_div_up(n_rays, 64), PN_SEGS) + 1) * 64); }
 
 // One lane per ray slot: fast-forward over the leading run of IP-free search cells.
 __global__ void __launch_bounds__(256) k_march_skip(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
@@ -446,23 +469,31 @@ __global__ void __launch_bounds__(256) k_march_skip(pnm::MarchParams a, pnm2::Ma
             for (uint32_t s2 = 0; s2 < n_step; s2++) { dl[2 * s2] = 0.0f; dl[2 * s2 + 1] = 0.0f; }
         }
     }
-    if (io.active) {  // wave-aggregated append (order is irrelevant: every listed slot is processed independently)
+    if (io.active) {  // wave-aggregated append to this wave's segment (order is irrelevant: every listed slot is processed independently)
         const unsigned long long m = __ballot(work);
         const int lane = threadIdx.x & 63;
+        const int seg = (int)((n >> 6) % PN_SEGS);
         int base = 0;
-        if (lane == 0 && m) base = atomicAdd(io.active_count, (int)__popcll(m));
+        if (lane == 0 && m) base = atomicAdd(io.active_counts + seg * PN_SEG_STRIDE, (int)__popcll(m));
         base = __shfl(base, 0);
-        if (work) io.active[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int)n;
+        if (work) io.active[(size_t)seg * io.active_seg_cap + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (int)n;
     }
 }
 
 // ---- the per-ray march (pn_march3.h): pass 1 = k_march (8 lanes per ray, bounded number of rounds), pass 2 = k_march_tail
 // (one wave per ray that pass 1 left unfinished).
-struct TailEntry {
+// A ray handed from k_march to k_march_tail, with everything the tail pass needs to go on: fetching the slot's ray through rays_alive ->
+// rays_o / rays_d / fars again cost the tail three dependent memory round trips per ray — half of a typical tail ray's time (phase clocks).
+struct __attribute__((aligned(16))) TailEntry {
     int n;            // alive slot
     float t, last_t;  // pnm3::RayState
     int step;
+    float ox, oy, oz, dx;
+    float dy, dz, rdx, rdy;
+    float rdz, far;
+    int pad0, pad1;
 };
+static_assert(sizeof(TailEntry) == 64, "four 16-byte parts");
 
 // waves per SIMD the march kernels are compiled for: 4 -> at most 128 VGPRs.  The kernels wait on memory rather than on
 // occupancy, but their register footprint decides what else fits beside them: with 3 waves x 146 VGPRs a SIMD had no room left
@@ -483,20 +514,16 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams 
     __shared__ float4 stage_mem[4][PN_STAGE_CAP];
     float4* stage = stage_mem[threadIdx.x >> 6];
     // 32-ray chunks are dealt round-robin to a bounded grid: in frame mode the alive count is only known on the device, and a
-    // grid sized for all N rays would push ~20 000 mostly empty workgroups through the dispatcher on every trip
-    const uint32_t n_work = io.active ? (uint32_t)__hip_atomic_load(io.active_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : n_alive;
+    // grid sized for all N rays would push ~20 000 mostly empty workgroups through the dispatcher on every trip.  With an active list
+    // (trip 0) workgroup b walks segment b % PN_SEGS of it; either way `seg` names the segment this workgroup's own appends go to.
+    const uint32_t act_seg = blockIdx.x % PN_SEGS;
+    const uint32_t n_work = io.active ? (uint32_t)seg_count(io.active_counts, (int)act_seg) : n_alive;
+    const uint32_t k0 = io.active ? blockIdx.x / PN_SEGS : blockIdx.x, kstep = io.active ? (uint32_t)seg_workers((int)gridDim.x, (int)act_seg) : gridDim.x;
     PN_PHASE_DECL(pk);
-    // Chunk -> workgroup mapping: workgroup b runs on XCD b % 8 (observed dispatch order, MI355X_MICROARCH.md) and each XCD has its own 4 MB L2;
-    // the alive list is in raster order, so XCD x takes the x-th contiguous eighth of the chunks — one band of the image, one slab of the object,
-    // one eighth of the candidate lists and IP records in its L2 instead of all of them in all eight (rocprofv3: > 50 % L2 misses before).
-    const uint32_t n_chunks = (n_work + 31u) / 32u;
-    const uint32_t xcd = blockIdx.x & 7u, per_xcd = (n_chunks + 7u) / 8u, wg_per_xcd = max(gridDim.x >> 3, 1u);
-    const bool xcd_map = (gridDim.x & 7u) == 0;
-    for (uint32_t k = xcd_map ? (blockIdx.x >> 3) : blockIdx.x; xcd_map ? (k < per_xcd) : (k < n_chunks); k += xcd_map ? wg_per_xcd : gridDim.x) {
-        const uint32_t chunk = xcd_map ? xcd * per_xcd + k : k;
-        if (chunk >= n_chunks) break;
+    for (uint32_t chunk = k0; chunk * 32u < n_work; chunk += kstep) {
+        const uint32_t seg = io.active ? act_seg : chunk % PN_SEGS;
         const uint32_t i_work = chunk * 32u + (threadIdx.x >> 3);
-        const uint32_t n = io.active ? (i_work < n_work ? (uint32_t)io.active[i_work] : 0xffffffffu) : i_work;
+        const uint32_t n = io.active ? (i_work < n_work ? (uint32_t)io.active[(size_t)act_seg * io.active_seg_cap + i_work] : 0xffffffffu) : i_work;
         uint32_t emitted = 0;
         bool deferred = false, have = false;
         float* dl = nullptr;
@@ -514,15 +541,26 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams 
         const bool done = pnm3::march_window<K, MULTI, 8>(a, tb, c, n_step, sub, gbase, lane, stage, io.xyzs + (size_t)n * n_step * 3,
                                                           io.dirs + (size_t)n * n_step * 3, dl, st, budget, have PN_PHASE_PASS);
         if (n < n_alive) {
-            if (have && !done) {  // still marching after the round budget: continue with a whole wave (k_march_tail)
-                deferred = true;
-                if (sub == 0) {
-                    const int pos = atomicAdd(io.tail_count, 1);
-                    io.tail[pos] = TailEntry{(int)n, st.t, st.last_t, (int)st.step};
-                }
-            }
+            deferred = have && !done;  // still marching after the round budget: continue with a whole wave (k_march_tail)
             emitted = deferred ? 0u : st.step;  // a deferred ray's samples are listed by the tail pass
             if (!PN_DBG_PHASES_ON && a.stats && sub == 0 && emitted) atomicAdd(a.stats + 3, (unsigned long long)emitted);
+        }
+        if (io.tail) {  // one counter update per wave for all its deferred rays
+            const unsigned long long dm = __ballot(deferred && sub == 0);
+            if (dm) {
+                int pos = 0;
+                if (lane == 0) pos = atomicAdd(io.tail_counts + seg * PN_SEG_STRIDE, (int)__popcll(dm));
+                pos = __shfl(pos, 0);
+                if (deferred && sub < 4) {  // lanes 0..3 of the group write one 16-byte part each
+                    float4* te = reinterpret_cast<float4*>(io.tail + (size_t)seg * io.tail_seg_cap + pos + (int)__popcll(dm & ((1ull << (lane & ~7)) - 1ull)));
+                    float4 part;
+                    if (sub == 0) part = make_float4(__int_as_float((int)n), st.t, st.last_t, __int_as_float((int)st.step));
+                    else if (sub == 1) part = make_float4(c.ox, c.oy, c.oz, c.dx);
+                    else if (sub == 2) part = make_float4(c.dy, c.dz, c.rdx, c.rdy);
+                    else part = make_float4(c.rdz, c.far, 0.f, 0.f);
+                    te[sub] = part;
+                }
+            }
         }
         if (io.trip) {
             // slots the ray did not fill end it in composite (delta == 0); the op-level wrapper zero-fills instead (raymarching.py:415-417)
@@ -535,9 +573,9 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams 
                     for (uint32_t s = emitted + sub; s < n_step; s += PN_G) { X[3 * s] = X[3 * s + 1] = X[3 * s + 2] = 0.0f; Dd[3 * s] = Dd[3 * s + 1] = Dd[3 * s + 2] = 0.0f; }
                     for (uint32_t s = sub; s < n_step; s += PN_G) io.list[n * n_step + s] = (int)(n * n_step + s);
                 }
-                int v = (sub == 0 && dl && !deferred) ? (int)emitted : 0;  // one counter update per wave, result unused: no wait
+                int v = (sub == 0 && dl && !deferred) ? (int)emitted : 0;  // one counter update per wave
                 v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-                if (lane == 0 && v) atomicAdd(&io.trip->n_emitted, v);
+                if (lane == 0 && v) atomicAdd(io.emit_parts + seg * PN_SEG_STRIDE, v);
             } else {
             // wave-aggregated append of this wave's valid sample slots (one atomic per wave)
             int inc = (sub == 0) ? (int)emitted : 0;
@@ -548,10 +586,11 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams 
             }
             const int total = __shfl(inc, 63);
             int base = 0;
-            if (lane == 63 && total > 0) base = atomicAdd(&io.trip->n_samples, total);
+            if (lane == 63 && total > 0) base = atomicAdd(io.samp_counts + seg * PN_SEG_STRIDE, total);
             base = __shfl(base, 63);
             const int first = base + __shfl(inc, gbase) - (int)emitted;  // exclusive prefix of this group's first lane
-            for (uint32_t s = sub; s < emitted; s += PN_G) io.list[first + s] = (int)(n * n_step + s);
+            int* seg_list = io.list_seg + (size_t)seg * io.list_seg_cap;
+            for (uint32_t s = sub; s < emitted; s += PN_G) seg_list[first + s] = (int)(n * n_step + s);
             }
         }
         PN_PHASE(pk, 5);
@@ -565,19 +604,20 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march_tail(pnm::MarchPa
     uint32_t n_step = io.n_step;
     bool dense = false;
     if (io.trip) { n_step = (uint32_t)io.trip->n_step; dense = trip_is_dense(io.trip); }
-    const int total = __hip_atomic_load(io.tail_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int lane = threadIdx.x & 63;
-    const int n_waves = (int)gridDim.x * 4;
+    const int gw = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), n_waves = (int)gridDim.x * 4;
+    const int seg = gw % PN_SEGS;  // this wave's segment of the tail list; its own appends go to the same segment of the sample list
+    const int total = seg_count(io.tail_counts, seg);
     __shared__ float4 stage_mem[4][PN_STAGE_CAP];
     float4* stage = stage_mem[threadIdx.x >> 6];
     PN_PHASE_DECL(pk);
-    for (int e = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); e < total; e += n_waves) {
-        const TailEntry te = io.tail[e];
+    for (int e = gw / PN_SEGS; e < total; e += seg_workers(n_waves, seg)) {
+        const TailEntry te = io.tail[(size_t)seg * io.tail_seg_cap + e];
         const uint32_t n = (uint32_t)te.n;
-        const int index = io.rays_alive[n];
         float* dl = io.deltas + (size_t)n * n_step * 2;
         pnm3::RayConsts c;
-        pnm3::ray_consts(a, index, c);
+        c.ox = te.ox; c.oy = te.oy; c.oz = te.oz; c.dx = te.dx; c.dy = te.dy; c.dz = te.dz; c.rdx = te.rdx; c.rdy = te.rdy; c.rdz = te.rdz; c.far = te.far;
+        pnm3::frame_consts(a, c);
         pnm3::RayState st{te.t, te.last_t, (uint32_t)te.step};
         PN_PHASE(pk, 0);
         pnm3::march_window<K, MULTI, 64>(a, tb, c, n_step, lane, 0, lane, stage, io.xyzs + (size_t)n * n_step * 3, io.dirs + (size_t)n * n_step * 3,
@@ -591,12 +631,13 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march_tail(pnm::MarchPa
                 float* Dd = io.dirs + (size_t)n * n_step * 3;
                 for (uint32_t s = emitted + lane; s < n_step; s += 64) { X[3 * s] = X[3 * s + 1] = X[3 * s + 2] = 0.0f; Dd[3 * s] = Dd[3 * s + 1] = Dd[3 * s + 2] = 0.0f; }
                 for (uint32_t s = lane; s < n_step; s += 64) io.list[n * n_step + s] = (int)(n * n_step + s);
-                if (lane == 0 && emitted) atomicAdd(&io.trip->n_emitted, (int)emitted);
+                if (lane == 0 && emitted) atomicAdd(io.emit_parts + seg * PN_SEG_STRIDE, (int)emitted);
             } else {
                 int base = 0;
-                if (lane == 0 && emitted > 0) base = atomicAdd(&io.trip->n_samples, (int)emitted);
+                if (lane == 0 && emitted > 0) base = atomicAdd(io.samp_counts + seg * PN_SEG_STRIDE, (int)emitted);
                 base = __shfl(base, 0);
-                for (uint32_t s = lane; s < emitted; s += 64) io.list[base + s] = (int)(n * n_step + s);
+                int* seg_list = io.list_seg + (size_t)seg * io.list_seg_cap;
+                for (uint32_t s = lane; s < emitted; s += 64) seg_list[base + s] = (int)(n * n_step + s);
             }
         }
         PN_PHASE(pk, 5);
@@ -670,9 +711,11 @@ extern "C" int pn_march_rays_quadratic_bending(const int* pig_cnt, const int* pi
     const size_t ints = ((size_t)n_grid + 1) * 3 * sizeof(int), nbb = (size_t)s.nb_capacity * sizeof(float4), recb = (size_t)n_vtx * PN_REC_FLOATS * sizeof(float);
     const size_t off_nb = (ints + 255) & ~(size_t)255, off_rec = (off_nb + nbb + 255) & ~(size_t)255;
     const size_t off_res = (off_rec + recb + 255) & ~(size_t)255;
-    const size_t off_tail = (off_res + (size_t)n_alive * sizeof(float) + 255) & ~(size_t)255;  // [tail counter | 16 B pad | tail entries]
-    PN_HIP_CHECK(hipMallocAsync((void**)&pool, off_tail + 16 + (size_t)n_alive * sizeof(TailEntry), st));
-    PN_HIP_CHECK(hipMemsetAsync(pool + off_tail, 0, 16, st));
+    const uint32_t tail_cap = seg_cap_for(n_alive);
+    const size_t tail_ctr = (size_t)PN_SEGS * PN_SEG_STRIDE * sizeof(int);
+    const size_t off_tail = (off_res + (size_t)n_alive * sizeof(float) + 255) & ~(size_t)255;  // [segment counters | tail entries]
+    PN_HIP_CHECK(hipMallocAsync((void**)&pool, off_tail + tail_ctr + (size_t)PN_SEGS * tail_cap * sizeof(TailEntry), st));
+    PN_HIP_CHECK(hipMemsetAsync(pool + off_tail, 0, tail_ctr, st));
     s.nb_cnt = (int*)pool; s.nb_bgn = s.nb_cnt + n_grid + 1; s.nb_cursor = s.nb_bgn + n_grid + 1;
     s.nb = (float4*)(pool + off_nb); s.rec = (float*)(pool + off_rec);
     int rc = march_side_build(s, n_vtx, n_grid, nullptr, resolution, pig_cnt, pig_bgn, pig_idx, p_def, p_ori, F_IP, dF_IP, num_seek_IP, err_flag, st);
@@ -682,9 +725,10 @@ extern "C" int pn_march_rays_quadratic_bending(const int* pig_cnt, const int* pi
                                                C, H, grid, fars, err_flag);
         pnm2::March2Tables tb{s.nb_bgn, s.nb, (const float4*)s.rec};
         MarchIO io{n_alive, n_step, rays_alive, xyzs, dirs, deltas, noises, nullptr, nullptr, (float*)(pool + off_res),
-                   (TailEntry*)(pool + off_tail + 16), (int*)(pool + off_tail), (int)march_tail_rounds(), nullptr, nullptr};
+                   (TailEntry*)(pool + off_tail + tail_ctr), (int*)(pool + off_tail), (int)tail_cap, (int)march_tail_rounds(), nullptr, nullptr, 0,
+                   nullptr, nullptr, 0, nullptr};
         if (io.t_resume) k_march_skip<<<pn_div_up(n_alive, 256), 256, 0, st>>>(a, tb, io);
-        launch_march(num_seek_IP, pn_div_up(n_alive, 32), std::min(pn_div_up(n_alive, 4), 2048u), st, a, tb, io);
+        launch_march(num_seek_IP, pn_div_up(n_alive, 32), std::max(std::min(pn_div_up(n_alive, 4), 2048u), (uint32_t)PN_SEGS / 4), st, a, tb, io);
     }
     PN_HIP_CHECK(hipFreeAsync(pool, st));
     if (rc) return rc;
@@ -991,11 +1035,32 @@ __global__ void __launch_bounds__(256) k_chunk_count(const int* __restrict__ ray
     if (threadIdx.x == 0) chunk_counts[blockIdx.x] = c;
 }
 
+// Packs the PN_SEGS segments of a list trip's sample list into the dense list the network kernel reads and publishes the total
+// (workgroup s copies segment s behind the segments before it).  A dense trip has nothing to pack.
+__global__ void __launch_bounds__(256) k_list_pack(PnTrip* trip, const int* __restrict__ samp_counts, const int* __restrict__ list_seg, int seg_cap,
+                                                   int* __restrict__ list) {
+    if (trip_is_dense(trip) || trip->n_alive <= 0) return;
+    const int s = (int)blockIdx.x, lane = threadIdx.x & 63;
+    __shared__ int before_s, total_s;
+    if (threadIdx.x < 64) {
+        const int c = samp_counts[lane * PN_SEG_STRIDE];
+        int pre = lane < s ? c : 0, tot = c;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { pre += __shfl_xor(pre, o); tot += __shfl_xor(tot, o); }
+        if (lane == 0) { before_s = pre; total_s = tot; }
+    }
+    __syncthreads();
+    const int n = samp_counts[s * PN_SEG_STRIDE], off = before_s;
+    const int* src = list_seg + (size_t)s * seg_cap;
+    for (int i = threadIdx.x; i < n; i += 256) list[off + i] = src[i];
+    if (s == 0 && threadIdx.x == 0) trip->n_samples = total_s;
+}
+
 // Block c moves the survivors of chunk c to out[prefix(c) ...], keeping order (== rays_alive[rays_alive >= 0]).
 // Block 0 also publishes the total and, in frame-driver mode, the next trip's record (renderer.py:839-846,891).
 __global__ void __launch_bounds__(256) k_compact(const int* __restrict__ in, uint32_t n_arg, const int* __restrict__ chunk_counts,
-                                                 int* __restrict__ out, int* n_out, const PnTrip* trip, PnTrip* next, uint32_t N_rays,
-                                                 uint32_t max_steps, int dense_trips) {
+                                                 int* __restrict__ out, int* n_out, PnTrip* trip, PnTrip* next, uint32_t N_rays,
+                                                 uint32_t max_steps, int dense_trips, int* seg_counters, int* tail_diag) {
     __shared__ int red[4];
     __shared__ int woff[4];
     const uint32_t n = trip ? (uint32_t)trip->n_alive : n_arg;
@@ -1013,6 +1078,18 @@ __global__ void __launch_bounds__(256) k_compact(const int* __restrict__ in, uin
         __syncthreads();
         const int sum = red[0] + red[1] + red[2] + red[3];
         const int offset = (c == 0) ? 0 : sum;
+        if (c == 0 && seg_counters && wid == 0) {
+            // frame driver: this trip's march is over — fold its segment counters (seg_counters = [tail | sample | emitted] x PN_SEGS) into
+            // the records and clear them for the next trip
+            int* tail_c = seg_counters + lane * PN_SEG_STRIDE;
+            int* samp_c = tail_c + PN_SEGS * PN_SEG_STRIDE;
+            int* emit_c = samp_c + PN_SEGS * PN_SEG_STRIDE;
+            int tl = *tail_c, em = *emit_c;
+            *tail_c = 0; *samp_c = 0; *emit_c = 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { tl += __shfl_xor(tl, o); em += __shfl_xor(em, o); }
+            if (lane == 0) { if (tail_diag) *tail_diag = tl; if (trip) trip->n_emitted = em; }
+        }
         if (c == 0 && threadIdx.x == 0) {
             if (n_out) *n_out = sum;
             if (next) {
@@ -1051,7 +1128,7 @@ extern "C" int pn_compact_rays(const int* rays_alive, uint32_t n, int* out, int*
     PN_REQUIRE(rays_alive && out && scratch);
     const uint32_t chunks = pn_div_up(n, 256);
     k_chunk_count<<<chunks, 256, 0, st>>>(rays_alive, n, scratch);
-    k_compact<<<chunks, 256, 0, st>>>(rays_alive, n, scratch, out, n_out, nullptr, nullptr, 0, 0, 0);
+    k_compact<<<chunks, 256, 0, st>>>(rays_alive, n, scratch, out, n_out, nullptr, nullptr, 0, 0, 0, nullptr, nullptr);
     PN_LAUNCH_CHECK();
     return PN_OK;
 }
@@ -1068,8 +1145,12 @@ struct pn_frame {
     float* acc_image;  // [max_rays,3] colour accumulated by composite; the epilogue writes image = acc + (1 - weights_sum) * bg, so a frame can be
                        // continued with more trips and finished again (pn_render_continue)
     int *alive_a, *alive_b, *list, *chunk_counts;
-    TailEntry* tail;   // [max_rays] rays handed from k_march to k_march_tail
-    int* tail_counts;  // [PN_MAX_TRIPS + 2] one counter per trip, zeroed by k_frame_rays
+    TailEntry* tail;    // [PN_SEGS x seg_cap] rays handed from k_march to k_march_tail
+    int* list_seg;      // [PN_SEGS x seg_cap] segmented sample list of a list trip (k_list_pack -> list)
+    int* active_seg;    // [PN_SEGS x seg_cap] trip 0: the slots k_march_skip left something to march for
+    uint32_t seg_cap;
+    int* seg_counters;  // [4][PN_SEGS] counters, one per 128 B: tail | sample | emitted (cleared by each trip's compaction) | active (k_frame_rays)
+    int* tail_counts;   // [PN_MAX_TRIPS + 2] diagnostics: rays each trip handed to the tail pass
     int *pig_cnt, *pig_bgn, *pig_idx, *pig_cursor;
     MarchSide side;  // candidate lists + packed IP records of the cooperative march
     PnTrip* trips;  // [PN_MAX_TRIPS + 2]
@@ -1313,7 +1394,7 @@ __global__ void __launch_bounds__(256) k_frame_lists(int n_grid_max, const int* 
 //     rays_alive = arange(N) (:828), rays_t = nears (:829), zeroed trip records and tail counters, trip 0 = (N rays, n_step 1).
 __global__ void __launch_bounds__(256) k_frame_rays(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const PnFrameDev* dev, uint32_t N,
                                                     float min_near, float* __restrict__ nears, float* __restrict__ fars, float* __restrict__ rays_t,
-                                                    PnTrip* trips, int* tail_counts, int n_trip_records, int* alive, float* __restrict__ weights_sum,
+                                                    PnTrip* trips, int* tail_counts, int* seg_counters, int n_trip_records, int* alive, float* __restrict__ weights_sum,
                                                     float* __restrict__ depth_0, float* __restrict__ image) {
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
     if (blockIdx.x == 0) {
@@ -1324,6 +1405,7 @@ __global__ void __launch_bounds__(256) k_frame_rays(const float* __restrict__ ra
             trips[t] = r;
             tail_counts[t] = 0;
         }
+        for (int t = threadIdx.x; t < 4 * PN_SEGS; t += blockDim.x) seg_counters[t * PN_SEG_STRIDE] = 0;
     }
     if (n >= N) return;
     const float* aabb = dev->aabb;
@@ -1374,7 +1456,10 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
     PN_ALLOC(f->side.nb_cursor, ((size_t)max_grid_cells + 1) * 4);
     f->side.nb_capacity = 27 * (int)max_vtx;
     PN_ALLOC(f->side.nb, (size_t)f->side.nb_capacity * sizeof(float4)); PN_ALLOC(f->side.rec, (size_t)max_vtx * PN_REC_FLOATS * 4);
-    PN_ALLOC(f->tail, N * sizeof(TailEntry)); PN_ALLOC(f->tail_counts, sizeof(int) * (PN_MAX_TRIPS + 2));
+    f->seg_cap = seg_cap_for(max_rays);
+    PN_ALLOC(f->tail, (size_t)PN_SEGS * f->seg_cap * sizeof(TailEntry)); PN_ALLOC(f->tail_counts, sizeof(int) * (PN_MAX_TRIPS + 2));
+    PN_ALLOC(f->list_seg, (size_t)PN_SEGS * f->seg_cap * 4); PN_ALLOC(f->active_seg, (size_t)PN_SEGS * f->seg_cap * 4);
+    PN_ALLOC(f->seg_counters, (size_t)4 * PN_SEGS * PN_SEG_STRIDE * 4);
     PN_ALLOC(f->trips, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)); PN_ALLOC(f->dev, sizeof(PnFrameDev)); PN_ALLOC(f->cut_bounds, 6 * 4);
 #undef PN_ALLOC
     PN_HIP_CHECK(hipMalloc((void**)&f->march_counters, 16 * sizeof(unsigned long long)));  // [4..15]: debug phase clocks (PN_DBG_PHASES builds)
@@ -1391,7 +1476,8 @@ extern "C" void pn_frame_destroy(pn_frame* f) {
     if (!f) return;
     void* ptrs[] = {f->acc_image, f->nears, f->fars, f->rays_t, f->xyzs, f->dirs, f->deltas, f->sigmas, f->rgbs, f->alive_a, f->alive_b, f->list,
                     f->chunk_counts, f->pig_cnt, f->pig_bgn, f->pig_cursor, f->pig_idx, f->trips, f->dev, f->cut_bounds,
-                    f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, f->side.nb, f->side.rec, f->march_counters, f->tail, f->tail_counts, f->stamps};
+                    f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, f->side.nb, f->side.rec, f->march_counters, f->tail, f->tail_counts, f->stamps,
+                    f->list_seg, f->active_seg, f->seg_counters};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int t = 0; t < PN_TIMED_TRIPS; t++)
         for (int e = 0; e < 3; e++) if (f->ev[t][e]) (void)hipEventDestroy(f->ev[t][e]);
@@ -1441,7 +1527,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     static const uint32_t march_grid_cfg = pn_env_u32("PN_MARCH_GRID", 8192), trip_grid_cfg = pn_env_u32("PN_TRIP_GRID", 1024);
     const uint32_t march_grid = march_grid_cfg, trip_grid = std::min(nblk, trip_grid_cfg);
     static const uint32_t tail_grid_cfg = pn_env_u32("PN_TAIL_GRID", 1024);  // x4 waves, one unfinished ray per wave at a time
-    const uint32_t tail_grid = std::min(pn_div_up(N, 4), tail_grid_cfg);
+    const uint32_t tail_grid = std::max(std::min(pn_div_up(N, 4), tail_grid_cfg), (uint32_t)PN_SEGS / 4);  // every tail segment needs a wave
 
     if (!f->cut_bounds_valid || memcmp(f->cut_bounds_host, o->cut_bounds, sizeof(f->cut_bounds_host)) != 0) {  // uploaded only when it changes
         memcpy(f->cut_bounds_host, o->cut_bounds, sizeof(f->cut_bounds_host));
@@ -1493,7 +1579,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                                                                  f->side.nb_cnt, f->side.nb_bgn, f->side.nb, f->side.nb_capacity, err, list_blocks, n_vtx,
                                                                  p_ori, F_IP, dF_IP, f->side.rec);
     }
-    k_frame_rays<<<nblk, 256, 0, st>>>(rays_o, rays_d, f->dev, N, o->min_near, f->nears, f->fars, f->rays_t, f->trips, f->tail_counts,
+    k_frame_rays<<<nblk, 256, 0, st>>>(rays_o, rays_d, f->dev, N, o->min_near, f->nears, f->fars, f->rays_t, f->trips, f->tail_counts, f->seg_counters,
                                        PN_MAX_TRIPS + 2, f->alive_a, weights_sum, depth_0, f->acc_image);
     PN_LAUNCH_CHECK();
     }
@@ -1517,8 +1603,14 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             // fast-forwards them; its per-ray resume point lives in `sigmas`, which is not written before this trip's network launch
             // ... and lists the slots that still have work (in `nxt`, which nobody reads before this trip's compaction writes it; the counter is
             // the spare last entry of the per-trip tail counters, zeroed by k_frame_rays)
+            int* seg_tail = f->seg_counters;
+            int* seg_samp = seg_tail + PN_SEGS * PN_SEG_STRIDE;
+            int* seg_emit = seg_samp + PN_SEGS * PN_SEG_STRIDE;
+            int* seg_active = seg_emit + PN_SEGS * PN_SEG_STRIDE;
+            // trip 0 keeps its skip pre-pass state in f->sigmas (t_resume) and lists the slots worth marching in f->active_seg
             MarchIO io{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + t, f->list, (t == 0) ? f->sigmas : nullptr,
-                       f->tail, f->tail_counts + t, (int)march_tail_rounds(), (t == 0) ? nxt : nullptr, (t == 0) ? f->tail_counts + PN_MAX_TRIPS + 1 : nullptr};
+                       f->tail, seg_tail, (int)f->seg_cap, (int)march_tail_rounds(), (t == 0) ? f->active_seg : nullptr, (t == 0) ? seg_active : nullptr,
+                       (int)f->seg_cap, f->list_seg, seg_samp, (int)f->seg_cap, seg_emit};
             const bool timed = (f->march_counters_on & 2) && t < PN_TIMED_TRIPS;
             bool stamp = false;
             if (timed) {  // measurement mode: the two heavy launch groups of each trip are bracketed on the launch stream
@@ -1539,7 +1631,8 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                                                                o->grid_size, bitfield, f->fars, f->xyzs, f->dirs, f->deltas, f->list);
             } else {
                 if (io.t_resume) k_march_skip<<<nblk, 256, 0, st>>>(mp, tb, io);
-                launch_march(o->num_seek_IP, std::min(pn_div_up(N, 32), march_grid), tail_grid, st, mp, tb, io);
+                launch_march(o->num_seek_IP, std::max(std::min(pn_div_up(N, 32), march_grid), (uint32_t)PN_SEGS), tail_grid, st, mp, tb, io);
+                k_list_pack<<<PN_SEGS, 256, 0, st>>>(f->trips + t, seg_samp, f->list_seg, (int)f->seg_cap, f->list);
             }
             if (timed && stamp) k_stamp<<<1, 1, 0, st>>>(f->stamps + t * 3 + 1);
             else if (timed) PN_HIP_CHECK(hipEventRecord(f->ev[t][1], st));
@@ -1552,7 +1645,8 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             }
             k_composite<<<trip_grid, 256, 0, st>>>(0, 0, o->T_thresh, cur, f->rays_t, f->sigmas, f->rgbs, f->deltas, weights_sum, depth_0, f->acc_image,
                                                    f->trips + t, f->chunk_counts);
-            k_compact<<<trip_grid, 256, 0, st>>>(cur, 0, f->chunk_counts, nxt, nullptr, f->trips + t, f->trips + t + 1, N, o->max_steps, is_static ? 0 : 1);
+            k_compact<<<trip_grid, 256, 0, st>>>(cur, 0, f->chunk_counts, nxt, nullptr, f->trips + t, f->trips + t + 1, N, o->max_steps, is_static ? 0 : 1,
+                                                 is_static ? nullptr : f->seg_counters, f->tail_counts + t);
         }
         PN_LAUNCH_CHECK();
         if (async_trips > 0) break;
