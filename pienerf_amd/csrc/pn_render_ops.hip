@@ -419,7 +419,9 @@ struct MarchIO {
     float* t_resume;  // optional [n_alive]: written by k_march_skip, read by k_march (pn_march2.h: skip_empty_cells)
     // optional tail pass: rays unfinished after `max_rounds` windows in k_march are appended here (counters zeroed by the caller)
     struct TailEntry* tail;
-    int* tail_counts;   // segmented (see PN_SEGS)
+    int* tail_counts;   // segmented (see PN_SEGS): rays with a long way to go, appended from the front of the segment's region
+    int* tail_back;     // segmented: the others, appended from the back (the tail pass starts the long ones first)
+    int* tail_cursors;  // segmented: next unprocessed entry (the tail pass hands its rays out dynamically)
     int tail_seg_cap;
     int max_rounds;
     // optional (trip 0 of the frame driver): k_march_skip lists the alive slots that still have something to march — nine rays in ten miss the
@@ -545,14 +547,20 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams 
             emitted = deferred ? 0u : st.step;  // a deferred ray's samples are listed by the tail pass
             if (!PN_DBG_PHASES_ON && a.stats && sub == 0 && emitted) atomicAdd(a.stats + 3, (unsigned long long)emitted);
         }
-        if (io.tail) {  // one counter update per wave for all its deferred rays
-            const unsigned long long dm = __ballot(deferred && sub == 0);
+        if (io.tail) {  // one counter update per wave and class for all its deferred rays
+            // class: more than three 64-element windows still to go (longest-first start order shortens the tail pass's critical path)
+            const bool is_long = deferred && (c.far - st.t) > 192.0f * pnm3::dtf(a, c, st.t);
+            const unsigned long long dm = __ballot(deferred && sub == 0), lm = __ballot(is_long && sub == 0), sm = dm & ~lm;
             if (dm) {
-                int pos = 0;
-                if (lane == 0) pos = atomicAdd(io.tail_counts + seg * PN_SEG_STRIDE, (int)__popcll(dm));
-                pos = __shfl(pos, 0);
+                int posl = 0, poss = 0;
+                if (lane == 0 && lm) posl = atomicAdd(io.tail_counts + seg * PN_SEG_STRIDE, (int)__popcll(lm));
+                if (lane == 0 && sm) poss = atomicAdd(io.tail_back + seg * PN_SEG_STRIDE, (int)__popcll(sm));
+                posl = __shfl(posl, 0);
+                poss = __shfl(poss, 0);
                 if (deferred && sub < 4) {  // lanes 0..3 of the group write one 16-byte part each
-                    float4* te = reinterpret_cast<float4*>(io.tail + (size_t)seg * io.tail_seg_cap + pos + (int)__popcll(dm & ((1ull << (lane & ~7)) - 1ull)));
+                    const unsigned long long below = (1ull << (lane & ~7)) - 1ull;
+                    const int slot = is_long ? posl + (int)__popcll(lm & below) : io.tail_seg_cap - 1 - (poss + (int)__popcll(sm & below));
+                    float4* te = reinterpret_cast<float4*>(io.tail + (size_t)seg * io.tail_seg_cap + slot);
                     float4 part;
                     if (sub == 0) part = make_float4(__int_as_float((int)n), st.t, st.last_t, __int_as_float((int)st.step));
                     else if (sub == 1) part = make_float4(c.ox, c.oy, c.oz, c.dx);
@@ -607,12 +615,19 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march_tail(pnm::MarchPa
     const int lane = threadIdx.x & 63;
     const int gw = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), n_waves = (int)gridDim.x * 4;
     const int seg = gw % PN_SEGS;  // this wave's segment of the tail list; its own appends go to the same segment of the sample list
-    const int total = seg_count(io.tail_counts, seg);
+    const int n_long = seg_count(io.tail_counts, seg), total = n_long + seg_count(io.tail_back, seg);
     __shared__ float4 stage_mem[4][PN_STAGE_CAP];
     float4* stage = stage_mem[threadIdx.x >> 6];
     PN_PHASE_DECL(pk);
-    for (int e = gw / PN_SEGS; e < total; e += seg_workers(n_waves, seg)) {
-        const TailEntry te = io.tail[(size_t)seg * io.tail_seg_cap + e];
+    // the rays of a segment are handed out one at a time to the waves that serve it: their lengths differ by an order of magnitude (1 to 8
+    // windows), and with a fixed assignment the wave that drew several long ones set the kernel's duration
+    (void)n_waves;
+    for (;;) {
+        int e = 0;
+        if (lane == 0) e = atomicAdd(io.tail_cursors + seg * PN_SEG_STRIDE, 1);
+        e = __builtin_amdgcn_readfirstlane(e);
+        if (e >= total) break;
+        const TailEntry te = io.tail[(size_t)seg * io.tail_seg_cap + (e < n_long ? e : io.tail_seg_cap - 1 - (e - n_long))];
         const uint32_t n = (uint32_t)te.n;
         float* dl = io.deltas + (size_t)n * n_step * 2;
         pnm3::RayConsts c;
@@ -712,7 +727,7 @@ extern "C" int pn_march_rays_quadratic_bending(const int* pig_cnt, const int* pi
     const size_t off_nb = (ints + 255) & ~(size_t)255, off_rec = (off_nb + nbb + 255) & ~(size_t)255;
     const size_t off_res = (off_rec + recb + 255) & ~(size_t)255;
     const uint32_t tail_cap = seg_cap_for(n_alive);
-    const size_t tail_ctr = (size_t)PN_SEGS * PN_SEG_STRIDE * sizeof(int);
+    const size_t tail_ctr = (size_t)3 * PN_SEGS * PN_SEG_STRIDE * sizeof(int);  // front counters, back counters, cursors
     const size_t off_tail = (off_res + (size_t)n_alive * sizeof(float) + 255) & ~(size_t)255;  // [segment counters | tail entries]
     PN_HIP_CHECK(hipMallocAsync((void**)&pool, off_tail + tail_ctr + (size_t)PN_SEGS * tail_cap * sizeof(TailEntry), st));
     PN_HIP_CHECK(hipMemsetAsync(pool + off_tail, 0, tail_ctr, st));
@@ -725,7 +740,9 @@ extern "C" int pn_march_rays_quadratic_bending(const int* pig_cnt, const int* pi
                                                C, H, grid, fars, err_flag);
         pnm2::March2Tables tb{s.nb_bgn, s.nb, (const float4*)s.rec};
         MarchIO io{n_alive, n_step, rays_alive, xyzs, dirs, deltas, noises, nullptr, nullptr, (float*)(pool + off_res),
-                   (TailEntry*)(pool + off_tail + tail_ctr), (int*)(pool + off_tail), (int)tail_cap, (int)march_tail_rounds(), nullptr, nullptr, 0,
+                   (TailEntry*)(pool + off_tail + tail_ctr), (int*)(pool + off_tail), (int*)(pool + off_tail) + PN_SEGS * PN_SEG_STRIDE,
+                   (int*)(pool + off_tail) + 2 * PN_SEGS * PN_SEG_STRIDE, (int)tail_cap,
+                   (int)march_tail_rounds(), nullptr, nullptr, 0,
                    nullptr, nullptr, 0, nullptr};
         if (io.t_resume) k_march_skip<<<pn_div_up(n_alive, 256), 256, 0, st>>>(a, tb, io);
         launch_march(num_seek_IP, pn_div_up(n_alive, 32), std::max(std::min(pn_div_up(n_alive, 4), 2048u), (uint32_t)PN_SEGS / 4), st, a, tb, io);
@@ -1079,13 +1096,15 @@ __global__ void __launch_bounds__(256) k_compact(const int* __restrict__ in, uin
         const int sum = red[0] + red[1] + red[2] + red[3];
         const int offset = (c == 0) ? 0 : sum;
         if (c == 0 && seg_counters && wid == 0) {
-            // frame driver: this trip's march is over — fold its segment counters (seg_counters = [tail | sample | emitted] x PN_SEGS) into
+            // frame driver: this trip's march is over — fold its segment counters (seg_counters = [tail | sample | emitted | cursor | tail back] x PN_SEGS) into
             // the records and clear them for the next trip
             int* tail_c = seg_counters + lane * PN_SEG_STRIDE;
             int* samp_c = tail_c + PN_SEGS * PN_SEG_STRIDE;
             int* emit_c = samp_c + PN_SEGS * PN_SEG_STRIDE;
-            int tl = *tail_c, em = *emit_c;
-            *tail_c = 0; *samp_c = 0; *emit_c = 0;
+            int* curs_c = emit_c + PN_SEGS * PN_SEG_STRIDE;
+            int* back_c = curs_c + PN_SEGS * PN_SEG_STRIDE;
+            int tl = *tail_c + *back_c, em = *emit_c;
+            *tail_c = 0; *samp_c = 0; *emit_c = 0; *curs_c = 0; *back_c = 0;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { tl += __shfl_xor(tl, o); em += __shfl_xor(em, o); }
             if (lane == 0) { if (tail_diag) *tail_diag = tl; if (trip) trip->n_emitted = em; }
@@ -1149,7 +1168,7 @@ struct pn_frame {
     int* list_seg;      // [PN_SEGS x seg_cap] segmented sample list of a list trip (k_list_pack -> list)
     int* active_seg;    // [PN_SEGS x seg_cap] trip 0: the slots k_march_skip left something to march for
     uint32_t seg_cap;
-    int* seg_counters;  // [4][PN_SEGS] counters, one per 128 B: tail | sample | emitted (cleared by each trip's compaction) | active (k_frame_rays)
+    int* seg_counters;  // [6][PN_SEGS] counters, one per 128 B: tail | sample | emitted | tail cursor | tail back (cleared by each trip's compaction) | active (k_frame_rays)
     int* tail_counts;   // [PN_MAX_TRIPS + 2] diagnostics: rays each trip handed to the tail pass
     int *pig_cnt, *pig_bgn, *pig_idx, *pig_cursor;
     MarchSide side;  // candidate lists + packed IP records of the cooperative march
@@ -1405,7 +1424,7 @@ __global__ void __launch_bounds__(256) k_frame_rays(const float* __restrict__ ra
             trips[t] = r;
             tail_counts[t] = 0;
         }
-        for (int t = threadIdx.x; t < 4 * PN_SEGS; t += blockDim.x) seg_counters[t * PN_SEG_STRIDE] = 0;
+        for (int t = threadIdx.x; t < 6 * PN_SEGS; t += blockDim.x) seg_counters[t * PN_SEG_STRIDE] = 0;
     }
     if (n >= N) return;
     const float* aabb = dev->aabb;
@@ -1459,7 +1478,7 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
     f->seg_cap = seg_cap_for(max_rays);
     PN_ALLOC(f->tail, (size_t)PN_SEGS * f->seg_cap * sizeof(TailEntry)); PN_ALLOC(f->tail_counts, sizeof(int) * (PN_MAX_TRIPS + 2));
     PN_ALLOC(f->list_seg, (size_t)PN_SEGS * f->seg_cap * 4); PN_ALLOC(f->active_seg, (size_t)PN_SEGS * f->seg_cap * 4);
-    PN_ALLOC(f->seg_counters, (size_t)4 * PN_SEGS * PN_SEG_STRIDE * 4);
+    PN_ALLOC(f->seg_counters, (size_t)6 * PN_SEGS * PN_SEG_STRIDE * 4);
     PN_ALLOC(f->trips, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)); PN_ALLOC(f->dev, sizeof(PnFrameDev)); PN_ALLOC(f->cut_bounds, 6 * 4);
 #undef PN_ALLOC
     PN_HIP_CHECK(hipMalloc((void**)&f->march_counters, 16 * sizeof(unsigned long long)));  // [4..15]: debug phase clocks (PN_DBG_PHASES builds)
@@ -1606,10 +1625,12 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             int* seg_tail = f->seg_counters;
             int* seg_samp = seg_tail + PN_SEGS * PN_SEG_STRIDE;
             int* seg_emit = seg_samp + PN_SEGS * PN_SEG_STRIDE;
-            int* seg_active = seg_emit + PN_SEGS * PN_SEG_STRIDE;
+            int* seg_curs = seg_emit + PN_SEGS * PN_SEG_STRIDE;
+            int* seg_back = seg_curs + PN_SEGS * PN_SEG_STRIDE;
+            int* seg_active = seg_back + PN_SEGS * PN_SEG_STRIDE;
             // trip 0 keeps its skip pre-pass state in f->sigmas (t_resume) and lists the slots worth marching in f->active_seg
             MarchIO io{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + t, f->list, (t == 0) ? f->sigmas : nullptr,
-                       f->tail, seg_tail, (int)f->seg_cap, (int)march_tail_rounds(), (t == 0) ? f->active_seg : nullptr, (t == 0) ? seg_active : nullptr,
+                       f->tail, seg_tail, seg_back, seg_curs, (int)f->seg_cap, (int)march_tail_rounds(), (t == 0) ? f->active_seg : nullptr, (t == 0) ? seg_active : nullptr,
                        (int)f->seg_cap, f->list_seg, seg_samp, (int)f->seg_cap, seg_emit};
             const bool timed = (f->march_counters_on & 2) && t < PN_TIMED_TRIPS;
             bool stamp = false;
