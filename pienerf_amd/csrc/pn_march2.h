@@ -113,85 +113,4 @@ __device__ inline bool warp_record(const float4 (&h)[4], const float4* __restric
     return fabsf(p[0] - pk0) > IP_dx || fabsf(p[1] - pk1) > IP_dx || fabsf(p[2] - pk2) > IP_dx;
 }
 
-// Leading run of marching iterations that can neither emit nor warp, ONE lane per ray: search cells whose 27-neighbourhood holds no IP
-// and, in --cut mode, static-background points (outside the cut box) in empty density voxels.  In --cut mode every ray crosses the
-// whole +-bound volume, so without this pre-pass all of those iterations went through the 8-lane / wave-per-ray kernels
-// (trex option set at 1008x756: 65.7 M visited points per frame).
-// At 800x800 ~86 % of the first trip's iterations are of this kind (rays crossing the empty part of the IP bounding box): no
-// candidate is found, so the sample is not warped and the ray just hops to the next density-grid voxel.  They need no memory but
-// the cell's list range, and in the cooperative kernel 7 of 8 lanes would replicate them.  Returns the t at which march_group
-// has to take over (first iteration whose cell has candidates, or t >= far); the arithmetic is march_group's, expression by
-// expression, so resuming there is bit-identical to having run every iteration in march_group.
-__device__ inline float skip_empty_cells(const MarchParams& a, const March2Tables& tb, int index, float noise, unsigned* n_iter_out) {
-    const float ox = a.rays_o[index * 3], oy = a.rays_o[index * 3 + 1], oz = a.rays_o[index * 3 + 2];
-    const float dx = a.rays_d[index * 3], dy = a.rays_d[index * 3 + 1], dz = a.rays_d[index * 3 + 2];
-    const uint32_t H = a.H, C = a.C;
-    const float far = a.fars[index];
-    const float dt_min = 2 * 1.7320508075688772f / a.max_steps;
-    const float dt_max = 2 * 1.7320508075688772f * (1 << (C - 1)) / H;
-    *n_iter_out = 0;
-    float t = a.rays_t[index];
-    t += clampf(t * a.dt_gamma, dt_min, dt_max) * noise;
-    if (!(t < far)) return t;
-    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
-    const float rH = 1 / (float)H;
-    const float H3 = (float)(H * H * H);
-    const bool cut = a.cut != 0;
-    const float bmin0 = a.bbmin[0], bmin1 = a.bbmin[1], bmin2 = a.bbmin[2];
-    // clamp range of the sample point: +-bound in --cut mode (raymarching.cu:1196-1199), [bbmin, bbmax - 1e-6] otherwise (:1203-1205)
-    const float lo0 = cut ? -a.bound : bmin0, lo1 = cut ? -a.bound : bmin1, lo2 = cut ? -a.bound : bmin2;
-    const float hi0 = cut ? a.bound : (float)((double)a.bbmax[0] - 1e-6), hi1 = cut ? a.bound : (float)((double)a.bbmax[1] - 1e-6),
-                hi2 = cut ? a.bound : (float)((double)a.bbmax[2] - 1e-6);
-    float cb[6] = {0, 0, 0, 0, 0, 0};
-    if (cut)
-        for (int i = 0; i < 6; i++) cb[i] = a.cut_bounds[i];
-    const int r0 = a.resolution[0], r1 = a.resolution[1], r2 = a.resolution[2];
-    const float rbound = 1 / a.bound;
-    const float halfH = 0.5f * (float)H;
-    int cell_id = -1;
-    unsigned n_iter = 0;
-    while (t < far) {
-        const float x = clampf(ox + t * dx, lo0, hi0);
-        const float y = clampf(oy + t * dy, lo1, hi1);
-        const float z = clampf(oz + t * dz, lo2, hi2);
-        // --cut: a point outside the cut box is a static-background sample (found = true, un-warped, :1380-1383); the cut test is the
-        // reference's, `x < cut_bounds[3]` included (:1210)
-        const bool searched = !cut || (x > cb[0] && x < cb[1] && y > cb[2] && x < cb[3] && z > cb[4] && z < cb[5]);
-        if (searched) {
-        const int g0 = (int)floorf((x - bmin0) / a.hgs);
-        const int g1 = (int)floorf((y - bmin1) / a.hgs);
-        const int g2 = (int)floorf((z - bmin2) / a.hgs);
-        if (g0 < 0 || g1 < 0 || g2 < 0 || g0 >= r0 || g1 >= r1 || g2 >= r2) break;  // march_group raises the error flag
-        const int gid = g2 * r1 * r0 + g1 * r0 + g0;
-        if (gid != cell_id) {
-            if (tb.nb_bgn[gid] != tb.nb_bgn[gid + 1]) break;  // candidates: hand over
-            cell_id = gid;
-        }
-        }
-        // found == false (or a static sample in an empty voxel): un-warped voxel skip (raymarching.cu:1386-1428)
-        const float dt = clampf(t * a.dt_gamma, dt_min, dt_max);
-        const int level = max(mip_from_pos(x, y, z, (float)C), mip_from_dt(dt, (float)H, (float)C));
-        const float pw = scalbnf(1.0f, level);
-        const bool use_pw = pw <= a.bound;
-        const float mip_bound = use_pw ? pw : a.bound;
-        const float mip_rbound = use_pw ? scalbnf(1.0f, -level) : rbound;
-        // (float)(0.5 * (double)v * (double)H) == v * (0.5f * H): both round the exact product once (v has 24 significant bits, H < 2^24)
-        const int nx = (int)clampf((x * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
-        const int ny = (int)clampf((y * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
-        const int nz = (int)clampf((z * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
-        if (!searched) {  // static sample: emitted when its voxel is occupied -> hand over to march_group at this element
-            const uint32_t vox = (uint32_t)(level * H3 + (float)morton3D(nx, ny, nz));
-            if (a.grid[vox / 8] & (1 << (vox % 8))) break;
-        }
-        n_iter++;
-        const float tx = (((nx + 0.5f + 0.5f * signf(dx)) * rH * 2 - 1) * mip_bound - x) * rdx;
-        const float ty = (((ny + 0.5f + 0.5f * signf(dy)) * rH * 2 - 1) * mip_bound - y) * rdy;
-        const float tz = (((nz + 0.5f + 0.5f * signf(dz)) * rH * 2 - 1) * mip_bound - z) * rdz;
-        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-        do { t += clampf(t * a.dt_gamma, dt_min, dt_max); } while (t < tt);
-    }
-    *n_iter_out = n_iter;
-    return t;
-}
-
 }  // namespace pnm2

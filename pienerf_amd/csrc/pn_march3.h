@@ -128,6 +128,127 @@ __device__ __forceinline__ bool ray_start(const MarchParams& a, const RayConsts&
     return true;
 }
 
+// floor((v - lo) / hgs) as the reference computes it (IEEE division), without the division in the common case: the quotient by reciprocal
+// is within a few 1e-7 relative of the correctly rounded one, so the two can only floor differently when the quotient sits within 1e-3 of an
+// integer — then, and for anything not finite, the real division decides.
+__device__ __forceinline__ int cell_coord(float v, float lo, float hgs, float rhgs) {
+    const float d = v - lo;
+    const float q = d * rhgs;
+    const float f = floorf(q);
+    const float fr = q - f;
+    if (!(fr >= 1e-3f && fr <= 0.999f && fabsf(q) < 1e6f)) return (int)floorf(d / hgs);
+    return (int)f;
+}
+
+// Leading run of marching iterations that can neither emit nor warp, ONE lane per ray: search cells whose 27-neighbourhood holds no IP
+// and, in --cut mode, static-background points (outside the cut box) in empty density voxels.  In --cut mode every ray crosses the
+// whole +-bound volume, so without this pre-pass all of those iterations went through the 8-lane / wave-per-ray kernels
+// (trex option set at 1008x756: 65.7 M visited points per frame).  At 800x800 ~86 % of the first trip's iterations are of this kind
+// (rays crossing the empty part of the IP bounding box): no candidate is found, the sample is not warped, the only memory touched is
+// the cell's list range.  Returns the t at which the windowed march has to take over (first iteration whose cell has candidates, or
+// t >= far); the arithmetic is eval_point's, expression by expression, so resuming there is bit-identical to having run every
+// iteration in the windowed march.  The kernel's duration is its longest lane's chain (~130 hops), so the hop is kept short: the cell
+// coordinates without divisions (cell_coord), one cascade without the mip functions, and with a fixed step the do-while that advances t
+// past the voxel exit replaced by lattice arithmetic (Binade).
+__device__ inline float skip_empty_cells(const MarchParams& a, const March2Tables& tb, int index, float noise, unsigned* n_iter_out) {
+    const Float3 o = *reinterpret_cast<const Float3*>(a.rays_o + (size_t)index * 3), d = *reinterpret_cast<const Float3*>(a.rays_d + (size_t)index * 3);
+    const float ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
+    const uint32_t H = a.H, C = a.C;
+    const float far = a.fars[index];
+    const float dt_min = 2 * 1.7320508075688772f / a.max_steps;
+    const float dt_max = 2 * 1.7320508075688772f * (1 << (C - 1)) / H;
+    *n_iter_out = 0;
+    float t = a.rays_t[index];
+    t += clampf(t * a.dt_gamma, dt_min, dt_max) * noise;
+    if (!(t < far)) return t;
+    const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
+    const float rH = 1 / (float)H;
+    const float H3 = (float)(H * H * H);
+    const bool cut = a.cut != 0;
+    const float bmin0 = a.bbmin[0], bmin1 = a.bbmin[1], bmin2 = a.bbmin[2];
+    // clamp range of the sample point: +-bound in --cut mode (raymarching.cu:1196-1199), [bbmin, bbmax - 1e-6] otherwise (:1203-1205)
+    const float lo0 = cut ? -a.bound : bmin0, lo1 = cut ? -a.bound : bmin1, lo2 = cut ? -a.bound : bmin2;
+    const float hi0 = cut ? a.bound : (float)((double)a.bbmax[0] - 1e-6), hi1 = cut ? a.bound : (float)((double)a.bbmax[1] - 1e-6),
+                hi2 = cut ? a.bound : (float)((double)a.bbmax[2] - 1e-6);
+    float cb[6] = {0, 0, 0, 0, 0, 0};
+    if (cut)
+        for (int i = 0; i < 6; i++) cb[i] = a.cut_bounds[i];
+    const int r0 = a.resolution[0], r1 = a.resolution[1], r2 = a.resolution[2];
+    const float rbound = 1 / a.bound;
+    const float halfH = 0.5f * (float)H;
+    const float rhgs = __builtin_amdgcn_rcpf(a.hgs);
+    const float sx = 0.5f + 0.5f * signf(dx), sy = 0.5f + 0.5f * signf(dy), sz = 0.5f + 0.5f * signf(dz);  // exact: 0, 0.5 or 1
+    const bool one_cascade = C == 1;
+    const bool fixed = a.dt_gamma == 0.0f;
+    const float D = clampf(0.0f, dt_min, dt_max);
+    Binade bn;
+    bn.Dq = bn.rDq = 0.f; bn.top = -1.f; bn.ok = false;
+    float bn_lo = 0.f, k_max = 0.f;
+    int cell_id = -1;
+    unsigned n_iter = 0;
+    while (t < far) {
+        const float x = clampf(ox + t * dx, lo0, hi0);
+        const float y = clampf(oy + t * dy, lo1, hi1);
+        const float z = clampf(oz + t * dz, lo2, hi2);
+        // --cut: a point outside the cut box is a static-background sample (found = true, un-warped, :1380-1383); the cut test is the
+        // reference's, `x < cut_bounds[3]` included (:1210)
+        const bool searched = !cut || (x > cb[0] && x < cb[1] && y > cb[2] && x < cb[3] && z > cb[4] && z < cb[5]);
+        if (searched) {
+            const int g0 = cell_coord(x, bmin0, a.hgs, rhgs);
+            const int g1 = cell_coord(y, bmin1, a.hgs, rhgs);
+            const int g2 = cell_coord(z, bmin2, a.hgs, rhgs);
+            if (g0 < 0 || g1 < 0 || g2 < 0 || g0 >= r0 || g1 >= r1 || g2 >= r2) break;  // the windowed march raises the error flag
+            const int gid = g2 * r1 * r0 + g1 * r0 + g0;
+            if (gid != cell_id) {
+                if (tb.nb_bgn[gid] != tb.nb_bgn[gid + 1]) break;  // candidates: hand over
+                cell_id = gid;
+            }
+        }
+        // found == false (or a static sample in an empty voxel): un-warped voxel skip (raymarching.cu:1386-1428)
+        const float dt = clampf(t * a.dt_gamma, dt_min, dt_max);
+        const int level = one_cascade ? 0 : max(mip_from_pos(x, y, z, (float)C), mip_from_dt(dt, (float)H, (float)C));
+        const float pw = scalbnf(1.0f, level);
+        const bool use_pw = pw <= a.bound;
+        const float mip_bound = use_pw ? pw : a.bound;
+        const float mip_rbound = use_pw ? scalbnf(1.0f, -level) : rbound;
+        // (float)(0.5 * (double)v * (double)H) == v * (0.5f * H): both round the exact product once (v has 24 significant bits, H < 2^24)
+        const int nx = (int)clampf((x * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
+        const int ny = (int)clampf((y * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
+        const int nz = (int)clampf((z * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
+        if (!searched) {  // static sample: emitted when its voxel is occupied -> hand over to the windowed march at this element
+            const uint32_t vox = (uint32_t)(level * H3 + (float)morton3D(nx, ny, nz));
+            if (a.grid[vox / 8] & (1 << (vox % 8))) break;
+        }
+        n_iter++;
+        // (n + 0.5f + 0.5f * sign) == n + (0.5f + 0.5f * sign): n is an integer below 2^23 and the addend 0, 0.5 or 1 — both sums are exact
+        const float tx = ((((float)nx + sx) * rH * 2 - 1) * mip_bound - x) * rdx;
+        const float ty = ((((float)ny + sy) * rH * 2 - 1) * mip_bound - y) * rdy;
+        const float tz = ((((float)nz + sz) * rH * 2 - 1) * mip_bound - z) * rdz;
+        const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        // do { t += dt(t); } while (t < tt);
+        bool stepped = false;
+        if (fixed) {
+            if (!(t >= bn_lo && t < bn.top)) {  // entered another binade
+                bn = binade_of<1>(t, D);
+                bn_lo = bn.top * 0.5f;
+                k_max = bn.ok ? floorf(16777215.0f / (bn.Dq * scalbnf(1.0f, 150 - (int)(__float_as_uint(t) >> 23)))) - 2.0f : 0.0f;
+            }
+            if (bn.ok) {
+                // at least one step; k = first k >= 1 with t + k * Dq >= tt (quotient off by one at most, corrected by exact comparisons)
+                float kf = fminf(fmaxf(ceilf((tt - t) * bn.rDq), 1.0f), k_max);
+                if (kf > 1.0f && t + (kf - 1.0f) * bn.Dq >= tt) kf -= 1.0f;
+                else if (t + kf * bn.Dq < tt) kf += 1.0f;
+                const float tn = t + kf * bn.Dq;
+                if (kf <= k_max && tn < bn.top && tn >= tt) { t = tn; stepped = true; }  // everything inside the binade: exact
+            }
+        }
+        if (!stepped)
+            do { t += clampf(t * a.dt_gamma, dt_min, dt_max); } while (t < tt);
+    }
+    *n_iter_out = n_iter;
+    return t;
+}
+
 // Timing experiment (-DPN_DBG_PHASES=1 builds only, tools/build_variant.py): per-wave clocks of the phases of a march kernel, summed into
 // MarchParams::stats[4 + base ...].  Every phase boundary drains the memory counters, so the phases add up to the wave's lifetime.
 #if PN_DBG_PHASES
@@ -188,9 +309,10 @@ __device__ __forceinline__ void point_cell(const MarchParams& a, const March2Tab
     p.gid = -1;
     p.b = p.e = 0;
     if (p.in_cut) {
-        const int g0 = (int)floorf((p.x - c.bmin0) / a.hgs);
-        const int g1 = (int)floorf((p.y - c.bmin1) / a.hgs);
-        const int g2 = (int)floorf((p.z - c.bmin2) / a.hgs);
+        const float rhgs = __builtin_amdgcn_rcpf(a.hgs);
+        const int g0 = cell_coord(p.x, c.bmin0, a.hgs, rhgs);
+        const int g1 = cell_coord(p.y, c.bmin1, a.hgs, rhgs);
+        const int g2 = cell_coord(p.z, c.bmin2, a.hgs, rhgs);
         p.oob = (g0 < 0 || g1 < 0 || g2 < 0 || g0 >= c.r0 || g1 >= c.r1 || g2 >= c.r2);
         if (!p.oob) {
             p.gid = g2 * c.r1 * c.r0 + g1 * c.r0 + g0;
@@ -403,7 +525,8 @@ __device__ __forceinline__ void eval_point(const MarchParams& a, const March2Tab
     }
 
     const float dt = dtf(a, c, t);
-    const int level = max(mip_from_pos(x, y, z, c.Cf), mip_from_dt(dt, c.Hf, c.Cf));
+    // one cascade: both mip functions clamp to [0, C - 1] = 0
+    const int level = (c.Cf == 1.0f) ? 0 : max(mip_from_pos(x, y, z, c.Cf), mip_from_dt(dt, c.Hf, c.Cf));
     const float pw2 = scalbnf(1.0f, level);  // mip_bound = fminf(2^level, bound); 1 / 2^level is exact
     const bool use_pw = pw2 <= a.bound;
     const float mip_bound = use_pw ? pw2 : a.bound;

@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(256) k_march_skip(pnm::MarchParams a, pnm2::Ma
     if (n < n_alive) {
         unsigned n_iter = 0;
         const int index = io.rays_alive[n];
-        const float t = pnm2::skip_empty_cells(a, tb, index, io.noises ? io.noises[n] : 0.0f, &n_iter);
+        const float t = pnm3::skip_empty_cells(a, tb, index, io.noises ? io.noises[n] : 0.0f, &n_iter);
         io.t_resume[n] = t;
         if (!PN_DBG_PHASES_ON && a.stats && n_iter) atomicAdd(a.stats, (unsigned long long)n_iter);
         work = t < a.fars[index];
@@ -677,9 +677,13 @@ static void launch_march(int K, uint32_t blocks, uint32_t tail_blocks, hipStream
 
 // Rounds of 8 sequence elements a ray gets in k_march before it is handed to the wave-per-ray tail pass (PN_TAIL_ROUNDS overrides).
 static int g_tail_rounds_override = 0;  // pn_march_set_tail_rounds (tests): > 0 replaces the default below
-static uint32_t march_tail_rounds() {
-    static const uint32_t r = pn_env_u32("PN_TAIL_ROUNDS", 4);  // measured on the chair: 2..4 within 1 % for latency, 4 best for throughput
-    return g_tail_rounds_override > 0 ? (uint32_t)g_tail_rounds_override : r;
+// Defaults measured on the chair once the append lists were segmented (k_march + tail per trip, us): trip 0 (every ray looks for its first sample)
+// 232 / 201 / 210 / 211 for 1 / 2 / 3 / 4 rounds; later trips (alive rays, 8 samples each: most are done after one window) 70 / 76 / 78 / 79.
+static uint32_t march_tail_rounds(int trip = -1) {
+    static const uint32_t r = pn_env_u32("PN_TAIL_ROUNDS", 0);  // 0: per-trip defaults
+    if (g_tail_rounds_override > 0) return (uint32_t)g_tail_rounds_override;
+    if (r) return r;
+    return trip < 0 ? 4u : (trip == 0 ? 2u : 1u);
 }
 extern "C" int pn_march_set_tail_rounds(int rounds) {
     PN_REQUIRE(rounds >= 0);
@@ -1630,7 +1634,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             int* seg_active = seg_back + PN_SEGS * PN_SEG_STRIDE;
             // trip 0 keeps its skip pre-pass state in f->sigmas (t_resume) and lists the slots worth marching in f->active_seg
             MarchIO io{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + t, f->list, (t == 0) ? f->sigmas : nullptr,
-                       f->tail, seg_tail, seg_back, seg_curs, (int)f->seg_cap, (int)march_tail_rounds(), (t == 0) ? f->active_seg : nullptr, (t == 0) ? seg_active : nullptr,
+                       f->tail, seg_tail, seg_back, seg_curs, (int)f->seg_cap, (int)march_tail_rounds(t), (t == 0) ? f->active_seg : nullptr, (t == 0) ? seg_active : nullptr,
                        (int)f->seg_cap, f->list_seg, seg_samp, (int)f->seg_cap, seg_emit};
             const bool timed = (f->march_counters_on & 2) && t < PN_TIMED_TRIPS;
             bool stamp = false;
