@@ -150,7 +150,10 @@ __device__ __forceinline__ int cell_coord(float v, float lo, float hgs, float rh
 // iteration in the windowed march.  The kernel's duration is its longest lane's chain (~130 hops), so the hop is kept short: the cell
 // coordinates without divisions (cell_coord), one cascade without the mip functions, and with a fixed step the do-while that advances t
 // past the voxel exit replaced by lattice arithmetic (Binade).
-__device__ inline float skip_empty_cells(const MarchParams& a, const March2Tables& tb, int index, float noise, unsigned* n_iter_out) {
+// `cell_bits` (may be null): bit c set <=> search cell c has candidates, held in LDS by the caller — the emptiness test then costs an LDS read
+// instead of a dependent global round trip every third hop or so.
+__device__ inline float skip_empty_cells(const MarchParams& a, const March2Tables& tb, int index, float noise, unsigned* n_iter_out,
+                                         const uint32_t* cell_bits = nullptr) {
     const Float3 o = *reinterpret_cast<const Float3*>(a.rays_o + (size_t)index * 3), d = *reinterpret_cast<const Float3*>(a.rays_d + (size_t)index * 3);
     const float ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
     const uint32_t H = a.H, C = a.C;
@@ -186,7 +189,11 @@ __device__ inline float skip_empty_cells(const MarchParams& a, const March2Table
     float bn_lo = 0.f, k_max = 0.f;
     int cell_id = -1;
     unsigned n_iter = 0;
+#if PN_DBG_SKIP_HOPS  // timing experiment: at most this many hops per ray (results invalid)
+    while (t < far && n_iter < PN_DBG_SKIP_HOPS) {
+#else
     while (t < far) {
+#endif
         const float x = clampf(ox + t * dx, lo0, hi0);
         const float y = clampf(oy + t * dy, lo1, hi1);
         const float z = clampf(oz + t * dz, lo2, hi2);
@@ -200,7 +207,8 @@ __device__ inline float skip_empty_cells(const MarchParams& a, const March2Table
             if (g0 < 0 || g1 < 0 || g2 < 0 || g0 >= r0 || g1 >= r1 || g2 >= r2) break;  // the windowed march raises the error flag
             const int gid = g2 * r1 * r0 + g1 * r0 + g0;
             if (gid != cell_id) {
-                if (tb.nb_bgn[gid] != tb.nb_bgn[gid + 1]) break;  // candidates: hand over
+                const bool has = cell_bits ? ((cell_bits[gid >> 5] >> (gid & 31)) & 1u) != 0 : tb.nb_bgn[gid] != tb.nb_bgn[gid + 1];
+                if (has) break;  // candidates: hand over
                 cell_id = gid;
             }
         }
@@ -599,15 +607,25 @@ __device__ inline bool march_window(const MarchParams& a, const March2Tables& tb
             if (active) point_cell(a, tb, c, s, pc);
         }
         PN_PHASE(pk, 1);
-        const int my_off = stage_lists(stage, tb.nb, pc.b, pc.e - pc.b, lane);
+        // a window none of whose points has a candidate (rays that have left the object and walk on to `far`, grazing rays between two parts of
+        // it) needs no lists, no scan and no record heads: what is left of the round is the voxel arithmetic and the chain
+        const bool any_list = __any(pc.e != pc.b);
+        int my_off = -1;
+        if (any_list) my_off = stage_lists(stage, tb.nb, pc.b, pc.e - pc.b, lane);
         PN_PHASE(pk, 2);
         PointEval ev;
         ev.emit = false; ev.oob = false; ev.tt = 0.f; ev.dt = 0.f; ev.x = ev.y = ev.z = 0.f; ev.n_cand = 0; ev.n_warp = 0;
         int ips[3] = {-1, -1, -1};
         unsigned n_cand = 0;
-        if (go && active) eval_scan<K>(a, tb, pc, stage, my_off, ips, n_cand);
         float4 rh[3][4];
-        head_fetch<K>(stage, tb.rec, ips, lane, rh);
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int u = 0; u < 4; u++) rh[k][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (any_list) {
+            if (go && active) eval_scan<K>(a, tb, pc, stage, my_off, ips, n_cand);
+            head_fetch<K>(stage, tb.rec, ips, lane, rh);
+        }
         if (go && active) eval_point<K, MULTI>(a, tb, c, s, pc, ips, rh, n_cand, ev);
         PN_PHASE(pk, 3);
         if (go) {

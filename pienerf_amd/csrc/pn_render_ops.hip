@@ -435,6 +435,10 @@ struct MarchIO {
     int* samp_counts;
     int list_seg_cap;
     int* emit_parts;
+    // optional: one bit per search cell, set when the cell has candidates (frame driver); k_march_skip keeps it in LDS when launched with
+    // cell_bits_words * 4 bytes of dynamic shared memory
+    const uint32_t* cell_bits;
+    int cell_bits_words;
 };
 
 // Append lists are SEGMENTED: PN_SEGS independent (counter, region) pairs, every counter on a cache line of its own, the producer picking
@@ -454,14 +458,23 @@ static uint32_t seg_cap_for(uint32_t n_rays) { return (uint32_t)((pn_div_up(pn_d
 
 // One lane per ray slot: fast-forward over the leading run of IP-free search cells.
 __global__ void __launch_bounds__(256) k_march_skip(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
+    extern __shared__ uint32_t bits_lds[];
     uint32_t n_alive = io.n_alive;
     if (io.trip) n_alive = (uint32_t)io.trip->n_alive;
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    const uint32_t* cell_bits = nullptr;
+    if (io.cell_bits_words > 0) {  // uniform
+        const int n_grid = a.resolution[0] * a.resolution[1] * a.resolution[2];
+        const int words = min((n_grid + 31) >> 5, io.cell_bits_words);
+        for (int w = threadIdx.x; w < words; w += blockDim.x) bits_lds[w] = io.cell_bits[w];
+        __syncthreads();
+        cell_bits = bits_lds;
+    }
     bool work = false;
     if (n < n_alive) {
         unsigned n_iter = 0;
         const int index = io.rays_alive[n];
-        const float t = pnm3::skip_empty_cells(a, tb, index, io.noises ? io.noises[n] : 0.0f, &n_iter);
+        const float t = pnm3::skip_empty_cells(a, tb, index, io.noises ? io.noises[n] : 0.0f, &n_iter, cell_bits);
         io.t_resume[n] = t;
         if (!PN_DBG_PHASES_ON && a.stats && n_iter) atomicAdd(a.stats, (unsigned long long)n_iter);
         work = t < a.fars[index];
@@ -747,7 +760,7 @@ extern "C" int pn_march_rays_quadratic_bending(const int* pig_cnt, const int* pi
                    (TailEntry*)(pool + off_tail + tail_ctr), (int*)(pool + off_tail), (int*)(pool + off_tail) + PN_SEGS * PN_SEG_STRIDE,
                    (int*)(pool + off_tail) + 2 * PN_SEGS * PN_SEG_STRIDE, (int)tail_cap,
                    (int)march_tail_rounds(), nullptr, nullptr, 0,
-                   nullptr, nullptr, 0, nullptr};
+                   nullptr, nullptr, 0, nullptr, nullptr, 0};
         if (io.t_resume) k_march_skip<<<pn_div_up(n_alive, 256), 256, 0, st>>>(a, tb, io);
         launch_march(num_seek_IP, pn_div_up(n_alive, 32), std::max(std::min(pn_div_up(n_alive, 4), 2048u), (uint32_t)PN_SEGS / 4), st, a, tb, io);
     }
@@ -1172,6 +1185,7 @@ struct pn_frame {
     int* list_seg;      // [PN_SEGS x seg_cap] segmented sample list of a list trip (k_list_pack -> list)
     int* active_seg;    // [PN_SEGS x seg_cap] trip 0: the slots k_march_skip left something to march for
     uint32_t seg_cap;
+    uint32_t* cell_bits;  // [(max_cells + 31) / 32] bit c: search cell c has candidates (cleared by k_frame_tables, set by k_frame_lists)
     int* seg_counters;  // [6][PN_SEGS] counters, one per 128 B: tail | sample | emitted | tail cursor | tail back (cleared by each trip's compaction) | active (k_frame_rays)
     int* tail_counts;   // [PN_MAX_TRIPS + 2] diagnostics: rays each trip handed to the tail pass
     int *pig_cnt, *pig_bgn, *pig_idx, *pig_cursor;
@@ -1227,8 +1241,9 @@ __global__ void k_stamp(unsigned long long* slot) { *slot = __builtin_amdgcn_s_m
 template <bool LARGE>
 __global__ void __launch_bounds__(1024) k_frame_tables(const float* __restrict__ p_def, int n_vtx, int cut, float bound, float hgs, int max_cells,
                                                        PnFrameDev* dev, int* pig_cnt, int* pig_bgn, int* pig_idx, int* pig_cursor, int swap,
-                                                       int* nb_cnt, int* nb_bgn, int* nb_cursor) {
+                                                       int* nb_cnt, int* nb_bgn, int* nb_cursor, uint32_t* cell_bits) {
     extern __shared__ unsigned cnt2[];  // per-cell point counts, two 16-bit counters per word (a cell never holds 65 536 IPs)
+    for (int w = threadIdx.x; w < (max_cells + 31) / 32; w += blockDim.x) cell_bits[w] = 0u;  // set by k_frame_lists
     __shared__ float smin[3][16], smax[3][16];
     __shared__ float sh_min[3];
     __shared__ int sh_res[4];
@@ -1371,7 +1386,7 @@ __global__ void __launch_bounds__(256) k_frame_lists(int n_grid_max, const int* 
                                                      const float* __restrict__ p_def, int swap, const int* __restrict__ nb_cnt, int* __restrict__ nb_bgn,
                                                      float4* __restrict__ nb, int nb_capacity, int* err_flag, int list_blocks, int n_vtx,
                                                      const float* __restrict__ p_ori, const float* __restrict__ F_IP, const float* __restrict__ dF_IP,
-                                                     float* __restrict__ rec) {
+                                                     float* __restrict__ rec, uint32_t* cell_bits) {
     if ((int)blockIdx.x >= list_blocks) {  // k_pack_ip
         const int t = threadIdx.x + ((int)blockIdx.x - list_blocks) * 256;
         const int ip = t / PN_REC_FLOATS, j = t % PN_REC_FLOATS;
@@ -1386,6 +1401,7 @@ __global__ void __launch_bounds__(256) k_frame_lists(int n_grid_max, const int* 
         const int w0 = nb_bgn[c], total = nb_cnt[c];
         if (c == n_grid - 1 && sub == 0) nb_bgn[n_grid] = w0 + total;  // closing offset
         if (total == 0) continue;
+        if (sub == 0) atomicOr(cell_bits + (c >> 5), 1u << (c & 31));
         if (w0 + total > nb_capacity) { if (err_flag && sub == 0) atomicOr(err_flag, 8); continue; }
         int g0, g1, g2;
         nb_cell_coords(c, r0, r1, g0, g1, g2);
@@ -1483,6 +1499,7 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
     PN_ALLOC(f->tail, (size_t)PN_SEGS * f->seg_cap * sizeof(TailEntry)); PN_ALLOC(f->tail_counts, sizeof(int) * (PN_MAX_TRIPS + 2));
     PN_ALLOC(f->list_seg, (size_t)PN_SEGS * f->seg_cap * 4); PN_ALLOC(f->active_seg, (size_t)PN_SEGS * f->seg_cap * 4);
     PN_ALLOC(f->seg_counters, (size_t)6 * PN_SEGS * PN_SEG_STRIDE * 4);
+    PN_ALLOC(f->cell_bits, ((size_t)max_grid_cells + 31) / 32 * 4);
     PN_ALLOC(f->trips, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)); PN_ALLOC(f->dev, sizeof(PnFrameDev)); PN_ALLOC(f->cut_bounds, 6 * 4);
 #undef PN_ALLOC
     PN_HIP_CHECK(hipMalloc((void**)&f->march_counters, 16 * sizeof(unsigned long long)));  // [4..15]: debug phase clocks (PN_DBG_PHASES builds)
@@ -1500,7 +1517,7 @@ extern "C" void pn_frame_destroy(pn_frame* f) {
     void* ptrs[] = {f->acc_image, f->nears, f->fars, f->rays_t, f->xyzs, f->dirs, f->deltas, f->sigmas, f->rgbs, f->alive_a, f->alive_b, f->list,
                     f->chunk_counts, f->pig_cnt, f->pig_bgn, f->pig_cursor, f->pig_idx, f->trips, f->dev, f->cut_bounds,
                     f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, f->side.nb, f->side.rec, f->march_counters, f->tail, f->tail_counts, f->stamps,
-                    f->list_seg, f->active_seg, f->seg_counters};
+                    f->list_seg, f->active_seg, f->seg_counters, f->cell_bits};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int t = 0; t < PN_TIMED_TRIPS; t++)
         for (int e = 0; e < 3; e++) if (f->ev[t][e]) (void)hipEventDestroy(f->ev[t][e]);
@@ -1551,6 +1568,8 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     const uint32_t march_grid = march_grid_cfg, trip_grid = std::min(nblk, trip_grid_cfg);
     static const uint32_t tail_grid_cfg = pn_env_u32("PN_TAIL_GRID", 1024);  // x4 waves, one unfinished ray per wave at a time
     const uint32_t tail_grid = std::max(std::min(pn_div_up(N, 4), tail_grid_cfg), (uint32_t)PN_SEGS / 4);  // every tail segment needs a wave
+    // the skip pre-pass keeps the cells' emptiness bits in LDS when they fit (48 KB = 393 k cells)
+    const int skip_bits_words = ((f->max_cells + 31) / 32) * 4 <= 48 * 1024 ? (int)((f->max_cells + 31) / 32) : 0;
 
     if (!f->cut_bounds_valid || memcmp(f->cut_bounds_host, o->cut_bounds, sizeof(f->cut_bounds_host)) != 0) {  // uploaded only when it changes
         memcpy(f->cut_bounds_host, o->cut_bounds, sizeof(f->cut_bounds_host));
@@ -1584,10 +1603,10 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             if (dev_id >= 0 && dev_id < PN_MAX_DEVICES) tables_lds_set[dev_id] = tables_lds;
         }
         k_frame_tables<false><<<1, 1024, tables_lds, st>>>(p_def, n_vtx, o->cut, o->bound, o->hash_grid_size, (int)f->max_cells, f->dev, f->pig_cnt,
-                                                           f->pig_bgn, f->pig_idx, f->pig_cursor, swap, f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor);
+                                                           f->pig_bgn, f->pig_idx, f->pig_cursor, swap, f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, f->cell_bits);
     } else {
         k_frame_tables<true><<<1, 1024, 0, st>>>(p_def, n_vtx, o->cut, o->bound, o->hash_grid_size, (int)f->max_cells, f->dev, f->pig_cnt, f->pig_bgn,
-                                                 f->pig_idx, f->pig_cursor, swap, f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor);
+                                                 f->pig_idx, f->pig_cursor, swap, f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, f->cell_bits);
         rc = pig_build(n_vtx, (int)f->max_cells, n_grid_dev, p_def, bbmin, o->hash_grid_size, res, f->pig_cnt, f->pig_bgn, f->pig_idx, f->pig_cursor, err, st);
         if (rc) return rc;
         const int gz = (int)std::min(pn_div_up(f->max_cells, 256), 1024u);
@@ -1600,7 +1619,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
         const int pack_blocks = (int)pn_div_up((uint64_t)n_vtx * PN_REC_FLOATS, 256);
         k_frame_lists<<<list_blocks + pack_blocks, 256, 0, st>>>((int)f->max_cells, n_grid_dev, res, f->pig_cnt, f->pig_bgn, f->pig_idx, p_def, swap,
                                                                  f->side.nb_cnt, f->side.nb_bgn, f->side.nb, f->side.nb_capacity, err, list_blocks, n_vtx,
-                                                                 p_ori, F_IP, dF_IP, f->side.rec);
+                                                                 p_ori, F_IP, dF_IP, f->side.rec, f->cell_bits);
     }
     k_frame_rays<<<nblk, 256, 0, st>>>(rays_o, rays_d, f->dev, N, o->min_near, f->nears, f->fars, f->rays_t, f->trips, f->tail_counts, f->seg_counters,
                                        PN_MAX_TRIPS + 2, f->alive_a, weights_sum, depth_0, f->acc_image);
@@ -1635,7 +1654,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             // trip 0 keeps its skip pre-pass state in f->sigmas (t_resume) and lists the slots worth marching in f->active_seg
             MarchIO io{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + t, f->list, (t == 0) ? f->sigmas : nullptr,
                        f->tail, seg_tail, seg_back, seg_curs, (int)f->seg_cap, (int)march_tail_rounds(t), (t == 0) ? f->active_seg : nullptr, (t == 0) ? seg_active : nullptr,
-                       (int)f->seg_cap, f->list_seg, seg_samp, (int)f->seg_cap, seg_emit};
+                       (int)f->seg_cap, f->list_seg, seg_samp, (int)f->seg_cap, seg_emit, f->cell_bits, skip_bits_words};
             const bool timed = (f->march_counters_on & 2) && t < PN_TIMED_TRIPS;
             bool stamp = false;
             if (timed) {  // measurement mode: the two heavy launch groups of each trip are bracketed on the launch stream
@@ -1655,7 +1674,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                 k_march_static_trip<<<trip_grid, 256, 0, st>>>(f->trips + t, cur, f->rays_t, rays_o, rays_d, o->bound, o->dt_gamma, o->max_steps, o->cascade,
                                                                o->grid_size, bitfield, f->fars, f->xyzs, f->dirs, f->deltas, f->list);
             } else {
-                if (io.t_resume) k_march_skip<<<nblk, 256, 0, st>>>(mp, tb, io);
+                if (io.t_resume) k_march_skip<<<nblk, 256, (size_t)skip_bits_words * 4, st>>>(mp, tb, io);
                 launch_march(o->num_seek_IP, std::max(std::min(pn_div_up(N, 32), march_grid), (uint32_t)PN_SEGS), tail_grid, st, mp, tb, io);
                 k_list_pack<<<PN_SEGS, 256, 0, st>>>(f->trips + t, seg_samp, f->list_seg, (int)f->seg_cap, f->list);
             }
