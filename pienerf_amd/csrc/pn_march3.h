@@ -189,6 +189,62 @@ __device__ inline float skip_empty_cells(const MarchParams& a, const March2Table
     float bn_lo = 0.f, k_max = 0.f;
     int cell_id = -1;
     unsigned n_iter = 0;
+    if (!cut && cell_bits) {
+        // The common case (no --cut, emptiness bits in LDS) with as few branches as the semantics allow: the kernel is issue-bound (its busy
+        // waves share a third of the SIMDs) and the general loop below costs ~25 exec-mask branches per hop.  Same expressions, same order.
+        const float Hm1 = (float)(H - 1);
+        while (true) {
+            const float x = clampf(ox + t * dx, lo0, hi0);
+            const float y = clampf(oy + t * dy, lo1, hi1);
+            const float z = clampf(oz + t * dz, lo2, hi2);
+            const float d0 = x - bmin0, d1 = y - bmin1, d2 = z - bmin2;
+            const float q0 = d0 * rhgs, q1 = d1 * rhgs, q2 = d2 * rhgs;
+            float f0 = floorf(q0), f1 = floorf(q1), f2 = floorf(q2);
+            const float e0 = q0 - f0, e1 = q1 - f1, e2 = q2 - f2;
+            const bool sure = e0 >= 1e-3f && e0 <= 0.999f && e1 >= 1e-3f && e1 <= 0.999f && e2 >= 1e-3f && e2 <= 0.999f &&
+                              fmaxf(fabsf(q0), fmaxf(fabsf(q1), fabsf(q2))) < 1e6f;
+            if (!sure) { f0 = floorf(d0 / a.hgs); f1 = floorf(d1 / a.hgs); f2 = floorf(d2 / a.hgs); }  // see cell_coord
+            const int g0 = (int)f0, g1 = (int)f1, g2 = (int)f2;
+            const bool inside = (g0 | g1 | g2) >= 0 && g0 < r0 && g1 < r1 && g2 < r2;
+            const int gid = inside ? g2 * r1 * r0 + g1 * r0 + g0 : 0;
+            const bool has = ((cell_bits[gid >> 5] >> (gid & 31)) & 1u) != 0;
+            if (!inside || has) break;  // outside the hash (the windowed march raises the error flag) or candidates: hand over
+            int level = 0;
+            if (!one_cascade) level = max(mip_from_pos(x, y, z, (float)C), mip_from_dt(clampf(t * a.dt_gamma, dt_min, dt_max), (float)H, (float)C));
+            const float pw = scalbnf(1.0f, level);
+            const bool use_pw = pw <= a.bound;
+            const float mip_bound = use_pw ? pw : a.bound;
+            const float mip_rbound = use_pw ? scalbnf(1.0f, -level) : rbound;
+            const int nx = (int)clampf((x * mip_rbound + 1) * halfH, 0.0f, Hm1);
+            const int ny = (int)clampf((y * mip_rbound + 1) * halfH, 0.0f, Hm1);
+            const int nz = (int)clampf((z * mip_rbound + 1) * halfH, 0.0f, Hm1);
+            n_iter++;
+            const float tx = ((((float)nx + sx) * rH * 2 - 1) * mip_bound - x) * rdx;
+            const float ty = ((((float)ny + sy) * rH * 2 - 1) * mip_bound - y) * rdy;
+            const float tz = ((((float)nz + sz) * rH * 2 - 1) * mip_bound - z) * rdz;
+            const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+            bool stepped = false;
+            if (fixed) {
+                if (!(t >= bn_lo && t < bn.top)) {  // entered another binade
+                    bn = binade_of<1>(t, D);
+                    bn_lo = bn.top * 0.5f;
+                    k_max = bn.ok ? floorf(16777215.0f / (bn.Dq * scalbnf(1.0f, 150 - (int)(__float_as_uint(t) >> 23)))) - 2.0f : 0.0f;
+                }
+                float kf = fminf(fmaxf(ceilf((tt - t) * bn.rDq), 1.0f), k_max);
+                const bool dec = kf > 1.0f && t + (kf - 1.0f) * bn.Dq >= tt;
+                const bool inc = !dec && t + kf * bn.Dq < tt;
+                kf = dec ? kf - 1.0f : (inc ? kf + 1.0f : kf);
+                const float tn = t + kf * bn.Dq;
+                stepped = bn.ok && kf <= k_max && tn < bn.top && tn >= tt;  // everything inside the binade: exact
+                if (stepped) t = tn;
+            }
+            if (!stepped)
+                do { t += clampf(t * a.dt_gamma, dt_min, dt_max); } while (t < tt);
+            if (!(t < far)) break;
+        }
+        *n_iter_out = n_iter;
+        return t;
+    }
 #if PN_DBG_SKIP_HOPS  // timing experiment: at most this many hops per ray (results invalid)
     while (t < far && n_iter < PN_DBG_SKIP_HOPS) {
 #else
