@@ -320,7 +320,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the short additional measurements after the timed region")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying captured HIP graphs")
-    ap.add_argument("--trips", type=int, default=None, help="render-loop trips baked into the captured graphs (default: what one eager frame needs + 3; a frame "
+    ap.add_argument("--trips", type=int, default=None, help="render-loop trips baked into the captured graphs (default: what one eager frame needs + 2; a frame "
                     "that needs more is continued when it is retired)")
     ap.add_argument("--copy-on", choices=("copy", "lane", "sim"), default="lane", help="stream of the per-frame D2H: a copy stream of its own, or the frame's render stream")
     ap.add_argument("--staged-streams", type=int, default=3, help="--config stress: streams the 4096-ray batches of a frame are dealt to")

@@ -373,10 +373,16 @@ __device__ __forceinline__ void point_cell(const MarchParams& a, const March2Tab
     p.gid = -1;
     p.b = p.e = 0;
     if (p.in_cut) {
+        // the three cell coordinates as in cell_coord, with ONE (rare) branch for all of them
         const float rhgs = __builtin_amdgcn_rcpf(a.hgs);
-        const int g0 = cell_coord(p.x, c.bmin0, a.hgs, rhgs);
-        const int g1 = cell_coord(p.y, c.bmin1, a.hgs, rhgs);
-        const int g2 = cell_coord(p.z, c.bmin2, a.hgs, rhgs);
+        const float d0 = p.x - c.bmin0, d1 = p.y - c.bmin1, d2 = p.z - c.bmin2;
+        const float q0 = d0 * rhgs, q1 = d1 * rhgs, q2 = d2 * rhgs;
+        float f0 = floorf(q0), f1 = floorf(q1), f2 = floorf(q2);
+        const float e0 = q0 - f0, e1 = q1 - f1, e2 = q2 - f2;
+        const bool sure = e0 >= 1e-3f && e0 <= 0.999f && e1 >= 1e-3f && e1 <= 0.999f && e2 >= 1e-3f && e2 <= 0.999f &&
+                          fmaxf(fabsf(q0), fmaxf(fabsf(q1), fabsf(q2))) < 1e6f;
+        if (!sure) { f0 = floorf(d0 / a.hgs); f1 = floorf(d1 / a.hgs); f2 = floorf(d2 / a.hgs); }
+        const int g0 = (int)f0, g1 = (int)f1, g2 = (int)f2;
         p.oob = (g0 < 0 || g1 < 0 || g2 < 0 || g0 >= c.r0 || g1 >= c.r1 || g2 >= c.r2);
         if (!p.oob) {
             p.gid = g2 * c.r1 * c.r0 + g1 * c.r0 + g0;
@@ -394,6 +400,9 @@ __device__ __forceinline__ void point_cell(const MarchParams& a, const March2Tab
 // LDS-DMA loads (global_load_lds_dwordx4: no staging registers, one wait for all lists), and the per-lane scans read LDS.
 // Must be called with all 64 lanes active (destination = wave-uniform base + lane * 16).  Returns this lane's list offset in `stage`
 // (entries), or -1 when the wave's lists did not all fit: those lanes scan from global memory as before.
+#ifndef PN_HEAD_SPLIT
+#define PN_HEAD_SPLIT 0
+#endif
 #ifndef PN_STAGE_CAP
 #define PN_STAGE_CAP 768  // entries per wave: 12 KB (the record heads of a round need 4 * 3 * 64); 4 waves per workgroup, 3 workgroups per CU -> 144 of the 160 KB
 #endif
@@ -508,21 +517,28 @@ __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_d
 template <int K>
 __device__ __forceinline__ void head_fetch(float4* stage, const float4* __restrict__ rec, const int (&ips)[3], int lane, float4 (&rh)[3][4]) {
     const int q = lane & 3;
+    // PN_HEAD_SPLIT = 1: the first two records, then the third, through the same 8 KB (one more round trip per round, a third less LDS per wave)
+    constexpr int K0 = (PN_HEAD_SPLIT && K > 2) ? 2 : K;
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        const int ipk = ips[k] >= 0 ? ips[k] : (ips[0] >= 0 ? ips[0] : 0);
-        const int i0 = dpp_i32<0x00>(ipk), i1 = dpp_i32<0x55>(ipk), i2 = dpp_i32<0xAA>(ipk), i3 = dpp_i32<0xFF>(ipk);  // quad_perm broadcasts
-        glds16(rec + (size_t)i0 * PN_REC_VEC4 + q, stage + (k * 4 + 0) * 64);
-        glds16(rec + (size_t)i1 * PN_REC_VEC4 + q, stage + (k * 4 + 1) * 64);
-        glds16(rec + (size_t)i2 * PN_REC_VEC4 + q, stage + (k * 4 + 2) * 64);
-        glds16(rec + (size_t)i3 * PN_REC_VEC4 + q, stage + (k * 4 + 3) * 64);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int pass = 0; pass < ((K0 < K) ? 2 : 1); pass++) {
+        const int kb = pass ? K0 : 0, ke = pass ? K : K0;
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        const float4* h = stage + (k * 4 + q) * 64 + (lane & ~3);
+        for (int k = kb; k < ke; k++) {
+            const int ipk = ips[k] >= 0 ? ips[k] : (ips[0] >= 0 ? ips[0] : 0);
+            const int i0 = dpp_i32<0x00>(ipk), i1 = dpp_i32<0x55>(ipk), i2 = dpp_i32<0xAA>(ipk), i3 = dpp_i32<0xFF>(ipk);  // quad_perm broadcasts
+            glds16(rec + (size_t)i0 * PN_REC_VEC4 + q, stage + ((k - kb) * 4 + 0) * 64);
+            glds16(rec + (size_t)i1 * PN_REC_VEC4 + q, stage + ((k - kb) * 4 + 1) * 64);
+            glds16(rec + (size_t)i2 * PN_REC_VEC4 + q, stage + ((k - kb) * 4 + 2) * 64);
+            glds16(rec + (size_t)i3 * PN_REC_VEC4 + q, stage + ((k - kb) * 4 + 3) * 64);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int u = 0; u < 4; u++) rh[k][u] = h[u];
+        for (int k = kb; k < ke; k++) {
+            const float4* h = stage + ((k - kb) * 4 + q) * 64 + (lane & ~3);
+#pragma unroll
+            for (int u = 0; u < 4; u++) rh[k][u] = h[u];
+        }
+        if (K0 < K) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads above complete before the region is overwritten
     }
 }
 

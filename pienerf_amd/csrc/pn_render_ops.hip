@@ -21,7 +21,7 @@ struct PnTrip {
     int pad1[30];
 };
 static_assert(sizeof(PnTrip) == 256, "two cache lines");
-// Dense trips (frame driver of the deformed render, n_step > 1): after the first trip nearly every alive ray fills all its n_step slots
+// Dense trips (frame driver of the deformed render, every trip after the first): there nearly every alive ray fills all its n_step slots
 // (measured on the chair: 98-99 %), so the sample list is the identity over the n_alive * n_step slots — written by the march without the
 // returning atomic a compact list costs every wave (one more dependent memory round trip at the end of a latency-bound kernel: -24 % on
 // trip 0's k_march without it) — and the few unfilled slots are zero-filled and run through the network as well; composite never reads
@@ -1135,7 +1135,9 @@ __global__ void __launch_bounds__(256) k_compact(const int* __restrict__ in, uin
                 next->n_step = done ? 1 : max(min((int)(N_rays / (uint32_t)sum), 8), 1);
                 next->step_base = step;
                 // dense trip (see trip_is_dense): the list is the identity over all slots; n_emitted = -1 marks a list trip
-                const bool dense = dense_trips && !done && next->n_step > 1;
+                // every trip after the first is dense: its rays are the ones that found a sample before (n_step == 1 then means more than half of
+                // all rays are still alive — they will mostly fill their single slot too)
+                const bool dense = dense_trips && !done;
                 next->dense = dense ? 1 : 0;
                 next->n_samples = dense ? sum * next->n_step : 0;
                 next->n_emitted = 0;
@@ -1676,7 +1678,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             } else {
                 if (io.t_resume) k_march_skip<<<nblk, 256, (size_t)skip_bits_words * 4, st>>>(mp, tb, io);
                 launch_march(o->num_seek_IP, std::max(std::min(pn_div_up(N, 32), march_grid), (uint32_t)PN_SEGS), tail_grid, st, mp, tb, io);
-                k_list_pack<<<PN_SEGS, 256, 0, st>>>(f->trips + t, seg_samp, f->list_seg, (int)f->seg_cap, f->list);
+                if (t == 0) k_list_pack<<<PN_SEGS, 256, 0, st>>>(f->trips + t, seg_samp, f->list_seg, (int)f->seg_cap, f->list);  // the only list trip
             }
             if (timed && stamp) k_stamp<<<1, 1, 0, st>>>(f->stamps + t * 3 + 1);
             else if (timed) PN_HIP_CHECK(hipEventRecord(f->ev[t][1], st));

@@ -204,7 +204,7 @@ class SimRenderHarness:
         `sim_ahead` frames ahead on dof snapshots, every frame's image / depth / depth_0 copied to pinned host memory on a copy stream
         (the reference's device->host boundary, trainer.py:589-592; copy_out=False leaves the results on the device).  Everything a frame
         launches is captured in HIP graphs — one for the substep, one per workspace for get_rays + the render with `n_trips` loop trips
-        (None: measured on one eager frame, + 3); a frame that still has rays alive after its trips is continued when it is retired
+        (None: measured on one eager frame, + 2); a frame that still has rays alive after its trips is continued when it is retired
         (renderer.py:836-891).  frame_parallel=True (or ``capture_frame_parallel``): the same pipeline over the ranks of `group` — the sim
         owner broadcasts every snapshot (<= 82 KB) over RCCL, rank frames.frame_owner(f) renders frame f.
 
@@ -226,7 +226,7 @@ class SimRenderHarness:
         rank = dist.get_rank(group) if on else 0
         if n_trips is None:  # calibrate: the trips one eager frame needs from the current state and pose, plus a margin
             self.step(simulate=False, collect_stats=True, W=W, H=H)
-            n_trips = max(8, int(self.model.last_stats["trips"]) + 3)
+            n_trips = int(self.model.last_stats["trips"]) + 2  # every captured trip costs five launches whether it has rays or not
         be = _HipBackend(self, lanes, depth, int(n_trips), W, H, sim_priority, sim_cus, copy_out, group if on else None,
                          (dist.get_global_rank(group, sim_owner) if (on and group is not None) else sim_owner), _probe_no_substep, _time_trips, copy_on)
         self._pipe = FramePipeline(be, world=world, rank=rank, lanes=lanes, depth=depth, ahead=(lanes if sim_ahead is None and world == 1 else sim_ahead),
