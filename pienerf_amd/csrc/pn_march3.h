@@ -128,6 +128,33 @@ __device__ __forceinline__ bool ray_start(const MarchParams& a, const RayConsts&
     return true;
 }
 
+// Where a ray can stop.  A sample is only ever emitted at a point whose search cell has candidates, so beyond the last such cell on its way
+// a ray does nothing but hop from voxel to voxel until `far` — for a ray that misses the object but crosses its bounding box that is ALL it
+// does (most of k_march_skip's work), and a ray that has left the object behind walks on through the tail pass (the longest tail rays).
+// `bits2` marks the cells within one cell of a cell with candidates (k_frame_lists); the ray is sampled backwards from `far` every 0.9 cell
+// lengths, and the march may end at the last sample before the first marked one: any point beyond it lies within one cell (per axis) of an
+// unmarked sample, hence in a cell without candidates — with a whole cell to spare for the rounding of the reference's own cell arithmetic.
+// Returns `near` when no sample is marked (nothing to march).  Not for --cut (static samples need no candidates).
+__device__ inline float ray_end_of_candidates(const MarchParams& a, const uint32_t* bits2, float ox, float oy, float oz, float dx, float dy, float dz,
+                                              float near, float far) {
+    const float bmin0 = a.bbmin[0], bmin1 = a.bbmin[1], bmin2 = a.bbmin[2];
+    const int r0 = a.resolution[0], r1 = a.resolution[1], r2 = a.resolution[2];
+    const float rhgs = __builtin_amdgcn_rcpf(a.hgs);
+    const float dts = 0.9f * a.hgs * __builtin_amdgcn_rsqf(dx * dx + dy * dy + dz * dz);
+    if (!(dts > 0.0f) || !(far - near < 1e3f * dts)) return far;  // degenerate direction or an absurdly long ray: no shortcut
+    float s_prev = far, s = far;
+    while (true) {
+        const int g0 = min(max((int)floorf((ox + s * dx - bmin0) * rhgs), 0), r0 - 1);
+        const int g1 = min(max((int)floorf((oy + s * dy - bmin1) * rhgs), 0), r1 - 1);
+        const int g2 = min(max((int)floorf((oz + s * dz - bmin2) * rhgs), 0), r2 - 1);
+        const int gid = g2 * r1 * r0 + g1 * r0 + g0;
+        if ((bits2[gid >> 5] >> (gid & 31)) & 1u) return s_prev;
+        if (!(s > near)) return near;
+        s_prev = s;
+        s = fmaxf(s - dts, near);
+    }
+}
+
 // floor((v - lo) / hgs) as the reference computes it (IEEE division), without the division in the common case: the quotient by reciprocal
 // is within a few 1e-7 relative of the correctly rounded one, so the two can only floor differently when the quotient sits within 1e-3 of an
 // integer — then, and for anything not finite, the real division decides.
@@ -152,12 +179,13 @@ __device__ __forceinline__ int cell_coord(float v, float lo, float hgs, float rh
 // past the voxel exit replaced by lattice arithmetic (Binade).
 // `cell_bits` (may be null): bit c set <=> search cell c has candidates, held in LDS by the caller — the emptiness test then costs an LDS read
 // instead of a dependent global round trip every third hop or so.
+// `far_override` >= 0: the ray's end (see ray_end_of_candidates) instead of a.fars[index].
 __device__ inline float skip_empty_cells(const MarchParams& a, const March2Tables& tb, int index, float noise, unsigned* n_iter_out,
-                                         const uint32_t* cell_bits = nullptr) {
+                                         const uint32_t* cell_bits = nullptr, float far_override = -1.0f) {
     const Float3 o = *reinterpret_cast<const Float3*>(a.rays_o + (size_t)index * 3), d = *reinterpret_cast<const Float3*>(a.rays_d + (size_t)index * 3);
     const float ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
     const uint32_t H = a.H, C = a.C;
-    const float far = a.fars[index];
+    const float far = far_override >= 0.0f ? far_override : a.fars[index];
     const float dt_min = 2 * 1.7320508075688772f / a.max_steps;
     const float dt_max = 2 * 1.7320508075688772f * (1 << (C - 1)) / H;
     *n_iter_out = 0;

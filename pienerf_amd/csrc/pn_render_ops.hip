@@ -439,6 +439,10 @@ struct MarchIO {
     // cell_bits_words * 4 bytes of dynamic shared memory
     const uint32_t* cell_bits;
     int cell_bits_words;
+    // optional (with cell_bits): the cells within one cell of a cell with candidates, and where k_march_skip writes each ray's shortened end
+    // (pn_march3.h: ray_end_of_candidates); the march kernels then run with MarchParams::fars = fars_eff
+    const uint32_t* cell_bits2;
+    float* fars_eff;
 };
 
 // Append lists are SEGMENTED: PN_SEGS independent (counter, region) pairs, every counter on a cache line of its own, the producer picking
@@ -462,22 +466,36 @@ __global__ void __launch_bounds__(256) k_march_skip(pnm::MarchParams a, pnm2::Ma
     uint32_t n_alive = io.n_alive;
     if (io.trip) n_alive = (uint32_t)io.trip->n_alive;
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
-    const uint32_t* cell_bits = nullptr;
+    const uint32_t *cell_bits = nullptr, *cell_bits2 = nullptr;
     if (io.cell_bits_words > 0) {  // uniform
         const int n_grid = a.resolution[0] * a.resolution[1] * a.resolution[2];
         const int words = min((n_grid + 31) >> 5, io.cell_bits_words);
         for (int w = threadIdx.x; w < words; w += blockDim.x) bits_lds[w] = io.cell_bits[w];
-        __syncthreads();
         cell_bits = bits_lds;
+        if (io.cell_bits2 && io.fars_eff && !a.cut) {
+            for (int w = threadIdx.x; w < words; w += blockDim.x) bits_lds[io.cell_bits_words + w] = io.cell_bits2[w];
+            cell_bits2 = bits_lds + io.cell_bits_words;
+        }
+        __syncthreads();
     }
     bool work = false;
     if (n < n_alive) {
         unsigned n_iter = 0;
         const int index = io.rays_alive[n];
-        const float t = pnm3::skip_empty_cells(a, tb, index, io.noises ? io.noises[n] : 0.0f, &n_iter, cell_bits);
+        float far = a.fars[index];
+        if (cell_bits2) {  // shorten the ray to where it can still find candidates
+            const float near = a.rays_t[index];
+            if (near < far) {
+                const pnm3::Float3 o = *reinterpret_cast<const pnm3::Float3*>(a.rays_o + (size_t)index * 3),
+                                   d = *reinterpret_cast<const pnm3::Float3*>(a.rays_d + (size_t)index * 3);
+                far = pnm3::ray_end_of_candidates(a, cell_bits2, o.x, o.y, o.z, d.x, d.y, d.z, near, far);
+            }
+            io.fars_eff[index] = far;
+        }
+        const float t = pnm3::skip_empty_cells(a, tb, index, io.noises ? io.noises[n] : 0.0f, &n_iter, cell_bits, cell_bits2 ? far : -1.0f);
         io.t_resume[n] = t;
         if (!PN_DBG_PHASES_ON && a.stats && n_iter) atomicAdd(a.stats, (unsigned long long)n_iter);
-        work = t < a.fars[index];
+        work = t < far;
         if (io.active && !work) {  // nothing left to march: k_march will not visit the slot, so its (single, n_step == 1) sample slot is ended here
             const uint32_t n_step = (uint32_t)io.trip->n_step;
             float* dl = io.deltas + (size_t)n * n_step * 2;
@@ -760,7 +778,7 @@ extern "C" int pn_march_rays_quadratic_bending(const int* pig_cnt, const int* pi
                    (TailEntry*)(pool + off_tail + tail_ctr), (int*)(pool + off_tail), (int*)(pool + off_tail) + PN_SEGS * PN_SEG_STRIDE,
                    (int*)(pool + off_tail) + 2 * PN_SEGS * PN_SEG_STRIDE, (int)tail_cap,
                    (int)march_tail_rounds(), nullptr, nullptr, 0,
-                   nullptr, nullptr, 0, nullptr, nullptr, 0};
+                   nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr};
         if (io.t_resume) k_march_skip<<<pn_div_up(n_alive, 256), 256, 0, st>>>(a, tb, io);
         launch_march(num_seek_IP, pn_div_up(n_alive, 32), std::max(std::min(pn_div_up(n_alive, 4), 2048u), (uint32_t)PN_SEGS / 4), st, a, tb, io);
     }
@@ -1187,7 +1205,9 @@ struct pn_frame {
     int* list_seg;      // [PN_SEGS x seg_cap] segmented sample list of a list trip (k_list_pack -> list)
     int* active_seg;    // [PN_SEGS x seg_cap] trip 0: the slots k_march_skip left something to march for
     uint32_t seg_cap;
-    uint32_t* cell_bits;  // [(max_cells + 31) / 32] bit c: search cell c has candidates (cleared by k_frame_tables, set by k_frame_lists)
+    uint32_t* cell_bits;  // [2][(max_cells + 31) / 32] bit c: search cell c has candidates / is within one cell of such a cell (cleared by
+                          // k_frame_tables, set by k_frame_lists)
+    float* fars_eff;      // [max_rays] the rays' ends shortened to where they can still find candidates (k_march_skip)
     int* seg_counters;  // [6][PN_SEGS] counters, one per 128 B: tail | sample | emitted | tail cursor | tail back (cleared by each trip's compaction) | active (k_frame_rays)
     int* tail_counts;   // [PN_MAX_TRIPS + 2] diagnostics: rays each trip handed to the tail pass
     int *pig_cnt, *pig_bgn, *pig_idx, *pig_cursor;
@@ -1245,7 +1265,7 @@ __global__ void __launch_bounds__(1024) k_frame_tables(const float* __restrict__
                                                        PnFrameDev* dev, int* pig_cnt, int* pig_bgn, int* pig_idx, int* pig_cursor, int swap,
                                                        int* nb_cnt, int* nb_bgn, int* nb_cursor, uint32_t* cell_bits) {
     extern __shared__ unsigned cnt2[];  // per-cell point counts, two 16-bit counters per word (a cell never holds 65 536 IPs)
-    for (int w = threadIdx.x; w < (max_cells + 31) / 32; w += blockDim.x) cell_bits[w] = 0u;  // set by k_frame_lists
+    for (int w = threadIdx.x; w < 2 * ((max_cells + 31) / 32); w += blockDim.x) cell_bits[w] = 0u;  // both maps; set by k_frame_lists
     __shared__ float smin[3][16], smax[3][16];
     __shared__ float sh_min[3];
     __shared__ int sh_res[4];
@@ -1399,9 +1419,21 @@ __global__ void __launch_bounds__(256) k_frame_lists(int n_grid_max, const int* 
     const int n_grid = min(*n_grid_dev, n_grid_max);
     const int r0 = res[0], r1 = res[1], r2 = res[2];
     const int sub = threadIdx.x & 7;
+    const int max_cells_words = (n_grid_max + 31) / 32;
     for (int c = (threadIdx.x + blockIdx.x * 256) >> 3; c < n_grid; c += (list_blocks * 256) >> 3) {
         const int w0 = nb_bgn[c], total = nb_cnt[c];
         if (c == n_grid - 1 && sub == 0) nb_bgn[n_grid] = w0 + total;  // closing offset
+        {   // second map: a cell with candidates within one cell (the 8 lanes share the 27 neighbours)
+            int gg0, gg1, gg2;
+            nb_cell_coords(c, r0, r1, gg0, gg1, gg2);
+            int any = 0;
+            for (int q = sub; q < 27; q += 8) {
+                const int cell = (q == 0) ? c : nb_neighbour(q - 1, swap, gg0, gg1, gg2, r0, r1, r2);
+                if (cell >= 0 && nb_cnt[cell] > 0) any = 1;
+            }
+            any |= __shfl_xor(any, 1); any |= __shfl_xor(any, 2); any |= __shfl_xor(any, 4);
+            if (any && sub == 0) atomicOr(cell_bits + ((max_cells_words) + (c >> 5)), 1u << (c & 31));
+        }
         if (total == 0) continue;
         if (sub == 0) atomicOr(cell_bits + (c >> 5), 1u << (c & 31));
         if (w0 + total > nb_capacity) { if (err_flag && sub == 0) atomicOr(err_flag, 8); continue; }
@@ -1501,7 +1533,8 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
     PN_ALLOC(f->tail, (size_t)PN_SEGS * f->seg_cap * sizeof(TailEntry)); PN_ALLOC(f->tail_counts, sizeof(int) * (PN_MAX_TRIPS + 2));
     PN_ALLOC(f->list_seg, (size_t)PN_SEGS * f->seg_cap * 4); PN_ALLOC(f->active_seg, (size_t)PN_SEGS * f->seg_cap * 4);
     PN_ALLOC(f->seg_counters, (size_t)6 * PN_SEGS * PN_SEG_STRIDE * 4);
-    PN_ALLOC(f->cell_bits, ((size_t)max_grid_cells + 31) / 32 * 4);
+    PN_ALLOC(f->cell_bits, 2 * (((size_t)max_grid_cells + 31) / 32) * 4);
+    PN_ALLOC(f->fars_eff, N * 4);
     PN_ALLOC(f->trips, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)); PN_ALLOC(f->dev, sizeof(PnFrameDev)); PN_ALLOC(f->cut_bounds, 6 * 4);
 #undef PN_ALLOC
     PN_HIP_CHECK(hipMalloc((void**)&f->march_counters, 16 * sizeof(unsigned long long)));  // [4..15]: debug phase clocks (PN_DBG_PHASES builds)
@@ -1519,7 +1552,7 @@ extern "C" void pn_frame_destroy(pn_frame* f) {
     void* ptrs[] = {f->acc_image, f->nears, f->fars, f->rays_t, f->xyzs, f->dirs, f->deltas, f->sigmas, f->rgbs, f->alive_a, f->alive_b, f->list,
                     f->chunk_counts, f->pig_cnt, f->pig_bgn, f->pig_cursor, f->pig_idx, f->trips, f->dev, f->cut_bounds,
                     f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, f->side.nb, f->side.rec, f->march_counters, f->tail, f->tail_counts, f->stamps,
-                    f->list_seg, f->active_seg, f->seg_counters, f->cell_bits};
+                    f->list_seg, f->active_seg, f->seg_counters, f->cell_bits, f->fars_eff};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int t = 0; t < PN_TIMED_TRIPS; t++)
         for (int e = 0; e < 3; e++) if (f->ev[t][e]) (void)hipEventDestroy(f->ev[t][e]);
@@ -1571,7 +1604,10 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     static const uint32_t tail_grid_cfg = pn_env_u32("PN_TAIL_GRID", 1024);  // x4 waves, one unfinished ray per wave at a time
     const uint32_t tail_grid = std::max(std::min(pn_div_up(N, 4), tail_grid_cfg), (uint32_t)PN_SEGS / 4);  // every tail segment needs a wave
     // the skip pre-pass keeps the cells' emptiness bits in LDS when they fit (48 KB = 393 k cells)
-    const int skip_bits_words = ((f->max_cells + 31) / 32) * 4 <= 48 * 1024 ? (int)((f->max_cells + 31) / 32) : 0;
+    const size_t bit_words = (f->max_cells + 31) / 32;
+    const bool short_rays = !is_static && !o->cut && bit_words * 8 <= 48 * 1024;  // both maps in LDS: rays end where their candidates end
+    const int skip_bits_words = (short_rays || bit_words * 4 <= 48 * 1024) ? (int)bit_words : 0;
+    const size_t skip_lds = (size_t)skip_bits_words * 4 * (short_rays ? 2 : 1);
 
     if (!f->cut_bounds_valid || memcmp(f->cut_bounds_host, o->cut_bounds, sizeof(f->cut_bounds_host)) != 0) {  // uploaded only when it changes
         memcpy(f->cut_bounds_host, o->cut_bounds, sizeof(f->cut_bounds_host));
@@ -1656,7 +1692,8 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             // trip 0 keeps its skip pre-pass state in f->sigmas (t_resume) and lists the slots worth marching in f->active_seg
             MarchIO io{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + t, f->list, (t == 0) ? f->sigmas : nullptr,
                        f->tail, seg_tail, seg_back, seg_curs, (int)f->seg_cap, (int)march_tail_rounds(t), (t == 0) ? f->active_seg : nullptr, (t == 0) ? seg_active : nullptr,
-                       (int)f->seg_cap, f->list_seg, seg_samp, (int)f->seg_cap, seg_emit, f->cell_bits, skip_bits_words};
+                       (int)f->seg_cap, f->list_seg, seg_samp, (int)f->seg_cap, seg_emit, f->cell_bits, skip_bits_words,
+                       short_rays ? f->cell_bits + bit_words : nullptr, short_rays ? f->fars_eff : nullptr};
             const bool timed = (f->march_counters_on & 2) && t < PN_TIMED_TRIPS;
             bool stamp = false;
             if (timed) {  // measurement mode: the two heavy launch groups of each trip are bracketed on the launch stream
@@ -1676,8 +1713,10 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                 k_march_static_trip<<<trip_grid, 256, 0, st>>>(f->trips + t, cur, f->rays_t, rays_o, rays_d, o->bound, o->dt_gamma, o->max_steps, o->cascade,
                                                                o->grid_size, bitfield, f->fars, f->xyzs, f->dirs, f->deltas, f->list);
             } else {
-                if (io.t_resume) k_march_skip<<<nblk, 256, (size_t)skip_bits_words * 4, st>>>(mp, tb, io);
-                launch_march(o->num_seek_IP, std::max(std::min(pn_div_up(N, 32), march_grid), (uint32_t)PN_SEGS), tail_grid, st, mp, tb, io);
+                if (io.t_resume) k_march_skip<<<nblk, 256, skip_lds, st>>>(mp, tb, io);
+                pnm::MarchParams mq = mp;
+                if (short_rays) mq.fars = f->fars_eff;  // written by trip 0's k_march_skip
+                launch_march(o->num_seek_IP, std::max(std::min(pn_div_up(N, 32), march_grid), (uint32_t)PN_SEGS), tail_grid, st, mq, tb, io);
                 if (t == 0) k_list_pack<<<PN_SEGS, 256, 0, st>>>(f->trips + t, seg_samp, f->list_seg, (int)f->seg_cap, f->list);  // the only list trip
             }
             if (timed && stamp) k_stamp<<<1, 1, 0, st>>>(f->stamps + t * 3 + 1);
