@@ -756,18 +756,40 @@ __device__ inline bool march_window(const MarchParams& a, const March2Tables& tb
             int cur = 0, prev_emit = -1, n_emit = 0, last_vis = 0;
             int my_ord = -1, my_prev = -1;
             bool visited = false, ended = false;
+            if (G == 64) {
+                // one ray per wave: the chain is wave-uniform — walked with scalar registers and v_readlane instead of 64 lanes each
+                // following it through ds_bpermute (~14 dependent LDS round trips per round)
+                unsigned long long vis = 0ull;
+                const int need = (int)(n_step - step);
+                while (cur < 64) {
+                    if (!((actm >> cur) & 1ull)) { ended = true; break; }
+                    vis |= 1ull << cur;
+                    last_vis = cur;
+                    if ((emitm >> cur) & 1ull) {
+                        prev_emit = cur;
+                        n_emit++;
+                        if (n_emit == need) { ended = true; break; }
+                    }
+                    cur = __builtin_amdgcn_readlane(jump, cur);
+                }
+                const unsigned long long ev_m = vis & emitm, below = (1ull << sub) - 1ull;
+                visited = ((vis >> sub) & 1ull) != 0;
+                my_ord = (int)__popcll(ev_m & below);
+                my_prev = (ev_m & below) ? 63 - (int)__clzll(ev_m & below) : -1;
+            } else {
             while (cur < G) {
                 if (!((actm >> cur) & 1ull)) { ended = true; break; }  // s_cur >= far: the march is over
                 if (cur == sub) { visited = true; my_ord = n_emit; my_prev = prev_emit; }
                 last_vis = cur;
                 const bool em = (emitm >> cur) & 1ull;
-                const int nx_idx = (G == 8) ? (int)((word >> (4 * cur)) & 0xFu) : __shfl(jump, gbase + cur);
+                const int nx_idx = (int)((word >> (4 * cur)) & 0xFu);
                 if (em) {
                     prev_emit = cur;
                     n_emit++;
                     if (step + (uint32_t)n_emit == n_step) { ended = true; break; }
                 }
                 cur = nx_idx;
+            }
             }
             // emitted samples: slot = step + rank in the chain; deltas[1] = t_after - last_t (raymarching.cu:1395-1410)
             const float prev_nxt = __shfl(nxt, gbase + max(my_prev, 0));
