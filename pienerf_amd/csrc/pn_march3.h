@@ -806,12 +806,13 @@ __device__ inline bool march_window(const MarchParams& a, const March2Tables& tb
                     *reinterpret_cast<float2*>(L) = make_float2(ev.dt, nxt - (my_prev >= 0 ? prev_nxt : last_t));
                 }
             }
-            const float last_emit_nxt = __shfl(nxt, gbase + max(prev_emit, 0));
+            // (G == 64: wave-uniform lane indices — v_readlane instead of a ds_bpermute round trip)
+            const float last_emit_nxt = (G == 64) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nxt), max(prev_emit, 0))) : __shfl(nxt, gbase + max(prev_emit, 0));
             if (n_emit > 0) last_t = last_emit_nxt;
             step += (uint32_t)n_emit;
             // next window start: s_G, or further when the last visited point's voxel exit lies beyond the window
-            const float sG = __shfl(nxt, gbase + G - 1);
-            const float tt_last = __shfl(ev.tt, gbase + last_vis);
+            const float sG = (G == 64) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nxt), 63)) : __shfl(nxt, gbase + G - 1);
+            const float tt_last = (G == 64) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ev.tt), last_vis)) : __shfl(ev.tt, gbase + last_vis);
             if (ended) {
                 running = false;  // done for this trip; t is not needed any more (composite tracks rays_t itself)
             } else {
