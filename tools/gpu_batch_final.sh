@@ -19,7 +19,7 @@ S chair python $R/bench.py --no-cpu-baseline --no-extras --steps 100 --warmup 10
 S stress python $R/bench.py --no-cpu-baseline --no-extras --config stress --steps 3 --warmup 1
 S trex python $R/bench.py --no-cpu-baseline --no-extras --config trex --steps 100 --warmup 10
 S eager python $R/tools/run_frames.py --frames 5
-P() { name=$1; shift; rm -rf /tmp/pmc_$name; timeout 200 rocprofv3 --pmc "$@" --kernel-trace -d /tmp/pmc_$name -o $name --output-format csv -- python $R/tools/run_frames.py --frames 3 --no-sim > /tmp/pmc_$name.log 2>&1 || { echo "pass $name failed"; return; }; python $R/tools/pmc_summary.py /tmp/pmc_$name k_ > $O/pmc_${name}_per_kernel.txt 2>&1; }
+P() { name=$1; shift; rm -rf /tmp/pmc_$name; timeout 200 rocprofv3 --pmc "$@" --kernel-trace -d /tmp/pmc_$name -o $name --output-format csv -- python $R/tools/run_frames.py --frames 3 --no-sim --no-counters > /tmp/pmc_$name.log 2>&1 || { echo "pass $name failed"; return; }; python $R/tools/pmc_summary.py /tmp/pmc_$name k_ > $O/pmc_${name}_per_kernel.txt 2>&1; }
 P sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
 P sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH
 P sq3 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_BUSY_CU_CYCLES SQ_THREAD_CYCLES_VALU

@@ -19,6 +19,7 @@ ap.add_argument("--presim", type=int, default=20, help="untimed simulator steps 
 ap.add_argument("--no-sim", action="store_true")
 ap.add_argument("--W", type=int, default=800)
 ap.add_argument("--graph", action="store_true")
+ap.add_argument("--no-counters", action="store_true", help="skip the extra frame rendered with the march work counters on")
 args = ap.parse_args()
 opt = scene.default_opt(W=args.W, H=args.W)
 h = SimRenderHarness(opt, device="cuda:0")
@@ -35,6 +36,8 @@ else:
         h.step(simulate=not args.no_sim, collect_stats=True)
     torch.cuda.synchronize()
     print(h.model.last_stats)
+    if args.no_counters:
+        sys.exit(0)
     h.model.march_counters(1)
     h.step(simulate=False, collect_stats=True)
     print("counters", h.model.march_counters(1, read=True))
