@@ -1,13 +1,20 @@
-"""ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY PARTLY PINNED (see below), UNPINNED FOR THE CUDA/WARP KERNELS.
 
 CPU restatement of the PIE-NeRF simulate-and-render hot path.
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import this package; nothing under ``pienerf_amd/`` does.
 
-"Parity unpinned": the reference (FYTalon/pienerf) ships no tests, golden
-vectors or fixtures, and its CUDA/Warp implementation can neither be compiled
-nor imported in the build container, so the restatement is
-pinned by independent-maths checks in ``tests/test_oracle_*.py`` instead.
+Pinning: the reference (FYTalon/pienerf) ships no tests, golden vectors or
+fixtures.  The parts of it that import or can be extracted from its source in
+the build container were RUN there and their outputs committed as fixtures
+(tests/golden/make_golden_ref.py -> opts_*.json, ref_kat.npz, ref_bindings.json:
+get_opts, trunc_exp forward/backward, get_rays, OrbitCamera, nerf_matrix_to_ngp,
+the colour-space helpers, the GridEncoder table layout, the pybind signatures);
+tests/test_golden_ref.py holds this package against them.  Its CUDA/Warp
+implementation can neither be compiled nor imported there: for
+the march, composite, encoders, MLP and the simulator substep the status is
+"parity unpinned" — pinned by independent-maths checks in
+``tests/test_oracle_*.py`` instead.
 
 Layout:
   render_oracle.cpp  R7-R16  (march w/ inverse-GMLS warp, composite, compaction,

@@ -1,4 +1,5 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED for the kernels restated here (pinned: get_rays and trunc_exp, by
+// reference-run fixtures — tests/golden/make_golden_ref.py, tests/test_golden_ref.py).
 //
 // CPU restatement of the render half of the PIE-NeRF simulate-and-render hot
 // path.  Only tests/, __graft_entry__.smoke() and
