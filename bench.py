@@ -323,6 +323,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the short additional measurements after the timed region")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from the host instead of replaying captured HIP graphs")
+    ap.add_argument("--prime", type=int, default=40, help="untimed priming steps right after the graph captures, before the warm-up steps (see the timed loop)")
     ap.add_argument("--trips", type=int, default=None, help="render-loop trips baked into the captured graphs (default: what one eager frame needs + 2; a frame "
                     "that needs more is continued when it is retired)")
     ap.add_argument("--copy-on", choices=("copy", "lane", "sim"), default="lane", help="stream of the per-frame D2H: a copy stream of its own, or the frame's render stream")
@@ -431,6 +432,11 @@ def main():
         launch = f"hip graphs, {args.trips} trips, {args.lanes} render streams x {args.depth} workspaces per rank"
 
     with torch.no_grad():
+        # priming, part of the set-up like the graph captures before it: the first replay of each of the lanes x depth render graphs, first
+        # touches of the pinned buffers, clocks coming up from the host-bound capture phase.  Measured: with 5 / 20 / 40 untimed steps in
+        # front, 20 timed steps take 25.2 / 22.2 / 18.7 ms.  The W warm-up steps the caller asked for follow, then exactly K timed steps.
+        run_steps(args.prime)
+        barrier()
         run_steps(args.warmup)
         barrier()
         t0 = time.perf_counter()
@@ -471,7 +477,7 @@ def main():
                        + ("" if copy_out else " [--no-d2h: outputs left on the device]"),
                        "rays": opt["W"] * opt["H"], "n_IP": hk.sim.n_IP, "n_kernels": hk.sim.n_k, "n_points": int(len(cloud["pos"])),
                        "samples_per_frame": st["samples"], "trips_per_frame": st["trips"], "d2h_bytes_per_step": (opt["W"] * opt["H"] * 20 if copy_out else 0),
-                       "frames_continued_past_captured_trips": continued, "launch": launch, "sigma_gain": args.sigma_gain,
+                       "frames_continued_past_captured_trips": continued, "launch": launch, "prime_steps": args.prime, "sigma_gain": args.sigma_gain,
                        "hit_rays": st["hit_rays"], "mean_samples_per_hit_ray": round(st["samples"] / max(1, st["hit_rays"]), 2),
                        "parallelism": (f"frame-parallel x{world} ({rccl_ranks} RCCL ranks), dof snapshots broadcast over RCCL, "
                                        + ("rank 0 simulates only, frames round-robin over the other ranks" if del_h._pipe.dedicated else "frames round-robin over all ranks")

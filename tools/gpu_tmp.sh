@@ -1,9 +1,6 @@
-O=gpurun_out/r02final; mkdir -p $O
-python bench.py > $O/bench_chair.json 2> $O/bench_chair.err
-python bench.py --config stress > $O/bench_stress.json 2> $O/bench_stress.err
-python bench.py --config trex > $O/bench_trex.json 2> $O/bench_trex.err
-python -c "
-import json
-for c in ('chair','stress','trex'):
-    d=json.load(open('$O/bench_%s.json'%c)); print(c, d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['cpu_baseline'])
-"
+for a in "20 5" "20 0" "200 20"; do set -- $a; python bench.py --no-cpu-baseline --no-extras --steps $1 --warmup $2 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('steps $1 warmup $2', d['value'], round(d['ms_per_step']*d['steps'],2),'ms total')"; done
+python bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 5 --prime 200 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('prime 200 steps 20', d['value'])"
