@@ -1,6 +1,3 @@
-for a in "20 5" "20 0" "200 20"; do set -- $a; python bench.py --no-cpu-baseline --no-extras --steps $1 --warmup $2 2>/dev/null | python -c "
+for a in "--lanes 3 --depth 1" "--lanes 3 --depth 2" "--lanes 3 --depth 1" "--lanes 3 --depth 2" "--lanes 3 --depth 1 --no-d2h" "--lanes 2 --depth 1 --copy-on copy" "--lanes 3 --depth 1 --steps 20 --warmup 5"; do python bench.py --no-cpu-baseline --no-extras $a 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('steps $1 warmup $2', d['value'], round(d['ms_per_step']*d['steps'],2),'ms total')"; done
-python bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 5 --prime 200 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('prime 200 steps 20', d['value'])"
+d=json.loads(sys.stdin.read()); print('$a', d['value'])"; done
