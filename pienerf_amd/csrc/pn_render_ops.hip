@@ -133,40 +133,64 @@ __global__ void __launch_bounds__(256) k_pig_count(int n_vtx, int n_grid_max, co
     else if (err_flag) atomicOr(err_flag, 2);
 }
 
-// pig_bgn = cumsum(cnt) - cnt (nerf/utils.py:369), one workgroup of 1024 threads, 4 cells per thread per tile.
+// pig_bgn = cumsum(cnt) - cnt (nerf/utils.py:369), one workgroup of 1024 threads, 16 cells per thread per tile (16 384 cells per round: a 300 k-cell
+// grid — --cut with bound 2 — is 19 rounds of one barrier each; with 4 cells per thread and three barriers per round it was 74 rounds, 0.23 ms per scan).
+// The running carry lives in a register of every thread (each adds the same 16 wave totals), the wave totals alternate between two LDS rows.
 __device__ __forceinline__ void block_scan_1024(int n_grid, const int* __restrict__ cnt, int* __restrict__ bgn, int* __restrict__ cursor) {
-    __shared__ int wsum[16];
-    __shared__ int carry_s;
+    __shared__ int wsum[2][16];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < n_grid; base += 4096) {
-        const int i0 = base + threadIdx.x * 4;
-        int v[4];
+    int carry = 0, buf = 0;
+    for (int base = 0; base < n_grid; base += 16384, buf ^= 1) {
+        const int i0 = base + threadIdx.x * 16;
+        int v[16];
+        if (i0 + 16 <= n_grid) {  // (cnt + i0 is 64-byte aligned: the tables come from hipMalloc and i0 is a multiple of 16)
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = (i0 + k < n_grid) ? __hip_atomic_load(cnt + i0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        const int tsum = v[0] + v[1] + v[2] + v[3];
+            for (int q = 0; q < 4; q++) {
+                const int4 w = *reinterpret_cast<const int4*>(cnt + i0 + 4 * q);
+                v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = (i0 + k < n_grid) ? cnt[i0 + k] : 0;
+        }
+        int tsum = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) tsum += v[k];
         int inc = tsum;  // inclusive wave scan
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int u = __shfl_up(inc, o);
             if (lane >= o) inc += u;
         }
-        if (lane == 63) wsum[wid] = inc;
+        if (lane == 63) wsum[buf][wid] = inc;
         __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wid; w++) woff += wsum[w];
-        int total = 0;
-        for (int w = 0; w < 16; w++) total += wsum[w];
-        int run = carry_s + woff + inc - tsum;
+        int woff = 0, total = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (i0 + k < n_grid) { bgn[i0 + k] = run; cursor[i0 + k] = run; }
-            run += v[k];
+        for (int w = 0; w < 16; w++) {
+            const int x = wsum[buf][w];
+            woff += (w < wid) ? x : 0;
+            total += x;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s += total;
-        __syncthreads();
+        int run = carry + woff + inc - tsum;
+        if (i0 + 16 <= n_grid) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int4 o4;
+                o4.x = run; run += v[4 * q];
+                o4.y = run; run += v[4 * q + 1];
+                o4.z = run; run += v[4 * q + 2];
+                o4.w = run; run += v[4 * q + 3];
+                *reinterpret_cast<int4*>(bgn + i0 + 4 * q) = o4;
+                *reinterpret_cast<int4*>(cursor + i0 + 4 * q) = o4;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                if (i0 + k < n_grid) { bgn[i0 + k] = run; cursor[i0 + k] = run; }
+                run += v[k];
+            }
+        }
+        carry += total;
     }
 }
 __global__ void __launch_bounds__(1024) k_pig_scan(int n_grid_max, const int* __restrict__ n_grid_dev, const int* __restrict__ cnt,
