@@ -442,18 +442,40 @@ __global__ void __launch_bounds__(1024) k_rhs_gather_csr(int n_k, const int* __r
 #endif
 __global__ void __launch_bounds__(512) k_gather_plan(int n_k, int chunks_max, const int* __restrict__ csr_bg, const int* __restrict__ csr_cnt,
                                                      int* __restrict__ kc_bg, int2* __restrict__ chunk) {
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int k = 0; k < n_k; k++) { kc_bg[k] = acc; acc += (csr_cnt[k] + PN_GCH - 1) / PN_GCH; }
-        kc_bg[n_k] = acc;
-    }
+    // exclusive scan of the kernels' chunk counts by the whole workgroup (one lane walking the n_k kernels took 40 us of every substep)
+    __shared__ int wsum[8];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int k = threadIdx.x; k < n_k; k += blockDim.x)  // chunk[b] = (first entry, entry count): one load tells a workgroup its work
-        for (int b = kc_bg[k]; b < kc_bg[k + 1]; b++) {
-            const int first = (b - kc_bg[k]) * PN_GCH;
-            chunk[b] = make_int2(csr_bg[k] + first, min(PN_GCH, csr_cnt[k] - first));
+    for (int base = 0; base < n_k; base += 512) {
+        const int k = base + (int)threadIdx.x;
+        const int cnt = k < n_k ? csr_cnt[k] : 0;
+        const int nc = (cnt + PN_GCH - 1) / PN_GCH;
+        int inc = nc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
         }
-    for (int b = kc_bg[n_k] + threadIdx.x; b < chunks_max; b += blockDim.x) chunk[b] = make_int2(0, 0);  // unused tail of the grid
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int w = 0; w < 8; w++) { woff += (w < wid) ? wsum[w] : 0; total += wsum[w]; }
+        const int first_chunk = carry_s + woff + inc - nc;
+        if (k < n_k) {
+            kc_bg[k] = first_chunk;
+            const int bg = csr_bg[k];
+            for (int j = 0; j < nc; j++)  // chunk[b] = (first entry, entry count): one load tells a workgroup its work
+                chunk[first_chunk + j] = make_int2(bg + j * PN_GCH, min(PN_GCH, cnt - j * PN_GCH));
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += total;
+        __syncthreads();
+    }
+    const int n_chunks = carry_s;
+    if (threadIdx.x == 0) kc_bg[n_k] = n_chunks;
+    for (int b = n_chunks + threadIdx.x; b < chunks_max; b += blockDim.x) chunk[b] = make_int2(0, 0);  // unused tail of the grid
 }
 
 __global__ void __launch_bounds__(PN_GCH * 8) k_rhs_gather_chunk(const int2* __restrict__ chunk, const double* __restrict__ dNx_csr,
