@@ -7,15 +7,17 @@
 // the evaluations, but the evaluation at s_k (search cell -> nearest IPs -> Newton warps -> blend -> density bit -> voxel exit)
 // is a pure function of s_k.  So per round the G lanes of a ray evaluate s_0..s_{G-1} independently, each lane then walks its
 // own voxel hop to find the index it would jump to, and every lane replays the visit chain 0 -> jump[0] -> jump[jump[0]] ...
-// (G = 8: the 8 jump indices are OR-packed into one dword by DPP; G = 64: one ds_bpermute per chain link).  Visited lanes that
-// found an occupied sample write it to the slot given by their rank in the chain.
+// (G = 8: the 8 jump indices are OR-packed into one dword by DPP; G = 64: the wave-uniform chain is walked with scalar registers and
+// v_readlane).  Visited lanes that found an occupied sample write it to the slot given by their rank in the chain.  The round loop is
+// wave-uniform: the candidate lists and IP record heads the wave's points need are staged cooperatively in LDS (stage_lists, head_fetch).
 //
 // Two launches per loop trip use it (pn_render_ops.hip):
-//   k_march       G = 8, 8 rays per wave, at most `max_rounds` rounds per ray: a ray in a sample-dense region emits its 8
-//                 samples in one round.  Rays that are still going after the budget (a few hundred per trip: they graze the
-//                 object and hop through 60-90 voxels without emitting) are appended to a tail list with their state;
-//   k_march_tail  G = 64, one wave per listed ray: 64 sequence elements (~14 voxel hops) per round, so the critical path of
-//                 a trip is ~6 rounds instead of ~80 dependent iterations.
+//   k_march       G = 8, 8 rays per wave, at most `max_rounds` rounds per ray (2 on a frame's first trip, 1 afterwards): a ray in a
+//                 sample-dense region emits its 8 samples in one round.  Rays that are still going after the budget (they graze the
+//                 object or have left it and hop through 60-90 voxels without emitting) are appended to a segmented tail list with
+//                 their state and ray constants;
+//   k_march_tail  G = 64, one wave per listed ray (handed out dynamically, long ones first): 64 sequence elements (~14 voxel hops)
+//                 per round, so the critical path of a trip is ~6 rounds instead of ~80 dependent iterations.
 // vs. the cooperative form (pn_march2.h: 8 lanes share ONE evaluation, one iteration at a time) the results are identical bit
 // for bit: same -ffp-contract=off expressions, sequential strict-'<' insertion over the candidate list in the reference's
 // visiting order, the `n_IP--` loops replayed literally.

@@ -552,10 +552,10 @@ struct __attribute__((aligned(16))) TailEntry {
 };
 static_assert(sizeof(TailEntry) == 64, "four 16-byte parts");
 
-// waves per SIMD the march kernels are compiled for: 4 -> at most 128 VGPRs.  The kernels wait on memory rather than on
-// occupancy, but their register footprint decides what else fits beside them: with 3 waves x 146 VGPRs a SIMD had no room left
-// for a wave of the simulator's kernels (k_elastic: 94), and the substep running concurrently on its own stream cost the
-// pipelined step 5 % more than it does now (measured)
+// waves per SIMD the march kernels ask for.  What really sets their occupancy is LDS: 12 KB of staging per wave (PN_STAGE_CAP) = three
+// workgroups per CU, and the compiler then takes the registers three waves per SIMD leave it (~160 VGPRs, no spills).  One wave per SIMD is
+// only 15 % slower for the march alone (a wave is a chain of dependent instructions and round trips), but what a march wave holds while it
+// waits is what the other render lanes and the simulator cannot use (launch structure)
 #ifndef PN_MARCH_WAVES
 #define PN_MARCH_WAVES 4
 #endif

@@ -47,6 +47,28 @@ def test_full_frame_bookkeeping_and_compositing_invariants(full):
     assert bool((d0[miss] == 0).all()) and float(d0[~miss].max()) > 3.0   # camera at radius 5, object around the origin
 
 
+def test_trip_records_first_trip_lists_later_trips_are_dense(full):
+    """pn_frame_trip_records: trip 0 (every ray looks for its first sample) compacts a sample list through the segmented append lists; every
+    later trip runs the network over all n_alive x n_step slots and only counts what was really emitted (frame driver)."""
+    h, opt = full["h"], full["opt"]
+    N = opt["W"] * opt["H"]
+    with torch.no_grad():
+        h.step(simulate=False, collect_stats=True)
+    st = dict(h.model.last_stats)
+    rec = h.model.trip_records()
+    assert len(rec) == st["trips"]
+    n_alive, n_step, step_base, n_list, n_emitted, n_tail = rec[0]
+    assert (n_alive, n_step, step_base, n_emitted) == (N, 1, 0, -1) and 0 < n_list < N and 0 < n_tail < N
+    samples, base = n_list, 1
+    for (na, ns, sb, nl, ne, nt), prev in zip(rec[1:], rec[:-1]):
+        assert 0 < na <= prev[0] and ns == max(min(N // na, 8), 1) and sb == base      # renderer.py:841, :891
+        assert nl == na * ns and 0 <= ne <= nl and 0 <= nt <= na                         # dense: identity list; emitted <= slots
+        samples += ne
+        base += ns
+    assert samples == st["samples"]
+    assert rec[1][0] <= n_list                                                          # only rays that found a sample can be alive next
+
+
 def test_full_frame_is_reproducible_and_launch_forms_agree(full):
     """Same state -> same bits, eager twice; the captured graph and the pipelined lanes reproduce the eager images of a fresh harness."""
     from pienerf_amd.harness import SimRenderHarness
