@@ -327,7 +327,6 @@ def main():
     ap.add_argument("--trips", type=int, default=None, help="render-loop trips baked into the captured graphs (default: what one eager frame needs + 2; a frame "
                     "that needs more is continued when it is retired)")
     ap.add_argument("--copy-on", choices=("copy", "lane", "sim"), default="lane", help="stream of the per-frame D2H: a copy stream of its own, or the frame's render stream")
-    ap.add_argument("--staged-streams", type=int, default=3, help="--config stress: streams the 4096-ray batches of a frame are dealt to")
     ap.add_argument("--lanes", type=int, default=3,
                     help="render streams (3 render streams + the simulator stream = the 4 compute pipes of an XCD, more streams only time-slice)")
     ap.add_argument("--depth", type=int, default=2, help="workspaces per render stream")
@@ -365,6 +364,9 @@ def main():
 
     from pienerf_amd.harness import SimRenderHarness
     opt, cloud, ckpt, pose, force, workload = make_config(args.config, args.sigma_gain)
+    staged = args.config == "stress" and not args.whole_frame
+    if staged:
+        opt["ray_batch"] = int(opt.get("max_ray_batch", 4096))  # BASELINE configs[4]: "4096 rays/batch" (get_opts.py:24)
     if args.force is not None:
         force = np.asarray(args.force, dtype=np.float64)
 
@@ -383,7 +385,6 @@ def main():
         torch.cuda.synchronize()
 
     frames_done = [0]
-    staged = args.config == "stress" and not args.whole_frame and world == 1 and not args.eager and not args.single_graph
     if world == 1:
         if args.eager:
             def run_steps(n):
@@ -403,17 +404,15 @@ def main():
                     if copy_out:
                         h.to_host(o_)
             launch = f"one hip graph per step, {args.trips or 8} trips"
-        elif staged:
-            h.capture_staged(copy_out=copy_out, streams=args.staged_streams, n_trips=args.trips)
-            run_steps = lambda n: [h.step_staged() for _ in range(n)]
-            launch = (f"one captured graph replay per 4096-ray batch ({h._staged['trips']} trips each) dealt to {h._staged['L']} streams, tables built once per "
-                      "workspace and frame, substep on its own stream")
         else:
+            # --config stress: opt["ray_batch"] = 4096 (set above) — the frame's 157 ray batches keep their own trip schedules inside the same
+            # launches (pn_render_opts.ray_batch), so the staged frame runs on the same pipeline as the frame in one piece
             h.capture_pipelined(lanes=args.lanes, depth=args.depth, n_trips=args.trips, copy_out=copy_out, copy_on=args.copy_on)
             args.trips = h._pipe_backend.trips
             run_steps = lambda n: [h.step_pipelined() for _ in range(n)]
             launch = (f"hip graphs, {args.trips} trips, {args.lanes} render streams x {args.depth} workspaces, simulator running ahead, D2H on "
-                      + {"copy": "a copy stream", "lane": "the frame's render stream", "sim": "the simulator stream"}[args.copy_on])
+                      + {"copy": "a copy stream", "lane": "the frame's render stream", "sim": "the simulator stream"}[args.copy_on]
+                      + (f"; rays in batches of {opt['ray_batch']} with per-batch trip schedules (max_ray_batch), all batches in the same launches" if staged else ""))
     else:
         from pienerf_amd.frames import broadcast_tensors
         m = h.model
@@ -444,11 +443,9 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         continued = 0
-        if world > 1 or not (args.eager or args.single_graph or staged):  # the last frames in flight are retired (and verified) here
+        if world > 1 or not (args.eager or args.single_graph):  # the last frames in flight are retired (and verified) here
             frames_done[0] += len(h.drain_pipeline())
             continued = h._pipe_backend.continued
-        elif staged:
-            h.finish_staged()
         elif args.single_graph:
             h._check_previous_graph_frame()
             continued = getattr(h, "graph_continued", 0)
@@ -485,12 +482,14 @@ def main():
             "roofline": roofline,
         }
         res.update(extra)
-        if world == 1 and not args.no_extras and not (args.eager or args.single_graph or staged):
+        if world == 1 and not args.no_extras and not (args.eager or args.single_graph):
             with torch.no_grad():
                 res.update(pipelined_extras(make_harness, args, max(40, min(args.steps, 120))))
         if staged and not args.no_extras:  # the same configuration with the frame rendered in one shot (what render_deformed does with these options in the reference)
             with torch.no_grad():
+                opt.pop("ray_batch")
                 hw = make_harness()
+                opt["ray_batch"] = hw_batch = int(opt.get("max_ray_batch", 4096))
                 hw.capture_pipelined(lanes=args.lanes, depth=args.depth, n_trips=None, copy_out=copy_out)
                 for _ in range(12):
                     hw.step_pipelined()

@@ -213,6 +213,12 @@ typedef struct {
     int reuse_tables;     /* != 0: the IP state (p_def, F, dF) is the one of the previous pn_render_deformed on this workspace — keep its bounding box,
                              spatial hash, candidate lists and packed records and only start new rays.  For a frame rendered in ray batches
                              (max_ray_batch, get_opts.py:24): the reference rebuilds get_pnts_in_grids for every rund_cuda call */
+    int ray_batch;        /* > 0 (>= 64): the frame is rendered as ray batches of this many rays (opt.max_ray_batch = 4096, get_opts.py:24; the
+                             staging loop of nerf/renderer.py:562-576) — every batch with its OWN trip schedule n_step = max(min(N_b // n_alive_b, 8), 1)
+                             and its own max_steps count, exactly as if the batches were rendered one after the other, but all batches advance
+                             inside the same launches (rays are independent; the alive list stays sorted by ray id, so a batch is a contiguous
+                             run of it).  0: one schedule for the whole ray set (what the reference's render_deformed does, renderer.py:587-600).
+                             Deformed render only. */
 } pn_render_opts;
 int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_vtx, uint32_t max_grid_cells);
 void pn_frame_destroy(pn_frame* f);

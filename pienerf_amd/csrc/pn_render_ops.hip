@@ -28,6 +28,27 @@ static_assert(sizeof(PnTrip) == 256, "two cache lines");
 // them (their delta is 0).  The compaction kernel presets n_samples for such a trip.
 __device__ __forceinline__ bool trip_is_dense(const PnTrip* t) { return t->dense != 0; }
 
+// Ray groups (pn_render_opts::ray_batch > 0): the frame rendered "in ray batches of B" (max_ray_batch, get_opts.py:24; the staging loop of
+// renderer.py:562-576) WITHOUT one launch chain per batch.  Rays are independent, so what a batch changes is only its own trip schedule: batch
+// b = rays [b B, (b + 1) B) marches n_step_b = max(min(N_b // n_alive_b, 8), 1) samples per ray and trip, stops when none of ITS rays is alive or
+// ITS step count reaches max_steps.  Stable compaction keeps the alive list sorted by ray id, so the batches are contiguous runs of it; every
+// trip kernel handles all of them in one launch and looks up, per ray, its group's (first alive position, n_step, first sample slot).  One
+// record per group and trip parity, written by the previous trip's compaction (trip 0: k_frame_rays).  The sample slots of a trip stay dense:
+// slot_base is the running sum of n_alive_b * n_step_b.  n_step == 0 marks a group that ran into max_steps: composite retires its rays.
+struct PnGroup {
+    int alive_base, n_step, slot_base, step_base;
+};
+// n_step / first sample slot of the ray at alive position n (ray id `index`); groups == nullptr: one schedule for all rays (slot0 = n * n_step)
+__device__ __forceinline__ void ray_slots(const PnGroup* __restrict__ groups, uint32_t group_rays, int index, uint32_t n, uint32_t& n_step, uint32_t& slot0) {
+    if (groups) {
+        const PnGroup g = groups[(uint32_t)index / group_rays];
+        n_step = (uint32_t)g.n_step;
+        slot0 = (uint32_t)g.slot_base + (n - (uint32_t)g.alive_base) * (uint32_t)g.n_step;
+    } else {
+        slot0 = n * n_step;
+    }
+}
+
 // Per-frame device record of the frame drivers (pn_render_deformed / pn_render_static).
 struct PnFrameDev {
     float aabb[6];      // bbmin = aabb, bbmax = aabb + 3   (aabb = cat(bbmin, bbmax), renderer.py:796)
@@ -467,6 +488,9 @@ struct MarchIO {
     // (pn_march3.h: ray_end_of_candidates); the march kernels then run with MarchParams::fars = fars_eff
     const uint32_t* cell_bits2;
     float* fars_eff;
+    // optional (frame driver with ray groups, see PnGroup): this trip's group records
+    const PnGroup* groups;
+    uint32_t group_rays;
 };
 
 // Append lists are SEGMENTED: PN_SEGS independent (counter, region) pairs, every counter on a cache line of its own, the producer picking
@@ -548,7 +572,7 @@ struct __attribute__((aligned(16))) TailEntry {
     float ox, oy, oz, dx;
     float dy, dz, rdx, rdy;
     float rdz, far;
-    int pad0, pad1;
+    int slot0, n_step;  // first sample slot and sample budget of the ray in this trip (ray_slots)
 };
 static_assert(sizeof(TailEntry) == 64, "four 16-byte parts");
 
@@ -563,9 +587,9 @@ static_assert(sizeof(TailEntry) == 64, "four 16-byte parts");
 // 8 lanes per ray, 32 rays per 256-thread block.
 template <int K, bool MULTI>
 __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
-    uint32_t n_alive = io.n_alive, n_step = io.n_step;
+    uint32_t n_alive = io.n_alive, n_step_trip = io.n_step;
     bool dense = false;
-    if (io.trip) { n_alive = (uint32_t)io.trip->n_alive; n_step = (uint32_t)io.trip->n_step; dense = trip_is_dense(io.trip); }
+    if (io.trip) { n_alive = (uint32_t)io.trip->n_alive; n_step_trip = (uint32_t)io.trip->n_step; dense = trip_is_dense(io.trip); }
     const int lane = threadIdx.x & 63, sub = lane & 7, gbase = lane & ~7;
     const int budget = io.tail ? io.max_rounds : 0x7fffffff;
     __shared__ float4 stage_mem[4][PN_STAGE_CAP];
@@ -586,17 +610,19 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams 
         float* dl = nullptr;
         pnm3::RayConsts c;
         pnm3::RayState st{0.f, 0.f, 0u};
+        uint32_t n_step = n_step_trip, slot0 = 0;  // per ray with ray groups
         if (n < n_alive) {
             const int index = io.rays_alive[n];
             const float noise = io.noises ? io.noises[n] : 0.0f;
-            dl = io.deltas + (size_t)n * n_step * 2;
+            ray_slots(io.groups, io.group_rays, index, n, n_step, slot0);
+            dl = io.deltas + (size_t)slot0 * 2;
             pnm3::ray_consts(a, index, c);
             have = pnm3::ray_start(a, c, index, noise, io.t_resume ? io.t_resume + n : nullptr, st);
         }
         PN_PHASE(pk, 0);
         // all 64 lanes enter (the round loop inside is wave-uniform, pn_march3.h); lanes without a ray idle through it
-        const bool done = pnm3::march_window<K, MULTI, 8>(a, tb, c, n_step, sub, gbase, lane, stage, io.xyzs + (size_t)n * n_step * 3,
-                                                          io.dirs + (size_t)n * n_step * 3, dl, st, budget, have PN_PHASE_PASS);
+        const bool done = pnm3::march_window<K, MULTI, 8>(a, tb, c, n_step, sub, gbase, lane, stage, io.xyzs + (size_t)slot0 * 3,
+                                                          io.dirs + (size_t)slot0 * 3, dl, st, budget, have PN_PHASE_PASS);
         if (n < n_alive) {
             deferred = have && !done;  // still marching after the round budget: continue with a whole wave (k_march_tail)
             emitted = deferred ? 0u : st.step;  // a deferred ray's samples are listed by the tail pass
@@ -620,7 +646,7 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams 
                     if (sub == 0) part = make_float4(__int_as_float((int)n), st.t, st.last_t, __int_as_float((int)st.step));
                     else if (sub == 1) part = make_float4(c.ox, c.oy, c.oz, c.dx);
                     else if (sub == 2) part = make_float4(c.dy, c.dz, c.rdx, c.rdy);
-                    else part = make_float4(c.rdz, c.far, 0.f, 0.f);
+                    else part = make_float4(c.rdz, c.far, __int_as_float((int)slot0), __int_as_float((int)n_step));
                     te[sub] = part;
                 }
             }
@@ -631,10 +657,10 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams 
                 for (uint32_t s = emitted + sub; s < n_step; s += PN_G) { dl[2 * s] = 0.0f; dl[2 * s + 1] = 0.0f; }
             if (dense) {
                 if (dl && !deferred) {
-                    float* X = io.xyzs + (size_t)n * n_step * 3;
-                    float* Dd = io.dirs + (size_t)n * n_step * 3;
+                    float* X = io.xyzs + (size_t)slot0 * 3;
+                    float* Dd = io.dirs + (size_t)slot0 * 3;
                     for (uint32_t s = emitted + sub; s < n_step; s += PN_G) { X[3 * s] = X[3 * s + 1] = X[3 * s + 2] = 0.0f; Dd[3 * s] = Dd[3 * s + 1] = Dd[3 * s + 2] = 0.0f; }
-                    for (uint32_t s = sub; s < n_step; s += PN_G) io.list[n * n_step + s] = (int)(n * n_step + s);
+                    for (uint32_t s = sub; s < n_step; s += PN_G) io.list[slot0 + s] = (int)(slot0 + s);
                 }
                 int v = (sub == 0 && dl && !deferred) ? (int)emitted : 0;  // one counter update per wave
                 v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
@@ -653,7 +679,7 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams 
             base = __shfl(base, 63);
             const int first = base + __shfl(inc, gbase) - (int)emitted;  // exclusive prefix of this group's first lane
             int* seg_list = io.list_seg + (size_t)seg * io.list_seg_cap;
-            for (uint32_t s = sub; s < emitted; s += PN_G) seg_list[first + s] = (int)(n * n_step + s);
+            for (uint32_t s = sub; s < emitted; s += PN_G) seg_list[first + s] = (int)(slot0 + s);
             }
         }
         PN_PHASE(pk, 5);
@@ -664,9 +690,8 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams 
 // One wave per unfinished ray: windows of 64 sequence elements until the ray is done for this trip.
 template <int K, bool MULTI>
 __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march_tail(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
-    uint32_t n_step = io.n_step;
     bool dense = false;
-    if (io.trip) { n_step = (uint32_t)io.trip->n_step; dense = trip_is_dense(io.trip); }
+    if (io.trip) dense = trip_is_dense(io.trip);
     const int lane = threadIdx.x & 63;
     const int gw = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), n_waves = (int)gridDim.x * 4;
     const int seg = gw % PN_SEGS;  // this wave's segment of the tail list; its own appends go to the same segment of the sample list
@@ -683,31 +708,31 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march_tail(pnm::MarchPa
         e = __builtin_amdgcn_readfirstlane(e);
         if (e >= total) break;
         const TailEntry te = io.tail[(size_t)seg * io.tail_seg_cap + (e < n_long ? e : io.tail_seg_cap - 1 - (e - n_long))];
-        const uint32_t n = (uint32_t)te.n;
-        float* dl = io.deltas + (size_t)n * n_step * 2;
+        const uint32_t slot0 = (uint32_t)te.slot0, n_step = (uint32_t)te.n_step;
+        float* dl = io.deltas + (size_t)slot0 * 2;
         pnm3::RayConsts c;
         c.ox = te.ox; c.oy = te.oy; c.oz = te.oz; c.dx = te.dx; c.dy = te.dy; c.dz = te.dz; c.rdx = te.rdx; c.rdy = te.rdy; c.rdz = te.rdz; c.far = te.far;
         pnm3::frame_consts(a, c);
         pnm3::RayState st{te.t, te.last_t, (uint32_t)te.step};
         PN_PHASE(pk, 0);
-        pnm3::march_window<K, MULTI, 64>(a, tb, c, n_step, lane, 0, lane, stage, io.xyzs + (size_t)n * n_step * 3, io.dirs + (size_t)n * n_step * 3,
+        pnm3::march_window<K, MULTI, 64>(a, tb, c, n_step, lane, 0, lane, stage, io.xyzs + (size_t)slot0 * 3, io.dirs + (size_t)slot0 * 3,
                                          dl, st, 0x7fffffff, true PN_PHASE_PASS);
         const uint32_t emitted = st.step;
         if (!PN_DBG_PHASES_ON && a.stats && lane == 0 && emitted) atomicAdd(a.stats + 3, (unsigned long long)emitted);
         if (io.trip) {
             for (uint32_t s = emitted + lane; s < n_step; s += 64) { dl[2 * s] = 0.0f; dl[2 * s + 1] = 0.0f; }
             if (dense) {
-                float* X = io.xyzs + (size_t)n * n_step * 3;
-                float* Dd = io.dirs + (size_t)n * n_step * 3;
+                float* X = io.xyzs + (size_t)slot0 * 3;
+                float* Dd = io.dirs + (size_t)slot0 * 3;
                 for (uint32_t s = emitted + lane; s < n_step; s += 64) { X[3 * s] = X[3 * s + 1] = X[3 * s + 2] = 0.0f; Dd[3 * s] = Dd[3 * s + 1] = Dd[3 * s + 2] = 0.0f; }
-                for (uint32_t s = lane; s < n_step; s += 64) io.list[n * n_step + s] = (int)(n * n_step + s);
+                for (uint32_t s = lane; s < n_step; s += 64) io.list[slot0 + s] = (int)(slot0 + s);
                 if (lane == 0 && emitted) atomicAdd(io.emit_parts + seg * PN_SEG_STRIDE, (int)emitted);
             } else {
                 int base = 0;
                 if (lane == 0 && emitted > 0) base = atomicAdd(io.samp_counts + seg * PN_SEG_STRIDE, (int)emitted);
                 base = __shfl(base, 0);
                 int* seg_list = io.list_seg + (size_t)seg * io.list_seg_cap;
-                for (uint32_t s = lane; s < emitted; s += 64) seg_list[base + s] = (int)(n * n_step + s);
+                for (uint32_t s = lane; s < emitted; s += 64) seg_list[base + s] = (int)(slot0 + s);
             }
         }
         PN_PHASE(pk, 5);
@@ -802,7 +827,7 @@ extern "C" int pn_march_rays_quadratic_bending(const int* pig_cnt, const int* pi
                    (TailEntry*)(pool + off_tail + tail_ctr), (int*)(pool + off_tail), (int*)(pool + off_tail) + PN_SEGS * PN_SEG_STRIDE,
                    (int*)(pool + off_tail) + 2 * PN_SEGS * PN_SEG_STRIDE, (int)tail_cap,
                    (int)march_tail_rounds(), nullptr, nullptr, 0,
-                   nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr};
+                   nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0};
         if (io.t_resume) k_march_skip<<<pn_div_up(n_alive, 256), 256, 0, st>>>(a, tb, io);
         launch_march(num_seek_IP, pn_div_up(n_alive, 32), std::max(std::min(pn_div_up(n_alive, 4), 2048u), (uint32_t)PN_SEGS / 4), st, a, tb, io);
     }
@@ -814,13 +839,12 @@ extern "C" int pn_march_rays_quadratic_bending(const int* pig_cnt, const int* pi
 
 // ------------------------------------------------------------------------------------------------ composite
 // kernel_composite_rays, raymarching.cu:827-923.  __expf -> the gfx950 fast exponential (v_exp_f32 on x*log2e).
-__device__ __forceinline__ bool composite_one(uint32_t n, uint32_t n_step, float T_thresh, int* rays_alive, float* rays_t,
+__device__ __forceinline__ bool composite_one(uint32_t n, int index, uint32_t slot0, uint32_t n_step, float T_thresh, int* rays_alive, float* rays_t,
                                               const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ deltas,
                                               float* weights_sum, float* depth, float* image) {
-    const int index = rays_alive[n];
-    sigmas += (size_t)n * n_step;
-    rgbs += (size_t)n * n_step * 3;
-    deltas += (size_t)n * n_step * 2;
+    sigmas += (size_t)slot0;
+    rgbs += (size_t)slot0 * 3;
+    deltas += (size_t)slot0 * 2;
     float t = rays_t[index];
     float ws = weights_sum[index], d = depth[index];
     float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
@@ -848,16 +872,41 @@ __device__ __forceinline__ bool composite_one(uint32_t n, uint32_t n_step, float
 }
 
 // One 256-ray chunk per block; in frame-driver mode also records the chunk's survivor count for the compaction pass.
+// groups / group_cnt (ray groups, see PnGroup): per-ray schedule, and the survivors counted per group — the alive list is sorted by ray id, so the
+// lanes of a wave form a few runs of equal group id and every run costs one atomic (group_cnt == nullptr with a single group: its count is the
+// chunk total the compaction computes anyway, and one counter for every wave of the launch would serialise, see PN_SEGS).
 __global__ void __launch_bounds__(256) k_composite(uint32_t n_alive_arg, uint32_t n_step_arg, float T_thresh, int* rays_alive, float* rays_t,
                                                    const float* __restrict__ sigmas, const float* __restrict__ rgbs,
                                                    const float* __restrict__ deltas, float* weights_sum, float* depth, float* image,
-                                                   const PnTrip* trip, int* chunk_counts) {
-    uint32_t n_alive = n_alive_arg, n_step = n_step_arg;
-    if (trip) { n_alive = (uint32_t)trip->n_alive; n_step = (uint32_t)trip->n_step; }
+                                                   const PnTrip* trip, int* chunk_counts, const PnGroup* __restrict__ groups, uint32_t group_rays,
+                                                   int* group_cnt) {
+    uint32_t n_alive = n_alive_arg, n_step_trip = n_step_arg;
+    if (trip) { n_alive = (uint32_t)trip->n_alive; n_step_trip = (uint32_t)trip->n_step; }
     for (uint32_t chunk = blockIdx.x; chunk * 256u < n_alive; chunk += gridDim.x) {  // bounded grid, see k_march
         const uint32_t n = threadIdx.x + chunk * 256u;
         bool alive = false;
-        if (n < n_alive) alive = composite_one(n, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+        int grp = -1;
+        if (n < n_alive) {
+            const int index = rays_alive[n];
+            uint32_t n_step = n_step_trip, slot0;
+            ray_slots(groups, group_rays, index, n, n_step, slot0);
+            if (groups) grp = (int)((uint32_t)index / group_rays);
+            if (n_step == 0) rays_alive[n] = -1;  // its group has reached max_steps: the batch's loop is over (renderer.py:836), the ray is dropped
+            else alive = composite_one(n, index, slot0, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+        }
+        if (group_cnt) {
+            const int lane = threadIdx.x & 63;
+            const unsigned long long am = __ballot(alive);
+            const int prev = __shfl_up(grp, 1);
+            const bool head = lane == 0 || grp != prev;
+            const unsigned long long hm = __ballot(head);
+            if (head && grp >= 0) {  // this run: lanes [lane, next head)
+                const unsigned long long above = lane == 63 ? 0ull : hm & ~((2ull << lane) - 1ull);
+                const unsigned long long upto = above ? ((1ull << (__ffsll((long long)above) - 1)) - 1ull) : ~0ull;
+                const int c = (int)__popcll(am & upto & ~((1ull << lane) - 1ull));
+                if (c) atomicAdd(group_cnt + grp, c);
+            }
+        }
         if (chunk_counts) {
             const int c = __syncthreads_count(alive);
             if (threadIdx.x == 0) chunk_counts[chunk] = c;
@@ -870,7 +919,7 @@ extern "C" int pn_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thre
     if (n_alive == 0) return PN_OK;  // empty tensors have null data pointers
     PN_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image && n_step >= 1);
     k_composite<<<pn_div_up(n_alive, 256), 256, 0, (hipStream_t)stream>>>(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas,
-                                                                         weights_sum, depth, image, nullptr, nullptr);
+                                                                         weights_sum, depth, image, nullptr, nullptr, nullptr, 0, nullptr);
     PN_LAUNCH_CHECK();
     return PN_OK;
 }
@@ -1134,9 +1183,13 @@ __global__ void __launch_bounds__(256) k_list_pack(PnTrip* trip, const int* __re
 
 // Block c moves the survivors of chunk c to out[prefix(c) ...], keeping order (== rays_alive[rays_alive >= 0]).
 // Block 0 also publishes the total and, in frame-driver mode, the next trip's record (renderer.py:839-846,891).
+// Ray groups (g_next != nullptr, see PnGroup): chunk 0's first wave also writes the next trip's group records from this trip's records and the
+// per-group survivor counts of k_composite — N_b // n_alive_b per group, exclusive sums for the first alive position and the first sample slot.
 __global__ void __launch_bounds__(256) k_compact(const int* __restrict__ in, uint32_t n_arg, const int* __restrict__ chunk_counts,
                                                  int* __restrict__ out, int* n_out, PnTrip* trip, PnTrip* next, uint32_t N_rays,
-                                                 uint32_t max_steps, int dense_trips, int* seg_counters, int* tail_diag) {
+                                                 uint32_t max_steps, int dense_trips, int* seg_counters, int* tail_diag,
+                                                 const PnGroup* __restrict__ g_cur, PnGroup* __restrict__ g_next, int* group_cnt, uint32_t group_rays,
+                                                 uint32_t n_groups) {
     __shared__ int red[4];
     __shared__ int woff[4];
     const uint32_t n = trip ? (uint32_t)trip->n_alive : n_arg;
@@ -1168,7 +1221,49 @@ __global__ void __launch_bounds__(256) k_compact(const int* __restrict__ in, uin
             for (int o = 32; o > 0; o >>= 1) { tl += __shfl_xor(tl, o); em += __shfl_xor(em, o); }
             if (lane == 0) { if (tail_diag) *tail_diag = tl; if (trip) trip->n_emitted = em; }
         }
-        if (c == 0 && threadIdx.x == 0) {
+        if (c == 0 && g_next && wid == 0) {
+            // one wave, 64 groups per round, running sums carried in (uniform) registers
+            int alive_run = 0, slot_run = 0, live = 0, step0 = 1;
+            for (uint32_t b0 = 0; b0 < n_groups; b0 += 64) {
+                const uint32_t b = b0 + (uint32_t)lane;
+                int cnt = 0, nstep = 0, stepb = 0;
+                if (b < n_groups) {
+                    const PnGroup g = g_cur[b];
+                    cnt = (n_groups == 1) ? sum : group_cnt[b];
+                    if (n_groups > 1) group_cnt[b] = 0;
+                    stepb = g.step_base + g.n_step;
+                    const uint32_t rays_b = min(group_rays, N_rays - b * group_rays);  // N_b
+                    const bool over = cnt <= 0 || (uint32_t)stepb >= max_steps || g.n_step == 0;
+                    nstep = over ? 0 : max(min((int)(rays_b / (uint32_t)cnt), 8), 1);
+                }
+                const int slots = cnt * nstep;
+                int a_inc = cnt, s_inc = slots;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int ua = __shfl_up(a_inc, o), us = __shfl_up(s_inc, o);
+                    if (lane >= o) { a_inc += ua; s_inc += us; }
+                }
+                if (b < n_groups) g_next[b] = PnGroup{alive_run + a_inc - cnt, nstep, slot_run + s_inc - slots, stepb};
+                if (b == 0) step0 = nstep;
+                alive_run += __shfl(a_inc, 63);
+                slot_run += __shfl(s_inc, 63);
+                int lv = nstep > 0 ? cnt : 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) lv += __shfl_xor(lv, o);
+                live += lv;
+            }
+            step0 = __shfl(step0, 0);
+            if (lane == 0) {
+                // rays of groups that ran into max_steps stay listed until the next composite retires them; the frame is over when no group marches on
+                const bool done = live <= 0;
+                next->n_alive = done ? 0 : sum;
+                next->n_step = done ? 1 : max(step0, 1);  // informational with groups (every kernel reads the group records)
+                next->step_base = trip->step_base + trip->n_step;
+                next->dense = (dense_trips && !done) ? 1 : 0;
+                next->n_samples = (dense_trips && !done) ? slot_run : 0;
+                next->n_emitted = 0;
+            }
+        } else if (c == 0 && threadIdx.x == 0) {
             if (n_out) *n_out = sum;
             if (next) {
                 const int step = trip->step_base + trip->n_step;
@@ -1208,7 +1303,7 @@ extern "C" int pn_compact_rays(const int* rays_alive, uint32_t n, int* out, int*
     PN_REQUIRE(rays_alive && out && scratch);
     const uint32_t chunks = pn_div_up(n, 256);
     k_chunk_count<<<chunks, 256, 0, st>>>(rays_alive, n, scratch);
-    k_compact<<<chunks, 256, 0, st>>>(rays_alive, n, scratch, out, n_out, nullptr, nullptr, 0, 0, 0, nullptr, nullptr);
+    k_compact<<<chunks, 256, 0, st>>>(rays_alive, n, scratch, out, n_out, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0);
     PN_LAUNCH_CHECK();
     return PN_OK;
 }
@@ -1216,6 +1311,7 @@ extern "C" int pn_compact_rays(const int* rays_alive, uint32_t n, int* out, int*
 // ------------------------------------------------------------------------------------------------ whole frame
 
 #define PN_MAX_TRIPS 1100
+#define PN_MIN_RAY_BATCH 64  // smallest pn_render_opts::ray_batch (sizes the group records of a workspace)
 #define PN_TRIP_BATCH 8
 #define PN_TIMED_TRIPS 64
 
@@ -1237,6 +1333,9 @@ struct pn_frame {
     int *pig_cnt, *pig_bgn, *pig_idx, *pig_cursor;
     MarchSide side;  // candidate lists + packed IP records of the cooperative march
     PnTrip* trips;  // [PN_MAX_TRIPS + 2]
+    PnGroup* groups;     // [2][max_groups] ray-group records of the current / next trip (trip parity), see PnGroup
+    int* group_cnt;      // [max_groups] survivors per group (k_composite -> k_compact, which clears them)
+    uint32_t max_groups;
     PnFrameDev* dev;
     float* cut_bounds;
     PnTrip* trips_pinned;  // host-pinned mirror
@@ -1245,6 +1344,7 @@ struct pn_frame {
     int cut_bounds_valid;
     int last_trips;  // trips enqueued by the last render (incl. continuations)
     uint32_t last_N;
+    uint32_t last_group_rays;  // ray_batch of the last render (a continuation must use the same)
     int tables_n_vtx;  // IP count the workspace's tables were built for (0: none); pn_render_opts::reuse_tables
     unsigned long long* march_counters;  // device [4], see MarchParams::stats
     int march_counters_on;
@@ -1492,8 +1592,15 @@ __global__ void __launch_bounds__(256) k_frame_lists(int n_grid_max, const int* 
 __global__ void __launch_bounds__(256) k_frame_rays(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const PnFrameDev* dev, uint32_t N,
                                                     float min_near, float* __restrict__ nears, float* __restrict__ fars, float* __restrict__ rays_t,
                                                     PnTrip* trips, int* tail_counts, int* seg_counters, int n_trip_records, int* alive, float* __restrict__ weights_sum,
-                                                    float* __restrict__ depth_0, float* __restrict__ image) {
+                                                    float* __restrict__ depth_0, float* __restrict__ image, PnGroup* groups, int* group_cnt, uint32_t group_rays,
+                                                    uint32_t n_groups) {
     const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (blockIdx.x == 0 && groups) {  // trip 0 of every group: all its rays, one sample each (max(min(N_b // N_b, 8), 1))
+        for (uint32_t b = threadIdx.x; b < n_groups; b += blockDim.x) {
+            groups[b] = PnGroup{(int)(b * group_rays), 1, (int)(b * group_rays), 0};
+            group_cnt[b] = 0;
+        }
+    }
     if (blockIdx.x == 0) {
         for (int t = threadIdx.x; t < n_trip_records; t += blockDim.x) {
             PnTrip r;
@@ -1560,6 +1667,8 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
     PN_ALLOC(f->cell_bits, 2 * (((size_t)max_grid_cells + 31) / 32) * 4);
     PN_ALLOC(f->fars_eff, N * 4);
     PN_ALLOC(f->trips, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)); PN_ALLOC(f->dev, sizeof(PnFrameDev)); PN_ALLOC(f->cut_bounds, 6 * 4);
+    f->max_groups = pn_div_up(max_rays, PN_MIN_RAY_BATCH) + 1;
+    PN_ALLOC(f->groups, sizeof(PnGroup) * 2 * f->max_groups); PN_ALLOC(f->group_cnt, sizeof(int) * f->max_groups);
 #undef PN_ALLOC
     PN_HIP_CHECK(hipMalloc((void**)&f->march_counters, 16 * sizeof(unsigned long long)));  // [4..15]: debug phase clocks (PN_DBG_PHASES builds)
     PN_HIP_CHECK(hipMalloc((void**)&f->stamps, sizeof(unsigned long long) * PN_TIMED_TRIPS * 3));
@@ -1576,7 +1685,7 @@ extern "C" void pn_frame_destroy(pn_frame* f) {
     void* ptrs[] = {f->acc_image, f->nears, f->fars, f->rays_t, f->xyzs, f->dirs, f->deltas, f->sigmas, f->rgbs, f->alive_a, f->alive_b, f->list,
                     f->chunk_counts, f->pig_cnt, f->pig_bgn, f->pig_cursor, f->pig_idx, f->trips, f->dev, f->cut_bounds,
                     f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, f->side.nb, f->side.rec, f->march_counters, f->tail, f->tail_counts, f->stamps,
-                    f->list_seg, f->active_seg, f->seg_counters, f->cell_bits, f->fars_eff};
+                    f->list_seg, f->active_seg, f->seg_counters, f->cell_bits, f->fars_eff, f->groups, f->group_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int t = 0; t < PN_TIMED_TRIPS; t++)
         for (int e = 0; e < 3; e++) if (f->ev[t][e]) (void)hipEventDestroy(f->ev[t][e]);
@@ -1639,6 +1748,13 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
         f->cut_bounds_valid = 1;
     }
 
+    // ray groups (ray_batch > 0): per-batch trip schedules inside the same launches; not for the static render (its trip kernel keeps one schedule)
+    PN_REQUIRE(o->ray_batch == 0 || (o->ray_batch >= PN_MIN_RAY_BATCH && !is_static));
+    const uint32_t group_rays = o->ray_batch > 0 ? (uint32_t)o->ray_batch : 0u;
+    const uint32_t n_groups = group_rays ? pn_div_up(N, group_rays) : 0u;
+    PN_REQUIRE(n_groups <= f->max_groups);
+    PN_REQUIRE(!resume || group_rays == f->last_group_rays);
+
     const float* bbmin = f->dev->aabb;  // device addresses of struct members
     const float* bbmax = f->dev->aabb + 3;
     const int* res = f->dev->resolution;
@@ -1684,7 +1800,8 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                                                                  p_ori, F_IP, dF_IP, f->side.rec, f->cell_bits);
     }
     k_frame_rays<<<nblk, 256, 0, st>>>(rays_o, rays_d, f->dev, N, o->min_near, f->nears, f->fars, f->rays_t, f->trips, f->tail_counts, f->seg_counters,
-                                       PN_MAX_TRIPS + 2, f->alive_a, weights_sum, depth_0, f->acc_image);
+                                       PN_MAX_TRIPS + 2, f->alive_a, weights_sum, depth_0, f->acc_image, group_rays ? f->groups : nullptr, f->group_cnt, group_rays,
+                                       n_groups);
     PN_LAUNCH_CHECK();
     }
     pnm2::March2Tables tb{f->side.nb_bgn, f->side.nb, (const float4*)f->side.rec};
@@ -1717,7 +1834,8 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             MarchIO io{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + t, f->list, (t == 0) ? f->sigmas : nullptr,
                        f->tail, seg_tail, seg_back, seg_curs, (int)f->seg_cap, (int)march_tail_rounds(t), (t == 0) ? f->active_seg : nullptr, (t == 0) ? seg_active : nullptr,
                        (int)f->seg_cap, f->list_seg, seg_samp, (int)f->seg_cap, seg_emit, f->cell_bits, skip_bits_words,
-                       short_rays ? f->cell_bits + bit_words : nullptr, short_rays ? f->fars_eff : nullptr};
+                       short_rays ? f->cell_bits + bit_words : nullptr, short_rays ? f->fars_eff : nullptr,
+                       group_rays ? f->groups + (size_t)(t & 1) * f->max_groups : nullptr, group_rays};
             const bool timed = (f->march_counters_on & 2) && t < PN_TIMED_TRIPS;
             bool stamp = false;
             if (timed) {  // measurement mode: the two heavy launch groups of each trip are bracketed on the launch stream
@@ -1752,10 +1870,12 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                 else PN_HIP_CHECK(hipEventRecord(f->ev[t][2], st));
                 f->timed_trips = t + 1;
             }
+            PnGroup* g_cur = group_rays ? f->groups + (size_t)(t & 1) * f->max_groups : nullptr;
+            PnGroup* g_nxt = group_rays ? f->groups + (size_t)((t + 1) & 1) * f->max_groups : nullptr;
             k_composite<<<trip_grid, 256, 0, st>>>(0, 0, o->T_thresh, cur, f->rays_t, f->sigmas, f->rgbs, f->deltas, weights_sum, depth_0, f->acc_image,
-                                                   f->trips + t, f->chunk_counts);
+                                                   f->trips + t, f->chunk_counts, g_cur, group_rays, n_groups > 1 ? f->group_cnt : nullptr);
             k_compact<<<trip_grid, 256, 0, st>>>(cur, 0, f->chunk_counts, nxt, nullptr, f->trips + t, f->trips + t + 1, N, o->max_steps, is_static ? 0 : 1,
-                                                 is_static ? nullptr : f->seg_counters, f->tail_counts + t);
+                                                 is_static ? nullptr : f->seg_counters, f->tail_counts + t, g_cur, g_nxt, f->group_cnt, group_rays, n_groups);
         }
         PN_LAUNCH_CHECK();
         if (async_trips > 0) break;
@@ -1768,6 +1888,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     PN_LAUNCH_CHECK();
     f->last_trips = t;
     f->last_N = N;
+    f->last_group_rays = group_rays;
     // the trip records and the frame record always travel to pinned host memory (two small async copies): pn_render_status /
     // pn_render_continue read them once the caller knows the render has completed
     PN_HIP_CHECK(hipMemcpyAsync(f->trips_pinned, f->trips, sizeof(PnTrip) * (t + 1), hipMemcpyDeviceToHost, st));

@@ -298,154 +298,15 @@ class SimRenderHarness:
         return {"image": full[:, :3].reshape(1, H, W, 3), "depth": full[:, 3].reshape(1, H, W), "depth_0": full[:, 4].reshape(1, H, W)}
 
     # ------------------------------------------------------------------ a frame rendered in ray batches (BASELINE.json configs[4])
-    @torch.no_grad()
-    def capture_staged(self, batch=None, n_trips=None, W=None, H=None, copy_out=True, streams=3):
-        """The frame rendered in ray batches of `batch` (opt max_ray_batch = 4096, get_opts.py:24; renderer.py:562-576's staging loop).  Rays are
-        independent, so the batches reproduce the one-shot frame bit for bit (tests/test_gpu_parity.py, test_gpu_fullsize.py).  One batch = one
-        captured HIP-graph replay on a `batch`-ray workspace; a 4096-ray render is a chain of ~70 tiny dependent launches that leaves the chip
-        idle, so the batches of a frame go round-robin over `streams` streams, each with its own workspace.  The first batch a workspace sees in
-        a frame builds the spatial hash / candidate lists of the frame's IP state, its later batches keep them (pn_render_opts.reuse_tables —
-        the reference would rebuild get_pnts_in_grids for every call).  The substep runs on the simulator stream beside the batches; two
-        frame buffers alternate, so the D2H of frame f overlaps the batches of f + 1.  Batches that ran out of captured trips are counted on the
-        device (render_status 'unfinished') and reported when the frame is retired."""
-        o, m, dev = self.opt, self.model, self.device
-        W, H = W or o["W"], H or o["H"]
-        N = W * H
-        B = int(batch or o.get("max_ray_batch", 4096))
-        L = max(1, min(int(streams), (N + B - 1) // B))
-        if n_trips is None:
-            self.step(simulate=False, collect_stats=True, W=W, H=H)
-            n_trips = max(8, int(m.last_stats["trips"]) + 6)   # a 4096-ray batch thins out more slowly than the whole frame: generous margin
-        if not hasattr(self, "_sim_stream"):
-            self._sim_stream = torch.cuda.Stream(dev)
-        self.sim.force_stream = self._sim_stream
-        st = dict(B=B, N=N, W=W, H=H, L=L, trips=n_trips, stream=[torch.cuda.Stream(dev) for _ in range(L)], copy=torch.cuda.Stream(dev), k=0)
-        st["pose"] = torch.from_numpy(np.asarray(self.pose, np.float32)).unsqueeze(0).to(dev)
-        st["ip"] = tuple(torch.empty((self.sim.n_IP, c), dtype=torch.float32, device=dev) for c in (3, 9, 27))
-        st["ro"] = [torch.zeros(1, B, 3, device=dev) for _ in range(L)]
-        st["rd"] = [torch.zeros(1, B, 3, device=dev) for _ in range(L)]
-        st["frames"] = []
-        for _ in range(2):
-            pk = torch.empty(N * 5, dtype=torch.float32, device=dev)   # image | depth | depth_0: one D2H per frame
-            st["frames"].append(dict(packed=pk, image=pk[:3 * N].view(N, 3), depth=pk[3 * N:4 * N], depth_0=pk[4 * N:],
-                                     host=(torch.empty(N * 5, dtype=torch.float32).pin_memory() if copy_out else None), done=torch.cuda.Event(), used=False))
-        kw = dict(self.render_kwargs(), async_trips=n_trips)
-        m.p_def, m.IP_F, m.IP_dF = st["ip"]
-        keep = (self.sim.dof.clone(), self.sim.dof_vel.clone())
-        main = torch.cuda.current_stream(dev)
-        self.sim.get_IP_info(out=st["ip"])
-        rays = get_rays(st["pose"], self.intrinsics, H, W, -1)
-        for j in range(L):
-            st["ro"][j].copy_(rays["rays_o"][:, :B])
-            st["rd"][j].copy_(rays["rays_d"][:, :B])
-        torch.cuda.synchronize(dev)
-        st["graph"], st["out"] = {}, {}
-        for par in range(2):          # two sets of batch workspaces alternate from frame to frame: each keeps its frame's status words
-            for j in range(L):
-                slot = 900 + par * L + j
-                s = st["stream"][j]
-                s.wait_stream(main)
-                with torch.cuda.stream(s):
-                    with self._amp():
-                        m.render_deformed(st["ro"][j], st["rd"][j], bg_color=None, perturb=False, frame_slot=slot, **kw)
-                        m.render_deformed(st["ro"][j], st["rd"][j], bg_color=None, perturb=False, reuse_tables=True, frame_slot=slot, **kw)
-                torch.cuda.synchronize(dev)
-                for reuse in (False, True):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
-                        with self._amp():
-                            out = m.render_deformed(st["ro"][j], st["rd"][j], bg_color=None, perturb=False, reuse_tables=reuse, frame_slot=slot, **kw)
-                    st["graph"][slot, reuse] = g
-                    st["out"][slot, reuse] = out
-        torch.cuda.synchronize(dev)
-        self.sim.dof.copy_(keep[0])
-        self.sim.dof_vel.copy_(keep[1])
-        st["sim_done"] = torch.cuda.Event()
-        st["sim_done"].record(main)
-        self._staged = st
-        return self
-
-    @torch.no_grad()
-    def step_staged(self, pose=None):
-        """One sim+render step with the frame rendered in ray batches.  Enqueues this step and returns the PREVIOUS step's frame (complete,
-        checked; None on the first call); ``finish_staged()`` returns the last one."""
-        from ._lib import check, lib, stream_ptr
-        st, m, dev = self._staged, self.model, self.device
-        B, N, H, W, L = st["B"], st["N"], st["H"], st["W"], st["L"]
-        k = st["k"]
-        fr, par = st["frames"][k % 2], k % 2      # this buffer's previous frame (k - 2) was retired during the last call
-        s0 = st["stream"][0]
-        with torch.cuda.stream(s0):
-            if pose is not None:
-                st["pose"].copy_(torch.from_numpy(np.asarray(pose, np.float32)).view(1, 4, 4).to(dev))
-            s0.wait_event(st["sim_done"])                               # the previous substep must have finished before dof is read
-            for j in range(1, L):
-                s0.wait_stream(st["stream"][j])                         # ... and the previous frame's batches before the IP buffers are overwritten
-            self.sim.get_IP_info(out=st["ip"])
-            rays = get_rays(st["pose"], self.intrinsics, H, W, -1)
-            fr["rays"] = rays
-            ip_ready = torch.cuda.Event()
-            ip_ready.record(s0)
-        first = [True] * L
-        for b, head in enumerate(range(0, N, B)):
-            j = b % L
-            s, slot = st["stream"][j], 900 + par * L + j
-            n = min(B, N - head)
-            with torch.cuda.stream(s):
-                if first[j]:
-                    s.wait_event(ip_ready)
-                    check(lib().pn_frame_reset_unfinished(m._frames[slot][0], stream_ptr()), "reset_unfinished")
-                st["ro"][j][:, :n].copy_(rays["rays_o"][:, head:head + n])
-                st["rd"][j][:, :n].copy_(rays["rays_d"][:, head:head + n])
-                key = (slot, not first[j])                              # the workspace's first batch of the frame builds the tables, the others keep them
-                first[j] = False
-                st["graph"][key].replay()
-                out = st["out"][key]
-                fr["image"][head:head + n].copy_(out["image"].view(-1, 3)[:n])
-                fr["depth"][head:head + n].copy_(out["depth"].view(-1)[:n])
-                fr["depth_0"][head:head + n].copy_(out["depth_0"].view(-1)[:n])
-        self._sim_stream.wait_event(ip_ready)                           # the substep only feeds the NEXT frame: it runs beside the batches
-        with torch.cuda.stream(self._sim_stream):
-            self.sim.stepforward()
-            st["sim_done"].record(self._sim_stream)
-        tail = self._sim_stream if fr["host"] is not None else s0      # the D2H rides on the simulator stream (a 5th busy hardware queue would time-slice)
-        for j in range(L):
-            if st["stream"][j] is not tail:
-                tail.wait_stream(st["stream"][j])
-        with torch.cuda.stream(tail):
-            if fr["host"] is not None:
-                fr["host"].copy_(fr["packed"], non_blocking=True)
-            fr["done"] = torch.cuda.Event()
-            fr["done"].record(tail)
-        fr["used"], fr["par"] = True, par
-        st["k"] += 1
-        self.frame += 1
-        return self._retire_staged(st["frames"][(k + 1) % 2])           # frame k - 1: the GPU already has frame k queued behind it
-
-    def _retire_staged(self, fr):
-        if not fr["used"]:
-            return None
-        st = self._staged
-        fr["done"].synchronize()
-        # one status read per workspace and frame: batches the captured trips did not finish were counted on the device
-        unfinished = sum(self.model.render_status(synchronize=False, slot=900 + fr["par"] * st["L"] + j)["unfinished"] for j in range(st["L"]))
-        if unfinished > 0:
-            raise RuntimeError(f"staged frame: {unfinished} rays were still alive after the {st['trips']} captured trips of their batch; "
-                               "capture_staged(n_trips=...) with more trips")
-        fr["used"] = False
-        H, W, N = st["H"], st["W"], st["N"]
-        dev = {name: fr[name] for name in ("image", "depth", "depth_0")}
-        if fr["host"] is None:
-            return {"device": dev}
-        hb = fr["host"].numpy()
-        return {"image": hb[:3 * N].reshape(H, W, 3), "depth": hb[3 * N:4 * N].reshape(H, W), "depth_0": hb[4 * N:].reshape(H, W), "device": dev}
-
-    def finish_staged(self):
-        """Waits for and returns the last enqueued staged frame."""
-        st = self._staged
-        out = self._retire_staged(st["frames"][(st["k"] + 1) % 2])
-        torch.cuda.synchronize(self.device)
-        return out
+    def capture_staged(self, batch=None, **kw):
+        """The frame rendered in ray batches of `batch` rays (opt max_ray_batch = 4096, get_opts.py:24; renderer.py:562-576's staging loop):
+        every batch keeps its own trip schedule (n_step = max(min(N_b // n_alive_b, 8), 1), its own max_steps count), exactly as if the
+        batches were rendered one after the other — but all batches advance inside the same launches (pn_render_opts.ray_batch: rays are
+        independent, the alive list stays sorted by ray id, a batch is a contiguous run of it).  So the staged frame IS a pipelined frame:
+        same graphs, same lanes, same D2H; `kw` goes to capture_pipelined, frames come back through step_pipelined() / drain_pipeline().
+        (Rounds 1-2 replayed one captured launch chain per batch: ~10 000 launches per 800x800 frame, 20x slower than the frame in one piece.)"""
+        self.opt["ray_batch"] = int(batch or self.opt.get("max_ray_batch", 4096))
+        return self.capture_pipelined(**kw)
 
     def to_host(self, out):
         """The reference's device->host boundary (trainer.py:589-592)."""

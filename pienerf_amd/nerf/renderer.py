@@ -108,6 +108,7 @@ class NeRFRenderer(nn.Module):
         o.bg_color = float(bg_scalar)
         o.fp16 = int(self._autocast_half())  # Trainer.test_gui renders under autocast(enabled=self.fp16) (trainer.py:561)
         o.reuse_tables = int(bool(kwargs.get("reuse_tables")))  # extension: later ray batches of the same frame keep the first batch's tables
+        o.ray_batch = int(kwargs.get("ray_batch") or 0)  # extension: per-batch trip schedules inside one set of launches (pn_render_opts.ray_batch)
         return o
 
     def rund_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-2, **kwargs):

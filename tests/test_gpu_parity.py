@@ -495,31 +495,90 @@ def test_force_change_between_overlapped_steps_matches_oracle(small_cloud, small
     assert rel_err(p.sim.dof.cpu().numpy().reshape(-1, 3) - ref.dof_rest, ref.dof - ref.dof_rest) < 1e-6
 
 
+def _batches_one_after_the_other(h, out, B, **extra):
+    """The reference semantics of max_ray_batch (renderer.py:562-576): one render call per batch of B rays.  Returns image, depth_0, the summed
+    sample count and the largest trip count."""
+    m = h.model
+    o, d = out["rays_o"][0], out["rays_d"][0]
+    N = o.shape[0]
+    img, dep = torch.empty(N, 3, device=DEV), torch.empty(N, device=DEV)
+    total, trips = 0, 0
+    kw = dict(h.render_kwargs(), **extra)
+    kw.pop("ray_batch", None)
+    with h._amp():
+        for head in range(0, N, B):
+            r = m.render_deformed(o[None, head:head + B], d[None, head:head + B], collect_stats=True, frame_slot=7, **kw)
+            img[head:head + B], dep[head:head + B] = r["image"][0], r["depth_0"][0]
+            total += m.last_stats["samples"]
+            trips = max(trips, m.last_stats["trips"])
+    return img, dep, total, trips
+
+
+@pytest.mark.parametrize("fp16", [False, True])
+def test_ray_batches_keep_their_own_trip_schedules(small_cloud, small_opt, ckpt, fp16):
+    """pn_render_opts.ray_batch (BASELINE configs[4], max_ray_batch): all batches advance inside the same launches, each with its own schedule
+    n_step = max(min(N_b // n_alive_b, 8), 1) and its own max_steps count.  Against the batches rendered one after the other (one render call
+    per batch): the same image bit for bit, the same number of marched samples (it depends on every batch's n_step sequence), the same number
+    of trips as the slowest batch.  (A batch's own `step >= max_steps` exit is kept in the group records as well, but dt_min = 2 sqrt(3) / max_steps
+    makes it unreachable inside the box, as in the reference.)"""
+    from pienerf_amd.harness import SimRenderHarness
+    opt = dict(small_opt, W=60, H=60, fp16=fp16, max_iter_num=5)        # 3600 rays = 3 batches of 1024 + one of 528
+    whole = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV, overlap_sim=False)
+    grouped = SimRenderHarness(dict(opt, ray_batch=1024), cloud=small_cloud, ckpt=ckpt, device=DEV, overlap_sim=False)
+    for h in (whole, grouped):
+        h.sim.update_force(h.sim.n_IP // 2, np.array([300.0, 100.0, -200.0]))
+    for f in range(3):
+        pose = scene.orbit_pose(opt["radius"], 9.0 * f, 2.0 * f)
+        a = whole.step(pose=pose, collect_stats=True)
+        st_w = dict(whole.model.last_stats)
+        b = grouped.step(pose=pose, collect_stats=True)
+        st_g = dict(grouped.model.last_stats)
+        img, dep, total, trips = _batches_one_after_the_other(whole, a, 1024)
+        assert st_g["err"] == 0 and st_g["alive_at_exit"] == 0
+        assert st_g["samples"] == total and st_g["trips"] == trips, (st_g, total, trips, st_w)
+        assert torch.equal(b["image"].reshape(-1, 3), img) and torch.equal(b["depth_0"].reshape(-1), dep)
+        # compositing does not depend on the schedule at all, the number of marched samples does
+        assert torch.equal(b["image"], a["image"]) and torch.equal(b["depth_0"], a["depth_0"])
+        assert st_g["samples"] != st_w["samples"]
+    # one batch covering everything is the frame in one piece; a batch size that does not divide the ray count; the smallest batch
+    one = SimRenderHarness(dict(opt, ray_batch=4096), cloud=small_cloud, ckpt=ckpt, device=DEV, overlap_sim=False)
+    odd = SimRenderHarness(dict(opt, ray_batch=1000), cloud=small_cloud, ckpt=ckpt, device=DEV, overlap_sim=False)
+    tiny = SimRenderHarness(dict(opt, ray_batch=64), cloud=small_cloud, ckpt=ckpt, device=DEV, overlap_sim=False)
+    ref = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV, overlap_sim=False)
+    a = ref.step(collect_stats=True)
+    st_a = dict(ref.model.last_stats)
+    b = one.step(collect_stats=True)
+    assert torch.equal(a["image"], b["image"]) and one.model.last_stats["samples"] == st_a["samples"] and one.model.last_stats["trips"] == st_a["trips"]
+    for h, B in ((odd, 1000), (tiny, 64)):
+        c = h.step(collect_stats=True)
+        img, dep, total, trips = _batches_one_after_the_other(ref, a, B)
+        assert h.model.last_stats["samples"] == total and h.model.last_stats["trips"] == trips
+        assert torch.equal(c["image"].reshape(-1, 3), img)
+    with pytest.raises(RuntimeError):
+        SimRenderHarness(dict(opt, ray_batch=32), cloud=small_cloud, ckpt=ckpt, device=DEV, overlap_sim=False).step()
+
+
 @pytest.mark.parametrize("fp16", [False, True])
 def test_staged_ray_batches_equal_one_shot_frames(small_cloud, small_opt, ckpt, fp16):
-    """harness.capture_staged / step_staged (BASELINE configs[4]: the frame in ray batches, one captured graph replay per batch, tables built by
-    the first batch and kept by the others): rays are independent, so the frames equal the one-shot eager frames bit for bit — also the
-    last, partial batch — and a trip count that is too small for some batch is reported, not silently accepted."""
+    """harness.capture_staged (BASELINE configs[4]: the frame in ray batches — a ray-group dimension of the pipelined frame's launches): rays are
+    independent, so the frames equal the one-shot eager frames bit for bit — also the last, partial batch — and a trip count that is too small
+    for the slowest batch is made up for by continuing the frame when it is retired."""
     from pienerf_amd.harness import SimRenderHarness
     opt = dict(small_opt, W=60, H=60, fp16=fp16, max_iter_num=5)        # 3600 rays = 3 batches of 1024 + one of 528
     eager = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV)
-    st = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture_staged(batch=1024)
     poses = [scene.orbit_pose(opt["radius"], 9.0 * f, 2.0 * f) for f in range(5)]
     want = [eager.to_host(eager.step(pose=p)) for p in poses]
     eager.synchronize()
-    got = []
-    for p in poses:
-        r = st.step_staged(pose=p)
-        if r is not None:
-            got.append({k: r[k].copy() for k in ("image", "depth", "depth_0")})
-    r = st.finish_staged()
-    got.append({k: r[k].copy() for k in ("image", "depth", "depth_0")})
-    assert len(got) == 5
-    for f in range(5):
-        assert np.array_equal(got[f]["image"], want[f]["image"]) and np.array_equal(got[f]["depth_0"], want[f]["depth_0"]), f
-        assert np.array_equal(got[f]["depth"], want[f]["depth"], equal_nan=True), f
-    assert rel_err((st.sim.dof - st.sim.dof_rest).cpu().numpy(), (eager.sim.dof - eager.sim.dof_rest).cpu().numpy()) < 1e-7
-    short = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture_staged(batch=1024, n_trips=2)
-    short.step_staged()
-    with pytest.raises(RuntimeError, match="still alive"):
-        short.finish_staged()
+    for n_trips in (None, 2):
+        st = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture_staged(batch=1024, lanes=2, n_trips=n_trips)
+        assert st.opt["ray_batch"] == 1024
+        got = []
+        for p in poses:
+            got += [(i, {k: r[k].copy() for k in ("image", "depth", "depth_0")}) for i, r in st.step_pipelined(pose=p)]
+        got += [(i, {k: r[k].copy() for k in ("image", "depth", "depth_0")}) for i, r in st.drain_pipeline()]
+        assert [i for i, _ in got] == list(range(5))
+        for f in range(5):
+            assert np.array_equal(got[f][1]["image"], want[f]["image"]) and np.array_equal(got[f][1]["depth_0"], want[f]["depth_0"]), f
+            assert np.array_equal(got[f][1]["depth"], want[f]["depth"], equal_nan=True), f
+        assert rel_err((st.sim.dof - st.sim.dof_rest).cpu().numpy(), (eager.sim.dof - eager.sim.dof_rest).cpu().numpy()) < 1e-7
+        assert (st._pipe_backend.continued > 0) == (n_trips == 2)
