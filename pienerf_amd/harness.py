@@ -11,6 +11,9 @@ One ``step()`` = what ``NeRFSimGUI.test_step`` -> ``Trainer.test_gui`` -> ``Trai
 
 Start-up mirrors main_gui.py:26-56.
 """
+import contextlib
+import gc
+
 import numpy as np
 import torch
 
@@ -18,6 +21,21 @@ from . import scene
 from .nerf.network import NeRFNetwork
 from .nerf.utils import get_rays
 from .simulator.solver import Simulator
+
+
+@contextlib.contextmanager
+def _capture(graph, **kw):
+    """torch.cuda.graph with the cyclic garbage collector held off: a collection that runs DURING a stream capture may free another harness
+    (workspaces, streams, graphs of an earlier capture) — hipFree / hipGraphDestroy inside a capture abort the process."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph, capture_error_mode="thread_local", **kw):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class SimRenderHarness:
@@ -144,7 +162,7 @@ class SimRenderHarness:
         torch.cuda.current_stream(self.device).wait_stream(warm)
         torch.cuda.synchronize(self.device)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
+        with _capture(self._graph):
             self._graph_out = self._step_body(n_trips, W, H)
         self.sim.dof.copy_(keep[0])       # warm-up advanced the simulator; capture itself executes nothing
         self.sim.dof_vel.copy_(keep[1])
@@ -381,7 +399,7 @@ class _HipBackend:
         # capture_error_mode="thread_local": with a process group alive, RCCL's watchdog thread queries events while we capture;
         # in the default "global" mode any HIP call from another thread invalidates the capture
         self.sim_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.sim_graph, stream=self._streams["sim"], capture_error_mode="thread_local"):
+        with _capture(self.sim_graph, stream=self._streams["sim"]):
             if not probe_no_substep:
                 sim.stepforward()
             else:
@@ -397,7 +415,7 @@ class _HipBackend:
             pk = torch.empty(N * 5, dtype=torch.float32, device=dev)
             ob = {"image": pk[:3 * N].view(N, 3), "depth": pk[3 * N:4 * N], "depth_0": pk[4 * N:], "weights_sum": torch.empty(N, dtype=torch.float32, device=dev)}
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+            with _capture(g, stream=s):
                 rays = get_rays(self.pose_dev[ws], h.intrinsics, H, W, -1)
                 with h._amp():
                     out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, out_buffers=ob, **dict(kw, frame_slot=ws))

@@ -5,18 +5,22 @@ import torch
 
 from pienerf_amd._lib import check, lib, ptr, require_gpu, stream_ptr
 
-_host_offsets = {}
+import weakref
+
+_host_offsets = {}  # id(tensor) -> (weak reference, version, host copy)
 
 
 def _offsets_host(offsets):
-    """The reference hands `offsets` over as a device tensor; the launcher derives the level geometry on the host, so a host copy is kept per tensor version."""
-    key = (offsets.data_ptr(), offsets._version, str(offsets.device))
+    """The reference hands `offsets` over as a device tensor; the launcher derives the level geometry on the host, so a host copy is kept per tensor
+    OBJECT and version (a key made of the data pointer would be reused by the caching allocator for another table: stale geometry, out-of-range
+    reads)."""
+    key = id(offsets)
     hit = _host_offsets.get(key)
-    if hit is None:
-        if len(_host_offsets) > 64:
-            _host_offsets.clear()
-        hit = _host_offsets[key] = offsets.detach().to("cpu", torch.int32).contiguous()
-    return hit
+    if hit is not None and hit[0]() is offsets and hit[1] == offsets._version:
+        return hit[2]
+    host = offsets.detach().to("cpu", torch.int32).contiguous()
+    _host_offsets[key] = (weakref.ref(offsets, lambda _, k=key: _host_offsets.pop(k, None)), offsets._version, host)
+    return host
 
 
 def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp):
