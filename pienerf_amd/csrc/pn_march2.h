@@ -2,7 +2,7 @@
 // warp through one record and the one-lane-per-ray skip over IP-free cells.  The march itself is in pn_march3.h.
 //
 // Per-frame side tables (built by k_frame_lists / k_nb_* + k_pack_ip in pn_render_ops.hip):
-//   nb_bgn[n_grid+1], nb[...]  per cell: the candidates of its 27-cell neighbourhood as float4(p_def.xyz, bitcast id), in the
+//   nb_rng[n_grid], nb[...]    per cell (begin, end) of: the candidates of its 27-cell neighbourhood as float4(p_def.xyz, bitcast id), in the
 //                              reference's visiting order (own cell first, then NBR26; own-cell order = ascending id), so
 //                              "position in the list" is "visiting order" and ties resolve exactly as the sequential scan does
 //   rec[n_vtx][PN_REC_FLOATS]  packed IP record: p_ori(3) p_def(3) F^-1(9) pad(1) | F(9) dF(27) — 208 B, float4-aligned.  The head (first 64 B) is
@@ -49,7 +49,7 @@ __device__ __forceinline__ float pack_ip_float(int j, int ip, const float* __res
 }
 
 struct March2Tables {
-    const int* nb_bgn;    // [n_grid + 1]
+    const int2* nb_rng;   // [n_grid] candidates of the cell's 27-neighbourhood: nb[x .. y)
     const float4* nb;     // candidate entries
     const float4* rec;    // [n_vtx * PN_REC_VEC4]
 };

@@ -293,7 +293,7 @@ __device__ inline float skip_empty_cells(const MarchParams& a, const March2Table
             if (g0 < 0 || g1 < 0 || g2 < 0 || g0 >= r0 || g1 >= r1 || g2 >= r2) break;  // the windowed march raises the error flag
             const int gid = g2 * r1 * r0 + g1 * r0 + g0;
             if (gid != cell_id) {
-                const bool has = cell_bits ? ((cell_bits[gid >> 5] >> (gid & 31)) & 1u) != 0 : tb.nb_bgn[gid] != tb.nb_bgn[gid + 1];
+                const bool has = cell_bits ? ((cell_bits[gid >> 5] >> (gid & 31)) & 1u) != 0 : tb.nb_rng[gid].x != tb.nb_rng[gid].y;
                 if (has) break;  // candidates: hand over
                 cell_id = gid;
             }
@@ -416,8 +416,9 @@ __device__ __forceinline__ void point_cell(const MarchParams& a, const March2Tab
         p.oob = (g0 < 0 || g1 < 0 || g2 < 0 || g0 >= c.r0 || g1 >= c.r1 || g2 >= c.r2);
         if (!p.oob) {
             p.gid = g2 * c.r1 * c.r0 + g1 * c.r0 + g0;
-            p.b = tb.nb_bgn[p.gid];
-            p.e = tb.nb_bgn[p.gid + 1];
+            const int2 rng = tb.nb_rng[p.gid];
+            p.b = rng.x;
+            p.e = rng.y;
         }
     }
 }

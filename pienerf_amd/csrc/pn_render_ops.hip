@@ -57,7 +57,8 @@ struct PnFrameDev {
     int unfinished;     // rays left alive by fixed-trip renders since the last reset, summed (staged batches are checked once per frame)
     int trips_run;      // loop trips the last render (or continuation) on this workspace has enqueued: written by its epilogue, so that it is
                         // also right after a HIP-graph REPLAY, which the host-side bookkeeping never sees
-    int pad[3];
+    int nb_alloc;       // candidate-list entries handed out so far (k_frame_prologue bumps it once per 32 cells; cleared by k_frame_tables)
+    int pad[2];
 };
 
 // ------------------------------------------------------------------------------------------------ near/far
@@ -401,15 +402,16 @@ __global__ void __launch_bounds__(256) k_nb_count(int n_grid_max, const int* __r
 
 __global__ void __launch_bounds__(256) k_nb_fill(int n_grid_max, const int* __restrict__ n_grid_dev, const int* __restrict__ res,
                                                  const int* __restrict__ pig_cnt, const int* __restrict__ pig_bgn, const int* __restrict__ pig_idx,
-                                                 const float* __restrict__ p_def, int swap, const int* __restrict__ nb_cnt, int* __restrict__ nb_bgn,
-                                                 float4* __restrict__ nb, int nb_capacity, int* err_flag) {
+                                                 const float* __restrict__ p_def, int swap, const int* __restrict__ nb_cnt, const int* __restrict__ nb_bgn,
+                                                 float4* __restrict__ nb, int nb_capacity, int* err_flag, int2* __restrict__ nb_rng) {
     const int n_grid = n_grid_dev ? min(*n_grid_dev, n_grid_max) : n_grid_max;
     const int r0 = res[0], r1 = res[1], r2 = res[2];
     for (int c = threadIdx.x + blockIdx.x * blockDim.x; c < n_grid; c += gridDim.x * blockDim.x) {
         int w = nb_bgn[c];
-        if (c == n_grid - 1) nb_bgn[n_grid] = w + nb_cnt[c];  // closing offset
+        const bool fits = w + nb_cnt[c] <= nb_capacity;
+        nb_rng[c] = fits ? make_int2(w, w + nb_cnt[c]) : make_int2(0, 0);
         if (nb_cnt[c] == 0) continue;
-        if (w + nb_cnt[c] > nb_capacity) { if (err_flag) atomicOr(err_flag, 8); continue; }
+        if (!fits) { if (err_flag) atomicOr(err_flag, 8); continue; }
         int g0, g1, g2;
         nb_cell_coords(c, r0, r1, g0, g1, g2);
         for (int k = -1; k < 26; k++) {
@@ -434,7 +436,8 @@ __global__ void __launch_bounds__(256) k_pack_ip(int n_vtx, const float* __restr
 }
 
 struct MarchSide {  // device buffers of the side tables
-    int *nb_cnt, *nb_bgn, *nb_cursor;  // [n_grid_max + 1]
+    int *nb_cnt, *nb_bgn, *nb_cursor;  // [n_grid_max + 1] op-level build only (count -> scan -> fill); the frame driver allocates list space by bumping a counter
+    int2* nb_rng;                       // [n_grid_max]
     float4* nb;                         // [nb_capacity]
     float* rec;                         // [n_vtx * 44]
     int nb_capacity;
@@ -447,7 +450,7 @@ static int march_side_build(const MarchSide& s, int n_vtx, int n_grid_max, const
     const int gz = (int)pn_div_up(n_grid_max, 256) < 1024 ? (int)pn_div_up(n_grid_max, 256) : 1024;
     k_nb_count<<<gz, 256, 0, st>>>(n_grid_max, n_grid_dev, res, pig_cnt, swap, s.nb_cnt);
     launch_cell_scan(n_grid_max, n_grid_dev, s.nb_cnt, s.nb_bgn, s.nb_cursor, st);
-    k_nb_fill<<<gz, 256, 0, st>>>(n_grid_max, n_grid_dev, res, pig_cnt, pig_bgn, pig_idx, p_def, swap, s.nb_cnt, s.nb_bgn, s.nb, s.nb_capacity, err_flag);
+    k_nb_fill<<<gz, 256, 0, st>>>(n_grid_max, n_grid_dev, res, pig_cnt, pig_bgn, pig_idx, p_def, swap, s.nb_cnt, s.nb_bgn, s.nb, s.nb_capacity, err_flag, s.nb_rng);
     k_pack_ip<<<pn_div_up((uint64_t)n_vtx * PN_REC_FLOATS, 256), 256, 0, st>>>(n_vtx, p_ori, p_def, F_IP, dF_IP, s.rec);
     PN_LAUNCH_CHECK();
     return PN_OK;
@@ -807,7 +810,7 @@ extern "C" int pn_march_rays_quadratic_bending(const int* pig_cnt, const int* pi
     MarchSide s;
     s.nb_capacity = 27 * n_vtx;
     char* pool = nullptr;
-    const size_t ints = ((size_t)n_grid + 1) * 3 * sizeof(int), nbb = (size_t)s.nb_capacity * sizeof(float4), recb = (size_t)n_vtx * PN_REC_FLOATS * sizeof(float);
+    const size_t ints = ((size_t)n_grid + 1) * 5 * sizeof(int), nbb = (size_t)s.nb_capacity * sizeof(float4), recb = (size_t)n_vtx * PN_REC_FLOATS * sizeof(float);
     const size_t off_nb = (ints + 255) & ~(size_t)255, off_rec = (off_nb + nbb + 255) & ~(size_t)255;
     const size_t off_res = (off_rec + recb + 255) & ~(size_t)255;
     const uint32_t tail_cap = seg_cap_for(n_alive);
@@ -815,14 +818,14 @@ extern "C" int pn_march_rays_quadratic_bending(const int* pig_cnt, const int* pi
     const size_t off_tail = (off_res + (size_t)n_alive * sizeof(float) + 255) & ~(size_t)255;  // [segment counters | tail entries]
     PN_HIP_CHECK(hipMallocAsync((void**)&pool, off_tail + tail_ctr + (size_t)PN_SEGS * tail_cap * sizeof(TailEntry), st));
     PN_HIP_CHECK(hipMemsetAsync(pool + off_tail, 0, tail_ctr, st));
-    s.nb_cnt = (int*)pool; s.nb_bgn = s.nb_cnt + n_grid + 1; s.nb_cursor = s.nb_bgn + n_grid + 1;
+    s.nb_cnt = (int*)pool; s.nb_bgn = s.nb_cnt + n_grid + 1; s.nb_cursor = s.nb_bgn + n_grid + 1; s.nb_rng = (int2*)(s.nb_cursor + n_grid + 1);
     s.nb = (float4*)(pool + off_nb); s.rec = (float*)(pool + off_rec);
     int rc = march_side_build(s, n_vtx, n_grid, nullptr, resolution, pig_cnt, pig_bgn, pig_idx, p_def, p_ori, F_IP, dF_IP, num_seek_IP, err_flag, st);
     if (rc == PN_OK) {
         pnm::MarchParams a = make_march_params(pig_cnt, pig_bgn, pig_idx, n_vtx, n_grid, p_def, p_ori, F_IP, dF_IP, max_iter_num, bbmin, bbmax, hgs,
                                                resolution, num_seek_IP, IP_dx, cut, cut_bounds, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps,
                                                C, H, grid, fars, err_flag);
-        pnm2::March2Tables tb{s.nb_bgn, s.nb, (const float4*)s.rec};
+        pnm2::March2Tables tb{s.nb_rng, s.nb, (const float4*)s.rec};
         MarchIO io{n_alive, n_step, rays_alive, xyzs, dirs, deltas, noises, nullptr, nullptr, (float*)(pool + off_res),
                    (TailEntry*)(pool + off_tail + tail_ctr), (int*)(pool + off_tail), (int*)(pool + off_tail) + PN_SEGS * PN_SEG_STRIDE,
                    (int*)(pool + off_tail) + 2 * PN_SEGS * PN_SEG_STRIDE, (int)tail_cap,
@@ -839,7 +842,7 @@ extern "C" int pn_march_rays_quadratic_bending(const int* pig_cnt, const int* pi
 
 // ------------------------------------------------------------------------------------------------ composite
 // kernel_composite_rays, raymarching.cu:827-923.  __expf -> the gfx950 fast exponential (v_exp_f32 on x*log2e).
-__device__ __forceinline__ bool composite_one(uint32_t n, int index, uint32_t slot0, uint32_t n_step, float T_thresh, int* rays_alive, float* rays_t,
+__device__ __forceinline__ bool composite_one(int index, uint32_t slot0, uint32_t n_step, float T_thresh, float* rays_t,
                                               const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ deltas,
                                               float* weights_sum, float* depth, float* image) {
     sigmas += (size_t)slot0;
@@ -864,7 +867,7 @@ __device__ __forceinline__ bool composite_one(uint32_t n, int index, uint32_t sl
         sigmas++; rgbs += 3; deltas += 2; step++;
     }
     const bool alive = !(step < n_step);
-    if (!alive) rays_alive[n] = -1; else rays_t[index] = t;
+    if (alive) rays_t[index] = t;  // (the caller marks a dead ray in rays_alive)
     weights_sum[index] = ws;
     depth[index] = d;
     image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
@@ -891,8 +894,9 @@ __global__ void __launch_bounds__(256) k_composite(uint32_t n_alive_arg, uint32_
             uint32_t n_step = n_step_trip, slot0;
             ray_slots(groups, group_rays, index, n, n_step, slot0);
             if (groups) grp = (int)((uint32_t)index / group_rays);
-            if (n_step == 0) rays_alive[n] = -1;  // its group has reached max_steps: the batch's loop is over (renderer.py:836), the ray is dropped
-            else alive = composite_one(n, index, slot0, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+            // n_step == 0: its group has reached max_steps: the batch's loop is over (renderer.py:836), the ray is dropped
+            if (n_step != 0) alive = composite_one(index, slot0, n_step, T_thresh, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+            if (!alive) rays_alive[n] = -1;
         }
         if (group_cnt) {
             const int lane = threadIdx.x & 63;
@@ -1181,6 +1185,86 @@ __global__ void __launch_bounds__(256) k_list_pack(PnTrip* trip, const int* __re
     if (s == 0 && threadIdx.x == 0) trip->n_samples = total_s;
 }
 
+// End of a trip of the frame driver, executed by ONE wave once every ray of the trip has been composited and `sum` of them survive: folds the
+// march's segment counters into the records and clears them, and writes the next trip's record (renderer.py:839-846,891) — with ray groups
+// (g_next != nullptr, see PnGroup) also the next trip's group records from this trip's and the per-group survivor counts of the composite:
+// N_b // n_alive_b per group, exclusive sums for the first alive position and the first sample slot.
+__device__ __forceinline__ void trip_epilogue(int lane, int sum, PnTrip* trip, PnTrip* next, uint32_t N_rays, uint32_t max_steps, int dense_trips,
+                                              int* seg_counters, int* tail_diag, const PnGroup* __restrict__ g_cur, PnGroup* __restrict__ g_next,
+                                              int* group_cnt, uint32_t group_rays, uint32_t n_groups) {
+    if (seg_counters) {
+        // this trip's march is over — fold its segment counters (seg_counters = [tail | sample | emitted | cursor | tail back] x PN_SEGS) into
+        // the records and clear them for the next trip
+        int* tail_c = seg_counters + lane * PN_SEG_STRIDE;
+        int* samp_c = tail_c + PN_SEGS * PN_SEG_STRIDE;
+        int* emit_c = samp_c + PN_SEGS * PN_SEG_STRIDE;
+        int* curs_c = emit_c + PN_SEGS * PN_SEG_STRIDE;
+        int* back_c = curs_c + PN_SEGS * PN_SEG_STRIDE;
+        int tl = *tail_c + *back_c, em = *emit_c;
+        *tail_c = 0; *samp_c = 0; *emit_c = 0; *curs_c = 0; *back_c = 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { tl += __shfl_xor(tl, o); em += __shfl_xor(em, o); }
+        if (lane == 0) { if (tail_diag) *tail_diag = tl; if (trip) trip->n_emitted = em; }
+    }
+    if (!next) return;
+    if (g_next) {
+        // 64 groups per round, running sums carried in (uniform) registers
+        int alive_run = 0, slot_run = 0, live = 0, step0 = 1;
+        for (uint32_t b0 = 0; b0 < n_groups; b0 += 64) {
+            const uint32_t b = b0 + (uint32_t)lane;
+            int cnt = 0, nstep = 0, stepb = 0;
+            if (b < n_groups) {
+                const PnGroup g = g_cur[b];
+                cnt = (n_groups == 1) ? sum : group_cnt[b];
+                if (n_groups > 1) group_cnt[b] = 0;
+                stepb = g.step_base + g.n_step;
+                const uint32_t rays_b = min(group_rays, N_rays - b * group_rays);  // N_b
+                const bool over = cnt <= 0 || (uint32_t)stepb >= max_steps || g.n_step == 0;
+                nstep = over ? 0 : max(min((int)(rays_b / (uint32_t)cnt), 8), 1);
+            }
+            const int slots = cnt * nstep;
+            int a_inc = cnt, s_inc = slots;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int ua = __shfl_up(a_inc, o), us = __shfl_up(s_inc, o);
+                if (lane >= o) { a_inc += ua; s_inc += us; }
+            }
+            if (b < n_groups) g_next[b] = PnGroup{alive_run + a_inc - cnt, nstep, slot_run + s_inc - slots, stepb};
+            if (b == 0) step0 = nstep;
+            alive_run += __shfl(a_inc, 63);
+            slot_run += __shfl(s_inc, 63);
+            int lv = nstep > 0 ? cnt : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) lv += __shfl_xor(lv, o);
+            live += lv;
+        }
+        step0 = __shfl(step0, 0);
+        if (lane == 0) {
+            // rays of groups that ran into max_steps stay listed until the next composite retires them; the frame is over when no group marches on
+            const bool done = live <= 0;
+            next->n_alive = done ? 0 : sum;
+            next->n_step = done ? 1 : max(step0, 1);  // informational with groups (every kernel reads the group records)
+            next->step_base = trip->step_base + trip->n_step;
+            next->dense = (dense_trips && !done) ? 1 : 0;
+            next->n_samples = (dense_trips && !done) ? slot_run : 0;
+            next->n_emitted = 0;
+        }
+    } else if (lane == 0) {
+        const int step = trip->step_base + trip->n_step;
+        const bool done = (sum <= 0) || ((uint32_t)step >= max_steps);
+        next->n_alive = done ? 0 : sum;
+        next->n_step = done ? 1 : max(min((int)(N_rays / (uint32_t)sum), 8), 1);
+        next->step_base = step;
+        // dense trip (see trip_is_dense): the list is the identity over all slots; n_emitted = -1 marks a list trip
+        // every trip after the first is dense: its rays are the ones that found a sample before (n_step == 1 then means more than half of
+        // all rays are still alive — they will mostly fill their single slot too)
+        const bool dense = dense_trips && !done;
+        next->dense = dense ? 1 : 0;
+        next->n_samples = dense ? sum * next->n_step : 0;
+        next->n_emitted = 0;
+    }
+}
+
 // Block c moves the survivors of chunk c to out[prefix(c) ...], keeping order (== rays_alive[rays_alive >= 0]).
 // Block 0 also publishes the total and, in frame-driver mode, the next trip's record (renderer.py:839-846,891).
 // Ray groups (g_next != nullptr, see PnGroup): chunk 0's first wave also writes the next trip's group records from this trip's records and the
@@ -1207,78 +1291,9 @@ __global__ void __launch_bounds__(256) k_compact(const int* __restrict__ in, uin
         __syncthreads();
         const int sum = red[0] + red[1] + red[2] + red[3];
         const int offset = (c == 0) ? 0 : sum;
-        if (c == 0 && seg_counters && wid == 0) {
-            // frame driver: this trip's march is over — fold its segment counters (seg_counters = [tail | sample | emitted | cursor | tail back] x PN_SEGS) into
-            // the records and clear them for the next trip
-            int* tail_c = seg_counters + lane * PN_SEG_STRIDE;
-            int* samp_c = tail_c + PN_SEGS * PN_SEG_STRIDE;
-            int* emit_c = samp_c + PN_SEGS * PN_SEG_STRIDE;
-            int* curs_c = emit_c + PN_SEGS * PN_SEG_STRIDE;
-            int* back_c = curs_c + PN_SEGS * PN_SEG_STRIDE;
-            int tl = *tail_c + *back_c, em = *emit_c;
-            *tail_c = 0; *samp_c = 0; *emit_c = 0; *curs_c = 0; *back_c = 0;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { tl += __shfl_xor(tl, o); em += __shfl_xor(em, o); }
-            if (lane == 0) { if (tail_diag) *tail_diag = tl; if (trip) trip->n_emitted = em; }
-        }
-        if (c == 0 && g_next && wid == 0) {
-            // one wave, 64 groups per round, running sums carried in (uniform) registers
-            int alive_run = 0, slot_run = 0, live = 0, step0 = 1;
-            for (uint32_t b0 = 0; b0 < n_groups; b0 += 64) {
-                const uint32_t b = b0 + (uint32_t)lane;
-                int cnt = 0, nstep = 0, stepb = 0;
-                if (b < n_groups) {
-                    const PnGroup g = g_cur[b];
-                    cnt = (n_groups == 1) ? sum : group_cnt[b];
-                    if (n_groups > 1) group_cnt[b] = 0;
-                    stepb = g.step_base + g.n_step;
-                    const uint32_t rays_b = min(group_rays, N_rays - b * group_rays);  // N_b
-                    const bool over = cnt <= 0 || (uint32_t)stepb >= max_steps || g.n_step == 0;
-                    nstep = over ? 0 : max(min((int)(rays_b / (uint32_t)cnt), 8), 1);
-                }
-                const int slots = cnt * nstep;
-                int a_inc = cnt, s_inc = slots;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int ua = __shfl_up(a_inc, o), us = __shfl_up(s_inc, o);
-                    if (lane >= o) { a_inc += ua; s_inc += us; }
-                }
-                if (b < n_groups) g_next[b] = PnGroup{alive_run + a_inc - cnt, nstep, slot_run + s_inc - slots, stepb};
-                if (b == 0) step0 = nstep;
-                alive_run += __shfl(a_inc, 63);
-                slot_run += __shfl(s_inc, 63);
-                int lv = nstep > 0 ? cnt : 0;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) lv += __shfl_xor(lv, o);
-                live += lv;
-            }
-            step0 = __shfl(step0, 0);
-            if (lane == 0) {
-                // rays of groups that ran into max_steps stay listed until the next composite retires them; the frame is over when no group marches on
-                const bool done = live <= 0;
-                next->n_alive = done ? 0 : sum;
-                next->n_step = done ? 1 : max(step0, 1);  // informational with groups (every kernel reads the group records)
-                next->step_base = trip->step_base + trip->n_step;
-                next->dense = (dense_trips && !done) ? 1 : 0;
-                next->n_samples = (dense_trips && !done) ? slot_run : 0;
-                next->n_emitted = 0;
-            }
-        } else if (c == 0 && threadIdx.x == 0) {
-            if (n_out) *n_out = sum;
-            if (next) {
-                const int step = trip->step_base + trip->n_step;
-                const bool done = (sum <= 0) || ((uint32_t)step >= max_steps);
-                next->n_alive = done ? 0 : sum;
-                next->n_step = done ? 1 : max(min((int)(N_rays / (uint32_t)sum), 8), 1);
-                next->step_base = step;
-                // dense trip (see trip_is_dense): the list is the identity over all slots; n_emitted = -1 marks a list trip
-                // every trip after the first is dense: its rays are the ones that found a sample before (n_step == 1 then means more than half of
-                // all rays are still alive — they will mostly fill their single slot too)
-                const bool dense = dense_trips && !done;
-                next->dense = dense ? 1 : 0;
-                next->n_samples = dense ? sum * next->n_step : 0;
-                next->n_emitted = 0;
-            }
+        if (c == 0 && wid == 0) {
+            if (n_out && lane == 0) *n_out = sum;
+            trip_epilogue(lane, sum, trip, next, N_rays, max_steps, dense_trips, seg_counters, tail_diag, g_cur, g_next, group_cnt, group_rays, n_groups);
         }
         const uint32_t i = c * 256 + threadIdx.x;
         const int v = (i < n) ? in[i] : -1;
@@ -1291,6 +1306,104 @@ __global__ void __launch_bounds__(256) k_compact(const int* __restrict__ in, uin
         for (int w = 0; w < wid; w++) wbase += woff[w];
         if (keep) out[offset + wbase + rank] = v;
         __syncthreads();  // red / woff are reused by the next chunk
+    }
+}
+
+// ---- composite + stable compaction + end-of-trip bookkeeping in ONE launch (frame driver of the deformed render).
+// kernel_composite_rays (raymarching.cu:827-923) followed by rays_alive = rays_alive[rays_alive >= 0] (renderer.py:887) is a scan: where a
+// survivor goes depends on how many rays before it survive.  Two launches did that through per-chunk counts in memory (k_composite, k_compact);
+// here workgroup b takes the chunks b, b + grid, ... of 256 * R consecutive alive positions, composites them, publishes each chunk's survivor
+// count as (trip tag << 16 | count) and then sums the words of ALL chunks before its own, polling those that do not carry this trip's tag yet.
+// No chain: a chunk waits for the composites of earlier chunks, never for their sums, so the launch lasts one composite plus one gather of at
+// most n_chunks words.  (A decoupled look-back over 64 descriptors at a time was tried first: with every chunk of the trip in flight at once the
+// prefixes have nothing to propagate from — 10 dependent steps on trip 0 — and 1 250 returning ticket / completion atomics on one address at
+// 11.4 ns each: 174 us against 25 for the two launches.)  Progress: a chunk depends on lower-numbered chunks only, workgroups are dispatched in
+// index order and take their chunks in ascending order, so whatever a running workgroup polls belongs to a workgroup dispatched before it.
+// The tag makes last trip's words read as "not written yet"; the words are cleared once per frame (k_frame_prologue).  The workgroup of the
+// trip's LAST chunk has the grand total and runs trip_epilogue: every earlier chunk has published its count, i.e. finished its composites and
+// its per-group survivor atomics.  R = alive positions per thread (1; PN_CC_R0 = 2 / 4 for the frame's first trip are kept for experiments:
+// fewer chunks make the quadratic gather smaller, but the strided accesses of the composite cost more than that saves).
+template <int R>
+__global__ void __launch_bounds__(256) k_composite_compact(float T_thresh, const int* __restrict__ cur, int* __restrict__ nxt, float* rays_t,
+                                                           const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ deltas,
+                                                           float* weights_sum, float* depth, float* image, PnTrip* trip, PnTrip* next,
+                                                           unsigned* words, uint32_t tag, uint32_t N_rays, uint32_t max_steps, int dense_trips,
+                                                           int* seg_counters, int* tail_diag, const PnGroup* __restrict__ g_cur, PnGroup* __restrict__ g_next,
+                                                           int* group_cnt, uint32_t group_rays, uint32_t n_groups) {
+    __shared__ int s_wcnt[4], s_part[4];
+    const uint32_t n_alive = (uint32_t)trip->n_alive, n_step_trip = (uint32_t)trip->n_step;
+    const uint32_t CH = 256u * R;
+    const uint32_t n_chunks = max((n_alive + CH - 1) / CH, 1u);  // chunk 0 always runs: somebody has to write the next trip's record
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        // ---- composite: R consecutive alive positions per thread
+        int keep[R];
+        int mine = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t n = c * CH + threadIdx.x * R + r;
+            bool alive = false;
+            int grp = -1, index = -1;
+            if (n < n_alive) {
+                index = cur[n];
+                uint32_t n_step = n_step_trip, slot0;
+                ray_slots(g_cur, group_rays, index, n, n_step, slot0);
+                if (g_cur) grp = (int)((uint32_t)index / group_rays);
+                // n_step == 0: the ray's group has reached max_steps — the batch's loop is over (renderer.py:836), the ray is dropped
+                if (n_step != 0) alive = composite_one(index, slot0, n_step, T_thresh, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+            }
+            keep[r] = alive ? index : -1;
+            mine += alive ? 1 : 0;
+            if (n_groups > 1) {  // survivors per group: one atomic per run of equal group ids (the positions of the 64 lanes are R apart, still sorted)
+                const unsigned long long am = __ballot(alive);
+                const int prev = __shfl_up(grp, 1);
+                const bool head = lane == 0 || grp != prev;
+                const unsigned long long hm = __ballot(head);
+                if (head && grp >= 0) {
+                    const unsigned long long above = lane == 63 ? 0ull : hm & ~((2ull << lane) - 1ull);
+                    const unsigned long long upto = above ? ((1ull << (__ffsll((long long)above) - 1)) - 1ull) : ~0ull;
+                    const int cc = (int)__popcll(am & upto & ~((1ull << lane) - 1ull));
+                    // returning form: the value has to be back before this chunk's count is published below (the epilogue reads the counters once
+                    // every count is out); a release fence would do the same by writing this XCD's whole L2 back
+                    if (cc) { const int old = atomicAdd(group_cnt + grp, cc); asm volatile("" ::"v"(old)); }
+                }
+            }
+        }
+        // ---- this chunk's survivor count; exclusive prefix of the thread inside the chunk
+        int inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) s_wcnt[wid] = inc;
+        __syncthreads();
+        const int count = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        int tbase = inc - mine;
+        for (int w = 0; w < wid; w++) tbase += s_wcnt[w];
+        // relaxed, device scope: the word IS the message (the XCDs' L2s are not coherent with each other: release / acquire at device scope
+        // write back and invalidate whole caches — with them this kernel took 185 us on trip 0)
+        if (threadIdx.x == 0) __hip_atomic_store(words + c, (tag << 16) | (unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- survivors of all chunks before this one
+        int part = 0;
+        for (uint32_t k = threadIdx.x; k < c; k += 256) {
+            unsigned w;
+            do { w = __hip_atomic_load(words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((w >> 16) != tag);
+            part += (int)(w & 0xFFFFu);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (lane == 0) s_part[wid] = part;
+        __syncthreads();
+        const int excl = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        // ---- survivors in order
+        int w0 = excl + tbase;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (keep[r] >= 0) nxt[w0++] = keep[r];
+        if (c == n_chunks - 1 && wid == 0)
+            trip_epilogue(lane, excl + count, trip, next, N_rays, max_steps, dense_trips, seg_counters, tail_diag, g_cur, g_next, group_cnt, group_rays, n_groups);
+        __syncthreads();  // s_wcnt / s_part are rewritten by the next chunk
     }
 }
 
@@ -1334,7 +1447,7 @@ struct pn_frame {
     MarchSide side;  // candidate lists + packed IP records of the cooperative march
     PnTrip* trips;  // [PN_MAX_TRIPS + 2]
     PnGroup* groups;     // [2][max_groups] ray-group records of the current / next trip (trip parity), see PnGroup
-    int* group_cnt;      // [max_groups] survivors per group (k_composite -> k_compact, which clears them)
+    int* group_cnt;      // [max_groups] survivors per group (composite -> trip_epilogue, which clears them)
     uint32_t max_groups;
     PnFrameDev* dev;
     float* cut_bounds;
@@ -1386,8 +1499,7 @@ __global__ void k_stamp(unsigned long long* slot) { *slot = __builtin_amdgcn_s_m
 //     multi-workgroup kernels of get_pnts_in_grids (k_pig_*) + k_nb_count + a second scan; same tables, bit for bit.
 template <bool LARGE>
 __global__ void __launch_bounds__(1024) k_frame_tables(const float* __restrict__ p_def, int n_vtx, int cut, float bound, float hgs, int max_cells,
-                                                       PnFrameDev* dev, int* pig_cnt, int* pig_bgn, int* pig_idx, int* pig_cursor, int swap,
-                                                       int* nb_cnt, int* nb_bgn, int* nb_cursor, uint32_t* cell_bits) {
+                                                       PnFrameDev* dev, int* pig_cnt, int* pig_bgn, int* pig_idx, int* pig_cursor, uint32_t* cell_bits) {
     extern __shared__ unsigned cnt2[];  // per-cell point counts, two 16-bit counters per word (a cell never holds 65 536 IPs)
     for (int w = threadIdx.x; w < 2 * ((max_cells + 31) / 32); w += blockDim.x) cell_bits[w] = 0u;  // both maps; set by k_frame_lists
     __shared__ float smin[3][16], smax[3][16];
@@ -1426,13 +1538,14 @@ __global__ void __launch_bounds__(1024) k_frame_tables(const float* __restrict__
         if (ncell > max_cells || ncell <= 0) { err = 4; ncell = 0; }
         dev->resolution[3] = ncell;
         dev->err = err;
+        dev->nb_alloc = 0;
         sh_res[3] = ncell;
         carry_s = 0;
     }
     __syncthreads();
     const int n_grid = sh_res[3], r0 = sh_res[0], r1 = sh_res[1], r2 = sh_res[2];
     const float b0 = sh_min[0], b1 = sh_min[1], b2 = sh_min[2];
-    if (n_grid == 0) { if (threadIdx.x == 0) nb_bgn[0] = 0; return; }
+    if (n_grid == 0) return;
     if (LARGE) return;  // the tables themselves are built by the multi-workgroup kernels (pn_frame_prologue)
     for (int g = threadIdx.x; g < (n_grid + 1) / 2; g += blockDim.x) cnt2[g] = 0u;
     __syncthreads();
@@ -1450,11 +1563,13 @@ __global__ void __launch_bounds__(1024) k_frame_tables(const float* __restrict__
         else atomicOr(&dev->err, 2);
     }
     __syncthreads();
-    // exclusive scan of the counts -> pig_cnt / pig_bgn / pig_cursor, then of the 27-neighbourhood sums -> nb_cnt / nb_bgn / nb_cursor
-    for (int pass = 0; pass < 2; pass++) {
-        int* out_cnt = pass ? nb_cnt : pig_cnt;
-        int* out_bgn = pass ? nb_bgn : pig_bgn;
-        int* out_cur = pass ? nb_cursor : pig_cursor;
+    // exclusive scan of the counts -> pig_cnt / pig_bgn / pig_cursor.  (Rounds 1-2 also summed every cell's 27-neighbourhood here and scanned
+    // that for the candidate-list offsets: 27 LDS reads + the neighbour arithmetic per cell on ONE compute unit were 50 of this kernel's 82 us.
+    // The lists now get their space from a bump counter in k_frame_prologue, which runs on the whole chip.)
+    {
+        int* out_cnt = pig_cnt;
+        int* out_bgn = pig_bgn;
+        int* out_cur = pig_cursor;
         for (int base = 0; base < n_grid; base += 4096) {
             const int i0 = base + threadIdx.x * 4;
             int v[4];
@@ -1464,14 +1579,6 @@ __global__ void __launch_bounds__(1024) k_frame_tables(const float* __restrict__
                 int val = 0;
                 if (c < n_grid) {
                     val = count_of(c);
-                    if (pass) {  // k_nb_count: the cell and its 26 neighbours
-                        int g0, g1, g2;
-                        nb_cell_coords(c, r0, r1, g0, g1, g2);
-                        for (int q = 0; q < 26; q++) {
-                            const int nbc = nb_neighbour(q, swap, g0, g1, g2, r0, r1, r2);
-                            if (nbc >= 0) val += count_of(nbc);
-                        }
-                    }
                     out_cnt[c] = val;
                 }
                 v[k] = val;
@@ -1525,96 +1632,148 @@ __global__ void __launch_bounds__(1024) k_frame_tables(const float* __restrict__
     for (int p = threadIdx.x; p < n_vtx; p += blockDim.x) pig_idx[p] = lidx[p];
 }
 
-// (2) k_frame_lists: candidate lists with 8 lanes per cell (lane j copies neighbours j, j+8, j+16, j+24 of the 27 in visiting
-//     order, after summing the counts of the neighbours before its own) + the packed IP records (blocks >= list_blocks).
-__global__ void __launch_bounds__(256) k_frame_lists(int n_grid_max, const int* __restrict__ n_grid_dev, const int* __restrict__ res,
-                                                     const int* __restrict__ pig_cnt, const int* __restrict__ pig_bgn, const int* __restrict__ pig_idx,
-                                                     const float* __restrict__ p_def, int swap, const int* __restrict__ nb_cnt, int* __restrict__ nb_bgn,
-                                                     float4* __restrict__ nb, int nb_capacity, int* err_flag, int list_blocks, int n_vtx,
-                                                     const float* __restrict__ p_ori, const float* __restrict__ F_IP, const float* __restrict__ dF_IP,
-                                                     float* __restrict__ rec, uint32_t* cell_bits) {
-    if ((int)blockIdx.x >= list_blocks) {  // k_pack_ip
-        const int t = threadIdx.x + ((int)blockIdx.x - list_blocks) * 256;
-        const int ip = t / PN_REC_FLOATS, j = t % PN_REC_FLOATS;
-        if (ip >= n_vtx) return;
-        rec[t] = pnm2::pack_ip_float(j, ip, p_ori, p_def, F_IP, dF_IP);
-        return;
+// (2) k_frame_prologue, ONE launch for everything else the frame needs before its first trip, three independent block ranges:
+//     [0, list_blocks)  candidate lists, 8 lanes per cell and 32 cells per workgroup round: the 27 neighbours' counts (lane j holds visiting
+//                       positions j, j+8, j+16, j+24), their running sum inside the 8-lane group (= where each neighbour's entries go), list space
+//                       by ONE returning atomic per workgroup round on dev->nb_alloc (the order of the lists in memory means nothing; an
+//                       atomic per cell on one address would serialise, see PN_SEGS), the entries, the (begin, end) record, and the two cell maps:
+//                       "has candidates" and — scattered to the 27 neighbours of every such cell — "within one cell of a cell with candidates".
+//                       The maps are a few cache lines (chair: 10 k cells = 10 lines) and atomics on one LINE queue like atomics on one address
+//                       (measured: 160 k atomicOr straight to global memory made this kernel 125 us), so every workgroup collects its bits in
+//                       LDS (lds_words > 0) and ORs only its non-zero words into the global maps;
+//     [.., + pack_blocks)  the packed IP records (k_pack_ip);
+//     the rest             k_near_far + the per-ray initialisation: zeroed accumulators (renderer.py:807-809), rays_alive = arange(N) (:828),
+//                          rays_t = nears (:829), zeroed trip records / counters, trip 0 = (N rays, n_step 1).  Needs only the bounding box.
+struct FramePrologue {
+    // lists
+    int n_grid_max; const int* n_grid_dev; const int* res; const int* pig_cnt; const int* pig_bgn; const int* pig_idx; const float* p_def; int swap;
+    int2* nb_rng; float4* nb; int nb_capacity; int list_blocks; uint32_t* cell_bits; int lds_words;
+    // records
+    int pack_blocks; int n_vtx; const float* p_ori; const float* F_IP; const float* dF_IP; float* rec;
+    // rays
+    const float* rays_o; const float* rays_d; PnFrameDev* dev; uint32_t N; float min_near; float* nears; float* fars; float* rays_t; PnTrip* trips;
+    int* tail_counts; int* seg_counters; int n_trip_records; int* alive; float* weights_sum; float* depth_0; float* image; PnGroup* groups;
+    int* group_cnt; uint32_t group_rays; uint32_t n_groups; int* chunk_words;
+};
+
+__device__ __forceinline__ void frame_lists_block(const FramePrologue& a) {
+    extern __shared__ uint32_t lds_bits[];  // [2][lds_words] when lds_words > 0
+    __shared__ int wtot[4];
+    __shared__ int blk_base;
+    const int n_grid = min(*a.n_grid_dev, a.n_grid_max);
+    const int r0 = a.res[0], r1 = a.res[1], r2 = a.res[2];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = threadIdx.x & 7;
+    const int words = (a.n_grid_max + 31) / 32;
+    const int per_round = a.list_blocks * 32;
+    const bool in_lds = a.lds_words > 0;
+    if (in_lds) {
+        for (int w = threadIdx.x; w < 2 * a.lds_words; w += blockDim.x) lds_bits[w] = 0u;
+        __syncthreads();
     }
-    const int n_grid = min(*n_grid_dev, n_grid_max);
-    const int r0 = res[0], r1 = res[1], r2 = res[2];
-    const int sub = threadIdx.x & 7;
-    const int max_cells_words = (n_grid_max + 31) / 32;
-    for (int c = (threadIdx.x + blockIdx.x * 256) >> 3; c < n_grid; c += (list_blocks * 256) >> 3) {
-        const int w0 = nb_bgn[c], total = nb_cnt[c];
-        if (c == n_grid - 1 && sub == 0) nb_bgn[n_grid] = w0 + total;  // closing offset
-        {   // second map: a cell with candidates within one cell (the 8 lanes share the 27 neighbours)
-            int gg0, gg1, gg2;
-            nb_cell_coords(c, r0, r1, gg0, gg1, gg2);
-            int any = 0;
-            for (int q = sub; q < 27; q += 8) {
-                const int cell = (q == 0) ? c : nb_neighbour(q - 1, swap, gg0, gg1, gg2, r0, r1, r2);
-                if (cell >= 0 && nb_cnt[cell] > 0) any = 1;
+    for (int c0 = 0; c0 < n_grid; c0 += per_round) {  // uniform trip count: the round's workgroup-wide sum needs every thread
+        const int c = c0 + (int)blockIdx.x * 32 + ((int)threadIdx.x >> 3);
+        const bool valid = c < n_grid;
+        int g0 = 0, g1 = 0, g2 = 0;
+        if (valid) nb_cell_coords(c, r0, r1, g0, g1, g2);
+        int cell[4], cnt[4], before[4];
+        int total = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {  // visiting position q = 0 is the cell itself, q = 1..26 its neighbours q - 1
+            const int q = sub + 8 * k;
+            cell[k] = (valid && q < 27) ? ((q == 0) ? c : nb_neighbour(q - 1, a.swap, g0, g1, g2, r0, r1, r2)) : -1;
+            cnt[k] = cell[k] >= 0 ? a.pig_cnt[cell[k]] : 0;
+            int inc = cnt[k];  // running sum over the 8 lanes of the group
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+                const int u = __shfl_up(inc, o, 8);
+                if (sub >= o) inc += u;
             }
-            any |= __shfl_xor(any, 1); any |= __shfl_xor(any, 2); any |= __shfl_xor(any, 4);
-            if (any && sub == 0) atomicOr(cell_bits + ((max_cells_words) + (c >> 5)), 1u << (c & 31));
+            before[k] = total + inc - cnt[k];
+            total += __shfl(inc, 7, 8);
         }
-        if (total == 0) continue;
-        if (sub == 0) atomicOr(cell_bits + (c >> 5), 1u << (c & 31));
-        if (w0 + total > nb_capacity) { if (err_flag && sub == 0) atomicOr(err_flag, 8); continue; }
-        int g0, g1, g2;
-        nb_cell_coords(c, r0, r1, g0, g1, g2);
-        // visiting position q = 0 is the cell itself, q = 1..26 its neighbours k = q - 1
-        int before = 0;  // entries of the positions before this lane's first one
-        for (int q = 0; q < sub; q++) {
-            const int cell = (q == 0) ? c : nb_neighbour(q - 1, swap, g0, g1, g2, r0, r1, r2);
-            if (cell >= 0) before += pig_cnt[cell];
+        // list space: exclusive sum of the round's 32 totals + one bump of the frame's counter
+        const int mine = (sub == 0) ? total : 0;
+        int inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
         }
-        for (int q = sub; q < 27; q += 8) {
-            const int cell = (q == 0) ? c : nb_neighbour(q - 1, swap, g0, g1, g2, r0, r1, r2);
-            if (cell >= 0) {
-                const int n = pig_cnt[cell], b = pig_bgn[cell];
-                for (int i = 0; i < n; i++) {
-                    const int ip = pig_idx[b + i];
-                    nb[w0 + before + i] = make_float4(p_def[ip * 3], p_def[ip * 3 + 1], p_def[ip * 3 + 2], __int_as_float(ip));
-                }
-                before += n;
+        if (lane == 63) wtot[wid] = inc;
+        const int in_wave = __shfl(inc - mine, lane & ~7);  // the group's first lane holds the cell's exclusive offset
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int sum = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+            blk_base = sum ? atomicAdd(&a.dev->nb_alloc, sum) : 0;
+        }
+        __syncthreads();
+        int w0 = blk_base + in_wave;
+        for (int w = 0; w < wid; w++) w0 += wtot[w];
+        __syncthreads();  // wtot / blk_base are rewritten by the next round
+        if (!valid) continue;
+        const bool fits = w0 + total <= a.nb_capacity;
+        if (sub == 0) {
+            a.nb_rng[c] = (total > 0 && fits) ? make_int2(w0, w0 + total) : make_int2(0, 0);
+            if (total > 0 && !fits) atomicOr(&a.dev->err, 8);
+        }
+        if (total == 0 || !fits) continue;
+        if (sub == 0) atomicOr((in_lds ? lds_bits : a.cell_bits) + (c >> 5), 1u << (c & 31));
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (cell[k] < 0) continue;
+            // second map: `cell[k]` lies within one cell of a cell with candidates
+            atomicOr((in_lds ? lds_bits + a.lds_words : a.cell_bits + words) + (cell[k] >> 5), 1u << (cell[k] & 31));
+            const int n = cnt[k], b = a.pig_bgn[cell[k]];
+            for (int i = 0; i < n; i++) {
+                const int ip = a.pig_idx[b + i];
+                a.nb[w0 + before[k] + i] = make_float4(a.p_def[ip * 3], a.p_def[ip * 3 + 1], a.p_def[ip * 3 + 2], __int_as_float(ip));
             }
-            for (int q2 = q + 1; q2 < q + 8 && q2 < 27; q2++) {  // skip the 7 positions owned by the other lanes
-                const int cell2 = nb_neighbour(q2 - 1, swap, g0, g1, g2, r0, r1, r2);
-                if (cell2 >= 0) before += pig_cnt[cell2];
-            }
+        }
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (int w = threadIdx.x; w < 2 * a.lds_words; w += blockDim.x) {
+            const uint32_t v = lds_bits[w];
+            if (v) atomicOr(a.cell_bits + (w < a.lds_words ? w : words + (w - a.lds_words)), v);
         }
     }
 }
 
-// (3) k_frame_rays: k_near_far + the per-frame initialisation in one pass over the rays — zeroed accumulators (renderer.py:807-809),
-//     rays_alive = arange(N) (:828), rays_t = nears (:829), zeroed trip records and tail counters, trip 0 = (N rays, n_step 1).
-__global__ void __launch_bounds__(256) k_frame_rays(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const PnFrameDev* dev, uint32_t N,
-                                                    float min_near, float* __restrict__ nears, float* __restrict__ fars, float* __restrict__ rays_t,
-                                                    PnTrip* trips, int* tail_counts, int* seg_counters, int n_trip_records, int* alive, float* __restrict__ weights_sum,
-                                                    float* __restrict__ depth_0, float* __restrict__ image, PnGroup* groups, int* group_cnt, uint32_t group_rays,
-                                                    uint32_t n_groups) {
-    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
-    if (blockIdx.x == 0 && groups) {  // trip 0 of every group: all its rays, one sample each (max(min(N_b // N_b, 8), 1))
-        for (uint32_t b = threadIdx.x; b < n_groups; b += blockDim.x) {
-            groups[b] = PnGroup{(int)(b * group_rays), 1, (int)(b * group_rays), 0};
-            group_cnt[b] = 0;
+__device__ __forceinline__ void frame_rays_block(const FramePrologue& a, uint32_t block) {
+    const uint32_t n = threadIdx.x + block * blockDim.x;
+    if (block == 0 && a.groups) {  // trip 0 of every group: all its rays, one sample each (max(min(N_b // N_b, 8), 1))
+        for (uint32_t b = threadIdx.x; b < a.n_groups; b += blockDim.x) {
+            a.groups[b] = PnGroup{(int)(b * a.group_rays), 1, (int)(b * a.group_rays), 0};
+            a.group_cnt[b] = 0;
         }
     }
-    if (blockIdx.x == 0) {
-        for (int t = threadIdx.x; t < n_trip_records; t += blockDim.x) {
-            PnTrip r;
-            memset(&r, 0, sizeof(r));  // trip 0 (n_step == 1) is a list trip
-            if (t == 0) { r.n_alive = dev->err ? 0 : (int)N; r.n_step = 1; }  // max(min(N // N, 8), 1)
-            trips[t] = r;
-            tail_counts[t] = 0;
+    // the trip records (1102 x 256 B) are cleared four to a workgroup, one dword per lane (one workgroup clearing all of them was this launch's
+    // critical path); trip 0 (n_step == 1) is a list trip over all N rays
+    {
+        const int t = (int)block * 4 + (int)(threadIdx.x >> 6), w = threadIdx.x & 63;
+        if (t < a.n_trip_records) {
+            int v = 0;
+            if (t == 0 && w == 0) v = (a.dev->err & 7) ? 0 : (int)a.N;  // flags of k_frame_tables stop the frame
+            if (t == 0 && w == 1) v = 1;                                // n_step = max(min(N // N, 8), 1)
+            reinterpret_cast<int*>(a.trips + t)[w] = v;
+            if (w == 0) a.tail_counts[t] = 0;
         }
-        for (int t = threadIdx.x; t < 6 * PN_SEGS; t += blockDim.x) seg_counters[t * PN_SEG_STRIDE] = 0;
+        // a frame with fewer rays than that: the last workgroup clears what is left
+        if (block + 1 == gridDim.x - (uint32_t)(a.list_blocks + a.pack_blocks)) {
+            for (int t2 = ((int)block + 1) * 4 + (int)(threadIdx.x >> 6); t2 < a.n_trip_records; t2 += 4) {
+                reinterpret_cast<int*>(a.trips + t2)[w] = 0;
+                if (w == 0) a.tail_counts[t2] = 0;
+            }
+        }
     }
-    if (n >= N) return;
-    const float* aabb = dev->aabb;
-    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
-    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    if (block == 0)
+        for (int t = threadIdx.x; t < 6 * PN_SEGS; t += blockDim.x) a.seg_counters[t * PN_SEG_STRIDE] = 0;
+    if (threadIdx.x == 0) a.chunk_words[block] = 0;  // one (tag, count) word per 256 rays (+ the spare ones by the last workgroup), see k_composite_compact
+    if (threadIdx.x < 2 && block + 1 == gridDim.x - (uint32_t)(a.list_blocks + a.pack_blocks)) a.chunk_words[block + 1 + threadIdx.x] = 0;
+    if (n >= a.N) return;
+    const float* aabb = a.dev->aabb;
+    const float ox = a.rays_o[n * 3], oy = a.rays_o[n * 3 + 1], oz = a.rays_o[n * 3 + 2];
+    const float dx = a.rays_d[n * 3], dy = a.rays_d[n * 3 + 1], dz = a.rays_d[n * 3 + 2];
     const float rdx = 1 / dx, rdy = 1 / dy, rdz = 1 / dz;
     float near = (aabb[0] - ox) * rdx, far = (aabb[3] - ox) * rdx;
     if (near > far) { float c = near; near = far; far = c; }
@@ -1630,17 +1789,29 @@ __global__ void __launch_bounds__(256) k_frame_rays(const float* __restrict__ ra
         if (!miss) {
             if (near_z > near) near = near_z;
             if (far_z < far) far = far_z;
-            if (near < min_near) near = min_near;
+            if (near < a.min_near) near = a.min_near;
         }
     }
     if (miss) near = far = FLT_MAX;
-    nears[n] = near;
-    fars[n] = far;
-    rays_t[n] = near;  // rays_t = nears.clone() (renderer.py:829)
-    alive[n] = (int)n;
-    weights_sum[n] = 0.f;
-    depth_0[n] = 0.f;
-    image[n * 3] = 0.f; image[n * 3 + 1] = 0.f; image[n * 3 + 2] = 0.f;
+    a.nears[n] = near;
+    a.fars[n] = far;
+    a.rays_t[n] = near;  // rays_t = nears.clone() (renderer.py:829)
+    a.alive[n] = (int)n;
+    a.weights_sum[n] = 0.f;
+    a.depth_0[n] = 0.f;
+    a.image[n * 3] = 0.f; a.image[n * 3 + 1] = 0.f; a.image[n * 3 + 2] = 0.f;
+}
+
+__global__ void __launch_bounds__(256) k_frame_prologue(FramePrologue a) {
+    const int b = (int)blockIdx.x;
+    if (b < a.list_blocks) { frame_lists_block(a); return; }
+    if (b < a.list_blocks + a.pack_blocks) {  // k_pack_ip
+        const int t = threadIdx.x + (b - a.list_blocks) * 256;
+        const int ip = t / PN_REC_FLOATS, j = t % PN_REC_FLOATS;
+        if (ip < a.n_vtx) a.rec[t] = pnm2::pack_ip_float(j, ip, a.p_ori, a.p_def, a.F_IP, a.dF_IP);
+        return;
+    }
+    frame_rays_block(a, (uint32_t)(b - a.list_blocks - a.pack_blocks));
 }
 
 extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_vtx, uint32_t max_grid_cells) {
@@ -1653,11 +1824,10 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
     PN_ALLOC(f->nears, N * 4); PN_ALLOC(f->fars, N * 4); PN_ALLOC(f->rays_t, N * 4);
     PN_ALLOC(f->xyzs, N * 12); PN_ALLOC(f->dirs, N * 12); PN_ALLOC(f->deltas, N * 8); PN_ALLOC(f->sigmas, N * 4); PN_ALLOC(f->rgbs, N * 12);
     PN_ALLOC(f->acc_image, N * 12);
-    PN_ALLOC(f->alive_a, N * 4); PN_ALLOC(f->alive_b, N * 4); PN_ALLOC(f->list, N * 4); PN_ALLOC(f->chunk_counts, (N / 256 + 2) * 4);
+    PN_ALLOC(f->alive_a, N * 4); PN_ALLOC(f->alive_b, N * 4); PN_ALLOC(f->list, N * 4); PN_ALLOC(f->chunk_counts, (N / 256 + 4) * 4);
     PN_ALLOC(f->pig_cnt, (size_t)max_grid_cells * 4); PN_ALLOC(f->pig_bgn, (size_t)max_grid_cells * 4);
     PN_ALLOC(f->pig_cursor, (size_t)max_grid_cells * 4); PN_ALLOC(f->pig_idx, (size_t)max_vtx * 4);
-    PN_ALLOC(f->side.nb_cnt, ((size_t)max_grid_cells + 1) * 4); PN_ALLOC(f->side.nb_bgn, ((size_t)max_grid_cells + 1) * 4);
-    PN_ALLOC(f->side.nb_cursor, ((size_t)max_grid_cells + 1) * 4);
+    PN_ALLOC(f->side.nb_rng, ((size_t)max_grid_cells + 1) * sizeof(int2));
     f->side.nb_capacity = 27 * (int)max_vtx;
     PN_ALLOC(f->side.nb, (size_t)f->side.nb_capacity * sizeof(float4)); PN_ALLOC(f->side.rec, (size_t)max_vtx * PN_REC_FLOATS * 4);
     f->seg_cap = seg_cap_for(max_rays);
@@ -1684,7 +1854,7 @@ extern "C" void pn_frame_destroy(pn_frame* f) {
     if (!f) return;
     void* ptrs[] = {f->acc_image, f->nears, f->fars, f->rays_t, f->xyzs, f->dirs, f->deltas, f->sigmas, f->rgbs, f->alive_a, f->alive_b, f->list,
                     f->chunk_counts, f->pig_cnt, f->pig_bgn, f->pig_cursor, f->pig_idx, f->trips, f->dev, f->cut_bounds,
-                    f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, f->side.nb, f->side.rec, f->march_counters, f->tail, f->tail_counts, f->stamps,
+                    f->side.nb_rng, f->side.nb, f->side.rec, f->march_counters, f->tail, f->tail_counts, f->stamps,
                     f->list_seg, f->active_seg, f->seg_counters, f->cell_bits, f->fars_eff, f->groups, f->group_cnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int t = 0; t < PN_TIMED_TRIPS; t++)
@@ -1734,6 +1904,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     // PN_MARCH_GRID / PN_TRIP_GRID override for experiments.
     static const uint32_t march_grid_cfg = pn_env_u32("PN_MARCH_GRID", 8192), trip_grid_cfg = pn_env_u32("PN_TRIP_GRID", 1024);
     const uint32_t march_grid = march_grid_cfg, trip_grid = std::min(nblk, trip_grid_cfg);
+    static const bool split_compact = pn_env_u32("PN_SPLIT_COMPACT", 0) != 0;  // experiments: composite and compaction as two launches (rounds 1-2)
     static const uint32_t tail_grid_cfg = pn_env_u32("PN_TAIL_GRID", 1024);  // x4 waves, one unfinished ray per wave at a time
     const uint32_t tail_grid = std::max(std::min(pn_div_up(N, 4), tail_grid_cfg), (uint32_t)PN_SEGS / 4);  // every tail segment needs a wave
     // the skip pre-pass keeps the cells' emptiness bits in LDS when they fit (48 KB = 393 k cells)
@@ -1781,30 +1952,34 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             if (dev_id >= 0 && dev_id < PN_MAX_DEVICES) tables_lds_set[dev_id] = tables_lds;
         }
         k_frame_tables<false><<<1, 1024, tables_lds, st>>>(p_def, n_vtx, o->cut, o->bound, o->hash_grid_size, (int)f->max_cells, f->dev, f->pig_cnt,
-                                                           f->pig_bgn, f->pig_idx, f->pig_cursor, swap, f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, f->cell_bits);
+                                                           f->pig_bgn, f->pig_idx, f->pig_cursor, f->cell_bits);
     } else {
         k_frame_tables<true><<<1, 1024, 0, st>>>(p_def, n_vtx, o->cut, o->bound, o->hash_grid_size, (int)f->max_cells, f->dev, f->pig_cnt, f->pig_bgn,
-                                                 f->pig_idx, f->pig_cursor, swap, f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, f->cell_bits);
+                                                 f->pig_idx, f->pig_cursor, f->cell_bits);
         rc = pig_build(n_vtx, (int)f->max_cells, n_grid_dev, p_def, bbmin, o->hash_grid_size, res, f->pig_cnt, f->pig_bgn, f->pig_idx, f->pig_cursor, err, st);
         if (rc) return rc;
-        const int gz = (int)std::min(pn_div_up(f->max_cells, 256), 1024u);
-        k_nb_count<<<gz, 256, 0, st>>>((int)f->max_cells, n_grid_dev, res, f->pig_cnt, swap, f->side.nb_cnt);
-        launch_cell_scan((int)f->max_cells, n_grid_dev, f->side.nb_cnt, f->side.nb_bgn, f->side.nb_cursor, st);
     }
+    FramePrologue fp;
+    memset(&fp, 0, sizeof(fp));
     if (!is_static && !keep_tables) {
         f->tables_n_vtx = n_vtx;
-        const int list_blocks = (int)std::min(pn_div_up((uint64_t)f->max_cells * 8, 256), 2048u);
-        const int pack_blocks = (int)pn_div_up((uint64_t)n_vtx * PN_REC_FLOATS, 256);
-        k_frame_lists<<<list_blocks + pack_blocks, 256, 0, st>>>((int)f->max_cells, n_grid_dev, res, f->pig_cnt, f->pig_bgn, f->pig_idx, p_def, swap,
-                                                                 f->side.nb_cnt, f->side.nb_bgn, f->side.nb, f->side.nb_capacity, err, list_blocks, n_vtx,
-                                                                 p_ori, F_IP, dF_IP, f->side.rec, f->cell_bits);
+        fp.n_grid_max = (int)f->max_cells; fp.n_grid_dev = n_grid_dev; fp.res = res; fp.pig_cnt = f->pig_cnt; fp.pig_bgn = f->pig_bgn; fp.pig_idx = f->pig_idx;
+        fp.p_def = p_def; fp.swap = swap; fp.nb_rng = f->side.nb_rng; fp.nb = f->side.nb; fp.nb_capacity = f->side.nb_capacity; fp.cell_bits = f->cell_bits;
+        fp.list_blocks = (int)std::min(pn_div_up((uint64_t)f->max_cells, 32), 2048u);
+        fp.pack_blocks = (int)pn_div_up((uint64_t)n_vtx * PN_REC_FLOATS, 256);
+        fp.n_vtx = n_vtx; fp.p_ori = p_ori; fp.F_IP = F_IP; fp.dF_IP = dF_IP; fp.rec = f->side.rec;
     }
-    k_frame_rays<<<nblk, 256, 0, st>>>(rays_o, rays_d, f->dev, N, o->min_near, f->nears, f->fars, f->rays_t, f->trips, f->tail_counts, f->seg_counters,
-                                       PN_MAX_TRIPS + 2, f->alive_a, weights_sum, depth_0, f->acc_image, group_rays ? f->groups : nullptr, f->group_cnt, group_rays,
-                                       n_groups);
+    fp.rays_o = rays_o; fp.rays_d = rays_d; fp.dev = f->dev; fp.N = N; fp.min_near = o->min_near; fp.nears = f->nears; fp.fars = f->fars; fp.rays_t = f->rays_t;
+    fp.trips = f->trips; fp.tail_counts = f->tail_counts; fp.seg_counters = f->seg_counters; fp.n_trip_records = PN_MAX_TRIPS + 2; fp.alive = f->alive_a;
+    fp.weights_sum = weights_sum; fp.depth_0 = depth_0; fp.image = f->acc_image; fp.groups = group_rays ? f->groups : nullptr; fp.group_cnt = f->group_cnt;
+    fp.group_rays = group_rays; fp.n_groups = n_groups; fp.chunk_words = f->chunk_counts;
+    // both cell maps of a workgroup in LDS while it builds its lists (up to 64 KB = 262 k cells; beyond that straight to global memory, where
+    // the maps then span enough cache lines for the atomics not to queue)
+    fp.lds_words = (fp.list_blocks > 0 && bit_words * 8 <= 64 * 1024) ? (int)bit_words : 0;
+    k_frame_prologue<<<(uint32_t)(fp.list_blocks + fp.pack_blocks) + nblk, 256, (size_t)fp.lds_words * 8, st>>>(fp);
     PN_LAUNCH_CHECK();
     }
-    pnm2::March2Tables tb{f->side.nb_bgn, f->side.nb, (const float4*)f->side.rec};
+    pnm2::March2Tables tb{f->side.nb_rng, f->side.nb, (const float4*)f->side.rec};
 
     pnm::MarchParams mp = make_march_params(f->pig_cnt, f->pig_bgn, f->pig_idx, n_vtx, 0, p_def, p_ori, F_IP, dF_IP, o->max_iter_num, bbmin, bbmax,
                                             o->hash_grid_size, res, o->num_seek_IP, o->IP_dx, o->cut, f->cut_bounds, f->rays_t, rays_o, rays_d,
@@ -1872,10 +2047,25 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             }
             PnGroup* g_cur = group_rays ? f->groups + (size_t)(t & 1) * f->max_groups : nullptr;
             PnGroup* g_nxt = group_rays ? f->groups + (size_t)((t + 1) & 1) * f->max_groups : nullptr;
+            if (!is_static && !split_compact) {
+                // one workgroup per possible chunk: a chunk then only ever waits for workgroups with a lower index, which the dispatcher started
+                // before it (a bounded grid with chunk loops could leave a resident workgroup polling a chunk whose workgroup has no slot yet)
+#define PN_CC_LAUNCH(R_)                                                                                                                                   \
+    k_composite_compact<R_><<<pn_div_up(N, 256 * R_), 256, 0, st>>>(o->T_thresh, cur, nxt, f->rays_t, f->sigmas, f->rgbs, f->deltas, weights_sum, depth_0,          \
+                                                                     f->acc_image, f->trips + t, f->trips + t + 1, (unsigned*)f->chunk_counts, (uint32_t)t + 1, N, \
+                                                                     o->max_steps, 1, f->seg_counters, f->tail_counts + t, g_cur, g_nxt, f->group_cnt, group_rays,  \
+                                                                     n_groups)
+                static const uint32_t cc_r0 = pn_env_u32("PN_CC_R0", 1);  // alive positions per thread on a frame's first trip; measured 20.0 / 21.4 / 27.9 us for 1 / 2 / 4
+                if (t == 0 && cc_r0 >= 4) PN_CC_LAUNCH(4);
+                else if (t == 0 && cc_r0 == 2) PN_CC_LAUNCH(2);
+                else PN_CC_LAUNCH(1);
+#undef PN_CC_LAUNCH
+            } else {
             k_composite<<<trip_grid, 256, 0, st>>>(0, 0, o->T_thresh, cur, f->rays_t, f->sigmas, f->rgbs, f->deltas, weights_sum, depth_0, f->acc_image,
                                                    f->trips + t, f->chunk_counts, g_cur, group_rays, n_groups > 1 ? f->group_cnt : nullptr);
             k_compact<<<trip_grid, 256, 0, st>>>(cur, 0, f->chunk_counts, nxt, nullptr, f->trips + t, f->trips + t + 1, N, o->max_steps, is_static ? 0 : 1,
                                                  is_static ? nullptr : f->seg_counters, f->tail_counts + t, g_cur, g_nxt, f->group_cnt, group_rays, n_groups);
+            }
         }
         PN_LAUNCH_CHECK();
         if (async_trips > 0) break;
