@@ -326,7 +326,7 @@ def main():
     ap.add_argument("--prime", type=int, default=40, help="untimed priming steps right after the graph captures, before the warm-up steps (see the timed loop)")
     ap.add_argument("--trips", type=int, default=None, help="render-loop trips baked into the captured graphs (default: what one eager frame needs + 2; a frame "
                     "that needs more is continued when it is retired)")
-    ap.add_argument("--copy-on", choices=("copy", "lane", "sim"), default="lane", help="stream of the per-frame D2H: a copy stream of its own, or the frame's render stream")
+    ap.add_argument("--copy-on", choices=("copy", "lane", "sim", "host"), default="host", help="stream of the per-frame D2H: a copy stream of its own, or the frame's render stream")
     ap.add_argument("--lanes", type=int, default=3,
                     help="render streams (3 render streams + the simulator stream = the 4 compute pipes of an XCD, more streams only time-slice)")
     ap.add_argument("--depth", type=int, default=2, help="workspaces per render stream")
@@ -411,7 +411,7 @@ def main():
             args.trips = h._pipe_backend.trips
             run_steps = lambda n: [h.step_pipelined() for _ in range(n)]
             launch = (f"hip graphs, {args.trips} trips, {args.lanes} render streams x {args.depth} workspaces, simulator running ahead, D2H on "
-                      + {"copy": "a copy stream", "lane": "the frame's render stream", "sim": "the simulator stream"}[args.copy_on]
+                      + {"copy": "a copy stream", "lane": "the frame's render stream", "sim": "the simulator stream", "host": "no stream (copier thread + SDMA through the HSA runtime)"}[args.copy_on]
                       + (f"; rays in batches of {opt['ray_batch']} with per-batch trip schedules (max_ray_batch), all batches in the same launches" if staged else ""))
     else:
         from pienerf_amd.frames import broadcast_tensors

@@ -261,6 +261,20 @@ int pn_render_static(pn_frame* f, const pn_net* net, const pn_render_opts* opts,
                      const float* aabb_host, const uint8_t* bitfield, float* image, float* depth, float* depth_0, float* weights_sum,
                      int64_t* stats_host, int n_trips, void* stream);
 
+/* ------------------------------------------------------------------ frame copies to the host (nerf/trainer.py:589-592) ---- */
+
+/* The reference's device->host boundary: image / depth / depth_0 .cpu().numpy() per frame.  A pn_copier performs such copies without a HIP
+ * stream: a host thread waits for `after_event` (a hipEvent_t recorded behind the producing kernels; NULL: no wait), hands the copy to the
+ * HSA runtime (SDMA engine) and waits for its completion signal, so the render streams never carry it (this part runs four hardware queues
+ * concurrently; a copy on a fifth stream makes everything time-slice, a copy on a render stream holds that stream for the PCIe time).
+ * dst_host: pinned host memory (hipHostMalloc / torch pin_memory); src_dev: device memory.  Copies complete in submission order.
+ * pn_copier_wait blocks until the copy with that ticket (and every earlier one) has completed; returns PN_ERR_HIP if any copy failed. */
+typedef struct pn_copier pn_copier;
+int pn_copier_create(pn_copier** out);
+void pn_copier_destroy(pn_copier* c);
+int pn_copier_submit(pn_copier* c, void* dst_host, const void* src_dev, uint64_t bytes, void* after_event, uint64_t* ticket);
+int pn_copier_wait(pn_copier* c, uint64_t ticket);
+
 /* ------------------------------------------------------------------ density-grid state (off the hot path) */
 
 /* NeRFRenderer.mark_untrained_grid (nerf/renderer.py:390-452): density_grid [cascade, H^3] (morton order) gets -1 in every cell that no

@@ -32,6 +32,7 @@ UNITS = {
     "pn_nerf_forward.hip": ["-ffp-contract=fast"],
     "pn_encoder_grad.hip": ["-ffp-contract=fast"],
     "pn_sim.hip": ["-ffp-contract=fast"],
+    "pn_copier.hip": [],  # host code only: frame copies through the HSA runtime (links libhsa-runtime64)
 }
 
 
@@ -80,7 +81,7 @@ def build(force=False, save_temps=False, verbose=False):
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True, cwd=OBJ)
     if force or _stale(LIB, objs):
-        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lhsa-runtime64", "-lpthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

@@ -217,10 +217,12 @@ class SimRenderHarness:
 
     @torch.no_grad()
     def capture_pipelined(self, lanes=2, n_trips=8, W=None, H=None, sim_ahead=None, depth=2, sim_priority=0, sim_cus=0, copy_out=True, group=None,
-                          frame_parallel=False, sim_owner=0, dedicated_sim=None, on_retire=None, copy_on="lane", _probe_no_substep=False, _time_trips=False):
+                          frame_parallel=False, sim_owner=0, dedicated_sim=None, on_retire=None, copy_on="host", _probe_no_substep=False, _time_trips=False):
         """Throughput mode (pienerf_amd/frames.py: FramePipeline): `lanes` render streams with `depth` workspaces each, the simulator running
-        `sim_ahead` frames ahead on dof snapshots, every frame's image / depth / depth_0 copied to pinned host memory on a copy stream
-        (the reference's device->host boundary, trainer.py:589-592; copy_out=False leaves the results on the device).  Everything a frame
+        `sim_ahead` frames ahead on dof snapshots, every frame's image / depth / depth_0 copied to pinned host memory (the reference's
+        device->host boundary, trainer.py:589-592; copy_out=False leaves the results on the device) — copy_on="host": by the library's copier
+        thread through the HSA runtime's SDMA engine, no stream involved (csrc/pn_copier.hip; "lane" / "copy" / "sim": as a hipMemcpyAsync
+        on the frame's render stream / a stream of its own / the simulator stream).  Everything a frame
         launches is captured in HIP graphs — one for the substep, one per workspace for get_rays + the render with `n_trips` loop trips
         (None: measured on one eager frame, + 2); a frame that still has rays alive after its trips is continued when it is retired
         (renderer.py:836-891).  frame_parallel=True (or ``capture_frame_parallel``): the same pipeline over the ranks of `group` — the sim
@@ -339,26 +341,56 @@ class _HipStream:
         self.s.wait_event(ev.e)
 
 
+class _HostCopyStream:
+    """Stands where frames.FramePipeline expects the stream of the frame copies when they are done by the library's host-side copier
+    (pn_copier, copy_on="host"): `wait(event)` names the event the next copy has to follow, `_HipBackend.copy_out` submits the copy behind it,
+    an event `recorded` here carries the copy's ticket and can only be waited for by the host (which is all the pipeline does with it)."""
+
+    def __init__(self, backend):
+        self.backend, self.after, self.ticket = backend, None, None
+
+    def wait(self, ev):
+        self.after = ev
+
+
 class _HipEvent:
     def __init__(self):
         self.e = torch.cuda.Event()
+        self.copy = None  # (copier handle, ticket) when the event marks the end of a host-side frame copy
 
     def record(self, stream):
-        self.e.record(stream.s)
+        if isinstance(stream, _HostCopyStream):
+            self.copy = (stream.backend.copier, stream.ticket)
+        else:
+            self.copy = None
+            self.e.record(stream.s)
 
     def host_wait(self):
-        self.e.synchronize()
+        if self.copy is not None:
+            from ._lib import check, lib
+            check(lib().pn_copier_wait(self.copy[0], self.copy[1]), "copier_wait")
+        else:
+            self.e.synchronize()
 
 
 class _HipBackend:
     """The device side of frames.FramePipeline on one MI355X: torch streams and events, the substep and one render per workspace captured
     as HIP graphs, RCCL broadcasts of the dof snapshots, D2H into pinned buffers."""
 
-    def __init__(self, h, lanes, depth, n_trips, W, H, sim_priority, sim_cus, copy_out, group, src, probe_no_substep, time_trips=False, copy_on="lane"):
+    def __init__(self, h, lanes, depth, n_trips, W, H, sim_priority, sim_cus, copy_out, group, src, probe_no_substep, time_trips=False, copy_on="host"):
         # stream of the per-frame D2H.  gfx950 runs 4 hardware queues concurrently and time-slices beyond that (DESIGN.md 4): with 3 render lanes +
         # the simulator stream a copy stream of its own is a fifth busy queue (measured: 808 steps/s against 1016 with the copy on the frame's own
-        # lane).  "copy": a stream of its own; "lane": the frame's render stream; "sim": the simulator stream
+        # lane).  "copy": a stream of its own; "lane": the frame's render stream; "sim": the simulator stream; "host": no stream at all — the
+        # library's copier thread waits for the render's event and hands the copy to the HSA runtime (SDMA), see csrc/pn_copier.hip
         self.copy_on = copy_on
+        self.copier = None
+        if copy_on == "host" and copy_out:
+            import ctypes
+
+            from ._lib import check, lib
+            hc = ctypes.c_void_p()
+            check(lib().pn_copier_create(ctypes.byref(hc)), "copier_create")
+            self.copier = hc
         self.h, self.lanes, self.depth, self.trips, self.W, self.H, self.group, self.src = h, lanes, depth, n_trips, W, H, group, src
         dev, m, sim = h.device, h.model, h.sim
         self.continued = 0
@@ -435,7 +467,15 @@ class _HipBackend:
 
     # ---- streams / events
     def stream(self, name):
+        if name == "copy" and self.copier is not None:
+            return _HostCopyStream(self)
         return _HipStream(self._streams[name])
+
+    def __del__(self):
+        if getattr(self, "copier", None) is not None:
+            from ._lib import lib
+            lib().pn_copier_destroy(self.copier)
+            self.copier = None
 
     def event(self):
         return _HipEvent()
@@ -470,8 +510,19 @@ class _HipBackend:
     def copy_out(self, s, ws, same_buffer=False):
         if not same_buffer:
             self.host_gen[ws] ^= 1
+        dst, src = self.host[ws][self.host_gen[ws]], self.packed[ws]
+        if isinstance(s, _HostCopyStream):
+            import ctypes
+
+            from ._lib import check, lib
+            t = ctypes.c_uint64()
+            after = ctypes.c_void_p(s.after.e.cuda_event) if s.after is not None else None
+            check(lib().pn_copier_submit(self.copier, ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), src.numel() * src.element_size(), after,
+                                         ctypes.byref(t)), "copier_submit")
+            s.ticket = t.value
+            return
         with torch.cuda.stream(s.s):
-            self.host[ws][self.host_gen[ws]].copy_(self.packed[ws], non_blocking=True)
+            dst.copy_(src, non_blocking=True)
 
     # ---- host side of a retired workspace
     def complete(self, ws):
