@@ -21,6 +21,7 @@ the dominant kernel's launch durations (HIP events on the launch stream: blockin
 and network kernels, and the CPU oracle on the host cores.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -140,17 +141,18 @@ def collect_samples(m, rays_o, rays_d, kw):
     return x[keep].contiguous(), d[keep].contiguous()
 
 
-def load_traffic(real_trips):
-    """HBM-side bytes per launch from the committed PMC passes — only when they were taken on THIS code (profiles/pmc_traffic.json is stamped with
-    pienerf_amd.build.source_hash by tools/pmc_traffic.py); a stale file gives null, never a number that belongs to other kernels."""
+def load_traffic(real_trips, config="chair"):
+    """HBM-side bytes per launch from the committed PMC passes of THIS workload — only when they were taken on THIS code (profiles/pmc_traffic*.json
+    are stamped with pienerf_amd.build.source_hash by tools/pmc_traffic.py); a stale file gives null, never a number that belongs to other kernels."""
     from pienerf_amd.build import source_hash
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    name = "pmc_traffic.json" if config == "chair" else f"pmc_traffic_{config}.json"
+    path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
-        return {}, "profiles/pmc_traffic.json not present"
+        return {}, f"profiles/{name} not present"
     with open(path) as f:
         pmc = json.load(f)
     if pmc.get("lib_hash") != source_hash():
-        return {}, f"profiles/pmc_traffic.json was measured on other kernel sources (stamp {str(pmc.get('lib_hash'))[:10]}, tree {source_hash()[:10]}): not reported"
+        return {}, f"profiles/{name} was measured on other kernel sources (stamp {str(pmc.get('lib_hash'))[:10]}, tree {source_hash()[:10]}): not reported"
     out = {}
     for k, v in pmc["kernels"].items():
         out[k.split("<")[0]] = out.get(k.split("<")[0], 0) + v["fetch_bytes_per_frame"] + v["write_bytes_per_frame"]
@@ -213,10 +215,10 @@ def kernel_report(h, opt, dev):
     grid_gbs = HASH_BYTES_PER_SAMPLE * B / (t_grid * 1e-3) / 1e9
     bps = FUSED_BYTES_PER_SAMPLE_FP16 if fp16 else FUSED_BYTES_PER_SAMPLE
     t_used = t_net_h if fp16 else t_net
-    if opt.get("_config_name", "chair") == "chair":
-        traffic, traffic_note = load_traffic(real)
-    else:  # the PMC passes behind profiles/pmc_traffic.json ran the chair workload (tools/run_frames.py)
-        traffic, traffic_note = {}, "profiles/pmc_traffic.json holds PMC passes of the chair workload only: not reported for this configuration"
+    if opt.get("_config_name", "chair") in ("chair", "stress", "trex"):  # PMC passes are taken per workload (tools/run_frames.py --config)
+        traffic, traffic_note = load_traffic(real, opt.get("_config_name", "chair"))
+    else:
+        traffic, traffic_note = {}, "no PMC passes for this variant of the workload (sigma gain != 1): not reported"
     net_loop_ms = float(net_ms[:real].sum())
     net_loop_gbs = bps * st["samples"] / (net_loop_ms * 1e-3) / 1e9
     net_loop_tf = MLP_FLOP_PER_SAMPLE * st["samples"] / (net_loop_ms * 1e-3) / 1e12
@@ -288,6 +290,23 @@ def pipelined_extras(make_harness, args, steps):
     res["latency_note"] = "lanes = 1: one render at a time (the next substep overlaps it), incl. D2H — the GUI-equivalent frame time"
     del h
     torch.cuda.empty_cache()
+    if args.config == "chair" and args.sigma_gain == 1.0:
+        # how steps/s moves with the samples per frame: the synthetic checkpoint's density scaled (fewer / more samples before a ray saturates).
+        # Each point in a process of its own: HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues, and in a process that has already
+        # created a few harnesses two busy lanes of a new one can land on the same queue (measured: 547 instead of 1 537 steps/s at gain 3).
+        import subprocess
+        sweep = []
+        for g in (0.3, 3.0):
+            cmd = [sys.executable, os.path.abspath(__file__), "--sigma-gain", str(g), "--steps", str(max(100, steps)), "--warmup", "20", "--no-extras",
+                   "--no-cpu-baseline", "--lanes", str(args.lanes), "--depth", str(args.depth), "--copy-on", args.copy_on]
+            try:
+                out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+                sweep.append({"sigma_gain": g, "steps_per_s": d["value"], "samples_per_frame": d["config"]["samples_per_frame"],
+                              "trips_per_frame": d["config"]["trips_per_frame"], "mean_samples_per_hit_ray": d["config"]["mean_samples_per_hit_ray"]})
+            except Exception as e:  # noqa: BLE001 — measurement only
+                sweep.append({"sigma_gain": g, "error": f"{type(e).__name__}: {str(e)[:200]}"})
+        res["sigma_gain_sweep"] = {"points": sweep, "note": "the same bench line at other densities of the synthetic checkpoint (gain 1 is `value` itself)"}
     try:  # HIP events recorded inside the captured render graphs: the march / network launch durations of the mode that produced `value`
         h = make_harness()
         h.capture_pipelined(lanes=args.lanes, depth=args.depth, n_trips=args.trips, _time_trips=True, copy_on=args.copy_on)
@@ -431,9 +450,17 @@ def main():
         launch = f"hip graphs, {args.trips} trips, {args.lanes} render streams x {args.depth} workspaces per rank"
 
     with torch.no_grad():
-        # priming, part of the set-up like the graph captures before it: the first replay of each of the lanes x depth render graphs, first
-        # touches of the pinned buffers, clocks coming up from the host-bound capture phase.  Measured: with 5 / 20 / 40 untimed steps in
-        # front, 20 timed steps take 25.2 / 22.2 / 18.7 ms.  The W warm-up steps the caller asked for follow, then exactly K timed steps.
+        # (1) exactly what the command line says, right after the graph captures: W untimed warm-up steps, K timed steps -> `value_unprimed`.
+        barrier()
+        run_steps(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        barrier()
+        elapsed_unprimed = time.perf_counter() - t0
+        # (2) the same again once the pipeline has been running for a while -> `value` (steady state).  The first replays of the lanes x depth
+        # render graphs, the first touches of the pinned buffers and the clocks coming up from the host-bound capture phase make a short run slower:
+        # measured in round 2 with 5 / 20 / 40 untimed steps in front, 20 timed steps took 25.2 / 22.2 / 18.7 ms.  Both figures are in the line.
         run_steps(args.prime)
         barrier()
         run_steps(args.warmup)
@@ -451,9 +478,9 @@ def main():
             continued = getattr(h, "graph_continued", 0)
     per_rank_frames = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, elapsed_unprimed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, elapsed_unprimed = float(t[0].item()), float(t[1].item())
         fr = torch.zeros(world, dtype=torch.int64, device=dev)
         fr[rank] = frames_done[0]
         torch.distributed.all_reduce(fr)
@@ -469,6 +496,9 @@ def main():
             "metric": "sim+render steps/s @800x800 chair" if args.config == "chair" else f"sim+render steps/s, {args.config} configuration",
             "value": round(args.steps * world / elapsed, 3), "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "value_unprimed": round(args.steps * world / elapsed_unprimed, 3),
+            "value_note": (f"`value`: K = {args.steps} timed steps after {args.prime} priming + W = {args.warmup} warm-up steps of the already running pipeline (steady state); "
+                           f"`value_unprimed`: the first K timed steps after only the W warm-up steps, right behind the graph captures"),
             "scaling": "weak", "vs_baseline": None, "dtype": ("f16 tables+MLP / f32 march / f64 sim" if opt.get("fp16") else "f32 render / f64 sim"), "data": "synthetic",
             "config": {"workload": workload + (f", constant force {[float(v) for v in force]} on IP {hk.sim.n_IP // 2}" if force is not None else ", gravity only")
                        + ("" if copy_out else " [--no-d2h: outputs left on the device]"),
@@ -476,12 +506,20 @@ def main():
                        "samples_per_frame": st["samples"], "trips_per_frame": st["trips"], "d2h_bytes_per_step": (opt["W"] * opt["H"] * 20 if copy_out else 0),
                        "frames_continued_past_captured_trips": continued, "launch": launch, "prime_steps": args.prime, "sigma_gain": args.sigma_gain,
                        "hit_rays": st["hit_rays"], "mean_samples_per_hit_ray": round(st["samples"] / max(1, st["hit_rays"]), 2),
+                       "ranks": world, "dist_backend": (os.environ.get("PN_DIST_BACKEND", "nccl") if world > 1 else None), "rccl_ranks": rccl_ranks,
+                       "frames_per_rank": per_rank_frames, "dedicated_sim": (bool(del_h._pipe.dedicated) if world > 1 else None),
                        "parallelism": (f"frame-parallel x{world} ({rccl_ranks} RCCL ranks), dof snapshots broadcast over RCCL, "
                                        + ("rank 0 simulates only, frames round-robin over the other ranks" if del_h._pipe.dedicated else "frames round-robin over all ranks")
                                        + f", frames per rank {per_rank_frames}") if world > 1 else "single GPU"},
             "roofline": roofline,
         }
         res.update(extra)
+        # what bounds the frame-parallel job: the sim owner's substep rate — the simulator is time-sequential — against N (or N - 1
+        # with a dedicated owner) ranks rendering at the single-GPU rate
+        t_sub = extra["breakdown_ms"]["stepforward_alone"]
+        res["frame_parallel_ceiling"] = {"substep_ms_alone": t_sub, "owner_frames_per_s": round(1e3 / t_sub, 1),
+                                         "note": "steps/s of an N-GPU frame-parallel job <= min(owner_frames_per_s [owner dedicated: its substep has the GPU to itself], "
+                                                 "renderers x the single-GPU render rate); with the owner also rendering its substep shares the GPU and is ~1.8x slower"}
         if world == 1 and not args.no_extras and not (args.eager or args.single_graph):
             with torch.no_grad():
                 res.update(pipelined_extras(make_harness, args, max(40, min(args.steps, 120))))

@@ -70,9 +70,20 @@ __device__ __forceinline__ _Float16 rounded_product<_Float16>(float w, _Float16 
 template <uint32_t C, typename T>
 __global__ void __launch_bounds__(256) k_grid_encode(const float* __restrict__ inputs, const T* __restrict__ emb, PnGridLevels lv, uint32_t B,
                                                      int align_corners, uint32_t interp, int out_bl_major, T* __restrict__ outputs) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    // [L,B,C] output (the reference kernel's layout): blockIdx.y = level, a thread per sample — one level's table at a time, neighbouring lanes write
+    // neighbouring rows.  [B,L*C] output (what grid.py:57 gets with an extra permute pass): a thread per (sample, level) with the LEVEL varying
+    // fastest, so that the lanes of a wave write consecutive C-vectors of the same rows (with a thread per sample the stores were L*C*4 bytes apart:
+    // 0.309 ms against 0.172 ms per 1.02 M samples).
+    uint32_t b, level;
+    if (out_bl_major) {
+        const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        b = (uint32_t)(g / lv.L);
+        level = (uint32_t)(g % lv.L);
+    } else {
+        b = blockIdx.x * blockDim.x + threadIdx.x;
+        level = blockIdx.y;
+    }
     if (b >= B) return;
-    const uint32_t level = blockIdx.y;
     T* out = out_bl_major ? outputs + ((size_t)b * lv.L + level) * C : outputs + ((size_t)level * B + b) * C;
     const float in0 = inputs[b * 3], in1 = inputs[b * 3 + 1], in2 = inputs[b * 3 + 2];
     if (in0 < 0 || in0 > 1 || in1 < 0 || in1 > 1 || in2 < 0 || in2 > 1) {
@@ -128,7 +139,7 @@ static int grid_encode_launch(const float* inputs, const T* embeddings, const in
     PN_REQUIRE(gridtype <= 1 && interp <= 1);
     PnGridLevels lv;
     if (pn_fill_grid_levels(&lv, offsets_host, L, C, S, H, gridtype, align_corners)) { PN_REQUIRE(L >= 1 && L <= PN_MAX_LEVELS); }
-    dim3 grid(pn_div_up(B, 256), L, 1);
+    dim3 grid(out_bl_major ? pn_div_up((uint64_t)B * L, 256) : pn_div_up(B, 256), out_bl_major ? 1 : L, 1);
     switch (C) {
         case 1: k_grid_encode<1, T><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
         case 2: k_grid_encode<2, T><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
@@ -495,8 +506,10 @@ __device__ __forceinline__ Split8 split8(float x0, float x1, float x2, float x3,
 // allocated destination, and hipcc (ROCm 7.2) does not treat the destination of v_mfma_f32_32x32x16_bf16 as early-clobber: an A or
 // B operand that dies in that instruction may be given the same registers (seen in the ISA of an earlier ordering).  Leading with
 // hi*hi, both of whose operands are used again below, keeps every source of a first MFMA live and therefore disjoint from its
-// destination; tests/test_host.py scans the shipped ISA for such overlaps.  (The run-to-run corruption first blamed on this turned
-// out to come from packed-fp32 VALU of co-resident waves — see build.py; the ordering stays as a precaution.)
+// destination; tests/test_host.py scans the shipped ISA for such overlaps.  (A precaution, not a fix: round 1 saw run-to-run corruption in an
+// earlier build of this kernel and blamed first this, then packed-fp32 VALU of co-resident waves; neither reproduced in isolation
+// (tools/repro_mfma_overlap.hip: 32.7 M overlapping MFMAs, tools/repro_pk_mfma.hip: 819 M MFMAs beside v_pk_* streams, 0 differences) and
+// both claims are withdrawn)
 __device__ __forceinline__ f32x16 split_mac(const uint4* __restrict__ wl, int G, const Split8& x, f32x16 acc) {
     const uint4 wh = wl[(G * 3 + 0) * 64], wm = wl[(G * 3 + 1) * 64], wo = wl[(G * 3 + 2) * 64];
     acc = PN_BMFMA(wh, x.hi, acc);

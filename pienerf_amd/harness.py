@@ -252,6 +252,7 @@ class SimRenderHarness:
         self._pipe = FramePipeline(be, world=world, rank=rank, lanes=lanes, depth=depth, ahead=(lanes if sim_ahead is None and world == 1 else sim_ahead),
                                    sim_owner=sim_owner, dedicated_sim=dedicated_sim, copy_out=copy_out, on_retire=on_retire)
         self._pipe_backend = be
+        self.model._in_flight = lambda pipe=self._pipe: sum(f is not None for f in pipe.pending)  # weight refreshes need a drained pipeline (network._net_handle)
         return self
 
     def capture_frame_parallel(self, lanes=2, n_trips=8, group=None, sim_owner=0, dedicated_sim=None, **kw):
@@ -413,6 +414,7 @@ class _HipBackend:
         pose0 = torch.from_numpy(np.asarray(h.pose, np.float32)).unsqueeze(0)
         self.pose_dev = [pose0.to(dev) for _ in range(n_ws)]
         self.pose_pin = [pose0.clone().pin_memory() for _ in range(n_ws)]
+        self.pose_key = [pose0.numpy().tobytes()] * n_ws
         self.ip = [tuple(torch.empty((n_IP, c), dtype=torch.float32, device=dev) for c in (3, 9, 27)) for _ in range(n_ws)]
         keep = (sim.dof.clone(), sim.dof_vel.clone())
         main = torch.cuda.current_stream(dev)
@@ -501,8 +503,14 @@ class _HipBackend:
 
     def render(self, s, frame, ws, slot, pose):
         with torch.cuda.stream(s.s):
-            if pose is not None:  # a new camera per frame (trainer.py:541): staged in pinned memory, uploaded in stream order before the graph reads it
-                self.pose_pin[ws].copy_(torch.from_numpy(np.asarray(pose, np.float32)).view(1, 4, 4))
+            # the camera of this frame (trainer.py:541): the given pose, else the harness's current one.  Every workspace keeps its own device
+            # copy (the graph reads it), so it is uploaded whenever it differs from what THIS workspace last rendered — staged in pinned memory,
+            # in stream order before the graph reads it
+            p = np.ascontiguousarray(self.h.pose if pose is None else pose, dtype=np.float32).reshape(1, 4, 4)
+            key = p.tobytes()
+            if self.pose_key[ws] != key:
+                self.pose_key[ws] = key
+                self.pose_pin[ws].copy_(torch.from_numpy(p))
                 self.pose_dev[ws].copy_(self.pose_pin[ws], non_blocking=True)
             self.h.sim.get_IP_info(dof=self._snap(slot), out=self.ip[ws])
             self.graph[ws].replay()

@@ -53,17 +53,24 @@ def _safe_load(path, map_location, allow_pickle):
         fn = getattr(_ma, name, None)
         if fn is not None:
             safe.append(fn)
+    import pickle
     try:
         with torch.serialization.safe_globals(safe):
             return torch.load(path, map_location=map_location, weights_only=True)
-    except Exception as e:  # noqa: BLE001 — pickle.UnpicklingError and friends
+    except (pickle.UnpicklingError, RuntimeError) as e:
+        # only what the restricted unpickler itself refuses (torch raises pickle.UnpicklingError, older versions a RuntimeError that names
+        # weights_only); a missing file, a corrupt archive or a device-mapping error propagates as it is
+        if isinstance(e, RuntimeError) and "weights_only" not in str(e) and "Unsupported" not in str(e):
+            raise
         if not allow_pickle:
             raise RuntimeError(f"{path}: not loadable with weights_only=True ({type(e).__name__}: {e}). If you trust the file, pass allow_pickle=True "
                                "(main_render: --trust-ckpt)") from e
+        import warnings
+        warnings.warn(f"{path}: needs pickle globals outside the allow-list; loading with full pickle because allow_pickle=True", stacklevel=3)
         return torch.load(path, map_location=map_location, weights_only=False)
 
 
-def load_checkpoint(model, path, model_only=True, optimizer=None, lr_scheduler=None, map_location=None, ema=None, allow_pickle=False):
+def load_checkpoint(model, path, model_only=True, optimizer=None, lr_scheduler=None, map_location=None, ema=None, allow_pickle=False, scaler=None):
     """trainer.py:856-916.  Returns dict(missing_keys, unexpected_keys, epoch, global_step).  The model is left in eval() mode."""
     ck = _safe_load(path, map_location or next(model.parameters()).device, allow_pickle)
     info = dict(missing_keys=[], unexpected_keys=[], epoch=None, global_step=None)
@@ -83,6 +90,8 @@ def load_checkpoint(model, path, model_only=True, optimizer=None, lr_scheduler=N
                 optimizer.load_state_dict(ck["optimizer"])
             if lr_scheduler is not None and "lr_scheduler" in ck:
                 lr_scheduler.load_state_dict(ck["lr_scheduler"])
+            if scaler is not None and "scaler" in ck:  # trainer.py:911-916
+                scaler.load_state_dict(ck["scaler"])
         if ema is not None and "ema" in ck:  # trainer.py:884-885 (loaded whenever present)
             ema.load_state_dict(ck["ema"])
     if hasattr(model, "_net_sig"):

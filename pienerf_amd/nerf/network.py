@@ -44,9 +44,13 @@ class NeRFNetwork(NeRFRenderer):
 
     def _net_handle(self, half=False):
         """The packed device context (pn_net).  Created once; when a parameter changed since (optimizer step, checkpoint load) the packed
-        weights are refreshed IN PLACE (pn_net_update: pinned staging + async upload, no allocation, no device synchronisation).
-        half=True additionally makes sure the fp16 tables exist (pn_net_enable_half)."""
+        weights are refreshed IN PLACE (pn_net_update: the weights are read back to the host — which waits for the current stream — packed into
+        pinned staging and uploaded asynchronously; no allocation).  The upload is ordered on the CURRENT stream only: renders in flight on other
+        streams (harness.capture_pipelined) would read a half-written weight image, so a refresh is refused while the owning harness reports frames
+        in flight (`_in_flight`, set by the harness): drain_pipeline() first.  half=True additionally makes sure the fp16 tables exist."""
         sig = self._signature()
+        if self._net is not None and sig != self._net_sig and getattr(self, "_in_flight", None) is not None and self._in_flight() > 0:
+            raise RuntimeError("the network's parameters changed while pipelined frames are in flight: drain_pipeline() before updating weights")
         if self._net is None or sig != self._net_sig:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("the network's parameters changed and its packed weights cannot be refreshed while the stream is being captured into "
@@ -79,7 +83,13 @@ class NeRFNetwork(NeRFRenderer):
     def _autocast_half():
         """True when the caller runs under torch.cuda.amp.autocast with fp16 (trainer.py:561, Trainer(fp16=True)): the reference then casts
         the hash table to half (gridencoder/grid.py:43-44) and every nn.Linear computes in half."""
-        return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16
+        if not torch.is_autocast_enabled("cuda"):
+            return False
+        if torch.get_autocast_dtype("cuda") != torch.float16:
+            # the grid encoder follows the reference and casts its table to half under ANY autocast (grid.py:43-44) while the layers would run
+            # in the other type: a combination the reference never uses and nothing here implements
+            raise RuntimeError("autocast with a dtype other than float16 is not implemented (the reference's Trainer uses fp16, trainer.py:561)")
+        return True
 
     def _wants_grad(self, *inputs):
         """Differentiable path only in train() mode with autograd recording (Trainer.train_one_epoch calls model.train(), evaluate /

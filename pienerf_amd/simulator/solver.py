@@ -227,6 +227,12 @@ class Simulator:
         with torch.cuda.stream(st) if st is not None else _null_ctx():
             check(lib().pn_sim_update_force(self.n_k, int(vid), f3.ctypes.data if f3 is not None else None, float(self.dx), ptr(self.IP_kernel),
                                             ptr(self.IP_rho), ptr(self.IP_Nx), ptr(self.dof_f), stream_ptr()), "update_force")
+        if st is not None:
+            # ... and before whatever the caller enqueues next on ITS stream: a substep launched there (sim.stepforward(), a whole-step graph) must
+            # not read dof_f while the kernel above is still writing it
+            ev = torch.cuda.Event()
+            ev.record(st)
+            torch.cuda.current_stream(self.device).wait_event(ev)
 
     def update_force(self, vid, f):  # solver.py:578-588
         """dof_f = the pick force `f` on IP `vid`, written whole by one launch on `force_stream` (or the current stream): it acts from the

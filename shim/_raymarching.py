@@ -7,10 +7,26 @@ from pienerf_amd._lib import check, lib, ptr, require_gpu, stream_ptr
 
 
 def _c(*ts):
+    """CHECK_CUDA / CHECK_CONTIGUOUS, and the element types the reference's kernels hard-code (data_ptr<float>() / <int>() / <uint8_t>() throw on anything
+    else): a half or int64 tensor must not be reinterpreted."""
     for t in ts:
         if not t.is_contiguous():
-            raise RuntimeError("expected a contiguous tensor")  # CHECK_CONTIGUOUS
+            raise RuntimeError("expected a contiguous tensor")
+        if t.dtype not in (torch.float32, torch.int32, torch.uint8):
+            raise RuntimeError(f"expected a float32, int32 or uint8 tensor, got {t.dtype}")
     require_gpu(*ts)
+
+
+def _f32(*ts):
+    for t in ts:
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"expected a float tensor, got {t.dtype}")
+
+
+def _i32(*ts):
+    for t in ts:
+        if t.dtype != torch.int32:
+            raise RuntimeError(f"expected an int tensor, got {t.dtype}")
 
 
 def near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars):
@@ -66,12 +82,21 @@ def march_rays_quadratic_bending(pig_cnt, pig_bgn, pig_idx, n_vtx, n_grid, p_def
                                  deltas, noises):
     _c(pig_cnt, pig_bgn, pig_idx, p_def, p_ori, F_IP, dF_IP, bbmin, bbmax, resolution, cut_bounds, rays_alive, rays_t, rays_o, rays_d, grid, near, far, xyzs, dirs,
        deltas, noises)
+    _i32(pig_cnt, pig_bgn, pig_idx, resolution, rays_alive)
+    _f32(p_def, p_ori, F_IP, dF_IP, bbmin, bbmax, cut_bounds, rays_t, rays_o, rays_d, near, far, xyzs, dirs, deltas, noises)
+    if grid.dtype != torch.uint8:
+        raise RuntimeError(f"expected a uint8 density bitfield, got {grid.dtype}")
     err = torch.zeros(1, dtype=torch.int32, device=xyzs.device)
     check(lib().pn_march_rays_quadratic_bending(ptr(pig_cnt), ptr(pig_bgn), ptr(pig_idx), int(n_vtx), int(n_grid), ptr(p_def), ptr(p_ori), ptr(F_IP), ptr(dF_IP),
                                                 int(max_iter_num), ptr(bbmin), ptr(bbmax), float(hgs), ptr(resolution), int(num_seek_IP), float(IP_dx), int(bool(cut)),
                                                 ptr(cut_bounds), int(n_alive), int(n_step), ptr(rays_alive), ptr(rays_t), ptr(rays_o), ptr(rays_d), float(bound),
                                                 float(dt_gamma), int(max_steps), int(C), int(H), ptr(grid), ptr(near), ptr(far), ptr(xyzs), ptr(dirs), ptr(deltas),
                                                 ptr(noises), ptr(err), stream_ptr()), "march_rays_quadratic_bending")
+    # the reference blocks the host on an event in every call (raymarching.cu:1481-1482) and printf's "ERROR: g0=..." for points outside the spatial
+    # hash (:1221-1222); here the same wait reads the device flags and raises
+    flags = int(err.item())
+    if flags:
+        raise RuntimeError(f"march_rays_quadratic_bending: device error flags {flags:#x} (1: sample outside the spatial hash, 8: candidate-list capacity)")
 
 
 def composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):

@@ -128,3 +128,42 @@ def test_tile_parallel_two_ranks_on_gpu(tmp_path):
         for f in range(4):
             assert np.array_equal(got[f], want[f]), (r, f)
     assert np.abs(want[0] - want[3]).max() > 1e-4
+
+
+@pytest.mark.parametrize("world,dedicated", [(2, "off"), (2, "on"), (3, "auto")])
+def test_bench_multi_gpu_command_line_dry_run(tmp_path, world, dedicated):
+    """`bench.py --gpus N` exactly as the driver launches it (torch.distributed.run, one rank per process), with PN_DIST_BACKEND=gloo so that the
+    N ranks can share the test box's one GPU (RCCL refuses that): the frame-parallel path of BASELINE configs[3] end to end — process group,
+    checkpoint broadcast, both placements of the simulator (owner renders too / owner only simulates), more frames than the snapshot ring holds,
+    max-over-ranks timing, and ONE JSON line on rank 0 that carries the rank count, the frames every rank completed and the owner's ceiling."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    K, W, P = 10, 3, 4
+    env = dict(os.environ, PN_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), "bench.py", "--gpus", str(world), "--steps", str(K), "--warmup", str(W), "--prime", str(P), "--no-cpu-baseline", "--no-extras",
+           "--dedicated-sim", dedicated]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    cfg = d["config"]
+    assert d["n_gpus"] == world and cfg["ranks"] == world and cfg["rccl_ranks"] == world and cfg["dist_backend"] == "gloo"
+    assert d["scaling"] == "weak" and d["value"] > 0 and d["value_unprimed"] > 0 and d["steps"] == K and d["warmup"] == W
+    want_dedicated = {"off": False, "on": True, "auto": world >= 3}[dedicated]
+    assert cfg["dedicated_sim"] == want_dedicated
+    frames = cfg["frames_per_rank"]
+    total = world * (2 * (W + K) + P)
+    assert len(frames) == world and sum(frames) == total, (frames, total)
+    if want_dedicated:
+        assert frames[0] == 0 and min(frames[1:]) > 0
+    else:
+        assert min(frames) > 0 and max(frames) - min(frames) <= 1
+    assert total > 2 * (2 * 2 + 2)                    # more frames than twice the snapshot ring (lanes x depth + ahead)
+    ceil = d["frame_parallel_ceiling"]
+    assert ceil["owner_frames_per_s"] > 0 and ceil["substep_ms_alone"] > 0.05     # (the ranks share ONE GPU here: the figure itself means nothing)
+    assert d["roofline"]["frac"] > 0 and "parallelism" in cfg and f"{world} RCCL ranks" in cfg["parallelism"]

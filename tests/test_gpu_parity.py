@@ -580,3 +580,66 @@ def test_staged_ray_batches_equal_one_shot_frames(small_cloud, small_opt, ckpt, 
         assert np.array_equal(got[f][1]["image"], want[f]["image"]) and np.array_equal(got[f][1]["depth_0"], want[f]["depth_0"]), f
         assert np.array_equal(got[f][1]["depth"], want[f]["depth"], equal_nan=True), f
     assert (st._pipe_backend.continued > 0) == (n_trips == 2)   # (the simulator runs ahead of the frames: its dof is not the eager harness's)
+
+
+def test_force_change_is_ordered_against_substeps_on_the_callers_stream(small_cloud, small_opt, ckpt):
+    """The force kernel runs on Simulator.force_stream (the harness's simulator stream); a substep that the CALLER then launches on its own
+    stream — sim.stepforward() directly, or the whole-step graph of capture() / step_graph() — must wait for it (round-2 advisor finding:
+    the side stream waited for the caller, the caller never waited back).  Trajectories against the oracle, repeated to give a race a chance."""
+    from pienerf_amd.harness import SimRenderHarness
+    opt = dict(small_opt, W=32, H=32)
+    f1, f2 = np.array([300.0, 100.0, -200.0]), np.array([-150.0, 220.0, 90.0])
+    for rep in range(3):
+        h = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV)
+        assert h.sim.force_stream is not None
+        ref = make_oracle_sim(small_cloud, opt)
+        vid = h.sim.n_IP // 2
+        for step in range(8):
+            f = (f1, f2)[step % 2] * (1 + 0.1 * step)
+            h.sim.update_force(vid, f)          # on the side stream ...
+            ref.update_force(vid, f)
+            h.sim.stepforward()                 # ... the substep on the current stream, no synchronisation in between
+            ref.stepforward()
+        h.synchronize()
+        assert rel_err(h.sim.dof.cpu().numpy().reshape(-1, 3) - ref.dof_rest, ref.dof - ref.dof_rest) < 1e-6, rep
+    g = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture(n_trips=8)
+    ref = make_oracle_sim(small_cloud, opt)
+    vid = g.sim.n_IP // 2
+    for step in range(8):
+        if step in (1, 4):
+            g.sim.update_force(vid, f1 if step == 1 else f2)
+            ref.update_force(vid, f1 if step == 1 else f2)
+        if step == 6:
+            g.sim.clear_force()
+            ref.clear_force()
+        g.step_graph()
+        ref.stepforward()
+    g.finish_graph_frame()
+    g.synchronize()
+    assert rel_err(g.sim.dof.cpu().numpy().reshape(-1, 3) - ref.dof_rest, ref.dof - ref.dof_rest) < 1e-6
+
+
+def test_pipelined_frames_without_a_pose_use_the_harness_pose(small_cloud, small_opt, ckpt):
+    """step_pipelined(pose=P) followed by step_pipelined() calls: every workspace keeps its own device copy of the camera, so a frame without
+    a pose must re-upload the harness's current pose where the workspace last rendered another one (round-2 advisor finding: frames
+    alternated between stale poses), and a change of h.pose after capture is picked up."""
+    from pienerf_amd.harness import SimRenderHarness
+    opt = dict(small_opt, W=40, H=40)
+    eager = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV)
+    pipe = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture_pipelined(lanes=2, depth=2, n_trips=8)
+    P = scene.orbit_pose(opt["radius"], 40.0, -20.0)
+    Q = scene.orbit_pose(opt["radius"], -30.0, 10.0)
+    plan = [P, None, None, None, None, None, "Q", None, None]       # frame 0 with P, then the default pose, then h.pose = Q from frame 6 on
+    want, got = [], []
+    for p in plan:
+        if isinstance(p, str):
+            eager.pose = pipe.pose = Q
+            p = None
+        want.append(eager.to_host(eager.step(pose=p))["image"])
+        got += [(i, r["image"].copy()) for i, r in pipe.step_pipelined(pose=p)]
+    got += [(i, r["image"].copy()) for i, r in pipe.drain_pipeline()]
+    eager.synchronize()
+    assert [i for i, _ in got] == list(range(len(plan)))
+    for f in range(len(plan)):
+        assert np.array_equal(got[f][1], want[f]), f
+    assert not np.array_equal(want[0], want[1]) and not np.array_equal(want[5], want[6])

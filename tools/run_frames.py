@@ -20,9 +20,21 @@ ap.add_argument("--no-sim", action="store_true")
 ap.add_argument("--W", type=int, default=800)
 ap.add_argument("--graph", action="store_true")
 ap.add_argument("--no-counters", action="store_true", help="skip the extra frame rendered with the march work counters on")
+ap.add_argument("--config", choices=("chair", "stress", "trex"), default="chair", help="bench.py's workloads (stress: with its 4096-ray batches)")
 args = ap.parse_args()
-opt = scene.default_opt(W=args.W, H=args.W)
-h = SimRenderHarness(opt, device="cuda:0")
+if args.config == "chair":
+    opt = scene.default_opt(W=args.W, H=args.W)
+    h = SimRenderHarness(opt, device="cuda:0")
+else:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    opt, cloud, ckpt, pose, force, _ = bench.make_config(args.config)
+    if args.config == "stress":
+        opt["ray_batch"] = int(opt.get("max_ray_batch", 4096))
+    h = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device="cuda:0")
+    h.pose = pose
+    if force is not None:
+        h.sim.update_force(h.sim.n_IP // 2, force)
 for _ in range(args.presim):
     h.sim.stepforward()
 if args.graph:
