@@ -68,29 +68,11 @@ __device__ __forceinline__ _Float16 rounded_product<_Float16>(float w, _Float16 
 // T = float: kernel_grid<float,3,C>.  T = _Float16: kernel_grid<at::Half,3,C> — the table and the outputs are half, positions and weights
 // stay float, and `results[ch] += w * grid[index + ch]` rounds the float product to half and adds half + half (c10::Half operators).
 template <uint32_t C, typename T>
-__global__ void __launch_bounds__(256) k_grid_encode(const float* __restrict__ inputs, const T* __restrict__ emb, PnGridLevels lv, uint32_t B,
-                                                     int align_corners, uint32_t interp, int out_bl_major, T* __restrict__ outputs) {
-    // [L,B,C] output (the reference kernel's layout): blockIdx.y = level, a thread per sample — one level's table at a time, neighbouring lanes write
-    // neighbouring rows.  [B,L*C] output (what grid.py:57 gets with an extra permute pass): a thread per (sample, level) with the LEVEL varying
-    // fastest, so that the lanes of a wave write consecutive C-vectors of the same rows (with a thread per sample the stores were L*C*4 bytes apart:
-    // 0.309 ms against 0.172 ms per 1.02 M samples).
-    uint32_t b, level;
-    if (out_bl_major) {
-        const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        b = (uint32_t)(g / lv.L);
-        level = (uint32_t)(g % lv.L);
-    } else {
-        b = blockIdx.x * blockDim.x + threadIdx.x;
-        level = blockIdx.y;
-    }
-    if (b >= B) return;
-    T* out = out_bl_major ? outputs + ((size_t)b * lv.L + level) * C : outputs + ((size_t)level * B + b) * C;
-    const float in0 = inputs[b * 3], in1 = inputs[b * 3 + 1], in2 = inputs[b * 3 + 2];
-    if (in0 < 0 || in0 > 1 || in1 < 0 || in1 > 1 || in2 < 0 || in2 > 1) {
+__device__ __forceinline__ void grid_encode_one(float in0, float in1, float in2, const T* __restrict__ emb, const PnGridLevels& lv, uint32_t level, int align_corners,
+                                                uint32_t interp, T (&res)[C]) {
 #pragma unroll
-        for (uint32_t c = 0; c < C; c++) out[c] = (T)0.0f;
-        return;
-    }
+    for (uint32_t c = 0; c < C; c++) res[c] = (T)0.0f;
+    if (in0 < 0 || in0 > 1 || in1 < 0 || in1 > 1 || in2 < 0 || in2 > 1) return;  // gridencoder.cu:113-133
     const T* __restrict__ table = emb + (size_t)lv.offset[level] * C;
     const LevelIdx LI = level_idx(lv, level, align_corners);
     const float scale = lv.scale[level];
@@ -103,9 +85,6 @@ __global__ void __launch_bounds__(256) k_grid_encode(const float* __restrict__ i
         pos[d] -= (float)pg[d];
         if (interp == 1) pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
     }
-    T res[C];
-#pragma unroll
-    for (uint32_t c = 0; c < C; c++) res[c] = (T)0.0f;
 #pragma unroll
     for (uint32_t idx = 0; idx < 8; idx++) {
         float w = 1;
@@ -125,8 +104,46 @@ __global__ void __launch_bounds__(256) k_grid_encode(const float* __restrict__ i
             for (uint32_t c = 0; c < C; c++) res[c] = res[c] + rounded_product<T>(w, table[index + c]);
         }
     }
+}
+
+// [L,B,C] output (the reference kernel's own layout, gridencoder.cu:105): blockIdx.y = level, a thread per sample — the launch sweeps one level's
+// table at a time (it stays in the XCD L2s), neighbouring lanes write neighbouring rows.
+template <uint32_t C, typename T>
+__global__ void __launch_bounds__(256) k_grid_encode(const float* __restrict__ inputs, const T* __restrict__ emb, PnGridLevels lv, uint32_t B,
+                                                     int align_corners, uint32_t interp, T* __restrict__ outputs) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y;
+    T res[C];
+    grid_encode_one<C, T>(inputs[b * 3], inputs[b * 3 + 1], inputs[b * 3 + 2], emb, lv, level, align_corners, interp, res);
+    T* out = outputs + ((size_t)level * B + b) * C;
 #pragma unroll
     for (uint32_t c = 0; c < C; c++) out[c] = res[c];
+}
+
+// [B,L*C] output (what gridencoder/grid.py:57 obtains with an extra permute pass).  A thread per sample that wrote its C values of every level
+// straight to its row put neighbouring lanes' stores L*C*4 bytes apart (0.309 ms per 1.02 M samples against 0.172 for [L,B,C]); a thread per
+// (sample, level) with the level varying fastest writes coalesced but gathers from all L tables at once (0.306 ms: the tables no longer take turns
+// in L2).  Here a workgroup keeps its 256 samples, walks the levels like the [L,B,C] launch does — the workgroups of a launch move through the
+// levels roughly together — collects the rows in LDS (row stride padded by one bank) and writes them out whole.
+template <uint32_t C, typename T>
+__global__ void __launch_bounds__(256) k_grid_encode_rows(const float* __restrict__ inputs, const T* __restrict__ emb, PnGridLevels lv, uint32_t B,
+                                                          int align_corners, uint32_t interp, T* __restrict__ outputs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rows_raw[];
+    T* rows = reinterpret_cast<T*>(rows_raw);
+    const uint32_t row = lv.L * C, stride = row + (sizeof(T) == 4 ? 1 : 2);
+    const uint32_t b0 = blockIdx.x * 256u, b = b0 + threadIdx.x;
+    float in0 = -1.f, in1 = -1.f, in2 = -1.f;  // past the end: encoded as out of range, never written
+    if (b < B) { in0 = inputs[b * 3]; in1 = inputs[b * 3 + 1]; in2 = inputs[b * 3 + 2]; }
+    for (uint32_t level = 0; level < lv.L; level++) {
+        T res[C];
+        grid_encode_one<C, T>(in0, in1, in2, emb, lv, level, align_corners, interp, res);
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) rows[threadIdx.x * stride + level * C + c] = res[c];
+    }
+    __syncthreads();
+    const uint32_t n_rows = min(256u, B - b0);
+    for (uint32_t i = threadIdx.x; i < n_rows * row; i += 256) outputs[(size_t)b0 * row + i] = rows[(i / row) * stride + (i % row)];
 }
 
 template <typename T>
@@ -139,12 +156,31 @@ static int grid_encode_launch(const float* inputs, const T* embeddings, const in
     PN_REQUIRE(gridtype <= 1 && interp <= 1);
     PnGridLevels lv;
     if (pn_fill_grid_levels(&lv, offsets_host, L, C, S, H, gridtype, align_corners)) { PN_REQUIRE(L >= 1 && L <= PN_MAX_LEVELS); }
-    dim3 grid(out_bl_major ? pn_div_up((uint64_t)B * L, 256) : pn_div_up(B, 256), out_bl_major ? 1 : L, 1);
-    switch (C) {
-        case 1: k_grid_encode<1, T><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
-        case 2: k_grid_encode<2, T><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
-        case 4: k_grid_encode<4, T><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
-        default: k_grid_encode<8, T><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, out_bl_major, outputs); break;
+    if (out_bl_major) {
+        const size_t lds = (size_t)256 * (L * C + (sizeof(T) == 4 ? 1 : 2)) * sizeof(T);
+        PN_REQUIRE(lds <= 150 * 1024);
+        const dim3 grid(pn_div_up(B, 256), 1, 1);
+#define PN_ROWS_LAUNCH(C_)                                                                                                                        \
+    do {                                                                                                                                          \
+        if (lds > 64 * 1024) /* opted into per call: rows this long (C = 8 with 16 levels) are not on any hot path */                             \
+            PN_HIP_CHECK(hipFuncSetAttribute((const void*)k_grid_encode_rows<C_, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
+        k_grid_encode_rows<C_, T><<<grid, 256, lds, st>>>(inputs, embeddings, lv, B, align_corners, interp, outputs);                            \
+    } while (0)
+        switch (C) {
+            case 1: PN_ROWS_LAUNCH(1); break;
+            case 2: PN_ROWS_LAUNCH(2); break;
+            case 4: PN_ROWS_LAUNCH(4); break;
+            default: PN_ROWS_LAUNCH(8); break;
+        }
+#undef PN_ROWS_LAUNCH
+    } else {
+        const dim3 grid(pn_div_up(B, 256), L, 1);
+        switch (C) {
+            case 1: k_grid_encode<1, T><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, outputs); break;
+            case 2: k_grid_encode<2, T><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, outputs); break;
+            case 4: k_grid_encode<4, T><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, outputs); break;
+            default: k_grid_encode<8, T><<<grid, 256, 0, st>>>(inputs, embeddings, lv, B, align_corners, interp, outputs); break;
+        }
     }
     PN_LAUNCH_CHECK();
     if (lv_out) *lv_out = lv;
