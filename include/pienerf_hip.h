@@ -338,17 +338,22 @@ int pn_sim_collect_rhs(int n_k, double dx, const int* csr_bg, const int* csr_cnt
 int pn_sim_matvec3(int n, const double* A, const double* X, double* Y, void* stream);
 
 /* Simulator.stepforward (simulator/solver.py:595-602) incl. compute_momentum (:574-576) and build_rhs (:541-571).
- * All vectors [10 n_k,3] fp64.  dof and dof_vel are updated in place.  work: >= pn_sim_work_doubles(n_k, n_IP) doubles. */
+ * All vectors [10 n_k,3] fp64.  dof and dof_vel are updated in place.  work: >= pn_sim_work_doubles(n_k, n_IP) doubles.
+ * prepared != 0: pn_sim_prepare has run on this `work` (the gather's chunk layout is there, and the per-IP rotations the local step's SVD is
+ * warm-started from — they carry over from one local/global iteration and substep to the next); 0: the layout is rebuilt in this call and every
+ * SVD starts from the identity. */
 int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, double dx, const int* topo, const int* csr_bg, const int* csr_cnt,
                        const int* csr_buf, const double* mu, const double* lam, const double* dNx, const double* dNx_csr, const int* csr_pos,
                        const double* Ainv,
                        const double* Mmat, const double* dof_rest, const double* rhs_rest, const double* rhs_gravity, const double* dof_f,
-                       double* dof, double* dof_vel, double* work, void* stream);
+                       double* dof, double* dof_vel, double* work, int prepared, void* stream);
 /* dNx_csr (may be NULL): dNx rows gathered in CSR order, dNx_csr[e] = dNx[csr_buf[e]] (30 doubles each), built once at
  * initialisation; with it collect_rhs streams contiguous memory (one workgroup per kernel) instead of chasing csr_buf.
  * csr_pos (may be NULL; needs dNx_csr): inverse of csr_buf, csr_pos[csr_buf[e]] = e; calc_elastic then also writes P once per
  * neighbour slot in CSR order and the gather has no index left to follow. */
 uint64_t pn_sim_work_doubles(int n_k, int n_IP);
+/* State-independent contents of `work` (once per simulator / per allocation of `work`), see pn_sim_stepforward. */
+int pn_sim_prepare(int n_k, int n_IP, const int* csr_bg, const int* csr_cnt, double* work, void* stream);
 
 /* Simulator.update_force (simulator/solver.py:578-588): dof_f [10 n_k,3] is overwritten, in ONE launch, with the pick force f3 of IP `vid`
  * (every other entry zero).  vid < 0: clear_force (:590-593), f3_host / topo / rho / Nx may then be NULL.  Enqueue it on the stream the

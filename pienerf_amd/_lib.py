@@ -84,7 +84,8 @@ SIGNATURES = {
     "pn_sim_calc_elastic": (i32, [i32, P, P, P, P, P, P, P]),
     "pn_sim_collect_rhs": (i32, [i32, f64, P, P, P, P, P, P, P, P, P, P]),
     "pn_sim_matvec3": (i32, [i32, P, P, P, P]),
-    "pn_sim_stepforward": (i32, [i32, i32, i32, f64, f64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "pn_sim_stepforward": (i32, [i32, i32, i32, f64, f64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, i32, P]),
+    "pn_sim_prepare": (i32, [i32, i32, P, P, P, P]),
     "pn_sim_work_doubles": (u64, [i32, i32]),
     "pn_sim_update_force": (i32, [i32, i32, P, f64, P, P, P, P, P]),
 }

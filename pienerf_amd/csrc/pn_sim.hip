@@ -88,21 +88,34 @@ __device__ __forceinline__ void jacobi_rot(M3& S, M3& Q) {
 }
 
 // F = U diag(sig) V^T with det U = det V = +1, |sig| descending, sig[2] signed (contract of wp.svd3, cuda_utils.py:107).
-__device__ void svd3(const M3& F, M3& U, double* sig, M3& V) {
+// Q0 (may be null): a rotation to start the Jacobi iteration from — the V of the same integration point one local/global iteration earlier.
+// F changes by ~1e-3 between iterations, so Q0^T (F^T F) Q0 is already diagonal to ~1e-6 and two sweeps finish what five do from the identity
+// (the chain below is what k_elastic's duration consists of: 8 of its 15 us).  The decomposition is the same up to rounding: R = U V^T and
+// U diag(s') V^T do not depend on where the iteration started.  tol: stop at off^2 <= tol dia^2.
+__device__ void svd3(const M3& F, M3& U, double* sig, M3& V, const M3* Q0 = nullptr, double tol = 1e-30) {
     M3 S, Q;
+    if (Q0) {
+        const M3 B0 = mul33(F, *Q0);  // S = (F Q0)^T (F Q0)
+        Q = *Q0;
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+        for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            S.m[i][j] = F.m[0][i] * F.m[0][j] + F.m[1][i] * F.m[1][j] + F.m[2][i] * F.m[2][j];
-            Q.m[i][j] = (i == j) ? 1.0 : 0.0;
-        }
+            for (int j = 0; j < 3; j++) S.m[i][j] = B0.m[0][i] * B0.m[0][j] + B0.m[1][i] * B0.m[1][j] + B0.m[2][i] * B0.m[2][j];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                S.m[i][j] = F.m[0][i] * F.m[0][j] + F.m[1][i] * F.m[1][j] + F.m[2][i] * F.m[2][j];
+                Q.m[i][j] = (i == j) ? 1.0 : 0.0;
+            }
+    }
     for (int sweep = 0; sweep < 32; sweep++) {
         const double off = S.m[0][1] * S.m[0][1] + S.m[0][2] * S.m[0][2] + S.m[1][2] * S.m[1][2];
         const double dia = S.m[0][0] * S.m[0][0] + S.m[1][1] * S.m[1][1] + S.m[2][2] * S.m[2][2];
         // fp64 rounding leaves off ~ 1e-32 dia however long one sweeps (a 1e-34 test never fires and all 32 sweeps run);
         // 1e-30 is reached one sweep after ~1e-15 (quadratic convergence) — same rule as the oracle
-        if (off <= 1e-30 * dia || off == 0.0) break;
+        if (off <= tol * dia || off == 0.0) break;
         jacobi_rot<0, 1>(S, Q);
         jacobi_rot<0, 2>(S, Q);
         jacobi_rot<1, 2>(S, Q);
@@ -235,7 +248,8 @@ extern "C" int pn_sim_update_F(int n_IP, const int* topo, const double* dof, con
 __global__ void __launch_bounds__(256) k_elastic(int n_IP, const int* __restrict__ topo, const double* __restrict__ dNx, const double* __restrict__ dof,
                                                  double* __restrict__ RF, double* __restrict__ VF, double* __restrict__ FF, double* __restrict__ P,
                                                  const double* __restrict__ mu, const double* __restrict__ lam, double dx3,
-                                                 const int* __restrict__ csr_pos = nullptr, double* __restrict__ P_csr = nullptr) {
+                                                 const int* __restrict__ csr_pos = nullptr, double* __restrict__ P_csr = nullptr, int dbg_nosvd = 0,
+                                                 double* __restrict__ Vstore = nullptr) {
     PN_SIM_PRIO();
     const int tid = threadIdx.x + blockIdx.x * blockDim.x;
     const int v = tid >> 3, i = tid & 7;
@@ -276,6 +290,26 @@ __global__ void __launch_bounds__(256) k_elastic(int n_IP, const int* __restrict
     if (i == 0) {
         M3 U, V;
         double sig[3], sp[3];
+        if (dbg_nosvd) {  // timing experiment (PN_SIM_DBG_NOSVD=1): results invalid
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) { U.m[r][c] = (r == c); V.m[r][c] = (r == c); }
+            sig[0] = Fm.m[0][0]; sig[1] = Fm.m[1][1]; sig[2] = Fm.m[2][2];
+        } else if (Vstore) {
+            // step driver: start from this IP's V of the previous local/global iteration (identity before the first substep), leave the new one.
+            // 1e-24: off-diagonals below 1e-12 of the diagonal, ten digits beyond the 1e-4 relative bar of the DOF displacements
+            M3 Q0;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) Q0.m[r][c] = Vstore[(size_t)v * 9 + r * 3 + c];
+            svd3(Fm, U, sig, V, &Q0, 1e-24);
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) Vstore[(size_t)v * 9 + r * 3 + c] = V.m[r][c];
+        } else
         svd3(Fm, U, sig, V);
         volume_invariant_project(sig, sp);
         const double m_ = mu ? mu[v] : 0.0, l_ = lam ? lam[v] : 0.0;
@@ -507,13 +541,16 @@ __global__ void __launch_bounds__(PN_GCH * 8) k_rhs_gather_chunk(const int2* __r
         red[slot][q][0] = a0; red[slot][q][1] = a1; red[slot][q][2] = a2;
     }
     __syncthreads();
-    if (t < 30) {
-        const int x = t / 3, r = t - x * 3;
-        double s = 0.0;
-        for (int sl = 0; sl < NS; sl++)
+    // 30 outputs x NS slots: half-wave o adds slot sl = lane % 32 of output o (its three columns), then a fixed xor tree over the 32 lanes
+    // (30 threads adding 96 values each one after the other were 2.5 us of this kernel's 6.3)
+    static_assert(NS == 32, "one half-wave per output");
+    if (t < 30 * NS) {
+        const int o = t >> 5, sl = t & 31;
+        const int x = o / 3, r = o - x * 3;
+        double s = (red[sl][x][r] + red[sl][10 + x][r]) + red[sl][20 + x][r];
 #pragma unroll
-            for (int cc = 0; cc < 3; cc++) s += red[sl][cc * 10 + x][r];
-        part[(size_t)b * 30 + t] = s;
+        for (int m = 16; m > 0; m >>= 1) s += shfl_xor_d(s, m);
+        if (sl == 0) part[(size_t)b * 30 + o] = s;
     }
 }
 
@@ -672,13 +709,36 @@ static inline uint64_t pn_gather_chunks_max(int n_k, int n_IP) { return (uint64_
 // tilde, last, momentum, tot [n_k*30 each] | P [n_IP*9] | P_csr [n_IP*8*9] | chunk sums [chunks_max*30] | plan: kc_bg [n_k+1] ints + chunk [chunks_max] int2
 extern "C" uint64_t pn_sim_work_doubles(int n_k, int n_IP) {
     const uint64_t ch = pn_gather_chunks_max(n_k, n_IP);
-    return (uint64_t)n_k * 30 * 4 + (uint64_t)n_IP * 9 + (uint64_t)n_IP * 8 * 9 + ch * 30 + ((uint64_t)n_k + 2) / 2 + 1 + ch + 1;
+    return (uint64_t)n_k * 30 * 4 + (uint64_t)n_IP * 9 + (uint64_t)n_IP * 8 * 9 + ch * 30 + ((uint64_t)n_k + 2) / 2 + 1 + ch + 1 + (uint64_t)n_IP * 9;
+}
+// where the per-IP rotations of the warm-started SVD live in `work` (behind everything else)
+static inline double* pn_sim_vstore(double* work, int n_k, int n_IP) { return work + (pn_sim_work_doubles(n_k, n_IP) - (uint64_t)n_IP * 9); }
+
+__global__ void __launch_bounds__(256) k_vstore_identity(int n_IP, double* __restrict__ Vstore) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_IP * 9) Vstore[t] = (t % 9) % 4 == 0 ? 1.0 : 0.0;
+}
+
+// Once per simulator (and again whenever `work` is re-allocated): what a substep needs in `work` but does not depend on the state — the chunk
+// layout of the balanced gather (rounds 1-2 rebuilt it in every substep: one launch of the ~42) and identity rotations for the warm-started SVD.
+extern "C" int pn_sim_prepare(int n_k, int n_IP, const int* csr_bg, const int* csr_cnt, double* work, void* stream) {
+    PN_REQUIRE(n_k > 0 && n_IP > 0 && csr_bg && csr_cnt && work);
+    hipStream_t st = (hipStream_t)stream;
+    const int n3 = n_k * 30;
+    const uint64_t chunks_max = pn_gather_chunks_max(n_k, n_IP);
+    double* part = work + 4 * (size_t)n3 + (size_t)n_IP * 9 + (size_t)n_IP * 8 * 9;
+    int* kc_bg = reinterpret_cast<int*>(part + chunks_max * 30);
+    int2* chunk = reinterpret_cast<int2*>(kc_bg + ((n_k + 2) & ~1));
+    k_gather_plan<<<1, 512, 0, st>>>(n_k, (int)chunks_max, csr_bg, csr_cnt, kc_bg, chunk);
+    k_vstore_identity<<<pn_div_up((uint64_t)n_IP * 9, 256), 256, 0, st>>>(n_IP, pn_sim_vstore(work, n_k, n_IP));
+    PN_LAUNCH_CHECK();
+    return PN_OK;
 }
 
 extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, double dx, const int* topo, const int* csr_bg, const int* csr_cnt,
                                   const int* csr_buf, const double* mu, const double* lam, const double* dNx, const double* dNx_csr,
                                   const int* csr_pos, const double* Ainv, const double* Mmat, const double* dof_rest, const double* rhs_rest,
-                                  const double* rhs_gravity, const double* dof_f, double* dof, double* dof_vel, double* work, void* stream) {
+                                  const double* rhs_gravity, const double* dof_f, double* dof, double* dof_vel, double* work, int prepared, void* stream) {
     PN_REQUIRE(n_k > 0 && n_IP > 0 && iters >= 0 && topo && csr_bg && csr_cnt && csr_buf && mu && lam && dNx && Ainv && Mmat);
     PN_REQUIRE(dof_rest && rhs_rest && rhs_gravity && dof_f && dof && dof_vel && work);
     hipStream_t st = (hipStream_t)stream;
@@ -698,6 +758,7 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
     // balanced gather (chunked lists + right-hand side assembled inside the matvec); PN_SIM_GATHER=kernel keeps one workgroup per kernel
     static const bool chunked_ok = [] { const char* v = getenv("PN_SIM_GATHER"); return !(v && strcmp(v, "kernel") == 0); }();
     static const bool fused_x = [] { const char* v = getenv("PN_SIM_GATHER"); return v && strcmp(v, "fused") == 0; }();
+    static const int dbg_nosvd = (int)pn_env_u32("PN_SIM_DBG_NOSVD", 0);
     const size_t xs_bytes = (size_t)n3 * sizeof(double);
     const bool chunked = pcsr && chunked_ok && xs_bytes <= 160 * 1024 - 1024;
     if (chunked) {
@@ -710,13 +771,15 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
                 if (dev_id >= 0 && dev_id < PN_MAX_DEVICES) granted[dev_id] = xs_bytes;
             }
         }
-        k_gather_plan<<<1, 512, 0, st>>>(n_k, (int)chunks_max, csr_bg, csr_cnt, kc_bg, chunk);
+        if (!prepared) k_gather_plan<<<1, 512, 0, st>>>(n_k, (int)chunks_max, csr_bg, csr_cnt, kc_bg, chunk);
     }
+    static const bool warm_svd = pn_env_u32("PN_SIM_COLD_SVD", 0) == 0;  // experiments: PN_SIM_COLD_SVD=1 starts every SVD from the identity (rounds 1-2)
+    double* Vstore = (prepared && warm_svd) ? pn_sim_vstore(work, n_k, n_IP) : nullptr;
     k_step_begin<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, dt, dof, dof_vel, tilde, last);
     k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Mmat, tilde, momentum, 1, dof_f, rhs_gravity);  // compute_momentum (:574-576)
     for (int it = 0; it < iters; it++) {
         k_elastic<<<pn_div_up((uint64_t)n_IP * 8, 256), 256, 0, st>>>(n_IP, topo, dNx, dof, nullptr, nullptr, nullptr, pcsr ? nullptr : P, mu, lam, dx3,
-                                                                      pcsr ? csr_pos : nullptr, pcsr ? P_csr : nullptr);
+                                                                      pcsr ? csr_pos : nullptr, pcsr ? P_csr : nullptr, dbg_nosvd, Vstore);
         if (chunked) {
             k_rhs_gather_chunk<<<(uint32_t)chunks_max, PN_GCH * 8, 0, st>>>(chunk, dNx_csr, P_csr, part);
             if (fused_x) {

@@ -74,6 +74,7 @@ class Simulator:
     def initialize(self):
         self.precompute()
         self._work = torch.empty(int(lib().pn_sim_work_doubles(self.n_k, self.n_IP)), dtype=torchfloat, device=self.device)
+        self._prepared = False  # pn_sim_prepare runs with the first substep (the CSR lists it reads are built further down)
         self.rhs_rest = (self.build_rhs() + self._matvec(self.Mmat, self.dof)).contiguous()   # solver.py:314
 
     def precompute(self):
@@ -213,10 +214,13 @@ class Simulator:
         return pos, F, dF
 
     def stepforward(self):  # solver.py:595-602
+        if not self._prepared:
+            check(lib().pn_sim_prepare(self.n_k, self.n_IP, ptr(self.kernel_bg), ptr(self.kernel_cnt), ptr(self._work), stream_ptr()), "sim_prepare")
+            self._prepared = True
         check(lib().pn_sim_stepforward(self.n_k, self.n_IP, int(self.iters), float(self.dt), float(self.dx), ptr(self.IP_kernel), ptr(self.kernel_bg),
                                        ptr(self.kernel_cnt), ptr(self.buffer), ptr(self.IP_mu), ptr(self.IP_lam), ptr(self.IP_dNx), ptr(self.dNx_csr), ptr(self.csr_pos), ptr(self.Ainv),
                                        ptr(self.Mmat), ptr(self.dof_rest), ptr(self.rhs_rest), ptr(self.rhs_gravity), ptr(self.dof_f), ptr(self.dof),
-                                       ptr(self.dof_vel), ptr(self._work), stream_ptr()), "stepforward")
+                                       ptr(self.dof_vel), ptr(self._work), 1, stream_ptr()), "stepforward")
 
     step = stepforward  # BASELINE.json's name for the same entry point
 
