@@ -91,5 +91,6 @@ struct pn_net {
 // internal launcher shared by pn_nerf_forward and the frame driver: evaluates the network on the `count` samples whose
 // slot ids are list[0..count) (list == NULL: slots 0..M-1); when ctl_count != NULL the count is read from device memory.
 // half != 0: the fp16 form (fp16 tables, fp16 MFMA, half-rounded activations); requires pn_net_enable_half to have been called.
+// blocks_cap > 0: at most that many workgroups (the waves stride over the tiles): launches that are expected to find (next to) nothing.
 int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* dirs, const int* list, const int* ctl_count, uint32_t M_max,
-                           float density_scale, float* sigmas, float* rgbs, int half, hipStream_t stream);
+                           float density_scale, float* sigmas, float* rgbs, int half, hipStream_t stream, uint32_t blocks_cap = 0);

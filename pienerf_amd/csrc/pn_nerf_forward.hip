@@ -947,13 +947,14 @@ __global__ void __launch_bounds__(PN_H_WAVES * 64, MINW) k_nerf_forward_h(const 
 }
 
 int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* dirs, const int* list, const int* ctl_count, uint32_t M_max,
-                           float density_scale, float* sigmas, float* rgbs, int half, hipStream_t stream) {
+                           float density_scale, float* sigmas, float* rgbs, int half, hipStream_t stream, uint32_t blocks_cap) {
     if (M_max == 0) return PN_OK;
     const uint32_t tiles = pn_div_up(M_max, 32);
     if (half) {
         PN_REQUIRE(net->emb_half);  // pn_net_enable_half first
         static const uint32_t max_blocks_h = pn_env_u32("PN_NERF_BLOCKS_H", 1024);  // 4 workgroups per CU
         uint32_t blocks = std::min(pn_div_up(tiles, PN_H_WAVES), max_blocks_h);
+        if (blocks_cap) blocks = std::min(blocks, blocks_cap);
         k_nerf_forward_h<4, 4><<<blocks, PN_H_WAVES * 64, PN_NET_HALF_BYTES, stream>>>((const PnFusedLevel*)net->fused_levels, (const uint32_t*)net->emb_half,
                                                                                      (const uint4*)net->whalf, net->bound, xyzs, dirs, list, ctl_count,
                                                                                      M_max, density_scale, sigmas, rgbs, nullptr, net->n_entries * 4u, 0);
@@ -963,6 +964,7 @@ int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* di
     static const uint32_t max_blocks = pn_env_u32("PN_NERF_BLOCKS", 512);  // 2 workgroups per CU x 256 CUs; waves stride over tiles
     uint32_t blocks = pn_div_up(tiles, PN_BF_WAVES);
     if (blocks > max_blocks) blocks = max_blocks;
+    if (blocks_cap) blocks = std::min(blocks, blocks_cap);
     k_nerf_forward<2, 4><<<blocks, PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES, stream>>>((const PnFusedLevel*)net->fused_levels, net->embeddings,
                                                                                   (const uint4*)net->wsplit, net->bound, xyzs, dirs, list, ctl_count,
                                                                                   M_max, density_scale, sigmas, rgbs, nullptr, 0);

@@ -1426,6 +1426,7 @@ extern "C" int pn_compact_rays(const int* rays_alive, uint32_t n, int* out, int*
 #define PN_MAX_TRIPS 1100
 #define PN_MIN_RAY_BATCH 64  // smallest pn_render_opts::ray_batch (sizes the group records of a workspace)
 #define PN_TRIP_BATCH 8
+#define PN_TRIP_MARGIN 2  // trips a captured render carries beyond what its sizing frame needed (harness: measured + 2)
 #define PN_TIMED_TRIPS 64
 
 struct pn_frame {
@@ -1903,7 +1904,11 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     // 4 composite/compact blocks per CU (measured: 8192 march blocks is ~2 % faster than one block per 32 rays, 2048 is 6 % slower).
     // PN_MARCH_GRID / PN_TRIP_GRID override for experiments.
     static const uint32_t march_grid_cfg = pn_env_u32("PN_MARCH_GRID", 8192), trip_grid_cfg = pn_env_u32("PN_TRIP_GRID", 1024);
+    // trips after the first find at most N / 8 rays in the typical frame (n_step = 8) = N / 256 chunks of 32: a grid of that size (the chunk loop takes
+    // care of frames with more) instead of 8192 mostly empty workgroups per launch — what an empty captured trip costs is dispatch
+    static const uint32_t march_grid_later_cfg = pn_env_u32("PN_MARCH_GRID_LATER", 0);
     const uint32_t march_grid = march_grid_cfg, trip_grid = std::min(nblk, trip_grid_cfg);
+    const uint32_t march_grid_later = march_grid_later_cfg ? march_grid_later_cfg : std::max(std::min(pn_div_up(N, 256), march_grid_cfg), (uint32_t)PN_SEGS);
     static const bool split_compact = pn_env_u32("PN_SPLIT_COMPACT", 0) != 0;  // experiments: composite and compaction as two launches (rounds 1-2)
     static const uint32_t tail_grid_cfg = pn_env_u32("PN_TAIL_GRID", 1024);  // x4 waves, one unfinished ray per wave at a time
     const uint32_t tail_grid = std::max(std::min(pn_div_up(N, 4), tail_grid_cfg), (uint32_t)PN_SEGS / 4);  // every tail segment needs a wave
@@ -1993,6 +1998,10 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     while (!done && t < PN_MAX_TRIPS) {
         const int batch = async_trips > 0 ? async_trips : PN_TRIP_BATCH;
         for (int k = 0; k < batch; k++, t++) {
+            // margin trips: a fixed-trip render (captured graphs) carries PN_TRIP_MARGIN more trips than the frame it was sized on needed, and they
+            // find no ray (or a few hundred stragglers).  What they cost is the dispatch of their launches' workgroups, so they get small grids —
+            // the chunk loops take care of whatever is alive — and the two-launch composite / compaction (the fused one needs a workgroup per chunk)
+            const bool margin = async_trips > PN_TRIP_MARGIN && k >= async_trips - PN_TRIP_MARGIN && !resume;
             int* cur = (t & 1) ? f->alive_b : f->alive_a;
             int* nxt = (t & 1) ? f->alive_a : f->alive_b;
             // trip 0 (every ray, one sample each) is dominated by rays crossing IP-free cells: a one-lane-per-ray pre-pass
@@ -2033,12 +2042,13 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                 if (io.t_resume) k_march_skip<<<nblk, 256, skip_lds, st>>>(mp, tb, io);
                 pnm::MarchParams mq = mp;
                 if (short_rays) mq.fars = f->fars_eff;  // written by trip 0's k_march_skip
-                launch_march(o->num_seek_IP, std::max(std::min(pn_div_up(N, 32), march_grid), (uint32_t)PN_SEGS), tail_grid, st, mq, tb, io);
+                launch_march(o->num_seek_IP, t == 0 ? std::max(std::min(pn_div_up(N, 32), march_grid), (uint32_t)PN_SEGS) : (margin ? 2u * PN_SEGS : march_grid_later),
+                             margin ? (uint32_t)PN_SEGS : tail_grid, st, mq, tb, io);
                 if (t == 0) k_list_pack<<<PN_SEGS, 256, 0, st>>>(f->trips + t, seg_samp, f->list_seg, (int)f->seg_cap, f->list);  // the only list trip
             }
             if (timed && stamp) k_stamp<<<1, 1, 0, st>>>(f->stamps + t * 3 + 1);
             else if (timed) PN_HIP_CHECK(hipEventRecord(f->ev[t][1], st));
-            rc = pn_nerf_forward_launch(net, f->xyzs, f->dirs, f->list, &f->trips[t].n_samples, N, o->density_scale, f->sigmas, f->rgbs, o->fp16, st);
+            rc = pn_nerf_forward_launch(net, f->xyzs, f->dirs, f->list, &f->trips[t].n_samples, N, o->density_scale, f->sigmas, f->rgbs, o->fp16, st, margin ? 64u : 0u);
             if (rc) return rc;
             if (timed) {
                 if (stamp) k_stamp<<<1, 1, 0, st>>>(f->stamps + t * 3 + 2);
@@ -2047,7 +2057,8 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             }
             PnGroup* g_cur = group_rays ? f->groups + (size_t)(t & 1) * f->max_groups : nullptr;
             PnGroup* g_nxt = group_rays ? f->groups + (size_t)((t + 1) & 1) * f->max_groups : nullptr;
-            if (!is_static && !split_compact) {
+            const uint32_t pair_grid = margin ? std::min(trip_grid, 64u) : trip_grid;
+            if (!is_static && !split_compact && !margin) {
                 // one workgroup per possible chunk: a chunk then only ever waits for workgroups with a lower index, which the dispatcher started
                 // before it (a bounded grid with chunk loops could leave a resident workgroup polling a chunk whose workgroup has no slot yet)
 #define PN_CC_LAUNCH(R_)                                                                                                                                   \
@@ -2061,9 +2072,9 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                 else PN_CC_LAUNCH(1);
 #undef PN_CC_LAUNCH
             } else {
-            k_composite<<<trip_grid, 256, 0, st>>>(0, 0, o->T_thresh, cur, f->rays_t, f->sigmas, f->rgbs, f->deltas, weights_sum, depth_0, f->acc_image,
+            k_composite<<<pair_grid, 256, 0, st>>>(0, 0, o->T_thresh, cur, f->rays_t, f->sigmas, f->rgbs, f->deltas, weights_sum, depth_0, f->acc_image,
                                                    f->trips + t, f->chunk_counts, g_cur, group_rays, n_groups > 1 ? f->group_cnt : nullptr);
-            k_compact<<<trip_grid, 256, 0, st>>>(cur, 0, f->chunk_counts, nxt, nullptr, f->trips + t, f->trips + t + 1, N, o->max_steps, is_static ? 0 : 1,
+            k_compact<<<pair_grid, 256, 0, st>>>(cur, 0, f->chunk_counts, nxt, nullptr, f->trips + t, f->trips + t + 1, N, o->max_steps, is_static ? 0 : 1,
                                                  is_static ? nullptr : f->seg_counters, f->tail_counts + t, g_cur, g_nxt, f->group_cnt, group_rays, n_groups);
             }
         }
