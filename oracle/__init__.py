@@ -1,20 +1,21 @@
-"""ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY PARTLY PINNED (see below), UNPINNED FOR THE CUDA/WARP KERNELS.
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY: RENDER HALF PINNED AGAINST THE REFERENCE'S OWN KERNELS, SIMULATOR HALF UNPINNED (see below).
 
 CPU restatement of the PIE-NeRF simulate-and-render hot path.
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import this package; nothing under ``pienerf_amd/`` does.
 
-Pinning: the reference (FYTalon/pienerf) ships no tests, golden vectors or
-fixtures.  The parts of it that import or can be extracted from its source in
-the build container were RUN there and their outputs committed as fixtures
-(tests/golden/make_golden_ref.py -> opts_*.json, ref_kat.npz, ref_bindings.json:
-get_opts, trunc_exp forward/backward, get_rays, OrbitCamera, nerf_matrix_to_ngp,
-the colour-space helpers, the GridEncoder table layout, the pybind signatures);
-tests/test_golden_ref.py holds this package against them.  Its CUDA/Warp
-implementation can neither be compiled nor imported there: for
-the march, composite, encoders, MLP and the simulator substep the status is
-"parity unpinned" — pinned by independent-maths checks in
-``tests/test_oracle_*.py`` instead.
+Pinning: the reference (FYTalon/pienerf) ships no tests, golden vectors or fixtures.
+  * Host-side pieces that import or can be extracted from its source in the build container were RUN there and their outputs committed as
+    fixtures (tests/golden/make_golden_ref.py -> opts_*.json, ref_kat.npz, ref_bindings.json: get_opts, trunc_exp forward/backward, get_rays,
+    OrbitCamera, nerf_matrix_to_ngp, the colour-space helpers, the GridEncoder table layout, the pybind signatures); tests/test_golden_ref.py
+    holds this package against them.
+  * Its three CUDA extensions (raymarching, gridencoder, shencoder) are compiled for gfx950 from the sources where they lie by
+    ``oracle/ref_build.py`` -> ``oracle/_ref/*.so`` (test-only torch extensions, git-ignored, travel to the GPU box).  tests/test_gpu_ref.py
+    runs them beside the HIP path, which the other GPU tests hold against THIS restatement on the same inputs: march / static march / training
+    march / near-far / morton / packbits / composite bit for bit with the no-contraction build, encoders bit-identical to the contracting build.
+  * The Warp simulator kernels (warp-lang is absent: SURVEY.md §8c) can neither be compiled nor imported: for R1-R6 the status is
+    "parity unpinned" — pinned by independent-maths checks in ``tests/test_oracle_sim.py`` instead (numpy SVD polar factor, partition of unity,
+    the literal (30 n_k)^2 matrices, a numpy transcription of stepforward).
 
 Layout:
   render_oracle.cpp  R7-R16  (march w/ inverse-GMLS warp, composite, compaction,
