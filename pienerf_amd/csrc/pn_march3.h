@@ -182,8 +182,20 @@ __device__ __forceinline__ int cell_coord(float v, float lo, float hgs, float rh
 // `cell_bits` (may be null): bit c set <=> search cell c has candidates, held in LDS by the caller — the emptiness test then costs an LDS read
 // instead of a dependent global round trip every third hop or so.
 // `far_override` >= 0: the ray's end (see ray_end_of_candidates) instead of a.fars[index].
+// `cell_bits2` (may be null; with cell_bits, no --cut, fixed step, one cascade): LATE START.  Most of the ~100 hops of a ray in here cross
+// cells that are nowhere near a candidate, and the only thing the caller needs is the element at which the chain first meets one.  The t-sequence is
+// a lattice (Binade) whatever the chain visits, and WHICH elements it visits is local: from any visited element of a voxel V the chain computes
+// tt ~ the parameter at which the ray leaves V and lands on the first lattice element >= tt — so an element e is visited whenever its predecessor p
+// lies safely inside its voxel (p < tt_p - margin, tt_p = the chain's own exit expression evaluated at p) and e lies safely behind that exit
+// (e >= tt_p + margin): whichever element of p's voxel the chain is on, it computes an exit within the margin of tt_p and lands on e (and if an
+// ambiguity further back made it skip p's voxel, it landed on the first element behind p: e again).  So: sample the ray forward every 0.9 cell
+// lengths until the first sample whose cell is within one cell of a cell with candidates (the map that also ends the rays, ray_end_of_candidates:
+// every point before that sample lies in a cell without candidates, with a whole cell of slack for the rounding of the reference's own cell
+// arithmetic), take the last lattice element before it that passes the test, and run the exact hops from there — a handful instead of a hundred.
+// No such element within 12 tries, another binade in between, a direction nearly parallel to a voxel face (margin too wide): the walk starts
+// where it always did.  Bit-identical by construction, and the march tests compare every ray with the oracle and with the reference's own kernel.
 __device__ inline float skip_empty_cells(const MarchParams& a, const March2Tables& tb, int index, float noise, unsigned* n_iter_out,
-                                         const uint32_t* cell_bits = nullptr, float far_override = -1.0f) {
+                                         const uint32_t* cell_bits = nullptr, float far_override = -1.0f, const uint32_t* cell_bits2 = nullptr) {
     const Float3 o = *reinterpret_cast<const Float3*>(a.rays_o + (size_t)index * 3), d = *reinterpret_cast<const Float3*>(a.rays_d + (size_t)index * 3);
     const float ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
     const uint32_t H = a.H, C = a.C;
@@ -223,6 +235,45 @@ __device__ inline float skip_empty_cells(const MarchParams& a, const March2Table
         // The common case (no --cut, emptiness bits in LDS) with as few branches as the semantics allow: the kernel is issue-bound (its busy
         // waves share a third of the SIMDs) and the general loop below costs ~25 exec-mask branches per hop.  Same expressions, same order.
         const float Hm1 = (float)(H - 1);
+        if (cell_bits2 && fixed && one_cascade && a.bound <= 1.0f) {  // late start (see above); bound <= 1: mip_bound = fminf(2^0, bound) = bound
+            const float dts = 0.9f * a.hgs * __builtin_amdgcn_rsqf(dx * dx + dy * dy + dz * dz);
+            if (dts > 0.0f && far - t < 1e3f * dts) {
+                float s_prev = t, sm = t;
+                bool hit = false;
+                while (true) {
+                    const int g0 = min(max((int)floorf((ox + sm * dx - bmin0) * rhgs), 0), r0 - 1);
+                    const int g1 = min(max((int)floorf((oy + sm * dy - bmin1) * rhgs), 0), r1 - 1);
+                    const int g2 = min(max((int)floorf((oz + sm * dz - bmin2) * rhgs), 0), r2 - 1);
+                    const int gid = g2 * r1 * r0 + g1 * r0 + g0;
+                    if ((cell_bits2[gid >> 5] >> (gid & 31)) & 1u) { hit = true; break; }
+                    if (!(sm < far)) break;
+                    s_prev = sm;
+                    sm = fminf(sm + dts, far);
+                }
+                if (!hit) { *n_iter_out = 0; return far; }  // no candidate anywhere near the ray: the chain walks to `far` and emits nothing
+                bn = binade_of<1>(t, D);
+                const float kcap = bn.ok ? floorf(16777215.0f / (bn.Dq * scalbnf(1.0f, 150 - (int)(__float_as_uint(t) >> 23)))) - 2.0f : 0.0f;
+                const float rmax = fmaxf(fabsf(rdx), fmaxf(fabsf(rdy), fabsf(rdz)));
+                const float margin = 3e-5f * fmaxf(1.0f, fabsf(t)) + 2e-6f * rmax;  // ~60 ulp of t + the error of (face - x) * (1 / d) for the widest 1 / d
+                if (bn.ok && s_prev > t && s_prev < bn.top && rmax < 1e3f) {
+                    float kf = fminf(floorf((s_prev - t) * bn.rDq), kcap);
+                    if (kf >= 1.0f && t + kf * bn.Dq > s_prev) kf -= 1.0f;
+                    for (int tries = 0; tries < 12 && kf >= 1.0f; tries++, kf -= 1.0f) {
+                        const float e = t + kf * bn.Dq, p = t + (kf - 1.0f) * bn.Dq;  // exact: both inside the binade, k below the exactness cap
+                        const float x = clampf(ox + p * dx, lo0, hi0), y = clampf(oy + p * dy, lo1, hi1), z = clampf(oz + p * dz, lo2, hi2);
+                        const int nx = (int)clampf((x * rbound + 1) * halfH, 0.0f, Hm1);
+                        const int ny = (int)clampf((y * rbound + 1) * halfH, 0.0f, Hm1);
+                        const int nz = (int)clampf((z * rbound + 1) * halfH, 0.0f, Hm1);
+                        const float tx = ((((float)nx + sx) * rH * 2 - 1) * a.bound - x) * rdx;
+                        const float ty = ((((float)ny + sy) * rH * 2 - 1) * a.bound - y) * rdy;
+                        const float tz = ((((float)nz + sz) * rH * 2 - 1) * a.bound - z) * rdz;
+                        const float ttp = p + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+                        if (p < ttp - margin && e >= ttp + margin && e < far) { t = e; break; }
+                    }
+                }
+                bn.Dq = bn.rDq = 0.f; bn.top = -1.f; bn.ok = false;  // the hop loop below sets its own
+            }
+        }
         while (true) {
             const float x = clampf(ox + t * dx, lo0, hi0);
             const float y = clampf(oy + t * dy, lo1, hi1);
@@ -498,20 +549,30 @@ __device__ __forceinline__ void eval_scan(const MarchParams& a, const March2Tabl
                 // if / else-if chain is exactly this): the compiler's branchy form of the chain cost ~55 instructions and four
                 // exec-mask branches per candidate, this one 21 and none.  The IP id travels with the distance, so the selected
                 // entries need no second fetch.
-                float d0 = FLT_MAX, d1 = FLT_MAX, d2 = FLT_MAX;
-                auto insert = [&](const float4& v, bool valid) {
+                // Round 3: the three running minima are 64-bit KEYS (distance bits << 32 | position in the list), compared as doubles: for
+                // non-negative floats the bit pattern orders like the value, the position breaks ties towards the earlier candidate — exactly the
+                // sequential strict-'<' insertion — and any such pattern is a finite positive double (a float's exponent field never fills the
+                // double's), so v_min_f64 / v_max_f64 order the keys: five instructions per candidate instead of thirteen selects (a wave pays for
+                // its longest list, ~60 entries in the dense cells: the scan is more than half of pass 1's VALU instructions).  The ids of the
+                // winners are read back from the list afterwards.  Sentinel = (FLT_MAX bits, 0): a candidate at distance FLT_MAX, inf or NaN
+                // never enters, as `d < FLT_MAX` never holds for it.
+                const double sent = __hiloint2double(0x7F7FFFFF, 0);
+                double m0 = sent, m1 = sent, m2 = sent;
+                auto kmin = [](double a_, double b_) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a_), "v"(b_)); return r; };
+                auto kmax = [](double a_, double b_) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a_), "v"(b_)); return r; };
+                auto insert = [&](const float4& v, int pos, bool valid) {
                     const float ax = v.x - x, ay = v.y - y, az = v.z - z;
                     const float d = ax * ax + ay * ay + az * az;
-                    const int id = __float_as_int(v.w);
-                    const bool c0 = valid && d < d0, c1 = valid && d < d1, c2 = valid && d < d2;
+                    const double k = valid ? __hiloint2double(__float_as_int(d), pos) : sent;
+                    const double t0 = kmax(m0, k);
+                    m0 = kmin(m0, k);
                     if (K > 2) {
-                        ips[2] = c1 ? ips[1] : (c2 ? id : ips[2]);
-                        d2 = c1 ? d1 : (c2 ? d : d2);
+                        const double t1 = kmax(m1, t0);
+                        m1 = kmin(m1, t0);
+                        m2 = kmin(m2, t1);
+                    } else {
+                        m1 = kmin(m1, t0);
                     }
-                    ips[1] = c0 ? ips[0] : (c1 ? id : ips[1]);
-                    d1 = c0 ? d0 : (c1 ? d : d1);
-                    ips[0] = c0 ? id : ips[0];
-                    d0 = c0 ? d : d0;
                 };
                 auto scan = [&](const float4* base) {  // entries base[0 .. n_list)
                     int j0 = 0;
@@ -520,15 +581,20 @@ __device__ __forceinline__ void eval_scan(const MarchParams& a, const March2Tabl
 #pragma unroll
                         for (int u = 0; u < PN_CAND_FLIGHT; u++) v[u] = base[j0 + u];
 #pragma unroll
-                        for (int u = 0; u < PN_CAND_FLIGHT; u++) insert(v[u], true);
+                        for (int u = 0; u < PN_CAND_FLIGHT; u++) insert(v[u], j0 + u, true);
                     }
                     if (j0 < n_list) {
                         float4 v[PN_CAND_FLIGHT - 1];
 #pragma unroll
                         for (int u = 0; u < PN_CAND_FLIGHT - 1; u++) v[u] = base[min(j0 + u, n_list - 1)];
 #pragma unroll
-                        for (int u = 0; u < PN_CAND_FLIGHT - 1; u++) insert(v[u], j0 + u < n_list);
+                        for (int u = 0; u < PN_CAND_FLIGHT - 1; u++) insert(v[u], j0 + u, j0 + u < n_list);
                     }
+                    // a key still at the sentinel's distance bits found nothing (FLT_MAX itself is never inserted)
+                    const int h0 = __double2hiint(m0), h1 = __double2hiint(m1), h2 = __double2hiint(m2);
+                    if (h0 != 0x7F7FFFFF) ips[0] = __float_as_int(base[__double2loint(m0)].w);
+                    if (h1 != 0x7F7FFFFF) ips[1] = __float_as_int(base[__double2loint(m1)].w);
+                    if (K > 2 && h2 != 0x7F7FFFFF) ips[2] = __float_as_int(base[__double2loint(m2)].w);
                 };
                 if (my_off >= 0) scan(stage + my_off); else scan(tb.nb + pc.b);
             }
