@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel stats of the eager chair frame for a few settings of an environment knob: tools/gpu_r3c.sh VAR v1 v2 ...
+# kernel stats of the eager chair frame for a few settings of an environment knob: tools/gpu_knob_sweep.sh VAR v1 v2 ...
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/r03c; mkdir -p $O
 VAR=$1; shift
