@@ -1331,7 +1331,7 @@ __global__ void __launch_bounds__(256) k_composite_compact(float T_thresh, const
                                                            float* weights_sum, float* depth, float* image, PnTrip* trip, PnTrip* next,
                                                            unsigned* words, uint32_t tag, uint32_t N_rays, uint32_t max_steps, int dense_trips,
                                                            int* seg_counters, int* tail_diag, const PnGroup* __restrict__ g_cur, PnGroup* __restrict__ g_next,
-                                                           int* group_cnt, uint32_t group_rays, uint32_t n_groups) {
+                                                           int* group_cnt, uint32_t group_rays, uint32_t n_groups, int* err_flag) {
     __shared__ int s_wcnt[4], s_part[4];
     const uint32_t n_alive = (uint32_t)trip->n_alive, n_step_trip = (uint32_t)trip->n_step;
     const uint32_t CH = 256u * R;
@@ -1390,7 +1390,13 @@ __global__ void __launch_bounds__(256) k_composite_compact(float T_thresh, const
         int part = 0;
         for (uint32_t k = threadIdx.x; k < c; k += 256) {
             unsigned w;
-            do { w = __hip_atomic_load(words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((w >> 16) != tag);
+            uint32_t polls = 0;
+            do {
+                w = __hip_atomic_load(words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // never seen: a word that stays unwritten would mean the dispatcher started this workgroup before a lower-numbered one that has
+                // no slot yet.  Rather than hang the GPU, give up after ~a second, flag the frame (err bit 16) and carry on with garbage.
+                if (++polls > (1u << 20)) { if (err_flag) atomicOr(err_flag, 16); w = tag << 16; }
+            } while ((w >> 16) != tag);
             part += (int)(w & 0xFFFFu);
         }
 #pragma unroll
@@ -2071,7 +2077,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     k_composite_compact<R_><<<pn_div_up(N, 256 * R_), 256, 0, st>>>(o->T_thresh, cur, nxt, f->rays_t, f->sigmas, f->rgbs, f->deltas, weights_sum, depth_0,          \
                                                                      f->acc_image, f->trips + t, f->trips + t + 1, (unsigned*)f->chunk_counts, (uint32_t)t + 1, N, \
                                                                      o->max_steps, 1, f->seg_counters, f->tail_counts + t, g_cur, g_nxt, f->group_cnt, group_rays,  \
-                                                                     n_groups)
+                                                                     n_groups, err)
                 static const uint32_t cc_r0 = pn_env_u32("PN_CC_R0", 1);  // alive positions per thread on a frame's first trip; measured 20.0 / 21.4 / 27.9 us for 1 / 2 / 4
                 if (t == 0 && cc_r0 >= 4) PN_CC_LAUNCH(4);
                 else if (t == 0 && cc_r0 == 2) PN_CC_LAUNCH(2);

@@ -475,8 +475,11 @@ class _HipBackend:
 
     def __del__(self):
         if getattr(self, "copier", None) is not None:
-            from ._lib import lib
-            lib().pn_copier_destroy(self.copier)
+            try:
+                from ._lib import lib
+                lib().pn_copier_destroy(self.copier)
+            except Exception:  # noqa: BLE001 — interpreter shutdown: the import machinery is gone, the process is about to end anyway
+                pass
             self.copier = None
 
     def event(self):

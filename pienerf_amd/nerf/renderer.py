@@ -189,7 +189,8 @@ class NeRFRenderer(nn.Module):
         self.last_stats = dict(trips=int(stats[0]), samples=int(stats[1]), err=int(stats[2]), alive_at_exit=int(stats[3]), unfinished=int(stats[4]))
         if stats[2]:
             raise RuntimeError(f"render_deformed: device error flags {int(stats[2])} (1: sample cell outside the spatial hash, "
-                               "2: IP outside it, 4: spatial-hash capacity exceeded, 8: candidate-list capacity exceeded)")
+                               "2: IP outside it, 4: spatial-hash capacity exceeded, 8: candidate-list capacity exceeded, "
+                               "16: the fused composite/compaction gave up waiting for an earlier chunk)")
 
     def march_counters(self, enable, read=False, slot=0):
         """Measurement hook on workspace `slot`: 1 = device-side work counters of the march kernel (iterations, candidates, warps, samples);

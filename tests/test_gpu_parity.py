@@ -401,7 +401,7 @@ def test_graph_replay_equals_eager_steps(small_cloud, small_opt, ckpt):
     assert short.graph_continued == 3
 
 
-@pytest.mark.parametrize("lanes,depth,ahead,trips", [(2, 2, None, 8), (3, 1, 1, 8), (1, 2, 0, 8), (2, 2, None, 2), (1, 1, 0, None)])
+@pytest.mark.parametrize("lanes,depth,ahead,trips", [(2, 2, None, 8), (3, 1, 1, 8), (1, 2, 0, 8), (2, 2, None, 2), (1, 1, 0, None), (2, 1, None, 3)])
 def test_pipelined_frames_equal_eager_steps(small_cloud, small_opt, ckpt, lanes, depth, ahead, trips):
     """Frames in flight (frames.FramePipeline on the HIP backend: simulator running ahead on its own stream, one render graph per
     workspace, ordered by snapshot events, results copied to pinned host memory) give the eager sequence of images bit for bit — also
@@ -432,7 +432,7 @@ def test_pipelined_frames_equal_eager_steps(small_cloud, small_opt, ckpt, lanes,
         assert np.array_equal(got[f][1]["image"], want[f]["image"]) and np.array_equal(got[f][1]["depth_0"], want[f]["depth_0"]), f
         assert np.array_equal(got[f][1]["depth"], want[f]["depth"], equal_nan=True), f
         assert np.array_equal(dev_copies[f][0].cpu().numpy(), want[f]["image"])       # the device copy is the same frame
-    if trips == 2:
+    if trips in (2, 3):   # (3: two of the captured trips are margin trips — small grids, two-launch compaction — with most of the frame's rays in them)
         assert pipe._pipe_backend.continued == n_frames                                 # every frame needed the continuation
     else:
         assert pipe._pipe_backend.continued == 0
