@@ -161,8 +161,17 @@ def add_pin_penalty(mat, stiff, pin_ids, pts_topo, pts_Nx):
 
 
 def inverse_spd(mat):
-    """Dense fp64 inverse (solver.py:508); on the device when its solver stack is available, else host LAPACK (init only)."""
+    """Dense fp64 inverse of the system block (solver.py:508: `.inverse()`, an LU).  The block is symmetric positive definite (mass + stiffness +
+    pin penalty + 1e-3 I), so it is factored as L L^T and inverted from the factor (half the work of the LU, a symmetric result); LU if the
+    factorisation reports a non-positive pivot.  On the device when its solver stack is available, else host LAPACK (init only).  The explicit
+    inverse is kept for the substep itself: applying the factor instead would be two triangular solves — a chain of 10 n_k dependent steps per
+    local/global iteration against one 7 us matrix-vector product."""
+    def _inv(m):
+        L, info = torch.linalg.cholesky_ex(m)
+        if int(info) == 0:
+            return torch.cholesky_inverse(L)
+        return torch.linalg.inv(m)
     try:
-        return torch.linalg.inv(mat)
+        return _inv(mat)
     except RuntimeError:
-        return torch.linalg.inv(mat.cpu()).to(mat.device)
+        return _inv(mat.cpu()).to(mat.device)
