@@ -188,3 +188,27 @@ def test_harness_fp16_option_pipelined_equals_eager(small_cloud, small_opt, ckpt
         assert np.array_equal(got[f][1], want[f][0].cpu().numpy()), f
     a = f32.step()["image"]
     assert 1e-4 < (a - want[0]).abs().max() < 2e-2
+
+
+def test_weight_refresh_is_refused_while_frames_are_in_flight(small_cloud, small_opt, ckpt):
+    """The packed weight image is refreshed in place on the CURRENT stream only; renders in flight on the pipeline's lanes would read it half
+    written (round-2 advisor finding).  The harness tells the network how many frames are in flight and the refresh is refused until the
+    pipeline is drained; an autocast dtype other than float16 is refused as well (the grid encoder and the layers would disagree)."""
+    from pienerf_amd.harness import SimRenderHarness
+    opt = dict(small_opt, W=48, H=48)
+    h = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture_pipelined(lanes=2, n_trips=8)
+    for _ in range(3):
+        h.step_pipelined()
+    with torch.no_grad():
+        h.model.sigma_net[0].weight.mul_(1.0)            # bumps the parameter's version: the packed image is stale now
+    x = torch.rand(100, 3, device=DEV) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(100, 3, device=DEV), dim=-1)
+    with pytest.raises(RuntimeError, match="drain_pipeline"):
+        with torch.no_grad():
+            h.model(x, d)
+    h.drain_pipeline()
+    with torch.no_grad():
+        h.model(x, d)                                    # drained: the refresh goes through
+        with pytest.raises(RuntimeError, match="float16"):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                h.model(x, d)

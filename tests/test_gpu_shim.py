@@ -116,3 +116,22 @@ def test_reference_call_sequence_through_the_backend_modules(shim_path, small_cl
     assert torch.equal(back, coords)
     with pytest.raises(NotImplementedError):
         _backend.sph_from_ray(rays_o, rays_d, 2.0, N, torch.empty(N, 2, device=DEV))
+
+
+def test_backend_modules_reject_wrong_element_types(shim_path):
+    """The reference's kernels take data_ptr<float>() / <int>() / <uint8_t>() and throw on anything else; the drop-in must not reinterpret a half or
+    int64 tensor (round-2 advisor finding), and the march reports its device error flags (the reference printf's "ERROR: g0=..." for the same case)."""
+    import _raymarching as _backend
+    N = 64
+    o, d = torch.zeros(N, 3, device=DEV), torch.ones(N, 3, device=DEV)
+    aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1], device=DEV)
+    nears, fars = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    _backend.near_far_from_aabb(o, d, aabb, N, 0.2, nears, fars)
+    with pytest.raises(RuntimeError, match="float32"):
+        _backend.near_far_from_aabb(o.half(), d, aabb, N, 0.2, nears, fars)
+    with pytest.raises(RuntimeError, match="float32"):
+        _backend.near_far_from_aabb(o, d, aabb.double(), N, 0.2, nears, fars)
+    alive = torch.arange(N, dtype=torch.int64, device=DEV)
+    with pytest.raises(RuntimeError):
+        _backend.composite_rays(N, 1, 1e-2, alive, nears, torch.zeros(N, device=DEV), torch.zeros(N, 3, device=DEV), torch.zeros(N, 2, device=DEV),
+                                torch.zeros(N, device=DEV), torch.zeros(N, device=DEV), torch.zeros(N, 3, device=DEV))

@@ -42,6 +42,48 @@ def test_checkpoint_round_trip_in_reference_layout(tmp_path, ckpt):
     assert io.load_checkpoint(_model(), str(tmp_path / "best.pth"))["missing_keys"] == ["density_grid"]
 
 
+def test_checkpoint_errors_and_scaler(tmp_path, ckpt):
+    """Only what the restricted unpickler refuses is turned into the `--trust-ckpt` hint (round-2 advisor finding: a bare `except Exception` hid
+    missing files and corrupt archives behind it, and allow_pickle retried ANY failure with full pickle); the 'scaler' key is read back
+    (trainer.py:911-916)."""
+    a = _model()
+    a.load_checkpoint_dict(ckpt)
+    with pytest.raises(FileNotFoundError):
+        io.load_checkpoint(_model(), str(tmp_path / "nope.pth"))
+    with pytest.raises(FileNotFoundError):
+        io.load_checkpoint(_model(), str(tmp_path / "nope.pth"), allow_pickle=True)
+    bad = tmp_path / "corrupt.pth"
+    bad.write_bytes(b"this is not a checkpoint")
+    with pytest.raises(Exception) as ei:
+        io.load_checkpoint(_model(), str(bad), allow_pickle=True)
+    assert "trust" not in str(ei.value)                     # no advice to trust a file that is simply broken
+
+    class Evil:  # a global outside the allow-list
+        def __reduce__(self):
+            return (dict, ())
+    raw = {"model": a.state_dict(), "epoch": 1, "global_step": 2, "extra": Evil()}
+    torch.save(raw, str(tmp_path / "evil.pth"))
+    with pytest.raises(RuntimeError, match="trust"):
+        io.load_checkpoint(_model(), str(tmp_path / "evil.pth"))
+    with pytest.warns(UserWarning, match="full pickle"):
+        io.load_checkpoint(_model(), str(tmp_path / "evil.pth"), allow_pickle=True)
+
+    class Scaler:
+        def __init__(self, v):
+            self.v = v
+
+        def state_dict(self):
+            return {"scale": self.v, "growth_tracker": 3}
+
+        def load_state_dict(self, d):
+            self.v = d["scale"]
+    opt = torch.optim.Adam(a.get_params(1e-2))
+    p = io.save_checkpoint(a, str(tmp_path / "s.pth"), optimizer=opt, full=True, scaler=Scaler(4096.0))
+    s2 = Scaler(1.0)
+    io.load_checkpoint(_model(), p, model_only=False, scaler=s2)
+    assert s2.v == 4096.0
+
+
 def test_save_image_and_poses(tmp_path):
     from PIL import Image
     rng = np.random.default_rng(0)
