@@ -759,6 +759,10 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
     static const bool chunked_ok = [] { const char* v = getenv("PN_SIM_GATHER"); return !(v && strcmp(v, "kernel") == 0); }();
     static const bool fused_x = [] { const char* v = getenv("PN_SIM_GATHER"); return v && strcmp(v, "fused") == 0; }();
     static const int dbg_nosvd = (int)pn_env_u32("PN_SIM_DBG_NOSVD", 0);
+    // k_elastic in one-wave workgroups: a lane's 60 loads (its kernel's 30 DOFs, its 30 shape-function gradients) are 240-B blocks of its own, so every
+    // load instruction touches 64 cache lines and keeps the CU's address path busy for ~140 cycles; with 256-thread workgroups the 447 waves of the
+    // chair sat four to a CU on 112 of the 256 CUs and queued on that path (31.9 -> 28.3 us per local/global iteration; 16-byte loads on top: nothing)
+    static const uint32_t el_wg = std::min(std::max(pn_env_u32("PN_SIM_EL_WG", 64) & ~63u, 64u), 256u);
     const size_t xs_bytes = (size_t)n3 * sizeof(double);
     const bool chunked = pcsr && chunked_ok && xs_bytes <= 160 * 1024 - 1024;
     if (chunked) {
@@ -778,7 +782,7 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
     k_step_begin<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, dt, dof, dof_vel, tilde, last);
     k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Mmat, tilde, momentum, 1, dof_f, rhs_gravity);  // compute_momentum (:574-576)
     for (int it = 0; it < iters; it++) {
-        k_elastic<<<pn_div_up((uint64_t)n_IP * 8, 256), 256, 0, st>>>(n_IP, topo, dNx, dof, nullptr, nullptr, nullptr, pcsr ? nullptr : P, mu, lam, dx3,
+        k_elastic<<<pn_div_up((uint64_t)n_IP * 8, el_wg), el_wg, 0, st>>>(n_IP, topo, dNx, dof, nullptr, nullptr, nullptr, pcsr ? nullptr : P, mu, lam, dx3,
                                                                       pcsr ? csr_pos : nullptr, pcsr ? P_csr : nullptr, dbg_nosvd, Vstore);
         if (chunked) {
             k_rhs_gather_chunk<<<(uint32_t)chunks_max, PN_GCH * 8, 0, st>>>(chunk, dNx_csr, P_csr, part);
