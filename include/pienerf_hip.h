@@ -352,6 +352,21 @@ int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, double dx, const
  * csr_pos (may be NULL; needs dNx_csr): inverse of csr_buf, csr_pos[csr_buf[e]] = e; calc_elastic then also writes P once per
  * neighbour slot in CSR order and the gather has no index left to follow. */
 uint64_t pn_sim_work_doubles(int n_k, int n_IP);
+/* The local/global iterations of a substep as ONE persistent kernel of n_wg workgroups (one per CU; csrc/pn_sim.hip: k_substep_coop) instead of four
+ * launches per iteration: same arguments and results as pn_sim_stepforward (tolerance of the summation orders, ~1e-13 relative), `work` prepared by
+ * pn_sim_prepare, `coop` >= pn_sim_coop_bytes(n_k, n_IP, n_wg) bytes prepared by pn_sim_coop_prepare, which also returns plan[3] = {pieces, entries
+ * per slot, pieces per kernel at most} to pass on.  pn_sim_coop_bytes returns 0 and pn_sim_coop_prepare PN_ERR_ARG when the scene does not fit the persistent form (n_k > 204,
+ * more integration points than 32 n_wg, kernel lists too long): callers keep pn_sim_stepforward then.  Every workgroup must become resident; one that
+ * waits longer than ~2 s raises a flag and the launch ends with invalid results: pn_sim_coop_status (synchronous) reads the flag. */
+uint64_t pn_sim_coop_bytes(int n_k, int n_IP, int n_wg);
+int pn_sim_coop_prepare(int n_k, int n_IP, int n_wg, const int* csr_bg, const int* csr_cnt, void* coop, int* plan_out, void* stream);
+int pn_sim_coop_status(const void* coop, int* timed_out);
+/* Timing experiments only (environment PN_SIM_COOP_DBG & 4): per-phase tick sums of workgroup 0, see csrc/pn_sim.hip. */
+int pn_sim_coop_clocks(const void* coop, uint64_t* ticks9);
+int pn_sim_stepforward_coop(int n_k, int n_IP, int iters, double dt, double dx, const int* topo, const double* mu, const double* lam, const double* dNx,
+                            const double* dNx_csr, const int* csr_pos, const double* Ainv, const double* Mmat, const double* dof_rest,
+                            const double* rhs_rest, const double* rhs_gravity, const double* dof_f, double* dof, double* dof_vel, double* work,
+                            void* coop, int n_wg, const int* plan, void* stream);
 /* State-independent contents of `work` (once per simulator / per allocation of `work`), see pn_sim_stepforward. */
 int pn_sim_prepare(int n_k, int n_IP, const int* csr_bg, const int* csr_cnt, double* work, void* stream);
 

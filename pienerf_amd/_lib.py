@@ -87,6 +87,11 @@ SIGNATURES = {
     "pn_sim_stepforward": (i32, [i32, i32, i32, f64, f64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, i32, P]),
     "pn_sim_prepare": (i32, [i32, i32, P, P, P, P]),
     "pn_sim_work_doubles": (u64, [i32, i32]),
+    "pn_sim_coop_bytes": (u64, [i32, i32, i32]),
+    "pn_sim_coop_prepare": (i32, [i32, i32, i32, P, P, P, C.POINTER(i32), P]),
+    "pn_sim_coop_status": (i32, [P, C.POINTER(i32)]),
+    "pn_sim_coop_clocks": (i32, [P, C.POINTER(u64)]),
+    "pn_sim_stepforward_coop": (i32, [i32, i32, i32, f64, f64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, i32, C.POINTER(i32), P]),
     "pn_sim_update_force": (i32, [i32, i32, P, f64, P, P, P, P, P]),
 }
 

@@ -13,6 +13,8 @@
 //   * calc_elastic uses 8 lanes per integration point (one per neighbour kernel) so the 1.9 KB/IP of dNx is read coalesced.
 #include <math.h>
 
+#include <vector>
+
 #include "pn_common.h"
 
 // The substep is a chain of ~30 short dependent launches that runs concurrently with the render kernels of other frames
@@ -689,9 +691,11 @@ extern "C" int pn_sim_matvec3(int n, const double* A, const double* X, double* Y
 
 // ------------------------------------------------------------------------------------------------ stepforward
 __global__ void __launch_bounds__(256) k_step_begin(int n3, double dt, const double* __restrict__ dof, const double* __restrict__ vel,
-                                                    double* __restrict__ tilde, double* __restrict__ last) {
+                                                    double* __restrict__ tilde, double* __restrict__ last, int* __restrict__ coop_ctl = nullptr) {
     PN_SIM_PRIO();
     const int i = threadIdx.x + blockIdx.x * blockDim.x;
+    // persistent form: the barrier counters of k_substep_coop start every substep at zero (the previous substep's launch has ended: stream order)
+    if (coop_ctl && blockIdx.x == 0 && threadIdx.x < 10) coop_ctl[threadIdx.x * 32] = 0;  // PnCoopCtl: xcd_ctr[8], glob, gen
     if (i >= n3) return;
     const double d = dof[i];
     tilde[i] = d + dt * vel[i];  // solver.py:575
@@ -801,6 +805,508 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
         k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Ainv, tot, dof, 2, dof_rest, nullptr);  // x = G @ rhs ; dof = dof_rest + x (:600-601)
     }
     k_step_end<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, dt, dof, last, dof_vel);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ the local/global iterations as ONE persistent kernel
+// pn_sim_stepforward's loop is four dependent launches per local/global iteration, each 4-13 us although it moves a few hundred KB: what a launch costs
+// is its chain of dependent memory round trips (index -> data -> result), not its boundary.  k_substep_coop runs all `iters` iterations in ONE launch of
+// n_wg workgroups (one per CU) that keep everything state-independent where a round trip is not needed:
+//   * registers: this workgroup's rows of A^-1 (rpw rows x n columns over 512 threads), the dNx rows of its piece of a kernel's CSR list;
+//   * LDS: the shape-function gradients of its own integration points, the assembled right-hand side, the staged stresses of its piece.
+// What is left per iteration is three all-to-all exchanges through memory (integration points -> pieces: P; pieces -> rows: piece sums; rows ->
+// integration points: the new DOFs).  The XCDs' L2s are not coherent with each other and a release/acquire pair at device scope costs 13 us
+// (tools/calib_barrier.hip), so nothing is fenced: exchanged values are written and read with relaxed AGENT-scope atomics (sc1: written through to /
+// read from the memory side), a producer waits for its stores' acknowledgement (s_waitcnt vmcnt(0)) before it arrives at a counting barrier (arrivals
+// per XCD-sized group of workgroups on separate cache lines, a generation word everybody polls).  tools/calib_exchange.hip: 4.2 us per exchange at
+// 256 workgroups.  Every summation order is fixed (pieces in ascending entry order, waves in ascending order): bit-reproducible like the launch form.
+// A workgroup that waits longer than ~1 s for a generation raises ctl->err and leaves (every other one follows): a launch whose workgroups cannot all
+// be resident (a CU-masked stream, a debugger) fails instead of hanging the GPU; the host checks the flag (pn_sim_coop_status).
+#define PN_COOP_THREADS 512
+#define PN_COOP_NS (PN_COOP_THREADS / 30)  // 17 slots x 30 threads in the piece gather
+#define PN_COOP_EU 16                       // piece entries per slot, register-resident: pieces of <= 272 entries
+#define PN_COOP_RPW 8                       // rows of A^-1 per workgroup
+#define PN_COOP_CU 4                        // columns per thread and row: n <= 2048
+#define PN_COOP_IPW 32                      // integration points per workgroup (8 lanes each)
+#define PN_COOP_MAXP 4                      // pieces per kernel at most
+#define PN_COOP_ITERS 32                    // local/global iterations per launch at most (one exchange buffer per iteration, see k_substep_coop)
+
+struct PnCoopCtl {  // every word that is polled or counted on a cache line of its own
+    int xcd_ctr[8 * 32];
+    int glob[32];
+    int gen[32];
+    int err[32];
+};
+struct PnCoopPlan {
+    int n_wg, n_pieces, eu, ipw, rpw, max_pieces_per_kernel;
+    size_t off_pieces, off_kp, off_psum, off_dofx, bytes;  // byte offsets inside the coop buffer
+    size_t lds_bytes;
+};
+
+// cnt_host == NULL: sizes only, for `eu_known` entries per slot (0: the worst case PN_COOP_EU)
+static int pn_coop_plan(int n_k, int n_IP, int n_wg, const int* cnt_host, PnCoopPlan* pl, int eu_known = 0) {
+    const int n = n_k * 10;
+    pl->n_wg = n_wg;
+    pl->ipw = (n_IP + n_wg - 1) / n_wg;
+    pl->rpw = (n + n_wg - 1) / n_wg;
+    pl->eu = 0; pl->n_pieces = 0; pl->max_pieces_per_kernel = 0;
+    if (n_wg < 8 || n_wg > 256 || pl->ipw > PN_COOP_IPW || pl->rpw > PN_COOP_RPW || n > PN_COOP_THREADS * PN_COOP_CU) return 0;
+    auto lds_for = [&](size_t eu_l) {
+        const size_t xs = std::max((size_t)n * 3, eu_l * PN_COOP_NS * 9 + (size_t)PN_COOP_NS * 90);
+        return ((size_t)pl->ipw * 240 + xs + (size_t)n * 3 + eu_l * PN_COOP_NS * 30 + (size_t)pl->ipw * 9) * sizeof(double) + (((size_t)n_k + 2) & ~(size_t)1) * sizeof(int);
+    };
+    if (cnt_host) {
+        // the longest pieces up to 12 entries per slot (204 entries) that fit the LDS, where the piece's dNx rows live: fewer pieces, fewer kernels whose
+        // list is cut.  (16 per slot fit the chair at 160 KB of LDS and measured slower: 0.265 against 0.241 ms per substep.)
+        const int eu_cap = (int)std::min<uint32_t>(pn_env_u32("PN_SIM_COOP_EU", 12), PN_COOP_EU);
+        for (int eu = eu_cap; eu >= 1 && !pl->eu; eu--) {
+            if (lds_for(eu) > 160 * 1024) continue;
+            const int pmax = eu * PN_COOP_NS;
+            long np = 0; int mp = 0;
+            for (int k = 0; k < n_k; k++) { const int c = (cnt_host[k] + pmax - 1) / pmax; np += c; mp = std::max(mp, c); }
+            if (np <= n_wg && mp <= PN_COOP_MAXP) { pl->eu = eu; pl->n_pieces = (int)np; pl->max_pieces_per_kernel = mp; }
+        }
+        if (!pl->eu) return 0;
+    }
+    pl->off_pieces = sizeof(PnCoopCtl);
+    pl->off_kp = pl->off_pieces + (size_t)n_wg * sizeof(int4);
+    pl->off_psum = (pl->off_kp + (size_t)(n_k + 1) * sizeof(int) + 127) & ~(size_t)127;
+    pl->off_dofx = pl->off_psum + (size_t)PN_COOP_ITERS * n_wg * 30 * sizeof(double);  // psum: one [n_wg][30] block per iteration
+    pl->bytes = pl->off_dofx + (size_t)PN_COOP_ITERS * n * 3 * sizeof(double);            // dofx: one DOF vector per iteration
+    // LDS: Ds [ipw*240] | Xs [n*3] (aliased by Ps [eu*NS*9]) | Gs [eu*NS*30] | Qs [ipw*9] | red [NS*90] | pk [n_wg ints]
+    pl->lds_bytes = lds_for(cnt_host ? pl->eu : (eu_known ? eu_known : 1));  // without the lists: does the smallest piece size fit at all
+    return pl->lds_bytes <= 160 * 1024;
+}
+
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// A value another workgroup wrote (st_agent: through to the memory side) into a location that NO wave has read before in this launch: the piece sums
+// and the DOF vector are exchanged through one buffer per iteration, and every wave starts the kernel with an agent-scope acquire fence (this XCD's L2
+// and the CU's L1 hold nothing stale from earlier launches).  Such a location cannot be in any cache before its writer's barrier, so an ordinary cached
+// load is coherent — and the 256 workgroups that all read the same 51 KB of piece sums (and the same DOF blocks) fetch them from their XCD's L2 after
+// the first one instead of 13 MB per iteration from the memory side with sc1 loads (assembly phase 3.1 -> us).  Relaxed atomic at workgroup scope: the
+// compiler may neither cache nor hoist it.
+__device__ __forceinline__ double ld_fresh(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// Cross-lane sums on the DPP path (VALU moves) instead of ds_bpermute: a shuffle of a double is two LDS-crossbar operations, and the 18 x 6 of them in
+// the first version of the rows phase took 5 us of every iteration.
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    int2 tt = *reinterpret_cast<int2*>(&v);
+    tt.x = __builtin_amdgcn_update_dpp(0, tt.x, CTRL, 0xf, 0xf, false);
+    tt.y = __builtin_amdgcn_update_dpp(0, tt.y, CTRL, 0xf, 0xf, false);
+    return *reinterpret_cast<double*>(&tt);
+}
+__device__ __forceinline__ double wave_sum_d(double v) {  // every lane gets the sum; fixed tree
+    v += dpp_d<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_d<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_d<0x141>(v);  // row_half_mirror
+    v += dpp_d<0x140>(v);  // row_mirror
+    v += shfl_xor_d(v, 16);
+    v += shfl_xor_d(v, 32);
+    return v;
+}
+
+// All workgroups have arrived at generation g (counted from the launch's base) and their earlier agent-scope stores are at the memory side.
+__device__ __forceinline__ bool coop_sync(PnCoopCtl* ctl, int g, int per_xcd, int xcd) {
+    __shared__ int ok_s;
+    __builtin_amdgcn_s_waitcnt(0);  // this thread's exchange stores acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        const int a = __hip_atomic_fetch_add(ctl->xcd_ctr + xcd * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a == per_xcd * g - 1) {
+            const int gg = __hip_atomic_fetch_add(ctl->glob, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gg == 8 * g - 1) __hip_atomic_store(ctl->gen, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int spins = 0;
+        while (__hip_atomic_load(ctl->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023) == 0) {
+                if (spins > (1 << 21) || __hip_atomic_load(ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    __hip_atomic_store(ctl->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+            }
+        }
+        ok_s = ok;
+    }
+    __syncthreads();
+    return ok_s != 0;
+}
+
+// CW / EU / NO: columns of its row of A^-1 per lane, piece entries per slot (both register-resident: the budget is 256 registers per thread at two
+// waves per SIMD and the SVD of the integration-point phase needs ~120 of them), right-hand-side entries per thread in the assembly (30 n_k / 512)
+template <int CW, int EU, int NO>
+__global__ void __launch_bounds__(PN_COOP_THREADS) k_substep_coop(int n_k, int n_IP, int iters, double dt, double dx3, const int* __restrict__ topo,
+                                                                  const int* __restrict__ csr_pos, const double* __restrict__ mu,
+                                                                  const double* __restrict__ lam, const double* __restrict__ dNx,
+                                                                  const double* __restrict__ dNx_csr, const double* __restrict__ Ainv,
+                                                                  const double* __restrict__ dof_rest, const double* __restrict__ rhs_rest,
+                                                                  const double* __restrict__ momentum, const double* __restrict__ last, double* dof,
+                                                                  double* __restrict__ dof_vel, double* P_csr, double* __restrict__ Vstore, PnCoopCtl* ctl,
+                                                                  const int4* __restrict__ pieces, const int* __restrict__ kp_bg, double* psum_all,
+                                                                  double* dofx_all,
+                                                                  int n_pieces, int eu, int ipw, int rpw, int max_rank, int dbg) {
+    PN_SIM_PRIO();
+    extern __shared__ double coop_lds[];
+    const int n = n_k * 10, n3 = n * 3;
+    const int t = threadIdx.x, w = blockIdx.x, G = gridDim.x, lane = t & 63, wid = t >> 6;
+    double* Ds = coop_lds;                                   // [ipw * 240]: shape-function gradients of the own integration points
+    const size_t ps_len = (size_t)eu * PN_COOP_NS * 9;
+    const size_t xs_len = max((size_t)n3, ps_len + PN_COOP_NS * 90);
+    double* Xs = Ds + (size_t)ipw * 240;                     // [xs_len]: right-hand side (rows phase); in the pieces phase the staged stresses Ps ...
+    double* red = Xs + ps_len;                               // ... and behind them the [NS * 90] partial sums of the slots
+    double* Cs = Xs + xs_len;                                // [n3]: momentum - rhs_rest, the state-independent part of the right-hand side
+    double* Gs = Cs + n3;                                    // [eu * NS * 30]: the dNx rows of this workgroup's piece
+    double* Qs = Gs + (size_t)eu * PN_COOP_NS * 30;          // [ipw * 9]: warm-start rotations of the own integration points
+    int* kp_s = reinterpret_cast<int*>(Qs + (size_t)ipw * 9);  // [n_k + 1]: first piece of every kernel
+    const int xcd = w & 7, per_xcd = (G + 7 - xcd) / 8;
+    int g = 0;  // generations of this launch (k_step_begin cleared the counters)
+    const bool fresh = !(dbg & 8);  // PN_SIM_COOP_DBG & 8: sc1 loads for everything exchanged, no fence (timing experiment)
+    if (fresh && wid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // see ld_fresh (one wave per workgroup; the others pass the barrier below after it)
+    // PN_SIM_COOP_DBG & 4: workgroup 0 accumulates the wall-clock ticks (100 MHz) of the eight phases of an iteration in ctl->err[8..] (tools/time_sim.py)
+    __shared__ unsigned long long clk_s[10];
+    const bool clk_on = (dbg & 4) && w == 0 && t == 0;
+    if (clk_on) { for (int i = 0; i < 10; i++) clk_s[i] = 0; clk_s[9] = wall_clock64(); }
+#define PN_COOP_CLK(i) do { if (clk_on) { const unsigned long long now_ = wall_clock64(); clk_s[i] += now_ - clk_s[9]; clk_s[9] = now_; } } while (0)
+
+    // ---- state-independent residents
+    const int v0 = w * ipw, nown = max(min(ipw, n_IP - v0), 0);
+    for (int e = t; e < nown * 240; e += PN_COOP_THREADS) Ds[e] = dNx[(size_t)v0 * 240 + e];
+    for (int k = t; k <= n_k; k += PN_COOP_THREADS) kp_s[k] = kp_bg[k];
+    for (int o = t; o < n3; o += PN_COOP_THREADS) Cs[o] = momentum[o] - rhs_rest[o];
+    const bool ip_lane = t < nown * 8;
+    const int vl = t >> 3, i8 = t & 7, v = v0 + vl;
+    int kid = 0, cpos = 0;
+    double m_ = 0.0, l_ = 0.0;
+    // the warm-start rotations of the own integration points live in LDS between the iterations (18 registers of every thread otherwise)
+    for (int e = t; e < nown * 9; e += PN_COOP_THREADS) Qs[e] = Vstore[(size_t)v0 * 9 + e];
+    if (ip_lane) {
+        kid = topo[v * 8 + i8];
+        cpos = csr_pos[v * 8 + i8];
+        if (i8 == 0) { m_ = mu[v]; l_ = lam[v]; }
+    }
+    // rows [r0, r0 + nrow) of A^-1: wave wid holds row r0 + wid, lane-strided (<= 8 rows per workgroup = its 8 waves)
+    const int r0 = w * rpw, nrow = max(min(rpw, n - r0), 0);
+    double Areg[CW];
+#pragma unroll
+    for (int u = 0; u < CW; u++) {
+        const int j = lane + 64 * u;
+        Areg[u] = (wid < nrow && j < n) ? Ainv[(size_t)(r0 + wid) * n + j] : 0.0;
+    }
+    const bool row_lane = wid < nrow && lane < 3;
+    const double rest_o = row_lane ? dof_rest[(size_t)(r0 + wid) * 3 + lane] : 0.0, last_o = row_lane ? last[(size_t)(r0 + wid) * 3 + lane] : 0.0;
+    // this workgroup's piece of a kernel's CSR list: slot ps (of 17) takes entries ps + 17 u, thread (ps, q) holds their dNx value q
+    const int4 pc = w < n_pieces ? pieces[w] : make_int4(0, 0, 0, 0);  // (kernel, first entry, entries, -)
+    const int p_bg = pc.y, p_cnt = pc.z;
+    const int ps = t / 30, pq = t - ps * 30, pcq = pq / 10;
+    const bool piece_lane = ps < PN_COOP_NS && p_cnt > 0;
+    for (int e = t; e < p_cnt * 30; e += PN_COOP_THREADS) Gs[e] = dNx_csr[(size_t)p_bg * 30 + e];  // the piece's dNx rows, [entry][30]
+    __syncthreads();
+    PN_COOP_CLK(8);
+
+    for (int it = 0; it < iters; it++) {
+        // this iteration's exchange buffers (never read before in this launch, see ld_fresh)
+        const double* dof_in = it == 0 ? dof : dofx_all + (size_t)(it - 1) * n3;
+        double* dof_out = it == iters - 1 ? dof : dofx_all + (size_t)it * n3;
+        double* psum = psum_all + (size_t)it * G * 30;
+        // ================= integration points: F, warm-started SVD, stresses to the CSR positions of the eight neighbour kernels
+        if (ip_lane) {
+            double dv[30];
+            if (fresh) {
+#pragma unroll
+                for (int q = 0; q < 30; q++) dv[q] = ld_fresh(dof_in + (size_t)kid * 30 + q);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 30; q++) dv[q] = ld_agent(dof_in + (size_t)kid * 30 + q);
+            }
+            const double* __restrict__ dn = Ds + (size_t)(vl * 8 + i8) * 30;
+            M3 Fm;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) Fm.m[r][c] = 0.0;
+#pragma unroll
+            for (int x = 0; x < 10; x++) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const double gq = dn[c * 10 + x];
+                    Fm.m[0][c] += dv[x * 3] * gq;
+                    Fm.m[1][c] += dv[x * 3 + 1] * gq;
+                    Fm.m[2][c] += dv[x * 3 + 2] * gq;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    double sacc = Fm.m[r][c];
+                    sacc += dpp_d<0xB1>(sacc);   // lanes ^ 1
+                    sacc += dpp_d<0x4E>(sacc);   // lanes ^ 2
+                    sacc += dpp_d<0x141>(sacc);  // the other quad of the 8-lane group (row_half_mirror)
+                    Fm.m[r][c] = sacc;
+                }
+            double Pm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (i8 == 0) {
+                M3 U, V;
+                double sig[3], sp[3];
+                if (dbg & 1) {  // timing experiment (PN_SIM_COOP_DBG=1): no SVD, results invalid
+#pragma unroll
+                    for (int r = 0; r < 3; r++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++) { U.m[r][c] = (r == c); V.m[r][c] = (r == c); }
+                    sig[0] = Fm.m[0][0]; sig[1] = Fm.m[1][1]; sig[2] = Fm.m[2][2];
+                } else {
+                    M3 Qw;
+#pragma unroll
+                    for (int r = 0; r < 3; r++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++) Qw.m[r][c] = Qs[vl * 9 + r * 3 + c];
+                    svd3(Fm, U, sig, V, &Qw, 1e-24);
+#pragma unroll
+                    for (int r = 0; r < 3; r++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++) Qs[vl * 9 + r * 3 + c] = V.m[r][c];
+                }
+                volume_invariant_project(sig, sp);
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const double R = U.m[r][0] * V.m[c][0] + U.m[r][1] * V.m[c][1] + U.m[r][2] * V.m[c][2];
+                        const double Vv = U.m[r][0] * sp[0] * V.m[c][0] + U.m[r][1] * sp[1] * V.m[c][1] + U.m[r][2] * sp[2] * V.m[c][2];
+                        Pm[r * 3 + c] = dx3 * (m_ * R + l_ * Vv);
+                    }
+            }
+            const int src = lane & ~7;
+            double* dst = P_csr + (size_t)cpos * 9;
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+                int2 tt = *reinterpret_cast<int2*>(&Pm[q]);
+                tt.x = __shfl(tt.x, src);
+                tt.y = __shfl(tt.y, src);
+                st_agent(dst + q, *reinterpret_cast<double*>(&tt));
+            }
+        }
+        PN_COOP_CLK(0);
+        if (!(dbg & 2) && !coop_sync(ctl, ++g, per_xcd, xcd)) return;
+        PN_COOP_CLK(1);
+
+        // ================= pieces: sum_e dNx_e^T P_e over this workgroup's piece (ascending entries per slot, slots in ascending order)
+        if (p_cnt > 0) {
+            double* Ps = Xs;
+            {
+                double pv[6];  // <= 272 * 9 / 512 loads per thread, all in flight
+#pragma unroll
+                for (int u = 0; u < 6; u++) {  // (unconditional, clamped: a branch around an atomic load makes the compiler wait for each one in turn)
+                    const int e9 = min(t + PN_COOP_THREADS * u, p_cnt * 9 - 1);
+                    pv[u] = ld_agent(P_csr + (size_t)p_bg * 9 + e9);
+                }
+#pragma unroll
+                for (int u = 0; u < 6; u++) {
+                    const int e9 = t + PN_COOP_THREADS * u;
+                    if (e9 < p_cnt * 9) Ps[e9] = pv[u];
+                }
+            }
+            __syncthreads();
+            if (ps < PN_COOP_NS) {
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+                for (int u = 0; u < EU; u++) {
+                    const int e = ps + PN_COOP_NS * u;
+                    if (u < eu && e < p_cnt) {
+                        const double* __restrict__ pe = Ps + (size_t)e * 9 + pcq;
+                        const double gq = Gs[e * 30 + pq];
+                        a0 += pe[0] * gq; a1 += pe[3] * gq; a2 += pe[6] * gq;
+                    }
+                }
+                red[(ps * 30 + pq) * 3] = a0; red[(ps * 30 + pq) * 3 + 1] = a1; red[(ps * 30 + pq) * 3 + 2] = a2;
+            }
+            __syncthreads();
+            if (t < 90) {  // (q, r): the 17 slots in order
+                double sacc = 0.0;
+#pragma unroll
+                for (int sl = 0; sl < PN_COOP_NS; sl++) sacc += red[sl * 90 + t];
+                red[t] = sacc;  // slot 0's own value was read by this thread only
+            }
+            __syncthreads();
+            if (t < 30) {
+                const int x = t / 3, r = t - x * 3;
+                st_agent(psum + (size_t)w * 30 + t, (red[x * 3 + r] + red[(10 + x) * 3 + r]) + red[(20 + x) * 3 + r]);
+            }
+        }
+        PN_COOP_CLK(2);
+        if (!(dbg & 2) && !coop_sync(ctl, ++g, per_xcd, xcd)) return;
+        PN_COOP_CLK(3);
+
+        // ================= rows: right-hand side assembled in LDS (a kernel's pieces in ascending order), this workgroup's rows of A^-1 from registers
+        {
+            // every entry's first two pieces in ONE batch of unconditional loads (clamped addresses, selected afterwards), the third and fourth — a
+            // few long lists have them — in a second, wave-uniform batch: a branch around an atomic load makes the compiler wait for each load in
+            // turn, and nine dependent round trips per thread were 15 us of every iteration in the first version
+            double pv[NO][2], sum[NO];
+            int np[NO], pb[NO];
+            bool more = false;
+#pragma unroll
+            for (int u = 0; u < NO; u++) {
+                const int o = min(t + PN_COOP_THREADS * u, n3 - 1);
+                const int k = o / 30, q = o - k * 30;
+                pb[u] = kp_s[k];
+                np[u] = kp_s[k + 1] - pb[u];
+                const double* src = psum + (size_t)pb[u] * 30 + q;  // pb < n_wg always: a kernel without entries reads a neighbour's piece, unused
+                if (fresh) { pv[u][0] = ld_fresh(src); pv[u][1] = ld_fresh(src + (np[u] > 1 ? 30 : 0)); }
+                else { pv[u][0] = ld_agent(src); pv[u][1] = ld_agent(src + (np[u] > 1 ? 30 : 0)); }
+                more |= np[u] > 2;
+            }
+#pragma unroll
+            for (int u = 0; u < NO; u++) {
+                sum[u] = np[u] > 0 ? pv[u][0] : 0.0;
+                if (np[u] > 1) sum[u] += pv[u][1];
+            }
+            if (__builtin_amdgcn_ballot_w64(more) != 0ull) {
+#pragma unroll
+                for (int u = 0; u < NO; u++) {
+                    const int o = min(t + PN_COOP_THREADS * u, n3 - 1);
+                    const double* src = psum + (size_t)pb[u] * 30 + o % 30;
+                    if (fresh) { pv[u][0] = ld_fresh(src + (np[u] > 2 ? 60 : 0)); pv[u][1] = ld_fresh(src + (np[u] > 3 ? 90 : 0)); }
+                    else { pv[u][0] = ld_agent(src + (np[u] > 2 ? 60 : 0)); pv[u][1] = ld_agent(src + (np[u] > 3 ? 90 : 0)); }
+                }
+#pragma unroll
+                for (int u = 0; u < NO; u++) {
+                    if (np[u] > 2) sum[u] += pv[u][0];
+                    if (np[u] > 3) sum[u] += pv[u][1];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NO; u++) {
+                const int o = t + PN_COOP_THREADS * u;
+                if (o < n3) { const int j = o / 3, c = o - j * 3; Xs[c * n + j] = Cs[o] + sum[u]; }  // SoA by component: conflict-free reads in the row products
+            }
+        }
+        __syncthreads();
+        PN_COOP_CLK(4);
+        if (wid < nrow) {  // wave wid = row r0 + wid: lane-strided columns from registers, X from LDS, one reduction of three values
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+            for (int u = 0; u < CW; u++) {
+                const int j = lane + 64 * u;
+                if (j < n) {
+                    a0 += Areg[u] * Xs[j]; a1 += Areg[u] * Xs[n + j]; a2 += Areg[u] * Xs[2 * n + j];
+                }
+            }
+            a0 = wave_sum_d(a0); a1 = wave_sum_d(a1); a2 = wave_sum_d(a2);
+            if (lane < 3) {
+                const double sacc = lane == 0 ? a0 : (lane == 1 ? a1 : a2);
+                const size_t o = (size_t)(r0 + wid) * 3 + lane;
+                const double dnew = rest_o + sacc;  // solver.py:601
+                st_agent(dof_out + o, dnew);
+                if (it == iters - 1) dof_vel[o] = (dnew - last_o) / dt * 0.998;  // solver.py:602 (k_step_end)
+            }
+        }
+        PN_COOP_CLK(5);
+        if (it < iters - 1 && !(dbg & 2) && !coop_sync(ctl, ++g, per_xcd, xcd)) return;
+        PN_COOP_CLK(6);
+    }
+    if (clk_on) for (int i = 0; i < 9; i++) reinterpret_cast<unsigned long long*>(ctl->err + 8)[i] += clk_s[i];
+#undef PN_COOP_CLK
+    __syncthreads();
+    for (int e = t; e < nown * 9; e += PN_COOP_THREADS) Vstore[(size_t)v0 * 9 + e] = Qs[e];
+}
+
+extern "C" uint64_t pn_sim_coop_bytes(int n_k, int n_IP, int n_wg) {
+    PnCoopPlan pl;
+    if (n_k <= 0 || n_IP <= 0 || !pn_coop_plan(n_k, n_IP, n_wg, nullptr, &pl)) return 0;
+    return pl.bytes;
+}
+
+// Lays out the pieces (host side: reads csr_cnt back once) and clears the barrier state.  Returns PN_ERR_ARG when the scene does not fit the
+// persistent form (more than 2048 unknowns per component, lists too long for n_wg register-resident pieces, LDS) — the caller keeps the launch form.
+extern "C" int pn_sim_coop_prepare(int n_k, int n_IP, int n_wg, const int* csr_bg, const int* csr_cnt, void* coop, int* plan_out, void* stream) {
+    PN_REQUIRE(n_k > 0 && n_IP > 0 && csr_bg && csr_cnt && coop && plan_out);
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<int> cnt(n_k), bg(n_k);
+    PN_HIP_CHECK(hipMemcpyAsync(cnt.data(), csr_cnt, (size_t)n_k * sizeof(int), hipMemcpyDeviceToHost, st));
+    PN_HIP_CHECK(hipMemcpyAsync(bg.data(), csr_bg, (size_t)n_k * sizeof(int), hipMemcpyDeviceToHost, st));
+    PN_HIP_CHECK(hipStreamSynchronize(st));
+    PnCoopPlan pl;
+    PN_REQUIRE(pn_coop_plan(n_k, n_IP, n_wg, cnt.data(), &pl));
+    PN_REQUIRE(pl.max_pieces_per_kernel <= PN_COOP_MAXP);
+    std::vector<unsigned char> img(pl.bytes, 0);
+    int4* pieces = reinterpret_cast<int4*>(img.data() + pl.off_pieces);
+    int* kp = reinterpret_cast<int*>(img.data() + pl.off_kp);
+    const int pmax = pl.eu * PN_COOP_NS;
+    int np = 0;
+    for (int k = 0; k < n_k; k++) {
+        kp[k] = np;
+        for (int b = 0; b < cnt[k]; b += pmax) pieces[np++] = make_int4(k, bg[k] + b, std::min(pmax, cnt[k] - b), b / pmax);
+    }
+    kp[n_k] = np;
+    PN_REQUIRE(np == pl.n_pieces);
+    PN_HIP_CHECK(hipMemcpyAsync(coop, img.data(), pl.bytes, hipMemcpyHostToDevice, st));
+    PN_HIP_CHECK(hipStreamSynchronize(st));
+    plan_out[0] = pl.n_pieces;
+    plan_out[1] = pl.eu;
+    plan_out[2] = pl.max_pieces_per_kernel;
+    return PN_OK;
+}
+
+// 0: no launch of this buffer has timed out at a barrier; 1: one has (its results are invalid; pn_sim_coop_prepare again before reuse).  Synchronous.
+extern "C" int pn_sim_coop_status(const void* coop, int* timed_out) {
+    PN_REQUIRE(coop && timed_out);
+    PN_HIP_CHECK(hipMemcpy(timed_out, reinterpret_cast<const PnCoopCtl*>(coop)->err, sizeof(int), hipMemcpyDeviceToHost));
+    return PN_OK;
+}
+
+// Timing experiments (PN_SIM_COOP_DBG & 4): the nine tick accumulators of workgroup 0 (integration points, exchange, pieces, exchange, assembly,
+// rows, exchange, -, kernel start), 100 MHz ticks summed over all launches since pn_sim_coop_prepare.
+extern "C" int pn_sim_coop_clocks(const void* coop, uint64_t* ticks9) {
+    PN_REQUIRE(coop && ticks9);
+    PN_HIP_CHECK(hipMemcpy(ticks9, reinterpret_cast<const PnCoopCtl*>(coop)->err + 8, 9 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return PN_OK;
+}
+
+extern "C" int pn_sim_stepforward_coop(int n_k, int n_IP, int iters, double dt, double dx, const int* topo, const double* mu, const double* lam,
+                                       const double* dNx, const double* dNx_csr, const int* csr_pos, const double* Ainv, const double* Mmat,
+                                       const double* dof_rest, const double* rhs_rest, const double* rhs_gravity, const double* dof_f, double* dof,
+                                       double* dof_vel, double* work, void* coop, int n_wg, const int* plan, void* stream) {
+    PN_REQUIRE(n_k > 0 && n_IP > 0 && iters >= 1 && iters <= PN_COOP_ITERS && topo && mu && lam && dNx && dNx_csr && csr_pos && Ainv && Mmat);
+    PN_REQUIRE(dof_rest && rhs_rest && rhs_gravity && dof_f && dof && dof_vel && work && coop);
+    hipStream_t st = (hipStream_t)stream;
+    PnCoopPlan pl;
+    PN_REQUIRE(plan);
+    const int n_pieces = plan[0], eu = plan[1], max_rank = plan[2];
+    PN_REQUIRE(n_pieces > 0 && n_pieces <= n_wg && eu >= 1 && eu <= PN_COOP_EU && max_rank >= 1 && max_rank <= PN_COOP_MAXP);
+    PN_REQUIRE(pn_coop_plan(n_k, n_IP, n_wg, nullptr, &pl, eu));
+    const int n = n_k * 10, n3 = n * 3;
+    double* tilde = work;
+    double* last = work + n3;
+    double* momentum = work + 2 * (size_t)n3;
+    double* P_csr = work + 4 * (size_t)n3 + (size_t)n_IP * 9;
+    double* Vstore = pn_sim_vstore(work, n_k, n_IP);
+    unsigned char* cb = reinterpret_cast<unsigned char*>(coop);
+    // the smallest register-resident shape that holds this scene
+    const int cw = (n + 63) / 64, no = (n3 + PN_COOP_THREADS - 1) / PN_COOP_THREADS;
+    const bool small = cw <= 22 && no <= 9;
+    auto kern = small ? k_substep_coop<22, PN_COOP_EU, 9> : k_substep_coop<PN_COOP_CU * 8, PN_COOP_EU, PN_COOP_CU * 3>;
+    if (pl.lds_bytes > 48 * 1024) {  // dynamic LDS above 48 KB is opted into per device (and per function)
+        static size_t granted[2][PN_MAX_DEVICES] = {{0}, {0}};
+        int dev_id = 0;
+        PN_HIP_CHECK(hipGetDevice(&dev_id));
+        if (dev_id < 0 || dev_id >= PN_MAX_DEVICES || pl.lds_bytes > granted[small][dev_id]) {
+            PN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
+            if (dev_id >= 0 && dev_id < PN_MAX_DEVICES) granted[small][dev_id] = pl.lds_bytes;
+        }
+    }
+    k_step_begin<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, dt, dof, dof_vel, tilde, last, reinterpret_cast<int*>(cb));
+    k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Mmat, tilde, momentum, 1, dof_f, rhs_gravity);  // compute_momentum (:574-576)
+    kern<<<n_wg, PN_COOP_THREADS, pl.lds_bytes, st>>>(n_k, n_IP, iters, dt, pow(dx, 3.0), topo, csr_pos, mu, lam, dNx, dNx_csr, Ainv, dof_rest, rhs_rest, momentum, last,
+                                                      dof, dof_vel, P_csr, Vstore, reinterpret_cast<PnCoopCtl*>(cb), reinterpret_cast<const int4*>(cb + pl.off_pieces),
+                                                      reinterpret_cast<const int*>(cb + pl.off_kp), reinterpret_cast<double*>(cb + pl.off_psum), reinterpret_cast<double*>(cb + pl.off_dofx), n_pieces, eu,
+                                                      pl.ipw, pl.rpw, max_rank, (int)pn_env_u32("PN_SIM_COOP_DBG", 0));
     PN_LAUNCH_CHECK();
     return PN_OK;
 }

@@ -247,6 +247,12 @@ class SimRenderHarness:
         if n_trips is None:  # calibrate: the trips one eager frame needs from the current state and pose, plus a margin
             self.step(simulate=False, collect_stats=True, W=W, H=H)
             n_trips = int(self.model.last_stats["trips"]) + 2  # every captured trip costs five launches whether it has rays or not
+        from .frames import dedicated_sim_default
+        if (world > 1 and (dedicated_sim_default(world) if dedicated_sim is None else bool(dedicated_sim)) and rank == sim_owner
+                and dist.get_backend(group) == "nccl"):  # (a gloo group is the one-GPU dry run: the ranks share the device)
+            # this GPU only simulates: the substep's local/global iterations as one persistent kernel on every CU (csrc/pn_sim.hip: k_substep_coop;
+            # 0.24 instead of 0.28 ms).  Never beside renders: its workgroups and those of the fused composite/compaction would wait for each other
+            self.sim.enable_persistent()
         be = _HipBackend(self, lanes, depth, int(n_trips), W, H, sim_priority, sim_cus, copy_out, group if on else None,
                          (dist.get_global_rank(group, sim_owner) if (on and group is not None) else sim_owner), _probe_no_substep, _time_trips, copy_on)
         self._pipe = FramePipeline(be, world=world, rank=rank, lanes=lanes, depth=depth, ahead=(lanes if sim_ahead is None and world == 1 else sim_ahead),

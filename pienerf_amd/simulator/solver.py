@@ -9,6 +9,7 @@ Kept: constructor arguments, ``InitializeFromPly``, ``get_IP_info`` (fp32, permu
   * importing this module does not call ``torch.set_default_device("cuda")`` (func_utils.py:6).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -32,8 +33,15 @@ class _null_ctx:
 class Simulator:
     def __init__(self, dt=1e-2, iters=20, bbox=torch.tensor([1.0, 1.0, 1.0], dtype=torchfloat), kres=7, dx=1,
                  gravity=torch.tensor([0.0, -9.8, 0.0], dtype=torchfloat), stiff=1e5, base=torch.tensor([-0.5, -0.5, -0.5], dtype=torchfloat),
-                 device="cuda"):
+                 device="cuda", persistent=None):
         self.device = torch.device(device)
+        # persistent: run the local/global iterations of a substep as ONE cooperative kernel (pn_sim_stepforward_coop) instead of four launches per
+        # iteration.  None: environment PN_SIM_COOP (1 / 0), default off — the persistent kernel wants every CU for itself, which suits a GPU that
+        # only simulates (the owner rank of a frame-parallel job, a latency-bound single frame) and not one that renders three frames beside it
+        if persistent is None:
+            persistent = os.environ.get("PN_SIM_COOP", "") == "1"
+        self.persistent = bool(persistent)
+        self._coop = None
         bbox = bbox.clone() * 1.02   # solver.py:24-25 multiply in the caller's dtype (main_gui.py passes float32), then widen
         base = base.clone() * 1.01
         self.dt, self.iters, self.dx, self.kres, self.stiff = dt, iters, dx, kres, stiff
@@ -213,10 +221,55 @@ class Simulator:
                                     ptr(pos), ptr(F), ptr(dF), stream_ptr()), "update_F")
         return pos, F, dF
 
+    def _prepare_persistent(self):
+        """Lays out the persistent kernel's pieces (one host read-back of the CSR counts); falls back to the launch form when the scene does not fit."""
+        # one workgroup per CU, minus a few CUs left to whatever else runs on the device meanwhile (a collective's kernels, a copy kernel): a
+        # persistent workgroup takes a CU's whole register file, and with no CU to spare the launch would wait for those kernels to end
+        n_wg = min(max(int(lib().pn_device_cu_count()) - int(os.environ.get("PN_SIM_COOP_RESERVE", "8")), 8), 256)
+        nbytes = int(lib().pn_sim_coop_bytes(self.n_k, self.n_IP, n_wg))
+        self._coop = None
+        if nbytes == 0:
+            self.persistent = False
+            return
+        buf = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        plan = (C.c_int32 * 3)()
+        rc = lib().pn_sim_coop_prepare(self.n_k, self.n_IP, n_wg, ptr(self.kernel_bg), ptr(self.kernel_cnt), ptr(buf), plan, stream_ptr())
+        if rc != 0:  # PN_ERR_ARG: lists too long for register-resident pieces
+            self.persistent = False
+            return
+        self._coop = (buf, n_wg, plan)
+
+    def enable_persistent(self):
+        """Switch to the persistent substep (a harness calls this for a GPU that only simulates: the owner rank of a frame-parallel job with a
+        dedicated simulator).  PN_SIM_COOP=0 vetoes it; scenes that do not fit keep the launch form.  Returns whether it is on."""
+        if os.environ.get("PN_SIM_COOP", "") == "0":
+            return False
+        self.persistent = True
+        if getattr(self, "_prepared", False) and self._coop is None:
+            self._prepare_persistent()
+        return self.persistent and (self._coop is not None or not getattr(self, "_prepared", False))
+
+    def persistent_timed_out(self):
+        """True if a persistent substep gave up waiting at a device-wide barrier (its workgroups could not all become resident): results invalid."""
+        if self._coop is None:
+            return False
+        flag = C.c_int32(0)
+        check(lib().pn_sim_coop_status(ptr(self._coop[0]), C.byref(flag)), "sim_coop_status")
+        return flag.value != 0
+
     def stepforward(self):  # solver.py:595-602
         if not self._prepared:
             check(lib().pn_sim_prepare(self.n_k, self.n_IP, ptr(self.kernel_bg), ptr(self.kernel_cnt), ptr(self._work), stream_ptr()), "sim_prepare")
             self._prepared = True
+            if self.persistent:
+                self._prepare_persistent()
+        if self.persistent and self._coop is not None and 1 <= self.iters <= 32:
+            buf, n_wg, plan = self._coop
+            check(lib().pn_sim_stepforward_coop(self.n_k, self.n_IP, int(self.iters), float(self.dt), float(self.dx), ptr(self.IP_kernel), ptr(self.IP_mu),
+                                                ptr(self.IP_lam), ptr(self.IP_dNx), ptr(self.dNx_csr), ptr(self.csr_pos), ptr(self.Ainv), ptr(self.Mmat),
+                                                ptr(self.dof_rest), ptr(self.rhs_rest), ptr(self.rhs_gravity), ptr(self.dof_f), ptr(self.dof), ptr(self.dof_vel),
+                                                ptr(self._work), ptr(buf), n_wg, plan, stream_ptr()), "stepforward_coop")
+            return
         check(lib().pn_sim_stepforward(self.n_k, self.n_IP, int(self.iters), float(self.dt), float(self.dx), ptr(self.IP_kernel), ptr(self.kernel_bg),
                                        ptr(self.kernel_cnt), ptr(self.buffer), ptr(self.IP_mu), ptr(self.IP_lam), ptr(self.IP_dNx), ptr(self.dNx_csr), ptr(self.csr_pos), ptr(self.Ainv),
                                        ptr(self.Mmat), ptr(self.dof_rest), ptr(self.rhs_rest), ptr(self.rhs_gravity), ptr(self.dof_f), ptr(self.dof),

@@ -1,0 +1,98 @@
+"""The substep's local/global iterations as ONE persistent kernel (pn_sim_stepforward_coop, csrc/pn_sim.hip: k_substep_coop) against the launch form
+(pn_sim_stepforward) and the fp64 CPU oracle: same trajectory, bit-reproducible, inside captured graphs, and the fallback when a scene does not fit."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_oracle_sim, rel_err
+from pienerf_amd import scene
+from test_gpu_parity import DEV
+
+pytestmark = pytest.mark.gpu
+
+
+def _sim(cloud, opt, persistent, iters=None):
+    from pienerf_amd.simulator.solver import Simulator
+    s = Simulator(dt=opt["sim_dt"], iters=opt["sim_iters"] if iters is None else iters, bbox=torch.tensor([2.0 * opt["bound"]] * 3), dx=opt["sim_dx"],
+                  stiff=opt["sim_stiff"], base=torch.tensor([-opt["bound"]] * 3), device=DEV, persistent=persistent)
+    s.InitializeFromArrays(cloud["pos"], cloud["mass"], cloud["mu"], cloud["lam"], cloud["pin"])
+    return s
+
+
+def _run(s, steps, force_at=None, f=(300.0, 100.0, -200.0)):
+    traj = []
+    for k in range(steps):
+        if force_at is not None and k == force_at:
+            s.update_force(s.n_IP // 2, np.array(f))
+        s.stepforward()
+        traj.append(s.dof.clone())
+    torch.cuda.synchronize()
+    return traj
+
+
+@pytest.mark.parametrize("iters", [1, 4, 10])
+def test_persistent_substep_equals_the_launch_form_small_scene(small_cloud, small_opt, iters):
+    a, b = _sim(small_cloud, small_opt, False, iters), _sim(small_cloud, small_opt, True, iters)
+    ta, tb = _run(a, 8, force_at=2), _run(b, 8, force_at=2)
+    assert b.persistent and b._coop is not None and not b.persistent_timed_out()
+    rest = a.dof_rest
+    for k, (x, y) in enumerate(zip(ta, tb)):
+        # different summation orders (pieces of <= 272 entries instead of chunks of 128, a different lane -> column map in the matrix rows)
+        assert rel_err((y - rest).cpu().numpy(), (x - rest).cpu().numpy()) < 1e-9, k
+    assert rel_err(b.dof_vel.cpu().numpy(), a.dof_vel.cpu().numpy()) < 1e-7
+    assert float((ta[-1] - rest).abs().max()) > 1e-3  # the force moved it
+
+
+def test_persistent_substep_full_size_against_the_oracle_and_reproducible():
+    """139 kernels / 3 576 IPs on every CU: three substeps against the fp64 oracle (the launch form's own bar, 1e-6), the same bits from a second
+    simulator, the same trajectory as the launch form to 1e-9."""
+    opt = scene.default_opt()
+    cloud = scene.make_chair_points(hgs=opt["hash_grid_size"])
+    ref = make_oracle_sim(cloud, opt)
+    a, b, c = _sim(cloud, opt, True), _sim(cloud, opt, True), _sim(cloud, opt, False)
+    assert (a.n_k, a.n_IP) == (ref.n_k, ref.n_IP) == (139, 3576)
+    f = np.array([300.0, 100.0, -200.0])
+    for s in (a, b, c, ref):
+        s.update_force(s.n_IP // 2, f)
+    for step in range(3):
+        for s in (a, b, c, ref):
+            s.stepforward()
+            torch.cuda.synchronize()
+        da = a.dof.cpu().numpy().reshape(-1, 3) - ref.dof_rest
+        assert rel_err(da, ref.dof - ref.dof_rest) < 1e-6, step
+        assert torch.equal(a.dof, b.dof) and torch.equal(a.dof_vel, b.dof_vel), step
+        assert rel_err(da, c.dof.cpu().numpy().reshape(-1, 3) - ref.dof_rest) < 1e-9, step
+    assert a._coop is not None and not a.persistent_timed_out() and not b.persistent_timed_out()
+
+
+def test_persistent_substep_inside_a_captured_graph(small_cloud, small_opt):
+    """Replays of a captured persistent substep == eager persistent substeps, bit for bit.  (One persistent kernel at a time per device: two of
+    them on different streams can each hold part of the CUs and wait for the rest — the kernel's barrier guard then ends both with the timed-out
+    flag — so the two simulators take turns here.)"""
+    a, b = _sim(small_cloud, small_opt, True), _sim(small_cloud, small_opt, True)
+    for s in (a, b):
+        s.update_force(s.n_IP // 3, np.array([0.0, 250.0, 50.0]))
+        s.stepforward()
+        torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(g, stream=st):
+        b.stepforward()
+    with torch.cuda.stream(st):
+        for _ in range(4):  # a capture only records: 1 eager step + 4 replays
+            g.replay()
+    torch.cuda.synchronize()
+    for _ in range(4):
+        a.stepforward()
+    torch.cuda.synchronize()
+    assert not a.persistent_timed_out() and not b.persistent_timed_out()
+    assert torch.equal(b.dof, a.dof) and torch.equal(b.dof_vel, a.dof_vel)
+
+
+def test_scene_that_does_not_fit_keeps_the_launch_form():
+    """343 kernels: 3430 unknowns per component > 2048 register-resident columns: pn_sim_coop_bytes says 0 and the simulator steps as before."""
+    from pienerf_amd._lib import lib
+    assert int(lib().pn_sim_coop_bytes(343, 20000, 256)) == 0
+    assert int(lib().pn_sim_coop_bytes(139, 3576, 256)) > 0
+    assert int(lib().pn_sim_coop_bytes(139, 3576, 4)) == 0       # 894 integration points per workgroup
