@@ -46,6 +46,8 @@ const char* pn_last_error(void);
 
 /* ------------------------------------------------------------------ raymarching ---- */
 
+/* raymarching/src/raymarching.h:8 sph_from_ray (kernel raymarching.cu:165-202): coords [N,2] in [-1,1] where each ray leaves the sphere. */
+int pn_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords, void* stream);
 /* raymarching/src/raymarching.h:7 near_far_from_aabb (kernel raymarching.cu:91-159). */
 int pn_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near, float* nears, float* fars,
                           void* stream);

@@ -87,6 +87,14 @@ def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2):
     return nears, fars
 
 
+def sph_from_ray(rays_o, rays_d, radius):
+    rays_o, rays_d = _f32(rays_o).reshape(-1, 3), _f32(rays_d).reshape(-1, 3)
+    N = rays_o.shape[0]
+    coords = np.empty((N, 2), np.float32)
+    lib().orc_sph_from_ray(_p(rays_o, F), _p(rays_d, F), F(radius), C.c_uint32(N), _p(coords, F))
+    return coords
+
+
 def get_pnts_in_grids(n_vtx, n_grid, pnts, bbmin, bbmax, hgs, resolution):
     pnts, bbmin, resolution = _f32(pnts), _f32(bbmin), _i32(resolution)
     cnt, bgn, idx = np.zeros(n_grid, np.int32), np.zeros(n_grid, np.int32), np.zeros(n_vtx, np.int32)

@@ -613,6 +613,24 @@ void nerf_one(const Net& nt, const float* xyz, const float* dir, float* sigma, f
 
 extern "C" {
 
+// raymarching.cu:165-202
+void orc_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords) {
+    for (int64_t n = 0; n < (int64_t)N; n++) {
+        const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+        const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+        const float A = dx * dx + dy * dy + dz * dz;
+        const float B = ox * dx + oy * dy + oz * dz;
+        const float Cq = ox * ox + oy * oy + oz * oz - radius * radius;
+        const float t = (-B + sqrtf(B * B - A * Cq)) / A;
+        const float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+        const float theta = atan2f(sqrtf(x * x + z * z), y);
+        const float phi = atan2f(z, x);
+        const float rpi = 0.3183098861837907f;
+        coords[n * 2] = 2 * theta * rpi - 1;
+        coords[n * 2 + 1] = phi * rpi;
+    }
+}
+
 // raymarching.cu:91-159
 void orc_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N, float min_near, float* nears, float* fars) {
 #pragma omp parallel for schedule(static)

@@ -33,6 +33,7 @@ SIGNATURES = {
     "pn_copier_submit": (i32, [P, P, P, C.c_uint64, P, C.POINTER(C.c_uint64)]),
     "pn_copier_wait": (i32, [P, C.c_uint64]),
     "pn_near_far_from_aabb": (i32, [P, P, P, u32, f32, P, P, P]),
+    "pn_sph_from_ray": (i32, [P, P, f32, u32, P, P]),
     "pn_march_rays_quadratic_bending": (i32, [P, P, P, i32, i32, P, P, P, P, i32, P, P, f32, P, i32, f32, i32, P, u32, u32, P, P, P, P, f32, f32, u32,
                                               u32, u32, P, P, P, P, P, P, P, P, P]),
     "pn_composite_rays": (i32, [u32, u32, f32, P, P, P, P, P, P, P, P, P]),

@@ -61,6 +61,35 @@ struct PnFrameDev {
     int pad[2];
 };
 
+// ------------------------------------------------------------------------------------------------ sph_from_ray
+// kernel_sph_from_ray, raymarching.cu:165-202: where the ray leaves the sphere of `radius` (the larger root), as (theta, phi) scaled to [-1, 1] —
+// the texture coordinate of the background model (renderer.py:246, bg_radius > 0).  atan2f / sqrtf of the device library, like the reference.
+__global__ void __launch_bounds__(256) k_sph_from_ray(const float* __restrict__ rays_o, const float* __restrict__ rays_d, float radius, uint32_t N,
+                                                      float* __restrict__ coords) {
+    const uint32_t n = threadIdx.x + blockIdx.x * blockDim.x;
+    if (n >= N) return;
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+    const float A = dx * dx + dy * dy + dz * dz;
+    const float B = ox * dx + oy * dy + oz * dz;  // B / 2 of the quadratic
+    const float Cq = ox * ox + oy * oy + oz * oz - radius * radius;
+    const float t = (-B + sqrtf(B * B - A * Cq)) / A;
+    const float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+    const float theta = atan2f(sqrtf(x * x + z * z), y);  // y is up
+    const float phi = atan2f(z, x);
+    const float rpi = 0.3183098861837907f;
+    coords[n * 2] = 2 * theta * rpi - 1;
+    coords[n * 2 + 1] = phi * rpi;
+}
+
+extern "C" int pn_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords, void* stream) {
+    if (N == 0) return PN_OK;
+    PN_REQUIRE(rays_o && rays_d && coords);
+    k_sph_from_ray<<<pn_div_up(N, 256), 256, 0, (hipStream_t)stream>>>(rays_o, rays_d, radius, N, coords);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ near/far
 // kernel_near_far_from_aabb, raymarching.cu:91-159
 __global__ void __launch_bounds__(256) k_near_far(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ aabb,

@@ -9,7 +9,7 @@ import torch
 
 from .._lib import check, lib, ptr, require_gpu, stream_ptr
 
-__all__ = ["near_far_from_aabb", "march_rays_quadratic_bending", "march_rays", "composite_rays", "compact_rays", "morton3D", "morton3D_invert",
+__all__ = ["near_far_from_aabb", "sph_from_ray", "march_rays_quadratic_bending", "march_rays", "composite_rays", "compact_rays", "morton3D", "morton3D_invert",
            "packbits", "march_rays_train", "composite_rays_train"]
 
 
@@ -33,6 +33,21 @@ def near_far_from_aabb(rays_o, rays_d, aabb, min_near=0.2):
     check(lib().pn_near_far_from_aabb(ptr(rays_o), ptr(rays_d), ptr(aabb), N, float(min_near), ptr(nears), ptr(fars), stream_ptr()),
           "near_far_from_aabb")
     return nears, fars
+
+
+def sph_from_ray(rays_o, rays_d, radius):
+    """raymarching/raymarching.py:54-82.  rays_o, rays_d [N,3] -> coords [N,2] in [-1,1] (theta, phi of the point where the ray leaves the sphere)."""
+    if not rays_o.is_cuda:
+        rays_o = rays_o.cuda()
+    if not rays_d.is_cuda:
+        rays_d = rays_d.cuda()
+    rays_o = _f32(rays_o).view(-1, 3)
+    rays_d = _f32(rays_d).view(-1, 3)
+    require_gpu(rays_o, rays_d)
+    N = rays_o.shape[0]
+    coords = torch.empty(N, 2, dtype=rays_o.dtype, device=rays_o.device)
+    check(lib().pn_sph_from_ray(ptr(rays_o), ptr(rays_d), float(radius), N, ptr(coords), stream_ptr()), "sph_from_ray")
+    return coords
 
 
 def march_rays_quadratic_bending(pig_cnt, pig_bgn, pig_idx, n_vtx, n_grid, p_def, p_ori, F_IP, dF_IP, max_iter_num, bbmin, bbmax, hgs, res,

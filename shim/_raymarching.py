@@ -35,7 +35,9 @@ def near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars):
 
 
 def sph_from_ray(rays_o, rays_d, radius, N, coords):
-    raise NotImplementedError("sph_from_ray (background model, bg_radius > 0) is not on the simulate-and-render path and is not built (DESIGN.md 7)")
+    _c(rays_o, rays_d, coords)
+    _f32(rays_o, rays_d, coords)
+    check(lib().pn_sph_from_ray(ptr(rays_o), ptr(rays_d), float(radius), int(N), ptr(coords), stream_ptr()), "sph_from_ray")
 
 
 def morton3D(coords, N, indices):

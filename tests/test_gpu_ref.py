@@ -89,6 +89,13 @@ def test_near_far_morton_packbits_bit_exact(mods):
     assert bits_equal(out["ours"][0], out["ref"][0]) and bits_equal(out["ours"][1], out["ref"][1])
     assert (out["ref"][0] > 1e30).any() and (out["ref"][0] < 10).any()
     REPORT["near_far_vs_fma"] = dict(nears=mismatch(out["ours"][0], out["fma"][0]), fars=mismatch(out["ours"][1], out["fma"][1]))
+    sph = {}
+    for name, m in (("ref", ref), ("ours", ours)):   # kernel_sph_from_ray (raymarching.cu:165-202): same device libm, no contraction -> bit for bit
+        c = torch.empty(N, 2, device=DEV)
+        m["raymarching"].sph_from_ray(T(o), T(d), 8.0, N, c)
+        sph[name] = c
+    assert bits_equal(sph["ours"], sph["ref"]) and float(sph["ref"].abs().max()) <= 1.0
+    assert np.abs(sph["ours"].cpu().numpy() - oracle.sph_from_ray(o, d, 8.0)).max() < 2e-6
     coords = torch.randint(0, 1024, (5000, 3), dtype=torch.int32, device=DEV)
     grid = torch.rand(128 ** 3, device=DEV) * 20
     res = {}

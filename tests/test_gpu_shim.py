@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 
+import oracle
 from conftest import ROOT
 from pienerf_amd import scene
 
@@ -114,8 +115,10 @@ def test_reference_call_sequence_through_the_backend_modules(shim_path, small_cl
     _backend.morton3D(coords, 1000, idx)
     _backend.morton3D_invert(idx, 1000, back)
     assert torch.equal(back, coords)
-    with pytest.raises(NotImplementedError):
-        _backend.sph_from_ray(rays_o, rays_d, 2.0, N, torch.empty(N, 2, device=DEV))
+    sph = torch.empty(N, 2, device=DEV)
+    _backend.sph_from_ray(rays_o, rays_d, 8.0, N, sph)   # raymarching.h:8 (background model's texture coordinate)
+    want_sph = oracle.sph_from_ray(rays_o.cpu().numpy(), rays_d.cpu().numpy(), 8.0)   # the camera sits inside the sphere
+    assert np.abs(sph.cpu().numpy() - want_sph).max() < 2e-6 and float(sph.abs().max()) <= 1.0 + 1e-6   # atan2f of the device library vs libm: a few ulp
 
 
 def test_backend_modules_reject_wrong_element_types(shim_path):

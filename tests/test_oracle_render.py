@@ -374,3 +374,23 @@ def test_render_static_properties():
     assert np.all(r1["image"][ws == 0] == 1.0) and (ws > 0.9).sum() > 20
     nears, _ = oracle.near_far_from_aabb(o, d, np.array([-1, -1, -1, 1, 1, 1], np.float32), 0.2)
     assert np.array_equal(np.isnan(r1["depth"]), nears > 1e30)  # 0/0 exactly where the ray misses the +-bound box (renderer.py:384)
+
+
+def test_sph_from_ray_against_the_closed_form():
+    """oracle.sph_from_ray (raymarching.cu:165-202) against a float64 evaluation of the same geometry: the exit point lies on the sphere, theta is the
+    polar angle from +y, phi the azimuth in the x-z plane, both scaled to [-1, 1]."""
+    import oracle
+    rng = np.random.default_rng(3)
+    o = rng.uniform(-0.8, 0.8, (500, 3)).astype(np.float32)
+    d = rng.normal(size=(500, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    R = 2.0
+    c = oracle.sph_from_ray(o, d, R)
+    o64, d64 = o.astype(np.float64), d.astype(np.float64)
+    A, B, Cq = (d64 * d64).sum(1), (o64 * d64).sum(1), (o64 * o64).sum(1) - R * R
+    t = (-B + np.sqrt(B * B - A * Cq)) / A
+    p = o64 + t[:, None] * d64
+    assert np.abs(np.linalg.norm(p, axis=1) - R).max() < 1e-9
+    theta, phi = np.arctan2(np.hypot(p[:, 0], p[:, 2]), p[:, 1]), np.arctan2(p[:, 2], p[:, 0])
+    assert np.abs(c[:, 0] - (2 * theta / np.pi - 1)).max() < 5e-6 and np.abs(c[:, 1] - phi / np.pi).max() < 5e-6
+    assert c.min() >= -1.0 and c.max() <= 1.0
