@@ -40,7 +40,13 @@ S eager python $R/tools/run_frames.py --frames 20 --no-counters
 AMD_LOG_LEVEL=4 python $R/tools/d2h_probe.py 2> /tmp/amdlog.txt > $O/d2h_probe.txt; grep "HSA Copy" /tmp/amdlog.txt | head -3 | cut -c1-260 >> $O/d2h_probe.txt; echo "HSA Copy lines: $(grep -c 'HSA Copy' /tmp/amdlog.txt)" >> $O/d2h_probe.txt
 cd $R
 tools/bin/calib_barrier > $O/calib_barrier.txt 2>&1
+tools/bin/calib_exchange > $O/calib_exchange.txt 2>&1
 python tools/time_sim.py > $O/time_sim.txt 2>&1; PN_SIM_COLD_SVD=1 python tools/time_sim.py >> $O/time_sim.txt 2>&1; PN_SIM_DBG_NOSVD=1 python tools/time_sim.py >> $O/time_sim.txt 2>&1
+PN_SIM_EL_WG=256 python tools/time_sim.py >> $O/time_sim.txt 2>&1
+python tools/time_sim.py --persistent 2>&1 | grep -v amdgpu.ids > $O/time_sim_persistent.txt; python tools/time_sim.py --persistent --iters 20 2>&1 | tail -1 >> $O/time_sim_persistent.txt
+PN_SIM_COOP_DBG=4 python tools/time_sim.py --persistent 2>&1 | grep -v amdgpu.ids >> $O/time_sim_persistent.txt
+PN_SIM_COOP_DBG=1 python tools/time_sim.py --persistent 2>&1 | tail -1 >> $O/time_sim_persistent.txt
+bash tools/gpu_env_sweep.sh PN_TAIL_GRID 256 512 1024 2048 2>&1 | grep -v "^{\|^trips" > $O/tail_grid_sweep.txt
 timeout 900 python tools/soak.py --frames 3000 > $O/soak_3000.json 2> $O/soak.err; tail -c 400 $O/soak_3000.json
 python tools/run_frames.py --frames 2 2>&1 | grep -E "counters|trips" > $O/trip_records.txt
 timeout 600 python tools/time_widened.py > $O/widened_rows.json 2> $O/widened.err
