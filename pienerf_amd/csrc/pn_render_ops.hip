@@ -1348,8 +1348,13 @@ __global__ void __launch_bounds__(256) k_compact(const int* __restrict__ in, uin
 // No chain: a chunk waits for the composites of earlier chunks, never for their sums, so the launch lasts one composite plus one gather of at
 // most n_chunks words.  (A decoupled look-back over 64 descriptors at a time was tried first: with every chunk of the trip in flight at once the
 // prefixes have nothing to propagate from — 10 dependent steps on trip 0 — and 1 250 returning ticket / completion atomics on one address at
-// 11.4 ns each: 174 us against 25 for the two launches.)  Progress: a chunk depends on lower-numbered chunks only, workgroups are dispatched in
-// index order and take their chunks in ascending order, so whatever a running workgroup polls belongs to a workgroup dispatched before it.
+// 11.4 ns each: 174 us against 25 for the two launches.)  Progress: a chunk depends on lower-numbered chunks only and every workgroup takes its
+// chunks in ascending order, so the launch finishes whenever ALL its workgroups can be resident at the same time — which is why the grid is bounded
+// (PN_CC_GRID, 512 workgroups of 4 waves: three render lanes' composites together stay below the 8 192 wave slots of the part).  Rounds 2-3 launched
+// one workgroup per chunk (2 500 on a frame's first trip) on the assumption that workgroups start in index order; the eight XCDs dispatch their shares
+// independently, and two first-trip composites of different lanes could each fill an XCD with pollers waiting for a chunk whose workgroup had no slot
+// on the other one: a deadlock, seen (as the poll guard's flag 16) in bench.py --config stress.  A workgroup's later chunks add only the words
+// behind its previous chunk to the prefix it already has: 512 words per chunk instead of all before it.
 // The tag makes last trip's words read as "not written yet"; the words are cleared once per frame (k_frame_prologue).  The workgroup of the
 // trip's LAST chunk has the grand total and runs trip_epilogue: every earlier chunk has published its count, i.e. finished its composites and
 // its per-group survivor atomics.  R = alive positions per thread (1; PN_CC_R0 = 2 / 4 for the frame's first trip are kept for experiments:
@@ -1360,12 +1365,15 @@ __global__ void __launch_bounds__(256) k_composite_compact(float T_thresh, const
                                                            float* weights_sum, float* depth, float* image, PnTrip* trip, PnTrip* next,
                                                            unsigned* words, uint32_t tag, uint32_t N_rays, uint32_t max_steps, int dense_trips,
                                                            int* seg_counters, int* tail_diag, const PnGroup* __restrict__ g_cur, PnGroup* __restrict__ g_next,
-                                                           int* group_cnt, uint32_t group_rays, uint32_t n_groups, int* err_flag) {
+                                                           int* group_cnt, uint32_t group_rays, uint32_t n_groups, int* err_flag, uint32_t poll_cap) {
     __shared__ int s_wcnt[4], s_part[4];
     const uint32_t n_alive = (uint32_t)trip->n_alive, n_step_trip = (uint32_t)trip->n_step;
     const uint32_t CH = 256u * R;
     const uint32_t n_chunks = max((n_alive + CH - 1) / CH, 1u);  // chunk 0 always runs: somebody has to write the next trip's record
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    bool have_prev = false;
+    uint32_t c_prev = 0;
+    int excl_prev = 0, count_prev = 0;
     for (uint32_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
         // ---- composite: R consecutive alive positions per thread
         int keep[R];
@@ -1415,16 +1423,16 @@ __global__ void __launch_bounds__(256) k_composite_compact(float T_thresh, const
         // relaxed, device scope: the word IS the message (the XCDs' L2s are not coherent with each other: release / acquire at device scope
         // write back and invalidate whole caches — with them this kernel took 185 us on trip 0)
         if (threadIdx.x == 0) __hip_atomic_store(words + c, (tag << 16) | (unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // ---- survivors of all chunks before this one
+        // ---- survivors of all chunks before this one: the words of the chunks behind this workgroup's previous chunk, on top of what it had there
         int part = 0;
-        for (uint32_t k = threadIdx.x; k < c; k += 256) {
+        for (uint32_t k = (have_prev ? c_prev + 1 : 0u) + threadIdx.x; k < c; k += 256) {
             unsigned w;
             uint32_t polls = 0;
             do {
                 w = __hip_atomic_load(words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // never seen: a word that stays unwritten would mean the dispatcher started this workgroup before a lower-numbered one that has
                 // no slot yet.  Rather than hang the GPU, give up after ~a second, flag the frame (err bit 16) and carry on with garbage.
-                if (++polls > (1u << 20)) { if (err_flag) atomicOr(err_flag, 16); w = tag << 16; }
+                if (++polls > poll_cap) { if (err_flag) atomicOr(err_flag, 16); w = tag << 16; }
             } while ((w >> 16) != tag);
             part += (int)(w & 0xFFFFu);
         }
@@ -1432,7 +1440,8 @@ __global__ void __launch_bounds__(256) k_composite_compact(float T_thresh, const
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
         if (lane == 0) s_part[wid] = part;
         __syncthreads();
-        const int excl = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        const int excl = (have_prev ? excl_prev + count_prev : 0) + s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        have_prev = true; c_prev = c; excl_prev = excl; count_prev = count;
         // ---- survivors in order
         int w0 = excl + tbase;
 #pragma unroll
@@ -2099,14 +2108,18 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             PnGroup* g_cur = group_rays ? f->groups + (size_t)(t & 1) * f->max_groups : nullptr;
             PnGroup* g_nxt = group_rays ? f->groups + (size_t)((t + 1) & 1) * f->max_groups : nullptr;
             const uint32_t pair_grid = margin ? std::min(trip_grid, 64u) : trip_grid;
-            if (!is_static && !split_compact && !margin) {
-                // one workgroup per possible chunk: a chunk then only ever waits for workgroups with a lower index, which the dispatcher started
-                // before it (a bounded grid with chunk loops could leave a resident workgroup polling a chunk whose workgroup has no slot yet)
+            // a frame's first trip has every ray alive (2 500 chunks at 800x800): five rounds of the bounded fused kernel (31 us) cost more than the two
+            // launches (25 us), which poll nothing; PN_CC_TRIP0=1 keeps the fused form there
+            static const bool cc_trip0 = pn_env_u32("PN_CC_TRIP0", 0) != 0;
+            if (!is_static && !split_compact && !margin && (t > 0 || cc_trip0)) {
+                // a bounded grid with chunk loops: all of a launch's workgroups can be resident at once, whatever order the XCDs start them in (see the kernel)
 #define PN_CC_LAUNCH(R_)                                                                                                                                   \
-    k_composite_compact<R_><<<pn_div_up(N, 256 * R_), 256, 0, st>>>(o->T_thresh, cur, nxt, f->rays_t, f->sigmas, f->rgbs, f->deltas, weights_sum, depth_0,          \
+    k_composite_compact<R_><<<std::min(cc_grid, pn_div_up(N, 256 * R_)), 256, 0, st>>>(o->T_thresh, cur, nxt, f->rays_t, f->sigmas, f->rgbs, f->deltas, weights_sum, depth_0,          \
                                                                      f->acc_image, f->trips + t, f->trips + t + 1, (unsigned*)f->chunk_counts, (uint32_t)t + 1, N, \
                                                                      o->max_steps, 1, f->seg_counters, f->tail_counts + t, g_cur, g_nxt, f->group_cnt, group_rays,  \
-                                                                     n_groups, err)
+                                                                     n_groups, err, cc_poll_cap)
+                static const uint32_t cc_grid = pn_env_u32("PN_CC_GRID", 512);
+                static const uint32_t cc_poll_cap = 1u << std::min(pn_env_u32("PN_CC_POLL_LOG2", 20), 30u);
                 static const uint32_t cc_r0 = pn_env_u32("PN_CC_R0", 1);  // alive positions per thread on a frame's first trip; measured 20.0 / 21.4 / 27.9 us for 1 / 2 / 4
                 if (t == 0 && cc_r0 >= 4) PN_CC_LAUNCH(4);
                 else if (t == 0 && cc_r0 == 2) PN_CC_LAUNCH(2);
