@@ -239,3 +239,15 @@ def test_shim_backends_match_the_reference_binding_signatures():
         sys.path.remove(shim)
         for k in [k for k in sys.modules if k.split(".")[0] in ("_raymarching", "_gridencoder", "_shencoder", "raymarching", "gridencoder", "shencoder", "simulator")]:
             del sys.modules[k]
+
+
+def test_persistent_substep_plan_limits_are_host_side_checks():
+    """pn_sim_coop_bytes is pure host arithmetic (no HIP call): which scenes the persistent substep takes, without a GPU."""
+    from pienerf_amd._lib import lib
+    L = lib()
+    assert int(L.pn_sim_coop_bytes(139, 3576, 248)) > 0          # the chair on 248 workgroups
+    assert int(L.pn_sim_coop_bytes(42, 1208, 256)) > 0           # the trex cloud
+    assert int(L.pn_sim_coop_bytes(343, 20000, 256)) == 0        # 3430 unknowns per component > 2048 register-resident columns
+    assert int(L.pn_sim_coop_bytes(139, 3576, 4)) == 0           # 894 integration points per workgroup
+    assert int(L.pn_sim_coop_bytes(139, 3576, 512)) == 0         # more workgroups than the barrier's groups are sized for
+    assert int(L.pn_sim_coop_bytes(0, 10, 256)) == 0
