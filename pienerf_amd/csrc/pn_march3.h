@@ -182,20 +182,28 @@ __device__ __forceinline__ int cell_coord(float v, float lo, float hgs, float rh
 // `cell_bits` (may be null): bit c set <=> search cell c has candidates, held in LDS by the caller — the emptiness test then costs an LDS read
 // instead of a dependent global round trip every third hop or so.
 // `far_override` >= 0: the ray's end (see ray_end_of_candidates) instead of a.fars[index].
-// `cell_bits2` (may be null; with cell_bits, no --cut, fixed step, one cascade): LATE START.  Most of the ~100 hops of a ray in here cross
-// cells that are nowhere near a candidate, and the only thing the caller needs is the element at which the chain first meets one.  The t-sequence is
-// a lattice (Binade) whatever the chain visits, and WHICH elements it visits is local: from any visited element of a voxel V the chain computes
-// tt ~ the parameter at which the ray leaves V and lands on the first lattice element >= tt — so an element e is visited whenever its predecessor p
-// lies safely inside its voxel (p < tt_p - margin, tt_p = the chain's own exit expression evaluated at p) and e lies safely behind that exit
-// (e >= tt_p + margin): whichever element of p's voxel the chain is on, it computes an exit within the margin of tt_p and lands on e (and if an
-// ambiguity further back made it skip p's voxel, it landed on the first element behind p: e again).  So: sample the ray forward every 0.9 cell
-// lengths until the first sample whose cell is within one cell of a cell with candidates (the map that also ends the rays, ray_end_of_candidates:
-// every point before that sample lies in a cell without candidates, with a whole cell of slack for the rounding of the reference's own cell
-// arithmetic), take the last lattice element before it that passes the test, and run the exact hops from there — a handful instead of a hundred.
-// No such element within 12 tries, another binade in between, a direction nearly parallel to a voxel face (margin too wide): the walk starts
-// where it always did.  Bit-identical by construction, and the march tests compare every ray with the oracle and with the reference's own kernel.
+// `cell_bits2` (may be null; with cell_bits, no --cut, fixed step, one cascade, bound <= 1): DDA START.  A hop is ~230 dependent instructions
+// (0.7 us for a lone wave) and the rays that graze the object do up to ~85 of them across cells in which nothing can happen: 65 of the pre-pass's
+// 77 us were its longest such walk.  All the caller needs is the element at which the chain first meets a cell with candidates, and two facts make it
+// computable without walking:
+//   * the t-sequence is a lattice (Binade) whatever the chain visits, and WHICH elements it visits is local: from any visited element of a voxel V the
+//     chain computes tt ~ the parameter at which the ray leaves V and lands on the first lattice element >= tt — so an element e is visited whenever
+//     its predecessor p lies safely inside its voxel (p < tt_p - margin, tt_p = the chain's own exit expression evaluated at p) and e lies safely
+//     behind that exit (e >= tt_p + margin): whichever element of p's voxel the chain is on, it computes an exit within the margin of tt_p and lands
+//     on e (and if an ambiguity further back made it skip p's voxel, it landed on the first element behind p: e again);
+//   * a cell DDA over the search grid knows which cells the ray crosses.  It goes on while the next cell has no candidates; where the crossing point
+//     lies within 2e-3 cell lengths of another face (the reference's float cell arithmetic, errors ~1e-6 cell lengths, may put elements around it
+//     into a lateral neighbour) it also looks at those lateral neighbours of both cells and stops if one of them has candidates or does not exist.
+// The chain is restarted at the last certainly-visited element more than a margin before the stopping face and the exact hops take over; if the DDA
+// reaches `far` the chain emits nothing.  No such element within 32 tries, another binade in between, a start next to a face AND to candidates: the
+// hops start where they always did.  ONE attempt per ray, before the loop, so that the lanes of a wave stay together.
+// `hop_budget` (> 0, with the DDA start): a wave is as slow as its slowest ray, and 0.04 % of the rays (face-hugging or axis-parallel ones: ~270 of
+// 640 000, spread over a fifth of the busy waves) still walk 40-80 hops; after `hop_budget` hops the pre-pass hands the ray — standing on a visited
+// element like any other resume point — to the windowed march, which evaluates 64 elements (~14 hops) per round and has 12 000 other rays to hide
+// it behind.  Bit-identical by construction; the march tests compare every ray with the oracle and with the reference's own kernel.
 __device__ inline float skip_empty_cells(const MarchParams& a, const March2Tables& tb, int index, float noise, unsigned* n_iter_out,
-                                         const uint32_t* cell_bits = nullptr, float far_override = -1.0f, const uint32_t* cell_bits2 = nullptr) {
+                                         const uint32_t* cell_bits = nullptr, float far_override = -1.0f, const uint32_t* cell_bits2 = nullptr,
+                                         int hop_budget = 0) {
     const Float3 o = *reinterpret_cast<const Float3*>(a.rays_o + (size_t)index * 3), d = *reinterpret_cast<const Float3*>(a.rays_d + (size_t)index * 3);
     const float ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
     const uint32_t H = a.H, C = a.C;
@@ -235,40 +243,93 @@ __device__ inline float skip_empty_cells(const MarchParams& a, const March2Table
         // The common case (no --cut, emptiness bits in LDS) with as few branches as the semantics allow: the kernel is issue-bound (its busy
         // waves share a third of the SIMDs) and the general loop below costs ~25 exec-mask branches per hop.  Same expressions, same order.
         const float Hm1 = (float)(H - 1);
-        if (cell_bits2 && fixed && one_cascade && a.bound <= 1.0f) {  // late start (see above); bound <= 1: mip_bound = fminf(2^0, bound) = bound
-            const float dts = 0.9f * a.hgs * __builtin_amdgcn_rsqf(dx * dx + dy * dy + dz * dz);
-            if (dts > 0.0f && far - t < 1e3f * dts) {
-                float s_prev = t, sm = t;
-                bool hit = false;
-                while (true) {
-                    const int g0 = min(max((int)floorf((ox + sm * dx - bmin0) * rhgs), 0), r0 - 1);
-                    const int g1 = min(max((int)floorf((oy + sm * dy - bmin1) * rhgs), 0), r1 - 1);
-                    const int g2 = min(max((int)floorf((oz + sm * dz - bmin2) * rhgs), 0), r2 - 1);
-                    const int gid = g2 * r1 * r0 + g1 * r0 + g0;
-                    if ((cell_bits2[gid >> 5] >> (gid & 31)) & 1u) { hit = true; break; }
-                    if (!(sm < far)) break;
-                    s_prev = sm;
-                    sm = fminf(sm + dts, far);
+        if (cell_bits2 && fixed && one_cascade && a.bound <= 1.0f) {  // DDA start (see above); bound <= 1: mip_bound = fminf(2^0, bound) = bound
+            const float xs0 = clampf(ox + t * dx, lo0, hi0), ys0 = clampf(oy + t * dy, lo1, hi1), zs0 = clampf(oz + t * dz, lo2, hi2);
+            const float q0 = (xs0 - bmin0) * rhgs, q1 = (ys0 - bmin1) * rhgs, q2 = (zs0 - bmin2) * rhgs;
+            const float f0 = floorf(q0), f1 = floorf(q1), f2 = floorf(q2);
+            const float e0 = q0 - f0, e1 = q1 - f1, e2 = q2 - f2;
+            const bool sure0 = e0 >= 2e-3f && e0 <= 0.998f && e1 >= 2e-3f && e1 <= 0.998f && e2 >= 2e-3f && e2 <= 0.998f &&
+                               fmaxf(fabsf(q0), fmaxf(fabsf(q1), fabsf(q2))) < 1e6f;
+            int c0 = (int)f0, c1 = (int)f1, c2 = (int)f2;
+            const bool in0 = (c0 | c1 | c2) >= 0 && c0 < r0 && c1 < r1 && c2 < r2;
+            bool start_blocked = !in0;  // the start cell has candidates, or the start lies next to a face and within one cell of candidates: the hops decide
+            if (in0) {
+                const int cg = c2 * r1 * r0 + c1 * r0 + c0;
+                start_blocked = (((cell_bits[cg >> 5] >> (cg & 31)) & 1u) != 0) || (!sure0 && (((cell_bits2[cg >> 5] >> (cg & 31)) & 1u) != 0));
+            }
+            if (!start_blocked) {
+                const int st0 = dx > 0.0f ? 1 : -1, st1 = dy > 0.0f ? 1 : -1, st2 = dz > 0.0f ? 1 : -1;
+                const bool use0 = fabsf(dx) > 1e-6f, use1 = fabsf(dy) > 1e-6f, use2 = fabsf(dz) > 1e-6f;
+                // parameter of the next face per axis, recomputed from the cell index (no accumulation) for the axis that moved only
+                float tf0 = use0 ? ((bmin0 + (float)(c0 + (st0 > 0)) * a.hgs) - ox) * rdx : FLT_MAX;
+                float tf1 = use1 ? ((bmin1 + (float)(c1 + (st1 > 0)) * a.hgs) - oy) * rdy : FLT_MAX;
+                float tf2 = use2 ? ((bmin2 + (float)(c2 + (st2 > 0)) * a.hgs) - oz) * rdz : FLT_MAX;
+                int crossed = 0, m_stop = 0;
+                float t_stop = t;
+                bool to_far = false;
+                for (int it = 0; it < 96; it++) {
+                    const int m = (tf0 <= tf1 && tf0 <= tf2) ? 0 : (tf1 <= tf2 ? 1 : 2);
+                    const float tx = m == 0 ? tf0 : (m == 1 ? tf1 : tf2);
+                    if (!(tx < far)) { to_far = true; break; }
+                    const float fr0 = ((ox + tx * dx) - bmin0) * rhgs - (float)c0, fr1 = ((oy + tx * dy) - bmin1) * rhgs - (float)c1,
+                                fr2 = ((oz + tx * dz) - bmin2) * rhgs - (float)c2;
+                    const bool ok0 = m == 0 || (fr0 >= 2e-3f && fr0 <= 0.998f), ok1 = m == 1 || (fr1 >= 2e-3f && fr1 <= 0.998f),
+                               ok2 = m == 2 || (fr2 >= 2e-3f && fr2 <= 0.998f);
+                    const bool unsafe = !(ok0 && ok1 && ok2) || !(tx > t_stop);  // next to another face, or an edge / corner (two faces at one parameter)
+                    const int n0 = c0 + (m == 0 ? st0 : 0), n1 = c1 + (m == 1 ? st1 : 0), n2 = c2 + (m == 2 ? st2 : 0);
+                    if (tx > t_stop) { t_stop = tx; m_stop = m; }
+                    if (n0 < 0 || n1 < 0 || n2 < 0 || n0 >= r0 || n1 >= r1 || n2 >= r2) break;
+                    const int ng = n2 * r1 * r0 + n1 * r0 + n0;
+                    if ((cell_bits[ng >> 5] >> (ng & 31)) & 1u) break;
+                    if (unsafe) {
+                        // the lateral neighbours the rounding could mean: one step towards every face the crossing point is close to, for the cell
+                        // being left and the cell being entered; every one of them must exist and be free of candidates
+                        const int l0 = (m == 0 || ok0) ? 0 : (fr0 < 0.5f ? -1 : 1), l1 = (m == 1 || ok1) ? 0 : (fr1 < 0.5f ? -1 : 1),
+                                  l2 = (m == 2 || ok2) ? 0 : (fr2 < 0.5f ? -1 : 1);
+                        bool blocked = !(tx > t_stop - 1e-6f * fmaxf(1.0f, fabsf(tx)));  // a face clearly BEHIND the last one: not a rounding matter
+                        for (int q = 1; q < 8 && !blocked; q++) {  // the non-empty subsets of the (at most two) lateral steps
+                            const int s0 = (q & 1) ? l0 : 0, s1 = (q & 2) ? l1 : 0, s2 = (q & 4) ? l2 : 0;
+                            if ((s0 | s1 | s2) == 0 || ((q & 1) && !l0) || ((q & 2) && !l1) || ((q & 4) && !l2)) continue;
+                            for (int side = 0; side < 2; side++) {
+                                const int y0 = (side ? n0 : c0) + s0, y1 = (side ? n1 : c1) + s1, y2 = (side ? n2 : c2) + s2;
+                                if (y0 < 0 || y1 < 0 || y2 < 0 || y0 >= r0 || y1 >= r1 || y2 >= r2) { blocked = true; break; }
+                                const int yg = y2 * r1 * r0 + y1 * r0 + y0;
+                                if ((cell_bits[yg >> 5] >> (yg & 31)) & 1u) { blocked = true; break; }
+                            }
+                        }
+                        if (blocked) break;
+                    }
+                    c0 = n0; c1 = n1; c2 = n2;
+                    if (m == 0) tf0 = ((bmin0 + (float)(c0 + (st0 > 0)) * a.hgs) - ox) * rdx;
+                    else if (m == 1) tf1 = ((bmin1 + (float)(c1 + (st1 > 0)) * a.hgs) - oy) * rdy;
+                    else tf2 = ((bmin2 + (float)(c2 + (st2 > 0)) * a.hgs) - oz) * rdz;
+                    crossed++;
                 }
-                if (!hit) { *n_iter_out = 0; return far; }  // no candidate anywhere near the ray: the chain walks to `far` and emits nothing
+                if (to_far) { *n_iter_out = 0; return far; }  // no candidates and no doubt all the way: the chain walks to `far` and emits nothing
                 bn = binade_of<1>(t, D);
                 const float kcap = bn.ok ? floorf(16777215.0f / (bn.Dq * scalbnf(1.0f, 150 - (int)(__float_as_uint(t) >> 23)))) - 2.0f : 0.0f;
-                const float rmax = fmaxf(fabsf(rdx), fmaxf(fabsf(rdy), fabsf(rdz)));
-                const float margin = 3e-5f * fmaxf(1.0f, fabsf(t)) + 2e-6f * rmax;  // ~60 ulp of t + the error of (face - x) * (1 / d) for the widest 1 / d
-                if (bn.ok && s_prev > t && s_prev < bn.top && rmax < 1e3f) {
-                    float kf = fminf(floorf((s_prev - t) * bn.rDq), kcap);
-                    if (kf >= 1.0f && t + kf * bn.Dq > s_prev) kf -= 1.0f;
-                    for (int tries = 0; tries < 12 && kf >= 1.0f; tries++, kf -= 1.0f) {
+                // margins: ~60 ulp of t + the error of (face - x) * (1 / d) for the axis in question (an axis the ray is nearly parallel to has a huge
+                // 1 / d, but its face is never the nearest one)
+                const float rd_stop = fabsf(m_stop == 0 ? rdx : (m_stop == 1 ? rdy : rdz));
+                const float m_face = 2e-4f * fmaxf(1.0f, fabsf(t)) + 1e-5f * fminf(rd_stop, 1e3f);  // elements this far before the face are in the crossed cells
+                const float target = t_stop - m_face;
+                if (crossed >= 1 && bn.ok && target > t && target < bn.top && rd_stop < 1e3f) {
+                    float kf = fminf(floorf((target - t) * bn.rDq), kcap);
+                    if (kf >= 1.0f && t + kf * bn.Dq > target) kf -= 1.0f;
+                    for (int tries = 0; tries < 32 && kf >= 2.0f; tries++, kf -= 1.0f) {
                         const float e = t + kf * bn.Dq, p = t + (kf - 1.0f) * bn.Dq;  // exact: both inside the binade, k below the exactness cap
                         const float x = clampf(ox + p * dx, lo0, hi0), y = clampf(oy + p * dy, lo1, hi1), z = clampf(oz + p * dz, lo2, hi2);
                         const int nx = (int)clampf((x * rbound + 1) * halfH, 0.0f, Hm1);
                         const int ny = (int)clampf((y * rbound + 1) * halfH, 0.0f, Hm1);
                         const int nz = (int)clampf((z * rbound + 1) * halfH, 0.0f, Hm1);
-                        const float tx = ((((float)nx + sx) * rH * 2 - 1) * a.bound - x) * rdx;
-                        const float ty = ((((float)ny + sy) * rH * 2 - 1) * a.bound - y) * rdy;
-                        const float tz = ((((float)nz + sz) * rH * 2 - 1) * a.bound - z) * rdz;
-                        const float ttp = p + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-                        if (p < ttp - margin && e >= ttp + margin && e < far) { t = e; break; }
+                        const float ux = ((((float)nx + sx) * rH * 2 - 1) * a.bound - x) * rdx;
+                        const float uy = ((((float)ny + sy) * rH * 2 - 1) * a.bound - y) * rdy;
+                        const float uz = ((((float)nz + sz) * rH * 2 - 1) * a.bound - z) * rdz;
+                        const float um = fminf(ux, fminf(uy, uz));
+                        const float rd_min = fabsf(um == ux ? rdx : (um == uy ? rdy : rdz));
+                        const float m_vox = 3e-5f * fmaxf(1.0f, fabsf(t)) + 2e-6f * rd_min;
+                        const float ttp = p + fmaxf(0.0f, um);
+                        if (rd_min < 1e3f && p < ttp - m_vox && e >= ttp + m_vox && e < far) { t = e; break; }
                     }
                 }
                 bn.Dq = bn.rDq = 0.f; bn.top = -1.f; bn.ok = false;  // the hop loop below sets its own
@@ -290,6 +351,7 @@ __device__ inline float skip_empty_cells(const MarchParams& a, const March2Table
             const int gid = inside ? g2 * r1 * r0 + g1 * r0 + g0 : 0;
             const bool has = ((cell_bits[gid >> 5] >> (gid & 31)) & 1u) != 0;
             if (!inside || has) break;  // outside the hash (the windowed march raises the error flag) or candidates: hand over
+            if (hop_budget > 0 && (int)n_iter >= hop_budget) break;  // a straggler: the windowed march goes on from this (visited) element
             int level = 0;
             if (!one_cascade) level = max(mip_from_pos(x, y, z, (float)C), mip_from_dt(clampf(t * a.dt_gamma, dt_min, dt_max), (float)H, (float)C));
             const float pw = scalbnf(1.0f, level);

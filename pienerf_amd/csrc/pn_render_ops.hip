@@ -523,7 +523,7 @@ struct MarchIO {
     // optional (frame driver with ray groups, see PnGroup): this trip's group records
     const PnGroup* groups;
     uint32_t group_rays;
-    int late_start;  // k_march_skip: start the hop chain at the last lattice element before the candidates' neighbourhood (pn_march3.h)
+    int dda_start, hop_budget;  // k_march_skip: restart the hop chain just before the first cell with candidates; hops before a ray is handed on (pn_march3.h)
 };
 
 // Append lists are SEGMENTED: PN_SEGS independent (counter, region) pairs, every counter on a cache line of its own, the producer picking
@@ -574,7 +574,7 @@ __global__ void __launch_bounds__(256) k_march_skip(pnm::MarchParams a, pnm2::Ma
             io.fars_eff[index] = far;
         }
         const float t = pnm3::skip_empty_cells(a, tb, index, io.noises ? io.noises[n] : 0.0f, &n_iter, cell_bits, cell_bits2 ? far : -1.0f,
-                                               io.late_start ? cell_bits2 : nullptr);
+                                               io.dda_start ? cell_bits2 : nullptr, io.dda_start && cell_bits2 ? io.hop_budget : 0);
         io.t_resume[n] = t;
         if (!PN_DBG_PHASES_ON && a.stats && n_iter) atomicAdd(a.stats, (unsigned long long)n_iter);
         work = t < far;
@@ -1958,7 +1958,9 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     // PN_SKIP_LATE_START=1 (experiment, off by default): the skip pre-pass starts its hop chain at the last lattice element before the candidates'
     // neighbourhood (pn_march3.h).  Bit-identical in every march / frame test, but it only takes k_march_skip from 75 to 68 us on the chair (its
     // bounding box lies almost entirely within two cells of the object: the leading walks are short already) — not worth a second code path by default.
-    static const int late_start = [] { const char* v = getenv("PN_SKIP_LATE_START"); return (v && v[0] == '1') ? 1 : 0; }();
+    // k_march_skip: DDA start + hop budget (pn_march3.h: skip_empty_cells); PN_SKIP_DDA=0 walks hop by hop like rounds 1-2 (same results bit for bit)
+    static const int dda_start = [] { const char* v = getenv("PN_SKIP_DDA"); return (v && v[0] == '0') ? 0 : 1; }();
+    static const uint32_t skip_hop_budget = pn_env_u32("PN_SKIP_HOPS", 8);
     static const bool split_compact = pn_env_u32("PN_SPLIT_COMPACT", 0) != 0;  // experiments: composite and compaction as two launches (rounds 1-2)
     static const uint32_t tail_grid_cfg = pn_env_u32("PN_TAIL_GRID", 1024);  // x4 waves, one unfinished ray per wave at a time
     const uint32_t tail_grid = std::max(std::min(pn_div_up(N, 4), tail_grid_cfg), (uint32_t)PN_SEGS / 4);  // every tail segment needs a wave
@@ -2069,7 +2071,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                        f->tail, seg_tail, seg_back, seg_curs, (int)f->seg_cap, (int)march_tail_rounds(t), (t == 0) ? f->active_seg : nullptr, (t == 0) ? seg_active : nullptr,
                        (int)f->seg_cap, f->list_seg, seg_samp, (int)f->seg_cap, seg_emit, f->cell_bits, skip_bits_words,
                        short_rays ? f->cell_bits + bit_words : nullptr, short_rays ? f->fars_eff : nullptr,
-                       group_rays ? f->groups + (size_t)(t & 1) * f->max_groups : nullptr, group_rays, late_start};
+                       group_rays ? f->groups + (size_t)(t & 1) * f->max_groups : nullptr, group_rays, dda_start, (int)skip_hop_budget};
             const bool timed = (f->march_counters_on & 2) && t < PN_TIMED_TRIPS;
             bool stamp = false;
             if (timed) {  // measurement mode: the two heavy launch groups of each trip are bracketed on the launch stream
