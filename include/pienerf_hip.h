@@ -39,6 +39,10 @@ int pn_stream_destroy(void* stream);
  * wave-per-ray tail launch; 0 restores the default (4).  The samples do not depend on it (bit for bit) — tests use 1 and a
  * large value to push every ray through either launch.  Affects renders enqueued afterwards, process-wide. */
 int pn_march_set_tail_rounds(int rounds);
+/* Tests / experiments: 0 makes the frame driver's skip pre-pass walk hop by hop (rounds 1-2), 1 restarts the hop chain just before the first search cell
+ * with candidates and hands stragglers to the windowed march (the default), -1 restores the default (environment PN_SKIP_DDA).  Same results bit for
+ * bit.  Takes effect for renders enqueued (or captured) afterwards, process-wide. */
+int pn_march_set_skip_dda(int on);
 /* Number of compute units of the current device. */
 int pn_device_cu_count(void);
 /* Text of the last PN_ERR_HIP on the calling thread ("" if none). */

@@ -28,6 +28,7 @@ SIGNATURES = {
     "pn_stream_destroy": (i32, [P]),
     "pn_device_cu_count": (i32, []),
     "pn_march_set_tail_rounds": (i32, [i32]),
+    "pn_march_set_skip_dda": (i32, [i32]),
     "pn_copier_create": (i32, [C.POINTER(P)]),
     "pn_copier_destroy": (None, [P]),
     "pn_copier_submit": (i32, [P, P, P, C.c_uint64, P, C.POINTER(C.c_uint64)]),

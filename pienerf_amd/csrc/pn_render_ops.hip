@@ -790,6 +790,7 @@ static void launch_march(int K, uint32_t blocks, uint32_t tail_blocks, hipStream
 }
 
 // Rounds of 8 sequence elements a ray gets in k_march before it is handed to the wave-per-ray tail pass (PN_TAIL_ROUNDS overrides).
+static int g_skip_dda_override = -1;    // pn_march_set_skip_dda (tests): 0 / 1 replace the default, -1: default (environment PN_SKIP_DDA)
 static int g_tail_rounds_override = 0;  // pn_march_set_tail_rounds (tests): > 0 replaces the default below
 // Defaults measured on the chair once the append lists were segmented (k_march + tail per trip, us): trip 0 (every ray looks for its first sample)
 // 232 / 201 / 210 / 211 for 1 / 2 / 3 / 4 rounds; later trips (alive rays, 8 samples each: most are done after one window) 70 / 76 / 78 / 79.
@@ -798,6 +799,11 @@ static uint32_t march_tail_rounds(int trip = -1) {
     if (g_tail_rounds_override > 0) return (uint32_t)g_tail_rounds_override;
     if (r) return r;
     return trip < 0 ? 4u : (trip == 0 ? 2u : 1u);
+}
+extern "C" int pn_march_set_skip_dda(int on) {
+    PN_REQUIRE(on >= -1 && on <= 1);
+    g_skip_dda_override = on;
+    return PN_OK;
 }
 extern "C" int pn_march_set_tail_rounds(int rounds) {
     PN_REQUIRE(rounds >= 0);
@@ -1959,7 +1965,8 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     // neighbourhood (pn_march3.h).  Bit-identical in every march / frame test, but it only takes k_march_skip from 75 to 68 us on the chair (its
     // bounding box lies almost entirely within two cells of the object: the leading walks are short already) — not worth a second code path by default.
     // k_march_skip: DDA start + hop budget (pn_march3.h: skip_empty_cells); PN_SKIP_DDA=0 walks hop by hop like rounds 1-2 (same results bit for bit)
-    static const int dda_start = [] { const char* v = getenv("PN_SKIP_DDA"); return (v && v[0] == '0') ? 0 : 1; }();
+    static const int dda_env = [] { const char* v = getenv("PN_SKIP_DDA"); return (v && v[0] == '0') ? 0 : 1; }();
+    const int dda_start = g_skip_dda_override >= 0 ? g_skip_dda_override : dda_env;
     static const uint32_t skip_hop_budget = pn_env_u32("PN_SKIP_HOPS", 8);
     static const bool split_compact = pn_env_u32("PN_SPLIT_COMPACT", 0) != 0;  // experiments: composite and compaction as two launches (rounds 1-2)
     static const uint32_t tail_grid_cfg = pn_env_u32("PN_TAIL_GRID", 1024);  // x4 waves, one unfinished ray per wave at a time

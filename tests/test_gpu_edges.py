@@ -169,6 +169,37 @@ def test_frame_independent_of_tail_rounds(deformed_ip_state, small_opt, ckpt, ta
     assert torch.equal(alt["image"], img0) and torch.equal(alt["depth_0"], d0)
 
 
+@pytest.fixture
+def skip_dda():
+    from pienerf_amd._lib import check, lib
+
+    def set_dda(on):
+        check(lib().pn_march_set_skip_dda(int(on)), "set_skip_dda")
+    yield set_dda
+    set_dda(-1)
+
+
+@pytest.mark.parametrize("radius,theta,phi", [(5.0, 20.0, -15.0), (2.2, 75.0, -40.0), (9.0, -60.0, 5.0), (5.0, 0.0, 0.0), (5.0, 90.0, 0.0)])
+def test_frame_independent_of_the_skip_pre_pass_form(deformed_ip_state, small_opt, ckpt, skip_dda, radius, theta, phi):
+    """Trip 0's skip pre-pass with the DDA start + hop budget (pn_march3.h: skip_empty_cells; the default) and walking hop by hop (rounds 1-2): the same
+    samples (count, trips) and the same pixels bit for bit, from far, from close (rays crossing a binade of t), and along the grid axes (rays nearly
+    parallel to cell faces: the cases the DDA refuses or hands on)."""
+    W = 96
+    pose = scene.orbit_pose(radius, theta, phi)
+    o, d = oracle.get_rays(pose, scene.orbit_intrinsics(W, W, 50.0), W, W)
+    net = _net(ckpt, deformed_ip_state)
+    res = []
+    with torch.no_grad():
+        for on in (0, 1):
+            skip_dda(on)
+            out = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **small_opt)
+            res.append((dict(net.last_stats), out["image"].clone(), out["depth"].clone(), out["depth_0"].clone()))
+    (s0, i0, d0, e0), (s1, i1, d1, e1) = res
+    assert s0["samples"] == s1["samples"] > 500 and s0["trips"] == s1["trips"] and s0["err"] == s1["err"] == 0
+    assert torch.equal(i0, i1) and torch.equal(e0, e1)
+    assert torch.equal(torch.nan_to_num(d0, nan=-1.0), torch.nan_to_num(d1, nan=-1.0))
+
+
 def test_calc_elastic_on_adversarial_deformation_gradients():
     """pn_sim_calc_elastic (k_elastic: cyclic-Jacobi SVD with rcp/rsq + Newton instead of IEEE div/sqrt, det-+1 contract of wp.svd3, volume
     projection) on deformation gradients that decide R = U V^T: inverted (det < 0), rank 2, rank 1, zero, repeated singular values, pure

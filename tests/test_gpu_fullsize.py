@@ -93,6 +93,27 @@ def test_full_frame_is_reproducible_and_launch_forms_agree(full):
     assert (want[0] - want[3]).abs().max() > 1e-4   # gravity moved the chair between the frames
 
 
+def test_full_frame_independent_of_the_skip_pre_pass_form(full):
+    """All 640 000 rays with the skip pre-pass's DDA start + hop budget (the default) and walking hop by hop: the same trip records (alive rays, list
+    lengths, emitted samples per trip) and the same pixels bit for bit."""
+    from pienerf_amd._lib import check, lib
+    h = full["h"]
+    res = []
+    try:
+        with torch.no_grad():
+            for on in (0, 1):
+                check(lib().pn_march_set_skip_dda(on), "set_skip_dda")
+                out = h.step(simulate=False, collect_stats=True)
+                res.append((dict(h.model.last_stats), h.model.trip_records(), {k: out[k].clone() for k in ("image", "depth", "depth_0")}))
+    finally:
+        check(lib().pn_march_set_skip_dda(-1), "set_skip_dda")
+    (s0, r0, o0), (s1, r1, o1) = res
+    assert s0["samples"] == s1["samples"] and s0["trips"] == s1["trips"] and s0["err"] == s1["err"] == 0
+    assert [r[:5] for r in r0] == [r[:5] for r in r1]   # (the tail-list length of trip 0 may differ: where the pre-pass stops is not an output)
+    for k in o0:
+        assert torch.equal(torch.nan_to_num(o0[k], nan=-1.0), torch.nan_to_num(o1[k], nan=-1.0)), k
+
+
 def test_strided_subset_of_the_full_frame_matches_the_oracle(full):
     """Every 199th ray of the 800x800 frame, rendered by the CPU oracle from the same IP state, against the full frame's pixels;
     and the same subset rendered alone on the GPU reproduces the full frame's pixels bit for bit (rays are independent)."""
