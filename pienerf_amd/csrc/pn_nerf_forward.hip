@@ -560,10 +560,14 @@ __device__ __forceinline__ Split8 split8_of(const f32x16& v, int r0) {
     return split8(v[r0], v[r0 + 1], v[r0 + 2], v[r0 + 3], v[r0 + 4], v[r0 + 5], v[r0 + 6], v[r0 + 7]);
 }
 
-// Workgroup = 4 waves sharing the 61 KB LDS weight image: 2 workgroups per CU = 2 waves per SIMD (measured: 5 or 6 waves per
-// workgroup are no faster stand-alone and slower beside the other render lanes' march kernels, which want the wave slots).
+// Workgroup = 8 waves sharing ONE 61 KB LDS weight image, one workgroup per CU = 2 waves per SIMD (rounds 1-2: two 4-wave workgroups per CU with an
+// image each — the same waves with 122 KB of LDS, which kept the other render lanes' march workgroups (48 KB) off the CU; round 3: in-loop launches
+// 0.280 -> 0.265 ms per frame, pipelined step unchanged.  16 waves per CU (-DPN_BF_WAVES=8 with PN_NERF_BLOCKS=512) are faster alone, 0.249 ms, and cost
+// the pipelined step 5 %: the march kernels want the wave slots).
 // MINW = waves per SIMD the register allocator must leave room for; LU = how many hash levels' gathers are in flight per lane.
-#define PN_BF_WAVES 4
+#ifndef PN_BF_WAVES
+#define PN_BF_WAVES 8
+#endif
 template <int MINW, int LU>
 __global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const PnFusedLevel* __restrict__ lv, const float* __restrict__ emb,
                                                                           const uint4* __restrict__ wsplit, float bound, const float* __restrict__ xyzs,
@@ -961,7 +965,7 @@ int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* di
         PN_LAUNCH_CHECK();
         return PN_OK;
     }
-    static const uint32_t max_blocks = pn_env_u32("PN_NERF_BLOCKS", 512);  // 2 workgroups per CU x 256 CUs; waves stride over tiles
+    static const uint32_t max_blocks = pn_env_u32("PN_NERF_BLOCKS", 2048 / PN_BF_WAVES);  // 8 waves per CU x 256 CUs; waves stride over tiles
     uint32_t blocks = pn_div_up(tiles, PN_BF_WAVES);
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks_cap) blocks = std::min(blocks, blocks_cap);
@@ -982,7 +986,7 @@ static int density_launch(const pn_net* net, const float* xyzs, uint32_t M, floa
             (const PnFusedLevel*)net->fused_levels, (const uint32_t*)net->emb_half, (const uint4*)net->whalf, net->bound, xyzs, xyzs, nullptr, nullptr, M, scale,
             sigmas, nullptr, geo_feat, net->n_entries * 4u, sigma_only);
     } else {
-        k_nerf_forward<2, 4><<<std::min(pn_div_up(tiles, PN_BF_WAVES), 512u), PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES, st>>>(
+        k_nerf_forward<2, 4><<<std::min(pn_div_up(tiles, PN_BF_WAVES), 2048u / PN_BF_WAVES), PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES, st>>>(
             (const PnFusedLevel*)net->fused_levels, net->embeddings, (const uint4*)net->wsplit, net->bound, xyzs, xyzs, nullptr, nullptr, M, scale, sigmas,
             nullptr, geo_feat, sigma_only);
     }
