@@ -255,8 +255,10 @@ def kernel_report(h, opt, dev):
         "units_per_frame": cnt, "algorithmic_bytes_per_frame": int(march_bytes), "algorithmic_bytes_per_launch": int(march_bytes / real),
         "bytes_per_unit": MARCH_BYTES,
         "note": "achieved = algorithmic bytes (8 B per marched ray point, 16 B per candidate-list entry, 64 B per warped IP record head, 36 B per emitted sample, "
-                "40 B of ray state per ray and trip) / HIP-event time of the launch group.  A divergent pointer chase over cache-resident tables (SQ counters "
-                "in profiles/: waves parked on memory most of their cycles): latency-bound, the HBM roofline is an upper bound it cannot approach (DESIGN.md 4.1)",
+                "40 B of ray state per ray and trip) / HIP-event time of the launch group.  The tables are cache-resident (`traffic` = HBM-side bytes from the PMC "
+                "passes: ~0.13x the algorithmic bytes) and the kernels are bound by VALU issue, not bytes: a wave64 instruction holds its SIMD16 for four cycles, "
+                "two to three march waves fill a SIMD, and 78 % of the lanes evaluate lattice elements the ray's chain never visits (DESIGN.md 4.1; grid / "
+                "occupancy / LDS sweeps in profiles/r03_march_experiments.txt) — the HBM roofline is an upper bound this launch group cannot approach",
     }
     extra = {
         "network": network,
