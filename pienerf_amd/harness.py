@@ -469,6 +469,17 @@ class _HipBackend:
             self.host.append([torch.empty(N * 5, dtype=torch.float32).pin_memory() for _ in range(2)] if copy_out else None)
         self.host_gen = [0] * n_ws
         torch.cuda.synchronize(dev)
+        if self.copier is not None:
+            # the first SDMA copy into a pinned buffer maps it for the engine (milliseconds): once per buffer here, not inside the pipeline's first frames
+            import ctypes
+
+            from ._lib import check, lib
+            for ws in range(n_ws):
+                for hb in self.host[ws]:
+                    t = ctypes.c_uint64()
+                    check(lib().pn_copier_submit(self.copier, ctypes.c_void_p(hb.data_ptr()), ctypes.c_void_p(self.packed[ws].data_ptr()),
+                                                 hb.numel() * hb.element_size(), None, ctypes.byref(t)), "copier_submit")
+                    check(lib().pn_copier_wait(self.copier, t.value), "copier_wait")
         sim.dof.copy_(keep[0])      # warm-up advanced the simulator; capture itself executes nothing
         sim.dof_vel.copy_(keep[1])
         torch.cuda.synchronize(dev)
