@@ -74,6 +74,7 @@ class SimRenderHarness:
 
     def synchronize(self):
         torch.cuda.synchronize(self.device)
+        self._check_persistent_substep()
 
     def _amp(self):
         """Trainer.test_gui renders inside ``torch.cuda.amp.autocast(enabled=self.fp16)`` (trainer.py:561).  main_gui.py builds its Trainer
@@ -283,7 +284,15 @@ class SimRenderHarness:
         """Retires every frame in flight (continuing any that ran out of trips) and returns them; the device is idle afterwards."""
         out = self._pipe.drain()
         torch.cuda.synchronize(self.device)
+        self._check_persistent_substep()
         return out
+
+    def _check_persistent_substep(self):
+        """A persistent substep whose workgroups could not all become resident ends with a flag instead of hanging (csrc/pn_sim.hip); its DOFs
+        are garbage.  Checked where the host synchronises anyway."""
+        if self.sim.persistent and self.sim.persistent_timed_out():
+            raise RuntimeError("the persistent substep (pn_sim_stepforward_coop) timed out at a device-wide barrier: the simulator state is invalid "
+                               "(another kernel held CUs for seconds, or two persistent substeps ran at once); use Simulator(persistent=False)")
 
     # ------------------------------------------------------------------ one frame split over the ranks (interactive latency)
     @torch.no_grad()
