@@ -530,9 +530,10 @@ def main():
         t_sub = extra["breakdown_ms"]["stepforward_persistent_alone"] or extra["breakdown_ms"]["stepforward_alone"]
         res["frame_parallel_ceiling"] = {"substep_ms_alone": t_sub, "owner_frames_per_s": round(1e3 / t_sub, 1),
                                          "substep_form": "persistent kernel" if extra["breakdown_ms"]["stepforward_persistent_alone"] else "launch form",
-                                         "note": "steps/s of an N-GPU frame-parallel job <= min(owner_frames_per_s [owner dedicated: its substep has the GPU to itself and runs "
-                                                 "as one persistent kernel], renderers x the single-GPU render rate); with the owner also rendering its substep (launch form) "
-                                                 "shares the GPU and is ~1.8x slower"}
+                                         "owner_frames_per_s_launch_form": round(1e3 / extra["breakdown_ms"]["stepforward_alone"], 1),
+                                         "note": "steps/s of an N-GPU frame-parallel job <= min(owner_frames_per_s [owner dedicated: its substep has the GPU to itself; "
+                                                 "as one persistent kernel with PN_SIM_COOP=1 (opt-in: never run beside RCCL), else owner_frames_per_s_launch_form], "
+                                                 "renderers x the single-GPU render rate); with the owner also rendering its substep (launch form) shares the GPU and is ~1.8x slower"}
         if world == 1 and not args.no_extras and not (args.eager or args.single_graph):
             with torch.no_grad():
                 res.update(pipelined_extras(make_harness, args, max(40, min(args.steps, 120))))

@@ -250,9 +250,11 @@ class SimRenderHarness:
             n_trips = int(self.model.last_stats["trips"]) + 2  # every captured trip costs five launches whether it has rays or not
         from .frames import dedicated_sim_default
         if (world > 1 and (dedicated_sim_default(world) if dedicated_sim is None else bool(dedicated_sim)) and rank == sim_owner
-                and dist.get_backend(group) == "nccl"):  # (a gloo group is the one-GPU dry run: the ranks share the device)
-            # this GPU only simulates: the substep's local/global iterations as one persistent kernel on every CU (csrc/pn_sim.hip: k_substep_coop;
-            # 0.24 instead of 0.28 ms).  Never beside renders: its workgroups and those of the fused composite/compaction would wait for each other
+                and dist.get_backend(group) == "nccl" and os.environ.get("PN_SIM_COOP", "") == "1"):
+            # this GPU only simulates: with PN_SIM_COOP=1 the substep's local/global iterations run as one persistent kernel on (almost) every CU
+            # (csrc/pn_sim.hip: k_substep_coop; 0.24 instead of 0.28 ms).  Opt-in: it has never run beside RCCL's kernels (one-GPU test box), and a
+            # persistent kernel that cannot get all its CUs ends with a flag and an invalid state instead of a slower step.  Never beside renders:
+            # its workgroups and those of the fused composite/compaction would wait for each other.  (A gloo group is the one-GPU dry run.)
             self.sim.enable_persistent()
         be = _HipBackend(self, lanes, depth, int(n_trips), W, H, sim_priority, sim_cus, copy_out, group if on else None,
                          (dist.get_global_rank(group, sim_owner) if (on and group is not None) else sim_owner), _probe_no_substep, _time_trips, copy_on)
