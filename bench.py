@@ -214,7 +214,8 @@ def kernel_report(h, opt, dev):
     # the same substep as ONE persistent kernel (csrc/pn_sim.hip: k_substep_coop) — the form a GPU that only simulates uses (the dedicated owner of
     # a frame-parallel job); never beside renders, so it is measured here, alone, and switched off again
     t_sim_coop = None
-    if h.sim.enable_persistent():
+    alone = not (torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1)
+    if alone and h.sim.enable_persistent():  # (in a multi-rank job other ranks may still hold this GPU: one-GPU dry runs)
         t_sim_coop = cuda_time_ms(lambda: h.sim.stepforward(), iters=10)
         if h.sim._coop is None or h.sim.persistent_timed_out():
             t_sim_coop = None
