@@ -200,6 +200,54 @@ def test_frame_independent_of_the_skip_pre_pass_form(deformed_ip_state, small_op
     assert torch.equal(torch.nan_to_num(d0, nan=-1.0), torch.nan_to_num(d1, nan=-1.0))
 
 
+_FRAME_HASH_SCRIPT = r"""
+import hashlib, sys, numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import oracle
+from conftest import make_oracle_sim
+from pienerf_amd import scene
+from pienerf_amd.nerf.network import NeRFNetwork
+opt = scene.default_opt(sim_dx=0.1, sim_iters=4, W=48, H=48)
+cloud = scene.make_chair_points(sub_res=30, hgs=opt["hash_grid_size"])
+ck = scene.make_checkpoint(bound=1.0, seed=0)
+s = make_oracle_sim(cloud, opt)
+p_ori, _, _ = s.get_IP_info()
+s.update_force(s.n_IP // 2, np.array([300.0, 100.0, -200.0]))
+for _ in range(12):
+    s.stepforward()
+p_def, F, dF = s.get_IP_info()
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+net = NeRFNetwork(encoding="hashgrid", bound=1.0, cuda_ray=True).cuda().load_checkpoint_dict(ck)
+net.p_def, net.p_ori, net.IP_F, net.IP_dF, net.IP_dx = T(p_def), T(p_ori), T(F), T(dF), s.dx * 1.05
+W = 160
+o, d = oracle.get_rays(scene.orbit_pose(3.0, 20.0, -15.0), scene.orbit_intrinsics(W, W, 50.0), W, W)
+with torch.no_grad():
+    out = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **opt)
+st = dict(net.last_stats)
+h = hashlib.sha1(out["image"].cpu().numpy().tobytes() + out["depth_0"].cpu().numpy().tobytes()).hexdigest()
+print("FRAME", h, st["samples"], st["trips"], st["err"])
+"""
+
+
+def test_composite_with_chunk_loops_equals_one_workgroup_per_chunk():
+    """The fused composite / compaction with a grid far smaller than the number of 256-ray chunks (PN_CC_GRID=4: 25 rounds per workgroup on a
+    160x160 frame, every round adding the words behind the workgroup's previous chunk to its prefix), on the frame's first trip too
+    (PN_CC_TRIP0=1), against the default (two launches on trip 0, one workgroup per chunk afterwards): the same frame, bit for bit.  The
+    knobs are read once per process, hence two processes."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    res = []
+    for extra in ({}, {"PN_CC_GRID": "4", "PN_CC_TRIP0": "1"}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", _FRAME_HASH_SCRIPT % dict(root=ROOT)], env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("FRAME")]
+        assert r.returncode == 0 and line, r.stderr[-2000:]
+        res.append(line[0].split()[1:])
+    assert res[0] == res[1] and int(res[0][1]) > 5000 and res[0][3] == "0"
+
+
 def test_calc_elastic_on_adversarial_deformation_gradients():
     """pn_sim_calc_elastic (k_elastic: cyclic-Jacobi SVD with rcp/rsq + Newton instead of IEEE div/sqrt, det-+1 contract of wp.svd3, volume
     projection) on deformation gradients that decide R = U V^T: inverted (det < 0), rank 2, rank 1, zero, repeated singular values, pure
