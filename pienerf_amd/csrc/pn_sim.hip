@@ -20,7 +20,10 @@
 // The substep is a chain of ~30 short dependent launches that runs concurrently with the render kernels of other frames
 // (harness.capture_pipelined): its waves ask the SIMD arbiter for the highest user priority so the chain's latency does not
 // stretch when the CUs are full of march waves.
-#define PN_SIM_PRIO() __builtin_amdgcn_s_setprio(3)
+#ifndef PN_SIM_PRIO_LEVEL
+#define PN_SIM_PRIO_LEVEL 3
+#endif
+#define PN_SIM_PRIO() __builtin_amdgcn_s_setprio(PN_SIM_PRIO_LEVEL)
 
 namespace {
 
