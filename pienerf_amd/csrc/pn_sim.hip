@@ -475,12 +475,13 @@ __global__ void __launch_bounds__(1024) k_rhs_gather_csr(int n_k, const int* __r
 // 770 entries against a mean of 206, and only 139 of 256 CUs busy), so the lists are cut into chunks of PN_GCH entries, one
 // workgroup per chunk, each writing its 30 partial sums; the chunk sums of a kernel are added in ascending chunk order by the
 // consumer (k_matvec3_gathered builds its X operand from them in LDS), so the result is still reproducible bit for bit.
-// k_gather_plan (once per substep, one workgroup) lays the chunks out: kc_bg[k] = first chunk of kernel k, chunk[b] = (first entry, count).
+// k_gather_plan (once per simulator, one workgroup) lays the chunks out: kc_bg[k] = first chunk of kernel k, chunk[b] = (first entry, count, kernel,
+// chunks of that kernel); every kernel gets at least one chunk (an empty one if it has no entries), unused grid slots have kernel -1.
 #ifndef PN_GCH
 #define PN_GCH 128  // entries per chunk; the chunk kernel runs PN_GCH / 4 slots x 30 threads
 #endif
 __global__ void __launch_bounds__(512) k_gather_plan(int n_k, int chunks_max, const int* __restrict__ csr_bg, const int* __restrict__ csr_cnt,
-                                                     int* __restrict__ kc_bg, int2* __restrict__ chunk) {
+                                                     int* __restrict__ kc_bg, int4* __restrict__ chunk, int* __restrict__ kcount) {
     // exclusive scan of the kernels' chunk counts by the whole workgroup (one lane walking the n_k kernels took 40 us of every substep)
     __shared__ int wsum[8];
     __shared__ int carry_s;
@@ -490,7 +491,7 @@ __global__ void __launch_bounds__(512) k_gather_plan(int n_k, int chunks_max, co
     for (int base = 0; base < n_k; base += 512) {
         const int k = base + (int)threadIdx.x;
         const int cnt = k < n_k ? csr_cnt[k] : 0;
-        const int nc = (cnt + PN_GCH - 1) / PN_GCH;
+        const int nc = k < n_k ? max((cnt + PN_GCH - 1) / PN_GCH, 1) : 0;
         int inc = nc;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -505,8 +506,9 @@ __global__ void __launch_bounds__(512) k_gather_plan(int n_k, int chunks_max, co
         if (k < n_k) {
             kc_bg[k] = first_chunk;
             const int bg = csr_bg[k];
-            for (int j = 0; j < nc; j++)  // chunk[b] = (first entry, entry count): one load tells a workgroup its work
-                chunk[first_chunk + j] = make_int2(bg + j * PN_GCH, min(PN_GCH, cnt - j * PN_GCH));
+            for (int j = 0; j < nc; j++)  // one load tells a workgroup its work
+                chunk[first_chunk + j] = make_int4(bg + j * PN_GCH, max(min(PN_GCH, cnt - j * PN_GCH), 0), k, nc);
+            kcount[k] = 0;
         }
         __syncthreads();
         if (threadIdx.x == 0) carry_s += total;
@@ -514,18 +516,26 @@ __global__ void __launch_bounds__(512) k_gather_plan(int n_k, int chunks_max, co
     }
     const int n_chunks = carry_s;
     if (threadIdx.x == 0) kc_bg[n_k] = n_chunks;
-    for (int b = n_chunks + threadIdx.x; b < chunks_max; b += blockDim.x) chunk[b] = make_int2(0, 0);  // unused tail of the grid
+    for (int b = n_chunks + threadIdx.x; b < chunks_max; b += blockDim.x) chunk[b] = make_int4(0, 0, -1, 0);  // unused tail of the grid
 }
 
-__global__ void __launch_bounds__(PN_GCH * 8) k_rhs_gather_chunk(const int2* __restrict__ chunk, const double* __restrict__ dNx_csr,
-                                                                  const double* __restrict__ P_csr, double* __restrict__ part) {
+// `tot` != nullptr: the workgroup that completes its kernel's set of chunks ("last arriver") also adds them up, in ascending chunk order like
+// k_gather_sum, and writes momentum + sum - rhs_rest: one launch less per local/global iteration (of the 4).  The XCDs' L2s are not coherent with each
+// other, so the chunk sums go out as agent-scope stores (written through to the memory side), a workgroup waits for their acknowledgement before it bumps
+// its kernel's arrival counter (agent-scope atomic at the memory side; the counters only ever grow: the n-th arrival with n % chunks == 0 is the last of
+// an iteration), and the last arriver reads all sums with agent-scope loads.
+__global__ void __launch_bounds__(PN_GCH * 8) k_rhs_gather_chunk(const int4* __restrict__ chunk, const double* __restrict__ dNx_csr,
+                                                                  const double* __restrict__ P_csr, double* part, int* kcount,
+                                                                  const int* __restrict__ kc_bg, const double* __restrict__ momentum,
+                                                                  const double* __restrict__ rhs_rest, double* __restrict__ tot) {
     PN_SIM_PRIO();
     constexpr int NS = PN_GCH / 4;
     __shared__ double red[NS][30][3];
+    __shared__ int last_s;
     const int b = blockIdx.x;
-    const int2 ch = chunk[b];
-    const int bg = ch.x, cnt = ch.y;
-    if (cnt == 0) return;  // the grid is the host-side upper bound 8 n_IP / PN_GCH + n_k
+    const int4 ch = chunk[b];
+    const int bg = ch.x, cnt = ch.y, kern = ch.z, nck = ch.w;
+    if (kern < 0) return;  // the grid is the host-side upper bound 8 n_IP / PN_GCH + n_k
     const int t = threadIdx.x;
     const int slot = t / 30, q = t - slot * 30, c = q / 10;
     if (t < NS * 30) {
@@ -539,7 +549,7 @@ __global__ void __launch_bounds__(PN_GCH * 8) k_rhs_gather_chunk(const int2* __r
             const bool on = e < cnt;
             const size_t ee = on ? (size_t)e : 0;
             gv[u] = on ? g[ee * 30] : 0.0;
-            p0[u] = pc[ee * 9]; p1[u] = pc[ee * 9 + 3]; p2[u] = pc[ee * 9 + 6];
+            p0[u] = on ? pc[ee * 9] : 0.0; p1[u] = on ? pc[ee * 9 + 3] : 0.0; p2[u] = on ? pc[ee * 9 + 6] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) { a0 += p0[u] * gv[u]; a1 += p1[u] * gv[u]; a2 += p2[u] * gv[u]; }
@@ -555,8 +565,31 @@ __global__ void __launch_bounds__(PN_GCH * 8) k_rhs_gather_chunk(const int2* __r
         double s = (red[sl][x][r] + red[sl][10 + x][r]) + red[sl][20 + x][r];
 #pragma unroll
         for (int m = 16; m > 0; m >>= 1) s += shfl_xor_d(s, m);
-        if (sl == 0) part[(size_t)b * 30 + o] = s;
+        if (sl == 0) {
+            if (tot) __hip_atomic_store(part + (size_t)b * 30 + o, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else part[(size_t)b * 30 + o] = s;
+        }
     }
+    if (!tot) return;
+    __builtin_amdgcn_s_waitcnt(0);  // the sums are at the memory side
+    __syncthreads();
+    if (t == 0) {
+        const int old = __hip_atomic_fetch_add(kcount + kern, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = ((old + 1) % nck) == 0;
+    }
+    __syncthreads();
+    if (!last_s || t >= 30) return;
+    const int b0 = kc_bg[kern];
+    double sum = 0.0;
+    for (int j0 = 0; j0 < nck; j0 += 8) {  // ascending chunk order, eight loads in flight (unconditional, clamped)
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = __hip_atomic_load(part + (size_t)(b0 + min(j0 + u, nck - 1)) * 30 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (j0 + u < nck) sum += v[u];
+    }
+    const size_t o = (size_t)kern * 30 + t;
+    tot[o] = momentum[o] + sum - rhs_rest[o];
 }
 
 // out = momentum + (chunk sums of the row's kernel, ascending chunk order) - rhs_rest: one thread per output row
@@ -713,10 +746,21 @@ __global__ void __launch_bounds__(256) k_step_end(int n3, double dt, const doubl
 }
 
 static inline uint64_t pn_gather_chunks_max(int n_k, int n_IP) { return (uint64_t)n_IP * 8 / PN_GCH + (uint64_t)n_k; }
-// tilde, last, momentum, tot [n_k*30 each] | P [n_IP*9] | P_csr [n_IP*8*9] | chunk sums [chunks_max*30] | plan: kc_bg [n_k+1] ints + chunk [chunks_max] int2
+// tilde, last, momentum, tot [n_k*30 each] | P [n_IP*9] | P_csr [n_IP*8*9] | chunk sums [chunks_max*30] | plan: kc_bg [n_k+1] ints, kcount [n_k] ints,
+// chunk [chunks_max] int4 | Vstore [n_IP*9]
 extern "C" uint64_t pn_sim_work_doubles(int n_k, int n_IP) {
     const uint64_t ch = pn_gather_chunks_max(n_k, n_IP);
-    return (uint64_t)n_k * 30 * 4 + (uint64_t)n_IP * 9 + (uint64_t)n_IP * 8 * 9 + ch * 30 + ((uint64_t)n_k + 2) / 2 + 1 + ch + 1 + (uint64_t)n_IP * 9;
+    return (uint64_t)n_k * 30 * 4 + (uint64_t)n_IP * 9 + (uint64_t)n_IP * 8 * 9 + ch * 30 + 2 * (((uint64_t)n_k + 2) / 2 + 1) + 2 * ch + 2 + (uint64_t)n_IP * 9;
+}
+// the plan's three arrays behind the chunk sums
+struct PnGatherPlan { int* kc_bg; int* kcount; int4* chunk; };
+static inline PnGatherPlan pn_gather_plan_ptrs(double* part, uint64_t chunks_max, int n_k) {
+    PnGatherPlan p;
+    const size_t slot = ((size_t)n_k + 2) & ~(size_t)1;  // ints, even: every array starts on 8 bytes; the chunk table on 16
+    p.kc_bg = reinterpret_cast<int*>(part + chunks_max * 30);
+    p.kcount = p.kc_bg + slot;
+    p.chunk = reinterpret_cast<int4*>((reinterpret_cast<uintptr_t>(p.kcount + slot) + 15) & ~(uintptr_t)15);
+    return p;
 }
 // where the per-IP rotations of the warm-started SVD live in `work` (behind everything else)
 static inline double* pn_sim_vstore(double* work, int n_k, int n_IP) { return work + (pn_sim_work_doubles(n_k, n_IP) - (uint64_t)n_IP * 9); }
@@ -734,9 +778,8 @@ extern "C" int pn_sim_prepare(int n_k, int n_IP, const int* csr_bg, const int* c
     const int n3 = n_k * 30;
     const uint64_t chunks_max = pn_gather_chunks_max(n_k, n_IP);
     double* part = work + 4 * (size_t)n3 + (size_t)n_IP * 9 + (size_t)n_IP * 8 * 9;
-    int* kc_bg = reinterpret_cast<int*>(part + chunks_max * 30);
-    int2* chunk = reinterpret_cast<int2*>(kc_bg + ((n_k + 2) & ~1));
-    k_gather_plan<<<1, 512, 0, st>>>(n_k, (int)chunks_max, csr_bg, csr_cnt, kc_bg, chunk);
+    const PnGatherPlan gp = pn_gather_plan_ptrs(part, chunks_max, n_k);
+    k_gather_plan<<<1, 512, 0, st>>>(n_k, (int)chunks_max, csr_bg, csr_cnt, gp.kc_bg, gp.chunk, gp.kcount);
     k_vstore_identity<<<pn_div_up((uint64_t)n_IP * 9, 256), 256, 0, st>>>(n_IP, pn_sim_vstore(work, n_k, n_IP));
     PN_LAUNCH_CHECK();
     return PN_OK;
@@ -758,14 +801,16 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
     double* P_csr = P + (size_t)n_IP * 9;
     const uint64_t chunks_max = pn_gather_chunks_max(n_k, n_IP);
     double* part = P_csr + (size_t)n_IP * 8 * 9;
-    int* kc_bg = reinterpret_cast<int*>(part + chunks_max * 30);
-    int2* chunk = reinterpret_cast<int2*>(kc_bg + ((n_k + 2) & ~1));
+    const PnGatherPlan gp = pn_gather_plan_ptrs(part, chunks_max, n_k);
+    int* kc_bg = gp.kc_bg;
+    int4* chunk = gp.chunk;
     const double dx3 = pow(dx, 3.0);
     const bool pcsr = dNx_csr && csr_pos;
     // balanced gather (chunked lists + right-hand side assembled inside the matvec); PN_SIM_GATHER=kernel keeps one workgroup per kernel
     static const bool chunked_ok = [] { const char* v = getenv("PN_SIM_GATHER"); return !(v && strcmp(v, "kernel") == 0); }();
     static const bool fused_x = [] { const char* v = getenv("PN_SIM_GATHER"); return v && strcmp(v, "fused") == 0; }();
     static const int dbg_nosvd = (int)pn_env_u32("PN_SIM_DBG_NOSVD", 0);
+    static const bool fuse_sum = [] { const char* v = getenv("PN_SIM_FUSE_SUM"); return !(v && v[0] == '0'); }();  // the chunk kernel's last arriver sums (0: k_gather_sum)
     // k_elastic in one-wave workgroups: a lane's 60 loads (its kernel's 30 DOFs, its 30 shape-function gradients) are 240-B blocks of its own, so every
     // load instruction touches 64 cache lines and keeps the CU's address path busy for ~140 cycles; with 256-thread workgroups the 447 waves of the
     // chair sat four to a CU on 112 of the 256 CUs and queued on that path (31.9 -> 28.3 us per local/global iteration; 16-byte loads on top: nothing)
@@ -782,7 +827,7 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
                 if (dev_id >= 0 && dev_id < PN_MAX_DEVICES) granted[dev_id] = xs_bytes;
             }
         }
-        if (!prepared) k_gather_plan<<<1, 512, 0, st>>>(n_k, (int)chunks_max, csr_bg, csr_cnt, kc_bg, chunk);
+        if (!prepared) k_gather_plan<<<1, 512, 0, st>>>(n_k, (int)chunks_max, csr_bg, csr_cnt, kc_bg, chunk, gp.kcount);
     }
     static const bool warm_svd = pn_env_u32("PN_SIM_COLD_SVD", 0) == 0;  // experiments: PN_SIM_COLD_SVD=1 starts every SVD from the identity (rounds 1-2)
     double* Vstore = (prepared && warm_svd) ? pn_sim_vstore(work, n_k, n_IP) : nullptr;
@@ -792,11 +837,13 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
         k_elastic<<<pn_div_up((uint64_t)n_IP * 8, el_wg), el_wg, 0, st>>>(n_IP, topo, dNx, dof, nullptr, nullptr, nullptr, pcsr ? nullptr : P, mu, lam, dx3,
                                                                       pcsr ? csr_pos : nullptr, pcsr ? P_csr : nullptr, dbg_nosvd, Vstore);
         if (chunked) {
-            k_rhs_gather_chunk<<<(uint32_t)chunks_max, PN_GCH * 8, 0, st>>>(chunk, dNx_csr, P_csr, part);
+            const bool sum_in_chunk = fuse_sum && !fused_x;
+            k_rhs_gather_chunk<<<(uint32_t)chunks_max, PN_GCH * 8, 0, st>>>(chunk, dNx_csr, P_csr, part, gp.kcount, kc_bg, momentum, rhs_rest,
+                                                                            sum_in_chunk ? tot : nullptr);
             if (fused_x) {
                 k_matvec3_gathered<<<pn_div_up(n, 8), 256, xs_bytes, st>>>(n, Ainv, dof, dof_rest, momentum, rhs_rest, part, kc_bg);
             } else {
-                k_gather_sum<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, kc_bg, part, momentum, rhs_rest, tot);
+                if (!sum_in_chunk) k_gather_sum<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, kc_bg, part, momentum, rhs_rest, tot);
                 k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Ainv, tot, dof, 2, dof_rest, nullptr);
             }
             continue;

@@ -42,7 +42,7 @@ cd $R
 tools/bin/calib_barrier > $O/calib_barrier.txt 2>&1
 tools/bin/calib_exchange > $O/calib_exchange.txt 2>&1
 python tools/time_sim.py > $O/time_sim.txt 2>&1; PN_SIM_COLD_SVD=1 python tools/time_sim.py >> $O/time_sim.txt 2>&1; PN_SIM_DBG_NOSVD=1 python tools/time_sim.py >> $O/time_sim.txt 2>&1
-PN_SIM_EL_WG=256 python tools/time_sim.py >> $O/time_sim.txt 2>&1
+PN_SIM_EL_WG=256 python tools/time_sim.py >> $O/time_sim.txt 2>&1; PN_SIM_FUSE_SUM=0 python tools/time_sim.py >> $O/time_sim.txt 2>&1
 python tools/time_sim.py --persistent 2>&1 | grep -v amdgpu.ids > $O/time_sim_persistent.txt; python tools/time_sim.py --persistent --iters 20 2>&1 | tail -1 >> $O/time_sim_persistent.txt
 PN_SIM_COOP_DBG=4 python tools/time_sim.py --persistent 2>&1 | grep -v amdgpu.ids >> $O/time_sim_persistent.txt
 PN_SIM_COOP_DBG=1 python tools/time_sim.py --persistent 2>&1 | tail -1 >> $O/time_sim_persistent.txt
