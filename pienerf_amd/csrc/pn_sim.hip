@@ -617,9 +617,17 @@ extern "C" int pn_sim_collect_rhs(int n_k, double dx, const int* csr_bg, const i
 // ------------------------------------------------------------------------------------------------ structured matvec
 // Y[i,:] = sum_j A[i,j] X[j,:], one wave per row.  Epilogues: 0: Y = s ; 1: Y = s + add1 + add2 (momentum, solver.py:576) ;
 // 2: Y = add1 + s (dof = dof_rest + x, solver.py:601).
+// 3: mode 2 + the substep's epilogue vel = (Y - add2) / dt * 0.998 (add2 = dof_last; k_step_end, solver.py:602).  Xv != nullptr (mode 1, the momentum
+// product of a substep): X is read as X + dt * Xv (dof_tilde = dof + dt * vel, solver.py:575) and the first n * 3 threads also copy X to `copy_out`
+// (dof_last = dof.clone(), :597) — what k_step_begin did in a launch of its own.
 __global__ void __launch_bounds__(256) k_matvec3(int n, const double* __restrict__ A, const double* __restrict__ X, double* __restrict__ Y, int mode,
-                                                 const double* __restrict__ add1, const double* __restrict__ add2) {
+                                                 const double* __restrict__ add1, const double* __restrict__ add2, const double* __restrict__ Xv = nullptr,
+                                                 double dt = 0.0, double* __restrict__ copy_out = nullptr, double* __restrict__ vel_out = nullptr) {
     PN_SIM_PRIO();
+    if (copy_out) {
+        const int g = blockIdx.x * 256 + threadIdx.x;
+        if (g < n * 3) copy_out[g] = X[g];
+    }
     // two rows per wave: each X[j,:] fetched once serves both, and the four-deep unroll keeps 20 loads in flight per lane
     const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
     if (i0 >= n) return;
@@ -636,6 +644,7 @@ __global__ void __launch_bounds__(256) k_matvec3(int n, const double* __restrict
             const int jj = j + 64 * u;
             wa[u] = a[jj]; wb[u] = b[jj];
             x[u][0] = X[jj * 3]; x[u][1] = X[jj * 3 + 1]; x[u][2] = X[jj * 3 + 2];
+            if (Xv) { x[u][0] = x[u][0] + dt * Xv[jj * 3]; x[u][1] = x[u][1] + dt * Xv[jj * 3 + 1]; x[u][2] = x[u][2] + dt * Xv[jj * 3 + 2]; }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -645,7 +654,8 @@ __global__ void __launch_bounds__(256) k_matvec3(int n, const double* __restrict
     }
     for (; j < n; j += 64) {
         const double wa = a[j], wb = b[j];
-        const double x0 = X[j * 3], x1 = X[j * 3 + 1], x2 = X[j * 3 + 2];
+        double x0 = X[j * 3], x1 = X[j * 3 + 1], x2 = X[j * 3 + 2];
+        if (Xv) { x0 = x0 + dt * Xv[j * 3]; x1 = x1 + dt * Xv[j * 3 + 1]; x2 = x2 + dt * Xv[j * 3 + 2]; }
         s[0] += wa * x0; s[1] += wa * x1; s[2] += wa * x2;
         s[3] += wb * x0; s[4] += wb * x1; s[5] += wb * x2;
     }
@@ -659,8 +669,9 @@ __global__ void __launch_bounds__(256) k_matvec3(int n, const double* __restrict
         for (int q = 0; q < 6; q++) if (q == lane) v = s[q];
         const size_t o = (size_t)i0 * 3 + lane;
         if (mode == 1) v = v + add1[o] + add2[o];
-        else if (mode == 2) v = add1[o] + v;
+        else if (mode >= 2) v = add1[o] + v;
         Y[o] = v;
+        if (mode == 3) vel_out[o] = (v - add2[o]) / dt * 0.998;
     }
 }
 
@@ -831,8 +842,15 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
     }
     static const bool warm_svd = pn_env_u32("PN_SIM_COLD_SVD", 0) == 0;  // experiments: PN_SIM_COLD_SVD=1 starts every SVD from the identity (rounds 1-2)
     double* Vstore = (prepared && warm_svd) ? pn_sim_vstore(work, n_k, n_IP) : nullptr;
-    k_step_begin<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, dt, dof, dof_vel, tilde, last);
-    k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Mmat, tilde, momentum, 1, dof_f, rhs_gravity);  // compute_momentum (:574-576)
+    // the substep's two elementwise launches ride on the matrix products next to them (PN_SIM_FUSE_ENDS=0: k_step_begin / k_step_end as launches)
+    static const bool fuse_ends = [] { const char* v = getenv("PN_SIM_FUSE_ENDS"); return !(v && v[0] == '0'); }();
+    const bool ends = fuse_ends && chunked && !fused_x && iters >= 1;
+    if (ends) {
+        k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Mmat, dof, momentum, 1, dof_f, rhs_gravity, dof_vel, dt, last);  // dof_tilde on the fly, dof_last = dof
+    } else {
+        k_step_begin<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, dt, dof, dof_vel, tilde, last);
+        k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Mmat, tilde, momentum, 1, dof_f, rhs_gravity);  // compute_momentum (:574-576)
+    }
     for (int it = 0; it < iters; it++) {
         k_elastic<<<pn_div_up((uint64_t)n_IP * 8, el_wg), el_wg, 0, st>>>(n_IP, topo, dNx, dof, nullptr, nullptr, nullptr, pcsr ? nullptr : P, mu, lam, dx3,
                                                                       pcsr ? csr_pos : nullptr, pcsr ? P_csr : nullptr, dbg_nosvd, Vstore);
@@ -844,7 +862,8 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
                 k_matvec3_gathered<<<pn_div_up(n, 8), 256, xs_bytes, st>>>(n, Ainv, dof, dof_rest, momentum, rhs_rest, part, kc_bg);
             } else {
                 if (!sum_in_chunk) k_gather_sum<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, kc_bg, part, momentum, rhs_rest, tot);
-                k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Ainv, tot, dof, 2, dof_rest, nullptr);
+                if (ends && it == iters - 1) k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Ainv, tot, dof, 3, dof_rest, last, nullptr, dt, nullptr, dof_vel);
+                else k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Ainv, tot, dof, 2, dof_rest, nullptr);
             }
             continue;
         }
@@ -854,7 +873,7 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
             k_rhs_gather<<<pn_div_up(n_k, 4), 256, 0, st>>>(n_k, dx3, csr_bg, csr_cnt, csr_buf, mu, lam, dNx, nullptr, nullptr, P, momentum, rhs_rest, tot);
         k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Ainv, tot, dof, 2, dof_rest, nullptr);  // x = G @ rhs ; dof = dof_rest + x (:600-601)
     }
-    k_step_end<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, dt, dof, last, dof_vel);
+    if (!ends) k_step_end<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, dt, dof, last, dof_vel);
     PN_LAUNCH_CHECK();
     return PN_OK;
 }
