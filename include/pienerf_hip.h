@@ -225,6 +225,12 @@ typedef struct {
                              inside the same launches (rays are independent; the alive list stays sorted by ray id, so a batch is a contiguous
                              run of it).  0: one schedule for the whole ray set (what the reference's render_deformed does, renderer.py:587-600).
                              Deformed render only. */
+    int throughput;       /* > 0: the THROUGHPUT form of the frame's first trip — its first march pass walks every ray with ONE lane (one visited point of
+                             the ray's chain per round, up to this many rounds; rays that outlast them go on in the wave-per-ray windows) instead of
+                             evaluating windows of 8 / 64 consecutive lattice elements of which the chain visits one in 4.6: a quarter of the vector work
+                             per visited point, bit-identical samples, a longer first trip (~7 us per round).  For pipelines that keep several frames in
+                             flight (harness.capture_pipelined with more than one lane: +8 % steps/s on the chair, +13 % on configs[4]); 0: the latency
+                             form.  Deformed render only. */
 } pn_render_opts;
 int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_vtx, uint32_t max_grid_cells);
 void pn_frame_destroy(pn_frame* f);

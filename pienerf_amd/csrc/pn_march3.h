@@ -822,8 +822,9 @@ __device__ inline bool march_window(const MarchParams& a, const March2Tables& tb
         pc.x = pc.y = pc.z = 0.f; pc.in_cut = false; pc.oob = false; pc.gid = -1; pc.b = pc.e = 0;
         if (go) {
             if (fixed) {
-                bn = binade_of<G>(t, D);
-                fast = bn.ok && t + (float)G * bn.Dq < bn.top;
+                // (G == 1, one lane per ray: the lattice reaches 64 elements ahead, so that a voxel hop is one product instead of a stepping loop)
+                bn = binade_of<(G == 1 ? 64 : G)>(t, D);
+                fast = bn.ok && t + (float)(G == 1 ? 65 : G) * bn.Dq < bn.top;
             }
             if (fast) {
                 s = t + (float)sub * bn.Dq;
@@ -863,7 +864,16 @@ __device__ inline bool march_window(const MarchParams& a, const March2Tables& tb
             // where the chain goes from this point: the next element (emitted) or the first element not below the voxel exit;
             // G = first element of the next window, G + 1 = beyond it
             int jump = sub + 1;
-            if (active && !ev.emit) {
+            float t_hop = nxt;  // G == 1: where the chain goes from this (visited) point
+            if (G == 1 && active && !ev.emit) {
+                if (fast) {
+                    const int k = lattice_first_at_least(bn, t, ev.tt, 1, 64);
+                    t_hop = t + (float)min(k, 64) * bn.Dq;       // exact: inside the binade
+                    if (k > 64) while (t_hop < ev.tt) t_hop += dtf(a, c, t_hop);
+                } else {
+                    while (t_hop < ev.tt) t_hop += dtf(a, c, t_hop);  // do { t += dt } while (t < tt): the first step is `nxt`
+                }
+            } else if (active && !ev.emit) {
                 if (fast) {
                     jump = lattice_first_at_least(bn, t, ev.tt, sub + 1, G);
                 } else {
@@ -887,7 +897,14 @@ __device__ inline bool march_window(const MarchParams& a, const March2Tables& tb
             int cur = 0, prev_emit = -1, n_emit = 0, last_vis = 0;
             int my_ord = -1, my_prev = -1;
             bool visited = false, ended = false;
-            if (G == 64) {
+            if (G == 1) {
+                // one ray per lane: its single point is the visited one
+                if (!active) ended = true;
+                else {
+                    visited = true; my_ord = 0; my_prev = -1; last_vis = 0;
+                    if (ev.emit) { prev_emit = 0; n_emit = 1; if (step + 1u == n_step) ended = true; }
+                }
+            } else if (G == 64) {
                 // one ray per wave: the chain is wave-uniform — walked with scalar registers and v_readlane instead of 64 lanes each
                 // following it through ds_bpermute (~14 dependent LDS round trips per round)
                 unsigned long long vis = 0ull;
@@ -946,6 +963,8 @@ __device__ inline bool march_window(const MarchParams& a, const March2Tables& tb
             const float tt_last = (G == 64) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ev.tt), last_vis)) : __shfl(ev.tt, gbase + last_vis);
             if (ended) {
                 running = false;  // done for this trip; t is not needed any more (composite tracks rays_t itself)
+            } else if (G == 1) {
+                t = t_hop;
             } else {
                 t = sG;
                 if (cur == G + 1)

@@ -523,6 +523,7 @@ struct MarchIO {
     // optional (frame driver with ray groups, see PnGroup): this trip's group records
     const PnGroup* groups;
     uint32_t group_rays;
+    int lane_per_ray;           // k_march: one lane per ray instead of eight (the throughput form of a frame's first trip)
     int dda_start, hop_budget;  // k_march_skip: restart the hop chain just before the first cell with candidates; hops before a ray is handed on (pn_march3.h)
 };
 
@@ -618,13 +619,18 @@ static_assert(sizeof(TailEntry) == 64, "four 16-byte parts");
 #define PN_MARCH_WAVES 4
 #endif
 
-// 8 lanes per ray, 32 rays per 256-thread block.
-template <int K, bool MULTI>
+// G = 8: 8 lanes per ray (each lane one point of the ray's t-sequence per round), 32 rays per 256-thread block.
+// G = 1: ONE lane per ray, 256 rays per block — every evaluated point is a visited one (no speculation: a quarter of the VALU work per visited point of
+// the windows, whose lanes evaluate 4.6 elements per voxel hop), at one visited point per round (the windows: ~14).  The throughput form of a frame's
+// first trip (pn_render_opts.throughput): the wave-per-ray tail pass that the pipelined step is bound by only gets the rays that outlast the budget.
+template <int K, bool MULTI, int G>
 __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
     uint32_t n_alive = io.n_alive, n_step_trip = io.n_step;
     bool dense = false;
     if (io.trip) { n_alive = (uint32_t)io.trip->n_alive; n_step_trip = (uint32_t)io.trip->n_step; dense = trip_is_dense(io.trip); }
-    const int lane = threadIdx.x & 63, sub = lane & 7, gbase = lane & ~7;
+    static_assert(G == 8 || G == 1, "lanes per ray");
+    constexpr uint32_t RB = 256 / G;  // rays per block and chunk
+    const int lane = threadIdx.x & 63, sub = lane & (G - 1), gbase = lane & ~(G - 1);
     const int budget = io.tail ? io.max_rounds : 0x7fffffff;
     __shared__ float4 stage_mem[4][PN_STAGE_CAP];
     float4* stage = stage_mem[threadIdx.x >> 6];
@@ -635,9 +641,9 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams 
     const uint32_t n_work = io.active ? (uint32_t)seg_count(io.active_counts, (int)act_seg) : n_alive;
     const uint32_t k0 = io.active ? blockIdx.x / PN_SEGS : blockIdx.x, kstep = io.active ? (uint32_t)seg_workers((int)gridDim.x, (int)act_seg) : gridDim.x;
     PN_PHASE_DECL(pk);
-    for (uint32_t chunk = k0; chunk * 32u < n_work; chunk += kstep) {
+    for (uint32_t chunk = k0; chunk * RB < n_work; chunk += kstep) {
         const uint32_t seg = io.active ? act_seg : chunk % PN_SEGS;
-        const uint32_t i_work = chunk * 32u + (threadIdx.x >> 3);
+        const uint32_t i_work = chunk * RB + threadIdx.x / G;
         const uint32_t n = io.active ? (i_work < n_work ? (uint32_t)io.active[(size_t)act_seg * io.active_seg_cap + i_work] : 0xffffffffu) : i_work;
         uint32_t emitted = 0;
         bool deferred = false, have = false;
@@ -655,7 +661,7 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams 
         }
         PN_PHASE(pk, 0);
         // all 64 lanes enter (the round loop inside is wave-uniform, pn_march3.h); lanes without a ray idle through it
-        const bool done = pnm3::march_window<K, MULTI, 8>(a, tb, c, n_step, sub, gbase, lane, stage, io.xyzs + (size_t)slot0 * 3,
+        const bool done = pnm3::march_window<K, MULTI, G>(a, tb, c, n_step, sub, gbase, lane, stage, io.xyzs + (size_t)slot0 * 3,
                                                           io.dirs + (size_t)slot0 * 3, dl, st, budget, have PN_PHASE_PASS);
         if (n < n_alive) {
             deferred = have && !done;  // still marching after the round budget: continue with a whole wave (k_march_tail)
@@ -672,31 +678,35 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams 
                 if (lane == 0 && sm) poss = atomicAdd(io.tail_back + seg * PN_SEG_STRIDE, (int)__popcll(sm));
                 posl = __shfl(posl, 0);
                 poss = __shfl(poss, 0);
-                if (deferred && sub < 4) {  // lanes 0..3 of the group write one 16-byte part each
-                    const unsigned long long below = (1ull << (lane & ~7)) - 1ull;
+                if (deferred && sub < 4) {  // lanes 0..3 of the group write one 16-byte part each (G == 1: the lane writes all four)
+                    const unsigned long long below = (1ull << gbase) - 1ull;
                     const int slot = is_long ? posl + (int)__popcll(lm & below) : io.tail_seg_cap - 1 - (poss + (int)__popcll(sm & below));
                     float4* te = reinterpret_cast<float4*>(io.tail + (size_t)seg * io.tail_seg_cap + slot);
-                    float4 part;
-                    if (sub == 0) part = make_float4(__int_as_float((int)n), st.t, st.last_t, __int_as_float((int)st.step));
-                    else if (sub == 1) part = make_float4(c.ox, c.oy, c.oz, c.dx);
-                    else if (sub == 2) part = make_float4(c.dy, c.dz, c.rdx, c.rdy);
-                    else part = make_float4(c.rdz, c.far, __int_as_float((int)slot0), __int_as_float((int)n_step));
-                    te[sub] = part;
+#pragma unroll
+                    for (int part_i = (G == 1 ? 0 : sub); part_i < (G == 1 ? 4 : sub + 1); part_i++) {
+                        float4 part;
+                        if (part_i == 0) part = make_float4(__int_as_float((int)n), st.t, st.last_t, __int_as_float((int)st.step));
+                        else if (part_i == 1) part = make_float4(c.ox, c.oy, c.oz, c.dx);
+                        else if (part_i == 2) part = make_float4(c.dy, c.dz, c.rdx, c.rdy);
+                        else part = make_float4(c.rdz, c.far, __int_as_float((int)slot0), __int_as_float((int)n_step));
+                        te[part_i] = part;
+                    }
                 }
             }
         }
         if (io.trip) {
             // slots the ray did not fill end it in composite (delta == 0); the op-level wrapper zero-fills instead (raymarching.py:415-417)
             if (dl && !deferred)
-                for (uint32_t s = emitted + sub; s < n_step; s += PN_G) { dl[2 * s] = 0.0f; dl[2 * s + 1] = 0.0f; }
+                for (uint32_t s = emitted + sub; s < n_step; s += G) { dl[2 * s] = 0.0f; dl[2 * s + 1] = 0.0f; }
             if (dense) {
                 if (dl && !deferred) {
                     float* X = io.xyzs + (size_t)slot0 * 3;
                     float* Dd = io.dirs + (size_t)slot0 * 3;
-                    for (uint32_t s = emitted + sub; s < n_step; s += PN_G) { X[3 * s] = X[3 * s + 1] = X[3 * s + 2] = 0.0f; Dd[3 * s] = Dd[3 * s + 1] = Dd[3 * s + 2] = 0.0f; }
-                    for (uint32_t s = sub; s < n_step; s += PN_G) io.list[slot0 + s] = (int)(slot0 + s);
+                    for (uint32_t s = emitted + sub; s < n_step; s += G) { X[3 * s] = X[3 * s + 1] = X[3 * s + 2] = 0.0f; Dd[3 * s] = Dd[3 * s + 1] = Dd[3 * s + 2] = 0.0f; }
+                    for (uint32_t s = sub; s < n_step; s += G) io.list[slot0 + s] = (int)(slot0 + s);
                 }
                 int v = (sub == 0 && dl && !deferred) ? (int)emitted : 0;  // one counter update per wave
+                if (G == 1) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); }
                 v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
                 if (lane == 0 && v) atomicAdd(io.emit_parts + seg * PN_SEG_STRIDE, v);
             } else {
@@ -713,7 +723,7 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams 
             base = __shfl(base, 63);
             const int first = base + __shfl(inc, gbase) - (int)emitted;  // exclusive prefix of this group's first lane
             int* seg_list = io.list_seg + (size_t)seg * io.list_seg_cap;
-            for (uint32_t s = sub; s < emitted; s += PN_G) seg_list[first + s] = (int)(slot0 + s);
+            for (uint32_t s = sub; s < emitted; s += G) seg_list[first + s] = (int)(slot0 + s);
             }
         }
         PN_PHASE(pk, 5);
@@ -776,7 +786,8 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march_tail(pnm::MarchPa
 
 template <int K, bool MULTI>
 static void launch_march_km(uint32_t blocks, uint32_t tail_blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb, const MarchIO& io) {
-    k_march<K, MULTI><<<blocks, 256, 0, st>>>(a, tb, io);
+    if (io.lane_per_ray) k_march<K, MULTI, 1><<<blocks, 256, 0, st>>>(a, tb, io);
+    else k_march<K, MULTI, 8><<<blocks, 256, 0, st>>>(a, tb, io);
     if (io.tail) k_march_tail<K, MULTI><<<tail_blocks, 256, 0, st>>>(a, tb, io);
 }
 
@@ -1968,6 +1979,9 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     static const int dda_env = [] { const char* v = getenv("PN_SKIP_DDA"); return (v && v[0] == '0') ? 0 : 1; }();
     const int dda_start = g_skip_dda_override >= 0 ? g_skip_dda_override : dda_env;
     static const uint32_t skip_hop_budget = pn_env_u32("PN_SKIP_HOPS", 8);
+    // a frame's first trip with ONE lane per ray in pass 1 (k_march<.., 1>) for this many rounds = visited points before a ray goes to the windows
+    static const uint32_t lpr_env = pn_env_u32("PN_MARCH_LPR", 0);
+    const uint32_t lpr_rounds = lpr_env ? lpr_env : (o->throughput > 0 ? (uint32_t)o->throughput : 0u);  // (PN_MARCH_LPR: experiments)
     static const bool split_compact = pn_env_u32("PN_SPLIT_COMPACT", 0) != 0;  // experiments: composite and compaction as two launches (rounds 1-2)
     static const uint32_t tail_grid_cfg = pn_env_u32("PN_TAIL_GRID", 1024);  // x4 waves, one unfinished ray per wave at a time
     const uint32_t tail_grid = std::max(std::min(pn_div_up(N, 4), tail_grid_cfg), (uint32_t)PN_SEGS / 4);  // every tail segment needs a wave
@@ -2075,10 +2089,12 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             int* seg_active = seg_back + PN_SEGS * PN_SEG_STRIDE;
             // trip 0 keeps its skip pre-pass state in f->sigmas (t_resume) and lists the slots worth marching in f->active_seg
             MarchIO io{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + t, f->list, (t == 0) ? f->sigmas : nullptr,
-                       f->tail, seg_tail, seg_back, seg_curs, (int)f->seg_cap, (int)march_tail_rounds(t), (t == 0) ? f->active_seg : nullptr, (t == 0) ? seg_active : nullptr,
+                       f->tail, seg_tail, seg_back, seg_curs, (int)f->seg_cap, (t == 0 && lpr_rounds > 0) ? (int)lpr_rounds : (int)march_tail_rounds(t),
+                       (t == 0) ? f->active_seg : nullptr, (t == 0) ? seg_active : nullptr,
                        (int)f->seg_cap, f->list_seg, seg_samp, (int)f->seg_cap, seg_emit, f->cell_bits, skip_bits_words,
                        short_rays ? f->cell_bits + bit_words : nullptr, short_rays ? f->fars_eff : nullptr,
-                       group_rays ? f->groups + (size_t)(t & 1) * f->max_groups : nullptr, group_rays, dda_start, (int)skip_hop_budget};
+                       group_rays ? f->groups + (size_t)(t & 1) * f->max_groups : nullptr, group_rays, (t == 0 && lpr_rounds > 0) ? 1 : 0, dda_start,
+                       (int)skip_hop_budget};
             const bool timed = (f->march_counters_on & 2) && t < PN_TIMED_TRIPS;
             bool stamp = false;
             if (timed) {  // measurement mode: the two heavy launch groups of each trip are bracketed on the launch stream

@@ -427,6 +427,9 @@ class _HipBackend:
         self.snap = {}
         n_ws, n_IP = lanes * depth, sim.n_IP
         kw = dict(h.render_kwargs(), async_trips=n_trips)
+        # several frames in flight: the first trip's march pass in its throughput form (pn_render_opts.throughput: one lane per ray, no speculative
+        # evaluation; the same samples bit for bit, +8 % steps/s with three lanes) — with one lane the frame's own latency is what counts
+        kw.setdefault("march_throughput", 64 if lanes > 1 else 0)
         self.kw = kw
         pose0 = torch.from_numpy(np.asarray(h.pose, np.float32)).unsqueeze(0)
         self.pose_dev = [pose0.to(dev) for _ in range(n_ws)]

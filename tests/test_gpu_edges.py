@@ -200,6 +200,26 @@ def test_frame_independent_of_the_skip_pre_pass_form(deformed_ip_state, small_op
     assert torch.equal(torch.nan_to_num(d0, nan=-1.0), torch.nan_to_num(d1, nan=-1.0))
 
 
+@pytest.mark.parametrize("rounds", [1, 5, 64])
+@pytest.mark.parametrize("num_seek_IP,max_iter_num", [(3, 1), (2, 4), (1, 1)])
+def test_frame_independent_of_the_first_trip_form(deformed_ip_state, small_opt, ckpt, rounds, num_seek_IP, max_iter_num):
+    """pn_render_opts.throughput: the first trip's pass 1 with ONE lane per ray (every evaluated point a visited one) for `rounds` rounds before a ray
+    goes on in the wave-per-ray windows, against the latency form (windows of 8 lattice elements): the same samples, the same pixels bit for bit."""
+    W = 96
+    opt = dict(small_opt, num_seek_IP=num_seek_IP, max_iter_num=max_iter_num)
+    o, d = oracle.get_rays(scene.orbit_pose(3.0, 35.0, -25.0), scene.orbit_intrinsics(W, W, 50.0), W, W)
+    net = _net(ckpt, deformed_ip_state)
+    res = []
+    with torch.no_grad():
+        for thr in (0, rounds):
+            out = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **dict(opt, march_throughput=thr))
+            res.append((dict(net.last_stats), out["image"].clone(), out["depth"].clone(), out["depth_0"].clone()))
+    (s0, i0, d0, e0), (s1, i1, d1, e1) = res
+    assert s0["samples"] == s1["samples"] > 1000 and s0["trips"] == s1["trips"] and s0["err"] == s1["err"] == 0
+    assert torch.equal(i0, i1) and torch.equal(e0, e1)
+    assert torch.equal(torch.nan_to_num(d0, nan=-1.0), torch.nan_to_num(d1, nan=-1.0))
+
+
 _FRAME_HASH_SCRIPT = r"""
 import hashlib, sys, numpy as np, torch
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")

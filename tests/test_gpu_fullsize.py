@@ -114,6 +114,25 @@ def test_full_frame_independent_of_the_skip_pre_pass_form(full):
         assert torch.equal(torch.nan_to_num(o0[k], nan=-1.0), torch.nan_to_num(o1[k], nan=-1.0)), k
 
 
+def test_full_frame_independent_of_the_first_trip_form(full):
+    """All 640 000 rays with the first trip's pass 1 in its throughput form (one lane per ray, 64 rounds: what the pipelined harness renders with)
+    and in the latency form: the same trip records and the same pixels bit for bit."""
+    h = full["h"]
+    m = h.model
+    res = []
+    with torch.no_grad():
+        for thr in (0, 64):
+            rays = {k: full["out"][k] for k in ("rays_o", "rays_d")}
+            out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, collect_stats=True,
+                                    **dict(h.render_kwargs(), march_throughput=thr))
+            res.append((dict(m.last_stats), m.trip_records(), {k: out[k].clone() for k in ("image", "depth", "depth_0")}))
+    (s0, r0, o0), (s1, r1, o1) = res
+    assert s0["samples"] == s1["samples"] > 5e5 and s0["trips"] == s1["trips"] and s0["err"] == s1["err"] == 0
+    assert [r[:5] for r in r0] == [r[:5] for r in r1]
+    for k in o0:
+        assert torch.equal(torch.nan_to_num(o0[k], nan=-1.0), torch.nan_to_num(o1[k], nan=-1.0)), k
+
+
 def test_strided_subset_of_the_full_frame_matches_the_oracle(full):
     """Every 199th ray of the 800x800 frame, rendered by the CPU oracle from the same IP state, against the full frame's pixels;
     and the same subset rendered alone on the GPU reproduces the full frame's pixels bit for bit (rays are independent)."""
