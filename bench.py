@@ -441,7 +441,9 @@ def main():
             h.capture_pipelined(lanes=args.lanes, depth=args.depth, n_trips=args.trips, copy_out=copy_out, copy_on=args.copy_on)
             args.trips = h._pipe_backend.trips
             run_steps = lambda n: [h.step_pipelined() for _ in range(n)]
-            launch = (f"hip graphs, {args.trips} trips, {args.lanes} render streams x {args.depth} workspaces, simulator running ahead, D2H on "
+            launch = (f"hip graphs, {args.trips} trips, {args.lanes} render streams x {args.depth} workspaces, "
+                      + ("first trip's march pass 1 in its throughput form (one lane per ray, 64 rounds; pn_render_opts.throughput), " if args.lanes > 1 else "")
+                      + "simulator running ahead, D2H on "
                       + {"copy": "a copy stream", "lane": "the frame's render stream", "sim": "the simulator stream", "host": "no stream (copier thread + SDMA through the HSA runtime)"}[args.copy_on]
                       + (f"; rays in batches of {opt['ray_batch']} with per-batch trip schedules (max_ray_batch), all batches in the same launches" if staged else ""))
     else:
