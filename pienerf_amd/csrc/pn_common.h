@@ -58,7 +58,7 @@ struct PnGridLevels {
     uint32_t nomod[PN_MAX_LEVELS];         // 1 when the direct index is provably < hashmap_size (no modulo needed)
 };
 
-struct PnFusedLevel { float scale; uint32_t offset, m1, m2, mask, dense; uint32_t pad[2]; };  // see pn_nerf_forward.hip
+struct PnFusedLevel { float scale; uint32_t offset, m1, m2, mask, dense, dm, xm; };  // dm = dense ? ~0 : 0, xm = dense ? ~0 : mask; see pn_nerf_forward.hip
 
 int pn_fill_grid_levels(PnGridLevels* g, const int* offsets_host, uint32_t L, uint32_t C, float S, uint32_t H, uint32_t gridtype,
                         int align_corners);

@@ -19,6 +19,8 @@
 #include "pn_encoders.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------ level table
@@ -391,7 +393,7 @@ extern "C" int pn_net_create(pn_net** out, const float* embeddings, const int* o
         const bool hashed = g.dense[l] == 0 && g.mask[l] != 0;
         if (!dense && !hashed) { delete n; PN_REQUIRE(!"level is neither fully dense nor hashed into a power-of-two table"); }
         const uint32_t s1 = g.resolution[l] + 1;
-        fl[l] = PnFusedLevel{g.scale[l], g.offset[l], dense ? s1 : 2654435761u, dense ? s1 * s1 : 805459861u, g.mask[l], dense ? 1u : 0u, {0, 0}};
+        fl[l] = PnFusedLevel{g.scale[l], g.offset[l], dense ? s1 : 2654435761u, dense ? s1 * s1 : 805459861u, g.mask[l], dense ? 1u : 0u, dense ? 0xffffffffu : 0u, dense ? 0xffffffffu : g.mask[l]};
     }
     n->embeddings = embeddings;
     n->bound = bound;
@@ -467,41 +469,118 @@ extern "C" void pn_net_destroy(pn_net* n) {
 // (index = (g0 ^ g1*P1 ^ g2*P2) & mask) — pn_net_create rejects anything else — so both cases share the form
 // t0 + t1 + t2 / (t0 ^ t1 ^ t2) & mask with t1 = g1*m1, t2 = g2*m2 and the +1 corner is t + m (uint32 wrap-around exact).
 // 8 hash levels for one lane: feat[2j + c] = level (8h + j), channel c   (kernel_grid<float,3,2>, gridencoder.cu:87-197)
+// Build knobs of the fp32-accurate kernel's encoder (defaults = what measured fastest on MI355X):
+//   PN_ENC_PK       the corner weights and the two channels' sums on the packed fp32 pipe (v_pk_mul_f32 / v_pk_fma_f32: the same roundings)
+//   PN_ENC_LDS_LV   the per-level constants read per lane from an LDS copy (lane half h: levels 8h..8h+7) instead of two scalar loads and a
+//                   v_mov + v_mov + v_cndmask per constant
+//   PN_ENC_UNIFIED  one branch-free index form for dense and hashed levels instead of the compiler's exec-mask flow per corner
+#ifndef PN_ENC_PK
+#define PN_ENC_PK 1
+#endif
+#ifndef PN_ENC_LDS_LV
+#define PN_ENC_LDS_LV 1
+#endif
+#ifndef PN_ENC_UNIFIED
+#define PN_ENC_UNIFIED 1
+#endif
+#ifndef PN_SPLIT_PK
+#define PN_SPLIT_PK 0
+#endif
+#ifndef PN_BF_LU
+#define PN_BF_LU 4
+#endif
+// One level for one lane.  `L` = the lane's level constants.
+__device__ __forceinline__ void encode_level(const PnFusedLevel& L, const float* __restrict__ emb, float u0, float u1, float u2, bool oob, float* out2) {
+    const float scale = L.scale;
+    const uint32_t m1 = L.m1, m2 = L.m2, mask = L.mask;
+    const bool dense = L.dense != 0;
+    const float2* __restrict__ table = reinterpret_cast<const float2*>(emb) + L.offset;
+    float p0 = fmaf(u0, scale, 0.5f), p1 = fmaf(u1, scale, 0.5f), p2 = fmaf(u2, scale, 0.5f);
+    const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+    p0 -= f0; p1 -= f1; p2 -= f2;
+    const uint32_t t0[2] = {(uint32_t)f0, (uint32_t)f0 + 1u};
+    const uint32_t t1a = (uint32_t)f1 * m1, t2a = (uint32_t)f2 * m2;
+    const uint32_t t1[2] = {t1a, t1a + m1}, t2[2] = {t2a, t2a + m2};
+    f32x2 v[8];
+#if PN_ENC_UNIFIED
+    // index = ((a0 + S) ^ X) & M with (S, X, M) = (a1 + a2, 0, ~0) on a dense level and (0, a1 ^ a2, mask) on a hashed one
+    const uint32_t dm = L.dm, M = L.xm;
+    uint32_t S[4], X[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        S[c] = (t1[c & 1] + t2[c >> 1]) & dm;
+        X[c] = (t1[c & 1] ^ t2[c >> 1]) & ~dm;
+    }
+#pragma unroll
+    for (int idx = 0; idx < 8; idx++) {
+        const uint32_t index = ((t0[idx & 1] + S[idx >> 1]) ^ X[idx >> 1]) & M;
+        const float2 e = table[index];
+        v[idx] = f32x2{e.x, e.y};
+    }
+#else
+#pragma unroll
+    for (int idx = 0; idx < 8; idx++) {
+        const uint32_t a0 = t0[idx & 1], a1 = t1[(idx >> 1) & 1], a2 = t2[(idx >> 2) & 1];
+        const uint32_t index = dense ? (a0 + a1 + a2) : ((a0 ^ a1 ^ a2) & mask);
+        const float2 e = table[index];
+        v[idx] = f32x2{e.x, e.y};
+    }
+#endif
+#if PN_ENC_PK
+    // the eight corner weights ((1 * tx) * ty) * tz and the two channels' running sums, corner after corner as kernel_grid does them, on the
+    // packed fp32 pipe: (w_even, w_odd) pairs from v_pk_mul_f32, both channels of a corner in one v_pk_fma_f32
+    const f32x2 q0 = {1 - p0, p0};
+    const float n1 = 1 - p1, n2 = 1 - p2;
+    const f32x2 qa = q0 * n1, qb = q0 * p1;
+    const f32x2 w2[4] = {qa * n2, qb * n2, qa * p2, qb * p2};
+    f32x2 r = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        r = __builtin_elementwise_fma(f32x2{w2[c].x, w2[c].x}, v[2 * c], r);
+        r = __builtin_elementwise_fma(f32x2{w2[c].y, w2[c].y}, v[2 * c + 1], r);
+    }
+    out2[0] = oob ? 0.f : r.x;
+    out2[1] = oob ? 0.f : r.y;
+#else
+    float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+    for (int idx = 0; idx < 8; idx++) {
+        float w = 1;
+        w *= (idx & 1) ? p0 : 1 - p0;
+        w *= (idx & 2) ? p1 : 1 - p1;
+        w *= (idx & 4) ? p2 : 1 - p2;
+        r0 += w * v[idx].x;
+        r1 += w * v[idx].y;
+    }
+    out2[0] = oob ? 0.f : r0;
+    out2[1] = oob ? 0.f : r1;
+#endif
+}
+
+// `lv`: the 16 levels' constants (global memory: wave-uniform scalar loads); `lds_lv`: this lane half's 8 levels in LDS (PN_ENC_LDS_LV).
+// Fully unrolled in groups of LU levels (a partly unrolled loop writes feat[] through s_set_gpr_idx, four instructions per value); the
+// scheduling barrier between the groups bounds the gathers in flight per lane at 8 LU.
 template <int LU>
-__device__ __forceinline__ void encode8(const PnFusedLevel* __restrict__ lv, const float* __restrict__ emb, int half, float u0, float u1, float u2,
-                                        bool oob, float* feat) {
-#pragma unroll LU
-    for (int j = 0; j < 8; j++) {
-        const PnFusedLevel A = lv[j], B = lv[j + 8];  // wave-uniform
-        const float scale = half ? B.scale : A.scale;
-        const uint32_t m1 = half ? B.m1 : A.m1, m2 = half ? B.m2 : A.m2, mask = half ? B.mask : A.mask;
-        const bool dense = (half ? B.dense : A.dense) != 0;
-        const float2* __restrict__ table = reinterpret_cast<const float2*>(emb) + (half ? B.offset : A.offset);
-        float p0 = fmaf(u0, scale, 0.5f), p1 = fmaf(u1, scale, 0.5f), p2 = fmaf(u2, scale, 0.5f);
-        const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
-        p0 -= f0; p1 -= f1; p2 -= f2;
-        const uint32_t t0[2] = {(uint32_t)f0, (uint32_t)f0 + 1u};
-        const uint32_t t1a = (uint32_t)f1 * m1, t2a = (uint32_t)f2 * m2;
-        const uint32_t t1[2] = {t1a, t1a + m1}, t2[2] = {t2a, t2a + m2};
-        float2 v[8];
+__device__ __forceinline__ void encode8(const PnFusedLevel* __restrict__ lv, const PnFusedLevel* lds_lv, const float* __restrict__ emb, int half,
+                                        float u0, float u1, float u2, bool oob, float* feat) {
 #pragma unroll
-        for (int idx = 0; idx < 8; idx++) {
-            const uint32_t a0 = t0[idx & 1], a1 = t1[(idx >> 1) & 1], a2 = t2[(idx >> 2) & 1];
-            const uint32_t index = dense ? (a0 + a1 + a2) : ((a0 ^ a1 ^ a2) & mask);
-            v[idx] = table[index];
-        }
-        float r0 = 0.f, r1 = 0.f;
+    for (int g = 0; g < 8; g += LU) {
 #pragma unroll
-        for (int idx = 0; idx < 8; idx++) {
-            float w = 1;
-            w *= (idx & 1) ? p0 : 1 - p0;
-            w *= (idx & 2) ? p1 : 1 - p1;
-            w *= (idx & 4) ? p2 : 1 - p2;
-            r0 += w * v[idx].x;
-            r1 += w * v[idx].y;
+        for (int j = g; j < g + LU; j++) {
+#if PN_ENC_LDS_LV
+            const PnFusedLevel L = lds_lv[j];
+#else
+            const PnFusedLevel A = lv[j], B = lv[j + 8];  // wave-uniform
+            PnFusedLevel L;
+            L.scale = half ? B.scale : A.scale;
+            L.offset = half ? B.offset : A.offset;
+            L.m1 = half ? B.m1 : A.m1; L.m2 = half ? B.m2 : A.m2; L.mask = half ? B.mask : A.mask;
+            L.dense = half ? B.dense : A.dense;
+            L.dm = half ? B.dm : A.dm; L.xm = half ? B.xm : A.xm;
+#endif
+            encode_level(L, emb, u0, u1, u2, oob, feat + 2 * j);
         }
-        feat[2 * j] = oob ? 0.f : r0;
-        feat[2 * j + 1] = oob ? 0.f : r1;
+        if (g + LU < 8) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -524,16 +603,25 @@ struct Split8 { uint4 hi, mid, lo; };
 __device__ __forceinline__ uint32_t hi_pair(float a, float b) {  // bf16 (truncated) of a in the low half, of b in the high half
     return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
 }
-__device__ __forceinline__ float drop_hi(float x) { return x - __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+// x - (bf16 piece of x), two values per v_pk_add_f32
+__device__ __forceinline__ f32x2 drop_hi(f32x2 x) {
+    const f32x2 h = __builtin_bit_cast(f32x2, __builtin_bit_cast(u32x2, x) & 0xffff0000u);
+#if PN_SPLIT_PK
+    f32x2 r;  // written out: the vector combiner turns half of these subtractions back into scalar v_add_f32
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(h));
+    return r;
+#else
+    return f32x2{x.x - h.x, x.y - h.y};
+#endif
+}
 __device__ __forceinline__ Split8 split8(float x0, float x1, float x2, float x3, float x4, float x5, float x6, float x7) {
     Split8 o;
-    o.hi = make_uint4(hi_pair(x0, x1), hi_pair(x2, x3), hi_pair(x4, x5), hi_pair(x6, x7));
-    x0 = drop_hi(x0); x1 = drop_hi(x1); x2 = drop_hi(x2); x3 = drop_hi(x3);
-    x4 = drop_hi(x4); x5 = drop_hi(x5); x6 = drop_hi(x6); x7 = drop_hi(x7);
-    o.mid = make_uint4(hi_pair(x0, x1), hi_pair(x2, x3), hi_pair(x4, x5), hi_pair(x6, x7));
-    x0 = drop_hi(x0); x1 = drop_hi(x1); x2 = drop_hi(x2); x3 = drop_hi(x3);
-    x4 = drop_hi(x4); x5 = drop_hi(x5); x6 = drop_hi(x6); x7 = drop_hi(x7);
-    o.lo = make_uint4(hi_pair(x0, x1), hi_pair(x2, x3), hi_pair(x4, x5), hi_pair(x6, x7));
+    f32x2 a = {x0, x1}, b = {x2, x3}, c = {x4, x5}, d = {x6, x7};
+    o.hi = make_uint4(hi_pair(a.x, a.y), hi_pair(b.x, b.y), hi_pair(c.x, c.y), hi_pair(d.x, d.y));
+    a = drop_hi(a); b = drop_hi(b); c = drop_hi(c); d = drop_hi(d);
+    o.mid = make_uint4(hi_pair(a.x, a.y), hi_pair(b.x, b.y), hi_pair(c.x, c.y), hi_pair(d.x, d.y));
+    a = drop_hi(a); b = drop_hi(b); c = drop_hi(c); d = drop_hi(d);
+    o.lo = make_uint4(hi_pair(a.x, a.y), hi_pair(b.x, b.y), hi_pair(c.x, c.y), hi_pair(d.x, d.y));
     return o;
 }
 #define PN_BMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
@@ -582,10 +670,12 @@ __global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const P
     const uint32_t wave = blockIdx.x * PN_BF_WAVES + (threadIdx.x >> 6);
     if (blockIdx.x * PN_BF_WAVES >= n_tiles) return;  // no tile for any wave of this block
     for (int i = threadIdx.x; i < PN_NET_SPLIT_BYTES / 16; i += PN_BF_WAVES * 64) wimg[i] = wsplit[i];
+    if (threadIdx.x < 16 * sizeof(PnFusedLevel) / 16) wimg[PN_NET_SPLIT_BYTES / 16 + threadIdx.x] = reinterpret_cast<const uint4*>(lv)[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int s = lane & 31, half = lane >> 5;
     const uint4* __restrict__ wl = wimg + lane;
+    const PnFusedLevel* lds_lv = reinterpret_cast<const PnFusedLevel*>(wimg + PN_NET_SPLIT_BYTES / 16) + 8 * half;
 
     for (uint32_t tile = wave; tile < n_tiles; tile += waves_total) {
         const uint32_t li = tile * 32 + s;
@@ -600,7 +690,7 @@ __global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const P
         const float u0 = (x + bound) / (2 * bound), u1 = (y + bound) / (2 * bound), u2 = (z + bound) / (2 * bound);
         const bool oob = (u0 < 0 || u0 > 1 || u1 < 0 || u1 > 1 || u2 < 0 || u2 > 1);
         float feat[16];
-        encode8<LU>(lv, emb, half, oob ? 0.f : u0, oob ? 0.f : u1, oob ? 0.f : u2, oob, feat);
+        encode8<LU>(lv, lds_lv, emb, half, oob ? 0.f : u0, oob ? 0.f : u1, oob ? 0.f : u2, oob, feat);
         __builtin_amdgcn_sched_barrier(0);  // keep the next layer's LDS weight reads from being hoisted (register pressure)
         // ---- sigma net layer 0: 32 -> 64, ReLU   (groups 0..3 = tile*2 + chunk)
         f32x16 a0 = {0}, a1 = {0};
@@ -725,15 +815,25 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // allocator serialised them behind spills.
 typedef int pn_rsrc_t __attribute__((ext_vector_type(4)));
 template <int J0, int NJ>
-__device__ __forceinline__ void encode_levels_h(const PnFusedLevel* __restrict__ lv, __amdgpu_buffer_rsrc_t emb_rsrc, int half, float u0, float u1,
-                                                float u2, bool oob, _Float16* feat) {
+__device__ __forceinline__ void encode_levels_h(const PnFusedLevel* __restrict__ lv, const PnFusedLevel* lds_lv, __amdgpu_buffer_rsrc_t emb_rsrc, int half,
+                                                float u0, float u1, float u2, bool oob, _Float16* feat) {
 #pragma unroll
     for (int j = J0; j < J0 + NJ; j++) {
+#if PN_ENC_LDS_LV
+        const PnFusedLevel L = lds_lv[j];  // this lane half's level j (see encode8)
+#else
         const PnFusedLevel A = lv[j], B = lv[j + 8];  // wave-uniform
-        const float scale = half ? B.scale : A.scale;
-        const uint32_t m1 = half ? B.m1 : A.m1, m2 = half ? B.m2 : A.m2, mask = half ? B.mask : A.mask;
-        const bool dense = (half ? B.dense : A.dense) != 0;
-        const uint32_t base = half ? B.offset : A.offset;  // entries before this level
+        PnFusedLevel L;
+        L.scale = half ? B.scale : A.scale;
+        L.offset = half ? B.offset : A.offset;
+        L.m1 = half ? B.m1 : A.m1; L.m2 = half ? B.m2 : A.m2; L.mask = half ? B.mask : A.mask;
+        L.dense = half ? B.dense : A.dense;
+        L.dm = half ? B.dm : A.dm; L.xm = half ? B.xm : A.xm;
+#endif
+        const float scale = L.scale;
+        const uint32_t m1 = L.m1, m2 = L.m2, mask = L.mask;
+        const bool dense = L.dense != 0;
+        const uint32_t base = L.offset;  // entries before this level
         float p0 = fmaf(u0, scale, 0.5f), p1 = fmaf(u1, scale, 0.5f), p2 = fmaf(u2, scale, 0.5f);
         const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
         p0 -= f0; p1 -= f1; p2 -= f2;
@@ -741,19 +841,44 @@ __device__ __forceinline__ void encode_levels_h(const PnFusedLevel* __restrict__
         const uint32_t t1a = (uint32_t)f1 * m1, t2a = (uint32_t)f2 * m2;
         const uint32_t t1[2] = {t1a, t1a + m1}, t2[2] = {t2a, t2a + m2};
         uint32_t v[8];
+#if PN_ENC_UNIFIED
+        const uint32_t dm = L.dm, M = L.xm;  // see encode_level
+        uint32_t S[4], X[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            S[c] = (t1[c & 1] + t2[c >> 1]) & dm;
+            X[c] = (t1[c & 1] ^ t2[c >> 1]) & ~dm;
+        }
+#pragma unroll
+        for (int idx = 0; idx < 8; idx++) {
+            const uint32_t index = ((t0[idx & 1] + S[idx >> 1]) ^ X[idx >> 1]) & M;
+            v[idx] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(emb_rsrc, (int)((base + index) << 2), 0, 0);
+        }
+#else
 #pragma unroll
         for (int idx = 0; idx < 8; idx++) {
             const uint32_t a0 = t0[idx & 1], a1 = t1[(idx >> 1) & 1], a2 = t2[(idx >> 2) & 1];
             const uint32_t index = dense ? (a0 + a1 + a2) : ((a0 ^ a1 ^ a2) & mask);
             v[idx] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(emb_rsrc, (int)((base + index) << 2), 0, 0);
         }
+#endif
         _Float16 r0 = (_Float16)0.0f, r1 = (_Float16)0.0f;
+#if PN_ENC_PK
+        const f32x2 q0 = {1 - p0, p0};
+        const float n1 = 1 - p1, n2 = 1 - p2;
+        const f32x2 qa = q0 * n1, qb = q0 * p1;
+        const f32x2 w2[4] = {qa * n2, qb * n2, qa * p2, qb * p2};  // ((1 * tx) * ty) * tz, two corners per v_pk_mul_f32
+#endif
 #pragma unroll
         for (int idx = 0; idx < 8; idx++) {
+#if PN_ENC_PK
+            const float w = (idx & 1) ? w2[idx >> 1].y : w2[idx >> 1].x;
+#else
             float w = 1;
             w *= (idx & 1) ? p0 : 1 - p0;
             w *= (idx & 2) ? p1 : 1 - p1;
             w *= (idx & 4) ? p2 : 1 - p2;
+#endif
             const f16x2 e = __builtin_bit_cast(f16x2, v[idx]);
             r0 = r0 + half_of_product(w, e[0]);  // Half(float * Half) then Half + Half, gridencoder.cu:184
             r1 = r1 + half_of_product(w, e[1]);
@@ -764,23 +889,23 @@ __device__ __forceinline__ void encode_levels_h(const PnFusedLevel* __restrict__
 }
 // 8 hash levels of one lane, LU levels' gathers (8 x LU dword loads) in flight at a time
 template <int LU>
-__device__ __forceinline__ void encode8_h(const PnFusedLevel* __restrict__ lv, __amdgpu_buffer_rsrc_t emb_h, int half, float u0, float u1,
+__device__ __forceinline__ void encode8_h(const PnFusedLevel* __restrict__ lv, const PnFusedLevel* lds_lv, __amdgpu_buffer_rsrc_t emb_h, int half, float u0, float u1,
                                           float u2, bool oob, _Float16* feat) {
     static_assert(LU == 2 || LU == 4 || LU == 8, "LU");
-    if (LU == 8) { encode_levels_h<0, 8>(lv, emb_h, half, u0, u1, u2, oob, feat); return; }
+    if (LU == 8) { encode_levels_h<0, 8>(lv, lds_lv, emb_h, half, u0, u1, u2, oob, feat); return; }
     if (LU == 4) {
-        encode_levels_h<0, 4>(lv, emb_h, half, u0, u1, u2, oob, feat);
+        encode_levels_h<0, 4>(lv, lds_lv, emb_h, half, u0, u1, u2, oob, feat);
         __builtin_amdgcn_sched_barrier(0);
-        encode_levels_h<4, 4>(lv, emb_h, half, u0, u1, u2, oob, feat);
+        encode_levels_h<4, 4>(lv, lds_lv, emb_h, half, u0, u1, u2, oob, feat);
         return;
     }
-    encode_levels_h<0, 2>(lv, emb_h, half, u0, u1, u2, oob, feat);
+    encode_levels_h<0, 2>(lv, lds_lv, emb_h, half, u0, u1, u2, oob, feat);
     __builtin_amdgcn_sched_barrier(0);
-    encode_levels_h<2, 2>(lv, emb_h, half, u0, u1, u2, oob, feat);
+    encode_levels_h<2, 2>(lv, lds_lv, emb_h, half, u0, u1, u2, oob, feat);
     __builtin_amdgcn_sched_barrier(0);
-    encode_levels_h<4, 2>(lv, emb_h, half, u0, u1, u2, oob, feat);
+    encode_levels_h<4, 2>(lv, lds_lv, emb_h, half, u0, u1, u2, oob, feat);
     __builtin_amdgcn_sched_barrier(0);
-    encode_levels_h<6, 2>(lv, emb_h, half, u0, u1, u2, oob, feat);
+    encode_levels_h<6, 2>(lv, lds_lv, emb_h, half, u0, u1, u2, oob, feat);
 }
 
 // fp32 accumulators of one layer -> that layer's half output, optionally through ReLU, as the next layer's B operands
@@ -812,6 +937,7 @@ __global__ void __launch_bounds__(PN_H_WAVES * 64, MINW) k_nerf_forward_h(const 
     const uint32_t wave = blockIdx.x * PN_H_WAVES + (threadIdx.x >> 6);
     if (blockIdx.x * PN_H_WAVES >= n_tiles) return;
     for (int i = threadIdx.x; i < PN_NET_HALF_BYTES / 16; i += PN_H_WAVES * 64) wimg[i] = whalf[i];
+    if (threadIdx.x < 16 * sizeof(PnFusedLevel) / 16) wimg[PN_NET_HALF_BYTES / 16 + threadIdx.x] = reinterpret_cast<const uint4*>(lv)[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int s = lane & 31, half = lane >> 5;
@@ -848,7 +974,7 @@ __global__ void __launch_bounds__(PN_H_WAVES * 64, MINW) k_nerf_forward_h(const 
         // inside the loop (48 v_cndmask per 32 samples)
         int half_t = half;
         asm volatile("" : "+v"(half_t));
-        encode8_h<LU>(lv, emb_rsrc, half_t, oob ? 0.f : u0, oob ? 0.f : u1, oob ? 0.f : u2, oob, feat);
+        encode8_h<LU>(lv, reinterpret_cast<const PnFusedLevel*>(wimg + PN_NET_HALF_BYTES / 16) + 8 * half_t, emb_rsrc, half_t, oob ? 0.f : u0, oob ? 0.f : u1, oob ? 0.f : u2, oob, feat);
         __builtin_amdgcn_sched_barrier(0);
         // ---- sigma net layer 0: 32 -> 64, ReLU
         f32x16 a0 = zero16(), a1 = zero16();
@@ -959,7 +1085,7 @@ int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* di
         static const uint32_t max_blocks_h = pn_env_u32("PN_NERF_BLOCKS_H", 1024);  // 4 workgroups per CU
         uint32_t blocks = std::min(pn_div_up(tiles, PN_H_WAVES), max_blocks_h);
         if (blocks_cap) blocks = std::min(blocks, blocks_cap);
-        k_nerf_forward_h<4, 4><<<blocks, PN_H_WAVES * 64, PN_NET_HALF_BYTES, stream>>>((const PnFusedLevel*)net->fused_levels, (const uint32_t*)net->emb_half,
+        k_nerf_forward_h<4, 4><<<blocks, PN_H_WAVES * 64, PN_NET_HALF_BYTES + 16 * sizeof(PnFusedLevel), stream>>>((const PnFusedLevel*)net->fused_levels, (const uint32_t*)net->emb_half,
                                                                                      (const uint4*)net->whalf, net->bound, xyzs, dirs, list, ctl_count,
                                                                                      M_max, density_scale, sigmas, rgbs, nullptr, net->n_entries * 4u, 0);
         PN_LAUNCH_CHECK();
@@ -969,7 +1095,7 @@ int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* di
     uint32_t blocks = pn_div_up(tiles, PN_BF_WAVES);
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks_cap) blocks = std::min(blocks, blocks_cap);
-    k_nerf_forward<2, 4><<<blocks, PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES, stream>>>((const PnFusedLevel*)net->fused_levels, net->embeddings,
+    k_nerf_forward<2, PN_BF_LU><<<blocks, PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES + 16 * sizeof(PnFusedLevel), stream>>>((const PnFusedLevel*)net->fused_levels, net->embeddings,
                                                                                   (const uint4*)net->wsplit, net->bound, xyzs, dirs, list, ctl_count,
                                                                                   M_max, density_scale, sigmas, rgbs, nullptr, 0);
     PN_LAUNCH_CHECK();
@@ -982,11 +1108,11 @@ static int density_launch(const pn_net* net, const float* xyzs, uint32_t M, floa
     // dirs is only read by the colour net, which this mode never reaches: any readable buffer of >= 3 M floats will do
     if (half) {
         PN_REQUIRE(net->emb_half);
-        k_nerf_forward_h<4, 4><<<std::min(pn_div_up(tiles, PN_H_WAVES), 1024u), PN_H_WAVES * 64, PN_NET_HALF_BYTES, st>>>(
+        k_nerf_forward_h<4, 4><<<std::min(pn_div_up(tiles, PN_H_WAVES), 1024u), PN_H_WAVES * 64, PN_NET_HALF_BYTES + 16 * sizeof(PnFusedLevel), st>>>(
             (const PnFusedLevel*)net->fused_levels, (const uint32_t*)net->emb_half, (const uint4*)net->whalf, net->bound, xyzs, xyzs, nullptr, nullptr, M, scale,
             sigmas, nullptr, geo_feat, net->n_entries * 4u, sigma_only);
     } else {
-        k_nerf_forward<2, 4><<<std::min(pn_div_up(tiles, PN_BF_WAVES), 2048u / PN_BF_WAVES), PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES, st>>>(
+        k_nerf_forward<2, PN_BF_LU><<<std::min(pn_div_up(tiles, PN_BF_WAVES), 2048u / PN_BF_WAVES), PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES + 16 * sizeof(PnFusedLevel), st>>>(
             (const PnFusedLevel*)net->fused_levels, net->embeddings, (const uint4*)net->wsplit, net->bound, xyzs, xyzs, nullptr, nullptr, M, scale, sigmas,
             nullptr, geo_feat, sigma_only);
     }
