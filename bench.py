@@ -442,7 +442,8 @@ def main():
             args.trips = h._pipe_backend.trips
             run_steps = lambda n: [h.step_pipelined() for _ in range(n)]
             launch = (f"hip graphs, {args.trips} trips, {args.lanes} render streams x {args.depth} workspaces, "
-                      + ("first trip's march pass 1 in its throughput form (one lane per ray, 64 rounds; pn_render_opts.throughput), " if args.lanes > 1 else "")
+                      + (f"march pass 1 of the first {h._pipe_backend.kw.get('march_throughput_trips', 1)} trip(s) in its throughput form (one lane per ray, "
+                         f"{h._pipe_backend.kw.get('march_throughput')} rounds; pn_render_opts.throughput / throughput_trips), " if args.lanes > 1 else "")
                       + "simulator running ahead, D2H on "
                       + {"copy": "a copy stream", "lane": "the frame's render stream", "sim": "the simulator stream", "host": "no stream (copier thread + SDMA through the HSA runtime)"}[args.copy_on]
                       + (f"; rays in batches of {opt['ray_batch']} with per-batch trip schedules (max_ray_batch), all batches in the same launches" if staged else ""))

@@ -231,6 +231,10 @@ typedef struct {
                              per visited point, bit-identical samples, a longer first trip (~7 us per round).  For pipelines that keep several frames in
                              flight (harness.capture_pipelined with more than one lane: +8 % steps/s on the chair, +13 % on configs[4]); 0: the latency
                              form.  Deformed render only. */
+    int throughput_trips; /* with throughput > 0: how many leading trips of the frame march in that form (0 or 1: the first trip only).  Worth it for a
+                             trip that still has rays enough to fill the GPU with one lane each (>= ~128 k alive: the second trip of the trex option
+                             set, 246 k rays x 3 samples: +11 % steps/s); a trip of few rays with 8 samples each is faster in the windows.  The
+                             results do not depend on it.  harness.capture_pipelined picks it from the trip records of its warm-up frame. */
 } pn_render_opts;
 int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_vtx, uint32_t max_grid_cells);
 void pn_frame_destroy(pn_frame* f);

@@ -1982,6 +1982,8 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     // a frame's first trip with ONE lane per ray in pass 1 (k_march<.., 1>) for this many rounds = visited points before a ray goes to the windows
     static const uint32_t lpr_env = pn_env_u32("PN_MARCH_LPR", 0);
     const uint32_t lpr_rounds = lpr_env ? lpr_env : (o->throughput > 0 ? (uint32_t)o->throughput : 0u);  // (PN_MARCH_LPR: experiments)
+    static const uint32_t lpr_trips_env = pn_env_u32("PN_MARCH_LPR_TRIPS", 0);  // experiments
+    const uint32_t lpr_trips = lpr_trips_env ? lpr_trips_env : (uint32_t)std::max(o->throughput_trips, 1);  // leading trips in that form
     static const bool split_compact = pn_env_u32("PN_SPLIT_COMPACT", 0) != 0;  // experiments: composite and compaction as two launches (rounds 1-2)
     static const uint32_t tail_grid_cfg = pn_env_u32("PN_TAIL_GRID", 1024);  // x4 waves, one unfinished ray per wave at a time
     const uint32_t tail_grid = std::max(std::min(pn_div_up(N, 4), tail_grid_cfg), (uint32_t)PN_SEGS / 4);  // every tail segment needs a wave
@@ -2089,11 +2091,11 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             int* seg_active = seg_back + PN_SEGS * PN_SEG_STRIDE;
             // trip 0 keeps its skip pre-pass state in f->sigmas (t_resume) and lists the slots worth marching in f->active_seg
             MarchIO io{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + t, f->list, (t == 0) ? f->sigmas : nullptr,
-                       f->tail, seg_tail, seg_back, seg_curs, (int)f->seg_cap, (t == 0 && lpr_rounds > 0) ? (int)lpr_rounds : (int)march_tail_rounds(t),
+                       f->tail, seg_tail, seg_back, seg_curs, (int)f->seg_cap, ((uint32_t)t < lpr_trips && lpr_rounds > 0) ? (int)lpr_rounds : (int)march_tail_rounds(t),
                        (t == 0) ? f->active_seg : nullptr, (t == 0) ? seg_active : nullptr,
                        (int)f->seg_cap, f->list_seg, seg_samp, (int)f->seg_cap, seg_emit, f->cell_bits, skip_bits_words,
                        short_rays ? f->cell_bits + bit_words : nullptr, short_rays ? f->fars_eff : nullptr,
-                       group_rays ? f->groups + (size_t)(t & 1) * f->max_groups : nullptr, group_rays, (t == 0 && lpr_rounds > 0) ? 1 : 0, dda_start,
+                       group_rays ? f->groups + (size_t)(t & 1) * f->max_groups : nullptr, group_rays, ((uint32_t)t < lpr_trips && lpr_rounds > 0) ? 1 : 0, dda_start,
                        (int)skip_hop_budget};
             const bool timed = (f->march_counters_on & 2) && t < PN_TIMED_TRIPS;
             bool stamp = false;

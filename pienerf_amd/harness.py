@@ -38,6 +38,10 @@ def _capture(graph, **kw):
             gc.enable()
 
 
+# pn_render_opts.throughput_trips: a trip marches in the throughput form (one lane per ray) when it has at least this many alive rays — 2048 waves,
+# two per SIMD (measured: trex option set, second trip of 246 k rays: 1 191 -> 1 321 steps/s; chair, second trip of 41 k rays: 1 650 -> 1 480)
+THROUGHPUT_FORM_MIN_RAYS = 131072
+
 class SimRenderHarness:
     def __init__(self, opt=None, cloud=None, ckpt=None, device="cuda", overlap_sim=True):
         self.opt = dict(opt or scene.default_opt())
@@ -450,6 +454,16 @@ class _HipBackend:
                     with h._amp():
                         m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **dict(kw, frame_slot=ws))
             torch.cuda.synchronize(dev)
+            if ws == 0 and kw.get("march_throughput") and "march_throughput_trips" not in kw:
+                # the throughput form for every leading trip that still has rays enough to fill the GPU with ONE lane per ray (the trex option set's
+                # second trip: 246 k rays x 3 samples; the chair's: 41 k x 8, faster in the windows) — from this warm-up frame's trip records; the
+                # samples do not depend on the form, so a scene that changes later only loses speed
+                n_lpr = 1
+                for rec in m.trip_records(slot=0)[1:]:
+                    if rec[0] < THROUGHPUT_FORM_MIN_RAYS:
+                        break
+                    n_lpr += 1
+                kw["march_throughput_trips"] = n_lpr
         # capture_error_mode="thread_local": with a process group alive, RCCL's watchdog thread queries events while we capture;
         # in the default "global" mode any HIP call from another thread invalidates the capture
         self.sim_graph = torch.cuda.CUDAGraph()

@@ -110,6 +110,7 @@ class NeRFRenderer(nn.Module):
         o.reuse_tables = int(bool(kwargs.get("reuse_tables")))  # extension: later ray batches of the same frame keep the first batch's tables
         o.ray_batch = int(kwargs.get("ray_batch") or 0)  # extension: per-batch trip schedules inside one set of launches (pn_render_opts.ray_batch)
         o.throughput = int(kwargs.get("march_throughput") or 0)  # extension: one lane per ray in the first trip's pass 1 (pn_render_opts.throughput)
+        o.throughput_trips = int(kwargs.get("march_throughput_trips") or 0)  # ... and in this many leading trips (0: the first only)
         return o
 
     def rund_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-2, **kwargs):

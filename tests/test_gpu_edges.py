@@ -211,13 +211,15 @@ def test_frame_independent_of_the_first_trip_form(deformed_ip_state, small_opt, 
     net = _net(ckpt, deformed_ip_state)
     res = []
     with torch.no_grad():
-        for thr in (0, rounds):
-            out = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **dict(opt, march_throughput=thr))
+        for thr, trips in ((0, 0), (rounds, 0), (rounds, 3)):  # the latency form; the first trip; the first three trips (throughput_trips)
+            out = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **dict(opt, march_throughput=thr, march_throughput_trips=trips))
             res.append((dict(net.last_stats), out["image"].clone(), out["depth"].clone(), out["depth_0"].clone()))
-    (s0, i0, d0, e0), (s1, i1, d1, e1) = res
-    assert s0["samples"] == s1["samples"] > 1000 and s0["trips"] == s1["trips"] and s0["err"] == s1["err"] == 0
-    assert torch.equal(i0, i1) and torch.equal(e0, e1)
-    assert torch.equal(torch.nan_to_num(d0, nan=-1.0), torch.nan_to_num(d1, nan=-1.0))
+    (s0, i0, d0, e0) = res[0]
+    assert s0["trips"] >= 3
+    for s1, i1, d1, e1 in res[1:]:
+        assert s0["samples"] == s1["samples"] > 1000 and s0["trips"] == s1["trips"] and s0["err"] == s1["err"] == 0
+        assert torch.equal(i0, i1) and torch.equal(e0, e1)
+        assert torch.equal(torch.nan_to_num(d0, nan=-1.0), torch.nan_to_num(d1, nan=-1.0))
 
 
 _FRAME_HASH_SCRIPT = r"""

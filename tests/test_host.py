@@ -71,11 +71,14 @@ def test_no_mfma_overwrites_its_own_sources(tmp_path):
     assert n >= 120  # the fused network kernel alone carries 120
 
 
-def test_no_packed_fp32_valu_in_mfma_kernels(tmp_path):
-    """Kernels that issue MFMAs carry no packed-fp32 VALU (v_pk_{mul,add,fma}_f32): beside an MFMA chain each one costs ~20 extra cycles
-    (MI355X_MICROARCH.md, "price of one filler beside MFMAs"), and -O3's SLP vectoriser inserts them on its own — hence -fno-slp-vectorize
-    (pienerf_amd/build.py).  Round 1 also blamed them for corrupted MFMA results; tools/repro_pk_mfma.hip did not reproduce that
-    (profiles/r02_repro_pk_mfma.json: 0 wrong of 819 M MFMAs), so this is a performance rule, not an erratum workaround."""
+def test_no_packed_fp32_valu_beside_mfma_chains(tmp_path):
+    """No packed-fp32 VALU (v_pk_{mul,add,fma}_f32) among the MFMAs of a kernel: beside an MFMA chain each one costs ~20 extra cycles
+    (MI355X_MICROARCH.md, "price of one filler beside MFMAs"; measured here too: the bf16 split's subtractions as v_pk_add_f32 made
+    k_nerf_forward 1.5 % slower), and -O3's SLP vectoriser inserts them on its own — hence -fno-slp-vectorize (pienerf_amd/build.py).
+    The network kernels' hash-grid phase, fenced from the layers by scheduling barriers, does use them (corner weights and channel sums:
+    2 % faster) — so the rule is about distance: no packed op within 12 instructions of an MFMA.  Round 1 also blamed packed ops for
+    corrupted MFMA results; tools/repro_pk_mfma.hip did not reproduce that (profiles/r02_repro_pk_mfma.json: 0 wrong of 819 M MFMAs), so
+    this is a performance rule, not an erratum workaround."""
     import shutil
     import subprocess
     from pienerf_amd import _lib
@@ -94,8 +97,12 @@ def test_no_packed_fp32_valu_in_mfma_kernels(tmp_path):
             if "v_mfma_" not in body:
                 continue
             n_mfma_kernels += 1
-            bad = [ln.strip() for ln in body.splitlines() if re.search(r"\bv_pk_(mul|add|fma)_f32\b", ln)]
-            assert not bad, (body.splitlines()[0], bad[:5])
+            lines = body.splitlines()
+            mfma = [i for i, ln in enumerate(lines) if "v_mfma_" in ln]
+            for i, ln in enumerate(lines):
+                if re.search(r"\bv_pk_(mul|add|fma)_f32\b", ln):
+                    near = min(abs(i - j) for j in mfma)
+                    assert near > 12, (lines[0], ln.strip(), near)
     assert n_mfma_kernels >= 2
 
 
