@@ -121,16 +121,17 @@ def test_full_frame_independent_of_the_first_trip_form(full):
     m = h.model
     res = []
     with torch.no_grad():
-        for thr in (0, 64):
+        for thr, trips in ((0, 0), (64, 0), (64, 3)):  # latency form; first trip (the chair's pipelined form); three trips (throughput_trips)
             rays = {k: full["out"][k] for k in ("rays_o", "rays_d")}
             out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, collect_stats=True,
-                                    **dict(h.render_kwargs(), march_throughput=thr))
+                                    **dict(h.render_kwargs(), march_throughput=thr, march_throughput_trips=trips))
             res.append((dict(m.last_stats), m.trip_records(), {k: out[k].clone() for k in ("image", "depth", "depth_0")}))
-    (s0, r0, o0), (s1, r1, o1) = res
-    assert s0["samples"] == s1["samples"] > 5e5 and s0["trips"] == s1["trips"] and s0["err"] == s1["err"] == 0
-    assert [r[:5] for r in r0] == [r[:5] for r in r1]
-    for k in o0:
-        assert torch.equal(torch.nan_to_num(o0[k], nan=-1.0), torch.nan_to_num(o1[k], nan=-1.0)), k
+    s0, r0, o0 = res[0]
+    for s1, r1, o1 in res[1:]:
+        assert s0["samples"] == s1["samples"] > 5e5 and s0["trips"] == s1["trips"] and s0["err"] == s1["err"] == 0
+        assert [r[:5] for r in r0] == [r[:5] for r in r1]
+        for k in o0:
+            assert torch.equal(torch.nan_to_num(o0[k], nan=-1.0), torch.nan_to_num(o1[k], nan=-1.0)), k
 
 
 def test_strided_subset_of_the_full_frame_matches_the_oracle(full):
@@ -291,6 +292,16 @@ def test_trex_configuration_full_size():
     assert ws.min() >= 0.0 and ws.max() <= 1.0 + 1e-5 and np.abs(ws - ref["weights_sum"]).max() < 1e-4
     full_img = out["image"].reshape(N, 3)
     assert float(full_img.min()) >= 0.0 and float(full_img.max()) <= 1.0 + 1e-5
+    # two trips with one lane per ray (pn_render_opts.throughput / throughput_trips: what the pipelined harness picks when a later trip still has
+    # >= 128 k alive rays, as with bench.py's static background) — the same trip records and pixels as the latency form above, bit for bit
+    rec0 = m.trip_records()
+    assert len(rec0) >= 2 and rec0[1][0] > 10000
+    with torch.no_grad():
+        thr = m.render_deformed(out["rays_o"], out["rays_d"], staged=True, bg_color=None, perturb=False, collect_stats=True,
+                                **dict(h.render_kwargs(), march_throughput=64, march_throughput_trips=2))
+    assert dict(m.last_stats)["samples"] == st["samples"] and [r[:5] for r in m.trip_records()] == [r[:5] for r in rec0]
+    for k in ("image", "depth", "depth_0"):
+        assert torch.equal(torch.nan_to_num(thr[k].reshape(-1), nan=-1.0), torch.nan_to_num(out[k].reshape(-1), nan=-1.0)), k
 
 
 def test_full_kernel_grid_scene():
