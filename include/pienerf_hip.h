@@ -235,6 +235,14 @@ typedef struct {
                              trip that still has rays enough to fill the GPU with one lane each (>= ~128 k alive: the second trip of the trex option
                              set, 246 k rays x 3 samples: +11 % steps/s); a trip of few rays with 8 samples each is faster in the windows.  The
                              results do not depend on it.  harness.capture_pipelined picks it from the trip records of its warm-up frame. */
+    int ray_tile_w;       /* > 0: the N rays are the row-major pixels of an image this wide (get_rays, nerf/utils.py:65-147 with error_map None).  The
+                             frame then walks them in 16 x 4 pixel tiles instead of runs of 64 pixels of a row: rays_alive starts as that permutation
+                             of arange(N) (renderer.py:828) and every later list inherits the order, so the 64 rays that share a wave march about
+                             equally long and fewer waves hold a silhouette ray (chair: skip pre-pass -17 %, tail pass -6 %, one-lane pass -10 %;
+                             the network kernel's gathers share fewer lines, +2 %; +4 % steps/s).  Per-ray results do not depend on the order of
+                             the alive list (each ray's samples, its composite and its pixel are its own); ignored unless ray_tile_w % 16 == 0 and
+                             N % (4 * ray_tile_w) == 0, with ray_batch > 0 (whose batches are contiguous runs of a sorted alive list) and by
+                             pn_render_static. */
 } pn_render_opts;
 int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_vtx, uint32_t max_grid_cells);
 void pn_frame_destroy(pn_frame* f);

@@ -1718,6 +1718,7 @@ struct FramePrologue {
     const float* rays_o; const float* rays_d; PnFrameDev* dev; uint32_t N; float min_near; float* nears; float* fars; float* rays_t; PnTrip* trips;
     int* tail_counts; int* seg_counters; int n_trip_records; int* alive; float* weights_sum; float* depth_0; float* image; PnGroup* groups;
     int* group_cnt; uint32_t group_rays; uint32_t n_groups; int* chunk_words;
+    uint32_t tile_w, tile_lw;  // tile_w > 0: alive list starts in 16 x 4 pixel tile order (pn_render_opts.ray_tile_w, validated by the host)
 };
 
 __device__ __forceinline__ void frame_lists_block(const FramePrologue& a) {
@@ -1860,7 +1861,14 @@ __device__ __forceinline__ void frame_rays_block(const FramePrologue& a, uint32_
     a.nears[n] = near;
     a.fars[n] = far;
     a.rays_t[n] = near;  // rays_t = nears.clone() (renderer.py:829)
-    a.alive[n] = (int)n;
+    // rays_alive = arange(N) (renderer.py:828) — or, for a whole image, the same set in 16 x 4 pixel tiles: slot n = pixel (n & 15, (n >> 4) & 3) of
+    // tile n / 64 (tiles row-major).  A wave's 64 slots are then a tile, and every later alive list (stable compaction) keeps that order
+    uint32_t ray = n;
+    if (a.tile_w) {
+        const uint32_t lw = a.tile_lw, tile = n >> 6, in = n & 63u, tiles_x = a.tile_w >> lw;  // tile of (1 << lw) x (64 >> lw) pixels, lw = 4
+        ray = ((tile / tiles_x) * (64u >> lw) + (in >> lw)) * a.tile_w + ((tile % tiles_x) << lw) + (in & ((1u << lw) - 1u));
+    }
+    a.alive[n] = (int)ray;
     a.weights_sum[n] = 0.f;
     a.depth_0[n] = 0.f;
     a.image[n * 3] = 0.f; a.image[n * 3 + 1] = 0.f; a.image[n * 3 + 2] = 0.f;
@@ -2053,6 +2061,13 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     fp.trips = f->trips; fp.tail_counts = f->tail_counts; fp.seg_counters = f->seg_counters; fp.n_trip_records = PN_MAX_TRIPS + 2; fp.alive = f->alive_a;
     fp.weights_sum = weights_sum; fp.depth_0 = depth_0; fp.image = f->acc_image; fp.groups = group_rays ? f->groups : nullptr; fp.group_cnt = f->group_cnt;
     fp.group_rays = group_rays; fp.n_groups = n_groups; fp.chunk_words = f->chunk_counts;
+    {   // pn_render_opts.ray_tile_w; PN_RAY_TILE_OFF=1 keeps the row-major order (A/B runs: same frames, bit for bit)
+        static const bool tile_off = pn_env_u32("PN_RAY_TILE_OFF", 0) != 0;
+        static const uint32_t lw = std::min(pn_env_u32("PN_RAY_TILE_LOG2W", 4), 5u);  // experiments: 8 x 8 (3), 32 x 2 (5) pixel tiles
+        const uint32_t tw = o->ray_tile_w > 0 ? (uint32_t)o->ray_tile_w : 0u;
+        fp.tile_lw = lw;
+        fp.tile_w = (!tile_off && !is_static && !group_rays && tw && tw % (1u << lw) == 0 && N % ((64u >> lw) * tw) == 0) ? tw : 0u;
+    }
     // both cell maps of a workgroup in LDS while it builds its lists (up to 64 KB = 262 k cells; beyond that straight to global memory, where
     // the maps then span enough cache lines for the atomics not to queue)
     fp.lds_words = (fp.list_blocks > 0 && bit_words * 8 <= 64 * 1024) ? (int)bit_words : 0;

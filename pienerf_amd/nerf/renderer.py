@@ -87,7 +87,7 @@ class NeRFRenderer(nn.Module):
         return self._frames[slot][0]
 
     # ------------------------------------------------------------------ fused loop
-    def _deformed_opts(self, dt_gamma, bg_scalar, max_steps, T_thresh, kwargs):
+    def _deformed_opts(self, dt_gamma, bg_scalar, max_steps, T_thresh, kwargs, n_rays=0):
         o = RenderOpts()
         o.max_iter_num = int(kwargs.get("max_iter_num"))
         o.hash_grid_size = float(kwargs.get("hash_grid_size"))
@@ -111,6 +111,12 @@ class NeRFRenderer(nn.Module):
         o.ray_batch = int(kwargs.get("ray_batch") or 0)  # extension: per-batch trip schedules inside one set of launches (pn_render_opts.ray_batch)
         o.throughput = int(kwargs.get("march_throughput") or 0)  # extension: one lane per ray in the first trip's pass 1 (pn_render_opts.throughput)
         o.throughput_trips = int(kwargs.get("march_throughput_trips") or 0)  # ... and in this many leading trips (0: the first only)
+        # extension: walk a whole image's rays in 16 x 4 pixel tiles (pn_render_opts.ray_tile_w; results do not depend on it).  The reference hands
+        # **vars(opt) to the renderer (trainer.py:318), so W / H arrive by name; only a ray set of exactly W * H rays is taken for the image
+        tw = kwargs.get("ray_tile_w")
+        if tw is None and n_rays and kwargs.get("W") and kwargs.get("H") and int(kwargs["W"]) * int(kwargs["H"]) == n_rays:
+            tw = kwargs["W"]
+        o.ray_tile_w = int(tw or 0)
         return o
 
     def rund_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-2, **kwargs):
@@ -131,7 +137,7 @@ class NeRFRenderer(nn.Module):
         p_def, p_ori, F_IP, dF_IP = self._ip_state(device)
         assert p_def.shape == p_ori.shape and p_ori.shape[0] > 0  # renderer.py:816-817
         n_vtx = p_ori.shape[0]
-        o = self._deformed_opts(dt_gamma, 0.0 if bg_tensor is not None else bg_color, max_steps, T_thresh, kwargs)
+        o = self._deformed_opts(dt_gamma, 0.0 if bg_tensor is not None else bg_color, max_steps, T_thresh, kwargs, n_rays=N)
         ob = kwargs.get("out_buffers")  # extension: caller-owned outputs (the frame pipeline packs image | depth | depth_0 into one buffer -> one D2H)
         if ob is not None:
             image, depth, depth_0, weights_sum = ob["image"], ob["depth"], ob["depth_0"], ob["weights_sum"]
@@ -175,7 +181,7 @@ class NeRFRenderer(nn.Module):
             o.cascade, o.grid_size, o.density_scale, o.bg_color = int(self.cascade), int(self.grid_size), float(self.density_scale), float(1 if bg_color is None else bg_color)
             o.fp16 = int(self._autocast_half())
         else:
-            o = self._deformed_opts(dt_gamma, 1 if bg_color is None else bg_color, max_steps, T_thresh, kwargs)
+            o = self._deformed_opts(dt_gamma, 1 if bg_color is None else bg_color, max_steps, T_thresh, kwargs, n_rays=N)
         image, depth, ws = out["image"].view(-1, 3), out["depth"].view(-1), out["weights_sum"].view(-1)
         depth_0 = out["depth_0"].view(-1) if "depth_0" in out else torch.empty_like(depth)
         assert image.is_contiguous() and image.shape[0] == N

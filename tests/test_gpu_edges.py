@@ -222,6 +222,28 @@ def test_frame_independent_of_the_first_trip_form(deformed_ip_state, small_opt, 
         assert torch.equal(torch.nan_to_num(d0, nan=-1.0), torch.nan_to_num(d1, nan=-1.0))
 
 
+@pytest.mark.parametrize("W,H", [(96, 96), (112, 72), (100, 96), (96, 98)])
+def test_frame_independent_of_the_ray_tile_order(deformed_ip_state, small_opt, ckpt, W, H):
+    """pn_render_opts.ray_tile_w: the alive list of a whole image starts in 16 x 4 pixel tiles instead of arange(N) (renderer.py:828).  Every ray's
+    samples, composite and pixel are its own, so the frame is the same bit for bit — latency and throughput form, with trips enough that the
+    compacted lists of later trips inherit the order.  Widths that are not multiples of 16 / heights that are not multiples of 4 keep the row-major order (same frame, trivially)."""
+    o, d = oracle.get_rays(scene.orbit_pose(3.0, 35.0, -25.0), scene.orbit_intrinsics(W, H, 50.0), H, W)
+    net = _net(ckpt, deformed_ip_state)
+    opt = {k: v for k, v in small_opt.items() if k not in ("W", "H")}
+    res = []
+    with torch.no_grad():
+        for tile_w, thr in ((0, 0), (W, 0), (W, 64), (0, 64)):
+            out = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **dict(opt, ray_tile_w=tile_w, march_throughput=thr))
+            res.append((dict(net.last_stats), out["image"].clone(), out["depth"].clone(), out["depth_0"].clone(), net.trip_records()))
+    (s0, i0, d0, e0, r0) = res[0]
+    assert s0["trips"] >= 3 and s0["samples"] > 1000
+    for s1, i1, d1, e1, r1 in res[1:]:
+        assert s0["samples"] == s1["samples"] and s0["trips"] == s1["trips"] and s0["err"] == s1["err"] == 0
+        assert [tuple(r[:4]) for r in r0] == [tuple(r[:4]) for r in r1]  # (n_alive, n_step, step_base, n_samples) per trip
+        assert torch.equal(i0, i1) and torch.equal(e0, e1)
+        assert torch.equal(torch.nan_to_num(d0, nan=-1.0), torch.nan_to_num(d1, nan=-1.0))
+
+
 _FRAME_HASH_SCRIPT = r"""
 import hashlib, sys, numpy as np, torch
 sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
