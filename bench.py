@@ -444,6 +444,7 @@ def main():
             launch = (f"hip graphs, {args.trips} trips, {args.lanes} render streams x {args.depth} workspaces, "
                       + (f"march pass 1 of the first {h._pipe_backend.kw.get('march_throughput_trips', 1)} trip(s) in its throughput form (one lane per ray, "
                          f"{h._pipe_backend.kw.get('march_throughput')} rounds; pn_render_opts.throughput / throughput_trips), " if args.lanes > 1 else "")
+                      + ("" if staged else "alive list in 16 x 4 pixel tiles (pn_render_opts.ray_tile_w), ")
                       + "simulator running ahead, D2H on "
                       + {"copy": "a copy stream", "lane": "the frame's render stream", "sim": "the simulator stream", "host": "no stream (copier thread + SDMA through the HSA runtime)"}[args.copy_on]
                       + (f"; rays in batches of {opt['ray_batch']} with per-batch trip schedules (max_ray_batch), all batches in the same launches" if staged else ""))

@@ -258,3 +258,21 @@ def test_persistent_substep_plan_limits_are_host_side_checks():
     assert int(L.pn_sim_coop_bytes(139, 3576, 4)) == 0           # 894 integration points per workgroup
     assert int(L.pn_sim_coop_bytes(139, 3576, 512)) == 0         # more workgroups than the barrier's groups are sized for
     assert int(L.pn_sim_coop_bytes(0, 10, 256)) == 0
+
+
+def test_render_opts_mirror_follows_the_header():
+    """pienerf_amd._lib.RenderOpts is the ctypes mirror of pn_render_opts (include/pienerf_hip.h): same field names in the same order, same
+    element types — a field added on one side only would shift every later one silently."""
+    import ctypes as C
+    from pienerf_amd._lib import RenderOpts
+    text = open(os.path.join(ROOT, "include", "pienerf_hip.h")).read()
+    body = text[:text.index("} pn_render_opts;")]
+    body = re.sub(r"/\*.*?\*/", "", body[body.rindex("typedef struct {"):], flags=re.S)
+    decl = re.findall(r"\b(int|float|uint32_t)\s+(\w+)(?:\[(\d+)\])?\s*;", body)
+    ctype = {"int": C.c_int32, "float": C.c_float, "uint32_t": C.c_uint32}
+    want = [(name, ctype[t] * int(n) if n else ctype[t]) for t, name, n in decl]
+    got = list(RenderOpts._fields_)
+    assert [n for n, _ in got] == [n for n, _ in want]
+    for (n, a), (_, b) in zip(got, want):
+        assert C.sizeof(a) == C.sizeof(b) and getattr(a, "_type_", a) == getattr(b, "_type_", b), n
+    assert C.sizeof(RenderOpts) == sum(C.sizeof(t) for _, t in want)
