@@ -1,13 +1,16 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED for the kernels restated here (pinned: get_rays and trunc_exp, by
-// reference-run fixtures — tests/golden/make_golden_ref.py, tests/test_golden_ref.py).
+// ORACLE — TEST INFRASTRUCTURE ONLY.  PINNED (rounds 3-4) against the reference's own kernels: oracle/ref_build.py compiles
+// raymarching/src, gridencoder/src and shencoder/src of /root/reference for gfx950 into oracle/_ref/ (git-ignored binaries), and
+// tests/test_gpu_ref.py::test_cpu_oracle_equals_the_reference_kernels_directly runs THIS restatement and those kernels on the same
+// inputs: march (num_seek_IP 1/2/3, 1/3/5 Newton iterations, --cut), near/far, morton, packbits bit for bit; composite decisions
+// equal and values within 2e-6; hash grid within 2e-6 of the contracting build; SH within 1e-6.  get_rays and trunc_exp are pinned by
+// reference-run fixtures (tests/golden/make_golden_ref.py, tests/test_golden_ref.py).
 //
 // CPU restatement of the render half of the PIE-NeRF simulate-and-render hot
 // path.  Only tests/, __graft_entry__.smoke() and
 // bench.py's cpu_baseline leg may load this library; the product path
-// (pienerf_amd/) never does.  "Parity unpinned": the reference ships no tests,
-// golden vectors or fixtures for this path and its CUDA/Warp code can neither
-// be compiled nor imported in the build container, so this
-// restatement is pinned only by independent-maths checks in tests/.
+// (pienerf_amd/) never does.  The reference ships no tests or golden vectors of
+// its own for this path; nothing here is checked against anything but the
+// reference's kernels (GPU tests) and independent maths (CPU tests).
 //
 // Each function cites the reference file:line (relative to /root/reference)
 // whose arithmetic it restates.  Built with -ffp-contract=off so that every

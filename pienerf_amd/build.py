@@ -82,7 +82,8 @@ def build(force=False, save_temps=False, verbose=False):
                 print(" ".join(cmd))
             subprocess.run(cmd, check=True, cwd=OBJ)
     if force or _stale(LIB, objs):
-        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lhsa-runtime64", "-lpthread"]
+        rocm = os.environ.get("ROCM_PATH") or os.path.dirname(os.path.dirname(os.path.realpath(cc)))  # <rocm>/bin/hipcc
+        cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-L" + os.path.join(rocm, "lib"), "-lhsa-runtime64", "-lpthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

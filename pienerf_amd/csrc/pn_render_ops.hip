@@ -540,7 +540,12 @@ __device__ __forceinline__ int seg_count(const int* counts, int seg) {
 // entries a segment must hold when its producers are the workgroups (32 rays each) / waves (64 rays) with id % PN_SEGS == segment
 // workers (workgroups or waves) whose id % PN_SEGS == seg, out of `total` (launches of segment consumers have at least PN_SEGS workers)
 __device__ __forceinline__ int seg_workers(int total, int seg) { return max((total - seg + PN_SEGS - 1) / PN_SEGS, 1); }
-static uint32_t seg_cap_for(uint32_t n_rays) { return (uint32_t)((pn_div_up(pn_div_up(n_rays, 64), PN_SEGS) + 1) * 64); }
+// ... or, in the one-lane-per-ray form of k_march (G = 1), 256-ray chunks dealt by chunk % PN_SEGS: a segment then gets up to
+// ceil(ceil(n / 256) / PN_SEGS) * 256 entries (640 000 rays: 10 240, more than the 64-ray form's 10 112 — round-3 advisor finding); the larger of the two
+static uint32_t seg_cap_for(uint32_t n_rays) {
+    const uint32_t by64 = (pn_div_up(pn_div_up(n_rays, 64), PN_SEGS) + 1) * 64, by256 = pn_div_up(pn_div_up(n_rays, 256), PN_SEGS) * 256 + 64;
+    return std::max(by64, by256);
+}
 
 // One lane per ray slot: fast-forward over the leading run of IP-free search cells.
 __global__ void __launch_bounds__(256) k_march_skip(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {

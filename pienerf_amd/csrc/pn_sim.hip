@@ -522,8 +522,9 @@ __global__ void __launch_bounds__(512) k_gather_plan(int n_k, int chunks_max, co
 // `tot` != nullptr: the workgroup that completes its kernel's set of chunks ("last arriver") also adds them up, in ascending chunk order like
 // k_gather_sum, and writes momentum + sum - rhs_rest: one launch less per local/global iteration (of the 4).  The XCDs' L2s are not coherent with each
 // other, so the chunk sums go out as agent-scope stores (written through to the memory side), a workgroup waits for their acknowledgement before it bumps
-// its kernel's arrival counter (agent-scope atomic at the memory side; the counters only ever grow: the n-th arrival with n % chunks == 0 is the last of
-// an iteration), and the last arriver reads all sums with agent-scope loads.
+// its kernel's arrival counter (agent-scope atomic at the memory side), and the last arriver — the one that counts `chunks` arrivals — reads all sums
+// with agent-scope loads and stores 0 back into the counter: nobody else arrives at it before the next launch, so the counter is cyclic and a simulator
+// that runs for days never wraps it (rounds 1-3 let it grow and tested (n % chunks) == 0, which loses its phase at 2^31 for chunk counts that do not divide 2^32).
 __global__ void __launch_bounds__(PN_GCH * 8) k_rhs_gather_chunk(const int4* __restrict__ chunk, const double* __restrict__ dNx_csr,
                                                                   const double* __restrict__ P_csr, double* part, int* kcount,
                                                                   const int* __restrict__ kc_bg, const double* __restrict__ momentum,
@@ -575,7 +576,8 @@ __global__ void __launch_bounds__(PN_GCH * 8) k_rhs_gather_chunk(const int4* __r
     __syncthreads();
     if (t == 0) {
         const int old = __hip_atomic_fetch_add(kcount + kern, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last_s = ((old + 1) % nck) == 0;
+        last_s = (old + 1) == nck;
+        if (last_s) __hip_atomic_store(kcount + kern, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
     }
     __syncthreads();
     if (!last_s || t >= 30) return;

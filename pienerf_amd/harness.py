@@ -222,7 +222,8 @@ class SimRenderHarness:
 
     @torch.no_grad()
     def capture_pipelined(self, lanes=2, n_trips=8, W=None, H=None, sim_ahead=None, depth=2, sim_priority=0, sim_cus=0, copy_out=True, group=None,
-                          frame_parallel=False, sim_owner=0, dedicated_sim=None, on_retire=None, copy_on="host", _probe_no_substep=False, _time_trips=False):
+                          frame_parallel=False, sim_owner=0, dedicated_sim=None, on_retire=None, copy_on="host", _probe_no_substep=False, _time_trips=False,
+                          render_kw=None):
         """Throughput mode (pienerf_amd/frames.py: FramePipeline): `lanes` render streams with `depth` workspaces each, the simulator running
         `sim_ahead` frames ahead on dof snapshots, every frame's image / depth / depth_0 copied to pinned host memory (the reference's
         device->host boundary, trainer.py:589-592; copy_out=False leaves the results on the device) — copy_on="host": by the library's copier
@@ -261,7 +262,8 @@ class SimRenderHarness:
             # its workgroups and those of the fused composite/compaction would wait for each other.  (A gloo group is the one-GPU dry run.)
             self.sim.enable_persistent()
         be = _HipBackend(self, lanes, depth, int(n_trips), W, H, sim_priority, sim_cus, copy_out, group if on else None,
-                         (dist.get_global_rank(group, sim_owner) if (on and group is not None) else sim_owner), _probe_no_substep, _time_trips, copy_on)
+                         (dist.get_global_rank(group, sim_owner) if (on and group is not None) else sim_owner), _probe_no_substep, _time_trips, copy_on,
+                         render_kw=render_kw)
         self._pipe = FramePipeline(be, world=world, rank=rank, lanes=lanes, depth=depth, ahead=(lanes if sim_ahead is None and world == 1 else sim_ahead),
                                    sim_owner=sim_owner, dedicated_sim=dedicated_sim, copy_out=copy_out, on_retire=on_retire)
         self._pipe_backend = be
@@ -347,8 +349,15 @@ class SimRenderHarness:
         independent, the alive list stays sorted by ray id, a batch is a contiguous run of it).  So the staged frame IS a pipelined frame:
         same graphs, same lanes, same D2H; `kw` goes to capture_pipelined, frames come back through step_pipelined() / drain_pipeline().
         (Rounds 1-2 replayed one captured launch chain per batch: ~10 000 launches per 800x800 frame, 20x slower than the frame in one piece.)"""
-        self.opt["ray_batch"] = int(batch or self.opt.get("max_ray_batch", 4096))
-        return self.capture_pipelined(**kw)
+        rk = dict(kw.pop("render_kw", None) or {}, ray_batch=int(batch or self.opt.get("max_ray_batch", 4096)))  # this pipeline's renders only: self.opt stays as it was
+        return self.capture_pipelined(render_kw=rk, **kw)
+
+    # names of rounds 1-2 (one captured launch chain per batch), kept as aliases of the pipeline's calls
+    def step_staged(self, pose=None):
+        return self.step_pipelined(pose)
+
+    def finish_staged(self):
+        return self.drain_pipeline()
 
     def to_host(self, out):
         """The reference's device->host boundary (trainer.py:589-592)."""
@@ -399,7 +408,8 @@ class _HipBackend:
     """The device side of frames.FramePipeline on one MI355X: torch streams and events, the substep and one render per workspace captured
     as HIP graphs, RCCL broadcasts of the dof snapshots, D2H into pinned buffers."""
 
-    def __init__(self, h, lanes, depth, n_trips, W, H, sim_priority, sim_cus, copy_out, group, src, probe_no_substep, time_trips=False, copy_on="host"):
+    def __init__(self, h, lanes, depth, n_trips, W, H, sim_priority, sim_cus, copy_out, group, src, probe_no_substep, time_trips=False, copy_on="host",
+                 render_kw=None):
         # stream of the per-frame D2H.  gfx950 runs 4 hardware queues concurrently and time-slices beyond that (DESIGN.md 4): with 3 render lanes +
         # the simulator stream a copy stream of its own is a fifth busy queue (measured: 808 steps/s against 1016 with the copy on the frame's own
         # lane).  "copy": a stream of its own; "lane": the frame's render stream; "sim": the simulator stream; "host": no stream at all — the
@@ -431,6 +441,7 @@ class _HipBackend:
         self.snap = {}
         n_ws, n_IP = lanes * depth, sim.n_IP
         kw = dict(h.render_kwargs(), async_trips=n_trips)
+        kw.update(render_kw or {})  # options of THIS pipeline's renders (capture_staged: ray_batch)
         # several frames in flight: the first trip's march pass in its throughput form (pn_render_opts.throughput: one lane per ray, no speculative
         # evaluation; the same samples bit for bit, +8 % steps/s with three lanes) — with one lane the frame's own latency is what counts
         kw.setdefault("march_throughput", 64 if lanes > 1 else 0)

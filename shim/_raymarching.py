@@ -95,10 +95,14 @@ def march_rays_quadratic_bending(pig_cnt, pig_bgn, pig_idx, n_vtx, n_grid, p_def
                                                 float(dt_gamma), int(max_steps), int(C), int(H), ptr(grid), ptr(near), ptr(far), ptr(xyzs), ptr(dirs), ptr(deltas),
                                                 ptr(noises), ptr(err), stream_ptr()), "march_rays_quadratic_bending")
     # the reference blocks the host on an event in every call (raymarching.cu:1481-1482) and printf's "ERROR: g0=..." for points outside the spatial
-    # hash (:1221-1222); here the same wait reads the device flags and raises
+    # hash (:1221-1222) and carries on; here the same wait reads the device flags: the printf case becomes a warning (same results as the reference:
+    # such a sample finds no IP), anything else — a table that overflowed — raises
     flags = int(err.item())
-    if flags:
-        raise RuntimeError(f"march_rays_quadratic_bending: device error flags {flags:#x} (1: sample outside the spatial hash, 8: candidate-list capacity)")
+    if flags & 1:
+        import warnings
+        warnings.warn("march_rays_quadratic_bending: a sample point fell outside the spatial hash (the reference prints 'ERROR: g0=...' and goes on)", RuntimeWarning)
+    if flags & ~1:
+        raise RuntimeError(f"march_rays_quadratic_bending: device error flags {flags:#x} (8: candidate-list capacity)")
 
 
 def composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):

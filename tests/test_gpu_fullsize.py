@@ -230,7 +230,7 @@ def test_stress_configuration_exactly_as_baseline_states_it():
         pipe.sim.stepforward()
     pipe.synchronize()
     pipe.capture_staged(lanes=2, depth=2, n_trips=None)
-    assert pipe.opt["ray_batch"] == 4096
+    assert pipe._pipe_backend.kw["ray_batch"] == 4096 and "ray_batch" not in pipe.opt   # an option of this pipeline's renders, not of the harness
     res = []
     for _ in range(3):
         res += [(i, r["image"].copy()) for i, r in pipe.step_pipelined()]

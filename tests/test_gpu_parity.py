@@ -570,7 +570,7 @@ def test_staged_ray_batches_equal_one_shot_frames(small_cloud, small_opt, ckpt, 
     want = [eager.to_host(eager.step(pose=p)) for p in poses]
     eager.synchronize()
     st = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture_staged(batch=1024, lanes=2, n_trips=n_trips)
-    assert st.opt["ray_batch"] == 1024
+    assert st._pipe_backend.kw["ray_batch"] == 1024 and "ray_batch" not in st.opt   # round-3 advisor: capture_staged no longer edits the harness's options
     got = []
     for p in poses:
         got += [(i, {k: r[k].copy() for k in ("image", "depth", "depth_0")}) for i, r in st.step_pipelined(pose=p)]

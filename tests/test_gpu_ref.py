@@ -324,6 +324,120 @@ def test_sh_encode_equals_the_reference_kernel(mods, degree):
         assert e <= (1e-6 if i == 0 else 2e-5), (what, e)
 
 
+# ------------------------------------------------------------------------------------------------ the CPU oracle against the reference, first-hand
+@pytest.mark.parametrize("num_seek_IP,max_iter_num,n_step,cut", [(1, 1, 1, False), (3, 1, 8, False), (2, 3, 4, False), (3, 5, 8, False), (1, 1, 6, True), (3, 1, 2, True)])
+def test_cpu_oracle_march_equals_the_reference_kernel_directly(mods, deformed_ip_state, small_opt, ckpt, num_seek_IP, max_iter_num, n_step, cut):
+    """oracle/render_oracle.cpp (the CPU restatement every other test leans on) against kernel_march_rays_quadratic_bending itself — no HIP kernel of this
+    repository in between: the same inputs, xyzs / dirs / deltas bit for bit."""
+    ref, _, _ = mods
+    ip, ck = deformed_ip_state, dict(ckpt)
+    if cut:
+        blobs = np.repeat(np.random.default_rng(5).random(len(ck["density_bitfield"]) // 64) < 0.04, 64)
+        ck["density_bitfield"] = ck["density_bitfield"] | np.where(blobs, 0xFF, 0).astype(np.uint8)
+        W = 40
+        o, d = oracle.get_rays(scene.orbit_pose(4.0, 10.0, -5.0), scene.orbit_intrinsics(W, W, 50.0), W, W)
+        hgs = np.float32(small_opt["hash_grid_size"])
+        bbmin, bbmax, res = oracle.render_bbox(ip["p_def"], hgs, cut=True, bound=1.0)
+        n_grid = int(res.prod())
+        pig = oracle.get_pnts_in_grids(len(ip["p_def"]), n_grid, ip["p_def"], bbmin, bbmax, hgs, res)
+        nears, fars = oracle.near_far_from_aabb(o, d, np.concatenate([bbmin, bbmax]), 0.2)
+        m = dict(o=o, d=d, hgs=hgs, bbmin=bbmin, bbmax=bbmax, res=res, n_grid=n_grid, pig=pig, nears=nears, fars=fars)
+        alive = np.arange(W * W, dtype=np.int32)
+        cb = np.array([-0.3, 0.9, -0.9, 0.5, -0.9, 0.9], np.float32)
+        dt_gamma, max_steps = 1.0 / 128, 300
+    else:
+        m = _march_inputs(ip, small_opt, ck, W=96)
+        alive = np.nonzero(m["nears"] < 1e30)[0].astype(np.int32)
+        alive = np.concatenate([alive, np.arange(0, m["o"].shape[0], 97, dtype=np.int32)])
+        cb = np.zeros(6, np.float32)
+        dt_gamma, max_steps = 0.0, 1024
+    noises = np.random.default_rng(1).random(len(alive)).astype(np.float32) if n_step == 4 else np.zeros(len(alive), np.float32)
+    r = _call_march(ref["raymarching"], m, ip, ck, alive, n_step, num_seek_IP, max_iter_num, cut, cb, dt_gamma, max_steps, noises, m["nears"])
+    want = oracle.march_rays_quadratic_bending(*m["pig"], len(ip["p_def"]), m["n_grid"], ip["p_def"], ip["p_ori"], ip["F"], ip["dF"], max_iter_num, m["bbmin"],
+                                               m["bbmax"], m["hgs"], m["res"], num_seek_IP, np.float32(ip["IP_dx"]), cut, cb, len(alive), n_step, alive,
+                                               m["nears"], m["o"], m["d"], 1.0, ck["density_bitfield"], ck["cascade"], ck["grid_size"], m["nears"], m["fars"],
+                                               128, False, dt_gamma, max_steps, noises=noises)
+    assert int((want[2][:, 0] != 0).sum()) > 100
+    for name, a, b in zip(("xyzs", "dirs", "deltas"), r[:3], want):
+        a = a.cpu().numpy()
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{name}: {int(np.sum(a != b))} of {a.size} values differ"
+
+
+def test_cpu_oracle_equals_the_reference_kernels_directly(mods, ckpt):
+    """near/far, morton, packbits, composite, hash grid (float, all four option sets) and SH: the CPU oracle against the reference's kernels on the same
+    inputs, without this repository's HIP path in between."""
+    ref, fma, _ = mods
+    W = 96
+    o, d = oracle.get_rays(scene.orbit_pose(5.0, 30.0, -20.0), scene.orbit_intrinsics(W, W, 50.0), W, W)
+    N = len(o)
+    aabb = np.array([-0.6, -0.8, -0.5, 0.7, 0.9, 0.55], np.float32)
+    n, f = torch.empty(N, device=DEV), torch.empty(N, device=DEV)
+    ref["raymarching"].near_far_from_aabb(T(o), T(d), T(aabb), N, 0.2, n, f)
+    wn, wf = oracle.near_far_from_aabb(o, d, aabb, 0.2)
+    assert np.array_equal(n.cpu().numpy().view(np.uint32), wn.view(np.uint32)) and np.array_equal(f.cpu().numpy().view(np.uint32), wf.view(np.uint32))
+    # morton / packbits
+    rng = np.random.default_rng(9)
+    coords = rng.integers(0, 1024, (5000, 3)).astype(np.int32)
+    grid = (rng.random(128 ** 3).astype(np.float32) * 20)
+    idx, back = torch.empty(5000, dtype=torch.int32, device=DEV), torch.empty(5000, 3, dtype=torch.int32, device=DEV)
+    bits = torch.zeros(128 ** 3 // 8, dtype=torch.uint8, device=DEV)
+    ref["raymarching"].morton3D(T(coords), 5000, idx)
+    ref["raymarching"].morton3D_invert(idx, 5000, back)
+    ref["raymarching"].packbits(T(grid), 128 ** 3 // 8, 10.0, bits)
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy().astype(np.uint32), np.asarray(oracle.morton3D(coords)).astype(np.uint32))
+    assert np.array_equal(back.cpu().numpy(), np.asarray(oracle.morton3D_invert(idx.cpu().numpy())).reshape(-1, 3))
+    assert np.array_equal(bits.cpu().numpy(), oracle.packbits(grid, 10.0))
+    # composite
+    Nr, n_alive, n_step = 3000, 1700, 8
+    alive = np.sort(rng.choice(Nr, n_alive, replace=False)).astype(np.int32)
+    M = n_alive * n_step
+    sig = (rng.random(M).astype(np.float32) * 120)
+    rgb = rng.random((M, 3)).astype(np.float32)
+    deltas = np.stack([np.full(M, 0.0034, np.float32), (rng.random(M) * 0.01 + 0.0034).astype(np.float32)], 1)
+    for k in range(0, n_alive, 3):
+        deltas[k * n_step + rng.integers(0, n_step):(k + 1) * n_step] = 0
+    st = dict(t=(rng.random(Nr).astype(np.float32) + 3), ws=(rng.random(Nr).astype(np.float32) * 0.9), dep=rng.random(Nr).astype(np.float32),
+              img=rng.random((Nr, 3)).astype(np.float32))
+    g = {k: T(v.copy()) for k, v in st.items()}
+    al = T(alive.copy())
+    keep = (T(sig), T(rgb), T(deltas))
+    ref["raymarching"].composite_rays(n_alive, n_step, 1e-2, al, g["t"], keep[0], keep[1], keep[2], g["ws"], g["dep"], g["img"])
+    torch.cuda.synchronize()
+    w = {k: v.copy() for k, v in st.items()}
+    wal = alive.copy()
+    oracle.composite_rays(n_alive, n_step, wal, w["t"], sig, rgb, deltas, w["ws"], w["dep"], w["img"], 1e-2)
+    assert np.array_equal(al.cpu().numpy(), wal) and (wal < 0).any() and (wal >= 0).any()
+    assert np.array_equal(g["t"].cpu().numpy().view(np.uint32), w["t"].view(np.uint32))   # a running sum of deltas: nothing to approximate
+    for k in ("ws", "dep", "img"):   # __expf: the GPU's v_exp_f32 against the oracle's exp2f(x * log2e)
+        assert np.abs(g[k].cpu().numpy() - w[k]).max() / np.abs(w[k]).max() < 2e-6, k
+    # hash grid: the oracle states pos = fmaf(u, scale, 0.5) as one rounding (what a contracting compiler makes of gridencoder.cu:129)
+    B, L, C = 20000, 16, 2
+    x = rng.random((B, 3)).astype(np.float32)
+    x[:7] = [[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [1.0, 0.0, 0.5], [-0.1, 0.5, 0.5], [0.5, 1.2, 0.5], [0.999999, 0.999999, 0.999999]]
+    S = float(np.log2(ckpt["per_level_scale"]))
+    emb, off = T(ckpt["embeddings"]), T(ckpt["offsets"].astype(np.int32))
+    for gridtype, align, interp in ((0, False, 0), (1, False, 0), (0, True, 0), (0, False, 1)):
+        want = oracle.grid_encode_forward(x, ckpt["embeddings"], ckpt["offsets"], ckpt["per_level_scale"], ckpt["base_resolution"], gridtype, align, interp)
+        got = {}
+        for name, mm in (("ref", ref), ("fma", fma)):
+            y = torch.empty(L, B, C, device=DEV)
+            mm["gridencoder"].grid_encode_forward(T(x), emb, off, y, B, 3, C, L, S, ckpt["base_resolution"], None, gridtype, align, interp)
+            torch.cuda.synchronize()
+            got[name] = y.permute(1, 0, 2).reshape(B, L * C).cpu().numpy()
+        e_fma, e_ref = float(np.abs(got["fma"] - want).max()), float(np.abs(got["ref"] - want).max())
+        REPORT[f"oracle_grid_encode[{gridtype},{int(align)},{interp}]"] = dict(max_abs_vs_fma=e_fma, max_abs_vs_nocontract=e_ref)
+        assert e_fma <= 2e-6 and e_ref <= (1e-4 if interp == 0 else 2e-4), (gridtype, align, interp, e_fma, e_ref)
+    # SH
+    dd = rng.standard_normal((B, 3)).astype(np.float32)
+    dd /= np.linalg.norm(dd, axis=-1, keepdims=True)
+    for degree in (1, 2, 3, 4):
+        y = torch.empty(B, degree ** 2, device=DEV)
+        ref["shencoder"].sh_encode_forward(T(dd), y, B, 3, degree, None)
+        torch.cuda.synchronize()
+        assert np.abs(y.cpu().numpy() - oracle.sh_encode_forward(dd, degree)).max() <= 1e-6, degree
+
+
 # ------------------------------------------------------------------------------------------------ training ops (SURVEY §8f rank 3)
 def test_march_rays_train_equals_the_reference_kernel(mods):
     """kernel_march_rays_train (raymarching.cu:314-483).  The reference hands out ray rows and point ranges with two atomicAdd counters (race order); the
