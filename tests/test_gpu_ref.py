@@ -427,7 +427,8 @@ def test_cpu_oracle_equals_the_reference_kernels_directly(mods, ckpt):
             got[name] = y.permute(1, 0, 2).reshape(B, L * C).cpu().numpy()
         e_fma, e_ref = float(np.abs(got["fma"] - want).max()), float(np.abs(got["ref"] - want).max())
         REPORT[f"oracle_grid_encode[{gridtype},{int(align)},{interp}]"] = dict(max_abs_vs_fma=e_fma, max_abs_vs_nocontract=e_ref)
-        assert e_fma <= 2e-6 and e_ref <= (1e-4 if interp == 0 else 2e-4), (gridtype, align, interp, e_fma, e_ref)
+        # (against the no-contraction build the one rounding of `pos` moves a finest-level weight by up to 1.2e-4 x a feature of O(1))
+        assert e_fma <= 2e-6 and e_ref <= (1.5e-4 if interp == 0 else 2.5e-4), (gridtype, align, interp, e_fma, e_ref)
     # SH
     dd = rng.standard_normal((B, 3)).astype(np.float32)
     dd /= np.linalg.norm(dd, axis=-1, keepdims=True)
