@@ -243,6 +243,15 @@ typedef struct {
                              the alive list (each ray's samples, its composite and its pixel are its own); ignored unless ray_tile_w % 16 == 0 and
                              N % (4 * ray_tile_w) == 0, with ray_batch > 0 (whose batches are contiguous runs of a sorted alive list) and by
                              pn_render_static. */
+    int fused_from;       /* the loop trips from this one on run as ONE persistent launch (csrc/pn_trips_fused.h): once n_alive <= N / 8 the reference's
+                             n_step = max(min(N // n_alive, 8), 1) (renderer.py:839-846) is 8 for the rest of the frame, so every ray can loop
+                             { march 8 samples; network; composite } on its own until it dies — the per-ray arithmetic, the samples, the pixels and the
+                             per-trip counts of the trip-by-trip loop, without its 4-6 launches and its compaction per trip.  0: from trip 1 (right behind
+                             the frame's first trip; the chair); k > 1: the first k trips as per-trip launches (a scene whose second trip still has more
+                             than N / 8 rays alive: the trex option set — harness.capture_pipelined reads k off its warm-up frame); < 0: never.  If the
+                             launch finds n_step < 8 at its first trip it does nothing and the frame is continued like one that ran out of captured
+                             trips (pn_render_continue; the blocking pn_render_deformed runs one per-trip trip and tries again).  Not with ray_batch > 0
+                             (batches keep their own n_step), not for pn_render_static, not for max_steps > 1024. */
 } pn_render_opts;
 int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_vtx, uint32_t max_grid_cells);
 void pn_frame_destroy(pn_frame* f);
@@ -329,9 +338,15 @@ int pn_density_grid_update(uint32_t n, float* density_grid, const float* tmp_gri
  * {marching-loop iterations, candidate entries scanned, per-IP inverse warps, samples emitted}, the units behind the march
  * kernel's algorithmic-bytes figure (the counters add atomics, so never time with this bit set);
  * bit 1 (2) — blocking renders bracket each trip's march and network launches with HIP events (see pn_frame_trip_times);
- * 0 switches both off.  counters_host (uint64[4], may be NULL): synchronises and reads the totals accumulated so far
+ * bit 2 (4) — the fused launches of the later trips (pn_render_opts.fused_from) sum per-phase shader-clock cycles over their waves (see
+ * pn_frame_fused_clocks; a drain of the memory counters at every phase boundary: never time `value` with it);
+ * 0 switches all off.  counters_host (uint64[4], may be NULL): synchronises and reads the totals accumulated so far
  * (before any re-zeroing caused by enabling). */
 int pn_frame_march_counters(pn_frame* f, int enable, uint64_t* counters_host, void* stream);
+/* With bit 2: clocks_host (uint64[8], may be NULL; synchronises) = cycles summed over the waves of the fused launches on f since the last reset for
+ * {hand-out of rays, march (8-lane window round), march (64-lane windows of the rays still going), network, composite}, then wave-rounds, waves, 0;
+ * *first_trip_out (may be NULL) = the trip at which the last render on f switched to the fused launch, -1 if it did not.  reset != 0: zero the sums. */
+int pn_frame_fused_clocks(pn_frame* f, uint64_t* clocks_host, int* first_trip_out, int reset, void* stream);
 /* With bit 1 of `enable` set: the per-trip durations (ms, HIP events on the launch stream) of the last blocking render:
  * *n_trips_out entries in each array. */
 /* Diagnostics: the device's per-trip records of the last render on `f` as int[max_trips][5] = (n_alive, n_step, step_base, n_samples, n_emitted; -1 on trips whose list is compacted)

@@ -17,7 +17,8 @@ class RenderOpts(C.Structure):
     """pn_render_opts (include/pienerf_hip.h)."""
     _fields_ = [("max_iter_num", i32), ("hash_grid_size", f32), ("num_seek_IP", i32), ("IP_dx", f32), ("cut", i32), ("cut_bounds", f32 * 6),
                 ("bound", f32), ("min_near", f32), ("dt_gamma", f32), ("max_steps", u32), ("T_thresh", f32), ("cascade", u32), ("grid_size", u32),
-                ("density_scale", f32), ("bg_color", f32), ("fp16", i32), ("reuse_tables", i32), ("ray_batch", i32), ("throughput", i32), ("throughput_trips", i32), ("ray_tile_w", i32)]
+                ("density_scale", f32), ("bg_color", f32), ("fp16", i32), ("reuse_tables", i32), ("ray_batch", i32), ("throughput", i32), ("throughput_trips", i32), ("ray_tile_w", i32),
+                ("fused_from", i32)]
 
 
 # name -> (restype, argtypes); every function declared in include/pienerf_hip.h
@@ -81,6 +82,7 @@ SIGNATURES = {
     "pn_density_grid_update": (i32, [u32, P, P, f32, f32, P, P, P, P]),
     "pn_frame_march_counters": (i32, [P, i32, P, P]),
     "pn_frame_trip_times": (i32, [P, P, P, i32, P, P]),
+    "pn_frame_fused_clocks": (i32, [P, P, P, i32, P]),
     "pn_frame_trip_records": (i32, [P, P, P, i32, P]),
     "pn_sim_update_F": (i32, [i32, P, P, P, P, P, P, P, P, P]),
     "pn_sim_calc_elastic": (i32, [i32, P, P, P, P, P, P, P]),

@@ -58,7 +58,12 @@ struct PnFrameDev {
     int trips_run;      // loop trips the last render (or continuation) on this workspace has enqueued: written by its epilogue, so that it is
                         // also right after a HIP-graph REPLAY, which the host-side bookkeeping never sees
     int nb_alloc;       // candidate-list entries handed out so far (k_frame_prologue bumps it once per 32 cells; cleared by k_frame_tables)
-    int pad[2];
+    int fused_trips;    // trips the last k_trips_fused launch ran (pn_trips_fused.h); k_frame_finish adds them to trips_run and clears the field
+    // summary of the trip records, written by k_frame_finish (the host reads this record instead of every trip's):
+    int stat_trips;     // trips that had rays
+    int alive_at_exit;  // rays alive behind the last trip enqueued
+    int pad0;
+    long long stat_samples;  // samples marched (dense trips: emitted; list trips: listed)
 };
 
 // ------------------------------------------------------------------------------------------------ sph_from_ray
@@ -1497,6 +1502,8 @@ extern "C" int pn_compact_rays(const int* rays_alive, uint32_t n, int* out, int*
 #define PN_TRIP_MARGIN 2  // trips a captured render carries beyond what its sizing frame needed (harness: measured + 2)
 #define PN_TIMED_TRIPS 64
 
+#include "pn_trips_fused.h"
+
 struct pn_frame {
     uint32_t max_rays, max_vtx, max_cells;
     float *nears, *fars, *rays_t, *xyzs, *dirs, *deltas, *sigmas, *rgbs;
@@ -1534,17 +1541,42 @@ struct pn_frame {
     int timed_trips;
     unsigned long long* stamps;          // device [PN_TIMED_TRIPS][3]: the same three points as 100 MHz wall-clock stamps written by one-lane kernels
     int stamped;                         // — the form that also works inside a captured graph (HIP events recorded in a graph cannot be timed)
+    // the fused later trips (pn_trips_fused.h)
+    int* fused_ctl;                      // [PN_FUSED_CTL_INTS] hand-out cursors, per-trip counters, workgroups done: zero between launches
+    uint32_t fused_blocks;               // workgroups of a fused launch (one per CU); xyzs / dirs / deltas / sigmas / rgbs hold 64 slots per wave of it
+    unsigned long long* fused_clocks;    // device [8] phase clocks of the fused launches (march_counters_on & 4)
+    int fused_first;                     // first trip the last render ran fused (-1: none): where its time stamps sit
 };
 
 // image = acc + (1 - weights_sum) * bg ; depth = clamp(depth - nears, 0) / (fars - nears) (renderer.py:896-899)
+// The first wave of the launch also closes the frame's books: trips_run (+ the trips a fused launch ran, whose number only the device knows), the summary
+// of the trip records (what pn_render_status reports) and the rays a fixed-trip render left alive.
 __global__ void __launch_bounds__(256) k_frame_finish(uint32_t N, float bg, const float* __restrict__ nears, const float* __restrict__ fars,
                                                       const float* __restrict__ weights_sum, const float* __restrict__ depth_0,
                                                       const float* __restrict__ acc, float* __restrict__ image, float* __restrict__ depth,
-                                                      const PnTrip* __restrict__ final_trip, PnFrameDev* dev, int trips_run) {
+                                                      const PnTrip* __restrict__ trips, PnFrameDev* dev, int trips_run, int add_fused) {
     const uint32_t i = threadIdx.x + blockIdx.x * blockDim.x;
-    if (i == 0) {
-        dev->trips_run = trips_run;
-        if (final_trip->n_alive > 0) atomicAdd(&dev->unfinished, final_trip->n_alive);
+    if (i < 64) {
+        const int lane = (int)i;
+        const int t_final = min(trips_run + (add_fused ? dev->fused_trips : 0), PN_MAX_TRIPS);
+        int n_trips = 0;
+        long long n_samples = 0;
+        for (int k = lane; k < t_final; k += 64) {
+            const PnTrip* r = trips + k;
+            if (r->n_alive > 0) n_trips++;
+            n_samples += r->dense ? r->n_emitted : r->n_samples;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { n_trips += __shfl_xor(n_trips, o); n_samples += __shfl_xor(n_samples, o); }
+        if (lane == 0) {
+            const int left = trips[t_final].n_alive;
+            dev->trips_run = t_final;
+            dev->fused_trips = 0;
+            dev->stat_trips = n_trips;
+            dev->stat_samples = n_samples;
+            dev->alive_at_exit = left;
+            if (left > 0) atomicAdd(&dev->unfinished, left);
+        }
     }
     if (i >= N) return;
     const float k = (1 - weights_sum[i]) * bg;
@@ -1899,7 +1931,20 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
     const size_t N = max_rays;
 #define PN_ALLOC(ptr, bytes) PN_HIP_CHECK(hipMalloc((void**)&(ptr), (bytes)))
     PN_ALLOC(f->nears, N * 4); PN_ALLOC(f->fars, N * 4); PN_ALLOC(f->rays_t, N * 4);
-    PN_ALLOC(f->xyzs, N * 12); PN_ALLOC(f->dirs, N * 12); PN_ALLOC(f->deltas, N * 8); PN_ALLOC(f->sigmas, N * 4); PN_ALLOC(f->rgbs, N * 12);
+    // sample slots: one per ray for the per-trip launches, 64 per wave of a fused launch (pn_trips_fused.h: one workgroup per CU) — the larger of the two
+    {
+        int dev_id = 0, cus = 0;
+        PN_HIP_CHECK(hipGetDevice(&dev_id));
+        PN_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id));
+        f->fused_blocks = (uint32_t)std::min(std::max(cus, 1), 1024);
+    }
+    const size_t NS = std::max(N, (size_t)f->fused_blocks * PN_FUSED_WAVES * 64);
+    PN_ALLOC(f->xyzs, NS * 12); PN_ALLOC(f->dirs, NS * 12); PN_ALLOC(f->deltas, NS * 8); PN_ALLOC(f->sigmas, NS * 4); PN_ALLOC(f->rgbs, NS * 12);
+    PN_ALLOC(f->fused_ctl, (size_t)PN_FUSED_CTL_INTS * 4);
+    PN_HIP_CHECK(hipMemset(f->fused_ctl, 0, (size_t)PN_FUSED_CTL_INTS * 4));
+    PN_ALLOC(f->fused_clocks, 8 * sizeof(unsigned long long));
+    PN_HIP_CHECK(hipMemset(f->fused_clocks, 0, 8 * sizeof(unsigned long long)));
+    f->fused_first = -1;
     PN_ALLOC(f->acc_image, N * 12);
     PN_ALLOC(f->alive_a, N * 4); PN_ALLOC(f->alive_b, N * 4); PN_ALLOC(f->list, N * 4); PN_ALLOC(f->chunk_counts, (N / 256 + 4) * 4);
     PN_ALLOC(f->pig_cnt, (size_t)max_grid_cells * 4); PN_ALLOC(f->pig_bgn, (size_t)max_grid_cells * 4);
@@ -1932,7 +1977,7 @@ extern "C" void pn_frame_destroy(pn_frame* f) {
     void* ptrs[] = {f->acc_image, f->nears, f->fars, f->rays_t, f->xyzs, f->dirs, f->deltas, f->sigmas, f->rgbs, f->alive_a, f->alive_b, f->list,
                     f->chunk_counts, f->pig_cnt, f->pig_bgn, f->pig_cursor, f->pig_idx, f->trips, f->dev, f->cut_bounds,
                     f->side.nb_rng, f->side.nb, f->side.rec, f->march_counters, f->tail, f->tail_counts, f->stamps,
-                    f->list_seg, f->active_seg, f->seg_counters, f->cell_bits, f->fars_eff, f->groups, f->group_cnt};
+                    f->list_seg, f->active_seg, f->seg_counters, f->cell_bits, f->fars_eff, f->groups, f->group_cnt, f->fused_ctl, f->fused_clocks};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int t = 0; t < PN_TIMED_TRIPS; t++)
         for (int e = 0; e < 3; e++) if (f->ev[t][e]) (void)hipEventDestroy(f->ev[t][e]);
@@ -1942,16 +1987,11 @@ extern "C" void pn_frame_destroy(pn_frame* f) {
 }
 
 static void frame_stats(pn_frame* f, int64_t* stats_host) {
-    int64_t trips = 0, samples = 0;
-    const int t = f->dev_pinned->trips_run;  // as the render itself recorded it (right after graph replays too)
-    for (int k = 0; k < t; k++) {
-        if (f->trips_pinned[k].n_alive > 0) trips++;
-        samples += f->trips_pinned[k].dense ? f->trips_pinned[k].n_emitted : f->trips_pinned[k].n_samples;
-    }
-    stats_host[0] = trips;
-    stats_host[1] = samples;
+    // the frame's own summary (k_frame_finish), as the render recorded it — right after graph replays too
+    stats_host[0] = f->dev_pinned->stat_trips;
+    stats_host[1] = f->dev_pinned->stat_samples;
     stats_host[2] = f->dev_pinned->err;
-    stats_host[3] = f->trips_pinned[t].n_alive;
+    stats_host[3] = f->dev_pinned->alive_at_exit;
     stats_host[4] = f->dev_pinned->unfinished;
 }
 
@@ -2090,13 +2130,66 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     int t = resume ? f->dev_pinned->trips_run : 0;
     PN_REQUIRE(t >= 0 && t <= PN_MAX_TRIPS);
     bool done = false;
+    // The trips from `fuse_from` on as ONE launch (pn_trips_fused.h) where that form applies: a deformed frame with one trip schedule, max_steps within
+    // the fused kernel's trip table.  pn_render_opts.fused_from: the first trip to run fused (0: 1 — right behind the frame's first trip; a scene whose
+    // later trips still have more than N / 8 rays alive — the trex option set's second — names a later one; < 0: never).  PN_FUSED=0 switches it off (A/B).
+    static const bool fused_env = [] { const char* v = getenv("PN_FUSED"); return !(v && v[0] == '0'); }();
+    static const uint32_t fused_grid_env = pn_env_u32("PN_FUSED_GRID", 0);
+    const bool fused_ok = fused_env && !is_static && !group_rays && o->fused_from >= 0 && o->max_steps <= 8u * PN_FUSED_MAX_TRIPS;
+    const int fuse_from = fused_ok ? std::max(o->fused_from, 1) : PN_MAX_TRIPS + 1;
+    int add_fused = 0;
+    f->fused_first = -1;
     while (!done && t < PN_MAX_TRIPS) {
-        const int batch = async_trips > 0 ? async_trips : PN_TRIP_BATCH;
+        if (t >= fuse_from) {
+            FusedArgs fa;
+            memset(&fa, 0, sizeof(fa));
+            fa.lv = (const PnFusedLevel*)net->fused_levels; fa.emb = net->embeddings; fa.emb_h = (const uint32_t*)net->emb_half; fa.emb_bytes = net->n_entries * 4u;
+            fa.wimg_g = (const uint4*)(o->fp16 ? net->whalf : net->wsplit); fa.net_bound = net->bound; fa.density_scale = o->density_scale;
+            fa.trips = f->trips + t; fa.N_rays = N; fa.max_steps = o->max_steps; fa.T_thresh = o->T_thresh;
+            fa.alive = (t & 1) ? f->alive_b : f->alive_a;
+            fa.rays_t = f->rays_t; fa.weights_sum = weights_sum; fa.depth = depth_0; fa.image = f->acc_image;
+            fa.xyzs = f->xyzs; fa.dirs = f->dirs; fa.deltas = f->deltas; fa.sigmas = f->sigmas; fa.rgbs = f->rgbs;
+            fa.ctl = f->fused_ctl; fa.dev = f->dev; fa.tail_diag = f->tail_counts + t;
+            fa.clocks = (f->march_counters_on & 4) ? f->fused_clocks : nullptr;
+            pnm::MarchParams mq = mp;
+            if (short_rays) mq.fars = f->fars_eff;  // written by trip 0's k_march_skip
+            const bool timed = (f->march_counters_on & 2) && t < PN_TIMED_TRIPS;
+            bool stamp = false;
+            if (timed) {  // the whole launch is bracketed like a trip's march group (its network share comes from the phase clocks)
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                PN_HIP_CHECK(hipStreamIsCapturing(st, &cs));
+                stamp = cs != hipStreamCaptureStatusNone;
+                f->stamped = stamp ? 1 : 0;
+                if (stamp) k_stamp<<<1, 1, 0, st>>>(f->stamps + t * 3);
+                else {
+                    for (int e = 0; e < 3; e++)
+                        if (!f->ev[t][e]) PN_HIP_CHECK(hipEventCreate(&f->ev[t][e]));
+                    PN_HIP_CHECK(hipEventRecord(f->ev[t][0], st));
+                }
+            }
+            const uint32_t blocks = fused_grid_env ? std::min(fused_grid_env, f->fused_blocks) : f->fused_blocks;
+            rc = launch_trips_fused(o->num_seek_IP, o->max_iter_num > 1, o->fp16 != 0, blocks, st, mq, tb, fa);
+            if (rc) return rc;
+            if (timed) {
+                if (stamp) { k_stamp<<<1, 1, 0, st>>>(f->stamps + t * 3 + 1); k_stamp<<<1, 1, 0, st>>>(f->stamps + t * 3 + 2); }
+                else { PN_HIP_CHECK(hipEventRecord(f->ev[t][1], st)); PN_HIP_CHECK(hipEventRecord(f->ev[t][2], st)); }
+                f->timed_trips = t + 1;
+            }
+            f->fused_first = t;
+            if (async_trips > 0) { add_fused = 1; break; }  // how many trips it ran only the device knows: k_frame_finish adds them
+            PN_HIP_CHECK(hipMemcpyAsync(f->dev_pinned, f->dev, sizeof(PnFrameDev), hipMemcpyDeviceToHost, st));
+            PN_HIP_CHECK(hipMemcpyAsync(f->trips_pinned + t, f->trips + t, sizeof(PnTrip), hipMemcpyDeviceToHost, st));
+            PN_HIP_CHECK(hipStreamSynchronize(st));
+            if (f->dev_pinned->fused_trips > 0) { t += f->dev_pinned->fused_trips; done = true; break; }  // ran until no ray was alive (or max_steps)
+            if (f->trips_pinned[t].n_alive <= 0) { done = true; break; }
+            // not applicable at this trip (more than N / 8 rays alive: n_step < 8): one trip of the per-trip launches, then again
+        }
+        const int batch = async_trips > 0 ? (fused_ok ? fuse_from - t : async_trips) : (fused_ok ? std::max(fuse_from - t, 1) : PN_TRIP_BATCH);
         for (int k = 0; k < batch; k++, t++) {
             // margin trips: a fixed-trip render (captured graphs) carries PN_TRIP_MARGIN more trips than the frame it was sized on needed, and they
             // find no ray (or a few hundred stragglers).  What they cost is the dispatch of their launches' workgroups, so they get small grids —
             // the chunk loops take care of whatever is alive — and the two-launch composite / compaction (the fused one needs a workgroup per chunk)
-            const bool margin = async_trips > PN_TRIP_MARGIN && k >= async_trips - PN_TRIP_MARGIN && !resume;
+            const bool margin = !fused_ok && async_trips > PN_TRIP_MARGIN && k >= async_trips - PN_TRIP_MARGIN && !resume;
             int* cur = (t & 1) ? f->alive_b : f->alive_a;
             int* nxt = (t & 1) ? f->alive_a : f->alive_b;
             // trip 0 (every ray, one sample each) is dominated by rays crossing IP-free cells: a one-lane-per-ray pre-pass
@@ -2180,20 +2273,23 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             }
         }
         PN_LAUNCH_CHECK();
-        if (async_trips > 0) break;
+        if (async_trips > 0) {
+            if (fused_ok) continue;  // the fused launch follows
+            break;
+        }
+        if (fused_ok && t >= fuse_from) continue;  // no read-back: the fused launch finds out by itself whether anything is alive
         // one small readback per batch decides whether more trips are needed (the reference syncs every trip)
         PN_HIP_CHECK(hipMemcpyAsync(f->trips_pinned + t, f->trips + t, sizeof(PnTrip), hipMemcpyDeviceToHost, st));
         PN_HIP_CHECK(hipStreamSynchronize(st));
         done = f->trips_pinned[t].n_alive <= 0;
     }
-    k_frame_finish<<<nblk, 256, 0, st>>>(N, o->bg_color, f->nears, f->fars, weights_sum, depth_0, f->acc_image, image, depth, f->trips + t, f->dev, t);
+    k_frame_finish<<<nblk, 256, 0, st>>>(N, o->bg_color, f->nears, f->fars, weights_sum, depth_0, f->acc_image, image, depth, f->trips, f->dev, t, add_fused);
     PN_LAUNCH_CHECK();
     f->last_trips = t;
     f->last_N = N;
     f->last_group_rays = group_rays;
-    // the trip records and the frame record always travel to pinned host memory (two small async copies): pn_render_status /
-    // pn_render_continue read them once the caller knows the render has completed
-    PN_HIP_CHECK(hipMemcpyAsync(f->trips_pinned, f->trips, sizeof(PnTrip) * (t + 1), hipMemcpyDeviceToHost, st));
+    // the frame record (trips run, summary of the trip records, flags: written by k_frame_finish) always travels to pinned host memory with one small
+    // async copy: pn_render_status / pn_render_continue read it once the caller knows the render has completed
     PN_HIP_CHECK(hipMemcpyAsync(f->dev_pinned, f->dev, sizeof(PnFrameDev), hipMemcpyDeviceToHost, st));
     if (async_trips == 0 && stats_host) {
         PN_HIP_CHECK(hipStreamSynchronize(st));
@@ -2251,7 +2347,21 @@ extern "C" int pn_frame_march_counters(pn_frame* f, int enable, uint64_t* counte
         PN_HIP_CHECK(hipStreamSynchronize(st));
     }
     if ((enable & 1) && !(f->march_counters_on & 1)) PN_HIP_CHECK(hipMemsetAsync(f->march_counters, 0, 16 * sizeof(unsigned long long), st));
-    f->march_counters_on = enable & 3;  // bit 0: work counters, bit 1: per-trip event timing
+    f->march_counters_on = enable & 7;  // bit 0: work counters, bit 1: per-trip event timing, bit 2: phase clocks of the fused launches
+    return PN_OK;
+}
+
+// Phase clocks of the fused launches on `f` (march_counters bit 2): shader-clock cycles summed over waves for {refill, march window round, 64-lane
+// windows, network, composite}, wave-rounds, waves; first_trip_out: the trip the last render started fusing at (-1: it did not).  reset != 0 zeroes them.
+extern "C" int pn_frame_fused_clocks(pn_frame* f, uint64_t* clocks_host, int* first_trip_out, int reset, void* stream) {
+    PN_REQUIRE(f);
+    hipStream_t st = (hipStream_t)stream;
+    if (clocks_host) {
+        PN_HIP_CHECK(hipMemcpyAsync(clocks_host, f->fused_clocks, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        PN_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    if (first_trip_out) *first_trip_out = f->fused_first;
+    if (reset) PN_HIP_CHECK(hipMemsetAsync(f->fused_clocks, 0, 8 * sizeof(unsigned long long), st));
     return PN_OK;
 }
 

@@ -1,0 +1,306 @@
+// Every loop trip after the first ones of a deformed frame as ONE launch (gfx950).  Included by pn_render_ops.hip behind composite_one / pn_frame.
+//
+// The reference's render loop (nerf/renderer.py:836-891) is, per trip: march n_step samples for every alive ray -> network on all samples -> composite
+// -> rays_alive = rays_alive[rays_alive >= 0], with n_step = max(min(N // n_alive, 8), 1).  Rounds 1-3 ran that as 4-6 launches per trip (march pass,
+// wave-per-ray tail pass, network, composite + compaction), 5-7 trips per frame: each launch fills the GPU for a fraction of its duration (a trip's tail
+// pass: 35 us for a few hundred rays), every trip pays the latency of its slowest ray three times over, and ~45 launch boundaries sit on a frame's chain.
+//
+// What couples the rays of a trip is ONLY n_step — and once n_alive <= N / 8 it is 8 for the rest of the frame, because n_alive never grows.  From that
+// trip on every ray can run its own loop { march 8 samples; network; composite } until it dies or reaches max_steps, with no global step in between and no
+// compaction at all: exactly the reference's arithmetic per ray (the march restarts from the rays_t the composite accumulated, eight samples at a time,
+// as in the per-trip launches), so samples, pixels and per-trip counts are those of the trip-by-trip loop bit for bit (tests: every frame test compares
+// the two forms through the oracle / the reference's own kernels; test_gpu_fused.py compares them directly).
+//
+// k_trips_fused: persistent workgroups of PN_FUSED_WAVES waves, one per CU.  A wave holds 8 rays, 8 lanes each (pn_march3.h: march_window<K, MULTI, 8>);
+// per round it
+//   1. refills the groups whose ray has died from the trip's alive list (64 segment cursors, one returning atomic per wave and refill),
+//   2. marches 8 samples per ray into the wave's own 64 sample slots — one window round; a ray still going after it (1 % of them: it grazes the object or
+//      has left it) is walked on by the whole wave in 64-element windows (march_window<K, MULTI, 64>: what k_march_tail does in the per-trip form),
+//   3. runs the network on its 64 slots (two 32-sample tiles of pn_net_tile.h: the LDS weight image is shared by the workgroup),
+//   4. composites its 8 rays (composite_one, one lane per ray) and keeps the survivors for the next round.
+// Waves in the march phase (chains of dependent VALU instructions) and waves in the network phase (gathers + MFMA) share a SIMD: what three render
+// lanes did for each other in the pipelined harness happens inside one launch.  Per-trip bookkeeping (rays entering each trip, samples emitted, rays that
+// needed the wave-per-ray windows) is counted in LDS, flushed once per workgroup, and the LAST workgroup to finish turns the counts into the trip
+// records the per-trip launches would have written (PnTrip) — frame statistics, trip-record tests and pn_render_continue see no difference.
+//
+// Precondition, checked on the device: the record of the first fused trip says n_step == 8 (and dense).  If not (a scene with more than N / 8 rays alive
+// after the classic trips) the kernel does nothing and the frame is left unfinished exactly like a captured render that ran out of trips: the caller
+// continues it (pn_render_continue / the blocking driver's own loop, which runs one more classic trip and tries again).
+#pragma once
+#define PN_TU_FP_CONTRACT_OFF 1  // this header lives in pn_render_ops.hip (-ffp-contract=off); pn_net_tile.h contracts inside itself and switches back
+#include "pn_net_tile.h"
+
+#define PN_FUSED_MAX_TRIPS 128  // fused trips per frame: (max_steps - 1) / 8 for max_steps <= 1024
+#ifndef PN_FUSED_WAVES
+#define PN_FUSED_WAVES 8        // waves per workgroup (one workgroup per CU: 61 KB weight image + 12 KB of march staging per wave)
+#endif
+// control block of a frame's fused launch, ints: [PN_SEGS cursors, one per 128 B][3 x PN_FUSED_MAX_TRIPS counters][workgroups done]; all zero at launch
+#define PN_FUSED_CTL_HIST (PN_SEGS * PN_SEG_STRIDE)
+#define PN_FUSED_CTL_DONE (PN_FUSED_CTL_HIST + 3 * PN_FUSED_MAX_TRIPS)
+#define PN_FUSED_CTL_INTS (PN_FUSED_CTL_DONE + 32)
+
+struct FusedArgs {
+    // network (pn_net)
+    const PnFusedLevel* lv;
+    const float* emb;
+    const uint32_t* emb_h;
+    uint32_t emb_bytes;
+    const uint4* wimg_g;  // the LDS weight image in global memory (wsplit / whalf)
+    float net_bound, density_scale;
+    // frame
+    PnTrip* trips;  // record of the first fused trip
+    uint32_t N_rays, max_steps;
+    float T_thresh;
+    const int* alive;  // that trip's alive list
+    float *rays_t, *weights_sum, *depth, *image;
+    float *xyzs, *dirs, *deltas, *sigmas, *rgbs;  // sample slots: 64 per wave of the launch
+    int* ctl;
+    PnFrameDev* dev;
+    int* tail_diag;              // per-trip diagnostics (rays that needed the 64-lane windows), aligned with `trips`
+    unsigned long long* clocks;  // optional [8]: shader-clock cycles per phase summed over waves (refill, march, windows, network, composite), wave-rounds, waves
+};
+
+__device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+template <int K, bool MULTI, bool HALF>
+__global__ void __launch_bounds__(PN_FUSED_WAVES * 64, PN_FUSED_WAVES / 4) k_trips_fused(pnm::MarchParams a, pnm2::March2Tables tb, FusedArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) uint4 fused_lds[];
+    constexpr int IMG16 = (HALF ? PN_NET_HALF_BYTES : PN_NET_SPLIT_BYTES) / 16;
+    constexpr int MAXT = PN_FUSED_MAX_TRIPS;
+    uint4* wimg = fused_lds;  // the weight image, then the 16 level records (512 B), as in k_nerf_forward
+    float4* stage_all = reinterpret_cast<float4*>(fused_lds + IMG16 + 32);
+    int* hist = reinterpret_cast<int*>(stage_all + PN_FUSED_WAVES * PN_STAGE_CAP);  // [3][MAXT]: rays entering trip j, samples emitted, rays through the 64-lane windows
+    __shared__ int s_last;
+
+    const PnTrip* tr = fa.trips;
+    const int A = tr->n_alive, sb0 = tr->step_base;
+    if (!(A > 0 && tr->n_step == 8 && tr->dense != 0)) return;  // nothing to do / not applicable: the records stay as they are (see the header comment)
+
+    for (int i = threadIdx.x; i < IMG16; i += PN_FUSED_WAVES * 64) wimg[i] = fa.wimg_g[i];
+    if (threadIdx.x < 16 * sizeof(PnFusedLevel) / 16) wimg[IMG16 + threadIdx.x] = reinterpret_cast<const uint4*>(fa.lv)[threadIdx.x];
+    for (int i = threadIdx.x; i < 3 * MAXT; i += PN_FUSED_WAVES * 64) hist[i] = 0;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sub = lane & 7, gbase = lane & ~7, grp = lane >> 3;
+    const uint32_t wave_g = blockIdx.x * PN_FUSED_WAVES + wv;
+    const uint32_t slotw = wave_g * 64u, slot0 = slotw + (uint32_t)grp * 8u;
+    float4* stage = stage_all + wv * PN_STAGE_CAP;
+    const uint4* __restrict__ wl = wimg + lane;
+    const int half = lane >> 5, s32 = lane & 31;
+    const PnFusedLevel* lds_lv = reinterpret_cast<const PnFusedLevel*>(wimg + IMG16) + 8 * half;
+    __amdgpu_buffer_rsrc_t emb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(fa.emb_h), 0, (int)fa.emb_bytes, 0x00020000);
+    float* const X = fa.xyzs + (size_t)slot0 * 3;
+    float* const Dd = fa.dirs + (size_t)slot0 * 3;
+    float* const dl = fa.deltas + (size_t)slot0 * 2;
+
+    // the alive list in PN_SEGS contiguous segments of `per` entries (a multiple of 8: a wave's 8 rays are neighbours in the list, i.e. pixels of one tile)
+    const int per = (((A + PN_SEGS - 1) / PN_SEGS) + 7) & ~7;
+    int seg = (int)(wave_g % PN_SEGS), seg_dead = 0;
+    int index = -1;  // this group's ray (the same on its 8 lanes), -1: none
+    int j = 0;       // trips it has been through in this launch
+    const bool clk = fa.clocks != nullptr;
+    unsigned long long c_acc[5] = {0, 0, 0, 0, 0}, c_t = 0, rounds = 0;
+    auto tick = [&](int k) {
+        if (clk) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned long long n = __builtin_readcyclecounter();
+            c_acc[k] += n - c_t;
+            c_t = n;
+        }
+    };
+    if (clk) c_t = __builtin_readcyclecounter();
+
+    for (;;) {
+        // ---- 1. refill the groups without a ray
+        {
+            const unsigned long long em = __ballot(index < 0 && sub == 0);
+            const int need = (int)__popcll(em);
+            const int my_rank = (int)__popcll(em & ((1ull << gbase) - 1ull));
+            int taken = 0, newpos = -1;
+            while (taken < need && seg_dead < PN_SEGS) {
+                const int want = need - taken;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(fa.ctl + seg * PN_SEG_STRIDE, want);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int seg_b = seg * per, seg_e = min(seg_b + per, A);
+                const int got = max(min(seg_e - (seg_b + base), want), 0);
+                if (index < 0 && my_rank >= taken && my_rank < taken + got) newpos = seg_b + base + (my_rank - taken);
+                taken += got;
+                if (got < want) { seg = (seg + 1) % PN_SEGS; seg_dead++; }  // this segment is used up
+            }
+            if (newpos >= 0) { index = fa.alive[newpos]; j = 0; }
+        }
+        if (!__any(index >= 0)) break;
+        rounds++;
+        tick(0);
+        // ---- 2. march: one window round of 8 lanes per ray, then the rays still going with the whole wave
+        const bool have_ray = index >= 0;
+        if (have_ray && sub == 0) atomicAdd(&hist[j], 1);
+        pnm3::RayConsts c;
+        c.ox = c.oy = c.oz = 0.f; c.dx = c.dy = c.dz = 1.f; c.rdx = c.rdy = c.rdz = 1.f; c.far = 0.f;
+        pnm3::RayState st{0.f, 0.f, 0u};
+        bool have = false;
+        if (have_ray) {
+            pnm3::ray_consts(a, index, c);
+            have = pnm3::ray_start(a, c, index, 0.0f, nullptr, st);
+        } else {
+            pnm3::frame_consts(a, c);
+        }
+        const bool done = pnm3::march_window<K, MULTI, 8>(a, tb, c, 8u, sub, gbase, lane, stage, X, Dd, dl, st, 1, have);
+        const bool deferred = have && !done;
+        tick(1);
+        unsigned long long dm = __ballot(deferred && sub == 0);
+        if (deferred && sub == 0) atomicAdd(&hist[2 * MAXT + j], 1);
+        while (dm) {
+            const int L = (int)__builtin_ctzll(dm);
+            dm &= dm - 1ull;
+            pnm3::RayConsts c2;
+            pnm3::frame_consts(a, c2);
+            c2.ox = readlane_f(c.ox, L); c2.oy = readlane_f(c.oy, L); c2.oz = readlane_f(c.oz, L);
+            c2.dx = readlane_f(c.dx, L); c2.dy = readlane_f(c.dy, L); c2.dz = readlane_f(c.dz, L);
+            c2.rdx = readlane_f(c.rdx, L); c2.rdy = readlane_f(c.rdy, L); c2.rdz = readlane_f(c.rdz, L);
+            c2.far = readlane_f(c.far, L);
+            pnm3::RayState s2{readlane_f(st.t, L), readlane_f(st.last_t, L), (uint32_t)__builtin_amdgcn_readlane((int)st.step, L)};
+            const size_t sl = (size_t)slotw + (size_t)(L >> 3) * 8;
+            pnm3::march_window<K, MULTI, 64>(a, tb, c2, 8u, lane, 0, lane, stage, fa.xyzs + sl * 3, fa.dirs + sl * 3, fa.deltas + sl * 2, s2, 0x7fffffff, true);
+            if (gbase == L) st.step = s2.step;
+        }
+        const uint32_t emitted = have_ray ? st.step : 0u;
+        if (have_ray && sub == 0 && emitted) {
+            atomicAdd(&hist[MAXT + j], (int)emitted);
+            if (a.stats) atomicAdd(a.stats + 3, (unsigned long long)emitted);
+        }
+        // slots the ray did not fill end it in the composite (delta == 0); they run through the network like the dense trips' (zero position)
+        if (have_ray && (uint32_t)sub >= emitted) {
+            dl[2 * sub] = 0.0f; dl[2 * sub + 1] = 0.0f;
+            X[3 * sub] = X[3 * sub + 1] = X[3 * sub + 2] = 0.0f;
+            Dd[3 * sub] = Dd[3 * sub + 1] = Dd[3 * sub + 2] = 0.0f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the wave's own stores before its own loads of the same slots by other lanes
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        tick(2);
+        // ---- 3. network on the wave's 64 slots: tile 0 = groups 0..3, tile 1 = groups 4..7
+        const unsigned long long rm = __ballot(have_ray);
+#pragma unroll 1
+        for (int tile = 0; tile < 2; tile++) {
+            if (!((rm >> (32 * tile)) & 0xFFFFFFFFull)) continue;
+            const uint32_t slot = slotw + 32u * (uint32_t)tile + (uint32_t)s32;
+            const pnm3::Float3 p = *reinterpret_cast<const pnm3::Float3*>(fa.xyzs + (size_t)slot * 3), d = *reinterpret_cast<const pnm3::Float3*>(fa.dirs + (size_t)slot * 3);
+            float sigma_logit, e[3];
+            if (HALF) {
+                float g2[8];
+                tile_sigma_net_h<4>(fa.lv, wimg, emb_rsrc, wl, half, fa.net_bound, p.x, p.y, p.z, g2);
+                sigma_logit = g2[0];
+                __builtin_amdgcn_sched_barrier(0);
+                tile_color_net_h(wl, wimg, half, g2, d.x, d.y, d.z, e);
+            } else {
+                const f32x16 h2 = tile_sigma_net<PN_BF_LU>(fa.lv, lds_lv, fa.emb, wl, half, fa.net_bound, p.x, p.y, p.z);
+                sigma_logit = h2[0];
+                __builtin_amdgcn_sched_barrier(0);
+                tile_color_net(wl, wimg, half, h2, d.x, d.y, d.z, e);
+            }
+            if (half == 0) {
+                fa.sigmas[slot] = tile_sigma_out(fa.density_scale, sigma_logit);
+#pragma unroll
+                for (int o = 0; o < 3; o++) fa.rgbs[(size_t)slot * 3 + o] = HALF ? tile_rgb_out_h(e[o]) : tile_rgb_out(e[o]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        tick(3);
+        // ---- 4. composite (kernel_composite_rays, raymarching.cu:827-923): one lane per ray; a ray goes on iff it used all 8 samples
+        int alive = 0;
+        if (have_ray && sub == 0)
+            alive = composite_one(index, slot0, 8u, fa.T_thresh, fa.rays_t, fa.sigmas, fa.rgbs, fa.deltas, fa.weights_sum, fa.depth, fa.image) ? 1 : 0;
+        alive = __shfl(alive, gbase);
+        if (have_ray) {
+            // renderer.py:836: the loop ends when `step` reaches max_steps, whatever is still alive
+            if (alive && (uint32_t)(sb0 + 8 * (j + 1)) < fa.max_steps && j + 1 < MAXT) j++;
+            else index = -1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rays_t of a surviving ray is read back by the next round's ray_start
+        tick(4);
+    }
+    if (clk && lane == 0) {
+        for (int k = 0; k < 5; k++) atomicAdd(fa.clocks + k, c_acc[k]);
+        atomicAdd(fa.clocks + 5, rounds);
+        atomicAdd(fa.clocks + 6, 1ull);
+    }
+
+    // ---- end of the launch: per-trip counts to memory; the last workgroup writes the trip records and re-arms the control block
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * MAXT; i += PN_FUSED_WAVES * 64) {
+        const int v = hist[i];
+        if (v) atomicAdd(fa.ctl + PN_FUSED_CTL_HIST + i, v);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the counts are at the memory side before this workgroup reports in
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int old = atomicAdd(fa.ctl + PN_FUSED_CTL_DONE, 1);
+        s_last = (old == (int)gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    int m = 0;
+    for (int j0 = 0; j0 < MAXT; j0 += 64) {
+        const int jj = j0 + lane;
+        int* hp = fa.ctl + PN_FUSED_CTL_HIST + jj;
+        const int al = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int em = __hip_atomic_load(hp + MAXT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int tl = __hip_atomic_load(hp + 2 * MAXT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        m += (int)__popcll(__ballot(al > 0));
+        if (al > 0) {
+            PnTrip* r = fa.trips + jj;
+            if (jj > 0) { r->n_alive = al; r->n_step = 8; r->step_base = sb0 + 8 * jj; r->dense = 1; r->n_samples = al * 8; }
+            r->n_emitted = em;
+            fa.tail_diag[jj] = tl;
+        }
+        __hip_atomic_store(hp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(hp + MAXT, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(hp + 2 * MAXT, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __hip_atomic_store(fa.ctl + lane * PN_SEG_STRIDE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // PN_SEGS == 64 cursors
+    if (lane == 0) {
+        PnTrip* r = fa.trips + m;  // the record behind the last trip that had rays: the frame is over
+        r->n_alive = 0; r->n_step = 1; r->step_base = sb0 + 8 * m; r->dense = 0; r->n_samples = 0; r->n_emitted = 0;
+        fa.dev->fused_trips = m;
+        __hip_atomic_store(fa.ctl + PN_FUSED_CTL_DONE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+static size_t fused_lds_bytes(bool half) {
+    return (size_t)(half ? PN_NET_HALF_BYTES : PN_NET_SPLIT_BYTES) + 16 * sizeof(PnFusedLevel) + (size_t)PN_FUSED_WAVES * PN_STAGE_CAP * sizeof(float4) +
+           3 * PN_FUSED_MAX_TRIPS * sizeof(int);
+}
+
+template <int K, bool MULTI, bool HALF>
+static int launch_trips_fused_t(uint32_t blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb, const FusedArgs& fa) {
+    const size_t lds = fused_lds_bytes(HALF);
+    static bool granted[PN_MAX_DEVICES] = {false};  // dynamic LDS above 64 KB is opted into per function and DEVICE
+    int dev_id = 0;
+    PN_HIP_CHECK(hipGetDevice(&dev_id));
+    if (dev_id < 0 || dev_id >= PN_MAX_DEVICES || !granted[dev_id]) {
+        PN_HIP_CHECK(hipFuncSetAttribute((const void*)k_trips_fused<K, MULTI, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev_id >= 0 && dev_id < PN_MAX_DEVICES) granted[dev_id] = true;
+    }
+    k_trips_fused<K, MULTI, HALF><<<blocks, PN_FUSED_WAVES * 64, lds, st>>>(a, tb, fa);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+static int launch_trips_fused(int K, bool multi, bool half, uint32_t blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb,
+                              const FusedArgs& fa) {
+#define PN_FUSED_CASE(K_)                                                                                                   \
+    if (K == K_) {                                                                                                            \
+        if (multi) return half ? launch_trips_fused_t<K_, true, true>(blocks, st, a, tb, fa) : launch_trips_fused_t<K_, true, false>(blocks, st, a, tb, fa); \
+        return half ? launch_trips_fused_t<K_, false, true>(blocks, st, a, tb, fa) : launch_trips_fused_t<K_, false, false>(blocks, st, a, tb, fa);          \
+    }
+    PN_FUSED_CASE(1)
+    PN_FUSED_CASE(2)
+    PN_FUSED_CASE(3)
+#undef PN_FUSED_CASE
+    return PN_ERR_ARG;
+}

@@ -117,6 +117,7 @@ class NeRFRenderer(nn.Module):
         if tw is None and n_rays and kwargs.get("W") and kwargs.get("H") and int(kwargs["W"]) * int(kwargs["H"]) == n_rays:
             tw = kwargs["W"]
         o.ray_tile_w = int(tw or 0)
+        o.fused_from = int(kwargs.get("fused_from") or 0)  # extension: first loop trip of the one-launch form (pn_render_opts.fused_from; 0: trip 1, < 0: never)
         return o
 
     def rund_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-2, **kwargs):
@@ -206,6 +207,14 @@ class NeRFRenderer(nn.Module):
         out = (C.c_uint64 * 4)() if read else None
         check(lib().pn_frame_march_counters(self._frames[slot][0], int(enable), out, stream_ptr()), "march_counters")
         return None if out is None else dict(iterations=int(out[0]), candidates=int(out[1]), warps=int(out[2]), samples=int(out[3]))
+
+    def fused_clocks(self, slot=0, reset=False):
+        """Phase clocks of the fused later-trips launches on `slot` (march_counters(4)): dict of cycles summed over waves + the trip the last render
+        switched to the fused launch at (-1: it did not)."""
+        out, first = (C.c_uint64 * 8)(), C.c_int(-1)
+        check(lib().pn_frame_fused_clocks(self._frames[slot][0], out, C.byref(first), int(bool(reset)), stream_ptr()), "fused_clocks")
+        return dict(refill=int(out[0]), march=int(out[1]), windows=int(out[2]), network=int(out[3]), composite=int(out[4]), wave_rounds=int(out[5]),
+                    waves=int(out[6]), first_trip=int(first.value))
 
     def trip_records(self, slot=0, max_trips=16):
         """Diagnostics: [(n_alive, n_step, step_base, n_samples, n_emitted, n_tail)] per trip of the last render on `slot`."""

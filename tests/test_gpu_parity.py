@@ -389,7 +389,8 @@ def test_graph_replay_equals_eager_steps(small_cloud, small_opt, ckpt):
     st = graph.model.render_status()
     assert st["alive_at_exit"] == 0 and st["err"] == 0 and st["trips"] >= 3
     # too few captured trips: the frame is finished with further trips (renderer.py:836-891 has no trip limit), bit-identical to the eager frame
-    short = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture(n_trips=1)
+    # (fused_from = -1: trip-by-trip launches only — with the later trips as one launch, pn_render_opts.fused_from, one captured trip is enough)
+    short = SimRenderHarness(dict(opt, fused_from=-1), cloud=small_cloud, ckpt=ckpt, device=DEV).capture(n_trips=1)
     fresh = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV)
     for frame in range(3):
         a = fresh.step()
@@ -413,8 +414,11 @@ def test_pipelined_frames_equal_eager_steps(small_cloud, small_opt, ckpt, lanes,
 
     def keep_device_copy(frame, res):   # runs when the frame is complete, before its workspace is reused
         dev_copies[frame] = res["device"]["image"].clone()
+    # a trip count that is too small only matters to the trip-by-trip launches: those cases run with fused_from = -1, the others with the later trips
+    # as one launch (pn_render_opts.fused_from, picked by the harness)
     pipe = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture_pipelined(lanes=lanes, depth=depth, n_trips=trips, sim_ahead=ahead,
-                                                                                             on_retire=keep_device_copy)
+                                                                                             on_retire=keep_device_copy,
+                                                                                             render_kw=(dict(fused_from=-1) if trips in (2, 3) else None))
     n_frames = 9
     poses = [scene.orbit_pose(opt["radius"], 7.0 * f, -3.0 * f) for f in range(n_frames)]
     want = []
