@@ -343,8 +343,9 @@ int pn_density_grid_update(uint32_t n, float* density_grid, const float* tmp_gri
  * 0 switches all off.  counters_host (uint64[4], may be NULL): synchronises and reads the totals accumulated so far
  * (before any re-zeroing caused by enabling). */
 int pn_frame_march_counters(pn_frame* f, int enable, uint64_t* counters_host, void* stream);
-/* With bit 2: clocks_host (uint64[8], may be NULL; synchronises) = cycles summed over the waves of the fused launches on f since the last reset for
- * {hand-out of rays, march (8-lane window round), march (64-lane windows of the rays still going), network, composite}, then wave-rounds, waves, 0;
+/* With bit 2: clocks_host (uint64[16], may be NULL; synchronises) = cycles summed over the waves of the fused launches on f since the last reset for
+ * {hand-out of rays, march (8-lane window round), march (64-lane windows of the rays still going), network, composite}, then wave-rounds, waves,
+ * wave lifetimes in 100 MHz ticks (sum), the largest round count and the longest lifetime of a wave, 0...;
  * *first_trip_out (may be NULL) = the trip at which the last render on f switched to the fused launch, -1 if it did not.  reset != 0: zero the sums. */
 int pn_frame_fused_clocks(pn_frame* f, uint64_t* clocks_host, int* first_trip_out, int reset, void* stream);
 /* With bit 1 of `enable` set: the per-trip durations (ms, HIP events on the launch stream) of the last blocking render:

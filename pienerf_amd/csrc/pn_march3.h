@@ -553,6 +553,7 @@ __device__ __forceinline__ void point_cell(const MarchParams& a, const March2Tab
 __device__ __forceinline__ void glds16(const float4* g, float4* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
+template <int CAP = PN_STAGE_CAP>
 __device__ __forceinline__ int stage_lists(float4* stage, const float4* __restrict__ nb, int b, int len, int lane) {
     int my_off = -1;
     int cursor = 0;
@@ -562,7 +563,7 @@ __device__ __forceinline__ int stage_lists(float4* stage, const float4* __restri
         const int lb = __builtin_amdgcn_readlane(b, leader), ll = __builtin_amdgcn_readlane(len, leader);
         const bool mine = len > 0 && b == lb;
         todo &= ~__ballot(mine);
-        if (cursor + ll > PN_STAGE_CAP) continue;
+        if (cursor + ll > CAP) continue;
         if (mine) my_off = cursor;
         for (int i0 = 0; i0 < ll; i0 += 64)
             if (i0 + lane < ll) glds16(nb + lb + i0 + lane, stage + cursor + i0);
@@ -673,11 +674,11 @@ __device__ __forceinline__ void eval_scan(const MarchParams& a, const March2Tabl
 // (the candidate lists staged there have been consumed by then).
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
-template <int K>
+template <int K, int SPLIT = PN_HEAD_SPLIT>
 __device__ __forceinline__ void head_fetch(float4* stage, const float4* __restrict__ rec, const int (&ips)[3], int lane, float4 (&rh)[3][4]) {
     const int q = lane & 3;
-    // PN_HEAD_SPLIT = 1: the first two records, then the third, through the same 8 KB (one more round trip per round, a third less LDS per wave)
-    constexpr int K0 = (PN_HEAD_SPLIT && K > 2) ? 2 : K;
+    // SPLIT = 1: the first two records, then the third, through the same 8 KB (one more round trip per round, a third less LDS per wave)
+    constexpr int K0 = (SPLIT && K > 2) ? 2 : K;
 #pragma unroll
     for (int pass = 0; pass < ((K0 < K) ? 2 : 1); pass++) {
         const int kb = pass ? K0 : 0, ke = pass ? K : K0;
@@ -792,8 +793,9 @@ __device__ __forceinline__ void eval_point(const MarchParams& a, const March2Tab
 // Returns true when the ray is done for this trip (t >= far, or n_step samples), false when the round budget ran out; `st` is
 // advanced either way (identically on all G lanes).  Samples go to xyzs/dirs/deltas[slot], slot = number emitted before.
 // Called by ALL 64 lanes of the wave (have_ray = false for the lanes of a group without a ray): the round loop is wave-uniform so that
-// the candidate lists of a round can be staged cooperatively (stage_lists) in `stage`, the wave's PN_STAGE_CAP entries of LDS.
-template <int K, bool MULTI, int G>
+// the candidate lists of a round can be staged cooperatively (stage_lists) in `stage`, the wave's CAP entries of LDS (CAP >= 512; below 768 the three
+// record heads of a lane go through it in two passes: SPLIT).
+template <int K, bool MULTI, int G, int CAP = PN_STAGE_CAP, int SPLIT = PN_HEAD_SPLIT>
 __device__ inline bool march_window(const MarchParams& a, const March2Tables& tb, const RayConsts& c, uint32_t n_step, int sub, int gbase, int lane,
                                     float4* stage, float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, RayState& st,
                                     int max_rounds, bool have_ray PN_PHASE_ARG) {
@@ -843,7 +845,7 @@ __device__ inline bool march_window(const MarchParams& a, const March2Tables& tb
         // it) needs no lists, no scan and no record heads: what is left of the round is the voxel arithmetic and the chain
         const bool any_list = __any(pc.e != pc.b);
         int my_off = -1;
-        if (any_list) my_off = stage_lists(stage, tb.nb, pc.b, pc.e - pc.b, lane);
+        if (any_list) my_off = stage_lists<CAP>(stage, tb.nb, pc.b, pc.e - pc.b, lane);
         PN_PHASE(pk, 2);
         PointEval ev;
         ev.emit = false; ev.oob = false; ev.tt = 0.f; ev.dt = 0.f; ev.x = ev.y = ev.z = 0.f; ev.n_cand = 0; ev.n_warp = 0;
@@ -856,7 +858,7 @@ __device__ inline bool march_window(const MarchParams& a, const March2Tables& tb
             for (int u = 0; u < 4; u++) rh[k][u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (any_list) {
             if (go && active) eval_scan<K>(a, tb, pc, stage, my_off, ips, n_cand);
-            head_fetch<K>(stage, tb.rec, ips, lane, rh);
+            head_fetch<K, SPLIT>(stage, tb.rec, ips, lane, rh);
         }
         if (go && active) eval_point<K, MULTI>(a, tb, c, s, pc, ips, rh, n_cand, ev);
         PN_PHASE(pk, 3);

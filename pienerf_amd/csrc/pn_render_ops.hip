@@ -1942,8 +1942,8 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
     PN_ALLOC(f->xyzs, NS * 12); PN_ALLOC(f->dirs, NS * 12); PN_ALLOC(f->deltas, NS * 8); PN_ALLOC(f->sigmas, NS * 4); PN_ALLOC(f->rgbs, NS * 12);
     PN_ALLOC(f->fused_ctl, (size_t)PN_FUSED_CTL_INTS * 4);
     PN_HIP_CHECK(hipMemset(f->fused_ctl, 0, (size_t)PN_FUSED_CTL_INTS * 4));
-    PN_ALLOC(f->fused_clocks, 8 * sizeof(unsigned long long));
-    PN_HIP_CHECK(hipMemset(f->fused_clocks, 0, 8 * sizeof(unsigned long long)));
+    PN_ALLOC(f->fused_clocks, 16 * sizeof(unsigned long long));
+    PN_HIP_CHECK(hipMemset(f->fused_clocks, 0, 16 * sizeof(unsigned long long)));
     f->fused_first = -1;
     PN_ALLOC(f->acc_image, N * 12);
     PN_ALLOC(f->alive_a, N * 4); PN_ALLOC(f->alive_b, N * 4); PN_ALLOC(f->list, N * 4); PN_ALLOC(f->chunk_counts, (N / 256 + 4) * 4);
@@ -2357,11 +2357,11 @@ extern "C" int pn_frame_fused_clocks(pn_frame* f, uint64_t* clocks_host, int* fi
     PN_REQUIRE(f);
     hipStream_t st = (hipStream_t)stream;
     if (clocks_host) {
-        PN_HIP_CHECK(hipMemcpyAsync(clocks_host, f->fused_clocks, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        PN_HIP_CHECK(hipMemcpyAsync(clocks_host, f->fused_clocks, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         PN_HIP_CHECK(hipStreamSynchronize(st));
     }
     if (first_trip_out) *first_trip_out = f->fused_first;
-    if (reset) PN_HIP_CHECK(hipMemsetAsync(f->fused_clocks, 0, 8 * sizeof(unsigned long long), st));
+    if (reset) PN_HIP_CHECK(hipMemsetAsync(f->fused_clocks, 0, 16 * sizeof(unsigned long long), st));
     return PN_OK;
 }
 

@@ -13,7 +13,7 @@
 //
 // k_trips_fused: persistent workgroups of PN_FUSED_WAVES waves, one per CU.  A wave holds 8 rays, 8 lanes each (pn_march3.h: march_window<K, MULTI, 8>);
 // per round it
-//   1. refills the groups whose ray has died from the trip's alive list (64 segment cursors, one returning atomic per wave and refill),
+//   1. refills the groups whose ray has died from its workgroup's share of the trip's alive list (packets of 8 dealt round-robin; an LDS cursor),
 //   2. marches 8 samples per ray into the wave's own 64 sample slots — one window round; a ray still going after it (1 % of them: it grazes the object or
 //      has left it) is walked on by the whole wave in 64-element windows (march_window<K, MULTI, 64>: what k_march_tail does in the per-trip form),
 //   3. runs the network on its 64 slots (two 32-sample tiles of pn_net_tile.h: the LDS weight image is shared by the workgroup),
@@ -32,10 +32,11 @@
 
 #define PN_FUSED_MAX_TRIPS 128  // fused trips per frame: (max_steps - 1) / 8 for max_steps <= 1024
 #ifndef PN_FUSED_WAVES
-#define PN_FUSED_WAVES 8        // waves per workgroup (one workgroup per CU: 61 KB weight image + 12 KB of march staging per wave)
+#define PN_FUSED_WAVES 12       // waves per workgroup, one workgroup per CU = 3 waves per SIMD: 61 KB weight image + 8 KB of march staging per wave
 #endif
-// control block of a frame's fused launch, ints: [PN_SEGS cursors, one per 128 B][3 x PN_FUSED_MAX_TRIPS counters][workgroups done]; all zero at launch
-#define PN_FUSED_CTL_HIST (PN_SEGS * PN_SEG_STRIDE)
+#define PN_FUSED_STAGE 512      // staging entries per wave (the record heads of a round go through it in two passes: pn_march3.h, SPLIT)
+// control block of a frame's fused launch, ints: [3 x PN_FUSED_MAX_TRIPS counters][workgroups done]; all zero at launch
+#define PN_FUSED_CTL_HIST 0
 #define PN_FUSED_CTL_DONE (PN_FUSED_CTL_HIST + 3 * PN_FUSED_MAX_TRIPS)
 #define PN_FUSED_CTL_INTS (PN_FUSED_CTL_DONE + 32)
 
@@ -57,20 +58,67 @@ struct FusedArgs {
     int* ctl;
     PnFrameDev* dev;
     int* tail_diag;              // per-trip diagnostics (rays that needed the 64-lane windows), aligned with `trips`
-    unsigned long long* clocks;  // optional [8]: shader-clock cycles per phase summed over waves (refill, march, windows, network, composite), wave-rounds, waves
+    unsigned long long* clocks;  // optional [16]: shader-clock cycles per phase summed over waves (refill, march, windows, network, composite), wave-rounds, waves
 };
+
+// composite_one (kernel_composite_rays, raymarching.cu:827-923) for the 8 slots of one ray of the fused launch: the same operations in the same order,
+// with the eight samples' sigma / rgb / deltas requested up front (one memory round trip instead of one per sample: a lone lane waiting for each
+// was 12 000 cycles of every wave-round) and the ray's t carried in a register (`t` in: rays_t; out: t behind the last composited sample).
+__device__ __forceinline__ bool composite_slots8(int index, uint32_t slot0, float T_thresh, float& t, float* rays_t, const float* __restrict__ sigmas,
+                                                 const float* __restrict__ rgbs, const float* __restrict__ deltas, float* weights_sum, float* depth,
+                                                 float* image) {
+    float sg[8], d0[8], d1[8], cr[8], cg[8], cb[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        sg[k] = sigmas[slot0 + k];
+        const float2 dd = *reinterpret_cast<const float2*>(deltas + (size_t)(slot0 + k) * 2);
+        d0[k] = dd.x; d1[k] = dd.y;
+        const pnm3::Float3 c3 = *reinterpret_cast<const pnm3::Float3*>(rgbs + (size_t)(slot0 + k) * 3);
+        cr[k] = c3.x; cg[k] = c3.y; cb[k] = c3.z;
+    }
+    float ws = weights_sum[index], d = depth[index];
+    float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
+    bool go = true;
+    int step = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (go) {
+            if (d0[k] == 0) {
+                go = false;
+            } else {
+                const float alpha = 1.0f - __expf(-sg[k] * d0[k]);
+                const float T = 1 - ws;
+                const float w = alpha * T;
+                ws += w;
+                t += d1[k];
+                d += w * t;
+                r += w * cr[k];
+                g += w * cg[k];
+                b += w * cb[k];
+                if (T < T_thresh) go = false;
+                else step++;
+            }
+        }
+    }
+    const bool alive = step == 8;
+    if (alive) rays_t[index] = t;
+    weights_sum[index] = ws;
+    depth[index] = d;
+    image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+    return alive;
+}
 
 __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 template <int K, bool MULTI, bool HALF>
-__global__ void __launch_bounds__(PN_FUSED_WAVES * 64, PN_FUSED_WAVES / 4) k_trips_fused(pnm::MarchParams a, pnm2::March2Tables tb, FusedArgs fa) {
+__global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4) k_trips_fused(pnm::MarchParams a, pnm2::March2Tables tb, FusedArgs fa) {
     extern __shared__ __attribute__((aligned(16))) uint4 fused_lds[];
     constexpr int IMG16 = (HALF ? PN_NET_HALF_BYTES : PN_NET_SPLIT_BYTES) / 16;
     constexpr int MAXT = PN_FUSED_MAX_TRIPS;
     uint4* wimg = fused_lds;  // the weight image, then the 16 level records (512 B), as in k_nerf_forward
     float4* stage_all = reinterpret_cast<float4*>(fused_lds + IMG16 + 32);
-    int* hist = reinterpret_cast<int*>(stage_all + PN_FUSED_WAVES * PN_STAGE_CAP);  // [3][MAXT]: rays entering trip j, samples emitted, rays through the 64-lane windows
-    __shared__ int s_last;
+    int* hist = reinterpret_cast<int*>(stage_all + PN_FUSED_WAVES * PN_FUSED_STAGE);  // [3][MAXT]: rays entering trip j, samples emitted, rays through the 64-lane windows
+    __shared__ int s_last, s_cursor;
 
     const PnTrip* tr = fa.trips;
     const int A = tr->n_alive, sb0 = tr->step_base;
@@ -79,13 +127,14 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, PN_FUSED_WAVES / 4) k_tri
     for (int i = threadIdx.x; i < IMG16; i += PN_FUSED_WAVES * 64) wimg[i] = fa.wimg_g[i];
     if (threadIdx.x < 16 * sizeof(PnFusedLevel) / 16) wimg[IMG16 + threadIdx.x] = reinterpret_cast<const uint4*>(fa.lv)[threadIdx.x];
     for (int i = threadIdx.x; i < 3 * MAXT; i += PN_FUSED_WAVES * 64) hist[i] = 0;
+    if (threadIdx.x == 0) s_cursor = 0;
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int sub = lane & 7, gbase = lane & ~7, grp = lane >> 3;
     const uint32_t wave_g = blockIdx.x * PN_FUSED_WAVES + wv;
     const uint32_t slotw = wave_g * 64u, slot0 = slotw + (uint32_t)grp * 8u;
-    float4* stage = stage_all + wv * PN_STAGE_CAP;
+    float4* stage = stage_all + wv * PN_FUSED_STAGE;
     const uint4* __restrict__ wl = wimg + lane;
     const int half = lane >> 5, s32 = lane & 31;
     const PnFusedLevel* lds_lv = reinterpret_cast<const PnFusedLevel*>(wimg + IMG16) + 8 * half;
@@ -94,11 +143,20 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, PN_FUSED_WAVES / 4) k_tri
     float* const Dd = fa.dirs + (size_t)slot0 * 3;
     float* const dl = fa.deltas + (size_t)slot0 * 2;
 
-    // the alive list in PN_SEGS contiguous segments of `per` entries (a multiple of 8: a wave's 8 rays are neighbours in the list, i.e. pixels of one tile)
-    const int per = (((A + PN_SEGS - 1) / PN_SEGS) + 7) & ~7;
-    int seg = (int)(wave_g % PN_SEGS), seg_dead = 0;
+    // Hand-out: the alive list is dealt to the workgroups in packets of 8 consecutive entries (neighbouring pixels: a wave's rays share candidate
+    // lists), packet p to workgroup p % gridDim — every CU gets the same number of rays from all over the image — and inside a workgroup the waves
+    // draw from its share through ONE LDS cursor.  No global atomics (a returning atomic on a shared word was 17 000 cycles of every wave-round with
+    // 3 072 waves drawing from 64 cursors), and — what matters more — an even END: the launch is bound by each CU's gather path, so a last
+    // generation of rays spread over all CUs at 60 % load takes 60 % of the time, while the same rays on 60 % of the CUs (a global pool: the waves
+    // that find it empty exit) take all of it.
+    const int n_packets = (A + 7) >> 3;
+    const int my_packets = (int)blockIdx.x < n_packets ? (n_packets - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int share = my_packets * 8;
+    bool pool_empty = false;
     int index = -1;  // this group's ray (the same on its 8 lanes), -1: none
     int j = 0;       // trips it has been through in this launch
+    // ... and what stays in registers while it lives: origin, direction, 1 / direction, end, and the t the composite has reached (rays_t)
+    float r_ox = 0.f, r_oy = 0.f, r_oz = 0.f, r_dx = 1.f, r_dy = 1.f, r_dz = 1.f, r_rdx = 1.f, r_rdy = 1.f, r_rdz = 1.f, r_far = 0.f, r_t = 0.f;
     const bool clk = fa.clocks != nullptr;
     unsigned long long c_acc[5] = {0, 0, 0, 0, 0}, c_t = 0, rounds = 0;
     auto tick = [&](int k) {
@@ -109,27 +167,31 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, PN_FUSED_WAVES / 4) k_tri
             c_t = n;
         }
     };
-    if (clk) c_t = __builtin_readcyclecounter();
+    unsigned long long rt0 = 0;
+    if (clk) { c_t = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
     for (;;) {
         // ---- 1. refill the groups without a ray
-        {
+        if (!pool_empty) {
             const unsigned long long em = __ballot(index < 0 && sub == 0);
             const int need = (int)__popcll(em);
-            const int my_rank = (int)__popcll(em & ((1ull << gbase) - 1ull));
-            int taken = 0, newpos = -1;
-            while (taken < need && seg_dead < PN_SEGS) {
-                const int want = need - taken;
+            if (need > 0) {
+                const int my_rank = (int)__popcll(em & ((1ull << gbase) - 1ull));
                 int base = 0;
-                if (lane == 0) base = atomicAdd(fa.ctl + seg * PN_SEG_STRIDE, want);
+                if (lane == 0) base = atomicAdd(&s_cursor, need);
                 base = __builtin_amdgcn_readfirstlane(base);
-                const int seg_b = seg * per, seg_e = min(seg_b + per, A);
-                const int got = max(min(seg_e - (seg_b + base), want), 0);
-                if (index < 0 && my_rank >= taken && my_rank < taken + got) newpos = seg_b + base + (my_rank - taken);
-                taken += got;
-                if (got < want) { seg = (seg + 1) % PN_SEGS; seg_dead++; }  // this segment is used up
+                pool_empty = base + need >= share;
+                const int p = base + my_rank;
+                const int gpos = ((p >> 3) * (int)gridDim.x + (int)blockIdx.x) * 8 + (p & 7);
+                if (index < 0 && p < share && gpos < A) {
+                    index = fa.alive[gpos];
+                    j = 0;
+                    pnm3::RayConsts cn;
+                    pnm3::ray_consts(a, index, cn);
+                    r_ox = cn.ox; r_oy = cn.oy; r_oz = cn.oz; r_dx = cn.dx; r_dy = cn.dy; r_dz = cn.dz; r_rdx = cn.rdx; r_rdy = cn.rdy; r_rdz = cn.rdz; r_far = cn.far;
+                    r_t = a.rays_t[index];
+                }
             }
-            if (newpos >= 0) { index = fa.alive[newpos]; j = 0; }
         }
         if (!__any(index >= 0)) break;
         rounds++;
@@ -138,16 +200,18 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, PN_FUSED_WAVES / 4) k_tri
         const bool have_ray = index >= 0;
         if (have_ray && sub == 0) atomicAdd(&hist[j], 1);
         pnm3::RayConsts c;
-        c.ox = c.oy = c.oz = 0.f; c.dx = c.dy = c.dz = 1.f; c.rdx = c.rdy = c.rdz = 1.f; c.far = 0.f;
+        pnm3::frame_consts(a, c);
+        c.ox = r_ox; c.oy = r_oy; c.oz = r_oz; c.dx = r_dx; c.dy = r_dy; c.dz = r_dz; c.rdx = r_rdx; c.rdy = r_rdy; c.rdz = r_rdz; c.far = r_far;
         pnm3::RayState st{0.f, 0.f, 0u};
         bool have = false;
-        if (have_ray) {
-            pnm3::ray_consts(a, index, c);
-            have = pnm3::ray_start(a, c, index, 0.0f, nullptr, st);
-        } else {
-            pnm3::frame_consts(a, c);
+        if (have_ray) {  // pnm3::ray_start with the ray's t from the register (noise = 0: perturb is off on this path, renderer.py:857)
+            float t = r_t;
+            t += pnm::clampf(t * a.dt_gamma, c.dt_min, c.dt_max) * 0.0f;
+            st.last_t = t;
+            st.t = t;
+            have = t < c.far;
         }
-        const bool done = pnm3::march_window<K, MULTI, 8>(a, tb, c, 8u, sub, gbase, lane, stage, X, Dd, dl, st, 1, have);
+        const bool done = pnm3::march_window<K, MULTI, 8, PN_FUSED_STAGE, 1>(a, tb, c, 8u, sub, gbase, lane, stage, X, Dd, dl, st, 1, have);
         const bool deferred = have && !done;
         tick(1);
         unsigned long long dm = __ballot(deferred && sub == 0);
@@ -163,7 +227,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, PN_FUSED_WAVES / 4) k_tri
             c2.far = readlane_f(c.far, L);
             pnm3::RayState s2{readlane_f(st.t, L), readlane_f(st.last_t, L), (uint32_t)__builtin_amdgcn_readlane((int)st.step, L)};
             const size_t sl = (size_t)slotw + (size_t)(L >> 3) * 8;
-            pnm3::march_window<K, MULTI, 64>(a, tb, c2, 8u, lane, 0, lane, stage, fa.xyzs + sl * 3, fa.dirs + sl * 3, fa.deltas + sl * 2, s2, 0x7fffffff, true);
+            pnm3::march_window<K, MULTI, 64, PN_FUSED_STAGE, 1>(a, tb, c2, 8u, lane, 0, lane, stage, fa.xyzs + sl * 3, fa.dirs + sl * 3, fa.deltas + sl * 2, s2, 0x7fffffff, true);
             if (gbase == L) st.step = s2.step;
         }
         const uint32_t emitted = have_ray ? st.step : 0u;
@@ -214,20 +278,23 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, PN_FUSED_WAVES / 4) k_tri
         // ---- 4. composite (kernel_composite_rays, raymarching.cu:827-923): one lane per ray; a ray goes on iff it used all 8 samples
         int alive = 0;
         if (have_ray && sub == 0)
-            alive = composite_one(index, slot0, 8u, fa.T_thresh, fa.rays_t, fa.sigmas, fa.rgbs, fa.deltas, fa.weights_sum, fa.depth, fa.image) ? 1 : 0;
+            alive = composite_slots8(index, slot0, fa.T_thresh, r_t, fa.rays_t, fa.sigmas, fa.rgbs, fa.deltas, fa.weights_sum, fa.depth, fa.image) ? 1 : 0;
         alive = __shfl(alive, gbase);
+        r_t = __shfl(r_t, gbase);
         if (have_ray) {
             // renderer.py:836: the loop ends when `step` reaches max_steps, whatever is still alive
             if (alive && (uint32_t)(sb0 + 8 * (j + 1)) < fa.max_steps && j + 1 < MAXT) j++;
             else index = -1;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // rays_t of a surviving ray is read back by the next round's ray_start
         tick(4);
     }
     if (clk && lane == 0) {
         for (int k = 0; k < 5; k++) atomicAdd(fa.clocks + k, c_acc[k]);
         atomicAdd(fa.clocks + 5, rounds);
         atomicAdd(fa.clocks + 6, 1ull);
+        atomicAdd(fa.clocks + 7, __builtin_amdgcn_s_memrealtime() - rt0);  // the wave's lifetime on the constant 100 MHz clock
+        atomicMax(fa.clocks + 8, rounds);
+        atomicMax(fa.clocks + 9, __builtin_amdgcn_s_memrealtime() - rt0);
     }
 
     // ---- end of the launch: per-trip counts to memory; the last workgroup writes the trip records and re-arms the control block
@@ -262,7 +329,6 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, PN_FUSED_WAVES / 4) k_tri
         __hip_atomic_store(hp + MAXT, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(hp + 2 * MAXT, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __hip_atomic_store(fa.ctl + lane * PN_SEG_STRIDE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // PN_SEGS == 64 cursors
     if (lane == 0) {
         PnTrip* r = fa.trips + m;  // the record behind the last trip that had rays: the frame is over
         r->n_alive = 0; r->n_step = 1; r->step_base = sb0 + 8 * m; r->dense = 0; r->n_samples = 0; r->n_emitted = 0;
@@ -272,7 +338,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, PN_FUSED_WAVES / 4) k_tri
 }
 
 static size_t fused_lds_bytes(bool half) {
-    return (size_t)(half ? PN_NET_HALF_BYTES : PN_NET_SPLIT_BYTES) + 16 * sizeof(PnFusedLevel) + (size_t)PN_FUSED_WAVES * PN_STAGE_CAP * sizeof(float4) +
+    return (size_t)(half ? PN_NET_HALF_BYTES : PN_NET_SPLIT_BYTES) + 16 * sizeof(PnFusedLevel) + (size_t)PN_FUSED_WAVES * PN_FUSED_STAGE * sizeof(float4) +
            3 * PN_FUSED_MAX_TRIPS * sizeof(int);
 }
 

@@ -211,10 +211,10 @@ class NeRFRenderer(nn.Module):
     def fused_clocks(self, slot=0, reset=False):
         """Phase clocks of the fused later-trips launches on `slot` (march_counters(4)): dict of cycles summed over waves + the trip the last render
         switched to the fused launch at (-1: it did not)."""
-        out, first = (C.c_uint64 * 8)(), C.c_int(-1)
+        out, first = (C.c_uint64 * 16)(), C.c_int(-1)
         check(lib().pn_frame_fused_clocks(self._frames[slot][0], out, C.byref(first), int(bool(reset)), stream_ptr()), "fused_clocks")
         return dict(refill=int(out[0]), march=int(out[1]), windows=int(out[2]), network=int(out[3]), composite=int(out[4]), wave_rounds=int(out[5]),
-                    waves=int(out[6]), first_trip=int(first.value))
+                    waves=int(out[6]), lifetime_ticks=int(out[7]), max_rounds=int(out[8]), max_lifetime_ticks=int(out[9]), first_trip=int(first.value))
 
     def trip_records(self, slot=0, max_trips=16):
         """Diagnostics: [(n_alive, n_step, step_base, n_samples, n_emitted, n_tail)] per trip of the last render on `slot`."""
