@@ -246,12 +246,18 @@ typedef struct {
     int fused_from;       /* the loop trips from this one on run as ONE persistent launch (csrc/pn_trips_fused.h): once n_alive <= N / 8 the reference's
                              n_step = max(min(N // n_alive, 8), 1) (renderer.py:839-846) is 8 for the rest of the frame, so every ray can loop
                              { march 8 samples; network; composite } on its own until it dies — the per-ray arithmetic, the samples, the pixels and the
-                             per-trip counts of the trip-by-trip loop, without its 4-6 launches and its compaction per trip.  0: from trip 1 (right behind
-                             the frame's first trip; the chair); k > 1: the first k trips as per-trip launches (a scene whose second trip still has more
-                             than N / 8 rays alive: the trex option set — harness.capture_pipelined reads k off its warm-up frame); < 0: never.  If the
-                             launch finds n_step < 8 at its first trip it does nothing and the frame is continued like one that ran out of captured
-                             trips (pn_render_continue; the blocking pn_render_deformed runs one per-trip trip and tries again).  Not with ray_batch > 0
-                             (batches keep their own n_step), not for pn_render_static, not for max_steps > 1024. */
+                             per-trip counts of the trip-by-trip loop, without its 4-6 launches and its compaction per trip.
+                             0: the WHOLE frame behind the skip pre-pass, first trip included, where that applies — the first trip couples the rays only
+                             through the next trip's n_step, and n_alive there cannot exceed the rays the skip pre-pass left anything to march for: the
+                             launch checks on the device that those are at most N / 8 (the chair: 10 % of the rays meet the bounding box of the
+                             integration points) and does nothing otherwise; the blocking pn_render_deformed then runs the first trip as per-trip
+                             launches and fuses from trip 1 (or later, see below), a fixed-trip render is left unfinished at trip 0 and finished by
+                             pn_render_continue;
+                             k >= 1: the first k trips as per-trip launches (a scene whose second trip still has more than N / 8 rays alive: the trex
+                             option set — harness.capture_pipelined reads k off its warm-up frame); < 0: never.  If the launch finds n_step < 8 at
+                             its first trip it does nothing and the frame is continued like one that ran out of captured trips (pn_render_continue;
+                             the blocking pn_render_deformed runs one per-trip trip and tries again).  Not with ray_batch > 0 (batches keep their own
+                             n_step), not for pn_render_static, not for max_steps > 1024. */
 } pn_render_opts;
 int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_vtx, uint32_t max_grid_cells);
 void pn_frame_destroy(pn_frame* f);
@@ -345,7 +351,8 @@ int pn_density_grid_update(uint32_t n, float* density_grid, const float* tmp_gri
 int pn_frame_march_counters(pn_frame* f, int enable, uint64_t* counters_host, void* stream);
 /* With bit 2: clocks_host (uint64[16], may be NULL; synchronises) = cycles summed over the waves of the fused launches on f since the last reset for
  * {hand-out of rays, march (8-lane window round), march (64-lane windows of the rays still going), network, composite}, then wave-rounds, waves,
- * wave lifetimes in 100 MHz ticks (sum), the largest round count and the longest lifetime of a wave, 0...;
+ * wave lifetimes in 100 MHz ticks (sum), the largest round count and the longest lifetime of a wave; [10..14] (whole-frame form, fused_from = 0): the
+ * first trip's one-lane march, its 64-lane windows, its network, its composite + hand-over, the wait at the workgroup barrier behind it;
  * *first_trip_out (may be NULL) = the trip at which the last render on f switched to the fused launch, -1 if it did not.  reset != 0: zero the sums. */
 int pn_frame_fused_clocks(pn_frame* f, uint64_t* clocks_host, int* first_trip_out, int reset, void* stream);
 /* With bit 1 of `enable` set: the per-trip durations (ms, HIP events on the launch stream) of the last blocking render:

@@ -1546,6 +1546,11 @@ struct pn_frame {
     uint32_t fused_blocks;               // workgroups of a fused launch (one per CU); xyzs / dirs / deltas / sigmas / rgbs hold 64 slots per wave of it
     unsigned long long* fused_clocks;    // device [8] phase clocks of the fused launches (march_counters_on & 4)
     int fused_first;                     // first trip the last render ran fused (-1: none): where its time stamps sit
+    float* t_resume;                     // [max_rays] per alive slot of a frame's first trip: where k_march_skip left the ray
+    int* blist;                          // whole-frame fused launch: [2 x blist_cap] ray ids of the first trip's shares / of the rays that outlive it
+    int4* strag;                         // [blist_cap] its rays still searching after the one-lane rounds
+    uint32_t blist_cap;
+    int skip_done;                       // the last render on this workspace ran k_march_skip (a continuation from trip 0 must not run it again)
 };
 
 // image = acc + (1 - weights_sum) * bg ; depth = clamp(depth - nears, 0) / (fars - nears) (renderer.py:896-899)
@@ -1931,20 +1936,25 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
     const size_t N = max_rays;
 #define PN_ALLOC(ptr, bytes) PN_HIP_CHECK(hipMalloc((void**)&(ptr), (bytes)))
     PN_ALLOC(f->nears, N * 4); PN_ALLOC(f->fars, N * 4); PN_ALLOC(f->rays_t, N * 4);
-    // sample slots: one per ray for the per-trip launches, 64 per wave of a fused launch (pn_trips_fused.h: one workgroup per CU) — the larger of the two
+    // sample slots: one per ray for the per-trip launches, 64 per wave of a fused launch (pn_trips_fused.h: one workgroup per CU) + one per position of a
+    // whole-frame launch's first trip — the larger of the two
     {
         int dev_id = 0, cus = 0;
         PN_HIP_CHECK(hipGetDevice(&dev_id));
         PN_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id));
         f->fused_blocks = (uint32_t)std::min(std::max(cus, 1), 1024);
     }
-    const size_t NS = std::max(N, (size_t)f->fused_blocks * PN_FUSED_WAVES * 64);
+    f->blist_cap = (uint32_t)(N / 8 + 64 + (size_t)(f->fused_blocks + 1) * 64);  // n_active <= N / 8, + one partial chunk per workgroup (pn_trips_fused.h)
+    const size_t NS = std::max(N, (size_t)f->fused_blocks * PN_FUSED_WAVES * 64 + f->blist_cap);
     PN_ALLOC(f->xyzs, NS * 12); PN_ALLOC(f->dirs, NS * 12); PN_ALLOC(f->deltas, NS * 8); PN_ALLOC(f->sigmas, NS * 4); PN_ALLOC(f->rgbs, NS * 12);
     PN_ALLOC(f->fused_ctl, (size_t)PN_FUSED_CTL_INTS * 4);
     PN_HIP_CHECK(hipMemset(f->fused_ctl, 0, (size_t)PN_FUSED_CTL_INTS * 4));
     PN_ALLOC(f->fused_clocks, 16 * sizeof(unsigned long long));
     PN_HIP_CHECK(hipMemset(f->fused_clocks, 0, 16 * sizeof(unsigned long long)));
     f->fused_first = -1;
+    PN_ALLOC(f->t_resume, N * 4);
+    PN_ALLOC(f->blist, (size_t)f->blist_cap * 8);
+    PN_ALLOC(f->strag, (size_t)f->blist_cap * 16);
     PN_ALLOC(f->acc_image, N * 12);
     PN_ALLOC(f->alive_a, N * 4); PN_ALLOC(f->alive_b, N * 4); PN_ALLOC(f->list, N * 4); PN_ALLOC(f->chunk_counts, (N / 256 + 4) * 4);
     PN_ALLOC(f->pig_cnt, (size_t)max_grid_cells * 4); PN_ALLOC(f->pig_bgn, (size_t)max_grid_cells * 4);
@@ -1977,7 +1987,7 @@ extern "C" void pn_frame_destroy(pn_frame* f) {
     void* ptrs[] = {f->acc_image, f->nears, f->fars, f->rays_t, f->xyzs, f->dirs, f->deltas, f->sigmas, f->rgbs, f->alive_a, f->alive_b, f->list,
                     f->chunk_counts, f->pig_cnt, f->pig_bgn, f->pig_cursor, f->pig_idx, f->trips, f->dev, f->cut_bounds,
                     f->side.nb_rng, f->side.nb, f->side.rec, f->march_counters, f->tail, f->tail_counts, f->stamps,
-                    f->list_seg, f->active_seg, f->seg_counters, f->cell_bits, f->fars_eff, f->groups, f->group_cnt, f->fused_ctl, f->fused_clocks};
+                    f->list_seg, f->active_seg, f->seg_counters, f->cell_bits, f->fars_eff, f->groups, f->group_cnt, f->fused_ctl, f->fused_clocks, f->t_resume, f->blist, f->strag};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int t = 0; t < PN_TIMED_TRIPS; t++)
         for (int e = 0; e < 3; e++) if (f->ev[t][e]) (void)hipEventDestroy(f->ev[t][e]);
@@ -2139,8 +2149,37 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     const int fuse_from = fused_ok ? std::max(o->fused_from, 1) : PN_MAX_TRIPS + 1;
     int add_fused = 0;
     f->fused_first = -1;
+    // ... and the WHOLE frame behind the skip pre-pass as one launch (pn_render_opts.fused_from == 0; pn_trips_fused.h, WHOLE): the launch checks on the
+    // device that at most N / 8 rays have anything to march (then every trip after the first marches 8 samples per ray whatever the first one finds) and
+    // does nothing otherwise — the blocking driver then goes on trip by trip as above, a fixed-trip render is left to pn_render_continue.
+    // PN_FUSED_WHOLE=0: the first trip always as per-trip launches (A/B).
+    static const bool whole_env = [] { const char* v = getenv("PN_FUSED_WHOLE"); return !(v && v[0] == '0'); }();
+    static const uint32_t a_rounds_env = pn_env_u32("PN_FUSED_AROUNDS", 0);
+    bool whole_try = fused_ok && whole_env && o->fused_from == 0 && !resume && t == 0;
+    bool skip_done = resume && f->skip_done != 0;
+    if (!resume) f->skip_done = 0;
+    int* const seg_tail = f->seg_counters;
+    int* const seg_samp = seg_tail + PN_SEGS * PN_SEG_STRIDE;
+    int* const seg_emit = seg_samp + PN_SEGS * PN_SEG_STRIDE;
+    int* const seg_curs = seg_emit + PN_SEGS * PN_SEG_STRIDE;
+    int* const seg_back = seg_curs + PN_SEGS * PN_SEG_STRIDE;
+    int* const seg_active = seg_back + PN_SEGS * PN_SEG_STRIDE;
+    // trip 0 keeps its skip pre-pass state in f->t_resume and lists the slots worth marching in f->active_seg
+    auto make_io = [&](int tt) {
+        int* cur = (tt & 1) ? f->alive_b : f->alive_a;
+        const bool lpr = (uint32_t)tt < lpr_trips && lpr_rounds > 0;
+        return MarchIO{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + tt, f->list, (tt == 0) ? f->t_resume : nullptr,
+                       f->tail, seg_tail, seg_back, seg_curs, (int)f->seg_cap, lpr ? (int)lpr_rounds : (int)march_tail_rounds(tt),
+                       (tt == 0) ? f->active_seg : nullptr, (tt == 0) ? seg_active : nullptr,
+                       (int)f->seg_cap, f->list_seg, seg_samp, (int)f->seg_cap, seg_emit, f->cell_bits, skip_bits_words,
+                       short_rays ? f->cell_bits + bit_words : nullptr, short_rays ? f->fars_eff : nullptr,
+                       group_rays ? f->groups + (size_t)(tt & 1) * f->max_groups : nullptr, group_rays, lpr ? 1 : 0, dda_start,
+                       (int)skip_hop_budget};
+    };
     while (!done && t < PN_MAX_TRIPS) {
-        if (t >= fuse_from) {
+        const bool whole = whole_try;
+        whole_try = false;
+        if (whole || t >= fuse_from) {
             FusedArgs fa;
             memset(&fa, 0, sizeof(fa));
             fa.lv = (const PnFusedLevel*)net->fused_levels; fa.emb = net->embeddings; fa.emb_h = (const uint32_t*)net->emb_half; fa.emb_bytes = net->n_entries * 4u;
@@ -2151,6 +2190,11 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             fa.xyzs = f->xyzs; fa.dirs = f->dirs; fa.deltas = f->deltas; fa.sigmas = f->sigmas; fa.rgbs = f->rgbs;
             fa.ctl = f->fused_ctl; fa.dev = f->dev; fa.tail_diag = f->tail_counts + t;
             fa.clocks = (f->march_counters_on & 4) ? f->fused_clocks : nullptr;
+            if (whole) {
+                fa.active = f->active_seg; fa.active_counts = seg_active; fa.active_seg_cap = (int)f->seg_cap; fa.t_resume = f->t_resume;
+                fa.blist = f->blist; fa.strag = f->strag; fa.blist_cap = f->blist_cap;
+                fa.a_rounds = a_rounds_env ? (int)a_rounds_env : 24;
+            }
             pnm::MarchParams mq = mp;
             if (short_rays) mq.fars = f->fars_eff;  // written by trip 0's k_march_skip
             const bool timed = (f->march_counters_on & 2) && t < PN_TIMED_TRIPS;
@@ -2167,8 +2211,14 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                     PN_HIP_CHECK(hipEventRecord(f->ev[t][0], st));
                 }
             }
+            if (whole) {  // the skip pre-pass: per-ray resume points, shortened ends, the active list (one lane per ray)
+                const MarchIO io0 = make_io(0);
+                k_march_skip<<<nblk, 256, skip_lds, st>>>(mp, tb, io0);
+                skip_done = true;
+                f->skip_done = 1;
+            }
             const uint32_t blocks = fused_grid_env ? std::min(fused_grid_env, f->fused_blocks) : f->fused_blocks;
-            rc = launch_trips_fused(o->num_seek_IP, o->max_iter_num > 1, o->fp16 != 0, blocks, st, mq, tb, fa);
+            rc = launch_trips_fused(o->num_seek_IP, o->max_iter_num > 1, o->fp16 != 0, whole, blocks, st, mq, tb, fa);
             if (rc) return rc;
             if (timed) {
                 if (stamp) { k_stamp<<<1, 1, 0, st>>>(f->stamps + t * 3 + 1); k_stamp<<<1, 1, 0, st>>>(f->stamps + t * 3 + 2); }
@@ -2183,6 +2233,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             if (f->dev_pinned->fused_trips > 0) { t += f->dev_pinned->fused_trips; done = true; break; }  // ran until no ray was alive (or max_steps)
             if (f->trips_pinned[t].n_alive <= 0) { done = true; break; }
             // not applicable at this trip (more than N / 8 rays alive: n_step < 8): one trip of the per-trip launches, then again
+            f->fused_first = -1;
         }
         const int batch = async_trips > 0 ? (fused_ok ? fuse_from - t : async_trips) : (fused_ok ? std::max(fuse_from - t, 1) : PN_TRIP_BATCH);
         for (int k = 0; k < batch; k++, t++) {
@@ -2193,23 +2244,8 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             int* cur = (t & 1) ? f->alive_b : f->alive_a;
             int* nxt = (t & 1) ? f->alive_a : f->alive_b;
             // trip 0 (every ray, one sample each) is dominated by rays crossing IP-free cells: a one-lane-per-ray pre-pass
-            // fast-forwards them; its per-ray resume point lives in `sigmas`, which is not written before this trip's network launch
-            // ... and lists the slots that still have work (in `nxt`, which nobody reads before this trip's compaction writes it; the counter is
-            // the spare last entry of the per-trip tail counters, zeroed by k_frame_rays)
-            int* seg_tail = f->seg_counters;
-            int* seg_samp = seg_tail + PN_SEGS * PN_SEG_STRIDE;
-            int* seg_emit = seg_samp + PN_SEGS * PN_SEG_STRIDE;
-            int* seg_curs = seg_emit + PN_SEGS * PN_SEG_STRIDE;
-            int* seg_back = seg_curs + PN_SEGS * PN_SEG_STRIDE;
-            int* seg_active = seg_back + PN_SEGS * PN_SEG_STRIDE;
-            // trip 0 keeps its skip pre-pass state in f->sigmas (t_resume) and lists the slots worth marching in f->active_seg
-            MarchIO io{0, 0, cur, f->xyzs, f->dirs, f->deltas, nullptr, f->trips + t, f->list, (t == 0) ? f->sigmas : nullptr,
-                       f->tail, seg_tail, seg_back, seg_curs, (int)f->seg_cap, ((uint32_t)t < lpr_trips && lpr_rounds > 0) ? (int)lpr_rounds : (int)march_tail_rounds(t),
-                       (t == 0) ? f->active_seg : nullptr, (t == 0) ? seg_active : nullptr,
-                       (int)f->seg_cap, f->list_seg, seg_samp, (int)f->seg_cap, seg_emit, f->cell_bits, skip_bits_words,
-                       short_rays ? f->cell_bits + bit_words : nullptr, short_rays ? f->fars_eff : nullptr,
-                       group_rays ? f->groups + (size_t)(t & 1) * f->max_groups : nullptr, group_rays, ((uint32_t)t < lpr_trips && lpr_rounds > 0) ? 1 : 0, dda_start,
-                       (int)skip_hop_budget};
+            // fast-forwards them (its per-ray resume point: f->t_resume) and lists the slots that still have work (f->active_seg)
+            MarchIO io = make_io(t);
             const bool timed = (f->march_counters_on & 2) && t < PN_TIMED_TRIPS;
             bool stamp = false;
             if (timed) {  // measurement mode: the two heavy launch groups of each trip are bracketed on the launch stream
@@ -2229,7 +2265,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                 k_march_static_trip<<<trip_grid, 256, 0, st>>>(f->trips + t, cur, f->rays_t, rays_o, rays_d, o->bound, o->dt_gamma, o->max_steps, o->cascade,
                                                                o->grid_size, bitfield, f->fars, f->xyzs, f->dirs, f->deltas, f->list);
             } else {
-                if (io.t_resume) k_march_skip<<<nblk, 256, skip_lds, st>>>(mp, tb, io);
+                if (io.t_resume && !skip_done) { k_march_skip<<<nblk, 256, skip_lds, st>>>(mp, tb, io); skip_done = true; f->skip_done = 1; }
                 pnm::MarchParams mq = mp;
                 if (short_rays) mq.fars = f->fars_eff;  // written by trip 0's k_march_skip
                 launch_march(o->num_seek_IP, t == 0 ? std::max(std::min(pn_div_up(N, 32), march_grid), (uint32_t)PN_SEGS) : (margin ? 2u * PN_SEGS : march_grid_later),

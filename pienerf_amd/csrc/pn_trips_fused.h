@@ -23,6 +23,9 @@
 // needed the wave-per-ray windows) is counted in LDS, flushed once per workgroup, and the LAST workgroup to finish turns the counts into the trip
 // records the per-trip launches would have written (PnTrip) — frame statistics, trip-record tests and pn_render_continue see no difference.
 //
+// Round 4: the frame's FIRST trip in the same launch too (template flag WHOLE, see the kernel) — a deformed frame is then prologue, skip pre-pass, this
+// launch, epilogue.
+//
 // Precondition, checked on the device: the record of the first fused trip says n_step == 8 (and dense).  If not (a scene with more than N / 8 rays alive
 // after the classic trips) the kernel does nothing and the frame is left unfinished exactly like a captured render that ran out of trips: the caller
 // continues it (pn_render_continue / the blocking driver's own loop, which runs one more classic trip and tries again).
@@ -58,7 +61,17 @@ struct FusedArgs {
     int* ctl;
     PnFrameDev* dev;
     int* tail_diag;              // per-trip diagnostics (rays that needed the 64-lane windows), aligned with `trips`
-    unsigned long long* clocks;  // optional [16]: shader-clock cycles per phase summed over waves (refill, march, windows, network, composite), wave-rounds, waves
+    unsigned long long* clocks;  // optional [16]: shader-clock cycles per phase summed over waves (refill, march, windows, network, composite), wave-rounds, waves;
+                                 // [10..14] whole-frame form: first-trip march, its 64-lane windows, its network, its composite + hand-over, wait at the barrier
+    // whole-frame form (WHOLE): the frame's FIRST trip inside the launch as well
+    const int* active;           // [PN_SEGS x active_seg_cap] alive slots k_march_skip left something to march for
+    const int* active_counts;    // their segmented counters
+    int active_seg_cap;
+    const float* t_resume;       // [N] per alive slot: where k_march_skip left the ray
+    int* blist;                  // [2 x blist_cap] ray ids of the workgroups' shares of the first trip / of the rays that outlive it, one region per workgroup
+    int4* strag;                 // [blist_cap] the first trip's rays still searching after the one-lane rounds
+    uint32_t blist_cap;          // positions; the sample arrays hold gridDim * PN_FUSED_WAVES * 64 + blist_cap slots
+    int a_rounds;                // one-lane rounds of the first trip before a ray goes to the 64-lane windows
 };
 
 // composite_one (kernel_composite_rays, raymarching.cu:827-923) for the 8 slots of one ray of the fused launch: the same operations in the same order,
@@ -110,27 +123,68 @@ __device__ __forceinline__ bool composite_slots8(int index, uint32_t slot0, floa
 
 __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
-template <int K, bool MULTI, bool HALF>
+#ifndef PN_FUSED_ACHUNK
+#define PN_FUSED_ACHUNK 64  // rays of the frame's first trip a wave takes at a time (whole-frame form): one lane each
+#endif
+
+// WHOLE = false: the trips from `fa.trips` on (n_step == 8 there), rays from that trip's alive list.
+// WHOLE = true: the whole frame behind k_march_skip.  The frame's first trip (every ray looks for its first sample, n_step = 1) couples the rays
+//   through nothing but the NEXT trip's n_step = max(min(N // n_alive, 8), 1) — and n_alive there cannot exceed the rays the skip pre-pass left
+//   anything to march for: when those are at most N / 8 (checked here, on the device), every later trip marches 8 samples per ray whatever the first
+//   trip finds, and the first trip can run per ray like the others.  Per workgroup:
+//     A. its share of the ACTIVE list (chunks of PN_FUSED_ACHUNK rays dealt round-robin over the workgroups, an LDS cursor inside) with ONE lane per ray
+//        (march_window<K, MULTI, 1>: every evaluated point is a visited one — the throughput form of k_march), a ray still searching after `a_rounds`
+//        rounds in the 64-lane windows; the network on the wave's 64 slots; composite (one sample); the rays that go on are appended to the
+//        workgroup's own list;
+//     B. (behind a workgroup barrier) the loop below over that list.
+//   Not applicable (more than N / 8 active rays, a frame stopped by an error flag): the launch does nothing and says so (fused_trips stays 0).
+template <int K, bool MULTI, bool HALF, bool WHOLE>
 __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4) k_trips_fused(pnm::MarchParams a, pnm2::March2Tables tb, FusedArgs fa) {
     extern __shared__ __attribute__((aligned(16))) uint4 fused_lds[];
     constexpr int IMG16 = (HALF ? PN_NET_HALF_BYTES : PN_NET_SPLIT_BYTES) / 16;
     constexpr int MAXT = PN_FUSED_MAX_TRIPS;
+    constexpr int AC = PN_FUSED_ACHUNK;
+    static_assert(AC == 64 || AC == 32, "rays per first-trip chunk");
     uint4* wimg = fused_lds;  // the weight image, then the 16 level records (512 B), as in k_nerf_forward
     float4* stage_all = reinterpret_cast<float4*>(fused_lds + IMG16 + 32);
     int* hist = reinterpret_cast<int*>(stage_all + PN_FUSED_WAVES * PN_FUSED_STAGE);  // [3][MAXT]: rays entering trip j, samples emitted, rays through the 64-lane windows
-    __shared__ int s_last, s_cursor;
+    __shared__ int s_last, s_cursor, s_bcount, s_strag;
+    __shared__ int s_pref[PN_SEGS + 1];
 
     const PnTrip* tr = fa.trips;
-    const int A = tr->n_alive, sb0 = tr->step_base;
-    if (!(A > 0 && tr->n_step == 8 && tr->dense != 0)) return;  // nothing to do / not applicable: the records stay as they are (see the header comment)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int A = 0, sb0 = 0, n_active = 0;
+    if (WHOLE) {
+        // exclusive prefix of the active list's segment counts (the same in every workgroup)
+        if (threadIdx.x < 64) {
+            const int cnt = seg_count(fa.active_counts, lane);
+            int inc = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int u = __shfl_up(inc, o);
+                if (lane >= o) inc += u;
+            }
+            s_pref[lane + 1] = inc;
+            if (lane == 0) s_pref[0] = 0;
+        }
+        __syncthreads();
+        n_active = s_pref[PN_SEGS];
+        const long long chunks = ((long long)n_active + AC - 1) / AC;
+        const bool ok = tr->n_alive == (int)fa.N_rays && tr->n_step == 1 && tr->step_base == 0 && (long long)n_active * 8 <= (long long)fa.N_rays &&
+                        (chunks + (long long)gridDim.x) * AC <= (long long)fa.blist_cap;  // (also the room behind the waves' sample slots)
+        if (!ok) return;
+        sb0 = 1;  // `step` behind the first trip
+    } else {
+        A = tr->n_alive; sb0 = tr->step_base;
+        if (!(A > 0 && tr->n_step == 8 && tr->dense != 0)) return;  // nothing to do / not applicable: the records stay as they are (see the header comment)
+    }
 
     for (int i = threadIdx.x; i < IMG16; i += PN_FUSED_WAVES * 64) wimg[i] = fa.wimg_g[i];
     if (threadIdx.x < 16 * sizeof(PnFusedLevel) / 16) wimg[IMG16 + threadIdx.x] = reinterpret_cast<const uint4*>(fa.lv)[threadIdx.x];
     for (int i = threadIdx.x; i < 3 * MAXT; i += PN_FUSED_WAVES * 64) hist[i] = 0;
-    if (threadIdx.x == 0) s_cursor = 0;
+    if (threadIdx.x == 0) { s_cursor = 0; s_bcount = 0; s_strag = 0; }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int sub = lane & 7, gbase = lane & ~7, grp = lane >> 3;
     const uint32_t wave_g = blockIdx.x * PN_FUSED_WAVES + wv;
     const uint32_t slotw = wave_g * 64u, slot0 = slotw + (uint32_t)grp * 8u;
@@ -143,22 +197,8 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
     float* const Dd = fa.dirs + (size_t)slot0 * 3;
     float* const dl = fa.deltas + (size_t)slot0 * 2;
 
-    // Hand-out: the alive list is dealt to the workgroups in packets of 8 consecutive entries (neighbouring pixels: a wave's rays share candidate
-    // lists), packet p to workgroup p % gridDim — every CU gets the same number of rays from all over the image — and inside a workgroup the waves
-    // draw from its share through ONE LDS cursor.  No global atomics (a returning atomic on a shared word was 17 000 cycles of every wave-round with
-    // 3 072 waves drawing from 64 cursors), and — what matters more — an even END: the launch is bound by each CU's gather path, so a last
-    // generation of rays spread over all CUs at 60 % load takes 60 % of the time, while the same rays on 60 % of the CUs (a global pool: the waves
-    // that find it empty exit) take all of it.
-    const int n_packets = (A + 7) >> 3;
-    const int my_packets = (int)blockIdx.x < n_packets ? (n_packets - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-    const int share = my_packets * 8;
-    bool pool_empty = false;
-    int index = -1;  // this group's ray (the same on its 8 lanes), -1: none
-    int j = 0;       // trips it has been through in this launch
-    // ... and what stays in registers while it lives: origin, direction, 1 / direction, end, and the t the composite has reached (rays_t)
-    float r_ox = 0.f, r_oy = 0.f, r_oz = 0.f, r_dx = 1.f, r_dy = 1.f, r_dz = 1.f, r_rdx = 1.f, r_rdy = 1.f, r_rdz = 1.f, r_far = 0.f, r_t = 0.f;
     const bool clk = fa.clocks != nullptr;
-    unsigned long long c_acc[5] = {0, 0, 0, 0, 0}, c_t = 0, rounds = 0;
+    unsigned long long c_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, c_t = 0, rounds = 0;
     auto tick = [&](int k) {
         if (clk) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -169,6 +209,195 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
     };
     unsigned long long rt0 = 0;
     if (clk) { c_t = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+
+    // the network on 32 consecutive sample slots (two lanes per sample: lanes s32 and s32 + 32 hold sample slot_of_lane's two level halves)
+    auto network_tile = [&](uint32_t slot) {
+        const pnm3::Float3 p = *reinterpret_cast<const pnm3::Float3*>(fa.xyzs + (size_t)slot * 3), d = *reinterpret_cast<const pnm3::Float3*>(fa.dirs + (size_t)slot * 3);
+        float sigma_logit, e[3];
+        if (HALF) {
+            float g2[8];
+            tile_sigma_net_h<4>(fa.lv, wimg, emb_rsrc, wl, half, fa.net_bound, p.x, p.y, p.z, g2);
+            sigma_logit = g2[0];
+            __builtin_amdgcn_sched_barrier(0);
+            tile_color_net_h(wl, wimg, half, g2, d.x, d.y, d.z, e);
+        } else {
+            const f32x16 h2 = tile_sigma_net<PN_BF_LU>(fa.lv, lds_lv, fa.emb, wl, half, fa.net_bound, p.x, p.y, p.z);
+            sigma_logit = h2[0];
+            __builtin_amdgcn_sched_barrier(0);
+            tile_color_net(wl, wimg, half, h2, d.x, d.y, d.z, e);
+        }
+        if (half == 0) {
+            fa.sigmas[slot] = tile_sigma_out(fa.density_scale, sigma_logit);
+#pragma unroll
+            for (int o = 0; o < 3; o++) fa.rgbs[(size_t)slot * 3 + o] = HALF ? tile_rgb_out_h(e[o]) : tile_rgb_out(e[o]);
+        }
+    };
+    // ... on the wave's 64 slots: tile 0 = slots 0..31, tile 1 = 32..63; `rm`: lanes whose slots carry something
+    auto network64 = [&](unsigned long long rm) {
+#pragma unroll 1
+        for (int tile = 0; tile < 2; tile++) {
+            if (!((rm >> (32 * tile)) & 0xFFFFFFFFull)) continue;
+            network_tile(slotw + 32u * (uint32_t)tile + (uint32_t)s32);
+        }
+    };
+    auto wave_sync_mem = [&]() {  // the wave's own stores before its own loads of the same addresses by other lanes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+
+    int share = 0;
+    const int* my_list = nullptr;
+    if (WHOLE) {
+        // ---- A. the frame's first trip on this workgroup's share of the active list, in three steps with a workgroup barrier behind each.
+        // Position p of the share (chunk p / AC of the workgroup, lane p % AC) owns sample slot a_base + p — behind the slots of the later trips' waves — and
+        // entry p of the workgroup's index list.
+        const int n_chunks = (n_active + AC - 1) / AC;
+        const int my_chunks = (int)blockIdx.x < n_chunks ? (n_chunks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+        const int bcap = ((n_chunks + (int)gridDim.x - 1) / (int)gridDim.x) * AC;
+        const size_t wg_off = (size_t)blockIdx.x * (size_t)bcap;
+        int* const a_index = fa.blist + wg_off;                         // ray id per position
+        int* const blist = fa.blist + (size_t)fa.blist_cap + wg_off;    // the rays that go on behind the first trip
+        int4* const strag = fa.strag + wg_off;                          // (position, t, last_t, ray id) of the rays still searching after the one-lane rounds
+        const uint32_t a_base = gridDim.x * (uint32_t)(PN_FUSED_WAVES * 64) + (uint32_t)wg_off;
+        my_list = blist;
+        const bool go_on = 1u < fa.max_steps;  // renderer.py:836: the loop ends when `step` (1 behind the first trip) reaches max_steps
+        // -- A1. ONE lane per ray for a_rounds rounds (march_window<K, MULTI, 1>: every evaluated point is a visited one)
+        for (;;) {
+            int ci = 0;
+            if (lane == 0) ci = atomicAdd(&s_cursor, 1);
+            ci = __builtin_amdgcn_readfirstlane(ci);
+            if (ci >= my_chunks) break;
+            const int gi = ((int)blockIdx.x + ci * (int)gridDim.x) * AC + lane;  // position in the concatenation of the active segments
+            const bool in_chunk = lane < AC;
+            const bool mine = in_chunk && gi < n_active;
+            const int pos = ci * AC + lane;
+            int index = -1;
+            pnm3::RayConsts c;
+            pnm3::frame_consts(a, c);
+            c.ox = c.oy = c.oz = 0.f; c.dx = c.dy = c.dz = 1.f; c.rdx = c.rdy = c.rdz = 1.f; c.far = 0.f;
+            pnm3::RayState st{0.f, 0.f, 0u};
+            bool have = false;
+            if (mine) {
+                int lo = 0, hi = PN_SEGS;  // segment with s_pref[seg] <= gi < s_pref[seg + 1]
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_pref[mid] <= gi) lo = mid; else hi = mid;
+                }
+                const int n = fa.active[(size_t)lo * fa.active_seg_cap + (gi - s_pref[lo])];
+                index = fa.alive[n];
+                pnm3::ray_consts(a, index, c);
+                have = pnm3::ray_start(a, c, index, 0.0f, fa.t_resume + n, st);
+            }
+            if (in_chunk) a_index[pos] = index;
+            const size_t sl = (size_t)a_base + (size_t)(in_chunk ? pos : ci * AC);
+            float* const Xa = fa.xyzs + sl * 3;
+            float* const Da = fa.dirs + sl * 3;
+            float* const La = fa.deltas + sl * 2;
+            tick(0);
+            const bool done = pnm3::march_window<K, MULTI, 1, PN_FUSED_STAGE, 1>(a, tb, c, 1u, 0, lane, lane, stage, Xa, Da, La, st, fa.a_rounds, have);
+            const bool deferred = have && !done;
+            const unsigned long long dm = __ballot(deferred);
+            if (dm) {
+                int base = 0;
+                if (lane == 0) { base = atomicAdd(&s_strag, (int)__popcll(dm)); atomicAdd(&hist[2 * MAXT], (int)__popcll(dm)); }
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (deferred) strag[base + (int)__popcll(dm & ((1ull << lane) - 1ull))] = make_int4(pos, __float_as_int(st.t), __float_as_int(st.last_t), index);
+            }
+            if (in_chunk && !deferred && !(have && st.step != 0u)) {  // no sample: the slot runs through the network like the dense trips' empty ones and ends nothing
+                La[0] = 0.0f; La[1] = 0.0f;
+                Xa[0] = Xa[1] = Xa[2] = 0.0f;
+                Da[0] = Da[1] = Da[2] = 0.0f;
+            }
+            tick(5);
+        }
+        wave_sync_mem();
+        __syncthreads();
+        if (threadIdx.x == 0) s_cursor = 0;
+        __syncthreads();
+        tick(9);
+        // -- A2. the rays still searching: 64 sequence elements per round with a whole wave each, handed out one at a time
+        const int n_strag = s_strag;
+        for (;;) {
+            int e = 0;
+            if (lane == 0) e = atomicAdd(&s_cursor, 1);
+            e = __builtin_amdgcn_readfirstlane(e);
+            if (e >= n_strag) break;
+            const int4 se = strag[e];
+            pnm3::RayConsts c2;
+            pnm3::ray_consts(a, se.w, c2);
+            pnm3::RayState s2{__int_as_float(se.y), __int_as_float(se.z), 0u};
+            const size_t sl = (size_t)a_base + (size_t)se.x;
+            pnm3::march_window<K, MULTI, 64, PN_FUSED_STAGE, 1>(a, tb, c2, 1u, lane, 0, lane, stage, fa.xyzs + sl * 3, fa.dirs + sl * 3, fa.deltas + sl * 2, s2, 0x7fffffff, true);
+            if (s2.step == 0u && lane < 8) {
+                if (lane < 2) fa.deltas[sl * 2 + lane] = 0.0f;
+                else if (lane < 5) fa.xyzs[sl * 3 + (lane - 2)] = 0.0f;
+                else fa.dirs[sl * 3 + (lane - 5)] = 0.0f;
+            }
+        }
+        wave_sync_mem();
+        __syncthreads();
+        if (threadIdx.x == 0) s_cursor = 0;
+        __syncthreads();
+        tick(6);
+        // -- A3. network on tiles of 32 positions, composite (one sample), hand-over: a ray goes on iff it used its sample (kernel_composite_rays,
+        // raymarching.cu:827-923)
+        const int n_tiles = my_chunks * AC / 32;
+        for (;;) {
+            int ti = 0;
+            if (lane == 0) ti = atomicAdd(&s_cursor, 1);
+            ti = __builtin_amdgcn_readfirstlane(ti);
+            if (ti >= n_tiles) break;
+            const int pos = ti * 32 + s32;
+            const uint32_t slot = a_base + (uint32_t)pos;
+            const bool has = fa.deltas[(size_t)slot * 2] != 0.0f;
+            const unsigned long long em = __ballot(has && half == 0);
+            if (!em) continue;
+            if (lane == 0) {
+                atomicAdd(&hist[MAXT], (int)__popcll(em));
+                if (a.stats) atomicAdd(a.stats + 3, (unsigned long long)__popcll(em));
+            }
+            network_tile(slot);
+            wave_sync_mem();
+            tick(7);
+            bool on = false;
+            int index = -1;
+            if (has && half == 0) {
+                index = a_index[pos];
+                on = composite_one(index, slot, 1u, fa.T_thresh, fa.rays_t, fa.sigmas, fa.rgbs, fa.deltas, fa.weights_sum, fa.depth, fa.image) && go_on;
+            }
+            const unsigned long long om = __ballot(on);
+            if (om) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_bcount, (int)__popcll(om));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (on) blist[base + (int)__popcll(om & ((1ull << lane) - 1ull))] = index;
+            }
+            tick(8);
+        }
+        wave_sync_mem();
+        __syncthreads();  // the workgroup's list is complete
+        share = s_bcount;
+        if (threadIdx.x == 0) s_cursor = 0;
+        __syncthreads();
+        tick(9);
+    } else {
+        const int n_packets = (A + 7) >> 3;
+        const int my_packets = (int)blockIdx.x < n_packets ? (n_packets - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+        share = my_packets * 8;
+    }
+
+    // Hand-out (WHOLE = false): the alive list is dealt to the workgroups in packets of 8 consecutive entries (neighbouring pixels: a wave's rays share candidate
+    // lists), packet p to workgroup p % gridDim — every CU gets the same number of rays from all over the image — and inside a workgroup the waves
+    // draw from its share through ONE LDS cursor.  No global atomics (a returning atomic on a shared word was 17 000 cycles of every wave-round with
+    // 3 072 waves drawing from 64 cursors), and — what matters more — an even END: the launch is bound by each CU's gather path, so a last
+    // generation of rays spread over all CUs at 60 % load takes 60 % of the time, while the same rays on 60 % of the CUs (a global pool: the waves
+    // that find it empty exit) take all of it.  (WHOLE: the workgroup's own list, in the order its first trip left it.)
+    bool pool_empty = false;
+    int index = -1;  // this group's ray (the same on its 8 lanes), -1: none
+    int j = 0;       // trips it has been through in this launch
+    // ... and what stays in registers while it lives: origin, direction, 1 / direction, end, and the t the composite has reached (rays_t)
+    float r_ox = 0.f, r_oy = 0.f, r_oz = 0.f, r_dx = 1.f, r_dy = 1.f, r_dz = 1.f, r_rdx = 1.f, r_rdy = 1.f, r_rdz = 1.f, r_far = 0.f, r_t = 0.f;
 
     for (;;) {
         // ---- 1. refill the groups without a ray
@@ -182,10 +411,10 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
                 base = __builtin_amdgcn_readfirstlane(base);
                 pool_empty = base + need >= share;
                 const int p = base + my_rank;
-                const int gpos = ((p >> 3) * (int)gridDim.x + (int)blockIdx.x) * 8 + (p & 7);
-                if (index < 0 && p < share && gpos < A) {
-                    index = fa.alive[gpos];
-                    j = 0;
+                const int gpos = WHOLE ? p : ((p >> 3) * (int)gridDim.x + (int)blockIdx.x) * 8 + (p & 7);
+                if (index < 0 && p < share && (WHOLE || gpos < A)) {
+                    index = WHOLE ? my_list[gpos] : fa.alive[gpos];
+                    j = WHOLE ? 1 : 0;
                     pnm3::RayConsts cn;
                     pnm3::ray_consts(a, index, cn);
                     r_ox = cn.ox; r_oy = cn.oy; r_oz = cn.oz; r_dx = cn.dx; r_dy = cn.dy; r_dz = cn.dz; r_rdx = cn.rdx; r_rdy = cn.rdy; r_rdz = cn.rdz; r_far = cn.far;
@@ -241,39 +470,11 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
             X[3 * sub] = X[3 * sub + 1] = X[3 * sub + 2] = 0.0f;
             Dd[3 * sub] = Dd[3 * sub + 1] = Dd[3 * sub + 2] = 0.0f;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the wave's own stores before its own loads of the same slots by other lanes
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        wave_sync_mem();
         tick(2);
         // ---- 3. network on the wave's 64 slots: tile 0 = groups 0..3, tile 1 = groups 4..7
-        const unsigned long long rm = __ballot(have_ray);
-#pragma unroll 1
-        for (int tile = 0; tile < 2; tile++) {
-            if (!((rm >> (32 * tile)) & 0xFFFFFFFFull)) continue;
-            const uint32_t slot = slotw + 32u * (uint32_t)tile + (uint32_t)s32;
-            const pnm3::Float3 p = *reinterpret_cast<const pnm3::Float3*>(fa.xyzs + (size_t)slot * 3), d = *reinterpret_cast<const pnm3::Float3*>(fa.dirs + (size_t)slot * 3);
-            float sigma_logit, e[3];
-            if (HALF) {
-                float g2[8];
-                tile_sigma_net_h<4>(fa.lv, wimg, emb_rsrc, wl, half, fa.net_bound, p.x, p.y, p.z, g2);
-                sigma_logit = g2[0];
-                __builtin_amdgcn_sched_barrier(0);
-                tile_color_net_h(wl, wimg, half, g2, d.x, d.y, d.z, e);
-            } else {
-                const f32x16 h2 = tile_sigma_net<PN_BF_LU>(fa.lv, lds_lv, fa.emb, wl, half, fa.net_bound, p.x, p.y, p.z);
-                sigma_logit = h2[0];
-                __builtin_amdgcn_sched_barrier(0);
-                tile_color_net(wl, wimg, half, h2, d.x, d.y, d.z, e);
-            }
-            if (half == 0) {
-                fa.sigmas[slot] = tile_sigma_out(fa.density_scale, sigma_logit);
-#pragma unroll
-                for (int o = 0; o < 3; o++) fa.rgbs[(size_t)slot * 3 + o] = HALF ? tile_rgb_out_h(e[o]) : tile_rgb_out(e[o]);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        network64(__ballot(have_ray));
+        wave_sync_mem();
         tick(3);
         // ---- 4. composite (kernel_composite_rays, raymarching.cu:827-923): one lane per ray; a ray goes on iff it used all 8 samples
         int alive = 0;
@@ -283,7 +484,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
         r_t = __shfl(r_t, gbase);
         if (have_ray) {
             // renderer.py:836: the loop ends when `step` reaches max_steps, whatever is still alive
-            if (alive && (uint32_t)(sb0 + 8 * (j + 1)) < fa.max_steps && j + 1 < MAXT) j++;
+            if (alive && (uint32_t)(sb0 + 8 * (j + (WHOLE ? 0 : 1))) < fa.max_steps && j + 1 < MAXT) j++;
             else index = -1;
         }
         tick(4);
@@ -295,6 +496,8 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
         atomicAdd(fa.clocks + 7, __builtin_amdgcn_s_memrealtime() - rt0);  // the wave's lifetime on the constant 100 MHz clock
         atomicMax(fa.clocks + 8, rounds);
         atomicMax(fa.clocks + 9, __builtin_amdgcn_s_memrealtime() - rt0);
+        if (WHOLE)
+            for (int k = 5; k < 10; k++) atomicAdd(fa.clocks + 5 + k, c_acc[k]);
     }
 
     // ---- end of the launch: per-trip counts to memory; the last workgroup writes the trip records and re-arms the control block
@@ -315,14 +518,16 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
     for (int j0 = 0; j0 < MAXT; j0 += 64) {
         const int jj = j0 + lane;
         int* hp = fa.ctl + PN_FUSED_CTL_HIST + jj;
-        const int al = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int al = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int em = __hip_atomic_load(hp + MAXT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int tl = __hip_atomic_load(hp + 2 * MAXT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (WHOLE && jj == 0) al = (int)fa.N_rays;  // the first trip: every ray (its record was written by the frame prologue)
         m += (int)__popcll(__ballot(al > 0));
         if (al > 0) {
             PnTrip* r = fa.trips + jj;
-            if (jj > 0) { r->n_alive = al; r->n_step = 8; r->step_base = sb0 + 8 * jj; r->dense = 1; r->n_samples = al * 8; }
-            r->n_emitted = em;
+            if (jj > 0) { r->n_alive = al; r->n_step = 8; r->step_base = sb0 + 8 * (jj - (WHOLE ? 1 : 0)); r->dense = 1; r->n_samples = al * 8; }
+            if (WHOLE && jj == 0) r->n_samples = em;  // a list trip: the samples listed (n_emitted stays -1)
+            else r->n_emitted = em;
             fa.tail_diag[jj] = tl;
         }
         __hip_atomic_store(hp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -331,7 +536,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
     }
     if (lane == 0) {
         PnTrip* r = fa.trips + m;  // the record behind the last trip that had rays: the frame is over
-        r->n_alive = 0; r->n_step = 1; r->step_base = sb0 + 8 * m; r->dense = 0; r->n_samples = 0; r->n_emitted = 0;
+        r->n_alive = 0; r->n_step = 1; r->step_base = WHOLE ? (m == 0 ? 0 : 1 + 8 * (m - 1)) : sb0 + 8 * m; r->dense = 0; r->n_samples = 0; r->n_emitted = 0;
         fa.dev->fused_trips = m;
         __hip_atomic_store(fa.ctl + PN_FUSED_CTL_DONE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -342,31 +547,37 @@ static size_t fused_lds_bytes(bool half) {
            3 * PN_FUSED_MAX_TRIPS * sizeof(int);
 }
 
-template <int K, bool MULTI, bool HALF>
+template <int K, bool MULTI, bool HALF, bool WHOLE>
 static int launch_trips_fused_t(uint32_t blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb, const FusedArgs& fa) {
     const size_t lds = fused_lds_bytes(HALF);
     static bool granted[PN_MAX_DEVICES] = {false};  // dynamic LDS above 64 KB is opted into per function and DEVICE
     int dev_id = 0;
     PN_HIP_CHECK(hipGetDevice(&dev_id));
     if (dev_id < 0 || dev_id >= PN_MAX_DEVICES || !granted[dev_id]) {
-        PN_HIP_CHECK(hipFuncSetAttribute((const void*)k_trips_fused<K, MULTI, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PN_HIP_CHECK(hipFuncSetAttribute((const void*)k_trips_fused<K, MULTI, HALF, WHOLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (dev_id >= 0 && dev_id < PN_MAX_DEVICES) granted[dev_id] = true;
     }
-    k_trips_fused<K, MULTI, HALF><<<blocks, PN_FUSED_WAVES * 64, lds, st>>>(a, tb, fa);
+    k_trips_fused<K, MULTI, HALF, WHOLE><<<blocks, PN_FUSED_WAVES * 64, lds, st>>>(a, tb, fa);
     PN_LAUNCH_CHECK();
     return PN_OK;
 }
 
-static int launch_trips_fused(int K, bool multi, bool half, uint32_t blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb,
+static int launch_trips_fused(int K, bool multi, bool half, bool whole, uint32_t blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb,
                               const FusedArgs& fa) {
-#define PN_FUSED_CASE(K_)                                                                                                   \
-    if (K == K_) {                                                                                                            \
-        if (multi) return half ? launch_trips_fused_t<K_, true, true>(blocks, st, a, tb, fa) : launch_trips_fused_t<K_, true, false>(blocks, st, a, tb, fa); \
-        return half ? launch_trips_fused_t<K_, false, true>(blocks, st, a, tb, fa) : launch_trips_fused_t<K_, false, false>(blocks, st, a, tb, fa);          \
+#define PN_FUSED_CASE2(K_, M_, H_) return whole ? launch_trips_fused_t<K_, M_, H_, true>(blocks, st, a, tb, fa) : launch_trips_fused_t<K_, M_, H_, false>(blocks, st, a, tb, fa)
+#define PN_FUSED_CASE(K_)                                      \
+    if (K == K_) {                                             \
+        if (multi) {                                           \
+            if (half) PN_FUSED_CASE2(K_, true, true);          \
+            PN_FUSED_CASE2(K_, true, false);                   \
+        }                                                      \
+        if (half) PN_FUSED_CASE2(K_, false, true);             \
+        PN_FUSED_CASE2(K_, false, false);                      \
     }
     PN_FUSED_CASE(1)
     PN_FUSED_CASE(2)
     PN_FUSED_CASE(3)
 #undef PN_FUSED_CASE
+#undef PN_FUSED_CASE2
     return PN_ERR_ARG;
 }

@@ -450,9 +450,12 @@ class _HipBackend:
             # pn_render_opts.fused_from: the loop trips from the first one with n_step == 8 on (n_alive <= N / 8: it stays 8 for the rest of the frame) run
             # as ONE persistent launch (csrc/pn_trips_fused.h) — read off the trip records of a blocking frame from the current state and pose.  A later
             # frame that still has more rays alive at that trip is finished when it is retired (frames.FramePipeline: continue), only slower
+            # fused_from = 0: the WHOLE frame behind the skip pre-pass in that launch, where at most N / 8 rays have anything to march (the blocking
+            # frame tries it and reports the trip at which the fused launch took over).
             h.step(simulate=False, collect_stats=True, W=W, H=H)
             recs = m.trip_records(slot=0, max_trips=64)
-            kw["fused_from"] = next((i for i, r in enumerate(recs) if i >= 1 and r[1] == 8), -1) if not kw.get("ray_batch") else -1
+            first = m.fused_clocks(slot=0)["first_trip"]
+            kw["fused_from"] = -1 if kw.get("ray_batch") else (0 if first == 0 else next((i for i, r in enumerate(recs) if i >= 1 and r[1] == 8), -1))
         pose0 = torch.from_numpy(np.asarray(h.pose, np.float32)).unsqueeze(0)
         self.pose_dev = [pose0.to(dev) for _ in range(n_ws)]
         self.pose_pin = [pose0.clone().pin_memory() for _ in range(n_ws)]

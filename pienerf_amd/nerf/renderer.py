@@ -117,7 +117,7 @@ class NeRFRenderer(nn.Module):
         if tw is None and n_rays and kwargs.get("W") and kwargs.get("H") and int(kwargs["W"]) * int(kwargs["H"]) == n_rays:
             tw = kwargs["W"]
         o.ray_tile_w = int(tw or 0)
-        o.fused_from = int(kwargs.get("fused_from") or 0)  # extension: first loop trip of the one-launch form (pn_render_opts.fused_from; 0: trip 1, < 0: never)
+        o.fused_from = int(kwargs.get("fused_from") or 0)  # extension: first loop trip of the one-launch form (pn_render_opts.fused_from; 0: the whole frame where it applies, else from trip 1; < 0: never)
         return o
 
     def rund_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-2, **kwargs):
@@ -214,7 +214,10 @@ class NeRFRenderer(nn.Module):
         out, first = (C.c_uint64 * 16)(), C.c_int(-1)
         check(lib().pn_frame_fused_clocks(self._frames[slot][0], out, C.byref(first), int(bool(reset)), stream_ptr()), "fused_clocks")
         return dict(refill=int(out[0]), march=int(out[1]), windows=int(out[2]), network=int(out[3]), composite=int(out[4]), wave_rounds=int(out[5]),
-                    waves=int(out[6]), lifetime_ticks=int(out[7]), max_rounds=int(out[8]), max_lifetime_ticks=int(out[9]), first_trip=int(first.value))
+                    waves=int(out[6]), lifetime_ticks=int(out[7]), max_rounds=int(out[8]), max_lifetime_ticks=int(out[9]), first_trip=int(first.value),
+                    # whole-frame form (fused_from = 0): the first trip's one-lane march, its 64-lane windows, its network, its composite + hand-over,
+                    # the wait at the workgroup barrier behind it
+                    a_march=int(out[10]), a_windows=int(out[11]), a_network=int(out[12]), a_composite=int(out[13]), a_barrier=int(out[14]))
 
     def trip_records(self, slot=0, max_trips=16):
         """Diagnostics: [(n_alive, n_step, step_base, n_samples, n_emitted, n_tail)] per trip of the last render on `slot`."""

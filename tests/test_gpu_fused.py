@@ -27,9 +27,11 @@ def _both_forms(net, o, d, opt, amp=False, **kw):
 
 def _assert_same(a, b):
     (sa, ra, oa, fa), (sb, rb, ob, fb) = a, b
-    assert fa == -1 and fb >= 1, (fa, fb)        # the second render did switch to the fused launch
+    assert fa == -1 and fb >= 0, (fa, fb)        # the second render did switch to the fused launch (0: for the whole frame)
     assert sa == sb and sa["err"] == 0 and sa["alive_at_exit"] == 0, (sa, sb)
-    assert ra == rb, (ra, rb)                    # (n_alive, n_step, step_base, n_samples, n_emitted, rays through the 64-lane windows) per trip
+    # (n_alive, n_step, step_base, n_samples, n_emitted, rays through the 64-lane windows) per trip; the last one is a diagnostic of the FORM of a frame's
+    # first trip (windows of 8 then 64 / one lane per ray then 64: how many rays outlast the first form)
+    assert ra[0][:5] == rb[0][:5] and ra[1:] == rb[1:], (ra, rb)
     for k in ("image", "depth_0", "weights_sum"):
         assert torch.equal(oa[k], ob[k]), k
     assert torch.equal(torch.nan_to_num(oa["depth"], nan=-1.0), torch.nan_to_num(ob["depth"], nan=-1.0))
@@ -45,6 +47,13 @@ def test_fused_trips_equal_the_trip_by_trip_frame(deformed_ip_state, small_opt, 
     assert a[0]["trips"] >= 4 and a[0]["samples"] > 3000, a[0]
     assert a[1][1][1] == 8  # the second trip marches 8 samples per ray: the fused launch starts there
     _assert_same(a, b)
+    assert b[3] == 0        # ... and, few enough rays meeting the object, it took the whole frame, first trip included
+    # the first trip as per-trip launches, the rest fused (fused_from = 1): the same frame again
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=fp16):
+        out = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **dict(opt, fused_from=1))
+    assert net.fused_clocks()["first_trip"] == 1 and dict(net.last_stats) == a[0] and net.trip_records(max_trips=140) == a[1]
+    for k in ("image", "depth_0", "weights_sum"):
+        assert torch.equal(out[k], a[2][k]), k
 
 
 @pytest.mark.parametrize("pose", [(5.0, 20.0, -15.0), (2.2, 75.0, -40.0), (9.0, -60.0, 5.0)])
@@ -73,14 +82,16 @@ def test_fused_launch_steps_aside_while_n_step_is_below_8(deformed_ip_state, sma
     assert a[0] == b[0] and a[1] == b[1]
     for k in ("image", "depth_0", "weights_sum"):
         assert torch.equal(a[2][k], b[2][k]), k
-    # async: 1 per-trip trip + the fused launch, which finds n_step < 8 and leaves the frame as it is
-    with torch.no_grad():
-        out = net.render_deformed(T(o)[None], T(d)[None], async_trips=8, **dict(opt, fused_from=0))
-        st = net.render_status()
-        assert st["alive_at_exit"] > 0 and st["trips"] == 1
-        net.render_continue(0, T(o)[None], T(d)[None], out, **dict(opt, fused_from=0))
-        assert net.last_stats["alive_at_exit"] == 0 and net.last_stats["samples"] == a[0]["samples"]
-    assert torch.equal(out["image"], a[2]["image"]) and torch.equal(out["weights_sum"], a[2]["weights_sum"])
+    # async: the fused launch finds too many rays with something to march (fused_from = 0: the whole frame) / n_step < 8 behind one per-trip trip
+    # (fused_from = 1) and leaves the frame as it is
+    for ff, trips_done in ((0, 0), (1, 1)):
+        with torch.no_grad():
+            out = net.render_deformed(T(o)[None], T(d)[None], async_trips=8, **dict(opt, fused_from=ff))
+            st = net.render_status()
+            assert st["alive_at_exit"] > 0 and st["trips"] == trips_done, st
+            net.render_continue(0, T(o)[None], T(d)[None], out, **dict(opt, fused_from=ff))
+            assert net.last_stats["alive_at_exit"] == 0 and net.last_stats["samples"] == a[0]["samples"]
+        assert torch.equal(out["image"], a[2]["image"]) and torch.equal(out["weights_sum"], a[2]["weights_sum"])
 
 
 def test_fused_trips_end_at_max_steps(deformed_ip_state, small_opt, ckpt):
@@ -133,7 +144,7 @@ def test_fused_trips_in_graphs_and_pipelines(small_cloud, small_opt, ckpt):
             got += [(i, {k: r[k].copy() for k in ("image", "depth_0")}) for i, r in h.step_pipelined(pose=p)]
         got += [(i, {k: r[k].copy() for k in ("image", "depth_0")}) for i, r in h.drain_pipeline()]
         res[name] = (got, h._pipe_backend.kw["fused_from"], h._pipe_backend.continued)
-    assert res["fused"][1] >= 1 and res["classic"][1] == -1
+    assert res["fused"][1] == 0 and res["classic"][1] == -1   # the pipeline's frames are whole-frame launches
     assert res["fused"][2] == 0
     assert [i for i, _ in res["fused"][0]] == list(range(7))
     for (i, a), (_, b) in zip(res["classic"][0], res["fused"][0]):

@@ -35,8 +35,9 @@ m.march_counters(0)
 n = args.frames
 waves = c["waves"] / n
 print(f"per frame: {waves:.0f} waves, {c['wave_rounds'] / n:.0f} wave-rounds ({c['wave_rounds'] / max(c['waves'], 1):.2f} per wave)")
-tot = sum(c[k] for k in ("refill", "march", "windows", "network", "composite"))
-for k in ("refill", "march", "windows", "network", "composite"):
+keys = ("refill", "march", "windows", "network", "composite", "a_march", "a_windows", "a_network", "a_composite", "a_barrier")
+tot = sum(c[k] for k in keys)
+for k in keys:
     print(f"  {k:10s} {c[k] / max(c['waves'], 1) / 1e3:8.1f} kcycles per wave  {100 * c[k] / tot:5.1f} %   {c[k] / max(c['wave_rounds'], 1):8.0f} cycles per wave-round")
 print(f"  total      {tot / max(c['waves'], 1) / 1e3:8.1f} kcycles per wave (~{tot / max(c['waves'], 1) / 2.4e3:.0f} us at 2.4 GHz)")
 life = c["lifetime_ticks"] / max(c["waves"], 1) * 10.0  # ns
