@@ -247,17 +247,30 @@ typedef struct {
                              n_step = max(min(N // n_alive, 8), 1) (renderer.py:839-846) is 8 for the rest of the frame, so every ray can loop
                              { march 8 samples; network; composite } on its own until it dies — the per-ray arithmetic, the samples, the pixels and the
                              per-trip counts of the trip-by-trip loop, without its 4-6 launches and its compaction per trip.
-                             0: the WHOLE frame behind the skip pre-pass, first trip included, where that applies — the first trip couples the rays only
-                             through the next trip's n_step, and n_alive there cannot exceed the rays the skip pre-pass left anything to march for: the
-                             launch checks on the device that those are at most N / 8 (the chair: 10 % of the rays meet the bounding box of the
-                             integration points) and does nothing otherwise; the blocking pn_render_deformed then runs the first trip as per-trip
-                             launches and fuses from trip 1 (or later, see below), a fixed-trip render is left unfinished at trip 0 and finished by
-                             pn_render_continue;
+                             0: from trip 1 (right behind the frame's first trip; the chair);
                              k >= 1: the first k trips as per-trip launches (a scene whose second trip still has more than N / 8 rays alive: the trex
                              option set — harness.capture_pipelined reads k off its warm-up frame); < 0: never.  If the launch finds n_step < 8 at
                              its first trip it does nothing and the frame is continued like one that ran out of captured trips (pn_render_continue;
                              the blocking pn_render_deformed runs one per-trip trip and tries again).  Not with ray_batch > 0 (batches keep their own
                              n_step), not for pn_render_static, not for max_steps > 1024. */
+    int fused_whole;      /* != 0 (with fused_from == 0): the WHOLE frame behind the skip pre-pass in that launch, first trip included, where that
+                             applies — the first trip couples the rays only through the next trip's n_step, and n_alive there cannot exceed the rays the
+                             skip pre-pass left anything to march for: the launch checks on the device that those are at most N / 8 (the chair: 10 % of the
+                             rays meet the bounding box of the integration points) and does nothing otherwise; the blocking pn_render_deformed then runs
+                             the first trip as per-trip launches and fuses from trip 1, a fixed-trip render is left unfinished at trip 0 and finished by
+                             pn_render_continue.  Inside the launch the first trip is three kinds of work items per workgroup (one lane per ray for a
+                             bounded number of rounds; 64-lane windows for the rays still searching; network tile + composite + hand-over per finished
+                             chunk of 64 rays) that its waves take whenever they hold no ray of a later trip.  A frame is then prologue (2 launches), skip
+                             pre-pass, this launch, epilogue.  Measured on the chair (MI355X): one frame at a time 0.90 ms against 0.86 ms, three frames in
+                             flight 1 730 against 1 930 steps/s (the workgroups of the launch hold a CU each while their first trip's dependency chain
+                             leaves most of its waves waiting), two frames in flight 1 700-1 740 against 1 560: harness.capture_pipelined switches it on for
+                             pipelines of two render lanes (what every rank of a multi-GPU job runs).  Same samples, records and pixels either way. */
+    int fused_grid;       /* workgroups of the fused launch (0: one per CU, its upper bound — 12 waves and 157 KB of LDS each, so a workgroup has its CU to
+                             itself).  A pipeline with several frames in flight gives each frame's launch a part of the GPU, so that the launches of
+                             different frames run side by side instead of one after the other and the rest of the frame's kernels (prologue, skip
+                             pre-pass, first trip, simulator) find CUs whose LDS is free: measured on the chair with three render lanes, 64 / 96 / 128 / 160 /
+                             192 / 256 workgroups: 1 798 / 1 939 / 1 937 / 1 874 / 1 799 / 1 721 steps/s (profiles/r04_fused_grid_sweep.txt);
+                             harness.capture_pipelined passes half the CUs when it runs more than one lane.  The results do not depend on it. */
 } pn_render_opts;
 int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_vtx, uint32_t max_grid_cells);
 void pn_frame_destroy(pn_frame* f);

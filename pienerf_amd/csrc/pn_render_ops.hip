@@ -2149,13 +2149,13 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     const int fuse_from = fused_ok ? std::max(o->fused_from, 1) : PN_MAX_TRIPS + 1;
     int add_fused = 0;
     f->fused_first = -1;
-    // ... and the WHOLE frame behind the skip pre-pass as one launch (pn_render_opts.fused_from == 0; pn_trips_fused.h, WHOLE): the launch checks on the
+    // ... and the WHOLE frame behind the skip pre-pass as one launch (pn_render_opts.fused_whole with fused_from == 0; pn_trips_fused.h, WHOLE): the launch checks on the
     // device that at most N / 8 rays have anything to march (then every trip after the first marches 8 samples per ray whatever the first one finds) and
     // does nothing otherwise — the blocking driver then goes on trip by trip as above, a fixed-trip render is left to pn_render_continue.
-    // PN_FUSED_WHOLE=0: the first trip always as per-trip launches (A/B).
-    static const bool whole_env = [] { const char* v = getenv("PN_FUSED_WHOLE"); return !(v && v[0] == '0'); }();
+    // PN_FUSED_WHOLE=0 / 1: never / wherever fused_from == 0 allows it (A/B runs).
+    static const int whole_env = [] { const char* v = getenv("PN_FUSED_WHOLE"); return !v ? -1 : (v[0] == '0' ? 0 : 1); }();
     static const uint32_t a_rounds_env = pn_env_u32("PN_FUSED_AROUNDS", 0);
-    bool whole_try = fused_ok && whole_env && o->fused_from == 0 && !resume && t == 0;
+    bool whole_try = fused_ok && (whole_env < 0 ? o->fused_whole != 0 : whole_env != 0) && o->fused_from == 0 && !resume && t == 0;
     bool skip_done = resume && f->skip_done != 0;
     if (!resume) f->skip_done = 0;
     int* const seg_tail = f->seg_counters;
@@ -2217,7 +2217,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                 skip_done = true;
                 f->skip_done = 1;
             }
-            const uint32_t blocks = fused_grid_env ? std::min(fused_grid_env, f->fused_blocks) : f->fused_blocks;
+            const uint32_t blocks = fused_grid_env ? std::min(fused_grid_env, f->fused_blocks) : (o->fused_grid > 0 ? std::min((uint32_t)o->fused_grid, f->fused_blocks) : f->fused_blocks);
             rc = launch_trips_fused(o->num_seek_IP, o->max_iter_num > 1, o->fp16 != 0, whole, blocks, st, mq, tb, fa);
             if (rc) return rc;
             if (timed) {

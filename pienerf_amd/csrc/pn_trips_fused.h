@@ -123,6 +123,7 @@ __device__ __forceinline__ bool composite_slots8(int index, uint32_t slot0, floa
 
 __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
+#define PN_FUSED_MAXCHUNKS 96  // first-trip chunks per workgroup (a counter each in LDS)
 #ifndef PN_FUSED_ACHUNK
 #define PN_FUSED_ACHUNK 64  // rays of the frame's first trip a wave takes at a time (whole-frame form): one lane each
 #endif
@@ -148,7 +149,9 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
     uint4* wimg = fused_lds;  // the weight image, then the 16 level records (512 B), as in k_nerf_forward
     float4* stage_all = reinterpret_cast<float4*>(fused_lds + IMG16 + 32);
     int* hist = reinterpret_cast<int*>(stage_all + PN_FUSED_WAVES * PN_FUSED_STAGE);  // [3][MAXT]: rays entering trip j, samples emitted, rays through the 64-lane windows
-    __shared__ int s_last, s_cursor, s_bcount, s_strag;
+    __shared__ int s_last, s_cursor;
+    __shared__ int s_bres, s_bready, s_bhead, s_sres, s_sready, s_shead, s_pending, s_a1done;  // WHOLE: the workgroup's list of rays going on, its straggler queue, chunks without their A3
+    __shared__ int s_pend[PN_FUSED_MAXCHUNKS];  // WHOLE: positions of each chunk still open
     __shared__ int s_pref[PN_SEGS + 1];
 
     const PnTrip* tr = fa.trips;
@@ -171,7 +174,8 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
         n_active = s_pref[PN_SEGS];
         const long long chunks = ((long long)n_active + AC - 1) / AC;
         const bool ok = tr->n_alive == (int)fa.N_rays && tr->n_step == 1 && tr->step_base == 0 && (long long)n_active * 8 <= (long long)fa.N_rays &&
-                        (chunks + (long long)gridDim.x) * AC <= (long long)fa.blist_cap;  // (also the room behind the waves' sample slots)
+                        (chunks + (long long)gridDim.x) * AC <= (long long)fa.blist_cap &&  // (also the room behind the waves' sample slots)
+                        (chunks + (long long)gridDim.x - 1) / (long long)gridDim.x <= PN_FUSED_MAXCHUNKS;
         if (!ok) return;
         sb0 = 1;  // `step` behind the first trip
     } else {
@@ -182,7 +186,13 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
     for (int i = threadIdx.x; i < IMG16; i += PN_FUSED_WAVES * 64) wimg[i] = fa.wimg_g[i];
     if (threadIdx.x < 16 * sizeof(PnFusedLevel) / 16) wimg[IMG16 + threadIdx.x] = reinterpret_cast<const uint4*>(fa.lv)[threadIdx.x];
     for (int i = threadIdx.x; i < 3 * MAXT; i += PN_FUSED_WAVES * 64) hist[i] = 0;
-    if (threadIdx.x == 0) { s_cursor = 0; s_bcount = 0; s_strag = 0; }
+    if (threadIdx.x == 0) { s_cursor = 0; s_bres = s_bready = s_bhead = s_sres = s_sready = s_shead = s_a1done = 0; }
+    if (WHOLE) {
+        const int n_chunks0 = (n_active + AC - 1) / AC;
+        const int mine0 = (int)blockIdx.x < n_chunks0 ? (n_chunks0 - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+        if (threadIdx.x == 0) s_pending = mine0;
+        for (int i = threadIdx.x; i < PN_FUSED_MAXCHUNKS; i += PN_FUSED_WAVES * 64) s_pend[i] = 64;
+    }
     __syncthreads();
 
     const int sub = lane & 7, gbase = lane & ~7, grp = lane >> 3;
@@ -199,7 +209,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
 
     const bool clk = fa.clocks != nullptr;
     unsigned long long c_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, c_t = 0, rounds = 0;
-    auto tick = [&](int k) {
+    auto tick = [&](int k) __attribute__((always_inline)) {
         if (clk) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             const unsigned long long n = __builtin_readcyclecounter();
@@ -211,7 +221,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
     if (clk) { c_t = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
     // the network on 32 consecutive sample slots (two lanes per sample: lanes s32 and s32 + 32 hold sample slot_of_lane's two level halves)
-    auto network_tile = [&](uint32_t slot) {
+    auto network_tile = [&](uint32_t slot) __attribute__((always_inline)) {
         const pnm3::Float3 p = *reinterpret_cast<const pnm3::Float3*>(fa.xyzs + (size_t)slot * 3), d = *reinterpret_cast<const pnm3::Float3*>(fa.dirs + (size_t)slot * 3);
         float sigma_logit, e[3];
         if (HALF) {
@@ -233,122 +243,61 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
         }
     };
     // ... on the wave's 64 slots: tile 0 = slots 0..31, tile 1 = 32..63; `rm`: lanes whose slots carry something
-    auto network64 = [&](unsigned long long rm) {
+    auto network64 = [&](unsigned long long rm) __attribute__((always_inline)) {
 #pragma unroll 1
         for (int tile = 0; tile < 2; tile++) {
             if (!((rm >> (32 * tile)) & 0xFFFFFFFFull)) continue;
             network_tile(slotw + 32u * (uint32_t)tile + (uint32_t)s32);
         }
     };
-    auto wave_sync_mem = [&]() {  // the wave's own stores before its own loads of the same addresses by other lanes
+    auto wave_sync_mem = [&]() __attribute__((always_inline)) {  // the wave's own stores before its own loads of the same addresses by other lanes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
 
+    // ---- WHOLE: the frame's first trip on this workgroup's share of the active list, as three kinds of work items the waves take whenever they hold no
+    // ray of a later trip.  Position p of the share (chunk p / AC of the workgroup, lane p % AC) owns sample slot a_base + p — behind the slots of the
+    // later trips' waves — and entry p of the workgroup's index list.
+    //   A1 (one per chunk)  ONE lane per ray for a_rounds rounds (march_window<K, MULTI, 1>: every evaluated point is a visited one); the rays still
+    //                       searching go to the workgroup's straggler queue;
+    //   A2 (one per such ray)  64 sequence elements per round with a whole wave;
+    //   A3 (one per chunk, run by the wave that finishes the chunk's last ray — s_pend[chunk] counts them down)  network on the chunk's two tiles of 32
+    //                       positions, composite (one sample), and the rays that go on appended to the workgroup's list, from which step 1 below refills.
+    // Queues are (reserved, ready, head) counters in LDS over arrays in global memory: a producer reserves, writes, waits for its stores and publishes in
+    // reservation order; consumers claim below `ready` with a compare-and-swap.  Nothing waits for a consumer, so every reserved entry gets published and
+    // every published entry taken: a wave only sleeps while another one is inside an item that can still produce work (s_pending: chunks without their A3).
     int share = 0;
     const int* my_list = nullptr;
-    if (WHOLE) {
-        // ---- A. the frame's first trip on this workgroup's share of the active list, in three steps with a workgroup barrier behind each.
-        // Position p of the share (chunk p / AC of the workgroup, lane p % AC) owns sample slot a_base + p — behind the slots of the later trips' waves — and
-        // entry p of the workgroup's index list.
-        const int n_chunks = (n_active + AC - 1) / AC;
-        const int my_chunks = (int)blockIdx.x < n_chunks ? (n_chunks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-        const int bcap = ((n_chunks + (int)gridDim.x - 1) / (int)gridDim.x) * AC;
-        const size_t wg_off = (size_t)blockIdx.x * (size_t)bcap;
-        int* const a_index = fa.blist + wg_off;                         // ray id per position
-        int* const blist = fa.blist + (size_t)fa.blist_cap + wg_off;    // the rays that go on behind the first trip
-        int4* const strag = fa.strag + wg_off;                          // (position, t, last_t, ray id) of the rays still searching after the one-lane rounds
-        const uint32_t a_base = gridDim.x * (uint32_t)(PN_FUSED_WAVES * 64) + (uint32_t)wg_off;
-        my_list = blist;
-        const bool go_on = 1u < fa.max_steps;  // renderer.py:836: the loop ends when `step` (1 behind the first trip) reaches max_steps
-        // -- A1. ONE lane per ray for a_rounds rounds (march_window<K, MULTI, 1>: every evaluated point is a visited one)
+    int my_chunks = 0;
+    int *a_index = nullptr, *blist = nullptr;
+    int4* strag = nullptr;
+    uint32_t a_base = 0;
+    bool go_on = true;
+    auto lds_ld = [](int* p_) __attribute__((always_inline)) { return __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto lds_st = [](int* p_, int v) __attribute__((always_inline)) { __hip_atomic_store(p_, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    // lane 0: claim up to `want` entries of a queue; returns the first one, `take` = how many (0: none ready)
+    auto q_claim = [&](int* head, int* ready, int want, int& take) __attribute__((always_inline)) {
+        int base = 0;
+        take = 0;
         for (;;) {
-            int ci = 0;
-            if (lane == 0) ci = atomicAdd(&s_cursor, 1);
-            ci = __builtin_amdgcn_readfirstlane(ci);
-            if (ci >= my_chunks) break;
-            const int gi = ((int)blockIdx.x + ci * (int)gridDim.x) * AC + lane;  // position in the concatenation of the active segments
-            const bool in_chunk = lane < AC;
-            const bool mine = in_chunk && gi < n_active;
-            const int pos = ci * AC + lane;
-            int index = -1;
-            pnm3::RayConsts c;
-            pnm3::frame_consts(a, c);
-            c.ox = c.oy = c.oz = 0.f; c.dx = c.dy = c.dz = 1.f; c.rdx = c.rdy = c.rdz = 1.f; c.far = 0.f;
-            pnm3::RayState st{0.f, 0.f, 0u};
-            bool have = false;
-            if (mine) {
-                int lo = 0, hi = PN_SEGS;  // segment with s_pref[seg] <= gi < s_pref[seg + 1]
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_pref[mid] <= gi) lo = mid; else hi = mid;
-                }
-                const int n = fa.active[(size_t)lo * fa.active_seg_cap + (gi - s_pref[lo])];
-                index = fa.alive[n];
-                pnm3::ray_consts(a, index, c);
-                have = pnm3::ray_start(a, c, index, 0.0f, fa.t_resume + n, st);
-            }
-            if (in_chunk) a_index[pos] = index;
-            const size_t sl = (size_t)a_base + (size_t)(in_chunk ? pos : ci * AC);
-            float* const Xa = fa.xyzs + sl * 3;
-            float* const Da = fa.dirs + sl * 3;
-            float* const La = fa.deltas + sl * 2;
-            tick(0);
-            const bool done = pnm3::march_window<K, MULTI, 1, PN_FUSED_STAGE, 1>(a, tb, c, 1u, 0, lane, lane, stage, Xa, Da, La, st, fa.a_rounds, have);
-            const bool deferred = have && !done;
-            const unsigned long long dm = __ballot(deferred);
-            if (dm) {
-                int base = 0;
-                if (lane == 0) { base = atomicAdd(&s_strag, (int)__popcll(dm)); atomicAdd(&hist[2 * MAXT], (int)__popcll(dm)); }
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (deferred) strag[base + (int)__popcll(dm & ((1ull << lane) - 1ull))] = make_int4(pos, __float_as_int(st.t), __float_as_int(st.last_t), index);
-            }
-            if (in_chunk && !deferred && !(have && st.step != 0u)) {  // no sample: the slot runs through the network like the dense trips' empty ones and ends nothing
-                La[0] = 0.0f; La[1] = 0.0f;
-                Xa[0] = Xa[1] = Xa[2] = 0.0f;
-                Da[0] = Da[1] = Da[2] = 0.0f;
-            }
-            tick(5);
+            const int h = lds_ld(head), r = lds_ld(ready);
+            const int t_ = min(want, r - h);
+            if (t_ <= 0) break;
+            if (atomicCAS(head, h, h + t_) == h) { base = h; take = t_; break; }
         }
-        wave_sync_mem();
-        __syncthreads();
-        if (threadIdx.x == 0) s_cursor = 0;
-        __syncthreads();
-        tick(9);
-        // -- A2. the rays still searching: 64 sequence elements per round with a whole wave each, handed out one at a time
-        const int n_strag = s_strag;
-        for (;;) {
-            int e = 0;
-            if (lane == 0) e = atomicAdd(&s_cursor, 1);
-            e = __builtin_amdgcn_readfirstlane(e);
-            if (e >= n_strag) break;
-            const int4 se = strag[e];
-            pnm3::RayConsts c2;
-            pnm3::ray_consts(a, se.w, c2);
-            pnm3::RayState s2{__int_as_float(se.y), __int_as_float(se.z), 0u};
-            const size_t sl = (size_t)a_base + (size_t)se.x;
-            pnm3::march_window<K, MULTI, 64, PN_FUSED_STAGE, 1>(a, tb, c2, 1u, lane, 0, lane, stage, fa.xyzs + sl * 3, fa.dirs + sl * 3, fa.deltas + sl * 2, s2, 0x7fffffff, true);
-            if (s2.step == 0u && lane < 8) {
-                if (lane < 2) fa.deltas[sl * 2 + lane] = 0.0f;
-                else if (lane < 5) fa.xyzs[sl * 3 + (lane - 2)] = 0.0f;
-                else fa.dirs[sl * 3 + (lane - 5)] = 0.0f;
-            }
-        }
-        wave_sync_mem();
-        __syncthreads();
-        if (threadIdx.x == 0) s_cursor = 0;
-        __syncthreads();
-        tick(6);
-        // -- A3. network on tiles of 32 positions, composite (one sample), hand-over: a ray goes on iff it used its sample (kernel_composite_rays,
-        // raymarching.cu:827-923)
-        const int n_tiles = my_chunks * AC / 32;
-        for (;;) {
-            int ti = 0;
-            if (lane == 0) ti = atomicAdd(&s_cursor, 1);
-            ti = __builtin_amdgcn_readfirstlane(ti);
-            if (ti >= n_tiles) break;
-            const int pos = ti * 32 + s32;
+        return base;
+    };
+    // lane 0, after the wave's stores to the reserved entries [base, base + n) have completed: publish them in reservation order
+    auto q_publish = [&](int* ready, int base, int n) __attribute__((always_inline)) {
+        while (lds_ld(ready) != base) __builtin_amdgcn_s_sleep(1);
+        lds_st(ready, base + n);
+    };
+    // A3 of chunk ci (see above)
+    auto chunk_finish = [&](int ci) __attribute__((always_inline)) {
+#pragma unroll 1
+        for (int tile = 0; tile < AC / 32; tile++) {
+            const int pos = ci * AC + tile * 32 + s32;
             const uint32_t slot = a_base + (uint32_t)pos;
             const bool has = fa.deltas[(size_t)slot * 2] != 0.0f;
             const unsigned long long em = __ballot(has && half == 0);
@@ -361,30 +310,133 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
             wave_sync_mem();
             tick(7);
             bool on = false;
-            int index = -1;
+            int idx = -1;
             if (has && half == 0) {
-                index = a_index[pos];
-                on = composite_one(index, slot, 1u, fa.T_thresh, fa.rays_t, fa.sigmas, fa.rgbs, fa.deltas, fa.weights_sum, fa.depth, fa.image) && go_on;
+                idx = a_index[pos];
+                on = composite_one(idx, slot, 1u, fa.T_thresh, fa.rays_t, fa.sigmas, fa.rgbs, fa.deltas, fa.weights_sum, fa.depth, fa.image) && go_on;
             }
             const unsigned long long om = __ballot(on);
+            wave_sync_mem();  // the composite's stores (rays_t: read by the wave that takes the ray on) before the ray is published
             if (om) {
                 int base = 0;
-                if (lane == 0) base = atomicAdd(&s_bcount, (int)__popcll(om));
+                if (lane == 0) base = atomicAdd(&s_bres, (int)__popcll(om));
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (on) blist[base + (int)__popcll(om & ((1ull << lane) - 1ull))] = index;
+                if (on) blist[base + (int)__popcll(om & ((1ull << lane) - 1ull))] = idx;
+                wave_sync_mem();
+                if (lane == 0) q_publish(&s_bready, base, (int)__popcll(om));
             }
             tick(8);
         }
-        wave_sync_mem();
-        __syncthreads();  // the workgroup's list is complete
-        share = s_bcount;
-        if (threadIdx.x == 0) s_cursor = 0;
-        __syncthreads();
-        tick(9);
+        if (lane == 0) atomicSub(&s_pending, 1);
+    };
+    // lane 0: `n` positions of chunk ci are final; true on the wave that made them all
+    auto chunk_arrive = [&](int ci, int n) __attribute__((always_inline)) {
+        int left = 1;
+        if (lane == 0) left = atomicSub(&s_pend[ci], n) - n;
+        return __builtin_amdgcn_readfirstlane(left) == 0;
+    };
+    if (WHOLE) {
+        const int n_chunks = (n_active + AC - 1) / AC;
+        my_chunks = (int)blockIdx.x < n_chunks ? (n_chunks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+        const int bcap = ((n_chunks + (int)gridDim.x - 1) / (int)gridDim.x) * AC;
+        const size_t wg_off = (size_t)blockIdx.x * (size_t)bcap;
+        a_index = fa.blist + wg_off;                         // ray id per position
+        blist = fa.blist + (size_t)fa.blist_cap + wg_off;    // the rays that go on behind the first trip
+        strag = fa.strag + wg_off;                           // (position, t, last_t, ray id) of the rays still searching after the one-lane rounds
+        a_base = gridDim.x * (uint32_t)(PN_FUSED_WAVES * 64) + (uint32_t)wg_off;
+        my_list = blist;
+        go_on = 1u < fa.max_steps;  // renderer.py:836: the loop ends when `step` (1 behind the first trip) reaches max_steps
     } else {
         const int n_packets = (A + 7) >> 3;
         const int my_packets = (int)blockIdx.x < n_packets ? (n_packets - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
         share = my_packets * 8;
+    }
+
+    if (WHOLE) {
+        // ---- the first trip's work items (see above), in the order of its dependency chain: a chunk if one is left, else a ray still searching; a wave
+        // moves on to the later trips when neither is left nor can appear (every chunk has been through its one-lane rounds)
+        for (;;) {
+            int fin_chunk = -1;  // a chunk this wave has just made complete
+            int ci = my_chunks;
+            if (lane == 0 && lds_ld(&s_cursor) < my_chunks) ci = atomicAdd(&s_cursor, 1);
+            ci = __builtin_amdgcn_readfirstlane(ci);
+            if (ci < my_chunks) {
+                const int gi = ((int)blockIdx.x + ci * (int)gridDim.x) * AC + lane;  // position in the concatenation of the active segments
+                const bool in_chunk = lane < AC;
+                const bool mine = in_chunk && gi < n_active;
+                const int pos = ci * AC + lane;
+                int idx = -1;
+                pnm3::RayConsts c;
+                pnm3::frame_consts(a, c);
+                c.ox = c.oy = c.oz = 0.f; c.dx = c.dy = c.dz = 1.f; c.rdx = c.rdy = c.rdz = 1.f; c.far = 0.f;
+                pnm3::RayState st{0.f, 0.f, 0u};
+                bool have = false;
+                if (mine) {
+                    int lo = 0, hi = PN_SEGS;  // segment with s_pref[seg] <= gi < s_pref[seg + 1]
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_pref[mid] <= gi) lo = mid; else hi = mid;
+                    }
+                    const int n = fa.active[(size_t)lo * fa.active_seg_cap + (gi - s_pref[lo])];
+                    idx = fa.alive[n];
+                    pnm3::ray_consts(a, idx, c);
+                    have = pnm3::ray_start(a, c, idx, 0.0f, fa.t_resume + n, st);
+                }
+                if (in_chunk) a_index[pos] = idx;
+                const size_t sl = (size_t)a_base + (size_t)(in_chunk ? pos : ci * AC);
+                float* const Xa = fa.xyzs + sl * 3;
+                float* const Da = fa.dirs + sl * 3;
+                float* const La = fa.deltas + sl * 2;
+                tick(0);
+                const bool done = pnm3::march_window<K, MULTI, 1, PN_FUSED_STAGE, 1>(a, tb, c, 1u, 0, lane, lane, stage, Xa, Da, La, st, fa.a_rounds, have);
+                const bool deferred = have && !done;
+                const unsigned long long dm = __ballot(deferred);
+                const int n_def = (int)__popcll(dm);
+                if (in_chunk && !deferred && !(have && st.step != 0u)) {  // no sample: the slot ends nothing (its tile runs it like the dense trips' empty slots)
+                    La[0] = 0.0f; La[1] = 0.0f;
+                    Xa[0] = Xa[1] = Xa[2] = 0.0f;
+                    Da[0] = Da[1] = Da[2] = 0.0f;
+                }
+                int qb = 0;
+                if (dm) {
+                    if (lane == 0) { qb = atomicAdd(&s_sres, n_def); atomicAdd(&hist[2 * MAXT], n_def); }
+                    qb = __builtin_amdgcn_readfirstlane(qb);
+                    if (deferred) strag[qb + (int)__popcll(dm & ((1ull << lane) - 1ull))] = make_int4(pos, __float_as_int(st.t), __float_as_int(st.last_t), idx);
+                }
+                wave_sync_mem();
+                if (dm && lane == 0) q_publish(&s_sready, qb, n_def);
+                if (lane == 0) atomicAdd(&s_a1done, 1);  // (behind the publication: whoever sees every chunk done sees every straggler)
+                tick(5);
+                if (chunk_arrive(ci, 64 - n_def)) fin_chunk = ci;  // (lanes beyond AC count as final positions of their own)
+            }
+            int e = 0, got = 0;
+            if (ci >= my_chunks && lane == 0) e = q_claim(&s_shead, &s_sready, 1, got);
+            got = __builtin_amdgcn_readfirstlane(got);
+            if (got) {
+                e = __builtin_amdgcn_readfirstlane(e);
+                const int4 se = strag[e];
+                pnm3::RayConsts c2;
+                pnm3::ray_consts(a, se.w, c2);
+                pnm3::RayState s2{__int_as_float(se.y), __int_as_float(se.z), 0u};
+                const size_t sl = (size_t)a_base + (size_t)se.x;
+                pnm3::march_window<K, MULTI, 64, PN_FUSED_STAGE, 1>(a, tb, c2, 1u, lane, 0, lane, stage, fa.xyzs + sl * 3, fa.dirs + sl * 3, fa.deltas + sl * 2, s2, 0x7fffffff, true);
+                if (s2.step == 0u && lane < 8) {
+                    if (lane < 2) fa.deltas[sl * 2 + lane] = 0.0f;
+                    else if (lane < 5) fa.xyzs[sl * 3 + (lane - 2)] = 0.0f;
+                    else fa.dirs[sl * 3 + (lane - 5)] = 0.0f;
+                }
+                wave_sync_mem();
+                tick(6);
+                if (chunk_arrive(se.x / AC, 1)) fin_chunk = se.x / AC;
+            }
+            if (fin_chunk >= 0) chunk_finish(fin_chunk);
+            if (ci < my_chunks || got) continue;
+            int gone = 0;
+            if (lane == 0) gone = (lds_ld(&s_a1done) >= my_chunks && lds_ld(&s_shead) >= lds_ld(&s_sready)) ? 1 : 0;
+            if (__builtin_amdgcn_readfirstlane(gone)) break;
+            __builtin_amdgcn_s_sleep(16);
+            tick(9);
+        }
     }
 
     // Hand-out (WHOLE = false): the alive list is dealt to the workgroups in packets of 8 consecutive entries (neighbouring pixels: a wave's rays share candidate
@@ -401,18 +453,23 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
 
     for (;;) {
         // ---- 1. refill the groups without a ray
-        if (!pool_empty) {
+        if (WHOLE || !pool_empty) {
             const unsigned long long em = __ballot(index < 0 && sub == 0);
             const int need = (int)__popcll(em);
             if (need > 0) {
                 const int my_rank = (int)__popcll(em & ((1ull << gbase) - 1ull));
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_cursor, need);
+                int base = 0, take = need;
+                if (WHOLE) {
+                    if (lane == 0) base = q_claim(&s_bhead, &s_bready, need, take);
+                    take = __builtin_amdgcn_readfirstlane(take);
+                } else {
+                    if (lane == 0) base = atomicAdd(&s_cursor, need);
+                }
                 base = __builtin_amdgcn_readfirstlane(base);
-                pool_empty = base + need >= share;
+                if (!WHOLE) pool_empty = base + need >= share;
                 const int p = base + my_rank;
                 const int gpos = WHOLE ? p : ((p >> 3) * (int)gridDim.x + (int)blockIdx.x) * 8 + (p & 7);
-                if (index < 0 && p < share && (WHOLE || gpos < A)) {
+                if (index < 0 && (WHOLE ? my_rank < take : (p < share && gpos < A))) {
                     index = WHOLE ? my_list[gpos] : fa.alive[gpos];
                     j = WHOLE ? 1 : 0;
                     pnm3::RayConsts cn;
@@ -422,7 +479,16 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
                 }
             }
         }
-        if (!__any(index >= 0)) break;
+        if (!__any(index >= 0)) {
+            if (!WHOLE) break;
+            // ---- no ray in hand and none to take: wait for the first trip's last chunks (another wave is in their A3), or done
+            int fin = 0;
+            if (lane == 0) fin = (lds_ld(&s_pending) == 0 && lds_ld(&s_bhead) >= lds_ld(&s_bready)) ? 1 : 0;
+            if (__builtin_amdgcn_readfirstlane(fin)) break;
+            __builtin_amdgcn_s_sleep(32);
+            tick(9);
+            continue;
+        }
         rounds++;
         tick(0);
         // ---- 2. march: one window round of 8 lanes per ray, then the rays still going with the whole wave

@@ -445,17 +445,33 @@ class _HipBackend:
         # several frames in flight: the first trip's march pass in its throughput form (pn_render_opts.throughput: one lane per ray, no speculative
         # evaluation; the same samples bit for bit, +8 % steps/s with three lanes) — with one lane the frame's own latency is what counts
         kw.setdefault("march_throughput", 64 if lanes > 1 else 0)
+        # ... and each frame's fused launch (pn_render_opts.fused_from) on half of the CUs: the launches of the frames in flight run side by side and the
+        # other kernels find CUs with free LDS (pn_render_opts.fused_grid; three lanes on the chair: 1 721 -> 1 937 steps/s)
+        if lanes > 1:
+            kw.setdefault("fused_grid", max(torch.cuda.get_device_properties(dev).multi_processor_count // 2, 1))
         self.kw = kw
         if "fused_from" not in kw:
             # pn_render_opts.fused_from: the loop trips from the first one with n_step == 8 on (n_alive <= N / 8: it stays 8 for the rest of the frame) run
             # as ONE persistent launch (csrc/pn_trips_fused.h) — read off the trip records of a blocking frame from the current state and pose.  A later
             # frame that still has more rays alive at that trip is finished when it is retired (frames.FramePipeline: continue), only slower
-            # fused_from = 0: the WHOLE frame behind the skip pre-pass in that launch, where at most N / 8 rays have anything to march (the blocking
-            # frame tries it and reports the trip at which the fused launch took over).
             h.step(simulate=False, collect_stats=True, W=W, H=H)
             recs = m.trip_records(slot=0, max_trips=64)
-            first = m.fused_clocks(slot=0)["first_trip"]
-            kw["fused_from"] = -1 if kw.get("ray_batch") else (0 if first == 0 else next((i for i, r in enumerate(recs) if i >= 1 and r[1] == 8), -1))
+            kw["fused_from"] = next((i for i, r in enumerate(recs) if i >= 1 and r[1] == 8), -1) if not kw.get("ray_batch") else -1
+        if "fused_whole" not in kw:
+            # pn_render_opts.fused_whole: the frame's first trip in that launch too (where at most N / 8 rays have anything to march: the blocking frame
+            # below tries it and reports the trip at which the fused launch took over).  Measured on the chair: better with two frames in flight
+            # (1 700-1 740 against 1 560 steps/s), worse with three (1 730 against 1 930) or one at a time — include/pienerf_hip.h
+            whole = lanes == 2 and kw["fused_from"] == 1
+            if whole:
+                h.opt["fused_whole"] = True   # (render_kwargs() hands the option set to the renderer by name)
+                try:
+                    h.step(simulate=False, collect_stats=True, W=W, H=H)
+                    whole = m.fused_clocks(slot=0)["first_trip"] == 0
+                finally:
+                    h.opt.pop("fused_whole", None)
+            kw["fused_whole"] = bool(whole)
+            if whole:
+                kw["fused_from"] = 0
         pose0 = torch.from_numpy(np.asarray(h.pose, np.float32)).unsqueeze(0)
         self.pose_dev = [pose0.to(dev) for _ in range(n_ws)]
         self.pose_pin = [pose0.clone().pin_memory() for _ in range(n_ws)]

@@ -117,7 +117,9 @@ class NeRFRenderer(nn.Module):
         if tw is None and n_rays and kwargs.get("W") and kwargs.get("H") and int(kwargs["W"]) * int(kwargs["H"]) == n_rays:
             tw = kwargs["W"]
         o.ray_tile_w = int(tw or 0)
-        o.fused_from = int(kwargs.get("fused_from") or 0)  # extension: first loop trip of the one-launch form (pn_render_opts.fused_from; 0: the whole frame where it applies, else from trip 1; < 0: never)
+        o.fused_from = int(kwargs.get("fused_from") or 0)  # extension: first loop trip of the one-launch form (pn_render_opts.fused_from; 0: trip 1, < 0: never)
+        o.fused_grid = int(kwargs.get("fused_grid") or 0)  # extension: workgroups of that launch (pn_render_opts.fused_grid; 0: one per CU)
+        o.fused_whole = int(bool(kwargs.get("fused_whole")))  # extension: ... the frame's first trip included, where it applies (pn_render_opts.fused_whole)
         return o
 
     def rund_cuda(self, rays_o, rays_d, dt_gamma=0, bg_color=None, perturb=False, max_steps=1024, T_thresh=1e-2, **kwargs):

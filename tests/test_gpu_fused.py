@@ -18,8 +18,8 @@ pytestmark = pytest.mark.gpu
 def _both_forms(net, o, d, opt, amp=False, **kw):
     res = []
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=amp):
-        for fused_from in (-1, 0):
-            out = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **dict(opt, fused_from=fused_from, **kw))
+        for fused_from in (-1, 0):   # trip by trip / the whole frame in the fused launch where that applies, else from the first trip with n_step == 8
+            out = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **dict(opt, fused_from=fused_from, fused_whole=True, **kw))
             res.append((dict(net.last_stats), net.trip_records(max_trips=140), {k: out[k].clone() for k in ("image", "depth", "depth_0", "weights_sum")},
                         net.fused_clocks()["first_trip"]))
     return res
@@ -48,9 +48,9 @@ def test_fused_trips_equal_the_trip_by_trip_frame(deformed_ip_state, small_opt, 
     assert a[1][1][1] == 8  # the second trip marches 8 samples per ray: the fused launch starts there
     _assert_same(a, b)
     assert b[3] == 0        # ... and, few enough rays meeting the object, it took the whole frame, first trip included
-    # the first trip as per-trip launches, the rest fused (fused_from = 1): the same frame again
+    # the first trip as per-trip launches, the rest fused (fused_from = 0 without fused_whole): the same frame again
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=fp16):
-        out = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **dict(opt, fused_from=1))
+        out = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **dict(opt, fused_from=0))
     assert net.fused_clocks()["first_trip"] == 1 and dict(net.last_stats) == a[0] and net.trip_records(max_trips=140) == a[1]
     for k in ("image", "depth_0", "weights_sum"):
         assert torch.equal(out[k], a[2][k]), k
@@ -82,14 +82,14 @@ def test_fused_launch_steps_aside_while_n_step_is_below_8(deformed_ip_state, sma
     assert a[0] == b[0] and a[1] == b[1]
     for k in ("image", "depth_0", "weights_sum"):
         assert torch.equal(a[2][k], b[2][k]), k
-    # async: the fused launch finds too many rays with something to march (fused_from = 0: the whole frame) / n_step < 8 behind one per-trip trip
-    # (fused_from = 1) and leaves the frame as it is
-    for ff, trips_done in ((0, 0), (1, 1)):
+    # async: the fused launch finds too many rays with something to march (fused_whole: the whole frame) / n_step < 8 behind one per-trip trip and
+    # leaves the frame as it is
+    for whole, trips_done in ((True, 0), (False, 1)):
         with torch.no_grad():
-            out = net.render_deformed(T(o)[None], T(d)[None], async_trips=8, **dict(opt, fused_from=ff))
+            out = net.render_deformed(T(o)[None], T(d)[None], async_trips=8, **dict(opt, fused_from=0, fused_whole=whole))
             st = net.render_status()
             assert st["alive_at_exit"] > 0 and st["trips"] == trips_done, st
-            net.render_continue(0, T(o)[None], T(d)[None], out, **dict(opt, fused_from=ff))
+            net.render_continue(0, T(o)[None], T(d)[None], out, **dict(opt, fused_from=0, fused_whole=whole))
             assert net.last_stats["alive_at_exit"] == 0 and net.last_stats["samples"] == a[0]["samples"]
         assert torch.equal(out["image"], a[2]["image"]) and torch.equal(out["weights_sum"], a[2]["weights_sum"])
 
@@ -135,7 +135,7 @@ def test_fused_trips_in_graphs_and_pipelines(small_cloud, small_opt, ckpt):
     opt = dict(small_opt, W=128, H=128)
     poses = [scene.orbit_pose(5.0, 30.0 + 4.0 * f, -20.0) for f in range(7)]
     res = {}
-    for name, kw in (("classic", dict(fused_from=-1)), ("fused", dict())):
+    for name, kw in (("classic", dict(fused_from=-1)), ("fused", dict())):   # two render lanes: the pipeline picks the whole-frame launch
         h = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV)
         h.sim.update_force(h.sim.n_IP // 2, np.array([300.0, 100.0, -200.0]))
         h.capture_pipelined(lanes=2, depth=2, n_trips=None, render_kw=kw)
