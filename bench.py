@@ -159,25 +159,54 @@ def load_traffic(real_trips, config="chair"):
     per_launch = {k: int(v / max(real_trips, 1)) for k, v in out.items()}
     if all(k in out for k in ("k_march", "k_march_tail", "k_march_skip")):
         per_launch["march_group"] = int((out["k_march"] + out["k_march_tail"] + out["k_march_skip"]) / max(real_trips, 1))
-    return per_launch, "FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 PMC passes on the same kernels (tools/pmc_traffic.py); per real trip"
+        per_launch["first_trip_march"] = int(out["k_march"] + out["k_march_tail"] + out["k_march_skip"])   # with the later trips fused these only run on trip 0
+    if "k_trips_fused" in out:
+        per_launch["k_trips_fused"] = int(out["k_trips_fused"])   # one launch per frame
+    return per_launch, "FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 PMC passes on the same kernels (tools/pmc_traffic.py); per launch"
 
 
-def kernel_report(h, opt, dev):
-    """Per-kernel figures on one real frame (HIP events on the launch stream) + the march kernel's work counters."""
+def march_bytes(cnt, ray_trips):
+    """Algorithmic bytes of marching work (SURVEY 8d / DESIGN 4): cell range per visited point, list entry per candidate scanned, record head per inverse
+    warp, outputs per emitted sample, ray state per ray and trip."""
+    return (cnt["iterations"] * MARCH_BYTES["iteration"] + cnt["candidates"] * MARCH_BYTES["candidate"] + cnt["warps"] * MARCH_BYTES["warp"]
+            + cnt["samples"] * MARCH_BYTES["sample"] + ray_trips * MARCH_BYTES["ray_trip"])
+
+
+def kernel_report(h, opt, dev, form_kw=None, graph_ms=None):
+    """Per-kernel figures of one real frame in the FORM that produced `value` (form_kw: the render options the pipeline picked — throughput form of the
+    first trip, fused launch from which trip on, its grid): HIP events on the launch stream around every launch group of a blocking render ("alone"),
+    graph_ms = the same brackets as time stamps inside the pipelined graphs ("in the pipeline": the durations behind `value`), the march's work counters
+    split into first trip / fused launch, the fused launch's phase clocks, the stand-alone network and hash-grid kernels."""
     from pienerf_amd._lib import check, lib, ptr, stream_ptr
     m = h.model
     fp16 = bool(opt.get("fp16"))
+    N = opt["W"] * opt["H"]
+    for k, v in (form_kw or {}).items():   # render_kwargs() hands the option set to the renderer by name
+        if v is not None:
+            h.opt[k] = v
     for _ in range(20):   # a deformed state like the ones the timed region rendered, not the rest pose
         h.step()
     h.synchronize()
     out = h.step(simulate=False, collect_stats=True)   # also makes sure the frame workspace exists
     st = dict(m.last_stats)
     st["hit_rays"] = int((~torch.isnan(out["depth"])).sum())  # rays that meet the bounding box of the deformed IPs (miss: near = far = FLT_MAX -> NaN depth)
-    # (1) work counters of the march kernel (separate pass: the counters add atomics)
+    recs = m.trip_records(max_trips=140)
+    ff = m.fused_clocks()["first_trip"]                 # trip at which the fused launch took over (-1: trip-by-trip launches only)
+    real = st["trips"]
+    # (1) work counters of the march (separate passes: the counters add atomics): the whole frame, and its first trip alone
     m.march_counters(1)
     h.step(simulate=False)
     cnt = m.march_counters(0, read=True)
-    # (2) per-trip launch durations, events around every march / network launch of a blocking render
+    cnt0 = None
+    if ff >= 1:
+        m.march_counters(1)
+        with h._amp():
+            m.render_deformed(out["rays_o"], out["rays_d"], staged=True, bg_color=None, perturb=False,
+                              **dict(h.render_kwargs(), async_trips=ff, fused_from=-1))   # the trips in front of the fused launch, as per-trip launches
+        torch.cuda.synchronize()
+        cnt0 = m.march_counters(0, read=True)
+        h.step(simulate=False)   # leave a finished frame on the workspace
+    # (2) launch durations, events around every launch group of a blocking render
     m.march_counters(2)
     for _ in range(3):
         h.step(simulate=False)
@@ -186,14 +215,25 @@ def kernel_report(h, opt, dev):
         h.step(simulate=False)
         reps.append(m.trip_times())
     m.march_counters(0)
-    march_ms = np.median(np.array([r[0] for r in reps]), axis=0)
-    net_ms = np.median(np.array([r[1] for r in reps]), axis=0)
-    real = st["trips"]
-    march_total, march_launch = float(march_ms[:real].sum()), float(march_ms[:real].mean())
-    march_bytes = (cnt["iterations"] * MARCH_BYTES["iteration"] + cnt["candidates"] * MARCH_BYTES["candidate"] + cnt["warps"] * MARCH_BYTES["warp"]
-                   + cnt["samples"] * MARCH_BYTES["sample"] + opt["W"] * opt["H"] * MARCH_BYTES["ray_trip"])  # trip 0 touches every ray once
-    march_gbs = march_bytes / (march_total * 1e-3) / 1e9
-    # (3) stand-alone network / hash-grid kernels on the frame's real sample set
+    n_timed = min(len(r[0]) for r in reps)
+    march_ms = np.median(np.array([r[0][:n_timed] for r in reps]), axis=0)
+    net_ms = np.median(np.array([r[1][:n_timed] for r in reps]), axis=0)
+    # (3) phase clocks of the fused launch
+    phases = None
+    if ff >= 0:
+        m.march_counters(4)
+        m.fused_clocks(reset=True)
+        for _ in range(5):
+            h.step(simulate=False)
+        c = m.fused_clocks()
+        m.march_counters(0)
+        keys = ("refill", "march", "windows", "network", "composite", "a_march", "a_windows", "a_network", "a_composite", "a_barrier")
+        tot = float(sum(c[k] for k in keys)) or 1.0
+        phases = {"share_of_wave_time": {k: round(c[k] / tot, 4) for k in keys if c[k]}, "waves": int(c["waves"] / 5), "wave_rounds_per_frame": int(c["wave_rounds"] / 5),
+                  "mean_wave_lifetime_us": round(c["lifetime_ticks"] / max(c["waves"], 1) / 100.0, 1), "longest_wave_lifetime_us": round(c["max_lifetime_ticks"] / 100.0, 1),
+                  "note": "shader-clock cycles per phase summed over the launch's waves (march_counters(4): a drain of the memory counters at every phase "
+                          "boundary — a measurement build of the same launch, never the timed one)"}
+    # (4) stand-alone network / hash-grid kernels on the frame's real sample set
     with h._amp():
         xyz, dirs = collect_samples(m, out["rays_o"], out["rays_d"], h.render_kwargs())
     B = xyz.shape[0]
@@ -228,38 +268,91 @@ def kernel_report(h, opt, dev):
         traffic, traffic_note = load_traffic(real, opt.get("_config_name", "chair"))
     else:
         traffic, traffic_note = {}, "no PMC passes for this variant of the workload (sigma gain != 1): not reported"
-    net_loop_ms = float(net_ms[:real].sum())
-    net_loop_gbs = bps * st["samples"] / (net_loop_ms * 1e-3) / 1e9
-    net_loop_tf = MLP_FLOP_PER_SAMPLE * st["samples"] / (net_loop_ms * 1e-3) / 1e12
+
+    def gbs(nbytes, ms):
+        return nbytes / (ms * 1e-3) / 1e9 if ms and ms > 0 else 0.0
+    g_march, g_net = (None, None) if graph_ms is None else graph_ms
+    per_trip = max(ff, 0) if ff >= 0 else real    # trips that ran as per-trip launches
     kname = "k_nerf_forward_h" if fp16 else "k_nerf_forward"
+    if ff >= 0:
+        # ---- the frame = `ff` per-trip trips + ONE fused launch: the fused launch is the dominant kernel
+        head = cnt0 if cnt0 is not None else {k: 0 for k in cnt}
+        cnt_f = {k: cnt[k] - head[k] for k in cnt}
+        ray_trips_f = int(sum(r[0] for r in recs[max(ff, 1):])) if ff >= 1 else int(sum(r[0] for r in recs[1:])) + N
+        bytes_f_march = march_bytes(cnt_f, ray_trips_f)
+        bytes_f_net = cnt_f["samples"] * bps
+        t_f_alone = float(march_ms[ff]) if ff < n_timed else None
+        t_f_graph = float(g_march[ff]) if g_march is not None and ff < len(g_march) else None
+        t_f = t_f_graph or t_f_alone
+        fused_gbs = gbs(bytes_f_march + bytes_f_net, t_f)
+        head_march_alone = float(march_ms[:ff].sum()) if ff >= 1 else None
+        head_march_graph = float(np.sum(g_march[:ff])) if (g_march is not None and ff >= 1) else None
+        head_bytes = march_bytes(head, N + int(sum(r[0] for r in recs[1:ff]))) if ff >= 1 else 0
+        net_share = phases["share_of_wave_time"].get("network", 0.0) + phases["share_of_wave_time"].get("a_network", 0.0) if phases else 0.0
+        roofline = {
+            "kernel": f"k_trips_fused<{opt['num_seek_IP']},{'true' if opt['max_iter_num'] > 1 else 'false'},{'true' if fp16 else 'false'},{'true' if ff == 0 else 'false'}> — "
+                      f"every loop trip from trip {ff} on as ONE persistent launch: per ray { '{' } march 8 samples + inverse-GMLS warp; hash grid + SH + MLP on MFMA; composite { '}' } "
+                      "until the ray dies (csrc/pn_trips_fused.h); the largest kernel of the mode that produced `value`",
+            "bound": "hbm", "achieved": round(fused_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fused_gbs / HBM_PEAK_GBS, 4),
+            "traffic": traffic.get("k_trips_fused"), "traffic_note": traffic_note,
+            "launch_ms": round(t_f, 4) if t_f else None, "launches_per_frame": 1,
+            "measured_in": ("time stamps inside the pipelined render graphs around the launch (the mode that produced `value`: "
+                            "other frames' kernels, the simulator and the frame copies share the GPU)" if t_f_graph else
+                            "blocking single-frame render, HIP events on the launch stream around the launch"),
+            "launch_ms_alone": round(t_f_alone, 4) if t_f_alone else None, "frac_alone": round(gbs(bytes_f_march + bytes_f_net, t_f_alone) / HBM_PEAK_GBS, 4) if t_f_alone else None,
+            "workgroups": int(h.opt.get("fused_grid") or 0) or "one per CU",
+            "algorithmic_bytes_per_launch": int(bytes_f_march + bytes_f_net),
+            "algorithmic_bytes": {"march": int(bytes_f_march), "network": int(bytes_f_net), "bytes_per_unit": dict(MARCH_BYTES, network_sample=bps)},
+            "units_per_launch": dict(cnt_f, ray_trips=ray_trips_f),
+            "phases": phases,
+            "first_trips_march": None if ff < 1 else {
+                "kernel": "k_march_skip + k_march (one lane per ray) + k_march_tail + k_list_pack: the march of the trip(s) in front of the fused launch — round 3's dominant kernel group",
+                "ms_per_frame_alone": round(head_march_alone, 4), "ms_per_frame_in_pipeline": round(head_march_graph, 4) if head_march_graph else None,
+                "algorithmic_bytes_per_frame": int(head_bytes), "achieved_GBps_alone": round(gbs(head_bytes, head_march_alone), 1),
+                "frac_alone": round(gbs(head_bytes, head_march_alone) / HBM_PEAK_GBS, 4),
+                "frac_in_pipeline": round(gbs(head_bytes, head_march_graph) / HBM_PEAK_GBS, 4) if head_march_graph else None,
+                "traffic": traffic.get("first_trip_march"), "units": head},
+            "note": "achieved = algorithmic bytes of the launch (march: 8 B per visited ray point, 16 B per candidate-list entry, 64 B per warped IP record head, 36 B per "
+                    "emitted sample, 40 B of ray state per ray and trip; network: 1024 B of hash-table corners + 44 B per sample) / duration of the launch.  The tables "
+                    "are cache-resident (`traffic`: HBM-side bytes from the PMC passes) and what bounds the launch is the per-CU gather path of the network phases "
+                    "(distinct cache lines per wave instruction) and the dependent-issue chains of the march phases that share the SIMDs with them (`phases`), "
+                    "not HBM bytes: the HBM roofline is the nominal ruler BASELINE asks for, an upper bound the launch cannot approach",
+        }
+        net_loop_ms = float(net_ms[:ff].sum()) + (t_f_alone or 0.0) * net_share
+        net_samples_head = int(head["samples"])
+    else:
+        # ---- trip-by-trip launches only (ray batches, static): the march launch group per trip, as in rounds 1-3
+        march_total = float(march_ms[:real].sum())
+        mb = march_bytes(cnt, N)
+        roofline = {
+            "kernel": "ray march + inverse-GMLS warp: k_march + k_march_tail per loop trip (+ k_march_skip on trip 0), one launch group",
+            "bound": "hbm", "achieved": round(gbs(mb, march_total), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs(mb, march_total) / HBM_PEAK_GBS, 4),
+            "traffic": traffic.get("march_group"), "traffic_note": traffic_note,
+            "launch_ms": round(march_total / real, 4), "launches_per_frame": real, "ms_per_frame": round(march_total, 4),
+            "ms_per_frame_in_pipeline": round(float(np.sum(g_march[:real])), 4) if g_march is not None else None,
+            "measured_in": "blocking single-frame render, HIP events on the launch stream around each trip's march launches (pn_frame_trip_times)",
+            "units_per_frame": cnt, "algorithmic_bytes_per_frame": int(mb), "algorithmic_bytes_per_launch": int(mb / real), "bytes_per_unit": MARCH_BYTES,
+            "note": "achieved = algorithmic bytes / HIP-event time of the launch group; the tables are cache-resident and the kernels are bound by VALU issue, not bytes (DESIGN.md 4.1)",
+        }
+        net_loop_ms = float(net_ms[:real].sum())
+        net_samples_head = st["samples"]
+    net_loop_gbs = gbs(bps * st["samples"], net_loop_ms)
+    net_loop_tf = MLP_FLOP_PER_SAMPLE * st["samples"] / (net_loop_ms * 1e-3) / 1e12 if net_loop_ms > 0 else 0.0
     network = {
-        "kernel": ("k_nerf_forward_h<4,4> (fp16 hash tables + SH + 5-layer MLP fused; dense layers on v_mfma_f32_32x32x16_f16, half activations)" if fp16 else
-                   "k_nerf_forward<2,4> (hash-grid gather + SH + 5-layer MLP fused; dense layers as three-way bf16-split MFMA at fp32 accuracy)")
-        + ", launches inside the render loop",
+        "kernel": ("k_nerf_forward_h<4,4> / the same tile inside k_trips_fused (fp16 hash tables + SH + 5-layer MLP fused; dense layers on v_mfma_f32_32x32x16_f16, half activations)" if fp16 else
+                   "k_nerf_forward<2,4> / the same tile inside k_trips_fused (hash-grid gather + SH + 5-layer MLP fused; dense layers as three-way bf16-split MFMA at fp32 accuracy)"),
         "bound": "hbm", "achieved": round(net_loop_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(net_loop_gbs / HBM_PEAK_GBS, 4),
-        "bytes_per_sample": bps, "algorithmic_bytes_per_launch": int(bps * st["samples"] / real), "traffic": traffic.get(kname), "traffic_note": traffic_note,
-        "launch_ms": round(net_loop_ms / real, 4), "launches_per_frame": real, "ms_per_frame": round(net_loop_ms, 4),
-        "samples_per_frame": st["samples"],
+        "bytes_per_sample": bps, "traffic": traffic.get(kname), "traffic_note": traffic_note,
+        "ms_per_frame": round(net_loop_ms, 4), "samples_per_frame": st["samples"],
+        "definition": ("network time of a frame = the network launches of the per-trip trips (HIP events) + the fused launch's duration x the share of its waves' time "
+                       "spent in network phases (phase clocks), both of a blocking render; achieved = samples x bytes_per_sample / that" if ff >= 0 else
+                       "network launches inside the render loop, HIP events"),
+        "per_trip_launch_ms": [round(float(v), 4) for v in net_ms[:per_trip]], "samples_in_per_trip_launches": net_samples_head,
         "mfma_view": {"flop_per_sample": MLP_FLOP_PER_SAMPLE, "TFLOPs": round(net_loop_tf, 2),
                       "frac_of_mfma_peak": round(net_loop_tf / (F16_MFMA_PEAK_TF if fp16 else F32_MFMA_PEAK_TF), 4),
                       "peak_used": "fp16 dense MFMA 2.5 PF" if fp16 else "fp32-input MFMA 157.3 TF (the kernel computes fp32-accurate products out of 6 bf16 MFMAs)"},
         "all_samples_one_launch": {"launch_ms_fp32": round(t_net, 4), "launch_ms_fp16": round(t_net_h, 4), "achieved_GBps": round(bps * B / (t_used * 1e-3) / 1e9, 1),
                                    "frac_of_hbm_peak": round(bps * B / (t_used * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-    }
-    roofline = {
-        "kernel": "ray march + inverse-GMLS warp: k_march + k_march_tail per loop trip (+ k_march_skip on trip 0), one launch group",
-        "bound": "hbm", "achieved": round(march_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(march_gbs / HBM_PEAK_GBS, 4),
-        "traffic": traffic.get("march_group"), "traffic_note": traffic_note,
-        "launch_ms": round(march_launch, 4), "launches_per_frame": real, "ms_per_frame": round(march_total, 4),
-        "measured_in": "blocking single-frame render, HIP events on the launch stream around each trip's march launches (pn_frame_trip_times); the same "
-                       "events recorded inside the pipelined graphs are under 'pipelined_kernel_ms'",
-        "units_per_frame": cnt, "algorithmic_bytes_per_frame": int(march_bytes), "algorithmic_bytes_per_launch": int(march_bytes / real),
-        "bytes_per_unit": MARCH_BYTES,
-        "note": "achieved = algorithmic bytes (8 B per marched ray point, 16 B per candidate-list entry, 64 B per warped IP record head, 36 B per emitted sample, "
-                "40 B of ray state per ray and trip) / HIP-event time of the launch group.  The tables are cache-resident (`traffic` = HBM-side bytes from the PMC "
-                "passes: ~0.13x the algorithmic bytes) and the kernels are bound by VALU issue, not bytes: a wave64 instruction holds its SIMD16 for four cycles, "
-                "two to three march waves fill a SIMD, and 78 % of the lanes evaluate lattice elements the ray's chain never visits (DESIGN.md 4.1; grid / "
-                "occupancy / LDS sweeps in profiles/r03_march_experiments.txt) — the HBM roofline is an upper bound this launch group cannot approach",
     }
     extra = {
         "network": network,
@@ -267,11 +360,36 @@ def kernel_report(h, opt, dev):
                         "achieved_GBps": round(grid_gbs, 1), "frac_of_hbm_peak": round(grid_gbs / HBM_PEAK_GBS, 4), "launch_ms": round(t_grid, 4),
                         "bytes_per_sample": HASH_BYTES_PER_SAMPLE, "launch_ms_direct_BLC_output": round(t_grid_bl, 4)},
         "breakdown_ms": {"stepforward_alone": round(t_sim, 4), "stepforward_persistent_alone": (round(t_sim_coop, 4) if t_sim_coop else None),
-                         "render_frame_eager": round(t_frame, 4),
-                         "march_per_trip": [round(float(v), 4) for v in march_ms[:real]], "network_per_trip": [round(float(v), 4) for v in net_ms[:real]],
+                         "render_frame_eager": round(t_frame, 4), "fused_from_trip": ff,
+                         "march_per_launch_group": [round(float(v), 4) for v in march_ms[:(ff + 1 if ff >= 0 else real)]],
+                         "network_per_trip_launch": [round(float(v), 4) for v in net_ms[:per_trip]],
+                         "in_pipeline_march_per_launch_group": [round(float(v), 4) for v in g_march[:(ff + 1 if ff >= 0 else real)]] if g_march is not None else None,
+                         "in_pipeline_network_per_trip_launch": [round(float(v), 4) for v in g_net[:per_trip]] if g_net is not None else None,
                          "local_global_iters_per_s": round(opt["sim_iters"] / (t_sim * 1e-3), 1)},
     }
     return st, roofline, extra
+
+
+def graph_stamps(make_harness, args):
+    """Time stamps (one-lane kernels reading the 100 MHz clock) captured inside the pipeline's render graphs around each launch group, while `lanes` frames,
+    the simulator and the frame copies run concurrently: the durations of the mode that produced `value` (HIP events recorded in a graph cannot be timed).
+    Returns ((march_ms per launch group, network_ms per trip launch), the render options the pipeline picked)."""
+    h = make_harness()
+    h.capture_pipelined(lanes=args.lanes, depth=args.depth, n_trips=args.trips, _time_trips=True, copy_on=args.copy_on)
+    for _ in range(4 * args.lanes * args.depth):
+        h.step_pipelined()
+    h.drain_pipeline()
+    m_all, n_all = [], []
+    for ws in range(args.lanes * args.depth):
+        a, b = h.model.trip_times(slot=ws)
+        m_all.append(a)
+        n_all.append(b)
+    n = min(len(a) for a in m_all)
+    kw = {k: h._pipe_backend.kw.get(k) for k in ("fused_from", "fused_grid", "fused_whole", "march_throughput", "march_throughput_trips")}
+    res = (np.median(np.array([a[:n] for a in m_all]), axis=0), np.median(np.array([b[:n] for b in n_all]), axis=0)), kw
+    del h
+    torch.cuda.empty_cache()
+    return res
 
 
 def pipelined_extras(make_harness, args, steps):
@@ -295,6 +413,19 @@ def pipelined_extras(make_harness, args, steps):
     res["device_resident"] = {"steps_per_s": round(1e3 / ms, 2), "ms_per_step": round(ms, 4), "note": "same pipeline without the D2H of image/depth/depth_0"}
     del h
     torch.cuda.empty_cache()
+    if args.lanes != 2 and args.config == "chair" and args.sigma_gain == 1.0:
+        # what a rank of a multi-GPU job runs (two render lanes beside the simulator and the RCCL stream): the per-rank rate behind `predicted_scaling`.
+        # In a process of its own (see the sigma-gain sweep below: stream-to-queue mapping of a process that has already created several pipelines)
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--lanes", "2", "--steps", str(max(100, steps)), "--warmup", "20", "--no-extras", "--no-cpu-baseline",
+               "--depth", str(args.depth), "--copy-on", args.copy_on]
+        try:
+            o_ = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            d = json.loads([ln for ln in o_.stdout.splitlines() if ln.startswith("{")][-1])
+            res["two_lanes"] = {"steps_per_s": d["value"], "ms_per_step": d["ms_per_step"], "verified": d.get("verified"), "launch": d["config"]["launch"],
+                                "note": "the same bench line with --lanes 2 (incl. D2H)"}
+        except Exception as e:  # noqa: BLE001 — measurement only
+            res["two_lanes_error"] = f"{type(e).__name__}: {str(e)[:200]}"
     h = make_harness()
     h.capture_pipelined(lanes=1, depth=2, n_trips=args.trips, sim_ahead=1, copy_on=args.copy_on)
     ms = rate(h, steps)
@@ -319,28 +450,24 @@ def pipelined_extras(make_harness, args, steps):
             except Exception as e:  # noqa: BLE001 — measurement only
                 sweep.append({"sigma_gain": g, "error": f"{type(e).__name__}: {str(e)[:200]}"})
         res["sigma_gain_sweep"] = {"points": sweep, "note": "the same bench line at other densities of the synthetic checkpoint (gain 1 is `value` itself)"}
-    try:  # HIP events recorded inside the captured render graphs: the march / network launch durations of the mode that produced `value`
-        h = make_harness()
-        h.capture_pipelined(lanes=args.lanes, depth=args.depth, n_trips=args.trips, _time_trips=True, copy_on=args.copy_on)
-        for _ in range(3 * args.lanes * args.depth):
-            h.step_pipelined()
-        h.drain_pipeline()
-        m_all, n_all = [], []
-        for ws in range(args.lanes * args.depth):
-            a, b = h.model.trip_times(slot=ws)
-            m_all.append(a)
-            n_all.append(b)
-        st = h.model.render_status(synchronize=False, slot=0)
-        real = st["trips"]
-        mm, nn = np.median(np.array(m_all), axis=0), np.median(np.array(n_all), axis=0)
-        res["pipelined_kernel_ms"] = {"march_per_trip": [round(float(v), 4) for v in mm[:real]], "network_per_trip": [round(float(v), 4) for v in nn[:real]],
-                                      "march_ms_per_frame": round(float(mm[:real].sum()), 4), "network_ms_per_frame": round(float(nn[:real].sum()), 4),
-                                      "note": f"time stamps (one-lane kernels reading the 100 MHz clock) captured inside the render graphs around each trip's march and "
-                                              f"network launches, while {args.lanes} lanes, the simulator and the D2H run concurrently: the durations of the mode that "
-                                              "produced `value`, including the slowdown from sharing the GPU (HIP events recorded in a graph cannot be timed)"}
-        del h
-    except Exception as e:  # noqa: BLE001 — measurement only
-        res["pipelined_kernel_ms"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+    if args.config == "chair" and args.sigma_gain == 1.0:
+        # the other single-GPU configurations of BASELINE.json (configs[2] trex option set, configs[4] stress) through the same command, each in a process of
+        # its own: `value` and the dominant kernel's roofline block, so that the driver's record of the default run covers every single-GPU config
+        import subprocess
+        oc = {}
+        for cfg in ("trex", "stress"):
+            cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", "100", "--warmup", "20", "--no-extras", "--no-cpu-baseline"]
+            try:
+                o_ = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                d = json.loads([ln for ln in o_.stdout.splitlines() if ln.startswith("{")][-1])
+                r = d["roofline"]
+                oc[cfg] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "verified": d.get("verified"), "workload": d["config"]["workload"],
+                           "samples_per_frame": d["config"]["samples_per_frame"], "trips_per_frame": d["config"]["trips_per_frame"], "launch": d["config"]["launch"],
+                           "roofline": {k: r.get(k) for k in ("kernel", "achieved", "frac", "launch_ms", "launch_ms_alone", "frac_alone", "ms_per_frame", "traffic", "first_trips_march")},
+                           "network_frac": d["network"]["frac"], "render_frame_eager_ms": d["breakdown_ms"]["render_frame_eager"]}
+            except Exception as e:  # noqa: BLE001 — measurement only
+                oc[cfg] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+        res["other_configs"] = oc
     torch.cuda.empty_cache()
     return res
 
@@ -369,6 +496,8 @@ def main():
                     help="N > 1: the sim owner only simulates and broadcasts, the other ranks render (auto: from 3 ranks on, frames.dedicated_sim_default)")
     ap.add_argument("--force", type=float, nargs=3, default=None, metavar=("FX", "FY", "FZ"),
                     help="constant update_force on the middle integration point (SURVEY 8d, config 2 second pass); default: per config")
+    ap.add_argument("--probe", choices=("none", "no-substep", "sim-priority", "sim-cus"), default="none",
+                    help="diagnosis (value is then NOT the benchmark): the pipeline without the substep's launches / with the simulator stream at high priority / on 16 CUs of its own")
     ap.add_argument("--sigma-gain", type=float, default=1.0, help="scales the synthetic checkpoint's density (samples per frame fall as it rises)")
     args = ap.parse_args()
 
@@ -414,6 +543,7 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+        h.wait_frame_copies()   # the copier thread's SDMA copies are on no stream: the clock stops when the last frame enqueued has landed in host memory
 
     frames_done = [0]
     if world == 1:
@@ -438,13 +568,17 @@ def main():
         else:
             # --config stress: opt["ray_batch"] = 4096 (set above) — the frame's 157 ray batches keep their own trip schedules inside the same
             # launches (pn_render_opts.ray_batch), so the staged frame runs on the same pipeline as the frame in one piece
-            h.capture_pipelined(lanes=args.lanes, depth=args.depth, n_trips=args.trips, copy_out=copy_out, copy_on=args.copy_on)
+            probe_kw = {"no-substep": dict(_probe_no_substep=True), "sim-priority": dict(sim_priority=-1), "sim-cus": dict(sim_cus=int(os.environ.get("PN_PROBE_SIM_CUS", "16")))}.get(args.probe, {})
+            h.capture_pipelined(lanes=args.lanes, depth=args.depth, n_trips=args.trips, copy_out=copy_out, copy_on=args.copy_on, **probe_kw)
             args.trips = h._pipe_backend.trips
             run_steps = lambda n: [h.step_pipelined() for _ in range(n)]
             launch = (f"hip graphs, {args.trips} trips, {args.lanes} render streams x {args.depth} workspaces, "
                       + (f"march pass 1 of the first {h._pipe_backend.kw.get('march_throughput_trips', 1)} trip(s) in its throughput form (one lane per ray, "
                          f"{h._pipe_backend.kw.get('march_throughput')} rounds; pn_render_opts.throughput / throughput_trips), " if args.lanes > 1 else "")
                       + ("" if staged else "alive list in 16 x 4 pixel tiles (pn_render_opts.ray_tile_w), ")
+                      + (f"loop trips from trip {h._pipe_backend.kw.get('fused_from')} on as ONE persistent launch"
+                         + (" (first trip included: fused_whole)" if h._pipe_backend.kw.get("fused_whole") else "")
+                         + f" on {h._pipe_backend.kw.get('fused_grid') or 'all'} CUs (pn_render_opts.fused_from / fused_grid), " if (h._pipe_backend.kw.get("fused_from") or 0) >= 0 and not staged else "")
                       + "simulator running ahead, D2H on "
                       + {"copy": "a copy stream", "lane": "the frame's render stream", "sim": "the simulator stream", "host": "no stream (copier thread + SDMA through the HSA runtime)"}[args.copy_on]
                       + (f"; rays in batches of {opt['ray_batch']} with per-batch trip schedules (max_ray_batch), all batches in the same launches" if staged else ""))
@@ -486,9 +620,13 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         continued = 0
-        if world > 1 or not (args.eager or args.single_graph):  # the last frames in flight are retired (and verified) here
+        verified = None
+        if world > 1 or not (args.eager or args.single_graph):  # the last frames in flight are retired here
             frames_done[0] += len(h.drain_pipeline())
             continued = h._pipe_backend.continued
+            # ... and the last frame the pipeline delivered is rendered again, launch by launch, from the state its workspace holds: bit for bit
+            if h._pipe.last_ws is not None:
+                verified = h.verify_last_frame()
         elif args.single_graph:
             h._check_previous_graph_frame()
             continued = getattr(h, "graph_continued", 0)
@@ -504,10 +642,18 @@ def main():
 
     if rank == 0:
         del_h = h
+        pipelined = world == 1 and not (args.eager or args.single_graph)
+        form_kw = {k: h._pipe_backend.kw.get(k) for k in ("fused_from", "fused_grid", "fused_whole", "march_throughput", "march_throughput_trips")} if hasattr(h, "_pipe_backend") else None
         with torch.no_grad():
+            graph_ms = None
+            if pipelined:
+                try:
+                    graph_ms, form_kw = graph_stamps(make_harness, args)
+                except Exception as e:  # noqa: BLE001 — measurement only
+                    print(f"graph stamps failed: {type(e).__name__}: {str(e)[:200]}", file=sys.stderr)
             hk = make_harness() if (world > 1 or not args.eager) else h   # a fresh eager harness for the per-kernel report
             opt["_config_name"] = args.config if args.sigma_gain == 1.0 else "other"
-            st, roofline, extra = kernel_report(hk, opt, dev)
+            st, roofline, extra = kernel_report(hk, opt, dev, form_kw, graph_ms)
         res = {
             "metric": "sim+render steps/s @800x800 chair" if args.config == "chair" else f"sim+render steps/s, {args.config} configuration",
             "value": round(args.steps * world / elapsed, 3), "unit": "steps/s", "n_gpus": world,
@@ -515,9 +661,13 @@ def main():
             "value_unprimed": round(args.steps * world / elapsed_unprimed, 3),
             "value_note": (f"`value`: K = {args.steps} timed steps after {args.prime} priming + W = {args.warmup} warm-up steps of the already running pipeline (steady state); "
                            f"`value_unprimed`: the first K timed steps after only the W warm-up steps, right behind the graph captures"),
+            "verified": (bool(verified["ok"]) if verified else None),
+            "verified_note": (f"frame {verified['frame']} (the last one the timed pipeline delivered, as copied to host memory) == a blocking launch-by-launch render of the "
+                              f"same integration-point state and pose, bit for bit on image and depth_0: max abs difference {verified.get('max_abs_diff')}" if verified else
+                              "not a pipelined run"),
             "scaling": "weak", "vs_baseline": None, "dtype": ("f16 tables+MLP / f32 march / f64 sim" if opt.get("fp16") else "f32 render / f64 sim"), "data": "synthetic",
             "config": {"workload": workload + (f", constant force {[float(v) for v in force]} on IP {hk.sim.n_IP // 2}" if force is not None else ", gravity only")
-                       + ("" if copy_out else " [--no-d2h: outputs left on the device]"),
+                       + ("" if copy_out else " [--no-d2h: outputs left on the device]") + ("" if args.probe == "none" else f" [--probe {args.probe}: a diagnosis run, not the benchmark]"),
                        "rays": opt["W"] * opt["H"], "n_IP": hk.sim.n_IP, "n_kernels": hk.sim.n_k, "n_points": int(len(cloud["pos"])),
                        "samples_per_frame": st["samples"], "trips_per_frame": st["trips"], "d2h_bytes_per_step": (opt["W"] * opt["H"] * 20 if copy_out else 0),
                        "frames_continued_past_captured_trips": continued, "launch": launch, "prime_steps": args.prime, "sigma_gain": args.sigma_gain,
@@ -542,6 +692,16 @@ def main():
         if world == 1 and not args.no_extras and not (args.eager or args.single_graph):
             with torch.no_grad():
                 res.update(pipelined_extras(make_harness, args, max(40, min(args.steps, 120))))
+        if world == 1 and "two_lanes" in res:
+            # what `python bench.py --gpus N` should print on one node, from this GPU's measurements: N = 2: both ranks render, the owner's
+            # substeps share its GPU with its renders (measured x1.8 slower than alone); N >= 3: rank 0 only simulates (launch form) and broadcasts each
+            # <= 82 KB snapshot, N - 1 ranks render with two lanes each; the broadcast (~20 us over xGMI) overlaps on the communication stream
+            r2, own = res["two_lanes"]["steps_per_s"], res["frame_parallel_ceiling"]["owner_frames_per_s_launch_form"]
+            res["predicted_scaling"] = {"steps_per_s": {"1": res["value"], "2": round(min(own / 1.8, 2 * r2), 1), "4": round(min(own, 3 * r2), 1), "8": round(min(own, 7 * r2), 1)},
+                                        "bound": {"2": "renderers" if 2 * r2 < own / 1.8 else "sim owner (shared GPU)", "4": "renderers" if 3 * r2 < own else "sim owner",
+                                                  "8": "renderers" if 7 * r2 < own else "sim owner"},
+                                        "note": "prediction, not a measurement (no multi-GPU node was available to the builder): min(sim owner's substep rate, rendering ranks x the "
+                                                "two-lane single-GPU rate); the simulator is time-sequential, so the owner's substep rate caps the job whatever N"}
         if staged and not args.no_extras:  # the same configuration with the frame rendered in one shot (what render_deformed does with these options in the reference)
             with torch.no_grad():
                 opt.pop("ray_batch")

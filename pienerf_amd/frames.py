@@ -142,6 +142,7 @@ class FramePipeline:
         self.sim_next = 0         # next snapshot / substep the owner enqueues
         self.bc_next = 0          # next broadcast this rank enqueues
         self.retired = []         # (frame, result) of workspaces retired by the last step()
+        self.last_ws, self.last_frame = None, None
 
     # ------------------------------------------------------------------ per-frame
     def _ws(self, k):
@@ -221,6 +222,7 @@ class FramePipeline:
                 b.copy_out(sc, ws)
                 self.out_ready[ws].record(sc)
             self.pending[ws] = f
+            self.last_ws, self.last_frame = ws, f   # (harness.verify_last_frame: the workspace still holds this frame's inputs after drain())
             self.my_frames += 1
         elif self.dedicated and self.rank == self.owner and self.world > 1:
             # a rank that never renders has nothing that paces its host: wait until this frame's snapshot has been delivered, so that the

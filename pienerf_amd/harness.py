@@ -295,6 +295,47 @@ class SimRenderHarness:
         self._check_persistent_substep()
         return out
 
+    def wait_frame_copies(self):
+        """Pipelined mode: host-waits for the device AND for the copier thread's frame copies (which are on no stream)."""
+        torch.cuda.synchronize(self.device)
+        be = getattr(self, "_pipe_backend", None)
+        if be is not None and hasattr(be, "wait_copies"):
+            be.wait_copies()
+
+    @torch.no_grad()
+    def verify_last_frame(self):
+        """After drain_pipeline(): renders the LAST frame this rank's pipeline enqueued once more — a blocking render, launch by launch, from the
+        integration-point state and pose its workspace still holds — and compares it bit for bit with what the pipeline delivered (the arrays in
+        pinned host memory when the frames are copied out, else the workspace's device buffers).  Every form of the frame (captured graph, several
+        frames in flight, fused launches, one lane per ray or windows) produces the same bits by construction; a difference means a race between the
+        pipeline's streams, a frame copied before it was finished, or a broken kernel.  Returns dict(ok, frame, max_abs_diff)."""
+        pipe, be, m = self._pipe, self._pipe_backend, self.model
+        ws = pipe.last_ws
+        if ws is None:
+            return {"ok": False, "frame": None, "why": "no frame was enqueued"}
+        torch.cuda.synchronize(self.device)
+        res = be.result(ws)
+        keep = (m.p_def, m.IP_F, m.IP_dF)
+        try:
+            m.p_def, m.IP_F, m.IP_dF = be.ip[ws]
+            rays = get_rays(be.pose_dev[ws], self.intrinsics, be.H, be.W, -1)
+            kw = dict(self.render_kwargs())
+            kw.pop("ray_batch", None)
+            if be.kw.get("ray_batch"):
+                kw["ray_batch"] = be.kw["ray_batch"]   # batches keep their own trip schedules: part of what the frame IS, not of how it is launched
+            with self._amp():
+                out = m.render_deformed(rays["rays_o"], rays["rays_d"], staged=True, bg_color=None, perturb=False, **kw)
+            torch.cuda.synchronize(self.device)
+            worst, ok = 0.0, True
+            for k in ("image", "depth_0"):
+                want = out[k].reshape(-1).cpu().numpy()
+                got = (res[k] if k in res else res["device"][k].cpu().numpy()).reshape(-1)
+                ok = ok and bool(np.array_equal(want, got))
+                worst = max(worst, float(np.abs(want - got).max()))
+        finally:
+            m.p_def, m.IP_F, m.IP_dF = keep
+        return {"ok": ok, "frame": int(pipe.last_frame), "max_abs_diff": worst}
+
     def _check_persistent_substep(self):
         """A persistent substep whose workgroups could not all become resident ends with a flag instead of hanging (csrc/pn_sim.hip); its DOFs
         are garbage.  Checked where the host synchronises anyway."""
@@ -613,9 +654,17 @@ class _HipBackend:
             check(lib().pn_copier_submit(self.copier, ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), src.numel() * src.element_size(), after,
                                          ctypes.byref(t)), "copier_submit")
             s.ticket = t.value
+            self.last_ticket = t.value
             return
         with torch.cuda.stream(s.s):
             dst.copy_(src, non_blocking=True)
+
+    def wait_copies(self):
+        """[host] Blocks until every frame copy submitted so far has landed in host memory.  The copier thread's SDMA copies are on no stream:
+        torch.cuda.synchronize() does not wait for them (bench.py stops its clock behind this)."""
+        if self.copier is not None and getattr(self, "last_ticket", None) is not None:
+            from ._lib import check, lib
+            check(lib().pn_copier_wait(self.copier, self.last_ticket), "copier_wait")
 
     # ---- host side of a retired workspace
     def complete(self, ws):
