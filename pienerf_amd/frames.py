@@ -118,12 +118,15 @@ class FramePipeline:
         result(ws) -> object      [host] what step() hands back for a retired frame
     """
 
-    def __init__(self, backend, world=1, rank=0, lanes=2, depth=2, ahead=None, sim_owner=0, dedicated_sim=None, copy_out=True, on_retire=None):
+    def __init__(self, backend, world=1, rank=0, lanes=2, depth=2, ahead=None, sim_owner=0, dedicated_sim=None, copy_out=True, on_retire=None, force_collectives=False):
         self.b, self.world, self.rank, self.lanes, self.depth, self.owner = backend, int(world), int(rank), int(lanes), int(depth), int(sim_owner)
         self.dedicated = dedicated_sim_default(self.world) if dedicated_sim is None else bool(dedicated_sim and self.world > 1)
         self.ahead = self.world * self.lanes * self.depth if ahead is None else int(ahead)
         self.slots = self.ahead + self.world * self.lanes * self.depth + 1   # snapshot ring: reuse is guarded by events, the size only avoids stalls
         self.copy_out = copy_out
+        # the snapshot broadcasts are skipped with a single rank — unless forced (tests: a world of ONE RCCL rank still runs every collective of the
+        # N-rank schedule on the communication stream, beside the graph replays, so that the first N-GPU run is a measurement, not a first execution)
+        self.collectives = self.world > 1 or bool(force_collectives)
         self.on_retire = on_retire   # called as on_retire(frame, result) the moment a frame is complete, BEFORE its workspace is reused
         b = backend
         self.s_sim, self.s_comm, self.s_copy = b.stream("sim"), b.stream("comm"), b.stream("copy")
@@ -197,7 +200,7 @@ class FramePipeline:
         self.retired = []
         if self.rank == self.owner:
             self._advance_simulator(f + self.ahead)
-        if self.world > 1:
+        if self.collectives:
             self._broadcasts(f + self.ahead)
         mine = frame_owner(f, self.world, self.owner, self.dedicated) == self.rank
         if mine:
@@ -207,7 +210,7 @@ class FramePipeline:
                 self.retired.append(done)
             slot = f % S
             s = self.s_lane[lane]
-            s.wait(self.bc_done[slot] if self.world > 1 else self.snap_ready[slot])
+            s.wait(self.bc_done[slot] if self.collectives else self.snap_ready[slot])
             b.render(s, f, ws, slot, pose)
             self.ip_done[slot].record(s)     # recorded after the whole render: conservative (update_F alone reads the snapshot)
             self.ip_used[slot] = True

@@ -167,3 +167,64 @@ def test_bench_multi_gpu_command_line_dry_run(tmp_path, world, dedicated):
     ceil = d["frame_parallel_ceiling"]
     assert ceil["owner_frames_per_s"] > 0 and ceil["substep_ms_alone"] > 0.05     # (the ranks share ONE GPU here: the figure itself means nothing)
     assert d["roofline"]["frac"] > 0 and "parallelism" in cfg and f"{world} RCCL ranks" in cfg["parallelism"]
+
+
+def _rccl_worker(rank, world, port, out_dir, persistent):
+    """ONE RCCL rank on cuda:0 that runs every collective of the N-rank schedule (frames.FramePipeline(force_collectives=True))."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))   # "nccl" IS RCCL on ROCm
+    assert dist.get_backend() == "nccl"
+    from pienerf_amd.frames import broadcast_tensors
+    from pienerf_amd.harness import SimRenderHarness
+    opt, cloud, ckpt = _scene()
+    h = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device="cuda:0")
+    m = h.model
+    # the one-off checkpoint broadcast of bench.py --gpus N: hash tables, density bitfield, every layer's weights
+    before = m.encoder.embeddings.data.clone()
+    broadcast_tensors([m.encoder.embeddings.data, m.density_bitfield] + [l.weight.data for l in list(m.sigma_net) + list(m.color_net)], src=0)
+    m._net_sig = None
+    assert torch.equal(before, m.encoder.embeddings.data)
+    if persistent:
+        assert h.sim.enable_persistent()   # the substep's iterations as ONE cooperative kernel (csrc/pn_sim.hip: k_substep_coop) beside RCCL's kernels
+    h.capture_frame_parallel(lanes=2, n_trips=8, _force_collectives=True)   # graphs on 2 lanes + simulator stream + RCCL broadcasts on the comm stream + copier thread
+    p = h._pipe
+    assert p.world == 1 and p.collectives and h._pipe_backend.copier is not None
+    got = {}
+    for f in range(N_FRAMES):
+        for idx, res in h.step_frame_parallel():
+            got[idx] = res["image"].copy()
+    for idx, res in h.drain_pipeline():
+        got[idx] = res["image"].copy()
+    assert p.bc_next == N_FRAMES + p.ahead    # one broadcast per snapshot, all of them enqueued
+    assert h.verify_last_frame()["ok"]
+    np.savez(os.path.join(out_dir, "rccl.npz"), **{str(k): v for k, v in got.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("persistent", [False, True])
+def test_rccl_snapshot_and_checkpoint_broadcasts_beside_graphs_and_copier(tmp_path, persistent):
+    """RCCL itself (backend "nccl"), world size 1 — all this box has: the checkpoint broadcast and one snapshot broadcast per frame on the communication
+    stream while the render graphs replay on two lanes, the simulator graph on its stream (both substep forms) and the copier thread moves the frames
+    to host memory.  Frames equal the eager single-process sequence bit for bit."""
+    import torch.multiprocessing as mp
+    from pienerf_amd.harness import SimRenderHarness
+    opt, cloud, ckpt = _scene()
+    eager = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device="cuda:0")
+    want = [eager.step()["image"].clone().cpu().numpy() for _ in range(N_FRAMES)]
+    eager.synchronize()
+    del eager
+    torch.cuda.empty_cache()
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path), persistent), nprocs=1, join=True)
+    with np.load(tmp_path / "rccl.npz") as z:
+        got = {int(k): z[k] for k in z.files}
+    assert sorted(got) == list(range(N_FRAMES))
+    for f in range(N_FRAMES):
+        if persistent:   # the cooperative kernel sums the chunk sums in another order than the launch form: 1e-9 on the DOFs
+            assert np.abs(want[f] - got[f]).max() < 1e-5, f
+        else:
+            assert np.abs(want[f] - got[f]).max() == 0.0, f
