@@ -14,7 +14,7 @@
 // of torch ops, so the set of unseen cells equals the CPU oracle's bit for bit.
 #include <float.h>
 
-#include "pn_march.h"
+#include "pn_march_math.h"
 
 namespace {
 using namespace pnm;

@@ -1,5 +1,5 @@
 // Shared pieces of the device-side ray march with the inverse-GMLS ("quadratic bending") warp, for gfx950: scalar helpers,
-// the literal flat-index 3x3 routines and the kernel parameter block.  The march itself is in pn_march2.h.
+// the literal flat-index 3x3 routines and the kernel parameter block (included by pn_march_tables.h; the march itself is pn_march_window.h).
 //
 // Semantics follow kernel_march_rays_quadratic_bending and its helpers
 // (/root/reference raymarching/src/raymarching.cu:930-1434) including the output-changing quirks listed in

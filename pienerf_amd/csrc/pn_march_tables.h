@@ -1,5 +1,5 @@
 // Side tables and per-point helpers of the ray march (gfx950): the candidate lists, the packed IP records, the Newton inverse
-// warp through one record and the one-lane-per-ray skip over IP-free cells.  The march itself is in pn_march3.h.
+// warp through one record.  The march itself (windows, skip pre-pass) is in pn_march_window.h.
 //
 // Per-frame side tables (built by k_frame_lists / k_nb_* + k_pack_ip in pn_render_ops.hip):
 //   nb_rng[n_grid], nb[...]    per cell (begin, end) of: the candidates of its 27-cell neighbourhood as float4(p_def.xyz, bitcast id), in the
@@ -18,7 +18,7 @@
 //   * Newton iteration 0 starts at q = +0, where dF.q = 0 and mul31(F, q) = 0: it is evaluated as A = F, b = -q'
 //     (identical results for finite F, dF; dF is only loaded if a second iteration runs).
 #pragma once
-#include "pn_march.h"
+#include "pn_march_math.h"
 
 namespace pnm2 {
 using namespace pnm;

@@ -18,11 +18,11 @@
 //                 their state and ray constants;
 //   k_march_tail  G = 64, one wave per listed ray (handed out dynamically, long ones first): 64 sequence elements (~14 voxel hops)
 //                 per round, so the critical path of a trip is ~6 rounds instead of ~80 dependent iterations.
-// vs. the cooperative form (pn_march2.h: 8 lanes share ONE evaluation, one iteration at a time) the results are identical bit
+// vs. the cooperative form (pn_march_tables.h: 8 lanes share ONE evaluation, one iteration at a time) the results are identical bit
 // for bit: same -ffp-contract=off expressions, sequential strict-'<' insertion over the candidate list in the reference's
 // visiting order, the `n_IP--` loops replayed literally.
 #pragma once
-#include "pn_march2.h"
+#include "pn_march_tables.h"
 
 namespace pnm3 {
 using namespace pnm;
@@ -771,7 +771,7 @@ __device__ __forceinline__ void eval_point(const MarchParams& a, const March2Tab
     const bool use_pw = pw2 <= a.bound;
     const float mip_bound = use_pw ? pw2 : a.bound;
     const float mip_rbound = use_pw ? scalbnf(1.0f, -level) : c.rbound;
-    // (float)(0.5 * (double)v * (double)H) == v * (0.5f * H): both round the exact product once (pn_march2.h)
+    // (float)(0.5 * (double)v * (double)H) == v * (0.5f * H): both round the exact product once (pn_march_tables.h)
     const int nx = (int)clampf((x * mip_rbound + 1) * c.halfH, 0.0f, c.Hm1);
     const int ny = (int)clampf((y * mip_rbound + 1) * c.halfH, 0.0f, c.Hm1);
     const int nz = (int)clampf((z * mip_rbound + 1) * c.halfH, 0.0f, c.Hm1);

@@ -1,8 +1,8 @@
 // Ray-side kernels of the render path + the whole-frame driver (gfx950).
-// Built with -ffp-contract=off (see pn_march.h).  Reference citations are relative to /root/reference.
+// Built with -ffp-contract=off (see pn_march_math.h).  Reference citations are relative to /root/reference.
 #include <float.h>
 
-#include "pn_march3.h"
+#include "pn_march_window.h"
 
 thread_local char pn_err_buf[512] = {0};
 
@@ -403,7 +403,7 @@ extern "C" int pn_pnts_in_grids(int n_vtx, int n_grid, const float* pnts, const 
 }
 
 // ------------------------------------------------------------------------------------------------ march
-// Side tables of the cooperative march (pn_march2.h): per-cell candidate lists and packed IP records.
+// Side tables of the cooperative march (pn_march_tables.h): per-cell candidate lists and packed IP records.
 __device__ __forceinline__ void nb_cell_coords(int c, int r0, int r1, int& g0, int& g1, int& g2) {
     g0 = c % r0;
     g1 = (c / r0) % r1;
@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(256) k_nb_fill(int n_grid_max, const int* __re
     }
 }
 
-// rec[ip]: see pn_march2.h (pack_ip_float)
+// rec[ip]: see pn_march_tables.h (pack_ip_float)
 __global__ void __launch_bounds__(256) k_pack_ip(int n_vtx, const float* __restrict__ p_ori, const float* __restrict__ p_def,
                                                  const float* __restrict__ F_IP, const float* __restrict__ dF_IP, float* __restrict__ rec) {
     const int t = threadIdx.x + blockIdx.x * blockDim.x;
@@ -498,7 +498,7 @@ struct MarchIO {
     // frame-driver mode (trip != nullptr): counts come from device memory, valid sample slots are appended to `list`
     PnTrip* trip;
     int* list;
-    float* t_resume;  // optional [n_alive]: written by k_march_skip, read by k_march (pn_march2.h: skip_empty_cells)
+    float* t_resume;  // optional [n_alive]: written by k_march_skip, read by k_march (pn_march_tables.h: skip_empty_cells)
     // optional tail pass: rays unfinished after `max_rounds` windows in k_march are appended here (counters zeroed by the caller)
     struct TailEntry* tail;
     int* tail_counts;   // segmented (see PN_SEGS): rays with a long way to go, appended from the front of the segment's region
@@ -522,14 +522,14 @@ struct MarchIO {
     const uint32_t* cell_bits;
     int cell_bits_words;
     // optional (with cell_bits): the cells within one cell of a cell with candidates, and where k_march_skip writes each ray's shortened end
-    // (pn_march3.h: ray_end_of_candidates); the march kernels then run with MarchParams::fars = fars_eff
+    // (pn_march_window.h: ray_end_of_candidates); the march kernels then run with MarchParams::fars = fars_eff
     const uint32_t* cell_bits2;
     float* fars_eff;
     // optional (frame driver with ray groups, see PnGroup): this trip's group records
     const PnGroup* groups;
     uint32_t group_rays;
     int lane_per_ray;           // k_march: one lane per ray instead of eight (the throughput form of a frame's first trip)
-    int dda_start, hop_budget;  // k_march_skip: restart the hop chain just before the first cell with candidates; hops before a ray is handed on (pn_march3.h)
+    int dda_start, hop_budget;  // k_march_skip: restart the hop chain just before the first cell with candidates; hops before a ray is handed on (pn_march_window.h)
 };
 
 // Append lists are SEGMENTED: PN_SEGS independent (counter, region) pairs, every counter on a cache line of its own, the producer picking
@@ -606,7 +606,7 @@ __global__ void __launch_bounds__(256) k_march_skip(pnm::MarchParams a, pnm2::Ma
     }
 }
 
-// ---- the per-ray march (pn_march3.h): pass 1 = k_march (8 lanes per ray, bounded number of rounds), pass 2 = k_march_tail
+// ---- the per-ray march (pn_march_window.h): pass 1 = k_march (8 lanes per ray, bounded number of rounds), pass 2 = k_march_tail
 // (one wave per ray that pass 1 left unfinished).
 // A ray handed from k_march to k_march_tail, with everything the tail pass needs to go on: fetching the slot's ray through rays_alive ->
 // rays_o / rays_d / fars again cost the tail three dependent memory round trips per ray — half of a typical tail ray's time (phase clocks).
@@ -670,7 +670,7 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams 
             have = pnm3::ray_start(a, c, index, noise, io.t_resume ? io.t_resume + n : nullptr, st);
         }
         PN_PHASE(pk, 0);
-        // all 64 lanes enter (the round loop inside is wave-uniform, pn_march3.h); lanes without a ray idle through it
+        // all 64 lanes enter (the round loop inside is wave-uniform, pn_march_window.h); lanes without a ray idle through it
         const bool done = pnm3::march_window<K, MULTI, G>(a, tb, c, n_step, sub, gbase, lane, stage, io.xyzs + (size_t)slot0 * 3,
                                                           io.dirs + (size_t)slot0 * 3, dl, st, budget, have PN_PHASE_PASS);
         if (n < n_alive) {
@@ -2036,9 +2036,9 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     const uint32_t march_grid = march_grid_cfg, trip_grid = std::min(nblk, trip_grid_cfg);
     const uint32_t march_grid_later = march_grid_later_cfg ? march_grid_later_cfg : std::max(std::min(pn_div_up(N, 256), march_grid_cfg), (uint32_t)PN_SEGS);
     // PN_SKIP_LATE_START=1 (experiment, off by default): the skip pre-pass starts its hop chain at the last lattice element before the candidates'
-    // neighbourhood (pn_march3.h).  Bit-identical in every march / frame test, but it only takes k_march_skip from 75 to 68 us on the chair (its
+    // neighbourhood (pn_march_window.h).  Bit-identical in every march / frame test, but it only takes k_march_skip from 75 to 68 us on the chair (its
     // bounding box lies almost entirely within two cells of the object: the leading walks are short already) — not worth a second code path by default.
-    // k_march_skip: DDA start + hop budget (pn_march3.h: skip_empty_cells); PN_SKIP_DDA=0 walks hop by hop like rounds 1-2 (same results bit for bit)
+    // k_march_skip: DDA start + hop budget (pn_march_window.h: skip_empty_cells); PN_SKIP_DDA=0 walks hop by hop like rounds 1-2 (same results bit for bit)
     static const int dda_env = [] { const char* v = getenv("PN_SKIP_DDA"); return (v && v[0] == '0') ? 0 : 1; }();
     const int dda_start = g_skip_dda_override >= 0 ? g_skip_dda_override : dda_env;
     static const uint32_t skip_hop_budget = pn_env_u32("PN_SKIP_HOPS", 8);

@@ -13,7 +13,7 @@
 // so samples of consecutive rays are consecutive in memory (coalesced composite reads) and every run gives the same bytes.
 #include <float.h>
 
-#include "pn_march.h"
+#include "pn_march_math.h"
 
 namespace {
 using namespace pnm;
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(128) k_train_count(const float* __restrict__ r
 // dependent iterations) is the launch time, with 1/16 of the SIMDs busy.  Both branches of the reference loop advance t by the same recurrence
 // s_{k+1} = s_k + clamp(s_k * dt_gamma, dt_min, dt_max) ("emit" takes one step, "hop to the voxel exit" takes steps until t >= tt), so the
 // values a ray can visit are a fixed sequence and the evaluation at s_k is a pure function of s_k (the observation behind the hot path's
-// pn_march3.h).  Per round the 64 lanes evaluate s_0..s_63 of the current window — lane k replays k steps of the recurrence, so every value is
+// pn_march_window.h).  Per round the 64 lanes evaluate s_0..s_63 of the current window — lane k replays k steps of the recurrence, so every value is
 // rounded exactly as in the sequential loop — each lane walks its own hop to the index it would land on, and the wave replays the visit chain
 // 0 -> jump[0] -> ... with uniform lane reads.  Samples, deltas and counts are bit-identical to the lane-per-ray kernels (and to the oracle).
 struct TrainEval { float x, y, z, dt, t_next; int jump; bool occ, valid; };

@@ -11,7 +11,7 @@
 // as in the per-trip launches), so samples, pixels and per-trip counts are those of the trip-by-trip loop bit for bit (tests: every frame test compares
 // the two forms through the oracle / the reference's own kernels; test_gpu_fused.py compares them directly).
 //
-// k_trips_fused: persistent workgroups of PN_FUSED_WAVES waves, one per CU.  A wave holds 8 rays, 8 lanes each (pn_march3.h: march_window<K, MULTI, 8>);
+// k_trips_fused: persistent workgroups of PN_FUSED_WAVES waves, one per CU.  A wave holds 8 rays, 8 lanes each (pn_march_window.h: march_window<K, MULTI, 8>);
 // per round it
 //   1. refills the groups whose ray has died from its workgroup's share of the trip's alive list (packets of 8 dealt round-robin; an LDS cursor),
 //   2. marches 8 samples per ray into the wave's own 64 sample slots — one window round; a ray still going after it (1 % of them: it grazes the object or
@@ -37,7 +37,7 @@
 #ifndef PN_FUSED_WAVES
 #define PN_FUSED_WAVES 12       // waves per workgroup, one workgroup per CU = 3 waves per SIMD: 61 KB weight image + 8 KB of march staging per wave
 #endif
-#define PN_FUSED_STAGE 512      // staging entries per wave (the record heads of a round go through it in two passes: pn_march3.h, SPLIT)
+#define PN_FUSED_STAGE 512      // staging entries per wave (the record heads of a round go through it in two passes: pn_march_window.h, SPLIT)
 // control block of a frame's fused launch, ints: [3 x PN_FUSED_MAX_TRIPS counters][workgroups done]; all zero at launch
 #define PN_FUSED_CTL_HIST 0
 #define PN_FUSED_CTL_DONE (PN_FUSED_CTL_HIST + 3 * PN_FUSED_MAX_TRIPS)

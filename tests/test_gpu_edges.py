@@ -181,7 +181,7 @@ def skip_dda():
 
 @pytest.mark.parametrize("radius,theta,phi", [(5.0, 20.0, -15.0), (2.2, 75.0, -40.0), (9.0, -60.0, 5.0), (5.0, 0.0, 0.0), (5.0, 90.0, 0.0)])
 def test_frame_independent_of_the_skip_pre_pass_form(deformed_ip_state, small_opt, ckpt, skip_dda, radius, theta, phi):
-    """Trip 0's skip pre-pass with the DDA start + hop budget (pn_march3.h: skip_empty_cells; the default) and walking hop by hop (rounds 1-2): the same
+    """Trip 0's skip pre-pass with the DDA start + hop budget (pn_march_window.h: skip_empty_cells; the default) and walking hop by hop (rounds 1-2): the same
     samples (count, trips) and the same pixels bit for bit, from far, from close (rays crossing a binade of t), and along the grid axes (rays nearly
     parallel to cell faces: the cases the DDA refuses or hands on)."""
     W = 96

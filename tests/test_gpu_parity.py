@@ -125,7 +125,7 @@ def test_march_bit_exact(deformed_ip_state, small_opt, ckpt, num_seek_IP, max_it
 def test_march_cut_mode(deformed_ip_state, small_opt, ckpt, background, num_seek_IP, n_step):
     """--cut: bbox = +-bound, samples outside cut_bounds are un-warped background (raymarching.cu:1195-1210,1380-1383).  `background`
     adds occupied density voxels outside the object (blobs of a random pattern), so that static samples are really emitted and the
-    lane-per-ray pre-pass (pn_march2.h: skip_empty_cells) has to hand over at the right sequence element."""
+    lane-per-ray pre-pass (pn_march_tables.h: skip_empty_cells) has to hand over at the right sequence element."""
     from pienerf_amd import raymarching
     ip, ck = deformed_ip_state, dict(ckpt)
     if background:
