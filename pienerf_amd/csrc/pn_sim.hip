@@ -203,12 +203,39 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) {
 
 }  // namespace
 
+#ifndef PN_SIM_STAMPS
+#define PN_SIM_STAMPS 0
+#endif
+#if PN_SIM_STAMPS
+// Timing build (tools/build_variant.py -DPN_SIM_STAMPS=1 with PN_VARIANT_UNITS=pn_sim.hip): the first thread of every substep kernel notes when its launch
+// STARTED (100 MHz wall clock) and which kernel it is, into a ring a tool reads back (pn_sim_stamps_read): start-to-start gaps along the simulator's
+// chain of dependent launches — alone, and beside the render lanes.  [0]: next slot; then entries (kernel id << 56 | ticks)
+#define PN_SIM_STAMP_CAP 65536
+__device__ unsigned long long g_sim_stamps[1 + PN_SIM_STAMP_CAP];
+__device__ __forceinline__ void sim_stamp(int id) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long i = atomicAdd(&g_sim_stamps[0], 1ull);
+        g_sim_stamps[1 + (i % PN_SIM_STAMP_CAP)] = ((unsigned long long)id << 56) | (__builtin_amdgcn_s_memrealtime() & 0x00ffffffffffffffull);
+    }
+}
+extern "C" int pn_sim_stamps_read(unsigned long long* host, int reset) {
+    PN_HIP_CHECK(hipDeviceSynchronize());
+    if (host) PN_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sim_stamps), sizeof(unsigned long long) * (1 + PN_SIM_STAMP_CAP)));
+    if (reset) { const unsigned long long z = 0; PN_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_sim_stamps), &z, sizeof(z))); }
+    return PN_OK;
+}
+#define PN_SIM_STAMP(id) sim_stamp(id)
+#else
+#define PN_SIM_STAMP(id)
+#endif
+
 // ------------------------------------------------------------------------------------------------ update_F / get_IP_info
 // One thread per (IP, shape-function row): row 0 = Nx -> pos; rows 1..3 = dNx[c] -> F[:,c]; rows 4..12 = ddNx[j][c] -> dF[j][:,c].
 // Output already in get_IP_info's permuted fp32 layout (solver.py:422-424).
 __global__ void __launch_bounds__(256) k_update_F(int n_IP, const int* __restrict__ topo, const double* __restrict__ dof, const double* __restrict__ Nx,
                                                   const double* __restrict__ dNx, const double* __restrict__ ddNx, float* __restrict__ pos,
                                                   float* __restrict__ F, float* __restrict__ dF) {
+    PN_SIM_STAMP(4);
     PN_SIM_PRIO();
     const int tid = threadIdx.x + blockIdx.x * blockDim.x;
     const int v = tid / 13, row = tid % 13;
@@ -255,6 +282,7 @@ __global__ void __launch_bounds__(256) k_elastic(int n_IP, const int* __restrict
                                                  const double* __restrict__ mu, const double* __restrict__ lam, double dx3,
                                                  const int* __restrict__ csr_pos = nullptr, double* __restrict__ P_csr = nullptr, int dbg_nosvd = 0,
                                                  double* __restrict__ Vstore = nullptr) {
+    PN_SIM_STAMP(1);
     PN_SIM_PRIO();
     const int tid = threadIdx.x + blockIdx.x * blockDim.x;
     const int v = tid >> 3, i = tid & 7;
@@ -478,7 +506,8 @@ __global__ void __launch_bounds__(1024) k_rhs_gather_csr(int n_k, const int* __r
 // k_gather_plan (once per simulator, one workgroup) lays the chunks out: kc_bg[k] = first chunk of kernel k, chunk[b] = (first entry, count, kernel,
 // chunks of that kernel); every kernel gets at least one chunk (an empty one if it has no entries), unused grid slots have kernel -1.
 #ifndef PN_GCH
-#define PN_GCH 128  // entries per chunk; the chunk kernel runs PN_GCH / 4 slots x 30 threads
+#define PN_GCH 64   // entries per chunk; the chunk kernel runs PN_GCH / 4 slots x 30 threads.  64 (512-thread workgroups) since round 4: 6.9 instead of 7.7 us alone, and beside the render
+                    // lanes a launch of smaller workgroups finds room sooner (start-to-next-start 10.8 instead of 14.4 us; 32: 11.6; profiles/r04_sim_stamps.txt)
 #endif
 __global__ void __launch_bounds__(512) k_gather_plan(int n_k, int chunks_max, const int* __restrict__ csr_bg, const int* __restrict__ csr_cnt,
                                                      int* __restrict__ kc_bg, int4* __restrict__ chunk, int* __restrict__ kcount) {
@@ -529,6 +558,7 @@ __global__ void __launch_bounds__(PN_GCH * 8) k_rhs_gather_chunk(const int4* __r
                                                                   const double* __restrict__ P_csr, double* part, int* kcount,
                                                                   const int* __restrict__ kc_bg, const double* __restrict__ momentum,
                                                                   const double* __restrict__ rhs_rest, double* __restrict__ tot) {
+    PN_SIM_STAMP(2);
     PN_SIM_PRIO();
     constexpr int NS = PN_GCH / 4;
     __shared__ double red[NS][30][3];
@@ -557,15 +587,15 @@ __global__ void __launch_bounds__(PN_GCH * 8) k_rhs_gather_chunk(const int4* __r
         red[slot][q][0] = a0; red[slot][q][1] = a1; red[slot][q][2] = a2;
     }
     __syncthreads();
-    // 30 outputs x NS slots: half-wave o adds slot sl = lane % 32 of output o (its three columns), then a fixed xor tree over the 32 lanes
+    // 30 outputs x NS slots: NS consecutive lanes add slot sl of output o (its three columns), then a fixed xor tree over those lanes
     // (30 threads adding 96 values each one after the other were 2.5 us of this kernel's 6.3)
-    static_assert(NS == 32, "one half-wave per output");
+    static_assert(NS == 32 || NS == 16 || NS == 8, "a power-of-two group of lanes per output");
     if (t < 30 * NS) {
-        const int o = t >> 5, sl = t & 31;
+        const int o = t / NS, sl = t % NS;
         const int x = o / 3, r = o - x * 3;
         double s = (red[sl][x][r] + red[sl][10 + x][r]) + red[sl][20 + x][r];
 #pragma unroll
-        for (int m = 16; m > 0; m >>= 1) s += shfl_xor_d(s, m);
+        for (int m = NS / 2; m > 0; m >>= 1) s += shfl_xor_d(s, m);
         if (sl == 0) {
             if (tot) __hip_atomic_store(part + (size_t)b * 30 + o, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else part[(size_t)b * 30 + o] = s;
@@ -625,13 +655,14 @@ extern "C" int pn_sim_collect_rhs(int n_k, double dx, const int* csr_bg, const i
 __global__ void __launch_bounds__(256) k_matvec3(int n, const double* __restrict__ A, const double* __restrict__ X, double* __restrict__ Y, int mode,
                                                  const double* __restrict__ add1, const double* __restrict__ add2, const double* __restrict__ Xv = nullptr,
                                                  double dt = 0.0, double* __restrict__ copy_out = nullptr, double* __restrict__ vel_out = nullptr) {
+    PN_SIM_STAMP(3);
     PN_SIM_PRIO();
     if (copy_out) {
-        const int g = blockIdx.x * 256 + threadIdx.x;
+        const int g = blockIdx.x * blockDim.x + threadIdx.x;   // (two rows per wave = 32 threads per row >= its 3 entries)
         if (g < n * 3) copy_out[g] = X[g];
     }
     // two rows per wave: each X[j,:] fetched once serves both, and the four-deep unroll keeps 20 loads in flight per lane
-    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    const int i0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 2;
     if (i0 >= n) return;
     const bool two = i0 + 1 < n;
     const int lane = threadIdx.x & 63;
@@ -828,6 +859,9 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
     // load instruction touches 64 cache lines and keeps the CU's address path busy for ~140 cycles; with 256-thread workgroups the 447 waves of the
     // chair sat four to a CU on 112 of the 256 CUs and queued on that path (31.9 -> 28.3 us per local/global iteration; 16-byte loads on top: nothing)
     static const uint32_t el_wg = std::min(std::max(pn_env_u32("PN_SIM_EL_WG", 64) & ~63u, 64u), 256u);
+    // ... and the matrix products in one-wave workgroups as well: beside the render lanes' persistent workgroups a launch starts when its workgroups find
+    // room, and a single wave finds it sooner than four (start-to-start gap behind k_matvec3 in the pipeline: profiles/r04_sim_stamps.txt)
+    static const uint32_t mv_wg = std::min(std::max(pn_env_u32("PN_SIM_MV_WG", 64) & ~63u, 64u), 256u);
     const size_t xs_bytes = (size_t)n3 * sizeof(double);
     const bool chunked = pcsr && chunked_ok && xs_bytes <= 160 * 1024 - 1024;
     if (chunked) {
@@ -848,10 +882,10 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
     static const bool fuse_ends = [] { const char* v = getenv("PN_SIM_FUSE_ENDS"); return !(v && v[0] == '0'); }();
     const bool ends = fuse_ends && chunked && !fused_x && iters >= 1;
     if (ends) {
-        k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Mmat, dof, momentum, 1, dof_f, rhs_gravity, dof_vel, dt, last);  // dof_tilde on the fly, dof_last = dof
+        k_matvec3<<<pn_div_up(n, 2 * (mv_wg / 64)), mv_wg, 0, st>>>(n, Mmat, dof, momentum, 1, dof_f, rhs_gravity, dof_vel, dt, last);  // dof_tilde on the fly, dof_last = dof
     } else {
         k_step_begin<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, dt, dof, dof_vel, tilde, last);
-        k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Mmat, tilde, momentum, 1, dof_f, rhs_gravity);  // compute_momentum (:574-576)
+        k_matvec3<<<pn_div_up(n, 2 * (mv_wg / 64)), mv_wg, 0, st>>>(n, Mmat, tilde, momentum, 1, dof_f, rhs_gravity);  // compute_momentum (:574-576)
     }
     for (int it = 0; it < iters; it++) {
         k_elastic<<<pn_div_up((uint64_t)n_IP * 8, el_wg), el_wg, 0, st>>>(n_IP, topo, dNx, dof, nullptr, nullptr, nullptr, pcsr ? nullptr : P, mu, lam, dx3,
@@ -864,8 +898,8 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
                 k_matvec3_gathered<<<pn_div_up(n, 8), 256, xs_bytes, st>>>(n, Ainv, dof, dof_rest, momentum, rhs_rest, part, kc_bg);
             } else {
                 if (!sum_in_chunk) k_gather_sum<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, kc_bg, part, momentum, rhs_rest, tot);
-                if (ends && it == iters - 1) k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Ainv, tot, dof, 3, dof_rest, last, nullptr, dt, nullptr, dof_vel);
-                else k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Ainv, tot, dof, 2, dof_rest, nullptr);
+                if (ends && it == iters - 1) k_matvec3<<<pn_div_up(n, 2 * (mv_wg / 64)), mv_wg, 0, st>>>(n, Ainv, tot, dof, 3, dof_rest, last, nullptr, dt, nullptr, dof_vel);
+                else k_matvec3<<<pn_div_up(n, 2 * (mv_wg / 64)), mv_wg, 0, st>>>(n, Ainv, tot, dof, 2, dof_rest, nullptr);
             }
             continue;
         }
@@ -873,7 +907,7 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
             k_rhs_gather_csr<<<n_k, 1024, 0, st>>>(n_k, csr_bg, csr_cnt, csr_buf, dNx_csr, P, pcsr ? P_csr : nullptr, momentum, rhs_rest, tot);
         else
             k_rhs_gather<<<pn_div_up(n_k, 4), 256, 0, st>>>(n_k, dx3, csr_bg, csr_cnt, csr_buf, mu, lam, dNx, nullptr, nullptr, P, momentum, rhs_rest, tot);
-        k_matvec3<<<pn_div_up(n, 8), 256, 0, st>>>(n, Ainv, tot, dof, 2, dof_rest, nullptr);  // x = G @ rhs ; dof = dof_rest + x (:600-601)
+        k_matvec3<<<pn_div_up(n, 2 * (mv_wg / 64)), mv_wg, 0, st>>>(n, Ainv, tot, dof, 2, dof_rest, nullptr);  // x = G @ rhs ; dof = dof_rest + x (:600-601)
     }
     if (!ends) k_step_end<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, dt, dof, last, dof_vel);
     PN_LAUNCH_CHECK();

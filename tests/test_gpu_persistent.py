@@ -37,7 +37,7 @@ def test_persistent_substep_equals_the_launch_form_small_scene(small_cloud, smal
     assert b.persistent and b._coop is not None and not b.persistent_timed_out()
     rest = a.dof_rest
     for k, (x, y) in enumerate(zip(ta, tb)):
-        # different summation orders (pieces of <= 272 entries instead of chunks of 128, a different lane -> column map in the matrix rows)
+        # different summation orders (pieces of <= 272 entries instead of chunks of 64, a different lane -> column map in the matrix rows)
         assert rel_err((y - rest).cpu().numpy(), (x - rest).cpu().numpy()) < 1e-9, k
     assert rel_err(b.dof_vel.cpu().numpy(), a.dof_vel.cpu().numpy()) < 1e-7
     assert float((ta[-1] - rest).abs().max()) > 1e-3  # the force moved it

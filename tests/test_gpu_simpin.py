@@ -71,13 +71,13 @@ def test_gather_arrival_counters_are_cyclic():
     """k_rhs_gather_chunk's per-kernel arrival counters return to 0 at the end of every launch (the last arriver stores 0), so they cannot wrap
     however long a simulator lives; rounds 1-3 let them grow by `chunks` per local/global iteration and tested (n % chunks) == 0."""
     from pienerf_amd._lib import lib
-    opt = scene.default_opt()   # 139 kernels, CSR lists of up to 770 entries: most kernels have several chunks of 128
+    opt = scene.default_opt()   # 139 kernels, CSR lists of up to 770 entries: most kernels have several chunks of 64
     s = _sim(scene.make_chair_points(hgs=opt["hash_grid_size"]), opt)
     for _ in range(5):
         s.stepforward()
     torch.cuda.synchronize()
     n_k, n_IP = s.n_k, s.n_IP
-    chunks_max = n_IP * 8 // 128 + n_k                      # pn_gather_chunks_max (PN_GCH = 128)
+    chunks_max = n_IP * 8 // 64 + n_k                       # pn_gather_chunks_max (PN_GCH = 64)
     part0 = 4 * n_k * 30 + n_IP * 9 + n_IP * 8 * 9           # doubles in front of the chunk sums
     kc_bg0 = (part0 + chunks_max * 30) * 2                  # int index of kc_bg in the work buffer
     slot = (n_k + 2) & ~1
