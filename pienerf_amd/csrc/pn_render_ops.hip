@@ -334,10 +334,11 @@ __global__ void __launch_bounds__(1024) k_scan_tile_apply(int n_grid_max, const 
 // exclusive scan cnt -> bgn, cursor over up to n_grid_max cells (the live count may come from device memory)
 static void launch_cell_scan(int n_grid_max, const int* n_grid_dev, const int* cnt, int* bgn, int* cursor, hipStream_t st) {
     const int tiles = (int)pn_div_up(n_grid_max, 4096);
-    // Measured on the trex option set (300 k cells): the tiled form shortens a single frame (1.77 vs 2.20 ms eager) but LOWERS pipelined
-    // throughput (1.30 vs 1.13 ms per step): a long one-workgroup kernel overlaps perfectly with the other lanes' work, three dependent
-    // launches of full-CU workgroups do not.  Throughput is the metric, so the tiled form is opt-in (PN_TILED_SCAN=1).
-    static const bool tiled = pn_env_u32("PN_TILED_SCAN", 0) != 0;
+    // Measured on the trex option set (300 k cells): the tiled form (three launches) shortens a single frame (1.04 vs 1.15 ms eager) and — since the
+    // pipeline's rate is its lanes' chain latency (round 4: frames per second = lanes / latency of a lane's launches) — the pipelined step as well:
+    // 1 464 -> 1 535 steps/s (profiles/r04_trex_scan.txt).  (Round 1 measured the opposite, 1.30 vs 1.13 ms per step, when a lane's chain was ~45
+    // launches and the one long workgroup hid behind the other lanes.)  PN_TILED_SCAN=0: the one-workgroup scan.
+    static const bool tiled = pn_env_u32("PN_TILED_SCAN", 1) != 0;
     if (!tiled || tiles <= 16 || tiles > 1024) {  // small grids: one workgroup is faster than three launches
         k_pig_scan<<<1, 1024, 0, st>>>(n_grid_max, n_grid_dev, cnt, bgn, cursor);
         return;
