@@ -265,6 +265,12 @@ typedef struct {
                              flight 1 730 against 1 930 steps/s (the workgroups of the launch hold a CU each while their first trip's dependency chain
                              leaves most of its waves waiting), two frames in flight 1 700-1 740 against 1 560: harness.capture_pipelined switches it on for
                              pipelines of two render lanes (what every rank of a multi-GPU job runs).  Same samples, records and pixels either way. */
+    int fused_fold;       /* != 0 (with fused_from <= 1, without fused_whole): the first trip's NETWORK, COMPOSITE and COMPACTION inside the fused launch — the
+                             trip's march stays what it is (skip pre-pass, one lane per ray or windows, tail pass: launches that use every CU) and leaves
+                             its segmented sample list; the launch runs network tiles of 32 list entries, composites (one sample per ray) and takes the
+                             survivors on through a per-workgroup list.  Four launches fewer on a frame's chain (k_list_pack, k_nerf_forward, k_composite,
+                             k_compact).  Applies when at most N / 8 rays found a sample on the first trip (checked on the device: then n_step is 8 from the
+                             second trip on); otherwise the launch does nothing and the frame goes on as with fused_whole.  Same results bit for bit. */
     int fused_grid;       /* workgroups of the fused launch (0: one per CU, its upper bound — 12 waves and 157 KB of LDS each, so a workgroup has its CU to
                              itself).  A pipeline with several frames in flight gives each frame's launch a part of the GPU, so that the launches of
                              different frames run side by side instead of one after the other and the rest of the frame's kernels (prologue, skip
@@ -365,7 +371,8 @@ int pn_frame_march_counters(pn_frame* f, int enable, uint64_t* counters_host, vo
 /* With bit 2: clocks_host (uint64[16], may be NULL; synchronises) = cycles summed over the waves of the fused launches on f since the last reset for
  * {hand-out of rays, march (8-lane window round), march (64-lane windows of the rays still going), network, composite}, then wave-rounds, waves,
  * wave lifetimes in 100 MHz ticks (sum), the largest round count and the longest lifetime of a wave; [10..14] (whole-frame form, fused_from = 0): the
- * first trip's one-lane march, its 64-lane windows, its network, its composite + hand-over, the wait at the workgroup barrier behind it;
+ * first trip's one-lane march, its 64-lane windows, its network, its composite + hand-over, the wait at the workgroup barrier behind it; [15]: the form
+ * of the last render's fused launch (0 later trips only, 1 whole frame, 2 first trip folded in);
  * *first_trip_out (may be NULL) = the trip at which the last render on f switched to the fused launch, -1 if it did not.  reset != 0: zero the sums. */
 int pn_frame_fused_clocks(pn_frame* f, uint64_t* clocks_host, int* first_trip_out, int reset, void* stream);
 /* With bit 1 of `enable` set: the per-trip durations (ms, HIP events on the launch stream) of the last blocking render:

@@ -18,7 +18,7 @@ class RenderOpts(C.Structure):
     _fields_ = [("max_iter_num", i32), ("hash_grid_size", f32), ("num_seek_IP", i32), ("IP_dx", f32), ("cut", i32), ("cut_bounds", f32 * 6),
                 ("bound", f32), ("min_near", f32), ("dt_gamma", f32), ("max_steps", u32), ("T_thresh", f32), ("cascade", u32), ("grid_size", u32),
                 ("density_scale", f32), ("bg_color", f32), ("fp16", i32), ("reuse_tables", i32), ("ray_batch", i32), ("throughput", i32), ("throughput_trips", i32), ("ray_tile_w", i32),
-                ("fused_from", i32), ("fused_whole", i32), ("fused_grid", i32)]
+                ("fused_from", i32), ("fused_whole", i32), ("fused_fold", i32), ("fused_grid", i32)]
 
 
 # name -> (restype, argtypes); every function declared in include/pienerf_hip.h

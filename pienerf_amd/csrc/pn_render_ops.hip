@@ -1552,6 +1552,8 @@ struct pn_frame {
     int4* strag;                         // [blist_cap] its rays still searching after the one-lane rounds
     uint32_t blist_cap;
     int skip_done;                       // the last render on this workspace ran k_march_skip (a continuation from trip 0 must not run it again)
+    int head_marched;                    // ... and the first trip's march launches (pn_render_opts.fused_fold): a continuation from trip 0 goes on behind them
+    int fused_mode;                      // form of the last fused launch that was enqueued: 0 later trips, 1 whole frame, 2 first trip folded in (pn_trips_fused.h)
 };
 
 // image = acc + (1 - weights_sum) * bg ; depth = clamp(depth - nears, 0) / (fars - nears) (renderer.py:896-899)
@@ -1946,7 +1948,7 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
         f->fused_blocks = (uint32_t)std::min(std::max(cus, 1), 1024);
     }
     f->blist_cap = (uint32_t)(N / 8 + 64 + (size_t)(f->fused_blocks + 1) * 64);  // n_active <= N / 8, + one partial chunk per workgroup (pn_trips_fused.h)
-    const size_t NS = std::max(N, (size_t)f->fused_blocks * PN_FUSED_WAVES * 64 + f->blist_cap);
+    const size_t NS = N + (size_t)f->fused_blocks * PN_FUSED_WAVES * 64 + f->blist_cap;  // (per-ray slots | the fused launch's waves' slots | its first-trip positions)
     PN_ALLOC(f->xyzs, NS * 12); PN_ALLOC(f->dirs, NS * 12); PN_ALLOC(f->deltas, NS * 8); PN_ALLOC(f->sigmas, NS * 4); PN_ALLOC(f->rgbs, NS * 12);
     PN_ALLOC(f->fused_ctl, (size_t)PN_FUSED_CTL_INTS * 4);
     PN_HIP_CHECK(hipMemset(f->fused_ctl, 0, (size_t)PN_FUSED_CTL_INTS * 4));
@@ -2157,8 +2159,31 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     static const int whole_env = [] { const char* v = getenv("PN_FUSED_WHOLE"); return !v ? -1 : (v[0] == '0' ? 0 : 1); }();
     static const uint32_t a_rounds_env = pn_env_u32("PN_FUSED_AROUNDS", 0);
     bool whole_try = fused_ok && (whole_env < 0 ? o->fused_whole != 0 : whole_env != 0) && o->fused_from == 0 && !resume && t == 0;
+    // ... or the first trip's NETWORK, COMPOSITE and COMPACTION inside that launch (pn_render_opts.fused_fold with fused_from <= 1; pn_trips_fused.h, FOLD): the
+    // march of the first trip stays what it is — skip pre-pass, one lane per ray / windows, tail pass, on every CU — and leaves the trip's segmented sample list;
+    // the launch runs network tiles over it, composites, and takes the survivors on.  Four launches fewer on a frame's chain (k_list_pack, k_nerf_forward,
+    // k_composite, k_compact).  Applies when at most N / 8 rays found a sample (checked on the device); otherwise as with fused_whole.  PN_FUSED_FOLD=0 / 1: A/B.
+    static const int fold_env = [] { const char* v = getenv("PN_FUSED_FOLD"); return !v ? -1 : (v[0] == '0' ? 0 : 1); }();
+    bool fold_try = fused_ok && (fold_env < 0 ? o->fused_fold != 0 : fold_env != 0) && o->fused_from <= 1 && !resume && t == 0;
     bool skip_done = resume && f->skip_done != 0;
-    if (!resume) f->skip_done = 0;
+    bool head_marched = resume && f->head_marched != 0 && t == 0;   // the first trip's march has run: its per-trip launches go on behind it
+    if (!resume) { f->skip_done = 0; f->head_marched = 0; }
+    // measurement mode (march_counters bit 1): point e (0 before the march, 1 behind it, 2 behind the network) of launch group `trip`
+    auto time_mark = [&](int trip, int e) -> int {
+        if (!(f->march_counters_on & 2) || trip >= PN_TIMED_TRIPS) return PN_OK;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        PN_HIP_CHECK(hipStreamIsCapturing(st, &cs));
+        const bool stamp = cs != hipStreamCaptureStatusNone;   // inside a capture: stamp kernels (events recorded in a graph cannot be timed)
+        f->stamped = stamp ? 1 : 0;
+        if (stamp) {
+            k_stamp<<<1, 1, 0, st>>>(f->stamps + trip * 3 + e);
+        } else {
+            if (!f->ev[trip][e]) PN_HIP_CHECK(hipEventCreate(&f->ev[trip][e]));
+            PN_HIP_CHECK(hipEventRecord(f->ev[trip][e], st));
+        }
+        if (e == 2) f->timed_trips = std::max(f->timed_trips, trip + 1);
+        return PN_OK;
+    };
     int* const seg_tail = f->seg_counters;
     int* const seg_samp = seg_tail + PN_SEGS * PN_SEG_STRIDE;
     int* const seg_emit = seg_samp + PN_SEGS * PN_SEG_STRIDE;
@@ -2180,7 +2205,20 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     while (!done && t < PN_MAX_TRIPS) {
         const bool whole = whole_try;
         whole_try = false;
-        if (whole || t >= fuse_from) {
+        const bool fold = !whole && fold_try && t == 0 && !head_marched;
+        if (fold) fold_try = false;
+        if (fold) {  // the first trip's march, as its per-trip launches would run it (no k_list_pack: the launch reads the segments)
+            const MarchIO io0 = make_io(0);
+            if ((rc = time_mark(0, 0))) return rc;
+            if (!skip_done) { k_march_skip<<<nblk, 256, skip_lds, st>>>(mp, tb, io0); skip_done = true; f->skip_done = 1; }
+            pnm::MarchParams mq0 = mp;
+            if (short_rays) mq0.fars = f->fars_eff;
+            launch_march(o->num_seek_IP, std::max(std::min(pn_div_up(N, 32), march_grid), (uint32_t)PN_SEGS), tail_grid, st, mq0, tb, io0);
+            head_marched = true;
+            f->head_marched = 1;
+            if ((rc = time_mark(0, 1)) || (rc = time_mark(0, 2))) return rc;
+        }
+        if (whole || fold || t >= fuse_from) {
             FusedArgs fa;
             memset(&fa, 0, sizeof(fa));
             fa.lv = (const PnFusedLevel*)net->fused_levels; fa.emb = net->embeddings; fa.emb_h = (const uint32_t*)net->emb_half; fa.emb_bytes = net->n_entries * 4u;
@@ -2198,22 +2236,14 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                 fa.blist = f->blist; fa.strag = f->strag; fa.blist_cap = f->blist_cap;
                 fa.a_rounds = a_rounds_env ? (int)a_rounds_env : 24;
             }
+            if (fold) {
+                fa.list_seg = f->list_seg; fa.samp_counts = seg_samp; fa.list_seg_cap = (int)f->seg_cap; fa.seg_tail = seg_tail; fa.seg_back = seg_back;
+                fa.blist = f->blist; fa.strag = f->strag; fa.blist_cap = f->blist_cap;
+            }
+            const int tb_idx = fold ? 1 : t;   // launch group the fused launch is timed as (fold: behind the first trip's march)
             pnm::MarchParams mq = mp;
             if (short_rays) mq.fars = f->fars_eff;  // written by trip 0's k_march_skip
-            const bool timed = (f->march_counters_on & 2) && t < PN_TIMED_TRIPS;
-            bool stamp = false;
-            if (timed) {  // the whole launch is bracketed like a trip's march group (its network share comes from the phase clocks)
-                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-                PN_HIP_CHECK(hipStreamIsCapturing(st, &cs));
-                stamp = cs != hipStreamCaptureStatusNone;
-                f->stamped = stamp ? 1 : 0;
-                if (stamp) k_stamp<<<1, 1, 0, st>>>(f->stamps + t * 3);
-                else {
-                    for (int e = 0; e < 3; e++)
-                        if (!f->ev[t][e]) PN_HIP_CHECK(hipEventCreate(&f->ev[t][e]));
-                    PN_HIP_CHECK(hipEventRecord(f->ev[t][0], st));
-                }
-            }
+            if ((rc = time_mark(tb_idx, 0))) return rc;  // the whole launch is bracketed like a trip's march group (its network share comes from the phase clocks)
             if (whole) {  // the skip pre-pass: per-ray resume points, shortened ends, the active list (one lane per ray)
                 const MarchIO io0 = make_io(0);
                 k_march_skip<<<nblk, 256, skip_lds, st>>>(mp, tb, io0);
@@ -2221,14 +2251,11 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                 f->skip_done = 1;
             }
             const uint32_t blocks = fused_grid_env ? std::min(fused_grid_env, f->fused_blocks) : (o->fused_grid > 0 ? std::min((uint32_t)o->fused_grid, f->fused_blocks) : f->fused_blocks);
-            rc = launch_trips_fused(o->num_seek_IP, o->max_iter_num > 1, o->fp16 != 0, whole, blocks, st, mq, tb, fa);
+            rc = launch_trips_fused(o->num_seek_IP, o->max_iter_num > 1, o->fp16 != 0, whole ? 1 : (fold ? 2 : 0), blocks, st, mq, tb, fa);
             if (rc) return rc;
-            if (timed) {
-                if (stamp) { k_stamp<<<1, 1, 0, st>>>(f->stamps + t * 3 + 1); k_stamp<<<1, 1, 0, st>>>(f->stamps + t * 3 + 2); }
-                else { PN_HIP_CHECK(hipEventRecord(f->ev[t][1], st)); PN_HIP_CHECK(hipEventRecord(f->ev[t][2], st)); }
-                f->timed_trips = t + 1;
-            }
-            f->fused_first = t;
+            if ((rc = time_mark(tb_idx, 1)) || (rc = time_mark(tb_idx, 2))) return rc;
+            f->fused_first = tb_idx;
+            f->fused_mode = whole ? 1 : (fold ? 2 : 0);
             if (async_trips > 0) { add_fused = 1; break; }  // how many trips it ran only the device knows: k_frame_finish adds them
             PN_HIP_CHECK(hipMemcpyAsync(f->dev_pinned, f->dev, sizeof(PnFrameDev), hipMemcpyDeviceToHost, st));
             PN_HIP_CHECK(hipMemcpyAsync(f->trips_pinned + t, f->trips + t, sizeof(PnTrip), hipMemcpyDeviceToHost, st));
@@ -2237,6 +2264,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             if (f->trips_pinned[t].n_alive <= 0) { done = true; break; }
             // not applicable at this trip (more than N / 8 rays alive: n_step < 8): one trip of the per-trip launches, then again
             f->fused_first = -1;
+            f->fused_mode = 0;
         }
         const int batch = async_trips > 0 ? (fused_ok ? fuse_from - t : async_trips) : (fused_ok ? std::max(fuse_from - t, 1) : PN_TRIP_BATCH);
         for (int k = 0; k < batch; k++, t++) {
@@ -2268,11 +2296,13 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                 k_march_static_trip<<<trip_grid, 256, 0, st>>>(f->trips + t, cur, f->rays_t, rays_o, rays_d, o->bound, o->dt_gamma, o->max_steps, o->cascade,
                                                                o->grid_size, bitfield, f->fars, f->xyzs, f->dirs, f->deltas, f->list);
             } else {
+                if (!(t == 0 && head_marched)) {   // (a first trip whose march has already run — a fused launch that stepped aside — goes on with its sample list)
                 if (io.t_resume && !skip_done) { k_march_skip<<<nblk, 256, skip_lds, st>>>(mp, tb, io); skip_done = true; f->skip_done = 1; }
                 pnm::MarchParams mq = mp;
                 if (short_rays) mq.fars = f->fars_eff;  // written by trip 0's k_march_skip
                 launch_march(o->num_seek_IP, t == 0 ? std::max(std::min(pn_div_up(N, 32), march_grid), (uint32_t)PN_SEGS) : (margin ? 2u * PN_SEGS : march_grid_later),
                              margin ? (uint32_t)PN_SEGS : tail_grid, st, mq, tb, io);
+                }
                 if (t == 0) k_list_pack<<<PN_SEGS, 256, 0, st>>>(f->trips + t, seg_samp, f->list_seg, (int)f->seg_cap, f->list);  // the only list trip
             }
             if (timed && stamp) k_stamp<<<1, 1, 0, st>>>(f->stamps + t * 3 + 1);
@@ -2398,6 +2428,7 @@ extern "C" int pn_frame_fused_clocks(pn_frame* f, uint64_t* clocks_host, int* fi
     if (clocks_host) {
         PN_HIP_CHECK(hipMemcpyAsync(clocks_host, f->fused_clocks, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         PN_HIP_CHECK(hipStreamSynchronize(st));
+        clocks_host[15] = f->fused_first >= 0 ? (uint64_t)f->fused_mode : 0u;   // form of the last render's fused launch (host-side knowledge)
     }
     if (first_trip_out) *first_trip_out = f->fused_first;
     if (reset) PN_HIP_CHECK(hipMemsetAsync(f->fused_clocks, 0, 16 * sizeof(unsigned long long), st));

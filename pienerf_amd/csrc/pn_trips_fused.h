@@ -73,6 +73,8 @@ struct FusedArgs {
     uint32_t blist_cap;          // positions; the sample arrays hold gridDim * PN_FUSED_WAVES * 64 + blist_cap slots
     int a_rounds;                // one-lane rounds of the first trip before a ray goes to the 64-lane windows
     int xcd_bands;               // WHOLE = false: deal the alive list to the XCDs in eight contiguous bands (see the hand-out)
+    // FOLD (MODE 2): the first trip's segmented sample list and the march's tail counters
+    const int* list_seg; const int* samp_counts; int list_seg_cap; const int* seg_tail; const int* seg_back;
 };
 
 // composite_one (kernel_composite_rays, raymarching.cu:827-923) for the 8 slots of one ray of the fused launch: the same operations in the same order,
@@ -82,12 +84,18 @@ __device__ __forceinline__ bool composite_slots8(int index, uint32_t slot0, floa
                                                  const float* __restrict__ rgbs, const float* __restrict__ deltas, float* weights_sum, float* depth,
                                                  float* image) {
     float sg[8], d0[8], d1[8], cr[8], cg[8], cb[8];
+    // ONE base address per array and constant offsets from it: with `slot0 + k` formed in 32 bits the compiler cannot rule out a wrap once slot0 has an
+    // unknown addend (FOLD: N_rays), builds 24 separate 64-bit addresses, hoists them out of the round loop, spills them and reloads them every round
+    // (the later trips' composite: 7 -> 30 k cycles per round)
+    const float* __restrict__ sgp = sigmas + (size_t)slot0;
+    const float* __restrict__ dlp = deltas + (size_t)slot0 * 2;
+    const float* __restrict__ cp = rgbs + (size_t)slot0 * 3;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        sg[k] = sigmas[slot0 + k];
-        const float2 dd = *reinterpret_cast<const float2*>(deltas + (size_t)(slot0 + k) * 2);
+        sg[k] = sgp[k];
+        const float2 dd = *reinterpret_cast<const float2*>(dlp + k * 2);
         d0[k] = dd.x; d1[k] = dd.y;
-        const pnm3::Float3 c3 = *reinterpret_cast<const pnm3::Float3*>(rgbs + (size_t)(slot0 + k) * 3);
+        const pnm3::Float3 c3 = *reinterpret_cast<const pnm3::Float3*>(cp + k * 3);
         cr[k] = c3.x; cg[k] = c3.y; cb[k] = c3.z;
     }
     float ws = weights_sum[index], d = depth[index];
@@ -140,13 +148,16 @@ __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_fl
 //        workgroup's own list;
 //     B. (behind a workgroup barrier) the loop below over that list.
 //   Not applicable (more than N / 8 active rays, a frame stopped by an error flag): the launch does nothing and says so (fused_trips stays 0).
-template <int K, bool MULTI, bool HALF, bool WHOLE>
+template <int K, bool MULTI, bool HALF, int MODE>
 __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4) k_trips_fused(pnm::MarchParams a, pnm2::March2Tables tb, FusedArgs fa) {
     extern __shared__ __attribute__((aligned(16))) uint4 fused_lds[];
     constexpr int IMG16 = (HALF ? PN_NET_HALF_BYTES : PN_NET_SPLIT_BYTES) / 16;
     constexpr int MAXT = PN_FUSED_MAX_TRIPS;
     constexpr int AC = PN_FUSED_ACHUNK;
     static_assert(AC == 64 || AC == 32, "rays per first-trip chunk");
+    constexpr bool WHOLE = MODE == 1;   // the frame's first trip inside the launch, its march included
+    constexpr bool FOLD = MODE == 2;    // ... its network, composite and hand-over only: the march ran as launches of its own and left the trip's sample list
+    constexpr bool QUEUED = MODE != 0;  // later-trip rays come from the workgroup's own list (filled while the launch runs)
     uint4* wimg = fused_lds;  // the weight image, then the 16 level records (512 B), as in k_nerf_forward
     float4* stage_all = reinterpret_cast<float4*>(fused_lds + IMG16 + 32);
     int* hist = reinterpret_cast<int*>(stage_all + PN_FUSED_WAVES * PN_FUSED_STAGE);  // [3][MAXT]: rays entering trip j, samples emitted, rays through the 64-lane windows
@@ -158,10 +169,10 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
     const PnTrip* tr = fa.trips;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int A = 0, sb0 = 0, n_active = 0;
-    if (WHOLE) {
-        // exclusive prefix of the active list's segment counts (the same in every workgroup)
+    if (QUEUED) {
+        // exclusive prefix of the segment counts of the active list (WHOLE) / of the first trip's sample list (FOLD): the same in every workgroup
         if (threadIdx.x < 64) {
-            const int cnt = seg_count(fa.active_counts, lane);
+            const int cnt = seg_count(WHOLE ? fa.active_counts : fa.samp_counts, lane);
             int inc = cnt;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -172,11 +183,11 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
             if (lane == 0) s_pref[0] = 0;
         }
         __syncthreads();
-        n_active = s_pref[PN_SEGS];
+        n_active = s_pref[PN_SEGS];   // (FOLD: the rays that found a sample on the first trip — n_alive of the next trip cannot exceed them either)
         const long long chunks = ((long long)n_active + AC - 1) / AC;
         const bool ok = tr->n_alive == (int)fa.N_rays && tr->n_step == 1 && tr->step_base == 0 && (long long)n_active * 8 <= (long long)fa.N_rays &&
                         (chunks + (long long)gridDim.x) * AC <= (long long)fa.blist_cap &&  // (also the room behind the waves' sample slots)
-                        (chunks + (long long)gridDim.x - 1) / (long long)gridDim.x <= PN_FUSED_MAXCHUNKS;
+                        (WHOLE ? (chunks + (long long)gridDim.x - 1) / (long long)gridDim.x <= PN_FUSED_MAXCHUNKS : true);
         if (!ok) return;
         sb0 = 1;  // `step` behind the first trip
     } else {
@@ -188,17 +199,18 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
     if (threadIdx.x < 16 * sizeof(PnFusedLevel) / 16) wimg[IMG16 + threadIdx.x] = reinterpret_cast<const uint4*>(fa.lv)[threadIdx.x];
     for (int i = threadIdx.x; i < 3 * MAXT; i += PN_FUSED_WAVES * 64) hist[i] = 0;
     if (threadIdx.x == 0) { s_cursor = 0; s_bres = s_bready = s_bhead = s_sres = s_sready = s_shead = s_a1done = 0; }
-    if (WHOLE) {
-        const int n_chunks0 = (n_active + AC - 1) / AC;
-        const int mine0 = (int)blockIdx.x < n_chunks0 ? (n_chunks0 - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    if (QUEUED) {   // work items that can still hand rays on: WHOLE: chunks of AC active rays; FOLD: tiles of 32 first-trip samples
+        const int n_items0 = WHOLE ? (n_active + AC - 1) / AC : (n_active + 31) / 32;
+        const int mine0 = (int)blockIdx.x < n_items0 ? (n_items0 - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
         if (threadIdx.x == 0) s_pending = mine0;
-        for (int i = threadIdx.x; i < PN_FUSED_MAXCHUNKS; i += PN_FUSED_WAVES * 64) s_pend[i] = 64;
+        if (WHOLE)
+            for (int i = threadIdx.x; i < PN_FUSED_MAXCHUNKS; i += PN_FUSED_WAVES * 64) s_pend[i] = 64;
     }
     __syncthreads();
 
     const int sub = lane & 7, gbase = lane & ~7, grp = lane >> 3;
     const uint32_t wave_g = blockIdx.x * PN_FUSED_WAVES + wv;
-    const uint32_t slotw = wave_g * 64u, slot0 = slotw + (uint32_t)grp * 8u;
+    const uint32_t slotw = (FOLD ? fa.N_rays : 0u) + wave_g * 64u, slot0 = slotw + (uint32_t)grp * 8u;  // (FOLD: the first trip's samples sit in the slots of their rays)
     float4* stage = stage_all + wv * PN_FUSED_STAGE;
     const uint4* __restrict__ wl = wimg + lane;
     const int half = lane >> 5, s32 = lane & 31;
@@ -244,11 +256,12 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
         }
     };
     // ... on the wave's 64 slots: tile 0 = slots 0..31, tile 1 = 32..63; `rm`: lanes whose slots carry something
-    auto network64 = [&](unsigned long long rm) __attribute__((always_inline)) {
+    // (`own` = false: ONE tile on the slots the lanes name themselves — a tile of the first trip's sample list, FOLD)
+    auto network64 = [&](unsigned long long rm, bool own = true, uint32_t lane_slot = 0u) __attribute__((always_inline)) {
 #pragma unroll 1
         for (int tile = 0; tile < 2; tile++) {
             if (!((rm >> (32 * tile)) & 0xFFFFFFFFull)) continue;
-            network_tile(slotw + 32u * (uint32_t)tile + (uint32_t)s32);
+            network_tile(own ? slotw + 32u * (uint32_t)tile + (uint32_t)s32 : lane_slot);
         }
     };
     auto wave_sync_mem = [&]() __attribute__((always_inline)) {  // the wave's own stores before its own loads of the same addresses by other lanes
@@ -337,10 +350,10 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
         if (lane == 0) left = atomicSub(&s_pend[ci], n) - n;
         return __builtin_amdgcn_readfirstlane(left) == 0;
     };
-    if (WHOLE) {
-        const int n_chunks = (n_active + AC - 1) / AC;
+    if (QUEUED) {
+        const int n_chunks = WHOLE ? (n_active + AC - 1) / AC : (n_active + 31) / 32;   // FOLD: tiles of 32 samples, `my_chunks` of them here
         my_chunks = (int)blockIdx.x < n_chunks ? (n_chunks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-        const int bcap = ((n_chunks + (int)gridDim.x - 1) / (int)gridDim.x) * AC;
+        const int bcap = ((n_chunks + (int)gridDim.x - 1) / (int)gridDim.x) * (WHOLE ? AC : 32);
         const size_t wg_off = (size_t)blockIdx.x * (size_t)bcap;
         a_index = fa.blist + wg_off;                         // ray id per position
         blist = fa.blist + (size_t)fa.blist_cap + wg_off;    // the rays that go on behind the first trip
@@ -465,26 +478,26 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
 
     for (;;) {
         // ---- 1. refill the groups without a ray
-        if (WHOLE || !pool_empty) {
+        if (QUEUED || !pool_empty) {
             const unsigned long long em = __ballot(index < 0 && sub == 0);
             const int need = (int)__popcll(em);
             if (need > 0) {
                 const int my_rank = (int)__popcll(em & ((1ull << gbase) - 1ull));
                 int base = 0, take = need;
-                if (WHOLE) {
+                if (QUEUED) {
                     if (lane == 0) base = q_claim(&s_bhead, &s_bready, need, take);
                     take = __builtin_amdgcn_readfirstlane(take);
                 } else {
                     if (lane == 0) base = atomicAdd(&s_cursor, need);
                 }
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (!WHOLE) pool_empty = base + need >= share;
+                if (!QUEUED) pool_empty = base + need >= share;
                 const int p = base + my_rank;
-                const int gpos = WHOLE ? p : (band_x >= 0 ? (band_x * band_E + band_local + (p >> 3) * band_per) * 8 + (p & 7)
+                const int gpos = QUEUED ? p : (band_x >= 0 ? (band_x * band_E + band_local + (p >> 3) * band_per) * 8 + (p & 7)
                                                           : ((p >> 3) * (int)gridDim.x + (int)blockIdx.x) * 8 + (p & 7));
-                if (index < 0 && (WHOLE ? my_rank < take : (p < share && gpos < A))) {
-                    index = WHOLE ? my_list[gpos] : fa.alive[gpos];
-                    j = WHOLE ? 1 : 0;
+                if (index < 0 && (QUEUED ? my_rank < take : (p < share && gpos < A))) {
+                    index = QUEUED ? my_list[gpos] : fa.alive[gpos];
+                    j = QUEUED ? 1 : 0;
                     pnm3::RayConsts cn;
                     pnm3::ray_consts(a, index, cn);
                     r_ox = cn.ox; r_oy = cn.oy; r_oz = cn.oz; r_dx = cn.dx; r_dy = cn.dy; r_dz = cn.dz; r_rdx = cn.rdx; r_rdy = cn.rdy; r_rdz = cn.rdz; r_far = cn.far;
@@ -492,20 +505,56 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
                 }
             }
         }
+        // FOLD: a wave without a ray takes a tile of the first trip's sample list (32 entries of its segments' concatenation, dealt round-robin over the
+        // workgroups, an LDS cursor inside): the round below is then network on that tile, composite (one sample), survivors to the workgroup's list.  The
+        // tile runs through the SAME network code as the later trips' rounds (a second inlined copy of the tile cost 40 more spilled registers, and the
+        // later trips' composite went from 7 to 30 k cycles per round reloading them)
+        bool fold_round = false, f_has = false;
+        uint32_t f_slot = 0u;
         if (!__any(index >= 0)) {
-            if (!WHOLE) break;
-            // ---- no ray in hand and none to take: wait for the first trip's last chunks (another wave is in their A3), or done
-            int fin = 0;
-            if (lane == 0) fin = (lds_ld(&s_pending) == 0 && lds_ld(&s_bhead) >= lds_ld(&s_bready)) ? 1 : 0;
-            if (__builtin_amdgcn_readfirstlane(fin)) break;
-            __builtin_amdgcn_s_sleep(32);
-            tick(9);
-            continue;
+            if (!QUEUED) break;
+            if (FOLD) {
+                int ti = my_chunks;
+                if (lane == 0 && lds_ld(&s_cursor) < my_chunks) ti = atomicAdd(&s_cursor, 1);
+                ti = __builtin_amdgcn_readfirstlane(ti);
+                if (ti < my_chunks) {
+                    fold_round = true;
+                    const int e = ((int)blockIdx.x + ti * (int)gridDim.x) * 32 + s32;   // position in the concatenation of the list's segments
+                    f_has = e < n_active;
+                    if (f_has) {
+                        int lo = 0, hi = PN_SEGS;
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (s_pref[mid] <= e) lo = mid; else hi = mid;
+                        }
+                        f_slot = (uint32_t)fa.list_seg[(size_t)lo * fa.list_seg_cap + (e - s_pref[lo])];
+                    }
+                    // lanes without an entry (the list's last tile) run the tile on the first entry's sample again: a valid position, and they store what
+                    // its own lane stores
+                    f_slot = f_has ? f_slot : (uint32_t)__builtin_amdgcn_readlane((int)f_slot, (int)__builtin_ctzll(__ballot(f_has)));
+                }
+            }
+            if (!fold_round) {
+                // ---- no ray in hand and none to take: wait for the first trip's last chunks / tiles (another wave is in them), or done
+                int fin = 0;
+                if (lane == 0) fin = (lds_ld(&s_pending) == 0 && lds_ld(&s_bhead) >= lds_ld(&s_bready)) ? 1 : 0;
+                if (__builtin_amdgcn_readfirstlane(fin)) break;
+                __builtin_amdgcn_s_sleep(32);
+                tick(9);
+                continue;
+            }
         }
+        unsigned long long net_mask = 0ull;   // lanes whose slots carry something for the network
+        bool have_ray = false;
+        if (fold_round) {
+            net_mask = __ballot(f_has && half == 0);
+            if (lane == 0) atomicAdd(&hist[MAXT], (int)__popcll(net_mask));   // (a.stats + 3, the emitted-sample counter, was advanced by the march launches)
+            tick(0);
+        } else {
         rounds++;
         tick(0);
         // ---- 2. march: one window round of 8 lanes per ray, then the rays still going with the whole wave
-        const bool have_ray = index >= 0;
+        have_ray = index >= 0;
         if (have_ray && sub == 0) atomicAdd(&hist[j], 1);
         pnm3::RayConsts c;
         pnm3::frame_consts(a, c);
@@ -551,10 +600,34 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
         }
         wave_sync_mem();
         tick(2);
-        // ---- 3. network on the wave's 64 slots: tile 0 = groups 0..3, tile 1 = groups 4..7
-        network64(__ballot(have_ray));
+        net_mask = __ballot(have_ray);
+        }
+        // ---- 3. network on the wave's 64 slots: tile 0 = groups 0..3, tile 1 = groups 4..7 (a fold round: one tile on the slots its lanes name) — ONE
+        // inlined copy of the tile for both kinds of round
+        network64(net_mask, !fold_round, f_slot);
         wave_sync_mem();
-        tick(3);
+        tick(fold_round ? 7 : 3);
+        if (fold_round) {
+            bool on = false;
+            int idx = -1;
+            if (f_has && half == 0) {
+                idx = fa.alive[f_slot];   // n_step == 1: a ray's sample slot is its position in the alive list
+                on = composite_one(idx, f_slot, 1u, fa.T_thresh, fa.rays_t, fa.sigmas, fa.rgbs, fa.deltas, fa.weights_sum, fa.depth, fa.image) && go_on;
+            }
+            const unsigned long long om = __ballot(on);
+            wave_sync_mem();
+            if (om) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_bres, (int)__popcll(om));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (on) blist[base + (int)__popcll(om & ((1ull << lane) - 1ull))] = idx;
+                wave_sync_mem();
+                if (lane == 0) q_publish(&s_bready, base, (int)__popcll(om));
+            }
+            if (lane == 0) atomicSub(&s_pending, 1);
+            tick(8);
+            continue;
+        }
         // ---- 4. composite (kernel_composite_rays, raymarching.cu:827-923): one lane per ray; a ray goes on iff it used all 8 samples
         int alive = 0;
         if (have_ray && sub == 0)
@@ -563,7 +636,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
         r_t = __shfl(r_t, gbase);
         if (have_ray) {
             // renderer.py:836: the loop ends when `step` reaches max_steps, whatever is still alive
-            if (alive && (uint32_t)(sb0 + 8 * (j + (WHOLE ? 0 : 1))) < fa.max_steps && j + 1 < MAXT) j++;
+            if (alive && (uint32_t)(sb0 + 8 * (j + (QUEUED ? 0 : 1))) < fa.max_steps && j + 1 < MAXT) j++;
             else index = -1;
         }
         tick(4);
@@ -575,7 +648,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
         atomicAdd(fa.clocks + 7, __builtin_amdgcn_s_memrealtime() - rt0);  // the wave's lifetime on the constant 100 MHz clock
         atomicMax(fa.clocks + 8, rounds);
         atomicMax(fa.clocks + 9, __builtin_amdgcn_s_memrealtime() - rt0);
-        if (WHOLE)
+        if (QUEUED)
             for (int k = 5; k < 10; k++) atomicAdd(fa.clocks + 5 + k, c_acc[k]);
     }
 
@@ -600,22 +673,28 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
         int al = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int em = __hip_atomic_load(hp + MAXT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int tl = __hip_atomic_load(hp + 2 * MAXT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (WHOLE && jj == 0) al = (int)fa.N_rays;  // the first trip: every ray (its record was written by the frame prologue)
+        if (QUEUED && jj == 0) al = (int)fa.N_rays;  // the first trip: every ray (its record was written by the frame prologue)
         m += (int)__popcll(__ballot(al > 0));
         if (al > 0) {
             PnTrip* r = fa.trips + jj;
-            if (jj > 0) { r->n_alive = al; r->n_step = 8; r->step_base = sb0 + 8 * (jj - (WHOLE ? 1 : 0)); r->dense = 1; r->n_samples = al * 8; }
-            if (WHOLE && jj == 0) r->n_samples = em;  // a list trip: the samples listed (n_emitted stays -1)
+            if (jj > 0) { r->n_alive = al; r->n_step = 8; r->step_base = sb0 + 8 * (jj - (QUEUED ? 1 : 0)); r->dense = 1; r->n_samples = al * 8; }
+            if (QUEUED && jj == 0) r->n_samples = em;  // a list trip: the samples listed (n_emitted stays -1)
             else r->n_emitted = em;
-            fa.tail_diag[jj] = tl;
+            if (!(FOLD && jj == 0)) fa.tail_diag[jj] = tl;  // (FOLD: the first trip's rays through the tail pass are counted below, from the march's counters)
         }
         __hip_atomic_store(hp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(hp + MAXT, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(hp + 2 * MAXT, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (FOLD) {  // what the first trip's compaction would have folded out of the march's segment counters: rays handed to the tail pass (front + back lists)
+        int tl0 = seg_count(fa.seg_tail, lane) + seg_count(fa.seg_back, lane);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tl0 += __shfl_xor(tl0, o);
+        if (lane == 0) fa.tail_diag[0] = tl0;
+    }
     if (lane == 0) {
         PnTrip* r = fa.trips + m;  // the record behind the last trip that had rays: the frame is over
-        r->n_alive = 0; r->n_step = 1; r->step_base = WHOLE ? (m == 0 ? 0 : 1 + 8 * (m - 1)) : sb0 + 8 * m; r->dense = 0; r->n_samples = 0; r->n_emitted = 0;
+        r->n_alive = 0; r->n_step = 1; r->step_base = QUEUED ? (m == 0 ? 0 : 1 + 8 * (m - 1)) : sb0 + 8 * m; r->dense = 0; r->n_samples = 0; r->n_emitted = 0;
         fa.dev->fused_trips = m;
         __hip_atomic_store(fa.ctl + PN_FUSED_CTL_DONE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -626,24 +705,26 @@ static size_t fused_lds_bytes(bool half) {
            3 * PN_FUSED_MAX_TRIPS * sizeof(int);
 }
 
-template <int K, bool MULTI, bool HALF, bool WHOLE>
+template <int K, bool MULTI, bool HALF, int MODE>
 static int launch_trips_fused_t(uint32_t blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb, const FusedArgs& fa) {
     const size_t lds = fused_lds_bytes(HALF);
     static bool granted[PN_MAX_DEVICES] = {false};  // dynamic LDS above 64 KB is opted into per function and DEVICE
     int dev_id = 0;
     PN_HIP_CHECK(hipGetDevice(&dev_id));
     if (dev_id < 0 || dev_id >= PN_MAX_DEVICES || !granted[dev_id]) {
-        PN_HIP_CHECK(hipFuncSetAttribute((const void*)k_trips_fused<K, MULTI, HALF, WHOLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PN_HIP_CHECK(hipFuncSetAttribute((const void*)k_trips_fused<K, MULTI, HALF, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (dev_id >= 0 && dev_id < PN_MAX_DEVICES) granted[dev_id] = true;
     }
-    k_trips_fused<K, MULTI, HALF, WHOLE><<<blocks, PN_FUSED_WAVES * 64, lds, st>>>(a, tb, fa);
+    k_trips_fused<K, MULTI, HALF, MODE><<<blocks, PN_FUSED_WAVES * 64, lds, st>>>(a, tb, fa);
     PN_LAUNCH_CHECK();
     return PN_OK;
 }
 
-static int launch_trips_fused(int K, bool multi, bool half, bool whole, uint32_t blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb,
+static int launch_trips_fused(int K, bool multi, bool half, int mode, uint32_t blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb,
                               const FusedArgs& fa) {
-#define PN_FUSED_CASE2(K_, M_, H_) return whole ? launch_trips_fused_t<K_, M_, H_, true>(blocks, st, a, tb, fa) : launch_trips_fused_t<K_, M_, H_, false>(blocks, st, a, tb, fa)
+#define PN_FUSED_CASE2(K_, M_, H_)                                                                  \
+    return mode == 1 ? launch_trips_fused_t<K_, M_, H_, 1>(blocks, st, a, tb, fa)                   \
+                     : (mode == 2 ? launch_trips_fused_t<K_, M_, H_, 2>(blocks, st, a, tb, fa) : launch_trips_fused_t<K_, M_, H_, 0>(blocks, st, a, tb, fa))
 #define PN_FUSED_CASE(K_)                                      \
     if (K == K_) {                                             \
         if (multi) {                                           \

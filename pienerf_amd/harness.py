@@ -514,6 +514,18 @@ class _HipBackend:
             kw["fused_whole"] = bool(whole)
             if whole:
                 kw["fused_from"] = 0
+        if "fused_fold" not in kw:
+            # pn_render_opts.fused_fold: the first trip's network, composite and compaction inside the fused launch (its march stays launches of its own): four
+            # launches fewer on a lane's chain.  Where the blocking frame below finds it applicable (at most N / 8 rays with a sample on the first trip)
+            fold = (not kw.get("fused_whole")) and kw["fused_from"] == 1
+            if fold:
+                h.opt["fused_fold"] = True
+                try:
+                    h.step(simulate=False, collect_stats=True, W=W, H=H)
+                    fold = m.fused_clocks(slot=0)["mode"] == 2
+                finally:
+                    h.opt.pop("fused_fold", None)
+            kw["fused_fold"] = bool(fold)
         pose0 = torch.from_numpy(np.asarray(h.pose, np.float32)).unsqueeze(0)
         self.pose_dev = [pose0.to(dev) for _ in range(n_ws)]
         self.pose_pin = [pose0.clone().pin_memory() for _ in range(n_ws)]

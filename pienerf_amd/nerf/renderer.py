@@ -119,6 +119,7 @@ class NeRFRenderer(nn.Module):
         o.ray_tile_w = int(tw or 0)
         o.fused_from = int(kwargs.get("fused_from") or 0)  # extension: first loop trip of the one-launch form (pn_render_opts.fused_from; 0: trip 1, < 0: never)
         o.fused_grid = int(kwargs.get("fused_grid") or 0)  # extension: workgroups of that launch (pn_render_opts.fused_grid; 0: one per CU)
+        o.fused_fold = int(bool(kwargs.get("fused_fold")))  # extension: ... the first trip's network + composite + compaction folded in (pn_render_opts.fused_fold)
         o.fused_whole = int(bool(kwargs.get("fused_whole")))  # extension: ... the frame's first trip included, where it applies (pn_render_opts.fused_whole)
         return o
 
@@ -219,7 +220,8 @@ class NeRFRenderer(nn.Module):
                     waves=int(out[6]), lifetime_ticks=int(out[7]), max_rounds=int(out[8]), max_lifetime_ticks=int(out[9]), first_trip=int(first.value),
                     # whole-frame form (fused_from = 0): the first trip's one-lane march, its 64-lane windows, its network, its composite + hand-over,
                     # the wait at the workgroup barrier behind it
-                    a_march=int(out[10]), a_windows=int(out[11]), a_network=int(out[12]), a_composite=int(out[13]), a_barrier=int(out[14]))
+                    a_march=int(out[10]), a_windows=int(out[11]), a_network=int(out[12]), a_composite=int(out[13]), a_barrier=int(out[14]),
+                    mode=int(out[15]))   # 0: later trips only, 1: whole frame, 2: first trip's network / composite / compaction folded in
 
     def trip_records(self, slot=0, max_trips=16):
         """Diagnostics: [(n_alive, n_step, step_base, n_samples, n_emitted, n_tail)] per trip of the last render on `slot`."""

@@ -54,6 +54,13 @@ def test_fused_trips_equal_the_trip_by_trip_frame(deformed_ip_state, small_opt, 
     assert net.fused_clocks()["first_trip"] == 1 and dict(net.last_stats) == a[0] and net.trip_records(max_trips=140) == a[1]
     for k in ("image", "depth_0", "weights_sum"):
         assert torch.equal(out[k], a[2][k]), k
+    # the first trip's march as its own launches, its network / composite / compaction inside the fused launch (fused_fold): the same frame again, trip
+    # records included (the rays the first trip handed to the tail pass are counted by the march itself)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=fp16):
+        out = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **dict(opt, fused_from=0, fused_fold=True))
+    assert net.fused_clocks()["mode"] == 2 and dict(net.last_stats) == a[0] and net.trip_records(max_trips=140) == a[1]
+    for k in ("image", "depth_0", "weights_sum"):
+        assert torch.equal(out[k], a[2][k]), k
 
 
 @pytest.mark.parametrize("pose", [(5.0, 20.0, -15.0), (2.2, 75.0, -40.0), (9.0, -60.0, 5.0)])
@@ -82,14 +89,17 @@ def test_fused_launch_steps_aside_while_n_step_is_below_8(deformed_ip_state, sma
     assert a[0] == b[0] and a[1] == b[1]
     for k in ("image", "depth_0", "weights_sum"):
         assert torch.equal(a[2][k], b[2][k]), k
+    with torch.no_grad():   # ... and the folded first trip steps aside the same way: its march has run, the per-trip launches go on behind it
+        out = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **dict(opt, fused_from=0, fused_fold=True))
+    assert dict(net.last_stats) == a[0] and net.trip_records(max_trips=140) == a[1] and torch.equal(out["image"], a[2]["image"])
     # async: the fused launch finds too many rays with something to march (fused_whole: the whole frame) / n_step < 8 behind one per-trip trip and
     # leaves the frame as it is
-    for whole, trips_done in ((True, 0), (False, 1)):
+    for whole, fold, trips_done in ((True, False, 0), (False, False, 1), (False, True, 0)):
         with torch.no_grad():
-            out = net.render_deformed(T(o)[None], T(d)[None], async_trips=8, **dict(opt, fused_from=0, fused_whole=whole))
+            out = net.render_deformed(T(o)[None], T(d)[None], async_trips=8, **dict(opt, fused_from=0, fused_whole=whole, fused_fold=fold))
             st = net.render_status()
             assert st["alive_at_exit"] > 0 and st["trips"] == trips_done, st
-            net.render_continue(0, T(o)[None], T(d)[None], out, **dict(opt, fused_from=0, fused_whole=whole))
+            net.render_continue(0, T(o)[None], T(d)[None], out, **dict(opt, fused_from=0, fused_whole=whole, fused_fold=fold))
             assert net.last_stats["alive_at_exit"] == 0 and net.last_stats["samples"] == a[0]["samples"]
         assert torch.equal(out["image"], a[2]["image"]) and torch.equal(out["weights_sum"], a[2]["weights_sum"])
 
