@@ -194,7 +194,9 @@ def kernel_report(h, opt, dev, form_kw=None, graph_ms=None):
     st = dict(m.last_stats)
     st["hit_rays"] = int((~torch.isnan(out["depth"])).sum())  # rays that meet the bounding box of the deformed IPs (miss: near = far = FLT_MAX -> NaN depth)
     recs = m.trip_records(max_trips=140)
-    ff = m.fused_clocks()["first_trip"]                 # trip at which the fused launch took over (-1: trip-by-trip launches only)
+    fc0 = m.fused_clocks()
+    ff = fc0["first_trip"]                              # trip at which the fused launch took over (-1: trip-by-trip launches only)
+    folded = ff >= 1 and fc0.get("mode") == 2           # ... with the first trip's network / composite / compaction inside it (pn_render_opts.fused_fold)
     real = st["trips"]
     # (1) work counters of the march (separate passes: the counters add atomics): the whole frame, and its first trip alone
     m.march_counters(1)
@@ -283,7 +285,7 @@ def kernel_report(h, opt, dev, form_kw=None, graph_ms=None):
         cnt_f = {k: cnt[k] - head[k] for k in cnt}
         ray_trips_f = int(sum(r[0] for r in recs[max(ff, 1):])) if ff >= 1 else int(sum(r[0] for r in recs[1:])) + N
         bytes_f_march = march_bytes(cnt_f, ray_trips_f)
-        bytes_f_net = cnt_f["samples"] * bps
+        bytes_f_net = (cnt_f["samples"] + (head["samples"] if folded else 0)) * bps   # (folded: the first trip's samples go through the launch's network tiles too)
         t_f_alone = float(march_ms[ff]) if ff < n_timed else None
         t_f_graph = float(g_march[ff]) if g_march is not None and ff < len(g_march) else None
         t_f = t_f_graph or t_f_alone
@@ -304,6 +306,7 @@ def kernel_report(h, opt, dev, form_kw=None, graph_ms=None):
                             "blocking single-frame render, HIP events on the launch stream around the launch"),
             "launch_ms_alone": round(t_f_alone, 4) if t_f_alone else None, "frac_alone": round(gbs(bytes_f_march + bytes_f_net, t_f_alone) / HBM_PEAK_GBS, 4) if t_f_alone else None,
             "workgroups": int(h.opt.get("fused_grid") or 0) or "one per CU",
+            "first_trip_folded_in": bool(folded),
             "algorithmic_bytes_per_launch": int(bytes_f_march + bytes_f_net),
             "algorithmic_bytes": {"march": int(bytes_f_march), "network": int(bytes_f_net), "bytes_per_unit": dict(MARCH_BYTES, network_sample=bps)},
             "units_per_launch": dict(cnt_f, ray_trips=ray_trips_f),
@@ -388,7 +391,7 @@ def graph_stamps(make_harness, args):
         m_all.append(a)
         n_all.append(b)
     n = min(len(a) for a in m_all)
-    kw = {k: h._pipe_backend.kw.get(k) for k in ("fused_from", "fused_grid", "fused_whole", "march_throughput", "march_throughput_trips")}
+    kw = {k: h._pipe_backend.kw.get(k) for k in ("fused_from", "fused_grid", "fused_whole", "fused_fold", "march_throughput", "march_throughput_trips")}
     res = (np.median(np.array([a[:n] for a in m_all]), axis=0), np.median(np.array([b[:n] for b in n_all]), axis=0)), kw
     del h
     torch.cuda.empty_cache()
@@ -581,6 +584,7 @@ def main():
                       + ("" if staged else "alive list in 16 x 4 pixel tiles (pn_render_opts.ray_tile_w), ")
                       + (f"loop trips from trip {h._pipe_backend.kw.get('fused_from')} on as ONE persistent launch"
                          + (" (first trip included: fused_whole)" if h._pipe_backend.kw.get("fused_whole") else "")
+                         + (" with the first trip's network / composite / compaction inside it (fused_fold)" if h._pipe_backend.kw.get("fused_fold") else "")
                          + f" on {h._pipe_backend.kw.get('fused_grid') or 'all'} CUs (pn_render_opts.fused_from / fused_grid), " if (h._pipe_backend.kw.get("fused_from") or 0) >= 0 and not staged else "")
                       + "simulator running ahead, D2H on "
                       + {"copy": "a copy stream", "lane": "the frame's render stream", "sim": "the simulator stream", "host": "no stream (copier thread + SDMA through the HSA runtime)"}[args.copy_on]
@@ -646,7 +650,7 @@ def main():
     if rank == 0:
         del_h = h
         pipelined = world == 1 and not (args.eager or args.single_graph)
-        form_kw = {k: h._pipe_backend.kw.get(k) for k in ("fused_from", "fused_grid", "fused_whole", "march_throughput", "march_throughput_trips")} if hasattr(h, "_pipe_backend") else None
+        form_kw = {k: h._pipe_backend.kw.get(k) for k in ("fused_from", "fused_grid", "fused_whole", "fused_fold", "march_throughput", "march_throughput_trips")} if hasattr(h, "_pipe_backend") else None
         with torch.no_grad():
             graph_ms = None
             if pipelined:
