@@ -742,128 +742,6 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams 
     PN_PHASE_FLUSH(pk, a.stats, 0, lane);
 }
 
-// The one-lane-per-ray pass of a frame's first trip with LANE REFILL (round 4).  k_march<K, MULTI, 1> gives every wave 64 rays of the active list and runs
-// until the last of them is done or out of rounds: rays need 1 to 64+ rounds (mean 9), so 44 % of the lanes of a wave-round hold a ray
-// (profiles/r03_pmc_lpr_march_dispatches.txt) — and the waves hold their registers and LDS for all of it.  Here a workgroup owns a contiguous slice of its
-// segment of the active list and its lanes draw the next ray from an LDS cursor the round after theirs has ended: the same rays, the same per-ray budget
-// (`max_rounds` one-lane rounds, then the tail pass), the same arithmetic per ray (march_window<K, MULTI, 1>, one round per call) — a quarter of the waves
-// and of the wave-instructions.  Samples are listed through a per-wave LDS buffer and ONE returning atomic per wave (a returning atomic per round would cost
-// a third of the round).  Launch: PN_SEGS * workers workgroups; workgroup b serves segment b % PN_SEGS, slice b / PN_SEGS of it.
-#define PN_LPR_BUF 512   // listed sample slots a wave can hold before it has to flush
-template <int K, bool MULTI>
-__global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march_lpr(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
-    const uint32_t n_alive = (uint32_t)io.trip->n_alive, n_step_trip = (uint32_t)io.trip->n_step;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __shared__ float4 stage_mem[4][PN_STAGE_CAP];
-    __shared__ int sbuf[4][PN_LPR_BUF];
-    __shared__ int s_cursor;
-    float4* stage = stage_mem[wv];
-    int* buf = sbuf[wv];
-    const int seg = (int)(blockIdx.x % PN_SEGS), worker = (int)(blockIdx.x / PN_SEGS), workers = max((int)(gridDim.x / PN_SEGS), 1);
-    const int n_seg = seg_count(io.active_counts, seg);
-    const int per = (n_seg + workers - 1) / workers;
-    const int lo = min(worker * per, n_seg), hi = min(lo + per, n_seg);
-    if (threadIdx.x == 0) s_cursor = lo;
-    __syncthreads();
-    if (lo >= hi) return;
-    const int budget = io.max_rounds;
-    bool have = false;
-    uint32_t n = 0, n_step = n_step_trip, slot0 = 0;
-    int used = 0, n_buf = 0;
-    pnm3::RayConsts c;
-    pnm3::frame_consts(a, c);
-    c.ox = c.oy = c.oz = 0.f; c.dx = c.dy = c.dz = 1.f; c.rdx = c.rdy = c.rdz = 1.f; c.far = 0.f;
-    pnm3::RayState st{0.f, 0.f, 0u};
-    auto flush = [&]() __attribute__((always_inline)) {   // the wave's listed slots -> its segment of the trip's sample list
-        if (n_buf > 0) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(io.samp_counts + seg * PN_SEG_STRIDE, n_buf);
-            base = __builtin_amdgcn_readfirstlane(base);
-            int* seg_list = io.list_seg + (size_t)seg * io.list_seg_cap;
-            for (int i = lane; i < n_buf; i += 64) seg_list[base + i] = buf[i];
-            n_buf = 0;
-        }
-    };
-    for (;;) {
-        // lanes without a ray draw the next one of the workgroup's slice
-        const unsigned long long fm = __ballot(!have);
-        if (fm) {
-            int base = hi;
-            if (lane == 0 && __hip_atomic_load(&s_cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < hi) base = atomicAdd(&s_cursor, (int)__popcll(fm));
-            base = __builtin_amdgcn_readfirstlane(base);
-            const int e = base + (int)__popcll(fm & ((1ull << lane) - 1ull));
-            if (!have && e < hi) {
-                n = (uint32_t)io.active[(size_t)seg * io.active_seg_cap + e];
-                if (n < n_alive) {
-                    const int index = io.rays_alive[n];
-                    n_step = n_step_trip;
-                    ray_slots(io.groups, io.group_rays, index, n, n_step, slot0);
-                    pnm3::ray_consts(a, index, c);
-                    used = 0;
-                    if (pnm3::ray_start(a, c, index, io.noises ? io.noises[n] : 0.0f, io.t_resume ? io.t_resume + n : nullptr, st)) {
-                        have = true;
-                    } else {  // nothing to march: its slots end it in composite (delta == 0)
-                        float* dl0 = io.deltas + (size_t)slot0 * 2;
-                        for (uint32_t s2 = 0; s2 < n_step; s2++) { dl0[2 * s2] = 0.0f; dl0[2 * s2 + 1] = 0.0f; }
-                    }
-                }
-            }
-        }
-        if (!__any(have)) break;
-        float* const Xl = io.xyzs + (size_t)slot0 * 3;
-        float* const Dl = io.dirs + (size_t)slot0 * 3;
-        float* const dl = io.deltas + (size_t)slot0 * 2;
-        const bool done = pnm3::march_window<K, MULTI, 1>(a, tb, c, n_step, 0, lane, lane, stage, Xl, Dl, dl, st, 1, have);
-        used += have ? 1 : 0;
-        const bool fin = have && done;                       // the ray is done for this trip
-        const bool over = have && !done && used >= budget;   // out of one-lane rounds: the wave-per-ray tail pass goes on (it lists the ray's samples)
-        if (fin) {
-            const uint32_t emitted = st.step;
-            if (!PN_DBG_PHASES_ON && a.stats && emitted) atomicAdd(a.stats + 3, (unsigned long long)emitted);
-            for (uint32_t s2 = emitted; s2 < n_step; s2++) { dl[2 * s2] = 0.0f; dl[2 * s2 + 1] = 0.0f; }
-        }
-        // listed slots of the rays that ended this round: through the wave's LDS buffer
-        {
-            int inc = fin ? (int)st.step : 0;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int u = __shfl_up(inc, o);
-                if (lane >= o) inc += u;
-            }
-            const int total = __shfl(inc, 63);
-            if (total > 0) {
-                if (n_buf + total > PN_LPR_BUF) flush();
-                const int first = n_buf + inc - (fin ? (int)st.step : 0);
-                if (fin)
-                    for (uint32_t s2 = 0; s2 < st.step; s2++) buf[first + (int)s2] = (int)(slot0 + s2);
-                n_buf += total;
-            }
-        }
-        if (io.tail) {
-            const bool is_long = over && (c.far - st.t) > 192.0f * pnm3::dtf(a, c, st.t);
-            const unsigned long long dm = __ballot(over), lm = __ballot(is_long), sm = dm & ~lm;
-            if (dm) {
-                int posl = 0, poss = 0;
-                if (lane == 0 && lm) posl = atomicAdd(io.tail_counts + seg * PN_SEG_STRIDE, (int)__popcll(lm));
-                if (lane == 0 && sm) poss = atomicAdd(io.tail_back + seg * PN_SEG_STRIDE, (int)__popcll(sm));
-                posl = __shfl(posl, 0);
-                poss = __shfl(poss, 0);
-                if (over) {
-                    const unsigned long long below = (1ull << lane) - 1ull;
-                    const int slot = is_long ? posl + (int)__popcll(lm & below) : io.tail_seg_cap - 1 - (poss + (int)__popcll(sm & below));
-                    float4* te = reinterpret_cast<float4*>(io.tail + (size_t)seg * io.tail_seg_cap + slot);
-                    te[0] = make_float4(__int_as_float((int)n), st.t, st.last_t, __int_as_float((int)st.step));
-                    te[1] = make_float4(c.ox, c.oy, c.oz, c.dx);
-                    te[2] = make_float4(c.dy, c.dz, c.rdx, c.rdy);
-                    te[3] = make_float4(c.rdz, c.far, __int_as_float((int)slot0), __int_as_float((int)n_step));
-                }
-            }
-        }
-        have = have && !(fin || over);
-    }
-    flush();
-}
-
 // One wave per unfinished ray: windows of 64 sequence elements until the ray is done for this trip.
 template <int K, bool MULTI>
 __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march_tail(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
@@ -919,11 +797,7 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march_tail(pnm::MarchPa
 
 template <int K, bool MULTI>
 static void launch_march_km(uint32_t blocks, uint32_t tail_blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb, const MarchIO& io) {
-    // one lane per ray over the active list of a frame's first trip: the refill form (PN_LPR_REFILL=0: one chunk of 64 rays per wave, rounds 3-4)
-    static const uint32_t lpr_workers = pn_env_u32("PN_LPR_REFILL", 2);   // workgroups per segment of the active list (0: off)
-    if (io.lane_per_ray && io.active && io.trip && io.tail && lpr_workers > 0)
-        k_march_lpr<K, MULTI><<<PN_SEGS * std::min(lpr_workers, 16u), 256, 0, st>>>(a, tb, io);
-    else if (io.lane_per_ray) k_march<K, MULTI, 1><<<blocks, 256, 0, st>>>(a, tb, io);
+    if (io.lane_per_ray) k_march<K, MULTI, 1><<<blocks, 256, 0, st>>>(a, tb, io);
     else k_march<K, MULTI, 8><<<blocks, 256, 0, st>>>(a, tb, io);
     if (io.tail) k_march_tail<K, MULTI><<<tail_blocks, 256, 0, st>>>(a, tb, io);
 }
@@ -2355,6 +2229,8 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             fa.xyzs = f->xyzs; fa.dirs = f->dirs; fa.deltas = f->deltas; fa.sigmas = f->sigmas; fa.rgbs = f->rgbs;
             fa.ctl = f->fused_ctl; fa.dev = f->dev; fa.tail_diag = f->tail_counts + t;
             fa.clocks = (f->march_counters_on & 4) ? f->fused_clocks : nullptr;
+            static const uint32_t xcd_bands_env = pn_env_u32("PN_FUSED_BANDS", 0);
+            fa.xcd_bands = (int)xcd_bands_env;
             if (whole) {
                 fa.active = f->active_seg; fa.active_counts = seg_active; fa.active_seg_cap = (int)f->seg_cap; fa.t_resume = f->t_resume;
                 fa.blist = f->blist; fa.strag = f->strag; fa.blist_cap = f->blist_cap;
