@@ -2229,8 +2229,6 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             fa.xyzs = f->xyzs; fa.dirs = f->dirs; fa.deltas = f->deltas; fa.sigmas = f->sigmas; fa.rgbs = f->rgbs;
             fa.ctl = f->fused_ctl; fa.dev = f->dev; fa.tail_diag = f->tail_counts + t;
             fa.clocks = (f->march_counters_on & 4) ? f->fused_clocks : nullptr;
-            static const uint32_t xcd_bands_env = pn_env_u32("PN_FUSED_BANDS", 0);
-            fa.xcd_bands = (int)xcd_bands_env;
             if (whole) {
                 fa.active = f->active_seg; fa.active_counts = seg_active; fa.active_seg_cap = (int)f->seg_cap; fa.t_resume = f->t_resume;
                 fa.blist = f->blist; fa.strag = f->strag; fa.blist_cap = f->blist_cap;

@@ -72,7 +72,6 @@ struct FusedArgs {
     int4* strag;                 // [blist_cap] the first trip's rays still searching after the one-lane rounds
     uint32_t blist_cap;          // positions; the sample arrays hold gridDim * PN_FUSED_WAVES * 64 + blist_cap slots
     int a_rounds;                // one-lane rounds of the first trip before a ray goes to the 64-lane windows
-    int xcd_bands;               // WHOLE = false: deal the alive list to the XCDs in eight contiguous bands (see the hand-out)
     // FOLD (MODE 2): the first trip's segmented sample list and the march's tail counters
     const int* list_seg; const int* samp_counts; int list_seg_cap; const int* seg_tail; const int* seg_back;
 };
@@ -282,7 +281,6 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
     // reservation order; consumers claim below `ready` with a compare-and-swap.  Nothing waits for a consumer, so every reserved entry gets published and
     // every published entry taken: a wave only sleeps while another one is inside an item that can still produce work (s_pending: chunks without their A3).
     int share = 0;
-    int band_x = -1, band_local = 0, band_E = 0, band_per = 1;  // XCD bands (WHOLE = false, see below)
     const int* my_list = nullptr;
     int my_chunks = 0;
     int *a_index = nullptr, *blist = nullptr;
@@ -363,18 +361,8 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
         go_on = 1u < fa.max_steps;  // renderer.py:836: the loop ends when `step` (1 behind the first trip) reaches max_steps
     } else {
         const int n_packets = (A + 7) >> 3;
-        if (fa.xcd_bands && (gridDim.x & 7u) == 0u) {
-            // XCD-aware hand-out: workgroup b runs on XCD b % 8 (round-robin dispatch), and the alive list keeps the image's tile order, so the eighth
-            // x of the list is a band of the image: its packets go to the workgroups of XCD x, whose L2 then sees neighbouring rays' samples
-            const int per_x = (int)(gridDim.x >> 3), E = (n_packets + 7) >> 3;
-            band_x = (int)(blockIdx.x & 7u); band_local = (int)(blockIdx.x >> 3); band_E = E; band_per = per_x;
-            const int in_band = max(min(n_packets - band_x * E, E), 0);
-            const int my_packets = band_local < in_band ? (in_band - band_local + per_x - 1) / per_x : 0;
-            share = my_packets * 8;
-        } else {
-            const int my_packets = (int)blockIdx.x < n_packets ? (n_packets - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-            share = my_packets * 8;
-        }
+        const int my_packets = (int)blockIdx.x < n_packets ? (n_packets - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+        share = my_packets * 8;
     }
 
     if (WHOLE) {
@@ -493,8 +481,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (!QUEUED) pool_empty = base + need >= share;
                 const int p = base + my_rank;
-                const int gpos = QUEUED ? p : (band_x >= 0 ? (band_x * band_E + band_local + (p >> 3) * band_per) * 8 + (p & 7)
-                                                          : ((p >> 3) * (int)gridDim.x + (int)blockIdx.x) * 8 + (p & 7));
+                const int gpos = QUEUED ? p : ((p >> 3) * (int)gridDim.x + (int)blockIdx.x) * 8 + (p & 7);
                 if (index < 0 && (QUEUED ? my_rank < take : (p < share && gpos < A))) {
                     index = QUEUED ? my_list[gpos] : fa.alive[gpos];
                     j = QUEUED ? 1 : 0;
