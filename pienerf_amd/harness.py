@@ -517,7 +517,9 @@ class _HipBackend:
         if "fused_fold" not in kw:
             # pn_render_opts.fused_fold: the first trip's network, composite and compaction inside the fused launch (its march stays launches of its own): four
             # launches fewer on a lane's chain.  Where the blocking frame below finds it applicable (at most N / 8 rays with a sample on the first trip)
-            fold = (not kw.get("fused_whole")) and kw["fused_from"] == 1
+            # (measured on the chair, alternating runs on one box: three lanes 1 960 against 1 925 steps/s, --steps 20: 1 801 against 1 790; one frame at a
+            # time the launch with the first trip's tiles in front of its rounds is longer than what it replaces, 0.884 against 0.859 ms per step)
+            fold = lanes >= 3 and (not kw.get("fused_whole")) and kw["fused_from"] == 1
             if fold:
                 h.opt["fused_fold"] = True
                 try:
