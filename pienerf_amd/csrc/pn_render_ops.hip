@@ -1764,6 +1764,8 @@ struct FramePrologue {
     int* tail_counts; int* seg_counters; int n_trip_records; int* alive; float* weights_sum; float* depth_0; float* image; PnGroup* groups;
     int* group_cnt; uint32_t group_rays; uint32_t n_groups; int* chunk_words;
     uint32_t tile_w, tile_lw;  // tile_w > 0: alive list starts in 16 x 4 pixel tile order (pn_render_opts.ray_tile_w, validated by the host)
+    // early_finish: the frame's epilogue is left to the fused launch (pn_trips_fused.h: finalize) — every ray gets the pixel of a ray without samples here
+    int early_finish; float bg; float* image_out; float* depth_out;
 };
 
 __device__ __forceinline__ void frame_lists_block(const FramePrologue& a) {
@@ -1878,6 +1880,9 @@ __device__ __forceinline__ void frame_rays_block(const FramePrologue& a, uint32_
     }
     if (block == 0)
         for (int t = threadIdx.x; t < 6 * PN_SEGS; t += blockDim.x) a.seg_counters[t * PN_SEG_STRIDE] = 0;
+    if (block == 0 && threadIdx.x == 0 && a.early_finish) {  // the frame's books until the fused launch closes them (if it steps aside: an unfinished frame at trip 0)
+        a.dev->trips_run = 0; a.dev->fused_trips = 0; a.dev->stat_trips = 0; a.dev->stat_samples = 0; a.dev->alive_at_exit = (int)a.N;
+    }
     if (threadIdx.x == 0) a.chunk_words[block] = 0;  // one (tag, count) word per 256 rays (+ the spare ones by the last workgroup), see k_composite_compact
     if (threadIdx.x < 2 && block + 1 == gridDim.x - (uint32_t)(a.list_blocks + a.pack_blocks)) a.chunk_words[block + 1 + threadIdx.x] = 0;
     if (n >= a.N) return;
@@ -1917,6 +1922,11 @@ __device__ __forceinline__ void frame_rays_block(const FramePrologue& a, uint32_
     a.weights_sum[n] = 0.f;
     a.depth_0[n] = 0.f;
     a.image[n * 3] = 0.f; a.image[n * 3 + 1] = 0.f; a.image[n * 3 + 2] = 0.f;
+    if (a.early_finish) {  // k_frame_finish's expressions for weights_sum = depth_0 = acc = 0 (renderer.py:896-899)
+        const float k = (1 - 0.f) * a.bg;
+        a.image_out[n * 3] = 0.f + k; a.image_out[n * 3 + 1] = 0.f + k; a.image_out[n * 3 + 2] = 0.f + k;
+        a.depth_out[n] = fmaxf(0.f - near, 0.0f) / (far - near);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_frame_prologue(FramePrologue a) {
@@ -2072,6 +2082,18 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     PN_REQUIRE(n_groups <= f->max_groups);
     PN_REQUIRE(!resume || group_rays == f->last_group_rays);
 
+    // forms of the fused launch that take the frame from its first trip on (see the trip loop below) also write its epilogue: decided here, before the prologue
+    static const bool fused_env0 = [] { const char* v = getenv("PN_FUSED"); return !(v && v[0] == '0'); }();
+    static const int whole_env0 = [] { const char* v = getenv("PN_FUSED_WHOLE"); return !v ? -1 : (v[0] == '0' ? 0 : 1); }();
+    static const int fold_env0 = [] { const char* v = getenv("PN_FUSED_FOLD"); return !v ? -1 : (v[0] == '0' ? 0 : 1); }();
+    // Measured on the chair, alternating runs on one box (profiles/r04_early_finish_ab.txt): with the whole-frame launch (two lanes) 1 719 against 1 601
+    // steps/s; with the folded first trip (three lanes) 1 983 / 1 950 against 2 002 / 1 981 — there the dying rays' extra loads inside the launch cost what
+    // the launch off the chain saves.  So: the whole-frame form only.  PN_EARLY_FINISH=0: never; 2: with the folded first trip too (A/B)
+    static const uint32_t early_env = pn_env_u32("PN_EARLY_FINISH", 1);
+    const bool fused_ok0 = fused_env0 && !is_static && !group_rays && o->fused_from >= 0 && o->max_steps <= 8u * PN_FUSED_MAX_TRIPS;
+    const bool want_whole = fused_ok0 && (whole_env0 < 0 ? o->fused_whole != 0 : whole_env0 != 0) && o->fused_from == 0 && !resume;
+    const bool want_fold = fused_ok0 && !want_whole && (fold_env0 < 0 ? o->fused_fold != 0 : fold_env0 != 0) && o->fused_from <= 1 && !resume;
+    const bool early_finish = early_env != 0 && (want_whole || (want_fold && early_env >= 2));
     const float* bbmin = f->dev->aabb;  // device addresses of struct members
     const float* bbmax = f->dev->aabb + 3;
     const int* res = f->dev->resolution;
@@ -2119,6 +2141,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     fp.trips = f->trips; fp.tail_counts = f->tail_counts; fp.seg_counters = f->seg_counters; fp.n_trip_records = PN_MAX_TRIPS + 2; fp.alive = f->alive_a;
     fp.weights_sum = weights_sum; fp.depth_0 = depth_0; fp.image = f->acc_image; fp.groups = group_rays ? f->groups : nullptr; fp.group_cnt = f->group_cnt;
     fp.group_rays = group_rays; fp.n_groups = n_groups; fp.chunk_words = f->chunk_counts;
+    fp.early_finish = early_finish ? 1 : 0; fp.bg = o->bg_color; fp.image_out = image; fp.depth_out = depth;
     {   // pn_render_opts.ray_tile_w; PN_RAY_TILE_OFF=1 keeps the row-major order (A/B runs: same frames, bit for bit)
         static const bool tile_off = pn_env_u32("PN_RAY_TILE_OFF", 0) != 0;
         static const uint32_t lw = std::min(pn_env_u32("PN_RAY_TILE_LOG2W", 4), 5u);  // experiments: 8 x 8 (3), 32 x 2 (5) pixel tiles
@@ -2156,15 +2179,14 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     // device that at most N / 8 rays have anything to march (then every trip after the first marches 8 samples per ray whatever the first one finds) and
     // does nothing otherwise — the blocking driver then goes on trip by trip as above, a fixed-trip render is left to pn_render_continue.
     // PN_FUSED_WHOLE=0 / 1: never / wherever fused_from == 0 allows it (A/B runs).
-    static const int whole_env = [] { const char* v = getenv("PN_FUSED_WHOLE"); return !v ? -1 : (v[0] == '0' ? 0 : 1); }();
     static const uint32_t a_rounds_env = pn_env_u32("PN_FUSED_AROUNDS", 0);
-    bool whole_try = fused_ok && (whole_env < 0 ? o->fused_whole != 0 : whole_env != 0) && o->fused_from == 0 && !resume && t == 0;
+    bool whole_try = want_whole && t == 0;
     // ... or the first trip's NETWORK, COMPOSITE and COMPACTION inside that launch (pn_render_opts.fused_fold with fused_from <= 1; pn_trips_fused.h, FOLD): the
     // march of the first trip stays what it is — skip pre-pass, one lane per ray / windows, tail pass, on every CU — and leaves the trip's segmented sample list;
     // the launch runs network tiles over it, composites, and takes the survivors on.  Four launches fewer on a frame's chain (k_list_pack, k_nerf_forward,
     // k_composite, k_compact).  Applies when at most N / 8 rays found a sample (checked on the device); otherwise as with fused_whole.  PN_FUSED_FOLD=0 / 1: A/B.
-    static const int fold_env = [] { const char* v = getenv("PN_FUSED_FOLD"); return !v ? -1 : (v[0] == '0' ? 0 : 1); }();
-    bool fold_try = fused_ok && (fold_env < 0 ? o->fused_fold != 0 : fold_env != 0) && o->fused_from <= 1 && !resume && t == 0;
+    bool fold_try = want_fold && t == 0;
+    bool finished_in_launch = false;   // the frame's epilogue was written by the fused launch (early_finish)
     bool skip_done = resume && f->skip_done != 0;
     bool head_marched = resume && f->head_marched != 0 && t == 0;   // the first trip's march has run: its per-trip launches go on behind it
     if (!resume) { f->skip_done = 0; f->head_marched = 0; }
@@ -2238,6 +2260,9 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                 fa.list_seg = f->list_seg; fa.samp_counts = seg_samp; fa.list_seg_cap = (int)f->seg_cap; fa.seg_tail = seg_tail; fa.seg_back = seg_back;
                 fa.blist = f->blist; fa.strag = f->strag; fa.blist_cap = f->blist_cap;
             }
+            if ((whole || fold) && early_finish) {
+                fa.finalize = 1; fa.bg = o->bg_color; fa.nears = f->nears; fa.fars_full = f->fars; fa.image_out = image; fa.depth_out = depth;
+            }
             const int tb_idx = fold ? 1 : t;   // launch group the fused launch is timed as (fold: behind the first trip's march)
             pnm::MarchParams mq = mp;
             if (short_rays) mq.fars = f->fars_eff;  // written by trip 0's k_march_skip
@@ -2254,11 +2279,20 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             if ((rc = time_mark(tb_idx, 1)) || (rc = time_mark(tb_idx, 2))) return rc;
             f->fused_first = tb_idx;
             f->fused_mode = whole ? 1 : (fold ? 2 : 0);
-            if (async_trips > 0) { add_fused = 1; break; }  // how many trips it ran only the device knows: k_frame_finish adds them
+            if (async_trips > 0) {  // how many trips it ran only the device knows: k_frame_finish adds them — or the launch itself closed the frame's books
+                add_fused = 1;
+                finished_in_launch = fa.finalize != 0;   // (if it steps aside the frame is an unfinished one at trip 0: pn_render_continue)
+                break;
+            }
             PN_HIP_CHECK(hipMemcpyAsync(f->dev_pinned, f->dev, sizeof(PnFrameDev), hipMemcpyDeviceToHost, st));
             PN_HIP_CHECK(hipMemcpyAsync(f->trips_pinned + t, f->trips + t, sizeof(PnTrip), hipMemcpyDeviceToHost, st));
             PN_HIP_CHECK(hipStreamSynchronize(st));
-            if (f->dev_pinned->fused_trips > 0) { t += f->dev_pinned->fused_trips; done = true; break; }  // ran until no ray was alive (or max_steps)
+            if (f->dev_pinned->fused_trips > 0) {  // ran until no ray was alive (or max_steps)
+                t += f->dev_pinned->fused_trips;
+                done = true;
+                finished_in_launch = fa.finalize != 0;
+                break;
+            }
             if (f->trips_pinned[t].n_alive <= 0) { done = true; break; }
             // not applicable at this trip (more than N / 8 rays alive: n_step < 8): one trip of the per-trip launches, then again
             f->fused_first = -1;
@@ -2350,7 +2384,8 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
         PN_HIP_CHECK(hipStreamSynchronize(st));
         done = f->trips_pinned[t].n_alive <= 0;
     }
-    k_frame_finish<<<nblk, 256, 0, st>>>(N, o->bg_color, f->nears, f->fars, weights_sum, depth_0, f->acc_image, image, depth, f->trips, f->dev, t, add_fused);
+    if (!finished_in_launch)
+        k_frame_finish<<<nblk, 256, 0, st>>>(N, o->bg_color, f->nears, f->fars, weights_sum, depth_0, f->acc_image, image, depth, f->trips, f->dev, t, add_fused);
     PN_LAUNCH_CHECK();
     f->last_trips = t;
     f->last_N = N;

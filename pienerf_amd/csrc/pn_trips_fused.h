@@ -72,6 +72,9 @@ struct FusedArgs {
     int4* strag;                 // [blist_cap] the first trip's rays still searching after the one-lane rounds
     uint32_t blist_cap;          // positions; the sample arrays hold gridDim * PN_FUSED_WAVES * 64 + blist_cap slots
     int a_rounds;                // one-lane rounds of the first trip before a ray goes to the 64-lane windows
+    // the frame's epilogue inside the launch (QUEUED modes, `finalize` != 0): a ray's pixel is final when the ray leaves the launch, written there as k_frame_finish
+    // would (renderer.py:896-899); the rays that never had a sample got theirs from the frame prologue
+    int finalize; float bg; const float* nears; const float* fars_full; float* image_out; float* depth_out;
     // FOLD (MODE 2): the first trip's segmented sample list and the march's tail counters
     const int* list_seg; const int* samp_counts; int list_seg_cap; const int* seg_tail; const int* seg_back;
 };
@@ -130,6 +133,16 @@ __device__ __forceinline__ bool composite_slots8(int index, uint32_t slot0, floa
 }
 
 __device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// image = acc + (1 - weights_sum) * bg ; depth = clamp(depth - nears, 0) / (fars - nears) (renderer.py:896-899; k_frame_finish, expression by expression) for
+// ONE ray whose composite has just been written by this lane
+__device__ __forceinline__ void finalize_ray(const FusedArgs& fa, int index) {
+    const float k = (1 - fa.weights_sum[index]) * fa.bg;
+    fa.image_out[index * 3] = fa.image[index * 3] + k;
+    fa.image_out[index * 3 + 1] = fa.image[index * 3 + 1] + k;
+    fa.image_out[index * 3 + 2] = fa.image[index * 3 + 2] + k;
+    fa.depth_out[index] = fmaxf(fa.depth[index] - fa.nears[index], 0.0f) / (fa.fars_full[index] - fa.nears[index]);
+}
 
 #define PN_FUSED_MAXCHUNKS 96  // first-trip chunks per workgroup (a counter each in LDS)
 #ifndef PN_FUSED_ACHUNK
@@ -327,6 +340,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
             if (has && half == 0) {
                 idx = a_index[pos];
                 on = composite_one(idx, slot, 1u, fa.T_thresh, fa.rays_t, fa.sigmas, fa.rgbs, fa.deltas, fa.weights_sum, fa.depth, fa.image) && go_on;
+                if (!on && fa.finalize) finalize_ray(fa, idx);
             }
             const unsigned long long om = __ballot(on);
             wave_sync_mem();  // the composite's stores (rays_t: read by the wave that takes the ray on) before the ray is published
@@ -600,6 +614,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
             if (f_has && half == 0) {
                 idx = fa.alive[f_slot];   // n_step == 1: a ray's sample slot is its position in the alive list
                 on = composite_one(idx, f_slot, 1u, fa.T_thresh, fa.rays_t, fa.sigmas, fa.rgbs, fa.deltas, fa.weights_sum, fa.depth, fa.image) && go_on;
+                if (!on && fa.finalize) finalize_ray(fa, idx);
             }
             const unsigned long long om = __ballot(on);
             wave_sync_mem();
@@ -624,7 +639,10 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
         if (have_ray) {
             // renderer.py:836: the loop ends when `step` reaches max_steps, whatever is still alive
             if (alive && (uint32_t)(sb0 + 8 * (j + (QUEUED ? 0 : 1))) < fa.max_steps && j + 1 < MAXT) j++;
-            else index = -1;
+            else {
+                if (QUEUED && fa.finalize && sub == 0) finalize_ray(fa, index);   // the ray leaves the launch: its pixel is final
+                index = -1;
+            }
         }
         tick(4);
     }
@@ -654,6 +672,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
     __syncthreads();
     if (!s_last || threadIdx.x >= 64) return;
     int m = 0;
+    long long n_samples_total = 0;   // what pn_render_status reports: samples listed on the first trip + emitted on the later ones
     for (int j0 = 0; j0 < MAXT; j0 += 64) {
         const int jj = j0 + lane;
         int* hp = fa.ctl + PN_FUSED_CTL_HIST + jj;
@@ -662,6 +681,12 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
         const int tl = __hip_atomic_load(hp + 2 * MAXT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (QUEUED && jj == 0) al = (int)fa.N_rays;  // the first trip: every ray (its record was written by the frame prologue)
         m += (int)__popcll(__ballot(al > 0));
+        {
+            long long e2 = al > 0 ? (long long)em : 0ll;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o);
+            n_samples_total += e2;
+        }
         if (al > 0) {
             PnTrip* r = fa.trips + jj;
             if (jj > 0) { r->n_alive = al; r->n_step = 8; r->step_base = sb0 + 8 * (jj - (QUEUED ? 1 : 0)); r->dense = 1; r->n_samples = al * 8; }
@@ -683,6 +708,12 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
         PnTrip* r = fa.trips + m;  // the record behind the last trip that had rays: the frame is over
         r->n_alive = 0; r->n_step = 1; r->step_base = QUEUED ? (m == 0 ? 0 : 1 + 8 * (m - 1)) : sb0 + 8 * m; r->dense = 0; r->n_samples = 0; r->n_emitted = 0;
         fa.dev->fused_trips = m;
+        if (QUEUED && fa.finalize) {   // the frame's books, as k_frame_finish closes them (the launch started at trip 0 and ran until no ray was left)
+            fa.dev->trips_run = min(m, PN_MAX_TRIPS);   // (fused_trips stays: the blocking driver reads it; the next frame's prologue clears it)
+            fa.dev->stat_trips = m;
+            fa.dev->stat_samples = n_samples_total;
+            fa.dev->alive_at_exit = 0;
+        }
         __hip_atomic_store(fa.ctl + PN_FUSED_CTL_DONE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
