@@ -76,8 +76,16 @@ struct pn_net {
     void* emb_half;           // device, owned: embeddings rounded to fp16 (RNE), [n_entries, 2] halves
     void* whalf;              // device, owned: the fp16 kernel's LDS weight image, PN_NET_HALF_BYTES
     // staging for in-place weight refreshes (pn_net_update): pinned host images + the event of the last upload that read them
-    void* stage;              // host pinned, PN_NET_SPLIT_BYTES + PN_NET_HALF_BYTES
+    void* stage;              // host pinned, PN_NET_SPLIT_BYTES + PN_NET_HALF_BYTES + PN_NET_X_BYTES
     hipEvent_t stage_done;
+    // fp16 hi/lo form of the fp32 network (round 4): every fp32 value as two fp16 pieces x = hi + lo (11 + 11 significant bits, round to nearest), a product as
+    // hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with the fp32 accumulator — three products instead of the six of the three-way bf16 split, five vector
+    // instructions per pair of split values instead of eleven; 2^-22 relative per value against the bf16 split's 2^-24.  fp16 holds 2^-24 .. 65504: the hash
+    // features are scaled by a power of two into [2^13, 2^14) (x_scale, taken out again behind the first layer) and the form is only chosen when the layers'
+    // worst-case outputs stay below 60 000 (interval bound over the weights and the tables' largest entry: x_ok); otherwise the bf16 split.
+    void* wx;                 // device, owned: the fp16 hi/lo LDS weight image, PN_NET_X_BYTES
+    int x_ok;                 // the fp32 network runs in the fp16 hi/lo form (PN_NET_FORM=bf16 forces 0)
+    float x_scale, x_rscale;  // feature scale 2^k and its reciprocal
 };
 
 // weight image: [20 MFMA operand groups][3 bf16 pieces hi/mid/lo][64 lanes][8 bf16], then the VALU output layer's 192 fp32 weights
@@ -87,6 +95,9 @@ struct pn_net {
 // fp16 weight image: [20 operand groups][64 lanes][8 fp16], then the output layer's 192 weights (fp16-rounded, stored as fp32)
 #define PN_NET_HALF_W_BYTES (PN_NET_GROUPS * 64 * 16)
 #define PN_NET_HALF_BYTES (PN_NET_HALF_W_BYTES + 192 * 4)
+// fp16 hi/lo weight image: [20 operand groups][hi, lo][64 lanes][8 fp16], then the output layer's 192 fp32 weights
+#define PN_NET_X_W_BYTES (PN_NET_GROUPS * 2 * 64 * 16)
+#define PN_NET_X_BYTES (PN_NET_X_W_BYTES + 192 * 4)
 
 // internal launcher shared by pn_nerf_forward and the frame driver: evaluates the network on the `count` samples whose
 // slot ids are list[0..count) (list == NULL: slots 0..M-1); when ctl_count != NULL the count is read from device memory.

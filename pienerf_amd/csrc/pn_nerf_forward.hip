@@ -273,18 +273,26 @@ static float pn_h2f(uint16_t h) {
 //     (truncation splits: exact, 8 + 8 + 8 significant bits); then the 64 -> 3 layer's fp32 weights for the vector ALU
 //     (wlast[h][q][o] = W4[o][krow(q, h)], q = tile*16 + register index of the D layout; an MFMA tile would be 29/32 row padding).
 //   himg (PN_NET_HALF_BYTES): the same groups with every weight rounded once to fp16 (autocast's `weight.to(half)`), one piece.
+//   ximg (PN_NET_X_BYTES): the same groups with every weight as two fp16 pieces w = hi + lo (round to nearest even both), then the 64 -> 3 layer's fp32 weights.
 static void build_weight_images(const float* W0, const float* W1, const float* W2, const float* W3, const float* W4, unsigned char* simg,
-                                unsigned char* himg) {
+                                unsigned char* himg, unsigned char* ximg) {
     float* host = new float[160 * 64];
     pack_weights(W0, W1, W2, W3, host);
     uint16_t* s16 = reinterpret_cast<uint16_t*>(simg);
     uint16_t* h16 = reinterpret_cast<uint16_t*>(himg);
+    uint16_t* x16 = reinterpret_cast<uint16_t*>(ximg);
     int G = 0;
     auto emit = [&](int m0) {
         for (int l = 0; l < 64; l++)
             for (int e2 = 0; e2 < 8; e2++) {
                 float v = host[(m0 + e2) * 64 + l];
                 h16[((size_t)G * 64 + l) * 8 + e2] = pn_f2h_bits(v);
+                {
+                    const uint16_t xh = pn_f2h_bits(v);
+                    const float r = v - pn_h2f(xh);   // exact: the remainder of a round-to-nearest fp16 has at most 13 significant bits
+                    x16[((size_t)(G * 2 + 0) * 64 + l) * 8 + e2] = xh;
+                    x16[((size_t)(G * 2 + 1) * 64 + l) * 8 + e2] = pn_f2h_bits(r);
+                }
                 for (int p = 0; p < 3; p++) {
                     uint32_t u;
                     memcpy(&u, &v, 4);
@@ -303,12 +311,14 @@ static void build_weight_images(const float* W0, const float* W1, const float* W
     for (int t = 0; t < 2; t++) for (int kc = 0; kc < 4; kc++) emit(96 + t * 32 + 8 * kc);   // layer 3: groups 12..19
     float* wlast = reinterpret_cast<float*>(simg + PN_NET_SPLIT_W_BYTES);
     float* wlast_h = reinterpret_cast<float*>(himg + PN_NET_HALF_W_BYTES);
+    float* wlast_x = reinterpret_cast<float*>(ximg + PN_NET_X_W_BYTES);
     for (int h = 0; h < 2; h++)
         for (int q = 0; q < 32; q++)
             for (int o = 0; o < 3; o++) {
                 const int t = q >> 4, r = q & 15;
                 const float w = W4[o * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
                 wlast[(h * 32 + q) * 3 + o] = w;
+                wlast_x[(h * 32 + q) * 3 + o] = w;
                 wlast_h[(h * 32 + q) * 3 + o] = pn_h2f(pn_f2h_bits(w));
             }
     delete[] host;
@@ -321,14 +331,69 @@ static int net_fail(pn_net* n, hipError_t e, const char* what) {
 }
 
 // stages both images in pinned memory and uploads them behind whatever `stream` holds; no allocation, no stream synchronisation
+// largest |entry| of the hash tables (bit pattern of a non-negative float orders like the float)
+__global__ void __launch_bounds__(256) k_table_absmax(const float* __restrict__ emb, uint32_t n, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (uint32_t i = threadIdx.x + blockIdx.x * blockDim.x; i < n; i += gridDim.x * blockDim.x) {
+        const float v = fabsf(emb[i]);
+        m = max(m, v == v ? __float_as_uint(v) : 0x7f800000u);   // NaN counts as infinite
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// Whether the fp16 hi/lo form is safe for these weights and tables (pn_common.h: pn_net::x_ok), and the features' scale.  Interval bound, layer by layer:
+// |out_i| <= sum_j |W_ij| max|in|; ReLU and the SH basis (|Y| < 4 up to degree 4 on unit directions) cannot raise it.  Every value that is split into
+// fp16 pieces — scaled features, the hidden activations, the geometry features — must stay below 60 000.
+static void net_choose_form(pn_net* n, const float* W0, const float* W1, const float* W2, const float* W3, float table_max) {
+    auto row_bound = [](const float* W, int rows, int cols, double in_max) {
+        double worst = 0.0;
+        for (int i = 0; i < rows; i++) {
+            double s2 = 0.0;
+            for (int j = 0; j < cols; j++) s2 += fabs((double)W[i * cols + j]);
+            worst = std::max(worst, s2 * in_max);
+        }
+        return worst;
+    };
+    n->x_ok = 0;
+    n->x_scale = n->x_rscale = 1.0f;
+    const char* form = getenv("PN_NET_FORM");   // "bf16": always the three-way bf16 split (A/B runs, tests)
+    if (form && strcmp(form, "bf16") == 0) return;
+    if (!(table_max > 0.0f) || !std::isfinite(table_max)) return;
+    int k = (int)floor(log2(16384.0 / (double)table_max));   // features * 2^k in [2^13, 2^14]
+    k = std::min(std::max(k, -14), 60);
+    const double b0 = row_bound(W0, 64, 32, (double)table_max);           // sigma layer 0 -> hidden
+    const double b1 = row_bound(W1, 16, 64, b0);                          // sigma layer 1 -> sigma logit + geometry features
+    const double b2 = row_bound(W2, 64, 31, std::max(b1, 4.0));           // colour layer 0 on [SH16 | geo15]
+    const double b3 = row_bound(W3, 64, 64, b2);                          // colour layer 1 (its outputs go to the fp32 vector layer: no fp16 piece)
+    (void)b3;
+    if (!(b0 < 6.0e4 && b1 < 6.0e4 && b2 < 6.0e4)) return;
+    n->x_ok = 1;
+    n->x_scale = (float)ldexp(1.0, k);
+    n->x_rscale = (float)ldexp(1.0, -k);
+}
+
 static int net_upload_weights(pn_net* n, const float* W0, const float* W1, const float* W2, const float* W3, const float* W4, hipStream_t st) {
     PN_HIP_CHECK(hipEventSynchronize(n->stage_done));  // the previous upload has finished reading the staging buffer (normally long ago)
     unsigned char* simg = reinterpret_cast<unsigned char*>(n->stage);
     unsigned char* himg = simg + PN_NET_SPLIT_BYTES;
-    build_weight_images(W0, W1, W2, W3, W4, simg, himg);
+    unsigned char* ximg = himg + PN_NET_HALF_BYTES;
+    build_weight_images(W0, W1, W2, W3, W4, simg, himg, ximg);
     PN_HIP_CHECK(hipMemcpyAsync(n->wsplit, simg, PN_NET_SPLIT_BYTES, hipMemcpyHostToDevice, st));
     PN_HIP_CHECK(hipMemcpyAsync(n->whalf, himg, PN_NET_HALF_BYTES, hipMemcpyHostToDevice, st));
+    PN_HIP_CHECK(hipMemcpyAsync(n->wx, ximg, PN_NET_X_BYTES, hipMemcpyHostToDevice, st));
     PN_HIP_CHECK(hipEventRecord(n->stage_done, st));
+    // the tables' largest entry (one small reduction + a 4-byte read-back: this function already waits for the host's packing) -> the form of the fp32 network
+    unsigned* d_max = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(n->wx) + PN_NET_X_BYTES);
+    PN_HIP_CHECK(hipMemsetAsync(d_max, 0, 4, st));
+    k_table_absmax<<<512, 256, 0, st>>>(n->embeddings, n->n_entries * 2u, d_max);
+    unsigned bits = 0;
+    PN_HIP_CHECK(hipMemcpyAsync(&bits, d_max, 4, hipMemcpyDeviceToHost, st));
+    PN_HIP_CHECK(hipStreamSynchronize(st));
+    float table_max;
+    memcpy(&table_max, &bits, 4);
+    net_choose_form(n, W0, W1, W2, W3, table_max);
     return PN_OK;
 }
 
@@ -363,8 +428,9 @@ extern "C" int pn_net_create(pn_net** out, const float* embeddings, const int* o
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMalloc((void**)&n->wsplit, PN_NET_SPLIT_BYTES);
     if (e == hipSuccess) e = hipMalloc((void**)&n->whalf, PN_NET_HALF_BYTES);
+    if (e == hipSuccess) e = hipMalloc((void**)&n->wx, PN_NET_X_BYTES + 16);   // (+ the tables' abs-max word of net_upload_weights)
     if (e == hipSuccess) e = hipMalloc((void**)&n->fused_levels, sizeof(fl));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&n->stage, PN_NET_SPLIT_BYTES + PN_NET_HALF_BYTES);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&n->stage, PN_NET_SPLIT_BYTES + PN_NET_HALF_BYTES + PN_NET_X_BYTES);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&n->stage_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventRecord(n->stage_done, st);
     if (e == hipSuccess) e = hipMemcpyAsync(n->fused_levels, fl, sizeof(fl), hipMemcpyHostToDevice, st);
@@ -398,6 +464,8 @@ extern "C" int pn_net_update(pn_net* n, const float* embeddings, const float* W0
     return PN_OK;
 }
 
+extern "C" int pn_net_form(const pn_net* n) { return (n && n->x_ok) ? 2 : 0; }
+
 extern "C" int pn_net_enable_half(pn_net* n, void* stream) {
     PN_REQUIRE(n);
     if (n->emb_half) return PN_OK;
@@ -418,6 +486,7 @@ extern "C" void pn_net_destroy(pn_net* n) {
     if (!n) return;
     if (n->wsplit) (void)hipFree(n->wsplit);
     if (n->whalf) (void)hipFree(n->whalf);
+    if (n->wx) (void)hipFree(n->wx);
     if (n->emb_half) (void)hipFree(n->emb_half);
     if (n->fused_levels) (void)hipFree(n->fused_levels);
     if (n->stage) (void)hipHostFree(n->stage);
@@ -434,26 +503,28 @@ extern "C" void pn_net_destroy(pn_net* n) {
 #ifndef PN_BF_WAVES
 #define PN_BF_WAVES 8
 #endif
-template <int MINW, int LU>
+// X: the fp16 hi/lo form of the dense layers (pn_common.h: pn_net::wx; `wsplit` is then that image, sf / rsf the features' scale and its reciprocal)
+template <int MINW, int LU, bool X = false>
 __global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const PnFusedLevel* __restrict__ lv, const float* __restrict__ emb,
                                                                           const uint4* __restrict__ wsplit, float bound, const float* __restrict__ xyzs,
                                                                           const float* __restrict__ dirs, const int* __restrict__ list,
                                                                           const int* __restrict__ count_dev, uint32_t M_arg, float density_scale,
                                                                           float* __restrict__ sigmas, float* __restrict__ rgbs,
-                                                                          float* __restrict__ geo, int sigma_only) {
-    extern __shared__ __attribute__((aligned(16))) uint4 wimg[];  // PN_NET_SPLIT_BYTES
+                                                                          float* __restrict__ geo, int sigma_only, float sf = 1.0f, float rsf = 1.0f) {
+    extern __shared__ __attribute__((aligned(16))) uint4 wimg[];  // the weight image, then the 16 level records
+    constexpr int PN_IMG_BYTES = X ? PN_NET_X_BYTES : PN_NET_SPLIT_BYTES;
     const uint32_t M = count_dev ? (uint32_t)*count_dev : M_arg;
     const uint32_t n_tiles = (M + 31) / 32;
     const uint32_t waves_total = gridDim.x * PN_BF_WAVES;
     const uint32_t wave = blockIdx.x * PN_BF_WAVES + (threadIdx.x >> 6);
     if (blockIdx.x * PN_BF_WAVES >= n_tiles) return;  // no tile for any wave of this block
-    for (int i = threadIdx.x; i < PN_NET_SPLIT_BYTES / 16; i += PN_BF_WAVES * 64) wimg[i] = wsplit[i];
-    if (threadIdx.x < 16 * sizeof(PnFusedLevel) / 16) wimg[PN_NET_SPLIT_BYTES / 16 + threadIdx.x] = reinterpret_cast<const uint4*>(lv)[threadIdx.x];
+    for (int i = threadIdx.x; i < PN_IMG_BYTES / 16; i += PN_BF_WAVES * 64) wimg[i] = wsplit[i];
+    if (threadIdx.x < 16 * sizeof(PnFusedLevel) / 16) wimg[PN_IMG_BYTES / 16 + threadIdx.x] = reinterpret_cast<const uint4*>(lv)[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int s = lane & 31, half = lane >> 5;
     const uint4* __restrict__ wl = wimg + lane;
-    const PnFusedLevel* lds_lv = reinterpret_cast<const PnFusedLevel*>(wimg + PN_NET_SPLIT_BYTES / 16) + 8 * half;
+    const PnFusedLevel* lds_lv = reinterpret_cast<const PnFusedLevel*>(wimg + PN_IMG_BYTES / 16) + 8 * half;
 
     for (uint32_t tile = wave; tile < n_tiles; tile += waves_total) {
         const uint32_t li = tile * 32 + s;
@@ -464,7 +535,9 @@ __global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const P
             x = xyzs[slot * 3]; y = xyzs[slot * 3 + 1]; z = xyzs[slot * 3 + 2];
             dx = dirs[slot * 3]; dy = dirs[slot * 3 + 1]; dz = dirs[slot * 3 + 2];
         }
-        const f32x16 h2 = tile_sigma_net<LU>(lv, lds_lv, emb, wl, half, bound, x, y, z);
+        f32x16 h2;
+        if (X) h2 = tile_sigma_net_x<LU>(lv, lds_lv, emb, wl, half, bound, x, y, z, sf, rsf);
+        else h2 = tile_sigma_net<LU>(lv, lds_lv, emb, wl, half, bound, x, y, z);
         const float sigma_logit = h2[0];  // row 0 lives in the low half's register 0
         if (geo || sigma_only) {  // NeRFNetwork.density (network.py:129-146): sigma = exp(h[0]), geo_feat = h[1:16]; no colour net (kernel-uniform)
             if (valid) {
@@ -482,7 +555,8 @@ __global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const P
         }
         __builtin_amdgcn_sched_barrier(0);
         float e[3];
-        tile_color_net(wl, wimg, half, h2, dx, dy, dz, e);
+        if (X) tile_color_net_x(wl, wimg, half, h2, dx, dy, dz, e);
+        else tile_color_net(wl, wimg, half, h2, dx, dy, dz, e);
         if (valid && half == 0) {
             sigmas[slot] = tile_sigma_out(density_scale, sigma_logit);
             rgbs[slot * 3 + 0] = tile_rgb_out(e[0]);
@@ -572,6 +646,11 @@ int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* di
     uint32_t blocks = pn_div_up(tiles, PN_BF_WAVES);
     if (blocks > max_blocks) blocks = max_blocks;
     if (blocks_cap) blocks = std::min(blocks, blocks_cap);
+    if (net->x_ok)
+        k_nerf_forward<2, PN_BF_LU, true><<<blocks, PN_BF_WAVES * 64, PN_NET_X_BYTES + 16 * sizeof(PnFusedLevel), stream>>>(
+            (const PnFusedLevel*)net->fused_levels, net->embeddings, (const uint4*)net->wx, net->bound, xyzs, dirs, list, ctl_count, M_max, density_scale, sigmas, rgbs,
+            nullptr, 0, net->x_scale, net->x_rscale);
+    else
     k_nerf_forward<2, PN_BF_LU><<<blocks, PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES + 16 * sizeof(PnFusedLevel), stream>>>((const PnFusedLevel*)net->fused_levels, net->embeddings,
                                                                                   (const uint4*)net->wsplit, net->bound, xyzs, dirs, list, ctl_count,
                                                                                   M_max, density_scale, sigmas, rgbs, nullptr, 0);
@@ -588,6 +667,10 @@ static int density_launch(const pn_net* net, const float* xyzs, uint32_t M, floa
         k_nerf_forward_h<4, 4><<<std::min(pn_div_up(tiles, PN_H_WAVES), 1024u), PN_H_WAVES * 64, PN_NET_HALF_BYTES + 16 * sizeof(PnFusedLevel), st>>>(
             (const PnFusedLevel*)net->fused_levels, (const uint32_t*)net->emb_half, (const uint4*)net->whalf, net->bound, xyzs, xyzs, nullptr, nullptr, M, scale,
             sigmas, nullptr, geo_feat, net->n_entries * 4u, sigma_only);
+    } else if (net->x_ok) {
+        k_nerf_forward<2, PN_BF_LU, true><<<std::min(pn_div_up(tiles, PN_BF_WAVES), 2048u / PN_BF_WAVES), PN_BF_WAVES * 64, PN_NET_X_BYTES + 16 * sizeof(PnFusedLevel), st>>>(
+            (const PnFusedLevel*)net->fused_levels, net->embeddings, (const uint4*)net->wx, net->bound, xyzs, xyzs, nullptr, nullptr, M, scale, sigmas, nullptr, geo_feat,
+            sigma_only, net->x_scale, net->x_rscale);
     } else {
         k_nerf_forward<2, PN_BF_LU><<<std::min(pn_div_up(tiles, PN_BF_WAVES), 2048u / PN_BF_WAVES), PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES + 16 * sizeof(PnFusedLevel), st>>>(
             (const PnFusedLevel*)net->fused_levels, net->embeddings, (const uint4*)net->wsplit, net->bound, xyzs, xyzs, nullptr, nullptr, M, scale, sigmas,

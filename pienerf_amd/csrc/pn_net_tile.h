@@ -340,6 +340,124 @@ __device__ __forceinline__ void tile_color_net(const uint4* __restrict__ wl, con
         for (int o = 0; o < 3; o++) e[o] += __shfl_xor(e[o], 32);
     }
 }
+// ------------------------------------------------------------------------------------------------ fp16 hi/lo form of the same two functions (pn_common.h: pn_net::wx)
+// x = hi + lo with hi = f16(x), lo = f16(x - hi) (v_cvt_pk_f16_f32: round to nearest even, two values per instruction); x * w = hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_32x32x16_f16 (the dropped lo*lo is <= 2^-22 |x w|).  `c`: a power-of-two factor applied before the split (exact).
+typedef _Float16 pn_h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 pn_h16x8 __attribute__((ext_vector_type(8)));
+struct Split8x { uint4 hi, lo; };
+// (Written out as v_cvt_pk_f16_f32 / v_fma_mix_f32 inline assembly — four instructions per pair instead of the ~nine the compiler makes of this, 1 319 instead of
+// 1 439 vector instructions per tile — the stand-alone kernel kept its accuracy but frames of the fused launch differed from the stand-alone kernel's by more
+// than 1e-5: the hazard recogniser does not look into inline assembly next to the matrix instructions.  Left to the compiler.)
+__device__ __forceinline__ void split_pair_x(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const pn_h16x2 h = {(_Float16)a, (_Float16)b};
+    const pn_h16x2 l = {(_Float16)(a - (float)h.x), (_Float16)(b - (float)h.y)};
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+__device__ __forceinline__ Split8x split8x(float x0, float x1, float x2, float x3, float x4, float x5, float x6, float x7, float c) {
+    Split8x o;
+    split_pair_x(x0 * c, x1 * c, o.hi.x, o.lo.x);
+    split_pair_x(x2 * c, x3 * c, o.hi.y, o.lo.y);
+    split_pair_x(x4 * c, x5 * c, o.hi.z, o.lo.z);
+    split_pair_x(x6 * c, x7 * c, o.hi.w, o.lo.w);
+    return o;
+}
+__device__ __forceinline__ Split8x split8x_of(const f32x16& v, int r0, float c) {
+    return split8x(v[r0], v[r0 + 1], v[r0 + 2], v[r0 + 3], v[r0 + 4], v[r0 + 5], v[r0 + 6], v[r0 + 7], c);
+}
+#define PN_XMFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pn_h16x8, (a)), __builtin_bit_cast(pn_h16x8, (b)), (c), 0, 0, 0)
+// acc += W(group G) . x for one K chunk (hi*hi first: see split_mac)
+__device__ __forceinline__ f32x16 split_mac_x(const uint4* __restrict__ wl, int G, const Split8x& x, f32x16 acc) {
+    const uint4 wh = wl[(G * 2 + 0) * 64], wo = wl[(G * 2 + 1) * 64];
+    acc = PN_XMFMA(wh, x.hi, acc);
+    acc = PN_XMFMA(wh, x.lo, acc);
+    acc = PN_XMFMA(wo, x.hi, acc);
+    return acc;
+}
+// sf / rsf: the features' power-of-two scale and its reciprocal (layer 0 sees sf * features; its outputs are scaled back in front of layer 1's split)
+template <int LU>
+__device__ __forceinline__ f32x16 tile_sigma_net_x(const PnFusedLevel* __restrict__ lv, const PnFusedLevel* lds_lv, const float* __restrict__ emb,
+                                                   const uint4* __restrict__ wl, int half, float bound, float x, float y, float z, float sf, float rsf) {
+#pragma clang fp contract(fast)
+    const float u0 = (x + bound) / (2 * bound), u1 = (y + bound) / (2 * bound), u2 = (z + bound) / (2 * bound);
+    const bool oob = (u0 < 0 || u0 > 1 || u1 < 0 || u1 > 1 || u2 < 0 || u2 > 1);
+    float feat[16];
+    encode8<LU>(lv, lds_lv, emb, half, oob ? 0.f : u0, oob ? 0.f : u1, oob ? 0.f : u2, oob, feat);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 a0 = {0}, a1 = {0};
+#pragma unroll
+    for (int kc = 0; kc < 2; kc++) {
+        const Split8x b = split8x(feat[8 * kc], feat[8 * kc + 1], feat[8 * kc + 2], feat[8 * kc + 3], feat[8 * kc + 4], feat[8 * kc + 5],
+                                  feat[8 * kc + 6], feat[8 * kc + 7], sf);
+        a0 = split_mac_x(wl, 0 + kc, b, a0);
+        a1 = split_mac_x(wl, 2 + kc, b, a1);
+    }
+    a0 = relu16(a0);
+    a1 = relu16(a1);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 h2 = {0};
+#pragma unroll
+    for (int kc = 0; kc < 4; kc++) h2 = split_mac_x(wl, 4 + kc, split8x_of(kc < 2 ? a0 : a1, (kc & 1) * 8, rsf), h2);
+    return h2;
+}
+__device__ __forceinline__ void tile_color_net_x(const uint4* __restrict__ wl, const uint4* wimg, int half, const f32x16& h2, float dx, float dy, float dz,
+                                                 float (&e)[3]) {
+#pragma clang fp contract(fast)
+    float sh[16];
+    sh16(dx, dy, dz, sh);
+    float v[16];
+    auto pick = [half](float a, float b) {
+        asm volatile("" : "+v"(a), "+v"(b));
+        return half ? a : b;
+    };
+#pragma unroll
+    for (int k = 0; k < 7; k++) v[k] = pick(h2[k], h2[k + 1]);
+    v[7] = pick(h2[7], sh[0]);
+#pragma unroll
+    for (int k = 8; k < 15; k++) v[k] = pick(sh[k + 1], sh[k - 7]);
+    v[15] = pick(0.0f, sh[8]);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 c0 = {0}, c1 = {0};
+#pragma unroll
+    for (int kc = 0; kc < 2; kc++) {
+        const Split8x b = split8x(v[8 * kc], v[8 * kc + 1], v[8 * kc + 2], v[8 * kc + 3], v[8 * kc + 4], v[8 * kc + 5], v[8 * kc + 6], v[8 * kc + 7], 1.0f);
+        c0 = split_mac_x(wl, 8 + kc, b, c0);
+        c1 = split_mac_x(wl, 10 + kc, b, c1);
+    }
+    c0 = relu16(c0);
+    c1 = relu16(c1);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 d0 = {0}, d1 = {0};
+#pragma unroll
+    for (int kc = 0; kc < 4; kc++) {
+        const Split8x b = split8x_of(kc < 2 ? c0 : c1, (kc & 1) * 8, 1.0f);
+        d0 = split_mac_x(wl, 12 + kc, b, d0);
+        d1 = split_mac_x(wl, 16 + kc, b, d1);
+    }
+    d0 = relu16(d0);
+    d1 = relu16(d1);
+    __builtin_amdgcn_sched_barrier(0);
+    e[0] = e[1] = e[2] = 0.f;
+    {
+        const float* __restrict__ wlast = reinterpret_cast<const float*>(wimg) + PN_NET_X_W_BYTES / 4 + half * 96;
+#pragma unroll
+        for (int q4 = 0; q4 < 8; q4++) {
+            const float4 wa = *reinterpret_cast<const float4*>(wlast + q4 * 12);
+            const float4 wb = *reinterpret_cast<const float4*>(wlast + q4 * 12 + 4);
+            const float4 wc = *reinterpret_cast<const float4*>(wlast + q4 * 12 + 8);
+            const f32x16& src = (q4 < 4) ? d0 : d1;
+            const int r = (q4 & 3) * 4;
+            e[0] = fmaf(wa.x, src[r], e[0]); e[1] = fmaf(wa.y, src[r], e[1]); e[2] = fmaf(wa.z, src[r], e[2]);
+            e[0] = fmaf(wa.w, src[r + 1], e[0]); e[1] = fmaf(wb.x, src[r + 1], e[1]); e[2] = fmaf(wb.y, src[r + 1], e[2]);
+            e[0] = fmaf(wb.z, src[r + 2], e[0]); e[1] = fmaf(wb.w, src[r + 2], e[1]); e[2] = fmaf(wc.x, src[r + 2], e[2]);
+            e[0] = fmaf(wc.y, src[r + 3], e[0]); e[1] = fmaf(wc.z, src[r + 3], e[1]); e[2] = fmaf(wc.w, src[r + 3], e[2]);
+        }
+#pragma unroll
+        for (int o = 0; o < 3; o++) e[o] += __shfl_xor(e[o], 32);
+    }
+}
+
 // exp(x) for the network's two activations, written out: the device library's expf is inlined bitcode whose multiply-adds contract or not with the
 // flags of the translation unit it lands in, and the same sample must give the same bits in the stand-alone network kernels (-ffp-contract=fast) and in
 // the fused trip kernel (a -ffp-contract=off unit).  exp(x) = 2^e * 2^a with x log2(e) = e + a evaluated with a two-piece log2(e) (the product's

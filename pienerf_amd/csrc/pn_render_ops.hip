@@ -2244,7 +2244,8 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             FusedArgs fa;
             memset(&fa, 0, sizeof(fa));
             fa.lv = (const PnFusedLevel*)net->fused_levels; fa.emb = net->embeddings; fa.emb_h = (const uint32_t*)net->emb_half; fa.emb_bytes = net->n_entries * 4u;
-            fa.wimg_g = (const uint4*)(o->fp16 ? net->whalf : net->wsplit); fa.net_bound = net->bound; fa.density_scale = o->density_scale;
+            fa.wimg_g = (const uint4*)(o->fp16 ? net->whalf : (net->x_ok ? net->wx : net->wsplit)); fa.net_bound = net->bound; fa.density_scale = o->density_scale;
+            fa.x_scale = net->x_scale; fa.x_rscale = net->x_rscale;
             fa.trips = f->trips + t; fa.N_rays = N; fa.max_steps = o->max_steps; fa.T_thresh = o->T_thresh;
             fa.alive = (t & 1) ? f->alive_b : f->alive_a;
             fa.rays_t = f->rays_t; fa.weights_sum = weights_sum; fa.depth = depth_0; fa.image = f->acc_image;
@@ -2274,7 +2275,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                 f->skip_done = 1;
             }
             const uint32_t blocks = fused_grid_env ? std::min(fused_grid_env, f->fused_blocks) : (o->fused_grid > 0 ? std::min((uint32_t)o->fused_grid, f->fused_blocks) : f->fused_blocks);
-            rc = launch_trips_fused(o->num_seek_IP, o->max_iter_num > 1, o->fp16 != 0, whole ? 1 : (fold ? 2 : 0), blocks, st, mq, tb, fa);
+            rc = launch_trips_fused(o->num_seek_IP, o->max_iter_num > 1, o->fp16 ? 1 : (net->x_ok ? 2 : 0), whole ? 1 : (fold ? 2 : 0), blocks, st, mq, tb, fa);
             if (rc) return rc;
             if ((rc = time_mark(tb_idx, 1)) || (rc = time_mark(tb_idx, 2))) return rc;
             f->fused_first = tb_idx;

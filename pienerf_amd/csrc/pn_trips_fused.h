@@ -49,8 +49,9 @@ struct FusedArgs {
     const float* emb;
     const uint32_t* emb_h;
     uint32_t emb_bytes;
-    const uint4* wimg_g;  // the LDS weight image in global memory (wsplit / whalf)
+    const uint4* wimg_g;  // the LDS weight image in global memory (wsplit / whalf / wx)
     float net_bound, density_scale;
+    float x_scale, x_rscale;  // fp16 hi/lo form: the features' power-of-two scale and its reciprocal
     // frame
     PnTrip* trips;  // record of the first fused trip
     uint32_t N_rays, max_steps;
@@ -160,10 +161,12 @@ __device__ __forceinline__ void finalize_ray(const FusedArgs& fa, int index) {
 //        workgroup's own list;
 //     B. (behind a workgroup barrier) the loop below over that list.
 //   Not applicable (more than N / 8 active rays, a frame stopped by an error flag): the launch does nothing and says so (fused_trips stays 0).
-template <int K, bool MULTI, bool HALF, int MODE>
+// NF: form of the network tile — 0: fp32 accuracy through the three-way bf16 split, 1: the autocast (fp16) form, 2: fp32 accuracy through the fp16 hi/lo split
+template <int K, bool MULTI, int NF, int MODE>
 __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4) k_trips_fused(pnm::MarchParams a, pnm2::March2Tables tb, FusedArgs fa) {
     extern __shared__ __attribute__((aligned(16))) uint4 fused_lds[];
-    constexpr int IMG16 = (HALF ? PN_NET_HALF_BYTES : PN_NET_SPLIT_BYTES) / 16;
+    constexpr bool HALF = NF == 1, XF = NF == 2;
+    constexpr int IMG16 = (HALF ? PN_NET_HALF_BYTES : (XF ? PN_NET_X_BYTES : PN_NET_SPLIT_BYTES)) / 16;
     constexpr int MAXT = PN_FUSED_MAX_TRIPS;
     constexpr int AC = PN_FUSED_ACHUNK;
     static_assert(AC == 64 || AC == 32, "rays per first-trip chunk");
@@ -255,6 +258,11 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
             sigma_logit = g2[0];
             __builtin_amdgcn_sched_barrier(0);
             tile_color_net_h(wl, wimg, half, g2, d.x, d.y, d.z, e);
+        } else if (XF) {
+            const f32x16 h2 = tile_sigma_net_x<PN_BF_LU>(fa.lv, lds_lv, fa.emb, wl, half, fa.net_bound, p.x, p.y, p.z, fa.x_scale, fa.x_rscale);
+            sigma_logit = h2[0];
+            __builtin_amdgcn_sched_barrier(0);
+            tile_color_net_x(wl, wimg, half, h2, d.x, d.y, d.z, e);
         } else {
             const f32x16 h2 = tile_sigma_net<PN_BF_LU>(fa.lv, lds_lv, fa.emb, wl, half, fa.net_bound, p.x, p.y, p.z);
             sigma_logit = h2[0];
@@ -718,44 +726,45 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
     }
 }
 
-static size_t fused_lds_bytes(bool half) {
-    return (size_t)(half ? PN_NET_HALF_BYTES : PN_NET_SPLIT_BYTES) + 16 * sizeof(PnFusedLevel) + (size_t)PN_FUSED_WAVES * PN_FUSED_STAGE * sizeof(float4) +
+static size_t fused_lds_bytes(int nf) {
+    return (size_t)(nf == 1 ? PN_NET_HALF_BYTES : (nf == 2 ? PN_NET_X_BYTES : PN_NET_SPLIT_BYTES)) + 16 * sizeof(PnFusedLevel) + (size_t)PN_FUSED_WAVES * PN_FUSED_STAGE * sizeof(float4) +
            3 * PN_FUSED_MAX_TRIPS * sizeof(int);
 }
 
-template <int K, bool MULTI, bool HALF, int MODE>
+template <int K, bool MULTI, int NF, int MODE>
 static int launch_trips_fused_t(uint32_t blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb, const FusedArgs& fa) {
-    const size_t lds = fused_lds_bytes(HALF);
+    const size_t lds = fused_lds_bytes(NF);
     static bool granted[PN_MAX_DEVICES] = {false};  // dynamic LDS above 64 KB is opted into per function and DEVICE
     int dev_id = 0;
     PN_HIP_CHECK(hipGetDevice(&dev_id));
     if (dev_id < 0 || dev_id >= PN_MAX_DEVICES || !granted[dev_id]) {
-        PN_HIP_CHECK(hipFuncSetAttribute((const void*)k_trips_fused<K, MULTI, HALF, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PN_HIP_CHECK(hipFuncSetAttribute((const void*)k_trips_fused<K, MULTI, NF, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (dev_id >= 0 && dev_id < PN_MAX_DEVICES) granted[dev_id] = true;
     }
-    k_trips_fused<K, MULTI, HALF, MODE><<<blocks, PN_FUSED_WAVES * 64, lds, st>>>(a, tb, fa);
+    k_trips_fused<K, MULTI, NF, MODE><<<blocks, PN_FUSED_WAVES * 64, lds, st>>>(a, tb, fa);
     PN_LAUNCH_CHECK();
     return PN_OK;
 }
 
-static int launch_trips_fused(int K, bool multi, bool half, int mode, uint32_t blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb,
+static int launch_trips_fused(int K, bool multi, int nf, int mode, uint32_t blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb,
                               const FusedArgs& fa) {
-#define PN_FUSED_CASE2(K_, M_, H_)                                                                  \
-    return mode == 1 ? launch_trips_fused_t<K_, M_, H_, 1>(blocks, st, a, tb, fa)                   \
-                     : (mode == 2 ? launch_trips_fused_t<K_, M_, H_, 2>(blocks, st, a, tb, fa) : launch_trips_fused_t<K_, M_, H_, 0>(blocks, st, a, tb, fa))
-#define PN_FUSED_CASE(K_)                                      \
-    if (K == K_) {                                             \
-        if (multi) {                                           \
-            if (half) PN_FUSED_CASE2(K_, true, true);          \
-            PN_FUSED_CASE2(K_, true, false);                   \
-        }                                                      \
-        if (half) PN_FUSED_CASE2(K_, false, true);             \
-        PN_FUSED_CASE2(K_, false, false);                      \
+#define PN_FUSED_CASE3(K_, M_, N_)                                                                  \
+    return mode == 1 ? launch_trips_fused_t<K_, M_, N_, 1>(blocks, st, a, tb, fa)                   \
+                     : (mode == 2 ? launch_trips_fused_t<K_, M_, N_, 2>(blocks, st, a, tb, fa) : launch_trips_fused_t<K_, M_, N_, 0>(blocks, st, a, tb, fa))
+#define PN_FUSED_CASE2(K_, M_)                 \
+    if (nf == 1) PN_FUSED_CASE3(K_, M_, 1);    \
+    if (nf == 2) PN_FUSED_CASE3(K_, M_, 2);    \
+    PN_FUSED_CASE3(K_, M_, 0)
+#define PN_FUSED_CASE(K_)                      \
+    if (K == K_) {                             \
+        if (multi) { PN_FUSED_CASE2(K_, true); } \
+        PN_FUSED_CASE2(K_, false);             \
     }
     PN_FUSED_CASE(1)
     PN_FUSED_CASE(2)
     PN_FUSED_CASE(3)
 #undef PN_FUSED_CASE
 #undef PN_FUSED_CASE2
+#undef PN_FUSED_CASE3
     return PN_ERR_ARG;
 }

@@ -13,6 +13,7 @@ Start-up mirrors main_gui.py:26-56.
 """
 import contextlib
 import gc
+import os
 
 import numpy as np
 import torch
@@ -486,7 +487,7 @@ class _HipBackend:
         kw.update(render_kw or {})  # options of THIS pipeline's renders (capture_staged: ray_batch)
         # several frames in flight: the first trip's march pass in its throughput form (pn_render_opts.throughput: one lane per ray, no speculative
         # evaluation; the same samples bit for bit, +8 % steps/s with three lanes) — with one lane the frame's own latency is what counts
-        kw.setdefault("march_throughput", 64 if lanes > 1 else 0)
+        kw.setdefault("march_throughput", int(os.environ.get("PN_HARNESS_THROUGHPUT", "64")) if lanes > 1 else 0)   # (the environment variable: experiments)
         # ... and each frame's fused launch (pn_render_opts.fused_from) on half of the CUs: the launches of the frames in flight run side by side and the
         # other kernels find CUs with free LDS (pn_render_opts.fused_grid; three lanes on the chair: 1 721 -> 1 937 steps/s)
         if lanes > 1:
