@@ -183,6 +183,7 @@ def kernel_report(h, opt, dev, form_kw=None, graph_ms=None):
     from pienerf_amd._lib import check, lib, ptr, stream_ptr
     m = h.model
     fp16 = bool(opt.get("fp16"))
+    x_form = (not fp16) and lib().pn_net_form(m._net_handle()) == 2   # how the fp32 network's dense layers run for these weights (include/pienerf_hip.h)
     N = opt["W"] * opt["H"]
     for k, v in (form_kw or {}).items():   # render_kwargs() hands the option set to the renderer by name
         if v is not None:
@@ -346,7 +347,9 @@ def kernel_report(h, opt, dev, form_kw=None, graph_ms=None):
     net_loop_tf = MLP_FLOP_PER_SAMPLE * st["samples"] / (net_loop_ms * 1e-3) / 1e12 if net_loop_ms > 0 else 0.0
     network = {
         "kernel": ("k_nerf_forward_h<4,4> / the same tile inside k_trips_fused (fp16 hash tables + SH + 5-layer MLP fused; dense layers on v_mfma_f32_32x32x16_f16, half activations)" if fp16 else
-                   "k_nerf_forward<2,4> / the same tile inside k_trips_fused (hash-grid gather + SH + 5-layer MLP fused; dense layers as three-way bf16-split MFMA at fp32 accuracy)"),
+                   "k_nerf_forward<2,4,X> / the same tile inside k_trips_fused (hash-grid gather + SH + 5-layer MLP fused; dense layers at fp32 accuracy: " +
+                   ("every value as fp16 hi + lo pieces, 3 products per K chunk on v_mfma_f32_32x32x16_f16)" if x_form else "three bf16 pieces, 6 products per K chunk on v_mfma_f32_32x32x16_bf16)")),
+        "dense_form": "fp16" if fp16 else ("fp16 hi/lo x3" if x_form else "bf16 x6"),
         "bound": "hbm", "achieved": round(net_loop_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(net_loop_gbs / HBM_PEAK_GBS, 4),
         "bytes_per_sample": bps, "traffic": traffic.get(kname), "traffic_note": traffic_note,
         "ms_per_frame": round(net_loop_ms, 4), "samples_per_frame": st["samples"],
@@ -356,7 +359,7 @@ def kernel_report(h, opt, dev, form_kw=None, graph_ms=None):
         "per_trip_launch_ms": [round(float(v), 4) for v in net_ms[:per_trip]], "samples_in_per_trip_launches": net_samples_head,
         "mfma_view": {"flop_per_sample": MLP_FLOP_PER_SAMPLE, "TFLOPs": round(net_loop_tf, 2),
                       "frac_of_mfma_peak": round(net_loop_tf / (F16_MFMA_PEAK_TF if fp16 else F32_MFMA_PEAK_TF), 4),
-                      "peak_used": "fp16 dense MFMA 2.5 PF" if fp16 else "fp32-input MFMA 157.3 TF (the kernel computes fp32-accurate products out of 6 bf16 MFMAs)"},
+                      "peak_used": "fp16 dense MFMA 2.5 PF" if fp16 else ("fp32-input MFMA 157.3 TF (the kernel computes fp32-accurate products out of " + ("3 fp16" if x_form else "6 bf16") + " MFMAs)")},
         "all_samples_one_launch": {"launch_ms_fp32": round(t_net, 4), "launch_ms_fp16": round(t_net_h, 4), "achieved_GBps": round(bps * B / (t_used * 1e-3) / 1e9, 1),
                                    "frac_of_hbm_peak": round(bps * B / (t_used * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
     }

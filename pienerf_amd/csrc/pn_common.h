@@ -60,6 +60,13 @@ struct PnGridLevels {
 
 struct PnFusedLevel { float scale; uint32_t offset, m1, m2, mask, dense, dm, xm; };  // dm = dense ? ~0 : 0, xm = dense ? ~0 : mask; see pn_nerf_forward.hip
 
+// The same constants as the fp32 network kernels' encoder wants them (pn_net_tile.h: encode_level): everything in BYTES of the [n_entries, 2] fp32 table, the
+// dense and the hashed index form side by side (a level uses one, the other is switched off by zeros):
+//   off_b = 8 offset;  dense: m1d = 8 s, m2d = 8 s^2 (s = resolution + 1; both < 2^24), mb = ~0, xmb = 0;  hashed: p1b = 8 P1, p2b = 8 P2 (mod 2^32),
+//   mb = xmb = 8 mask, m1d = m2d = 0.   Needs 8 n_entries < 2^32 (pn_net_create checks).
+struct PnByteLevel { float scale; uint32_t off_b, p1b, p2b, m1d, m2d, mb, xmb; };
+static_assert(sizeof(PnByteLevel) == sizeof(PnFusedLevel), "both level records share the kernels' LDS slot");
+
 int pn_fill_grid_levels(PnGridLevels* g, const int* offsets_host, uint32_t L, uint32_t C, float S, uint32_t H, uint32_t gridtype,
                         int align_corners);
 
@@ -68,7 +75,8 @@ struct pn_net {
     PnGridLevels levels;
     const float* embeddings;  // device, not owned
     void* wsplit;             // device, owned: the fp32-accurate kernel's LDS weight image, PN_NET_SPLIT_BYTES (pn_nerf_forward.hip)
-    void* fused_levels;       // device, owned: PnFusedLevel[16] (pn_nerf_forward.hip)
+    void* fused_levels;       // device, owned: PnFusedLevel[16] (pn_nerf_forward.hip): the fp16 kernel's level records
+    void* byte_levels;        // device, owned: PnByteLevel[16]: the fp32 kernels' level records
     float bound;
     uint32_t n_entries;       // rows of `embeddings` (offsets[L])
     // fp16 form (the reference under torch.cuda.amp.autocast: gridencoder/grid.py:43-44, nn.Linear in half): built on first use by
@@ -80,12 +88,13 @@ struct pn_net {
     hipEvent_t stage_done;
     // fp16 hi/lo form of the fp32 network (round 4): every fp32 value as two fp16 pieces x = hi + lo (11 + 11 significant bits, round to nearest), a product as
     // hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with the fp32 accumulator — three products instead of the six of the three-way bf16 split, five vector
-    // instructions per pair of split values instead of eleven; 2^-22 relative per value against the bf16 split's 2^-24.  fp16 holds 2^-24 .. 65504: the hash
-    // features are scaled by a power of two into [2^13, 2^14) (x_scale, taken out again behind the first layer) and the form is only chosen when the layers'
-    // worst-case outputs stay below 60 000 (interval bound over the weights and the tables' largest entry: x_ok); otherwise the bf16 split.
+    // instructions per pair of split values instead of eleven; 2^-22 relative per value against the bf16 split's 2^-24.  fp16 holds 2^-24 .. 65504: every
+    // layer's inputs are carried at a power-of-two scale that puts their interval bound (tables' largest entry x row sums of |W| through the layers) into
+    // [2^13, 2^14]; the scales are folded into the weight image, the kernel multiplies the features by x_scale and the density net's outputs by x_rscale
+    // (pn_nerf_forward.hip: net_choose_form).  Zero / non-finite bounds: x_ok = 0, the bf16 split runs.
     void* wx;                 // device, owned: the fp16 hi/lo LDS weight image, PN_NET_X_BYTES
     int x_ok;                 // the fp32 network runs in the fp16 hi/lo form (PN_NET_FORM=bf16 forces 0)
-    float x_scale, x_rscale;  // feature scale 2^k and its reciprocal
+    float x_scale, x_rscale;  // the features' scale xs[0]; 1 / xs[2], the scale the density net's 16 outputs leave the matrix pipe at
 };
 
 // weight image: [20 MFMA operand groups][3 bf16 pieces hi/mid/lo][64 lanes][8 bf16], then the VALU output layer's 192 fp32 weights

@@ -274,10 +274,24 @@ static float pn_h2f(uint16_t h) {
 //     (wlast[h][q][o] = W4[o][krow(q, h)], q = tile*16 + register index of the D layout; an MFMA tile would be 29/32 row padding).
 //   himg (PN_NET_HALF_BYTES): the same groups with every weight rounded once to fp16 (autocast's `weight.to(half)`), one piece.
 //   ximg (PN_NET_X_BYTES): the same groups with every weight as two fp16 pieces w = hi + lo (round to nearest even both), then the 64 -> 3 layer's fp32 weights.
+//     `xs` = the five power-of-two layer scales of net_choose_form (layer l's inputs are carried as xs[l] * value): W0 xs1/xs0, W1 xs2/xs1, W2's geometry
+//     columns xs3/xs2 and its SH columns xs3 (the SH basis enters unscaled), W3 xs4/xs3, W4 / xs4 — exact, ReLU commutes with positive factors.
 static void build_weight_images(const float* W0, const float* W1, const float* W2, const float* W3, const float* W4, unsigned char* simg,
-                                unsigned char* himg, unsigned char* ximg) {
+                                unsigned char* himg, unsigned char* ximg, const double* xs) {
     float* host = new float[160 * 64];
+    float* hostx = new float[160 * 64];
     pack_weights(W0, W1, W2, W3, host);
+    {
+        float* X = new float[64 * 32 + 16 * 64 + 64 * 31 + 64 * 64];
+        float *X0 = X, *X1 = X0 + 64 * 32, *X2 = X1 + 16 * 64, *X3 = X2 + 64 * 31;
+        for (int i = 0; i < 64 * 32; i++) X0[i] = (float)((double)W0[i] * (xs[1] / xs[0]));
+        for (int i = 0; i < 16 * 64; i++) X1[i] = (float)((double)W1[i] * (xs[2] / xs[1]));
+        for (int i = 0; i < 64; i++)
+            for (int j = 0; j < 31; j++) X2[i * 31 + j] = (float)((double)W2[i * 31 + j] * (j < 16 ? xs[3] : xs[3] / xs[2]));
+        for (int i = 0; i < 64 * 64; i++) X3[i] = (float)((double)W3[i] * (xs[4] / xs[3]));
+        pack_weights(X0, X1, X2, X3, hostx);
+        delete[] X;
+    }
     uint16_t* s16 = reinterpret_cast<uint16_t*>(simg);
     uint16_t* h16 = reinterpret_cast<uint16_t*>(himg);
     uint16_t* x16 = reinterpret_cast<uint16_t*>(ximg);
@@ -288,8 +302,9 @@ static void build_weight_images(const float* W0, const float* W1, const float* W
                 float v = host[(m0 + e2) * 64 + l];
                 h16[((size_t)G * 64 + l) * 8 + e2] = pn_f2h_bits(v);
                 {
-                    const uint16_t xh = pn_f2h_bits(v);
-                    const float r = v - pn_h2f(xh);   // exact: the remainder of a round-to-nearest fp16 has at most 13 significant bits
+                    const float vx = hostx[(m0 + e2) * 64 + l];
+                    const uint16_t xh = pn_f2h_bits(vx);
+                    const float r = vx - pn_h2f(xh);   // exact: the remainder of a round-to-nearest fp16 has at most 13 significant bits
                     x16[((size_t)(G * 2 + 0) * 64 + l) * 8 + e2] = xh;
                     x16[((size_t)(G * 2 + 1) * 64 + l) * 8 + e2] = pn_f2h_bits(r);
                 }
@@ -318,10 +333,11 @@ static void build_weight_images(const float* W0, const float* W1, const float* W
                 const int t = q >> 4, r = q & 15;
                 const float w = W4[o * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
                 wlast[(h * 32 + q) * 3 + o] = w;
-                wlast_x[(h * 32 + q) * 3 + o] = w;
+                wlast_x[(h * 32 + q) * 3 + o] = (float)((double)w / xs[4]);
                 wlast_h[(h * 32 + q) * 3 + o] = pn_h2f(pn_f2h_bits(w));
             }
     delete[] host;
+    delete[] hostx;
 }
 
 static int net_fail(pn_net* n, hipError_t e, const char* what) {
@@ -330,7 +346,6 @@ static int net_fail(pn_net* n, hipError_t e, const char* what) {
     return PN_ERR_HIP;
 }
 
-// stages both images in pinned memory and uploads them behind whatever `stream` holds; no allocation, no stream synchronisation
 // largest |entry| of the hash tables (bit pattern of a non-negative float orders like the float)
 __global__ void __launch_bounds__(256) k_table_absmax(const float* __restrict__ emb, uint32_t n, unsigned* __restrict__ out) {
     unsigned m = 0;
@@ -343,48 +358,49 @@ __global__ void __launch_bounds__(256) k_table_absmax(const float* __restrict__ 
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
-// Whether the fp16 hi/lo form is safe for these weights and tables (pn_common.h: pn_net::x_ok), and the features' scale.  Interval bound, layer by layer:
-// |out_i| <= sum_j |W_ij| max|in|; ReLU and the SH basis (|Y| < 4 up to degree 4 on unit directions) cannot raise it.  Every value that is split into
-// fp16 pieces — scaled features, the hidden activations, the geometry features — must stay below 60 000.
-static void net_choose_form(pn_net* n, const float* W0, const float* W1, const float* W2, const float* W3, float table_max) {
-    auto row_bound = [](const float* W, int rows, int cols, double in_max) {
+// Whether the fp16 hi/lo form runs for these weights and tables (pn_common.h: pn_net::x_ok), and the power-of-two scale every layer's inputs are carried
+// at.  Interval bound, layer by layer: |out_i| <= sum_j |W_ij| max|in_j|; ReLU cannot raise it, the SH basis is below 4 in magnitude up to degree 4 on unit
+// directions.  Layer l's inputs travel as xs[l] * value with xs[l] the power of two that puts their bound into [2^13, 2^14]: far inside fp16's range, and a
+// value's lo piece stays a normal fp16 number down to 2^-17 of the bound (hi + lo then carries 22 bits).  The scales live in the weight image
+// (build_weight_images), the kernel multiplies the features by xs[0] and the 16 outputs of the density net by 1 / xs[2]; nothing else.
+// xs[0] features, xs[1] hidden (density), xs[2] sigma logit + geometry features, xs[3] / xs[4] the colour net's hidden layers.
+static void net_choose_form(pn_net* n, const float* W0, const float* W1, const float* W2, const float* W3, float table_max, double* xs) {
+    auto row_bound = [](const float* W, int rows, int cols, int split, double in_a, double in_b) {   // columns < split see in_a, the others in_b
         double worst = 0.0;
         for (int i = 0; i < rows; i++) {
             double s2 = 0.0;
-            for (int j = 0; j < cols; j++) s2 += fabs((double)W[i * cols + j]);
-            worst = std::max(worst, s2 * in_max);
+            for (int j = 0; j < cols; j++) s2 += fabs((double)W[i * cols + j]) * (j < split ? in_a : in_b);
+            worst = std::max(worst, s2);
         }
         return worst;
     };
     n->x_ok = 0;
     n->x_scale = n->x_rscale = 1.0f;
+    for (int l = 0; l < 5; l++) xs[l] = 1.0;
     const char* form = getenv("PN_NET_FORM");   // "bf16": always the three-way bf16 split (A/B runs, tests)
     if (form && strcmp(form, "bf16") == 0) return;
-    if (!(table_max > 0.0f) || !std::isfinite(table_max)) return;
-    int k = (int)floor(log2(16384.0 / (double)table_max));   // features * 2^k in [2^13, 2^14]
-    k = std::min(std::max(k, -14), 60);
-    const double b0 = row_bound(W0, 64, 32, (double)table_max);           // sigma layer 0 -> hidden
-    const double b1 = row_bound(W1, 16, 64, b0);                          // sigma layer 1 -> sigma logit + geometry features
-    const double b2 = row_bound(W2, 64, 31, std::max(b1, 4.0));           // colour layer 0 on [SH16 | geo15]
-    const double b3 = row_bound(W3, 64, 64, b2);                          // colour layer 1 (its outputs go to the fp32 vector layer: no fp16 piece)
-    (void)b3;
-    if (!(b0 < 6.0e4 && b1 < 6.0e4 && b2 < 6.0e4)) return;
+    double bb[5];
+    bb[0] = (double)table_max;
+    bb[1] = row_bound(W0, 64, 32, 32, bb[0], 0.0);                            // density layer 0 -> hidden
+    bb[2] = row_bound(W1, 16, 64, 64, bb[1], 0.0);                            // density layer 1 -> sigma logit + geometry features
+    bb[3] = row_bound(W2, 64, 31, 16, 4.0, bb[2]);                            // colour layer 0 on [SH16 | geo15]
+    bb[4] = row_bound(W3, 64, 64, 64, bb[3], 0.0);                            // colour layer 1 (its outputs go to the fp32 vector layer)
+    double sc[5];
+    for (int l = 0; l < 5; l++) {
+        if (!(bb[l] > 0.0) || !std::isfinite(bb[l])) return;                  // zero / NaN / infinite somewhere: the bf16 form takes anything
+        const int k = (int)floor(log2(16384.0 / bb[l]));                      // bound * 2^k in (2^13, 2^14]
+        if (k < -100 || k > 100) return;                                      // (fp32 products of two scales must stay finite)
+        sc[l] = ldexp(1.0, k);
+    }
+    for (int l = 0; l < 5; l++) xs[l] = sc[l];
     n->x_ok = 1;
-    n->x_scale = (float)ldexp(1.0, k);
-    n->x_rscale = (float)ldexp(1.0, -k);
+    n->x_scale = (float)xs[0];
+    n->x_rscale = (float)(1.0 / xs[2]);
 }
 
+// stages the three images in pinned memory and uploads them behind whatever `stream` holds; no allocation; one stream synchronisation (the tables' abs-max)
 static int net_upload_weights(pn_net* n, const float* W0, const float* W1, const float* W2, const float* W3, const float* W4, hipStream_t st) {
-    PN_HIP_CHECK(hipEventSynchronize(n->stage_done));  // the previous upload has finished reading the staging buffer (normally long ago)
-    unsigned char* simg = reinterpret_cast<unsigned char*>(n->stage);
-    unsigned char* himg = simg + PN_NET_SPLIT_BYTES;
-    unsigned char* ximg = himg + PN_NET_HALF_BYTES;
-    build_weight_images(W0, W1, W2, W3, W4, simg, himg, ximg);
-    PN_HIP_CHECK(hipMemcpyAsync(n->wsplit, simg, PN_NET_SPLIT_BYTES, hipMemcpyHostToDevice, st));
-    PN_HIP_CHECK(hipMemcpyAsync(n->whalf, himg, PN_NET_HALF_BYTES, hipMemcpyHostToDevice, st));
-    PN_HIP_CHECK(hipMemcpyAsync(n->wx, ximg, PN_NET_X_BYTES, hipMemcpyHostToDevice, st));
-    PN_HIP_CHECK(hipEventRecord(n->stage_done, st));
-    // the tables' largest entry (one small reduction + a 4-byte read-back: this function already waits for the host's packing) -> the form of the fp32 network
+    // the tables' largest entry (one small reduction + a 4-byte read-back: this function waits for the host's packing anyway) -> the form of the fp32 network
     unsigned* d_max = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(n->wx) + PN_NET_X_BYTES);
     PN_HIP_CHECK(hipMemsetAsync(d_max, 0, 4, st));
     k_table_absmax<<<512, 256, 0, st>>>(n->embeddings, n->n_entries * 2u, d_max);
@@ -393,7 +409,17 @@ static int net_upload_weights(pn_net* n, const float* W0, const float* W1, const
     PN_HIP_CHECK(hipStreamSynchronize(st));
     float table_max;
     memcpy(&table_max, &bits, 4);
-    net_choose_form(n, W0, W1, W2, W3, table_max);
+    double xs[5];
+    net_choose_form(n, W0, W1, W2, W3, table_max, xs);
+    PN_HIP_CHECK(hipEventSynchronize(n->stage_done));  // the previous upload has finished reading the staging buffer (normally long ago)
+    unsigned char* simg = reinterpret_cast<unsigned char*>(n->stage);
+    unsigned char* himg = simg + PN_NET_SPLIT_BYTES;
+    unsigned char* ximg = himg + PN_NET_HALF_BYTES;
+    build_weight_images(W0, W1, W2, W3, W4, simg, himg, ximg, xs);
+    PN_HIP_CHECK(hipMemcpyAsync(n->wsplit, simg, PN_NET_SPLIT_BYTES, hipMemcpyHostToDevice, st));
+    PN_HIP_CHECK(hipMemcpyAsync(n->whalf, himg, PN_NET_HALF_BYTES, hipMemcpyHostToDevice, st));
+    PN_HIP_CHECK(hipMemcpyAsync(n->wx, ximg, PN_NET_X_BYTES, hipMemcpyHostToDevice, st));
+    PN_HIP_CHECK(hipEventRecord(n->stage_done, st));
     return PN_OK;
 }
 
@@ -414,6 +440,7 @@ extern "C" int pn_net_create(pn_net** out, const float* embeddings, const int* o
     memset(n, 0, sizeof(*n));
     if (pn_fill_grid_levels(&n->levels, offsets_host, L, C, per_level_scale_log2, base_resolution, 0, 0)) { delete n; return PN_ERR_ARG; }
     PnFusedLevel fl[16];
+    PnByteLevel bl[16];
     for (uint32_t l = 0; l < L; l++) {
         const PnGridLevels& g = n->levels;
         const bool dense = g.dense[l] == 3 && g.nomod[l];
@@ -421,7 +448,11 @@ extern "C" int pn_net_create(pn_net** out, const float* embeddings, const int* o
         if (!dense && !hashed) { delete n; PN_REQUIRE(!"level is neither fully dense nor hashed into a power-of-two table"); }
         const uint32_t s1 = g.resolution[l] + 1;
         fl[l] = PnFusedLevel{g.scale[l], g.offset[l], dense ? s1 : 2654435761u, dense ? s1 * s1 : 805459861u, g.mask[l], dense ? 1u : 0u, dense ? 0xffffffffu : 0u, dense ? 0xffffffffu : g.mask[l]};
+        if (dense && (uint64_t)s1 * s1 * 8u >= (1u << 24)) { delete n; PN_REQUIRE(!"dense level with a z stride of 2^24 bytes or more"); }
+        bl[l] = dense ? PnByteLevel{g.scale[l], g.offset[l] * 8u, 0u, 0u, s1 * 8u, s1 * s1 * 8u, 0xffffffffu, 0u}
+                      : PnByteLevel{g.scale[l], g.offset[l] * 8u, 2654435761u * 8u, 805459861u * 8u, 0u, 0u, g.mask[l] * 8u, g.mask[l] * 8u};
     }
+    if ((uint64_t)offsets_host[L] * 8u >= (1ull << 32)) { delete n; PN_REQUIRE(!"hash tables of 4 GiB or more (the fp32 kernels address them by 32-bit byte offsets)"); }
     n->embeddings = embeddings;
     n->bound = bound;
     n->n_entries = (uint32_t)offsets_host[L];
@@ -430,10 +461,12 @@ extern "C" int pn_net_create(pn_net** out, const float* embeddings, const int* o
     if (e == hipSuccess) e = hipMalloc((void**)&n->whalf, PN_NET_HALF_BYTES);
     if (e == hipSuccess) e = hipMalloc((void**)&n->wx, PN_NET_X_BYTES + 16);   // (+ the tables' abs-max word of net_upload_weights)
     if (e == hipSuccess) e = hipMalloc((void**)&n->fused_levels, sizeof(fl));
+    if (e == hipSuccess) e = hipMalloc((void**)&n->byte_levels, sizeof(bl));
     if (e == hipSuccess) e = hipHostMalloc((void**)&n->stage, PN_NET_SPLIT_BYTES + PN_NET_HALF_BYTES + PN_NET_X_BYTES);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&n->stage_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventRecord(n->stage_done, st);
     if (e == hipSuccess) e = hipMemcpyAsync(n->fused_levels, fl, sizeof(fl), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(n->byte_levels, bl, sizeof(bl), hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return net_fail(n, e, "pn_net_create");
     const int rc = net_upload_weights(n, W0, W1, W2, W3, W4, st);
     if (rc) { pn_net_destroy(n); return rc; }
@@ -489,6 +522,7 @@ extern "C" void pn_net_destroy(pn_net* n) {
     if (n->wx) (void)hipFree(n->wx);
     if (n->emb_half) (void)hipFree(n->emb_half);
     if (n->fused_levels) (void)hipFree(n->fused_levels);
+    if (n->byte_levels) (void)hipFree(n->byte_levels);
     if (n->stage) (void)hipHostFree(n->stage);
     if (n->stage_done) (void)hipEventDestroy(n->stage_done);
     delete n;
@@ -503,9 +537,9 @@ extern "C" void pn_net_destroy(pn_net* n) {
 #ifndef PN_BF_WAVES
 #define PN_BF_WAVES 8
 #endif
-// X: the fp16 hi/lo form of the dense layers (pn_common.h: pn_net::wx; `wsplit` is then that image, sf / rsf the features' scale and its reciprocal)
+// X: the fp16 hi/lo form of the dense layers (pn_common.h: pn_net::wx; `wsplit` is then that image, sf = pn_net::x_scale, rsf = pn_net::x_rscale)
 template <int MINW, int LU, bool X = false>
-__global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const PnFusedLevel* __restrict__ lv, const float* __restrict__ emb,
+__global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const PnByteLevel* __restrict__ lv, const float* __restrict__ emb,
                                                                           const uint4* __restrict__ wsplit, float bound, const float* __restrict__ xyzs,
                                                                           const float* __restrict__ dirs, const int* __restrict__ list,
                                                                           const int* __restrict__ count_dev, uint32_t M_arg, float density_scale,
@@ -524,7 +558,8 @@ __global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const P
     const int lane = threadIdx.x & 63;
     const int s = lane & 31, half = lane >> 5;
     const uint4* __restrict__ wl = wimg + lane;
-    const PnFusedLevel* lds_lv = reinterpret_cast<const PnFusedLevel*>(wimg + PN_IMG_BYTES / 16) + 8 * half;
+    const PnByteLevel* lds_lv = reinterpret_cast<const PnByteLevel*>(wimg + PN_IMG_BYTES / 16) + 8 * half;
+    const float inv2b = 1.0f / (2 * bound);
 
     for (uint32_t tile = wave; tile < n_tiles; tile += waves_total) {
         const uint32_t li = tile * 32 + s;
@@ -536,9 +571,9 @@ __global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const P
             dx = dirs[slot * 3]; dy = dirs[slot * 3 + 1]; dz = dirs[slot * 3 + 2];
         }
         f32x16 h2;
-        if (X) h2 = tile_sigma_net_x<LU>(lv, lds_lv, emb, wl, half, bound, x, y, z, sf, rsf);
-        else h2 = tile_sigma_net<LU>(lv, lds_lv, emb, wl, half, bound, x, y, z);
-        const float sigma_logit = h2[0];  // row 0 lives in the low half's register 0
+        if (X) h2 = tile_sigma_net_x<LU>(lds_lv, emb, wl, half, bound, inv2b, x, y, z, sf);   // xs[2] * outputs
+        else h2 = tile_sigma_net<LU>(lds_lv, emb, wl, half, bound, inv2b, x, y, z);
+        const float sigma_logit = X ? h2[0] * rsf : h2[0];  // row 0 lives in the low half's register 0
         if (geo || sigma_only) {  // NeRFNetwork.density (network.py:129-146): sigma = exp(h[0]), geo_feat = h[1:16]; no colour net (kernel-uniform)
             if (valid) {
                 if (half == 0) sigmas[slot] = tile_sigma_out(density_scale, sigma_logit);
@@ -547,7 +582,7 @@ __global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const P
 #pragma unroll
                     for (int r = 0; r < 8; r++) {  // this lane's rows (r&3) + 8*(r>>2) + 4*half of the 16 outputs
                         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (row >= 1) g[row - 1] = h2[r];
+                        if (row >= 1) g[row - 1] = X ? h2[r] * rsf : h2[r];
                     }
                 }
             }
@@ -648,10 +683,10 @@ int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* di
     if (blocks_cap) blocks = std::min(blocks, blocks_cap);
     if (net->x_ok)
         k_nerf_forward<2, PN_BF_LU, true><<<blocks, PN_BF_WAVES * 64, PN_NET_X_BYTES + 16 * sizeof(PnFusedLevel), stream>>>(
-            (const PnFusedLevel*)net->fused_levels, net->embeddings, (const uint4*)net->wx, net->bound, xyzs, dirs, list, ctl_count, M_max, density_scale, sigmas, rgbs,
+            (const PnByteLevel*)net->byte_levels, net->embeddings, (const uint4*)net->wx, net->bound, xyzs, dirs, list, ctl_count, M_max, density_scale, sigmas, rgbs,
             nullptr, 0, net->x_scale, net->x_rscale);
     else
-    k_nerf_forward<2, PN_BF_LU><<<blocks, PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES + 16 * sizeof(PnFusedLevel), stream>>>((const PnFusedLevel*)net->fused_levels, net->embeddings,
+    k_nerf_forward<2, PN_BF_LU><<<blocks, PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES + 16 * sizeof(PnFusedLevel), stream>>>((const PnByteLevel*)net->byte_levels, net->embeddings,
                                                                                   (const uint4*)net->wsplit, net->bound, xyzs, dirs, list, ctl_count,
                                                                                   M_max, density_scale, sigmas, rgbs, nullptr, 0);
     PN_LAUNCH_CHECK();
@@ -669,11 +704,11 @@ static int density_launch(const pn_net* net, const float* xyzs, uint32_t M, floa
             sigmas, nullptr, geo_feat, net->n_entries * 4u, sigma_only);
     } else if (net->x_ok) {
         k_nerf_forward<2, PN_BF_LU, true><<<std::min(pn_div_up(tiles, PN_BF_WAVES), 2048u / PN_BF_WAVES), PN_BF_WAVES * 64, PN_NET_X_BYTES + 16 * sizeof(PnFusedLevel), st>>>(
-            (const PnFusedLevel*)net->fused_levels, net->embeddings, (const uint4*)net->wx, net->bound, xyzs, xyzs, nullptr, nullptr, M, scale, sigmas, nullptr, geo_feat,
+            (const PnByteLevel*)net->byte_levels, net->embeddings, (const uint4*)net->wx, net->bound, xyzs, xyzs, nullptr, nullptr, M, scale, sigmas, nullptr, geo_feat,
             sigma_only, net->x_scale, net->x_rscale);
     } else {
         k_nerf_forward<2, PN_BF_LU><<<std::min(pn_div_up(tiles, PN_BF_WAVES), 2048u / PN_BF_WAVES), PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES + 16 * sizeof(PnFusedLevel), st>>>(
-            (const PnFusedLevel*)net->fused_levels, net->embeddings, (const uint4*)net->wsplit, net->bound, xyzs, xyzs, nullptr, nullptr, M, scale, sigmas,
+            (const PnByteLevel*)net->byte_levels, net->embeddings, (const uint4*)net->wsplit, net->bound, xyzs, xyzs, nullptr, nullptr, M, scale, sigmas,
             nullptr, geo_feat, sigma_only);
     }
     PN_LAUNCH_CHECK();

@@ -56,17 +56,13 @@ __device__ __forceinline__ void sh16(float x, float y, float z, float* o) {
     o[15] = SH_C3A * x * (-x2 + 3.0f * y2);
 }
 
-// 8 hash levels for one lane: feat[2j + c] = level (8h + j), channel c   (kernel_grid<float,3,2>, gridencoder.cu:87-197)
-// Per-level constants of the fused kernel, device-resident (scalar loads with a uniform index).  Every level is either
-// fully dense (index = g0 + g1*s + g2*s^2, provably < table size) or hashed into a power-of-two table
-// (index = (g0 ^ g1*P1 ^ g2*P2) & mask) — pn_net_create rejects anything else — so both cases share the form
-// t0 + t1 + t2 / (t0 ^ t1 ^ t2) & mask with t1 = g1*m1, t2 = g2*m2 and the +1 corner is t + m (uint32 wrap-around exact).
-// 8 hash levels for one lane: feat[2j + c] = level (8h + j), channel c   (kernel_grid<float,3,2>, gridencoder.cu:87-197)
-// Build knobs of the fp32-accurate kernel's encoder (defaults = what measured fastest on MI355X):
-//   PN_ENC_PK       the corner weights and the two channels' sums on the packed fp32 pipe (v_pk_mul_f32 / v_pk_fma_f32: the same roundings)
-//   PN_ENC_LDS_LV   the per-level constants read per lane from an LDS copy (lane half h: levels 8h..8h+7) instead of two scalar loads and a
-//                   v_mov + v_mov + v_cndmask per constant
+// 8 hash levels for one lane: feat[2j + c] = level (8h + j), channel c   (kernel_grid<float,3,2>, gridencoder.cu:87-197).  Every level is either
+// fully dense (index = g0 + g1 s + g2 s^2, provably < table size) or hashed into a power-of-two table (index = (g0 ^ g1 P1 ^ g2 P2) & mask) —
+// pn_net_create rejects anything else.
+// Build knobs of the fp16 kernel's encoder (encode_levels_h below; the fp32 kernels' encoder has one form):
+//   PN_ENC_LDS_LV   the per-level constants read per lane from an LDS copy instead of two scalar loads and a v_mov + v_mov + v_cndmask per constant
 //   PN_ENC_UNIFIED  one branch-free index form for dense and hashed levels instead of the compiler's exec-mask flow per corner
+//   PN_ENC_PK       the corner weights on the packed fp32 pipe (v_pk_mul_f32: the same roundings)
 #ifndef PN_ENC_PK
 #define PN_ENC_PK 1
 #endif
@@ -82,46 +78,40 @@ __device__ __forceinline__ void sh16(float x, float y, float z, float* o) {
 #ifndef PN_BF_LU
 #define PN_BF_LU 4
 #endif
-// One level for one lane.  `L` = the lane's level constants.
-__device__ __forceinline__ void encode_level(const PnFusedLevel& L, const float* __restrict__ emb, float u0, float u1, float u2, bool oob, float* out2) {
+// One level for one lane.  `L` = the lane's level constants in byte units (PnByteLevel, pn_common.h): the table entry of corner (i, c) — i: x / x + 1,
+// c: the (y, z) pair — sits at byte ((t0[i] ^ X[c]) + S[c]) of the embeddings, ONE v_xad_u32 per corner and no 64-bit address arithmetic (the load takes
+// the 32-bit offset beside the scalar base):
+//   dense level   X = 0, S[c] = 8 (g1' s + g2' s^2 + offset), t0 = 8 g0'                          (index g0 + g1 s + g2 s^2, provably inside the level)
+//   hashed level  S = 8 offset, X[c] = (8 g1' P1 ^ 8 g2' P2) & 8 mask, t0 = 8 g0' & 8 mask       (index (g0 ^ g1 P1 ^ g2 P2) & mask: masks and shifts
+//                 distribute over xor, products wrap mod 2^32 either way)
+// with both parts computed on every level (xmb = 0 switches the hash part off, m1d = m2d = 0 the dense part): the lane halves of a wave work on different
+// levels.  The dense strides fit 24 bits (v_mad_u32_u24, full rate; v_mul_lo_u32 is quarter rate).  Same entries as kernel_grid (gridencoder.cu:87-197).
+__device__ __forceinline__ void encode_level(const PnByteLevel& L, const float* __restrict__ emb, float u0, float u1, float u2, bool oob, float* out2) {
     const float scale = L.scale;
-    const uint32_t m1 = L.m1, m2 = L.m2, mask = L.mask;
-    const bool dense = L.dense != 0;
-    const float2* __restrict__ table = reinterpret_cast<const float2*>(emb) + L.offset;
     float p0 = fmaf(u0, scale, 0.5f), p1 = fmaf(u1, scale, 0.5f), p2 = fmaf(u2, scale, 0.5f);
     const float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
     p0 -= f0; p1 -= f1; p2 -= f2;
-    const uint32_t t0[2] = {(uint32_t)f0, (uint32_t)f0 + 1u};
-    const uint32_t t1a = (uint32_t)f1 * m1, t2a = (uint32_t)f2 * m2;
-    const uint32_t t1[2] = {t1a, t1a + m1}, t2[2] = {t2a, t2a + m2};
-    f32x2 v[8];
-#if PN_ENC_UNIFIED
-    // index = ((a0 + S) ^ X) & M with (S, X, M) = (a1 + a2, 0, ~0) on a dense level and (0, a1 ^ a2, mask) on a hashed one
-    const uint32_t dm = L.dm, M = L.xm;
+    const uint32_t g1 = (uint32_t)f1, g2 = (uint32_t)f2, a0 = (uint32_t)f0 << 3;
+    const uint32_t t0[2] = {a0 & L.mb, (a0 + 8u) & L.mb};
     uint32_t S[4], X[4];
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        S[c] = (t1[c & 1] + t2[c >> 1]) & dm;
-        X[c] = (t1[c & 1] ^ t2[c >> 1]) & ~dm;
-    }
-#pragma unroll
-    for (int idx = 0; idx < 8; idx++) {
-        const uint32_t index = ((t0[idx & 1] + S[idx >> 1]) ^ X[idx >> 1]) & M;
-        const float2 e = table[index];
-        v[idx] = f32x2{e.x, e.y};
-    }
-#else
+    S[0] = __umul24(g2, L.m2d) + (__umul24(g1, L.m1d) + L.off_b);
+    S[1] = S[0] + L.m1d;
+    S[2] = S[0] + L.m2d;
+    S[3] = S[1] + L.m2d;
+    const uint32_t h1 = g1 * L.p1b, h2 = g2 * L.p2b, h1n = h1 + L.p1b, h2n = h2 + L.p2b;
+    X[0] = (h1 ^ h2) & L.xmb;
+    X[1] = (h1n ^ h2) & L.xmb;
+    X[2] = (h1 ^ h2n) & L.xmb;
+    X[3] = (h1n ^ h2n) & L.xmb;
+    f32x2 v[8];
 #pragma unroll
     for (int idx = 0; idx < 8; idx++) {
-        const uint32_t a0 = t0[idx & 1], a1 = t1[(idx >> 1) & 1], a2 = t2[(idx >> 2) & 1];
-        const uint32_t index = dense ? (a0 + a1 + a2) : ((a0 ^ a1 ^ a2) & mask);
-        const float2 e = table[index];
+        const uint32_t boff = (t0[idx & 1] ^ X[idx >> 1]) + S[idx >> 1];
+        const float2 e = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(emb) + boff);
         v[idx] = f32x2{e.x, e.y};
     }
-#endif
-#if PN_ENC_PK
     // the eight corner weights ((1 * tx) * ty) * tz and the two channels' running sums, corner after corner as kernel_grid does them, on the
-    // packed fp32 pipe: (w_even, w_odd) pairs from v_pk_mul_f32, both channels of a corner in one v_pk_fma_f32
+    // packed fp32 pipe: (w_even, w_odd) pairs from v_pk_mul_f32, both channels of a corner in one v_pk_fma_f32 (the same roundings)
     const f32x2 q0 = {1 - p0, p0};
     const float n1 = 1 - p1, n2 = 1 - p2;
     const f32x2 qa = q0 * n1, qb = q0 * p1;
@@ -134,43 +124,18 @@ __device__ __forceinline__ void encode_level(const PnFusedLevel& L, const float*
     }
     out2[0] = oob ? 0.f : r.x;
     out2[1] = oob ? 0.f : r.y;
-#else
-    float r0 = 0.f, r1 = 0.f;
-#pragma unroll
-    for (int idx = 0; idx < 8; idx++) {
-        float w = 1;
-        w *= (idx & 1) ? p0 : 1 - p0;
-        w *= (idx & 2) ? p1 : 1 - p1;
-        w *= (idx & 4) ? p2 : 1 - p2;
-        r0 += w * v[idx].x;
-        r1 += w * v[idx].y;
-    }
-    out2[0] = oob ? 0.f : r0;
-    out2[1] = oob ? 0.f : r1;
-#endif
 }
 
-// `lv`: the 16 levels' constants (global memory: wave-uniform scalar loads); `lds_lv`: this lane half's 8 levels in LDS (PN_ENC_LDS_LV).
-// Fully unrolled in groups of LU levels (a partly unrolled loop writes feat[] through s_set_gpr_idx, four instructions per value); the
-// scheduling barrier between the groups bounds the gathers in flight per lane at 8 LU.
+// `lds_lv`: this lane half's 8 levels in LDS (lane half h: levels 8h .. 8h + 7; read per lane — as scalar loads of both halves' records every constant
+// would cost a v_mov + v_mov + v_cndmask).  Fully unrolled in groups of LU levels (a partly unrolled loop writes feat[] through s_set_gpr_idx, four
+// instructions per value); the scheduling barrier between the groups bounds the gathers in flight per lane at 8 LU.
 template <int LU>
-__device__ __forceinline__ void encode8(const PnFusedLevel* __restrict__ lv, const PnFusedLevel* lds_lv, const float* __restrict__ emb, int half,
-                                        float u0, float u1, float u2, bool oob, float* feat) {
+__device__ __forceinline__ void encode8(const PnByteLevel* lds_lv, const float* __restrict__ emb, float u0, float u1, float u2, bool oob, float* feat) {
 #pragma unroll
     for (int g = 0; g < 8; g += LU) {
 #pragma unroll
         for (int j = g; j < g + LU; j++) {
-#if PN_ENC_LDS_LV
-            const PnFusedLevel L = lds_lv[j];
-#else
-            const PnFusedLevel A = lv[j], B = lv[j + 8];  // wave-uniform
-            PnFusedLevel L;
-            L.scale = half ? B.scale : A.scale;
-            L.offset = half ? B.offset : A.offset;
-            L.m1 = half ? B.m1 : A.m1; L.m2 = half ? B.m2 : A.m2; L.mask = half ? B.mask : A.mask;
-            L.dense = half ? B.dense : A.dense;
-            L.dm = half ? B.dm : A.dm; L.xm = half ? B.xm : A.xm;
-#endif
+            const PnByteLevel L = lds_lv[j];
             encode_level(L, emb, u0, u1, u2, oob, feat + 2 * j);
         }
         if (g + LU < 8) __builtin_amdgcn_sched_barrier(0);
@@ -247,14 +212,16 @@ __device__ __forceinline__ Split8 split8_of(const f32x16& v, int r0) {
 // the pragma gives these bodies the contraction the network kernels have always been built with.
 // `wl` = the workgroup's LDS weight image + lane, `lds_lv` = this lane half's 8 level records in LDS.
 template <int LU>
-__device__ __forceinline__ f32x16 tile_sigma_net(const PnFusedLevel* __restrict__ lv, const PnFusedLevel* lds_lv, const float* __restrict__ emb,
-                                                 const uint4* __restrict__ wl, int half, float bound, float x, float y, float z) {
+__device__ __forceinline__ f32x16 tile_sigma_net(const PnByteLevel* lds_lv, const float* __restrict__ emb,
+                                                 const uint4* __restrict__ wl, int half, float bound, float inv2b, float x, float y, float z) {
 #pragma clang fp contract(fast)
-    // GridEncoder.forward: inputs = (x + bound) / (2 * bound)  (gridencoder/grid.py:149)
-    const float u0 = (x + bound) / (2 * bound), u1 = (y + bound) / (2 * bound), u2 = (z + bound) / (2 * bound);
+    // GridEncoder.forward: inputs = (x + bound) / (2 * bound)  (gridencoder/grid.py:149) — a tensor divided by a Python scalar, which torch's CUDA
+    // kernel computes as a multiplication by the scalar's fp32 reciprocal (ATen BinaryDivTrueKernel.cu, the CPU-scalar case); for the power-of-two
+    // bounds of every option set of the reference the two are the same number.  inv2b = 1.0f / (2 * bound).
+    const float u0 = (x + bound) * inv2b, u1 = (y + bound) * inv2b, u2 = (z + bound) * inv2b;
     const bool oob = (u0 < 0 || u0 > 1 || u1 < 0 || u1 > 1 || u2 < 0 || u2 > 1);
     float feat[16];
-    encode8<LU>(lv, lds_lv, emb, half, oob ? 0.f : u0, oob ? 0.f : u1, oob ? 0.f : u2, oob, feat);
+    encode8<LU>(lds_lv, emb, oob ? 0.f : u0, oob ? 0.f : u1, oob ? 0.f : u2, oob, feat);
     __builtin_amdgcn_sched_barrier(0);  // keep the next layer's LDS weight reads from being hoisted (register pressure)
     // ---- sigma net layer 0: 32 -> 64, ReLU   (groups 0..3 = tile*2 + chunk)
     f32x16 a0 = {0}, a1 = {0};
@@ -350,9 +317,13 @@ struct Split8x { uint4 hi, lo; };
 // 1 439 vector instructions per tile — the stand-alone kernel kept its accuracy but frames of the fused launch differed from the stand-alone kernel's by more
 // than 1e-5: the hazard recogniser does not look into inline assembly next to the matrix instructions.  Left to the compiler.)
 __device__ __forceinline__ void split_pair_x(float a, float b, uint32_t& hi, uint32_t& lo) {
-    const pn_h16x2 h = {(_Float16)a, (_Float16)b};
-    const pn_h16x2 l = {(_Float16)(a - (float)h.x), (_Float16)(b - (float)h.y)};
-    hi = __builtin_bit_cast(uint32_t, h);
+    float m1 = -1.0f;
+    asm("" : "+s"(m1));   // opaque: fma(h, -1, a) with a literal -1 is rewritten as a - h, which is selected as v_cvt_f32_f16 + v_sub_f32 + a conversion per value
+    const pn_h16x2 h0 = {(_Float16)a, (_Float16)b};
+    hi = __builtin_bit_cast(uint32_t, h0);
+    asm("" : "+v"(hi));   // opaque: otherwise each half is converted a second time on its own instead of being read out of the packed register
+    const pn_h16x2 h = __builtin_bit_cast(pn_h16x2, hi);
+    const pn_h16x2 l = {(_Float16)__builtin_fmaf((float)h.x, m1, a), (_Float16)__builtin_fmaf((float)h.y, m1, b)};
     lo = __builtin_bit_cast(uint32_t, l);
 }
 __device__ __forceinline__ Split8x split8x(float x0, float x1, float x2, float x3, float x4, float x5, float x6, float x7, float c) {
@@ -375,15 +346,16 @@ __device__ __forceinline__ f32x16 split_mac_x(const uint4* __restrict__ wl, int 
     acc = PN_XMFMA(wo, x.hi, acc);
     return acc;
 }
-// sf / rsf: the features' power-of-two scale and its reciprocal (layer 0 sees sf * features; its outputs are scaled back in front of layer 1's split)
+// sf: the features' power-of-two scale xs[0]; every later layer's scale sits in the weight image (pn_nerf_forward.hip: net_choose_form), so the result is
+// xs[2] * (sigma logit, geometry features): the colour net below takes it as it is, whoever wants the values multiplies by pn_net::x_rscale = 1 / xs[2].
 template <int LU>
-__device__ __forceinline__ f32x16 tile_sigma_net_x(const PnFusedLevel* __restrict__ lv, const PnFusedLevel* lds_lv, const float* __restrict__ emb,
-                                                   const uint4* __restrict__ wl, int half, float bound, float x, float y, float z, float sf, float rsf) {
+__device__ __forceinline__ f32x16 tile_sigma_net_x(const PnByteLevel* lds_lv, const float* __restrict__ emb,
+                                                   const uint4* __restrict__ wl, int half, float bound, float inv2b, float x, float y, float z, float sf) {
 #pragma clang fp contract(fast)
-    const float u0 = (x + bound) / (2 * bound), u1 = (y + bound) / (2 * bound), u2 = (z + bound) / (2 * bound);
+    const float u0 = (x + bound) * inv2b, u1 = (y + bound) * inv2b, u2 = (z + bound) * inv2b;   // see tile_sigma_net
     const bool oob = (u0 < 0 || u0 > 1 || u1 < 0 || u1 > 1 || u2 < 0 || u2 > 1);
     float feat[16];
-    encode8<LU>(lv, lds_lv, emb, half, oob ? 0.f : u0, oob ? 0.f : u1, oob ? 0.f : u2, oob, feat);
+    encode8<LU>(lds_lv, emb, oob ? 0.f : u0, oob ? 0.f : u1, oob ? 0.f : u2, oob, feat);
     __builtin_amdgcn_sched_barrier(0);
     f32x16 a0 = {0}, a1 = {0};
 #pragma unroll
@@ -398,7 +370,7 @@ __device__ __forceinline__ f32x16 tile_sigma_net_x(const PnFusedLevel* __restric
     __builtin_amdgcn_sched_barrier(0);
     f32x16 h2 = {0};
 #pragma unroll
-    for (int kc = 0; kc < 4; kc++) h2 = split_mac_x(wl, 4 + kc, split8x_of(kc < 2 ? a0 : a1, (kc & 1) * 8, rsf), h2);
+    for (int kc = 0; kc < 4; kc++) h2 = split_mac_x(wl, 4 + kc, split8x_of(kc < 2 ? a0 : a1, (kc & 1) * 8, 1.0f), h2);
     return h2;
 }
 __device__ __forceinline__ void tile_color_net_x(const uint4* __restrict__ wl, const uint4* wimg, int half, const f32x16& h2, float dx, float dy, float dz,

@@ -2243,8 +2243,8 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
         if (whole || fold || t >= fuse_from) {
             FusedArgs fa;
             memset(&fa, 0, sizeof(fa));
-            fa.lv = (const PnFusedLevel*)net->fused_levels; fa.emb = net->embeddings; fa.emb_h = (const uint32_t*)net->emb_half; fa.emb_bytes = net->n_entries * 4u;
-            fa.wimg_g = (const uint4*)(o->fp16 ? net->whalf : (net->x_ok ? net->wx : net->wsplit)); fa.net_bound = net->bound; fa.density_scale = o->density_scale;
+            fa.lv = (const PnFusedLevel*)(o->fp16 ? net->fused_levels : net->byte_levels); fa.emb = net->embeddings; fa.emb_h = (const uint32_t*)net->emb_half; fa.emb_bytes = net->n_entries * 4u;
+            fa.wimg_g = (const uint4*)(o->fp16 ? net->whalf : (net->x_ok ? net->wx : net->wsplit)); fa.net_bound = net->bound; fa.net_inv2b = 1.0f / (2 * net->bound); fa.density_scale = o->density_scale;
             fa.x_scale = net->x_scale; fa.x_rscale = net->x_rscale;
             fa.trips = f->trips + t; fa.N_rays = N; fa.max_steps = o->max_steps; fa.T_thresh = o->T_thresh;
             fa.alive = (t & 1) ? f->alive_b : f->alive_a;

@@ -45,13 +45,13 @@
 
 struct FusedArgs {
     // network (pn_net)
-    const PnFusedLevel* lv;
+    const PnFusedLevel* lv;   // the 16 level records of the network form that runs: PnFusedLevel (fp16) or PnByteLevel (fp32 forms) — the same size
     const float* emb;
     const uint32_t* emb_h;
     uint32_t emb_bytes;
     const uint4* wimg_g;  // the LDS weight image in global memory (wsplit / whalf / wx)
-    float net_bound, density_scale;
-    float x_scale, x_rscale;  // fp16 hi/lo form: the features' power-of-two scale and its reciprocal
+    float net_bound, net_inv2b, density_scale;   // net_inv2b = 1.0f / (2 * net_bound) (pn_net_tile.h: tile_sigma_net)
+    float x_scale, x_rscale;  // fp16 hi/lo form: the features' power-of-two scale xs[0]; 1 / xs[2] for the density net's outputs (pn_common.h)
     // frame
     PnTrip* trips;  // record of the first fused trip
     uint32_t N_rays, max_steps;
@@ -259,12 +259,12 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
             __builtin_amdgcn_sched_barrier(0);
             tile_color_net_h(wl, wimg, half, g2, d.x, d.y, d.z, e);
         } else if (XF) {
-            const f32x16 h2 = tile_sigma_net_x<PN_BF_LU>(fa.lv, lds_lv, fa.emb, wl, half, fa.net_bound, p.x, p.y, p.z, fa.x_scale, fa.x_rscale);
-            sigma_logit = h2[0];
+            const f32x16 h2 = tile_sigma_net_x<PN_BF_LU>(reinterpret_cast<const PnByteLevel*>(lds_lv), fa.emb, wl, half, fa.net_bound, fa.net_inv2b, p.x, p.y, p.z, fa.x_scale);
+            sigma_logit = h2[0] * fa.x_rscale;
             __builtin_amdgcn_sched_barrier(0);
             tile_color_net_x(wl, wimg, half, h2, d.x, d.y, d.z, e);
         } else {
-            const f32x16 h2 = tile_sigma_net<PN_BF_LU>(fa.lv, lds_lv, fa.emb, wl, half, fa.net_bound, p.x, p.y, p.z);
+            const f32x16 h2 = tile_sigma_net<PN_BF_LU>(reinterpret_cast<const PnByteLevel*>(lds_lv), fa.emb, wl, half, fa.net_bound, fa.net_inv2b, p.x, p.y, p.z);
             sigma_logit = h2[0];
             __builtin_amdgcn_sched_barrier(0);
             tile_color_net(wl, wimg, half, h2, d.x, d.y, d.z, e);

@@ -1,8 +1,8 @@
 """The two forms of the fp32 network's dense layers (include/pienerf_hip.h: pn_net_form): fp16 hi/lo pieces (three products per K chunk on the fp16 matrix
 pipe, the default where an interval bound over the weights and tables allows it) against three bf16 pieces (six products, any weights).  Both stand for
 NeRFNetwork.forward in fp32 (nerf/network.py:98-127): they agree with each other and with the sequential-fp32 oracle far inside the 1e-4 bar; weights
-that could push a split value past fp16's range select the bf16 form by themselves; tiny tables (features of 1e-6) keep their relative accuracy through
-the power-of-two feature scale in front of the split."""
+whose intermediates would leave fp16's range, and tiny tables (features of 1e-6), keep the form and its accuracy through the per-layer power-of-two
+scales folded into the weight image; weights without a finite positive interval bound select the bf16 form by themselves."""
 import os
 
 import numpy as np
@@ -34,9 +34,11 @@ def _model(ck, form=None):
 
 
 def _scaled(ckpt, tables=1.0, w0=1.0):
+    """w0: the first layer's weights times w0 and the second layer's divided by it (ReLU is positively homogeneous: the same network, other intermediates)."""
     ck = dict(ckpt)
     ck["embeddings"] = (ckpt["embeddings"] * np.float32(tables)).astype(np.float32)
     ck["W0"] = (ckpt["W0"] * np.float32(w0)).astype(np.float32)
+    ck["W1"] = (ckpt["W1"] / np.float32(w0)).astype(np.float32)
     return ck
 
 
@@ -62,22 +64,41 @@ def test_both_forms_agree_with_each_other_and_the_oracle(ckpt):
     assert float(np.abs(sx / sb - 1).max()) < 2e-5 and float(np.abs(cx - cb).max()) < 2e-6
 
 
-def test_weights_that_could_overflow_fp16_take_the_bf16_form(ckpt):
+def test_weights_that_would_overflow_fp16_unscaled_keep_the_form_and_the_accuracy(ckpt):
+    """The first layer's outputs reach 1e5 and more: no fp16 piece could hold them as they are; carried at the per-layer scale of net_choose_form they sit
+    where every other network's do, and the form's accuracy is that of the unscaled network (power-of-two factors are exact)."""
     x, d = _samples(8_000, 5)
-    ck = _scaled(ckpt, w0=3.0e4)   # the first layer's outputs reach 1e5 and more: no fp16 piece could hold them
+    ck = _scaled(ckpt, w0=32768.0)
     big = _model(ck)
-    assert lib().pn_net_form(big._net) == 0
+    assert lib().pn_net_form(big._net) == 2
     with torch.no_grad():
         s, c = [t.cpu().numpy() for t in big(T(x), T(d))]
     want_s, want_c = oracle.nerf_forward(x, d, ck, 1.0)
     assert np.isfinite(s).all() and np.isfinite(c).all() and np.isfinite(want_s).all()
-    assert float(np.abs(c - want_c).max()) < 1e-4
+    assert float(np.abs(c - want_c).max()) < 2e-6
     fin = want_s > 0
-    assert float(np.abs(s[fin] / want_s[fin] - 1).max()) < 1e-4
+    assert float(np.abs(s[fin] / want_s[fin] - 1).max()) < 2e-5
+
+
+def test_weights_without_a_finite_bound_take_the_bf16_form(ckpt):
+    """An all-zero layer (bound 0) or an infinite weight: no scale to choose, the three-way bf16 split runs and gives what fp32 arithmetic gives."""
+    x, d = _samples(4_000, 6)
+    ck = dict(ckpt)
+    ck["W1"] = np.zeros_like(ckpt["W1"])
+    zero = _model(ck)
+    assert lib().pn_net_form(zero._net) == 0
+    with torch.no_grad():
+        s, c = [t.cpu().numpy() for t in zero(T(x), T(d))]
+    want_s, want_c = oracle.nerf_forward(x, d, ck, 1.0)
+    assert float(np.abs(s - want_s).max()) < 1e-5 and float(np.abs(c - want_c).max()) < 2e-6
+    ck = dict(ckpt)
+    ck["W3"] = ckpt["W3"].copy()
+    ck["W3"][5, 7] = np.inf
+    assert lib().pn_net_form(_model(ck)._net) == 0
 
 
 def test_tiny_tables_keep_their_accuracy(ckpt):
-    """Features of 1e-6: as fp16 pieces they would be subnormal (6e-8 absolute, percents of the value); the scale in front of the split keeps 22 bits."""
+    """Features of 1e-6 and hidden activations of 1e-5: as fp16 pieces they would be subnormal (6e-8 absolute, percents of the value); the layers' scales keep 22 bits."""
     x, _ = _samples(30_000, 7)
     ck = _scaled(ckpt, tables=1e-5)
     tiny_x, tiny_b = _model(ck), _model(ck, "bf16")
