@@ -505,7 +505,7 @@ def main():
                     help="N > 1: the sim owner only simulates and broadcasts, the other ranks render (auto: from 3 ranks on, frames.dedicated_sim_default)")
     ap.add_argument("--force", type=float, nargs=3, default=None, metavar=("FX", "FY", "FZ"),
                     help="constant update_force on the middle integration point (SURVEY 8d, config 2 second pass); default: per config")
-    ap.add_argument("--probe", choices=("none", "no-substep", "sim-priority", "sim-cus"), default="none",
+    ap.add_argument("--probe", choices=("none", "no-substep", "sim-priority", "sim-cus", "render-excl"), default="none",
                     help="diagnosis (value is then NOT the benchmark): the pipeline without the substep's launches / with the simulator stream at high priority / on 16 CUs of its own")
     ap.add_argument("--form", choices=("auto", "whole", "fold", "plain", "trips"), default="auto",
                     help="form of a frame's launches in the pipeline (auto: what harness.capture_pipelined picks from a warm-up frame): the whole frame in the fused "
@@ -580,7 +580,8 @@ def main():
         else:
             # --config stress: opt["ray_batch"] = 4096 (set above) — the frame's 157 ray batches keep their own trip schedules inside the same
             # launches (pn_render_opts.ray_batch), so the staged frame runs on the same pipeline as the frame in one piece
-            probe_kw = {"no-substep": dict(_probe_no_substep=True), "sim-priority": dict(sim_priority=-1), "sim-cus": dict(sim_cus=int(os.environ.get("PN_PROBE_SIM_CUS", "16")))}.get(args.probe, {})
+            probe_kw = {"no-substep": dict(_probe_no_substep=True), "sim-priority": dict(sim_priority=-1), "sim-cus": dict(sim_cus=int(os.environ.get("PN_PROBE_SIM_CUS", "16"))),
+                        "render-excl": dict(sim_cus=-int(os.environ.get("PN_PROBE_RENDER_EXCL", "32")))}.get(args.probe, {})
             form_render_kw = {"whole": dict(fused_from=0, fused_whole=True, fused_fold=False), "fold": dict(fused_from=1, fused_whole=False, fused_fold=True),
                               "plain": dict(fused_from=1, fused_whole=False, fused_fold=False), "trips": dict(fused_from=-1, fused_whole=False, fused_fold=False)}.get(args.form)
             if form_render_kw is not None:

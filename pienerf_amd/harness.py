@@ -474,6 +474,10 @@ class _HipBackend:
             # the render lanes the rest, so a substep never waits for a render wave to release registers
             self._streams = {"sim": h._cu_masked_stream(0, sim_cus, invert=False)}
             lane_streams = [h._cu_masked_stream(0, sim_cus, invert=True) for _ in range(lanes)]
+        elif sim_cus < 0:
+            # the converse: the render lanes stay off -sim_cus CUs, the simulator may use every CU — its launches always find those free, and whatever else is
+            self._streams = {"sim": torch.cuda.Stream(dev, priority=sim_priority)}
+            lane_streams = [h._cu_masked_stream(0, -sim_cus, invert=True) for _ in range(lanes)]
         else:
             self._streams = {"sim": torch.cuda.Stream(dev, priority=sim_priority)}
             lane_streams = [torch.cuda.Stream(dev) for _ in range(lanes)]
