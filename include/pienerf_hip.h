@@ -173,8 +173,9 @@ int pn_net_update(pn_net* net, const float* embeddings, const float* W0_host, co
                   const float* W4_host, void* stream);
 /* Form of the fp32 network's dense layers on `net` (chosen by pn_net_create / pn_net_update from the weights and the tables): 2 = fp16 hi/lo pieces on the
  * fp16 matrix pipe (every fp32 value as hi + lo, 22 significant bits; three products per K chunk; 4e-6 relative on sigma against the sequential fp32 oracle,
- * as the bf16 form) — taken when an interval bound over the weights keeps every split value below 60 000; 0 = three bf16 pieces, six products (any weights).
- * PN_NET_FORM=bf16 in the environment forces 0. */
+ * as the bf16 form), every layer's inputs carried at the power of two that puts their interval bound (tables' largest entry x row sums of |W|) into
+ * [2^13, 2^14], the scales folded into the weight image — taken whenever those bounds are finite and positive; 0 = three bf16 pieces, six products (any
+ * weights: an all-zero layer, a non-finite weight).  PN_NET_FORM=bf16 in the environment forces 0. */
 int pn_net_form(const pn_net* net);
 /* Creates the fp16 copy of the hash tables (`embeddings.to(torch.half)`, gridencoder/grid.py:43-44; round to nearest even) once; the fp16
  * weight image always exists.  Call before the first *_half launch or fp16 render, outside stream capture. */
