@@ -147,6 +147,12 @@ int pn_composite_rays_train_backward(const float* grad_weights_sum, const float*
 int pn_grid_encode_backward(const float* grad, const float* inputs, const float* embeddings, const int* offsets_host, float* grad_embeddings,
                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const float* dy_dx, float* grad_inputs,
                             uint32_t gridtype, int align_corners, uint32_t interp, void* stream);
+/* The same under autocast (kernel_grid_backward<at::Half>, gridencoder.cu:248-341 with the __half2 atomicAdd of :324-331; grid.py:43-44 casts the table to
+ * half): grad [L,B,C] half, grad_embeddings [sO,C] HALF, zero-filled by the caller; every contribution is rounded to half and accumulated with packed
+ * half atomics (global_atomic_pk_add_f16), C in {2, 4, 8}.  The sum of halves depends on the order the atomics meet in, here as in the reference: results
+ * agree with the fp32 backward to the rounding of half sums.  No input gradients on this path. */
+int pn_grid_encode_backward_half(const uint16_t* grad, const float* inputs, const int* offsets_host, uint16_t* grad_embeddings, uint32_t B, uint32_t D,
+                                 uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, void* stream);
 /* grad_total_variation (gridencoder.h:15, kernel gridencoder.cu:506-611): grad [sO,C] += TV gradient at the cells of `inputs` [B,3] in [0,1]. */
 int pn_grad_total_variation(const float* inputs, const float* embeddings, float* grad, const int* offsets_host, float weight, uint32_t B, uint32_t D,
                             uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, void* stream);

@@ -58,6 +58,7 @@ SIGNATURES = {
     "pn_composite_rays_train_forward": (i32, [P, P, P, P, u32, u32, f32, P, P, P, P]),
     "pn_composite_rays_train_backward": (i32, [P, P, P, P, P, P, P, P, u32, u32, f32, P, P, P]),
     "pn_grid_encode_backward": (i32, [P, P, P, P, P, u32, u32, u32, u32, f32, u32, P, P, u32, i32, u32, P]),
+    "pn_grid_encode_backward_half": (i32, [P, P, P, P, u32, u32, u32, u32, f32, u32, u32, i32, u32, P]),
     "pn_grad_total_variation": (i32, [P, P, P, P, f32, u32, u32, u32, u32, f32, u32, u32, i32, P]),
     "pn_sh_encode_backward": (i32, [P, P, u32, u32, u32, P, P, P]),
     "pn_march_rays": (i32, [u32, u32, P, P, P, P, f32, f32, u32, u32, u32, P, P, P, P, P, P, P, P]),

@@ -130,6 +130,64 @@ __global__ void __launch_bounds__(256) k_grid_backward(const float* __restrict__
     }
 }
 
+// kernel_grid_backward<at::Half> (gridencoder.cu:248-341; the table is half under autocast, grid.py:43-44): grad [L,B,C] half, every contribution
+// rounded to half — (__half)(w * grad), :327 — and accumulated into the half table two channels at a time (:324-331: atomicAdd on a __half2; here
+// global_atomic_pk_add_f16).  The order in which contributions meet is the atomics' in the reference, so its result is only defined up to the rounding of
+// a sum of halves; the runs of equal rows inside a wave are folded first as above, with half additions (each partial sum rounded to half, as an atomic
+// would leave it), and the run heads issue the atomics.  C even (the reference uses this path for N_C % 2 == 0; with one channel autocast keeps fp32).
+typedef _Float16 pn_gh2 __attribute__((ext_vector_type(2)));
+template <uint32_t C>
+__global__ void __launch_bounds__(256) k_grid_backward_h(const _Float16* __restrict__ grad, const float* __restrict__ inputs, PnGridLevels lv, uint32_t B,
+                                                         int align_corners, uint32_t interp, _Float16* __restrict__ grad_emb) {
+    static_assert(C % 2 == 0, "channel pairs");
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t level = blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63;
+    Cell c;
+    const bool valid = b < B && locate(inputs + (size_t)b * 3, lv.scale[level], align_corners, interp, c);
+    _Float16* __restrict__ gt = grad_emb + (size_t)lv.offset[level] * C;
+    const LevelIdx LI = level_idx(lv, level, align_corners);
+    float g[C];
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) g[ch] = valid ? (float)grad[((size_t)level * B + b) * C + ch] : 0.0f;
+#pragma unroll
+    for (uint32_t idx = 0; idx < 8; idx++) {
+        float w = 1;
+        uint32_t pl[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            if ((idx & (1u << d)) == 0) { w *= 1 - c.pos[d]; pl[d] = c.pg[d]; }
+            else { w *= c.pos[d]; pl[d] = c.pg[d] + 1; }
+        }
+        const uint32_t row = valid ? grid_index3(LI, pl[0], pl[1], pl[2]) : 0xFFFFFFFFu;
+        _Float16 v[C];
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ch++) v[ch] = valid ? (_Float16)(w * g[ch]) : (_Float16)0.0f;
+        const uint32_t prev = __shfl_up(row, 1, 64);
+        const bool head = lane == 0 || prev != row;
+        const unsigned long long heads = __ballot(head);
+        const uint32_t run = __popcll(heads & ((2ull << lane) - 1ull));
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t run2 = __shfl_down(run, off, 64);
+            const bool take = lane + off < 64 && run2 == run;
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch += 2) {
+                const pn_gh2 mine = {v[ch], v[ch + 1]};
+                const pn_gh2 o = __builtin_bit_cast(pn_gh2, __shfl_down(__builtin_bit_cast(int, mine), off, 64));
+                if (take) { v[ch] = v[ch] + o.x; v[ch + 1] = v[ch + 1] + o.y; }
+            }
+        }
+        if (head && row != 0xFFFFFFFFu) {
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch += 2) {
+                const pn_gh2 pk = {v[ch], v[ch + 1]};
+                __builtin_amdgcn_global_atomic_fadd_v2f16(reinterpret_cast<pn_gh2*>(gt + (size_t)row * C + ch), pk);
+            }
+        }
+    }
+}
+
 // grad_inputs[b, d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c] (gridencoder.cu:343-369)
 __global__ void __launch_bounds__(256) k_grid_input_backward(const float* __restrict__ grad, const float* __restrict__ dy_dx, float* __restrict__ grad_inputs,
                                                              uint32_t B, uint32_t L, uint32_t C) {
@@ -263,6 +321,27 @@ extern "C" int pn_grid_encode_backward(const float* grad, const float* inputs, c
         default: k_grid_backward<8><<<grid, 256, 0, st>>>(grad, inputs, lv, B, align_corners, interp, grad_embeddings); break;
     }
     if (dy_dx) k_grid_input_backward<<<pn_div_up((uint64_t)B * 3, 256), 256, 0, st>>>(grad, dy_dx, grad_inputs, B, L, C);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+extern "C" int pn_grid_encode_backward_half(const uint16_t* grad, const float* inputs, const int* offsets_host, uint16_t* grad_embeddings, uint32_t B,
+                                            uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp,
+                                            void* stream) {
+    if (B == 0) return PN_OK;
+    PN_REQUIRE(grad && inputs && offsets_host && grad_embeddings);
+    PN_REQUIRE(D == 3 && (C == 2 || C == 4 || C == 8) && gridtype <= 1 && interp <= 1);
+    PnGridLevels lv;
+    if (pn_fill_grid_levels(&lv, offsets_host, L, C, S, H, gridtype, align_corners)) { PN_REQUIRE(L >= 1 && L <= PN_MAX_LEVELS); }
+    dim3 grid(pn_div_up(B, 256), L, 1);
+    hipStream_t st = (hipStream_t)stream;
+    const _Float16* g = reinterpret_cast<const _Float16*>(grad);
+    _Float16* ge = reinterpret_cast<_Float16*>(grad_embeddings);
+    switch (C) {
+        case 2: k_grid_backward_h<2><<<grid, 256, 0, st>>>(g, inputs, lv, B, align_corners, interp, ge); break;
+        case 4: k_grid_backward_h<4><<<grid, 256, 0, st>>>(g, inputs, lv, B, align_corners, interp, ge); break;
+        default: k_grid_backward_h<8><<<grid, 256, 0, st>>>(g, inputs, lv, B, align_corners, interp, ge); break;
+    }
     PN_LAUNCH_CHECK();
     return PN_OK;
 }

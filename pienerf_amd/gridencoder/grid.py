@@ -4,7 +4,7 @@ Interface replaced: /root/reference/gridencoder/grid.py:24-63 (``_grid_encode.fo
 :96-161 (``GridEncoder``): same call signatures, same module attributes / state-dict keys
 (``offsets`` buffer, ``embeddings`` parameter).  Forward is on the simulate-and-render path; backward, dy_dx and
 ``grad_total_variation`` (:65-92,168-190) are the training side.  Under autocast the forward runs on a half copy of the
-table (grid.py:43-44: ``embeddings.to(torch.half)``) and returns half features (inference only: the half backward is not built).
+table (grid.py:43-44: ``embeddings.to(torch.half)``) and returns half features; its backward is the half scatter-add of gridencoder.cu:324-331.
 """
 import math
 
@@ -34,7 +34,7 @@ class _grid_encode(torch.autograd.Function):
     grid.py:47,57), plus the dy_dx launch when ``calc_grad_inputs``.  Backward (training side): scatter-add into
     grad_embeddings with hardware fp32 atomics and, with dy_dx, the chain rule to the inputs.  Autocast (grid.py:43-44): when
     ``torch.is_autocast_enabled()`` and C is even, the table is cast to half, the kernel is kernel_grid<at::Half> and the features come
-    back in half — forward only (fp16 training is not built: it raises if a gradient is requested)."""
+    back in half; the backward then accumulates a half grad_embeddings with packed half atomics (kernel_grid_backward<at::Half>); input gradients: fp32 path only."""
 
     @staticmethod
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0, align_corners=False,
@@ -47,15 +47,23 @@ class _grid_encode(torch.autograd.Function):
             offsets_host = offsets.detach().to("cpu", torch.int32).contiguous()
         log2_scale = float(np.float32(np.log2(per_level_scale)))  # the reference passes S = log2(per_level_scale) as a float (grid.py:37)
         if (torch.is_autocast_enabled() and C % 2 == 0) or embeddings.dtype == torch.float16:  # grid.py:41-44
-            if calc_grad_inputs or (embeddings.requires_grad and torch.is_grad_enabled()):
-                raise RuntimeError("grid_encode: the half-precision path is inference-only (fp16 training is not built); disable autocast to train")
+            if calc_grad_inputs:
+                raise RuntimeError("grid_encode: input gradients are not built on the half-precision path; disable autocast for them")
             table = embeddings.detach().to(torch.float16).contiguous()
             require_gpu(x, table)
             feats = torch.empty(B, n_levels * C, device=x.device, dtype=torch.float16)
             check(lib().pn_grid_encode_forward_half(ptr(x), ptr(table), offsets_host.data_ptr(), ptr(feats), B, D, C, n_levels, log2_scale,
                                                     int(base_resolution), int(gridtype), int(bool(align_corners)), int(interpolation), 1, stream_ptr()),
                   "grid_encode_forward_half")
-            ctx.mark_non_differentiable(feats)
+            if ctx.needs_input_grad[1]:   # fp16 training (trainer.py:561 with --fp16): the half backward below
+                ctx.save_for_backward(x)
+                ctx.half = True
+                ctx.table_shape, ctx.table_dtype = tuple(embeddings.shape), embeddings.dtype
+                ctx.dims = [B, D, C, n_levels, log2_scale, int(base_resolution), int(gridtype), int(interpolation)]
+                ctx.align_corners = bool(align_corners)
+                ctx.offsets_host = offsets_host
+            else:
+                ctx.mark_non_differentiable(feats)
             return feats
         table = embeddings.to(torch.float32).contiguous()
         require_gpu(x, table)
@@ -65,6 +73,7 @@ class _grid_encode(torch.autograd.Function):
                                           ptr(dy_dx), int(gridtype), int(bool(align_corners)), int(interpolation), 1, stream_ptr())
         check(rc, "grid_encode_forward")
         ctx.save_for_backward(x, table, dy_dx)
+        ctx.half = False
         ctx.dims = [B, D, C, n_levels, log2_scale, int(base_resolution), int(gridtype), int(interpolation)]
         ctx.align_corners = bool(align_corners)
         ctx.offsets_host = offsets_host
@@ -72,6 +81,14 @@ class _grid_encode(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad):
+        if ctx.half:   # grid.py:65-92 with a half table: grad_embeddings in half (autograd casts it to the parameter's dtype)
+            (x,) = ctx.saved_tensors
+            B, D, C, L, S, H, gridtype, interpolation = ctx.dims
+            grad = grad.to(torch.float16).view(B, L, C).permute(1, 0, 2).contiguous()
+            grad_embeddings = torch.zeros(ctx.table_shape, device=x.device, dtype=torch.float16)
+            check(lib().pn_grid_encode_backward_half(ptr(grad), ptr(x), ctx.offsets_host.data_ptr(), ptr(grad_embeddings), B, D, C, L, S, H, gridtype,
+                                                     int(ctx.align_corners), interpolation, stream_ptr()), "grid_encode_backward_half")
+            return None, grad_embeddings.to(ctx.table_dtype), None, None, None, None, None, None, None, None
         x, table, dy_dx = ctx.saved_tensors
         B, D, C, L, S, H, gridtype, interpolation = ctx.dims
         grad = grad.to(torch.float32).view(B, L, C).permute(1, 0, 2).contiguous()  # [B, L*C] -> [L, B, C] (grid.py:73)

@@ -74,9 +74,13 @@ class ParamEMA:
 
 
 class Trainer:
-    def __init__(self, model, opt, lr=1e-2, iters=30000, update_extra_interval=16, num_rays=4096, ema_decay=None):
-        """ema_decay: main_train.py:78 passes 0.95; None (default) trains without an average, like Trainer's own default (trainer.py:19)."""
+    def __init__(self, model, opt, lr=1e-2, iters=30000, update_extra_interval=16, num_rays=4096, ema_decay=None, fp16=False):
+        """ema_decay: main_train.py:78 passes 0.95; None (default) trains without an average, like Trainer's own default (trainer.py:19).
+        fp16 (trainer.py:20,84: ``--fp16``): the steps run under autocast with a GradScaler — half hash tables, half nn.Linear, and the half
+        scatter-add of the grid's backward (gridencoder.cu:324-331)."""
         self.model, self.opt = model, dict(opt)
+        self.fp16 = bool(fp16)
+        self.scaler = torch.amp.GradScaler("cuda", enabled=self.fp16)   # trainer.py:84
         self.optimizer = torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
         self.lr_scheduler = torch.optim.lr_scheduler.LambdaLR(self.optimizer, lambda it: 0.1 ** min(it / iters, 1))
         self.criterion = torch.nn.MSELoss(reduction="none")
@@ -109,12 +113,15 @@ class Trainer:
         losses = []
         for _ in range(steps):
             if self.model.cuda_ray and self.global_step % self.update_extra_interval == 0:
-                self.model.update_extra_state()
+                with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):   # trainer.py:629
+                    self.model.update_extra_state()
             self.global_step += 1
             self.optimizer.zero_grad()
-            _, _, loss = self.train_step(dataset.batch(self.num_rays))
-            loss.backward()
-            self.optimizer.step()
+            with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):       # trainer.py:637
+                _, _, loss = self.train_step(dataset.batch(self.num_rays))
+            self.scaler.scale(loss).backward()                                         # trainer.py:640-642
+            self.scaler.step(self.optimizer)
+            self.scaler.update()
             self.lr_scheduler.step()
             if self.ema is not None:  # trainer.py:643-644
                 self.ema.update()

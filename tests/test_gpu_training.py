@@ -133,6 +133,38 @@ def test_grid_encode_backward_and_dy_dx(interp, log2_T):
     assert rel(te2.grad.cpu().numpy(), ge_r) < 1e-4
 
 
+@pytest.mark.parametrize("interp,log2_T,C", [(0, 12, 2), (1, 12, 4), (0, 19, 2)])
+def test_grid_encode_backward_under_autocast(interp, log2_T, C):
+    """kernel_grid_backward<at::Half> (gridencoder.cu:248-341; the __half2 atomicAdd of :324-331): under autocast the table is half (grid.py:43-44),
+    every contribution (__half)(w * grad) is accumulated in half, in the order the atomics meet.  Against the oracle's backward on the same
+    half-rounded gradients: each table entry within the rounding a sum of its contributions' halves can have (contributions x half epsilon x the
+    largest partial sum), and nothing lost (the fp32 sums agree to 1e-2 of the largest entry); rows no sample touches stay exactly zero."""
+    pls, base, L = 1.6, 8, 6
+    offsets = level_table_offsets(3, L, pls, base, log2_T, False)
+    rng = np.random.default_rng(16)
+    emb = rng.uniform(-1, 1, (int(offsets[-1]), C)).astype(np.float32)
+    B = 20000
+    x = rng.uniform(0, 1, (B, 3)).astype(np.float32)
+    x[:9] = [1.2, 0.5, 0.5]
+    grad = (rng.standard_normal((B, L * C)) * 1e-2).astype(np.float16)
+    _, ge_r = otr.grid_encode_backward(grad.astype(np.float32), x, emb.shape, offsets, pls, base, None, 0, False, interp)
+    _, ge_abs = otr.grid_encode_backward(np.abs(grad.astype(np.float32)), x, emb.shape, offsets, pls, base, None, 0, False, interp)
+    te = T(emb).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = grid_encode(T(x), te, T(offsets), pls, base, False, 0, False, interp)
+    assert y.dtype == torch.float16 and y.requires_grad
+    y.backward(torch.from_numpy(grad).to(DEV))
+    got = te.grad.cpu().numpy()
+    assert te.grad.dtype == torch.float32 and np.isfinite(got).all()
+    # a sum of n halves, every term and every partial sum rounded to half (2^-11 relative), partial sums bounded by the sum of magnitudes; the order is the
+    # atomics' (it changes from run to run): |error| <= 2^-6 x sum |terms| covers the coarse levels' hundreds of contributions per entry with room
+    assert (np.abs(got - ge_r) <= 2.0 ** -6 * ge_abs + 1e-6).all(), float((np.abs(got - ge_r) - 2.0 ** -6 * ge_abs).max())
+    assert rel(got, ge_r) < 1e-2
+    assert not got[ge_abs == 0].any()
+    with pytest.raises(RuntimeError), torch.autocast("cuda", dtype=torch.float16):
+        grid_encode(T(x).requires_grad_(True), te, T(offsets), pls, base, True, 0, False, interp)
+
+
 def test_grid_encoder_module_gradients_on_the_chair_tables(ckpt):
     """The real table geometry (16 levels, 2^19 entries, 6.1 M rows): autograd through GridEncoder against the oracle."""
     enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048).to(DEV)

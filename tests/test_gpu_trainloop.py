@@ -91,7 +91,10 @@ def test_update_extra_state_and_mark_untrained_grid():
     assert net.iter_density == 17 and bool((net.density_grid[~ok] == -1).all())
 
 
-def test_training_fits_the_teacher_images():
+@pytest.mark.parametrize("fp16", [False, True])
+def test_training_fits_the_teacher_images(fp16):
+    """fp16 (trainer.py:20,84,629-642: ``--fp16``): the same run under autocast with a GradScaler — half tables and features, the half scatter-add of the
+    grid's backward (gridencoder.cu:324-331), half nn.Linear."""
     ck, teacher = _teacher()
     Wd = 64
     intr = scene.orbit_intrinsics(Wd, Wd, 50.0)
@@ -108,7 +111,7 @@ def test_training_fits_the_teacher_images():
     torch.manual_seed(1)
     student = NeRFNetwork(encoding="hashgrid", bound=1.0, cuda_ray=True, density_thresh=10).to(DEV)
     data = RayImageSet(T(poses), intr, images, generator=torch.Generator().manual_seed(2))
-    tr = Trainer(student, dict(dt_gamma=0, max_steps=512, T_thresh=1e-2), lr=1e-2, iters=400, num_rays=2048)
+    tr = Trainer(student, dict(dt_gamma=0, max_steps=512, T_thresh=1e-2), lr=1e-2, iters=400, num_rays=2048, fp16=fp16)
     psnr0, _ = tr.evaluate(data, 0)
     losses = tr.train(data, 400)
     psnr1, out = tr.evaluate(data, 0)
