@@ -505,6 +505,7 @@ def main():
                     help="N > 1: the sim owner only simulates and broadcasts, the other ranks render (auto: from 3 ranks on, frames.dedicated_sim_default)")
     ap.add_argument("--force", type=float, nargs=3, default=None, metavar=("FX", "FY", "FZ"),
                     help="constant update_force on the middle integration point (SURVEY 8d, config 2 second pass); default: per config")
+    ap.add_argument("--sim-on-lanes", action="store_true", help="experiment: no simulator stream, substep g rides on render lane g %% lanes (frames.FramePipeline.sim_on_lanes)")
     ap.add_argument("--probe", choices=("none", "no-substep", "sim-priority", "sim-cus", "render-excl"), default="none",
                     help="diagnosis (value is then NOT the benchmark): the pipeline without the substep's launches / with the simulator stream at high priority / on 16 CUs of its own")
     ap.add_argument("--form", choices=("auto", "whole", "fold", "plain", "trips"), default="auto",
@@ -586,6 +587,8 @@ def main():
                               "plain": dict(fused_from=1, fused_whole=False, fused_fold=False), "trips": dict(fused_from=-1, fused_whole=False, fused_fold=False)}.get(args.form)
             if form_render_kw is not None:
                 probe_kw["render_kw"] = form_render_kw
+            if args.sim_on_lanes:
+                probe_kw["sim_on_lanes"] = True
             h.capture_pipelined(lanes=args.lanes, depth=args.depth, n_trips=args.trips, copy_out=copy_out, copy_on=args.copy_on, **probe_kw)
             args.trips = h._pipe_backend.trips
             run_steps = lambda n: [h.step_pipelined() for _ in range(n)]

@@ -118,7 +118,8 @@ class FramePipeline:
         result(ws) -> object      [host] what step() hands back for a retired frame
     """
 
-    def __init__(self, backend, world=1, rank=0, lanes=2, depth=2, ahead=None, sim_owner=0, dedicated_sim=None, copy_out=True, on_retire=None, force_collectives=False):
+    def __init__(self, backend, world=1, rank=0, lanes=2, depth=2, ahead=None, sim_owner=0, dedicated_sim=None, copy_out=True, on_retire=None, force_collectives=False,
+                 sim_on_lanes=False):
         self.b, self.world, self.rank, self.lanes, self.depth, self.owner = backend, int(world), int(rank), int(lanes), int(depth), int(sim_owner)
         self.dedicated = dedicated_sim_default(self.world) if dedicated_sim is None else bool(dedicated_sim and self.world > 1)
         self.ahead = self.world * self.lanes * self.depth if ahead is None else int(ahead)
@@ -146,6 +147,22 @@ class FramePipeline:
         self.bc_next = 0          # next broadcast this rank enqueues
         self.retired = []         # (frame, result) of workspaces retired by the last step()
         self.last_ws, self.last_frame = None, None
+        # sim_on_lanes (one rank): no simulator stream — substep g rides on render lane g % lanes, in front of that lane's next frame, chained to substep
+        # g - 1 by an event.  The part runs four hardware queues side by side: the queue the simulator does not take is a fourth render lane.
+        self.sim_on_lanes = bool(sim_on_lanes) and self.world == 1
+        self.sub_done = [b.event() for _ in range(self.lanes + 2)] if self.sim_on_lanes else []
+        self.force_done, self.force_pending = (b.event() if self.sim_on_lanes else None), False
+
+    # a force change between two substeps (Simulator.update_force on the backend's 'sim' stream, which then carries nothing else): behind the last substep
+    # enqueued, in front of the next one
+    def before_force(self):
+        if self.sim_on_lanes and self.sim_next > 0:
+            self.s_sim.wait(self.sub_done[(self.sim_next - 1) % len(self.sub_done)])
+
+    def after_force(self):
+        if self.sim_on_lanes:
+            self.force_done.record(self.s_sim)
+            self.force_pending = True
 
     # ------------------------------------------------------------------ per-frame
     def _ws(self, k):
@@ -155,14 +172,24 @@ class FramePipeline:
     def _advance_simulator(self, upto):
         b, S = self.b, self.slots
         while self.sim_next <= upto:
-            slot = self.sim_next % S
+            g = self.sim_next
+            slot = g % S
+            s = self.s_lane[g % self.lanes] if self.sim_on_lanes else self.s_sim
+            if self.sim_on_lanes:
+                if g > 0:
+                    s.wait(self.sub_done[(g - 1) % len(self.sub_done)])   # the simulator is time-sequential: behind the previous substep, wherever it ran
+                if self.force_pending:
+                    s.wait(self.force_done)
+                    self.force_pending = False
             if self.bc_used[slot]:
-                self.s_sim.wait(self.bc_done[slot])    # the slot's previous snapshot has been sent ...
+                s.wait(self.bc_done[slot])    # the slot's previous snapshot has been sent ...
             if self.ip_used[slot]:
-                self.s_sim.wait(self.ip_done[slot])    # ... and consumed by this rank's own render
-            b.snapshot(self.s_sim, slot)
-            self.snap_ready[slot].record(self.s_sim)
-            b.substep(self.s_sim)
+                s.wait(self.ip_done[slot])    # ... and consumed by this rank's own render
+            b.snapshot(s, slot)
+            self.snap_ready[slot].record(s)
+            b.substep(s)
+            if self.sim_on_lanes:
+                self.sub_done[g % len(self.sub_done)].record(s)
             self.sim_next += 1
 
     def _broadcasts(self, upto):
@@ -338,6 +365,7 @@ class SimulatedBackend:
 
         def run():
             prev = self.snap_tag.get(slot)
+            assert self.steps == g, f"snapshot of frame {g} taken after {self.steps} substeps"   # the state BEFORE the frame's own substep (trainer.py:300-318)
             assert self.readers_left.get((slot, prev), 0) == 0, f"snapshot slot {slot} overwritten with frame {g} while frame {prev} still has readers"
             self.snap[slot] = self.dof.clone()
             self.snap_tag[slot] = g

@@ -224,7 +224,7 @@ class SimRenderHarness:
     @torch.no_grad()
     def capture_pipelined(self, lanes=2, n_trips=8, W=None, H=None, sim_ahead=None, depth=2, sim_priority=0, sim_cus=0, copy_out=True, group=None,
                           frame_parallel=False, sim_owner=0, dedicated_sim=None, on_retire=None, copy_on="host", _probe_no_substep=False, _time_trips=False,
-                          render_kw=None, _force_collectives=False):
+                          render_kw=None, _force_collectives=False, sim_on_lanes=False):
         """Throughput mode (pienerf_amd/frames.py: FramePipeline): `lanes` render streams with `depth` workspaces each, the simulator running
         `sim_ahead` frames ahead on dof snapshots, every frame's image / depth / depth_0 copied to pinned host memory (the reference's
         device->host boundary, trainer.py:589-592; copy_out=False leaves the results on the device) — copy_on="host": by the library's copier
@@ -267,7 +267,8 @@ class SimRenderHarness:
                          render_kw=render_kw)
         self._pipe = FramePipeline(be, world=world, rank=rank, lanes=lanes, depth=depth, ahead=(lanes if sim_ahead is None and world == 1 else sim_ahead),
                                    sim_owner=sim_owner, dedicated_sim=dedicated_sim, copy_out=copy_out, on_retire=on_retire,
-                                   force_collectives=bool(_force_collectives) and on)
+                                   force_collectives=bool(_force_collectives) and on, sim_on_lanes=sim_on_lanes)
+        self.sim.force_hooks = (self._pipe.before_force, self._pipe.after_force) if self._pipe.sim_on_lanes else None
         self._pipe_backend = be
         self.model._in_flight = lambda pipe=self._pipe: sum(f is not None for f in pipe.pending)  # weight refreshes need a drained pipeline (network._net_handle)
         return self

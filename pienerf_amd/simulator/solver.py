@@ -55,6 +55,7 @@ class Simulator:
         # on a stream of their own (harness.py: overlap_sim, capture_pipelined) sets it to that stream, so that a force change is ordered
         # BETWEEN two substeps instead of racing with one
         self.force_stream = None
+        self.force_hooks = None   # (before, after): a pipeline whose substeps do not run on force_stream orders the change between two of them (frames.FramePipeline)
 
     # ------------------------------------------------------------------ IO (solver.py:109-137)
     def InitializeFromPly(self, path):
@@ -281,6 +282,8 @@ class Simulator:
         st = self.force_stream
         if st is not None:  # ordered between two substeps of the simulator's own stream, after whatever the caller has enqueued so far
             st.wait_stream(torch.cuda.current_stream(self.device))
+            if self.force_hooks:
+                self.force_hooks[0]()
         with torch.cuda.stream(st) if st is not None else _null_ctx():
             check(lib().pn_sim_update_force(self.n_k, int(vid), f3.ctypes.data if f3 is not None else None, float(self.dx), ptr(self.IP_kernel),
                                             ptr(self.IP_rho), ptr(self.IP_Nx), ptr(self.dof_f), stream_ptr()), "update_force")
@@ -290,6 +293,8 @@ class Simulator:
             ev = torch.cuda.Event()
             ev.record(st)
             torch.cuda.current_stream(self.device).wait_event(ev)
+            if self.force_hooks:
+                self.force_hooks[1]()
 
     def update_force(self, vid, f):  # solver.py:578-588
         """dof_f = the pick force `f` on IP `vid`, written whole by one launch on `force_stream` (or the current stream): it acts from the

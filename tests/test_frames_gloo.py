@@ -29,10 +29,10 @@ def _serial(n_frames, n_dof=64):
     return want
 
 
-def _run_rank(rank, world, n_frames, lanes, depth, dedicated, seed, ahead=None, short=()):
+def _run_rank(rank, world, n_frames, lanes, depth, dedicated, seed, ahead=None, short=(), sim_on_lanes=False):
     from pienerf_amd.frames import FramePipeline, SimulatedBackend
     be = SimulatedBackend(world, rank, seed=seed, needs_more_trips=lambda f: f in short)
-    pipe = FramePipeline(be, world=world, rank=rank, lanes=lanes, depth=depth, dedicated_sim=dedicated, ahead=ahead)
+    pipe = FramePipeline(be, world=world, rank=rank, lanes=lanes, depth=depth, dedicated_sim=dedicated, ahead=ahead, sim_on_lanes=sim_on_lanes)
     got = []
     for f in range(n_frames):
         got += pipe.step(pose=float(f) * 0.25)    # a per-frame pose travels with the frame
@@ -87,6 +87,19 @@ def test_frame_pipeline_single_rank(lanes, depth, ahead, seed):
     # frames come back lanes * depth frames late, in order, and drain() returns the rest
     pipe2, _, _ = _run_rank(0, 1, 0, lanes, depth, None, seed, ahead=ahead)
     assert pipe2.drain() == []
+
+
+@pytest.mark.parametrize("lanes,depth,ahead,seed", [(4, 2, None, 0), (3, 2, None, 1), (2, 1, 1, 2), (1, 1, 0, 3), (4, 1, 9, 4), (2, 2, 3, 5)])
+def test_frame_pipeline_with_the_substeps_on_the_render_lanes(lanes, depth, ahead, seed):
+    """FramePipeline(sim_on_lanes=True): no simulator stream; substep g is enqueued on lane g % lanes and chained to substep g - 1 by an event.  Under every
+    legal interleaving of the lanes (the stand-in draws them at random) the snapshot of frame g is taken after exactly g substeps, no slot is overwritten
+    while a render still reads it, and every frame sees the state before its own substep."""
+    n_frames = 50
+    pipe, be, got = _run_rank(0, 1, n_frames, lanes, depth, None, seed, ahead=ahead, short=(7,), sim_on_lanes=True)
+    assert pipe.sim_on_lanes and not be.stream("sim").ops and be.stream("sim").executed == 0      # nothing ever ran on a simulator stream
+    assert [f for f, _ in got] == list(range(n_frames))
+    assert np.allclose([r[1] for _, r in got], _serial(n_frames), rtol=0, atol=1e-9)
+    assert be.steps == n_frames + pipe.ahead and pipe.substeps_enqueued == n_frames + pipe.ahead
 
 
 def test_schedule_helpers():
