@@ -183,6 +183,10 @@ int pn_net_update(pn_net* net, const float* embeddings, const float* W0_host, co
  * [2^13, 2^14], the scales folded into the weight image — taken whenever those bounds are finite and positive; 0 = three bf16 pieces, six products (any
  * weights: an all-zero layer, a non-finite weight).  PN_NET_FORM=bf16 in the environment forces 0. */
 int pn_net_form(const pn_net* net);
+/* Number of times pn_net_update changed that form since pn_net_create.  The per-layer scales of form 2 live in device memory beside the weight image and are
+ * read by the kernels, so launches captured into HIP graphs follow an in-place refresh; the FORM itself (kernel template + image) is fixed in a captured
+ * launch: graphs captured under another epoch must be captured again (pienerf_amd/harness.py refuses to replay them). */
+int pn_net_form_epoch(const pn_net* net);
 /* Creates the fp16 copy of the hash tables (`embeddings.to(torch.half)`, gridencoder/grid.py:43-44; round to nearest even) once; the fp16
  * weight image always exists.  Call before the first *_half launch or fp16 render, outside stream capture. */
 int pn_net_enable_half(pn_net* net, void* stream);

@@ -85,6 +85,7 @@ SIGNATURES = {
     "pn_frame_trip_times": (i32, [P, P, P, i32, P, P]),
     "pn_frame_fused_clocks": (i32, [P, P, P, i32, P]),
     "pn_net_form": (i32, [P]),
+    "pn_net_form_epoch": (i32, [P]),
     "pn_frame_trip_records": (i32, [P, P, P, i32, P]),
     "pn_sim_update_F": (i32, [i32, P, P, P, P, P, P, P, P, P]),
     "pn_sim_calc_elastic": (i32, [i32, P, P, P, P, P, P, P]),

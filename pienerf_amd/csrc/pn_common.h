@@ -94,7 +94,13 @@ struct pn_net {
     // (pn_nerf_forward.hip: net_choose_form).  Zero / non-finite bounds: x_ok = 0, the bf16 split runs.
     void* wx;                 // device, owned: the fp16 hi/lo LDS weight image, PN_NET_X_BYTES
     int x_ok;                 // the fp32 network runs in the fp16 hi/lo form (PN_NET_FORM=bf16 forces 0)
-    float x_scale, x_rscale;  // the features' scale xs[0]; 1 / xs[2], the scale the density net's 16 outputs leave the matrix pipe at
+    float x_scale, x_rscale;  // the features' scale xs[0]; 1 / xs[2], the scale the density net's 16 outputs leave the matrix pipe at (host copies)
+    // What the kernels read: the two words {x_scale, x_rscale} in DEVICE memory, in the 16-byte tail behind the image (wx + PN_NET_X_BYTES: [tables' abs-max,
+    // 0, x_scale, x_rscale]), uploaded with it — so launches captured into HIP graphs follow an in-place refresh (round-4 advisor: as by-value kernel
+    // arguments a replay ran the new image with the old scales).  The FORM (x_ok: which kernel template and which image) is baked into a captured launch;
+    // form_epoch counts its flips and the host (network._net_handle -> harness) refuses to replay graphs captured under another epoch.
+    const float* x_scales;
+    int form_epoch;
 };
 
 // weight image: [20 MFMA operand groups][3 bf16 pieces hi/mid/lo][64 lanes][8 bf16], then the VALU output layer's 192 fp32 weights

@@ -410,7 +410,9 @@ static int net_upload_weights(pn_net* n, const float* W0, const float* W1, const
     float table_max;
     memcpy(&table_max, &bits, 4);
     double xs[5];
+    const int form_before = n->x_ok;
     net_choose_form(n, W0, W1, W2, W3, table_max, xs);
+    if (n->x_scales && n->x_ok != form_before) n->form_epoch++;   // (x_scales is null during pn_net_create: nothing captured yet)
     PN_HIP_CHECK(hipEventSynchronize(n->stage_done));  // the previous upload has finished reading the staging buffer (normally long ago)
     unsigned char* simg = reinterpret_cast<unsigned char*>(n->stage);
     unsigned char* himg = simg + PN_NET_SPLIT_BYTES;
@@ -418,7 +420,10 @@ static int net_upload_weights(pn_net* n, const float* W0, const float* W1, const
     build_weight_images(W0, W1, W2, W3, W4, simg, himg, ximg, xs);
     PN_HIP_CHECK(hipMemcpyAsync(n->wsplit, simg, PN_NET_SPLIT_BYTES, hipMemcpyHostToDevice, st));
     PN_HIP_CHECK(hipMemcpyAsync(n->whalf, himg, PN_NET_HALF_BYTES, hipMemcpyHostToDevice, st));
-    PN_HIP_CHECK(hipMemcpyAsync(n->wx, ximg, PN_NET_X_BYTES, hipMemcpyHostToDevice, st));
+    const float tail[4] = {0.0f, 0.0f, n->x_scale, n->x_rscale};   // the scales travel with the image they are folded into (pn_common.h: x_scales)
+    memcpy(ximg + PN_NET_X_BYTES, tail, 16);
+    PN_HIP_CHECK(hipMemcpyAsync(n->wx, ximg, PN_NET_X_BYTES + 16, hipMemcpyHostToDevice, st));
+    n->x_scales = reinterpret_cast<const float*>(reinterpret_cast<unsigned char*>(n->wx) + PN_NET_X_BYTES) + 2;
     PN_HIP_CHECK(hipEventRecord(n->stage_done, st));
     return PN_OK;
 }
@@ -459,10 +464,10 @@ extern "C" int pn_net_create(pn_net** out, const float* embeddings, const int* o
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMalloc((void**)&n->wsplit, PN_NET_SPLIT_BYTES);
     if (e == hipSuccess) e = hipMalloc((void**)&n->whalf, PN_NET_HALF_BYTES);
-    if (e == hipSuccess) e = hipMalloc((void**)&n->wx, PN_NET_X_BYTES + 16);   // (+ the tables' abs-max word of net_upload_weights)
+    if (e == hipSuccess) e = hipMalloc((void**)&n->wx, PN_NET_X_BYTES + 16);   // (+ the tail: the tables' abs-max word of net_upload_weights, the two scales)
     if (e == hipSuccess) e = hipMalloc((void**)&n->fused_levels, sizeof(fl));
     if (e == hipSuccess) e = hipMalloc((void**)&n->byte_levels, sizeof(bl));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&n->stage, PN_NET_SPLIT_BYTES + PN_NET_HALF_BYTES + PN_NET_X_BYTES);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&n->stage, PN_NET_SPLIT_BYTES + PN_NET_HALF_BYTES + PN_NET_X_BYTES + 16);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&n->stage_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventRecord(n->stage_done, st);
     if (e == hipSuccess) e = hipMemcpyAsync(n->fused_levels, fl, sizeof(fl), hipMemcpyHostToDevice, st);
@@ -498,6 +503,7 @@ extern "C" int pn_net_update(pn_net* n, const float* embeddings, const float* W0
 }
 
 extern "C" int pn_net_form(const pn_net* n) { return (n && n->x_ok) ? 2 : 0; }
+extern "C" int pn_net_form_epoch(const pn_net* n) { return n ? n->form_epoch : 0; }
 
 extern "C" int pn_net_enable_half(pn_net* n, void* stream) {
     PN_REQUIRE(n);
@@ -537,15 +543,16 @@ extern "C" void pn_net_destroy(pn_net* n) {
 #ifndef PN_BF_WAVES
 #define PN_BF_WAVES 8
 #endif
-// X: the fp16 hi/lo form of the dense layers (pn_common.h: pn_net::wx; `wsplit` is then that image, sf = pn_net::x_scale, rsf = pn_net::x_rscale)
+// X: the fp16 hi/lo form of the dense layers (pn_common.h: pn_net::wx; `wsplit` is then that image, sf, rsf = the device words pn_net::x_scales)
 template <int MINW, int LU, bool X = false>
 __global__ void __launch_bounds__(PN_BF_WAVES * 64, MINW) k_nerf_forward(const PnByteLevel* __restrict__ lv, const float* __restrict__ emb,
                                                                           const uint4* __restrict__ wsplit, float bound, const float* __restrict__ xyzs,
                                                                           const float* __restrict__ dirs, const int* __restrict__ list,
                                                                           const int* __restrict__ count_dev, uint32_t M_arg, float density_scale,
                                                                           float* __restrict__ sigmas, float* __restrict__ rgbs,
-                                                                          float* __restrict__ geo, int sigma_only, float sf = 1.0f, float rsf = 1.0f) {
+                                                                          float* __restrict__ geo, int sigma_only, const float* __restrict__ x_scales = nullptr) {
     extern __shared__ __attribute__((aligned(16))) uint4 wimg[];  // the weight image, then the 16 level records
+    const float sf = X ? x_scales[0] : 1.0f, rsf = X ? x_scales[1] : 1.0f;  // device words beside the image: a captured launch follows pn_net_update
     constexpr int PN_IMG_BYTES = X ? PN_NET_X_BYTES : PN_NET_SPLIT_BYTES;
     const uint32_t M = count_dev ? (uint32_t)*count_dev : M_arg;
     const uint32_t n_tiles = (M + 31) / 32;
@@ -684,7 +691,7 @@ int pn_nerf_forward_launch(const pn_net* net, const float* xyzs, const float* di
     if (net->x_ok)
         k_nerf_forward<2, PN_BF_LU, true><<<blocks, PN_BF_WAVES * 64, PN_NET_X_BYTES + 16 * sizeof(PnFusedLevel), stream>>>(
             (const PnByteLevel*)net->byte_levels, net->embeddings, (const uint4*)net->wx, net->bound, xyzs, dirs, list, ctl_count, M_max, density_scale, sigmas, rgbs,
-            nullptr, 0, net->x_scale, net->x_rscale);
+            nullptr, 0, net->x_scales);
     else
     k_nerf_forward<2, PN_BF_LU><<<blocks, PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES + 16 * sizeof(PnFusedLevel), stream>>>((const PnByteLevel*)net->byte_levels, net->embeddings,
                                                                                   (const uint4*)net->wsplit, net->bound, xyzs, dirs, list, ctl_count,
@@ -705,7 +712,7 @@ static int density_launch(const pn_net* net, const float* xyzs, uint32_t M, floa
     } else if (net->x_ok) {
         k_nerf_forward<2, PN_BF_LU, true><<<std::min(pn_div_up(tiles, PN_BF_WAVES), 2048u / PN_BF_WAVES), PN_BF_WAVES * 64, PN_NET_X_BYTES + 16 * sizeof(PnFusedLevel), st>>>(
             (const PnByteLevel*)net->byte_levels, net->embeddings, (const uint4*)net->wx, net->bound, xyzs, xyzs, nullptr, nullptr, M, scale, sigmas, nullptr, geo_feat,
-            sigma_only, net->x_scale, net->x_rscale);
+            sigma_only, net->x_scales);
     } else {
         k_nerf_forward<2, PN_BF_LU><<<std::min(pn_div_up(tiles, PN_BF_WAVES), 2048u / PN_BF_WAVES), PN_BF_WAVES * 64, PN_NET_SPLIT_BYTES + 16 * sizeof(PnFusedLevel), st>>>(
             (const PnByteLevel*)net->byte_levels, net->embeddings, (const uint4*)net->wsplit, net->bound, xyzs, xyzs, nullptr, nullptr, M, scale, sigmas,

@@ -1880,8 +1880,13 @@ __device__ __forceinline__ void frame_rays_block(const FramePrologue& a, uint32_
     }
     if (block == 0)
         for (int t = threadIdx.x; t < 6 * PN_SEGS; t += blockDim.x) a.seg_counters[t * PN_SEG_STRIDE] = 0;
-    if (block == 0 && threadIdx.x == 0 && a.early_finish) {  // the frame's books until the fused launch closes them (if it steps aside: an unfinished frame at trip 0)
-        a.dev->trips_run = 0; a.dev->fused_trips = 0; a.dev->stat_trips = 0; a.dev->stat_samples = 0; a.dev->alive_at_exit = (int)a.N;
+    if (block == 0 && threadIdx.x == 0) {
+        // Every frame starts with no fused trips on its books: a frame finished INSIDE a fused launch leaves its count behind (no k_frame_finish ran to
+        // clear it), and a later frame on this pn_frame whose fused launch steps aside would otherwise read it as "ran to the end" (round-4 advisor).
+        a.dev->fused_trips = 0;
+        if (a.early_finish) {  // the frame's books until the fused launch closes them (if it steps aside: an unfinished frame at trip 0)
+            a.dev->trips_run = 0; a.dev->stat_trips = 0; a.dev->stat_samples = 0; a.dev->alive_at_exit = (int)a.N;
+        }
     }
     if (threadIdx.x == 0) a.chunk_words[block] = 0;  // one (tag, count) word per 256 rays (+ the spare ones by the last workgroup), see k_composite_compact
     if (threadIdx.x < 2 && block + 1 == gridDim.x - (uint32_t)(a.list_blocks + a.pack_blocks)) a.chunk_words[block + 1 + threadIdx.x] = 0;
@@ -2245,7 +2250,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             memset(&fa, 0, sizeof(fa));
             fa.lv = (const PnFusedLevel*)(o->fp16 ? net->fused_levels : net->byte_levels); fa.emb = net->embeddings; fa.emb_h = (const uint32_t*)net->emb_half; fa.emb_bytes = net->n_entries * 4u;
             fa.wimg_g = (const uint4*)(o->fp16 ? net->whalf : (net->x_ok ? net->wx : net->wsplit)); fa.net_bound = net->bound; fa.net_inv2b = 1.0f / (2 * net->bound); fa.density_scale = o->density_scale;
-            fa.x_scale = net->x_scale; fa.x_rscale = net->x_rscale;
+            fa.x_scales = net->x_scales;
             fa.trips = f->trips + t; fa.N_rays = N; fa.max_steps = o->max_steps; fa.T_thresh = o->T_thresh;
             fa.alive = (t & 1) ? f->alive_b : f->alive_a;
             fa.rays_t = f->rays_t; fa.weights_sum = weights_sum; fa.depth = depth_0; fa.image = f->acc_image;

@@ -51,7 +51,8 @@ struct FusedArgs {
     uint32_t emb_bytes;
     const uint4* wimg_g;  // the LDS weight image in global memory (wsplit / whalf / wx)
     float net_bound, net_inv2b, density_scale;   // net_inv2b = 1.0f / (2 * net_bound) (pn_net_tile.h: tile_sigma_net)
-    float x_scale, x_rscale;  // fp16 hi/lo form: the features' power-of-two scale xs[0]; 1 / xs[2] for the density net's outputs (pn_common.h)
+    const float* x_scales;    // fp16 hi/lo form: device words {xs[0], 1 / xs[2]} beside the weight image (pn_common.h: pn_net::x_scales) — read by the kernel, so a
+                              // captured launch follows an in-place weight refresh (pn_net_update)
     // frame
     PnTrip* trips;  // record of the first fused trip
     uint32_t N_rays, max_steps;
@@ -183,6 +184,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
 
     const PnTrip* tr = fa.trips;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float x_scale = XF ? fa.x_scales[0] : 1.0f, x_rscale = XF ? fa.x_scales[1] : 1.0f;  // uniform: two scalar loads
     int A = 0, sb0 = 0, n_active = 0;
     if (QUEUED) {
         // exclusive prefix of the segment counts of the active list (WHOLE) / of the first trip's sample list (FOLD): the same in every workgroup
@@ -259,8 +261,8 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
             __builtin_amdgcn_sched_barrier(0);
             tile_color_net_h(wl, wimg, half, g2, d.x, d.y, d.z, e);
         } else if (XF) {
-            const f32x16 h2 = tile_sigma_net_x<PN_BF_LU>(reinterpret_cast<const PnByteLevel*>(lds_lv), fa.emb, wl, half, fa.net_bound, fa.net_inv2b, p.x, p.y, p.z, fa.x_scale);
-            sigma_logit = h2[0] * fa.x_rscale;
+            const f32x16 h2 = tile_sigma_net_x<PN_BF_LU>(reinterpret_cast<const PnByteLevel*>(lds_lv), fa.emb, wl, half, fa.net_bound, fa.net_inv2b, p.x, p.y, p.z, x_scale);
+            sigma_logit = h2[0] * x_rscale;
             __builtin_amdgcn_sched_barrier(0);
             tile_color_net_x(wl, wimg, half, h2, d.x, d.y, d.z, e);
         } else {

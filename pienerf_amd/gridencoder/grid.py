@@ -38,7 +38,8 @@ class _grid_encode(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0, align_corners=False,
-                interpolation=0, offsets_host=None):
+                interpolation=0, offsets_host=None, grad_mode=True):
+        # grad_mode: torch.is_grad_enabled() at the call site (inside forward() it is always off, and ctx.needs_input_grad follows requires_grad alone)
         x = inputs.to(torch.float32).contiguous()
         B, D = x.shape
         n_levels = offsets.shape[0] - 1
@@ -55,7 +56,9 @@ class _grid_encode(torch.autograd.Function):
             check(lib().pn_grid_encode_forward_half(ptr(x), ptr(table), offsets_host.data_ptr(), ptr(feats), B, D, C, n_levels, log2_scale,
                                                     int(base_resolution), int(gridtype), int(bool(align_corners)), int(interpolation), 1, stream_ptr()),
                   "grid_encode_forward_half")
-            if ctx.needs_input_grad[1]:   # fp16 training (trainer.py:561 with --fp16): the half backward below
+            if grad_mode and ctx.needs_input_grad[0]:
+                raise RuntimeError("grid_encode: the half-precision path has no gradient to its inputs (inputs.requires_grad under autocast)")
+            if grad_mode and ctx.needs_input_grad[1]:   # fp16 training (trainer.py:561 with --fp16): the half backward below
                 ctx.save_for_backward(x)
                 ctx.half = True
                 ctx.table_shape, ctx.table_dtype = tuple(embeddings.shape), embeddings.dtype
@@ -88,7 +91,7 @@ class _grid_encode(torch.autograd.Function):
             grad_embeddings = torch.zeros(ctx.table_shape, device=x.device, dtype=torch.float16)
             check(lib().pn_grid_encode_backward_half(ptr(grad), ptr(x), ctx.offsets_host.data_ptr(), ptr(grad_embeddings), B, D, C, L, S, H, gridtype,
                                                      int(ctx.align_corners), interpolation, stream_ptr()), "grid_encode_backward_half")
-            return None, grad_embeddings.to(ctx.table_dtype), None, None, None, None, None, None, None, None
+            return None, grad_embeddings.to(ctx.table_dtype), None, None, None, None, None, None, None, None, None
         x, table, dy_dx = ctx.saved_tensors
         B, D, C, L, S, H, gridtype, interpolation = ctx.dims
         grad = grad.to(torch.float32).view(B, L, C).permute(1, 0, 2).contiguous()  # [B, L*C] -> [L, B, C] (grid.py:73)
@@ -97,7 +100,7 @@ class _grid_encode(torch.autograd.Function):
         rc = lib().pn_grid_encode_backward(ptr(grad), ptr(x), ptr(table), ctx.offsets_host.data_ptr(), ptr(grad_embeddings), B, D, C, L, S, H, ptr(dy_dx),
                                            ptr(grad_inputs), gridtype, int(ctx.align_corners), interpolation, stream_ptr())
         check(rc, "grid_encode_backward")
-        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None, None
+        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None, None, None
 
 
 def grid_encode(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False, gridtype=0, align_corners=False,
@@ -105,7 +108,7 @@ def grid_encode(inputs, embeddings, offsets, per_level_scale, base_resolution, c
     """inputs [B,D] in [0,1], embeddings [sO,C], offsets [L+1] -> features [B, L*C] fp32 (differentiable w.r.t. embeddings, and w.r.t.
     inputs when ``calc_grad_inputs``)."""
     return _grid_encode.apply(inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs, gridtype, align_corners, interpolation,
-                              offsets_host)
+                              offsets_host, torch.is_grad_enabled())
 
 
 class GridEncoder(nn.Module):

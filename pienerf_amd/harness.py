@@ -174,7 +174,20 @@ class SimRenderHarness:
         self.sim.dof_vel.copy_(keep[1])
         self._graph_trips = n_trips
         self._graph_done = None
+        self._graph_form_epoch = self._net_form_epoch()
         return self
+
+    def _net_form_epoch(self):
+        """How often the fp32 network switched between its fp16 hi/lo and bf16 forms (include/pienerf_hip.h: pn_net_form_epoch).  The per-layer scales
+        live in device memory and follow an in-place weight refresh; the form is baked into every captured launch."""
+        from ._lib import lib
+        net = getattr(self.model, "_net", None)
+        return int(lib().pn_net_form_epoch(net)) if net is not None else 0
+
+    def _check_net_form(self, captured, what):
+        if self._net_form_epoch() != captured:
+            raise RuntimeError(f"the network's weights were refreshed into another arithmetic form (pn_net_form) since {what} was captured: its graphs "
+                               f"hold the old form's kernels — capture again")
 
     @torch.no_grad()
     def step_graph(self, pose=None):
@@ -182,6 +195,7 @@ class SimRenderHarness:
         that needed more trips than were captured — after the NEXT call or ``finish_graph_frame()``."""
         if getattr(self, "_graph", None) is None:
             self.capture()
+        self._check_net_form(self._graph_form_epoch, "the step")
         self._check_previous_graph_frame()
         if pose is not None:
             self._graph_pose.copy_(torch.from_numpy(np.asarray(pose, np.float32)).unsqueeze(0))
@@ -270,6 +284,7 @@ class SimRenderHarness:
                                    force_collectives=bool(_force_collectives) and on, sim_on_lanes=sim_on_lanes)
         self.sim.force_hooks = (self._pipe.before_force, self._pipe.after_force) if self._pipe.sim_on_lanes else None
         self._pipe_backend = be
+        self._pipe_form_epoch = self._net_form_epoch()
         self.model._in_flight = lambda pipe=self._pipe: sum(f is not None for f in pipe.pending)  # weight refreshes need a drained pipeline (network._net_handle)
         return self
 
@@ -279,6 +294,7 @@ class SimRenderHarness:
 
     @torch.no_grad()
     def step_pipelined(self, pose=None):
+        self._check_net_form(self._pipe_form_epoch, "the pipeline")
         out = self._pipe.step(pose)
         self.frame = self._pipe.frame
         return out

@@ -106,3 +106,87 @@ def test_tiny_tables_keep_their_accuracy(ckpt):
     with torch.no_grad():
         a, b = tiny_x.density(T(x))["geo_feat"].cpu().numpy(), tiny_b.density(T(x))["geo_feat"].cpu().numpy()
     assert np.abs(b).max() > 0 and rel_err(a, b) < 2e-5, rel_err(a, b)
+
+
+def test_captured_graphs_follow_an_in_place_weight_refresh_that_moves_the_scales(small_cloud, small_opt, ckpt):
+    """Round-4 advisor (high): the per-layer power-of-two scales of the fp16 hi/lo form were by-value kernel arguments, so graphs captured before an in-place
+    weight refresh (pn_net_update) replayed the new weight image with the old scales — a sigma logit off by 2^k.  They now live in device memory beside the
+    image.  Capture, drain, multiply the tables by 8 and divide W0 by 8 (the features' scale xs[0] moves by 2^-3), double W1 (the density net's output scale
+    xs[2] moves, the sigma logit doubles), refresh in place, replay: the replayed frames equal an eager harness built on the new weights, bit for bit."""
+    from pienerf_amd.harness import SimRenderHarness
+    opt = dict(small_opt, W=48, H=48)
+    h = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture_pipelined(lanes=2, n_trips=8)
+    for _ in range(3):
+        h.step_pipelined()
+    h.drain_pipeline()
+    assert lib().pn_net_form(h.model._net) == 2
+    with torch.no_grad():
+        h.model.encoder.embeddings.mul_(8.0)
+        h.model.sigma_net[0].weight.mul_(0.125)
+        h.model.sigma_net[1].weight.mul_(2.0)
+        x, d = _samples(64, 1)
+        h.model(T(x), T(d))                  # the refresh (in place, same handle)
+    assert lib().pn_net_form(h.model._net) == 2 and lib().pn_net_form_epoch(h.model._net) == 0
+    ck2 = dict(ckpt)
+    ck2["W0"] = (ckpt["W0"] * np.float32(0.125)).astype(np.float32)
+    ck2["W1"] = (ckpt["W1"] * np.float32(2.0)).astype(np.float32)
+    ck2["embeddings"] = (ckpt["embeddings"] * np.float32(8.0)).astype(np.float32)
+    first = h._pipe.frame
+    got = []
+    for _ in range(3):
+        got += [(i, r["image"].copy()) for i, r in h.step_pipelined()]
+    got += [(i, r["image"].copy()) for i, r in h.drain_pipeline()]
+    got = [g for g in got if g[0] >= first]
+    assert len(got) == 3
+    # every frame f is rendered from the state before substep f (the substeps do not depend on the network): an eager harness on the new weights
+    want_h = SimRenderHarness(opt, cloud=small_cloud, ckpt=ck2, device=DEV)
+    for f in range(first + 3):
+        out = want_h.step()
+        if f >= first:
+            assert np.array_equal(got[f - first][1], out["image"].cpu().numpy()), f
+
+
+def test_graphs_captured_under_another_network_form_are_refused(small_cloud, small_opt, ckpt):
+    """The form (fp16 hi/lo or bf16 pieces) selects the kernel template and the weight image and is fixed in a captured launch: a refresh that flips it
+    (here: an all-zero layer has no positive interval bound) bumps pn_net_form_epoch and the harness refuses to replay the stale graphs."""
+    from pienerf_amd.harness import SimRenderHarness
+    opt = dict(small_opt, W=32, H=32)
+    h = SimRenderHarness(opt, cloud=small_cloud, ckpt=ckpt, device=DEV).capture_pipelined(lanes=2, n_trips=8)
+    h.step_pipelined()
+    h.drain_pipeline()
+    with torch.no_grad():
+        h.model.color_net[1].weight.zero_()
+        x, d = _samples(64, 1)
+        h.model(T(x), T(d))
+    assert lib().pn_net_form(h.model._net) == 0 and lib().pn_net_form_epoch(h.model._net) == 1
+    with pytest.raises(RuntimeError, match="capture again"):
+        h.step_pipelined()
+    h.capture_pipelined(lanes=2, n_trips=8)      # recapture: runs
+    h.step_pipelined()
+    h.drain_pipeline()
+
+
+def test_heavy_tailed_weights_and_an_outlier_table_entry(ckpt):
+    """Round-4 advisor (low): the form is chosen from interval bounds, which heavy-tailed weights or one outlier table entry push far above the typical
+    magnitudes (and the slack compounds layer by layer).  Student-t (3 degrees of freedom) weights — single entries 10-30 standard deviations out — and a
+    table whose typical entry is 1e-2 with one entry at 40: whichever form net_choose_form takes, the outputs stay inside the 1e-4 bar of north_star
+    against the sequential-fp32 oracle, and the two forms agree."""
+    rng = np.random.default_rng(11)
+    ck = dict(ckpt)
+    ck["embeddings"] = (ckpt["embeddings"] * np.float32(0.02)).astype(np.float32)
+    ck["embeddings"][12345, 1] = 40.0
+    for k, fan in (("W0", 32), ("W1", 64), ("W2", 31), ("W3", 64), ("W4", 64)):
+        t = rng.standard_t(3, size=ckpt[k].shape) * np.sqrt(2.0 / fan) / np.sqrt(3.0)
+        ck[k] = t.astype(np.float32)
+    ck["W1"][0, :] *= 0.1   # keep exp(logit) finite
+    x, d = _samples(40_000, 9)
+    mx, mb = _model(ck), _model(ck, "bf16")
+    with torch.no_grad():
+        sx, cx = [t.cpu().numpy() for t in mx(T(x), T(d))]
+        sb, cb = [t.cpu().numpy() for t in mb(T(x), T(d))]
+    want_s, want_c = oracle.nerf_forward(x, d, ck, 1.0)
+    assert np.isfinite(want_s).all() and want_s.min() > 0
+    for name, s, c in ((f"chosen form {lib().pn_net_form(mx._net)}", sx, cx), ("bf16 x 3", sb, cb)):
+        es, ec = float(np.abs(s / want_s - 1).max()), float(np.abs(c - want_c).max())
+        print(f"{name}: sigma rel {es:.2e}, rgb abs {ec:.2e}")
+        assert es < 1e-4 and ec < 1e-4, (name, es, ec)
