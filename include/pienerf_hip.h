@@ -435,6 +435,25 @@ int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, double dx, const
  * csr_pos (may be NULL; needs dNx_csr): inverse of csr_buf, csr_pos[csr_buf[e]] = e; calc_elastic then also writes P once per
  * neighbour slot in CSR order and the gather has no index left to follow. */
 uint64_t pn_sim_work_doubles(int n_k, int n_IP);
+/* Simulator.stepforward in its CELL form (csrc/pn_sim.hip: k_cells_elastic_gather): calc_elastic (cuda_utils.py:83-121) and collect_rhs_IP (:124-151)
+ * of a local/global iteration as ONE launch, the dense product (solver.py:600-601) as the other — 1 + 2 iters launches per substep instead of 1 + 3 iters.
+ * All integration points of one kernel-grid cell share their 8 neighbour kernels (solver.py:186-205); the caller sorts the points by cell and cuts the
+ * cells into chunks of <= pn_sim_cells_chunk_ips() points:
+ *   chunk_tab [n_chunks][12] int32: {points in the chunk, kernel of neighbour slot 0..7, 0, 0, 0};
+ *   dNx_cell  [n_chunks][waves = chunk_ips / 8][15][64][2] fp64: lane l of wave w holds point w * 8 + l / 8, slot l % 8 of the chunk; its 30 gradients
+ *             dNx[point, slot, c, x] (flat c * 10 + x) as 15 pairs; zeros for lanes behind the chunk's last point;
+ *   mu_cell, lam_cell [n_chunks * chunk_ips] fp64 in chunk order;
+ *   kp_bg [n_k + 1], kp_pos [8 n_chunks]: the (chunk * 8 + slot) pairs that refer to a kernel, in ascending order, are that kernel's run of partial sums
+ *             [kp_bg[k], kp_bg[k + 1]); kp_pos[chunk * 8 + slot] = the pair's place in it (absolute) — where the chunk stores that partial sum.
+ * Same results as pn_sim_stepforward up to the summation order of collect_rhs (1e-16 relative), bit-reproducible run to run.
+ * work >= pn_sim_cells_work_doubles doubles, initialised once by pn_sim_cells_prepare (identity rotations for the warm-started SVD, arrival counters). */
+int pn_sim_cells_chunk_ips(void);
+uint64_t pn_sim_cells_work_doubles(int n_k, int n_chunks);
+int pn_sim_cells_prepare(int n_k, int n_chunks, double* work, void* stream);
+int pn_sim_stepforward_cells(int n_k, int n_chunks, int iters, double dt, double dx, const int* chunk_tab, const double* dNx_cell, const double* mu_cell,
+                             const double* lam_cell, const int* kp_bg, const int* kp_pos, const double* Ainv, const double* Mmat, const double* dof_rest,
+                             const double* rhs_rest, const double* rhs_gravity, const double* dof_f, double* dof, double* dof_vel, double* work,
+                             void* stream);
 /* The local/global iterations of a substep as ONE persistent kernel of n_wg workgroups (one per CU; csrc/pn_sim.hip: k_substep_coop) instead of four
  * launches per iteration: same arguments and results as pn_sim_stepforward (tolerance of the summation orders, ~1e-13 relative), `work` prepared by
  * pn_sim_prepare, `coop` >= pn_sim_coop_bytes(n_k, n_IP, n_wg) bytes prepared by pn_sim_coop_prepare, which also returns plan[3] = {pieces, entries

@@ -93,6 +93,10 @@ SIGNATURES = {
     "pn_sim_matvec3": (i32, [i32, P, P, P, P]),
     "pn_sim_stepforward": (i32, [i32, i32, i32, f64, f64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, i32, P]),
     "pn_sim_prepare": (i32, [i32, i32, P, P, P, P]),
+    "pn_sim_cells_chunk_ips": (i32, []),
+    "pn_sim_cells_work_doubles": (u64, [i32, i32]),
+    "pn_sim_cells_prepare": (i32, [i32, i32, P, P]),
+    "pn_sim_stepforward_cells": (i32, [i32, i32, i32, f64, f64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "pn_sim_work_doubles": (u64, [i32, i32]),
     "pn_sim_coop_bytes": (u64, [i32, i32, i32]),
     "pn_sim_coop_prepare": (i32, [i32, i32, i32, P, P, P, C.POINTER(i32), P]),

@@ -59,10 +59,12 @@ __device__ __forceinline__ double fast_rsq(double x) {
 }
 
 // One Jacobi rotation zeroing S[p][q] of the symmetric S, accumulated into Q (columns = eigenvectors).
+// skip > 0 (threshold Jacobi): a pair whose off-diagonal is already below sqrt(skip) of its diagonal entries is left alone — its rotation would move
+// nothing above that level, and in the late sweeps of a warm-started decomposition that is most pairs (~100 dependent instructions each).
 template <int p, int q>
-__device__ __forceinline__ void jacobi_rot(M3& S, M3& Q) {
+__device__ __forceinline__ void jacobi_rot(M3& S, M3& Q, double skip = 0.0) {
     const double spq = S.m[p][q];
-    if (spq == 0.0) return;
+    if (spq * spq <= skip * fabs(S.m[p][p] * S.m[q][q])) return;   // (skip == 0: spq == 0)
     const double theta = (S.m[q][q] - S.m[p][p]) * fast_rcp(2.0 * spq);
     double t;
     if (fabs(theta) > 1e100) {
@@ -97,7 +99,7 @@ __device__ __forceinline__ void jacobi_rot(M3& S, M3& Q) {
 // F changes by ~1e-3 between iterations, so Q0^T (F^T F) Q0 is already diagonal to ~1e-6 and two sweeps finish what five do from the identity
 // (the chain below is what k_elastic's duration consists of: 8 of its 15 us).  The decomposition is the same up to rounding: R = U V^T and
 // U diag(s') V^T do not depend on where the iteration started.  tol: stop at off^2 <= tol dia^2.
-__device__ void svd3(const M3& F, M3& U, double* sig, M3& V, const M3* Q0 = nullptr, double tol = 1e-30) {
+__device__ void svd3(const M3& F, M3& U, double* sig, M3& V, const M3* Q0 = nullptr, double tol = 1e-30, double skip = 0.0) {
     M3 S, Q;
     if (Q0) {
         const M3 B0 = mul33(F, *Q0);  // S = (F Q0)^T (F Q0)
@@ -121,9 +123,9 @@ __device__ void svd3(const M3& F, M3& U, double* sig, M3& V, const M3* Q0 = null
         // fp64 rounding leaves off ~ 1e-32 dia however long one sweeps (a 1e-34 test never fires and all 32 sweeps run);
         // 1e-30 is reached one sweep after ~1e-15 (quadratic convergence) — same rule as the oracle
         if (off <= tol * dia || off == 0.0) break;
-        jacobi_rot<0, 1>(S, Q);
-        jacobi_rot<0, 2>(S, Q);
-        jacobi_rot<1, 2>(S, Q);
+        jacobi_rot<0, 1>(S, Q, skip);
+        jacobi_rot<0, 2>(S, Q, skip);
+        jacobi_rot<1, 2>(S, Q, skip);
     }
     M3 B = mul33(F, Q);
     double n0 = B.m[0][0] * B.m[0][0] + B.m[1][0] * B.m[1][0] + B.m[2][0] * B.m[2][0];
@@ -225,8 +227,32 @@ extern "C" int pn_sim_stamps_read(unsigned long long* host, int reset) {
     return PN_OK;
 }
 #define PN_SIM_STAMP(id) sim_stamp(id)
+// ... and phase clocks inside k_cells_elastic_gather: thread 0 of EVERY workgroup reads the 100 MHz clock at the phase boundaries (a scalar instruction,
+// nothing in flight) and adds its differences to g_sim_phase at the very end: [p] ticks from boundary p to p + 1 summed over workgroups, [8] workgroups,
+// [9] the largest start-to-end of a workgroup, [10 + p] the largest single difference
+__device__ unsigned long long g_sim_phase[24];
+#define PN_SIM_PHASE_DECL unsigned long long ph_[8]; int ph_n_ = 0
+#define PN_SIM_PHASE_MARK do { if (ph_n_ < 8) ph_[ph_n_++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ __forceinline__ void sim_phase_flush(const unsigned long long* ph, int n) {
+    if (threadIdx.x == 0) {
+        for (int p = 0; p + 1 < n; p++) { atomicAdd(&g_sim_phase[p], ph[p + 1] - ph[p]); atomicMax(&g_sim_phase[10 + p], ph[p + 1] - ph[p]); }
+        atomicAdd(&g_sim_phase[8], 1ull);
+        atomicMax(&g_sim_phase[9], ph[n - 1] - ph[0]);
+    }
+}
+extern "C" int pn_sim_phase_read(unsigned long long* host, int reset) {
+    PN_HIP_CHECK(hipDeviceSynchronize());
+    if (host) PN_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_sim_phase), sizeof(unsigned long long) * 24));
+    if (reset) { unsigned long long z[24] = {0}; PN_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_sim_phase), z, sizeof(z))); }
+    return PN_OK;
+}
+#define PN_SIM_PHASE(id) PN_SIM_PHASE_MARK
+#define PN_SIM_PHASE_FLUSH sim_phase_flush(ph_, ph_n_)
 #else
 #define PN_SIM_STAMP(id)
+#define PN_SIM_PHASE(id)
+#define PN_SIM_PHASE_DECL
+#define PN_SIM_PHASE_FLUSH
 #endif
 
 // ------------------------------------------------------------------------------------------------ update_F / get_IP_info
@@ -910,6 +936,239 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
         k_matvec3<<<pn_div_up(n, 2 * (mv_wg / 64)), mv_wg, 0, st>>>(n, Ainv, tot, dof, 2, dof_rest, nullptr);  // x = G @ rhs ; dof = dof_rest + x (:600-601)
     }
     if (!ends) k_step_end<<<pn_div_up(n3, 256), 256, 0, st>>>(n3, dt, dof, last, dof_vel);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ the substep in its CELL form (round 5)
+// calc_elastic and collect_rhs_IP of one local/global iteration as ONE launch (k_cells_elastic_gather), the dense product as the other: 21 launches per
+// substep instead of 31.  What a launch of this chain costs is its boundary (~4.5 us of the 6.8-9.2 us from one start to the next, alone; beside the render
+// lanes every launch also waits for room on a CU), so the way to a shorter substep is fewer of them.
+// The reference's topology makes the merge cheap: an integration point's 8 neighbour kernels are the corners of the KERNEL-GRID CELL it lies in
+// (solver.py:186-205), so all points of one cell share the same 8 kernels, slot i meaning the same kernel for each of them.  The host sorts the points by
+// cell and cuts every cell into chunks of <= PN_CELL_IPS points (simulator/solver.py: _build_cells); a workgroup takes one chunk:
+//   * 8 lanes per point as in k_elastic, but the chunk's shape-function gradients come from a copy laid out for it ([chunk][wave][15][64 lanes] double2:
+//     every load instruction reads 1 KB contiguous, k_elastic's touched 64 cache lines) and the 8 lanes of a point read the 8 kernels' DOFs that the whole
+//     workgroup shares (8 distinct 240-B rows per instruction instead of 64);
+//   * the point's stress times ITS OWN gradients — still in the lane's registers from the deformation gradient — is its contribution to its 8 kernels:
+//     no P_csr, no dNx_csr, no index;
+//   * summed over the chunk's points in LDS in a fixed order (point after point) into 8 x 30 partial sums, stored write-through; the workgroup that
+//     completes a kernel's set of partial sums (cyclic arrival counters, as k_rhs_gather_chunk; the sums of a kernel lie side by side, kp_pos) adds them
+//     by a fixed tree and writes momentum + sum - rhs_rest.  Bit-reproducible run to run; against the CSR form the summation order differs (1e-16 relative).
+#ifndef PN_CELL_WAVES
+#define PN_CELL_WAVES 4
+#endif
+#define PN_CELL_IPS (PN_CELL_WAVES * 8)
+#ifndef PN_CELL_SVD_TOL
+#define PN_CELL_SVD_TOL 1e-22
+#endif
+#ifndef PN_CELL_SVD_SKIP
+#define PN_CELL_SVD_SKIP 1e-23
+#endif
+#define PN_CELL_TAB_INTS 12   // per chunk: {points, kernel of slot 0..7, 0, 0, 0}
+#define PN_CELL_RSTRIDE 66    // doubles per output row of the LDS reduction buffer (64 lanes + 2: rows 4 banks apart)
+
+__global__ void __launch_bounds__(PN_CELL_WAVES * 64) k_cells_elastic_gather(const int* __restrict__ chunk_tab, const double2* __restrict__ dNx_cell,
+                                                                              const double* __restrict__ mu_cell, const double* __restrict__ lam_cell,
+                                                                              const double* __restrict__ dof, double dx3, double* __restrict__ Vstore,
+                                                                              double* part, int* kcount, const int* __restrict__ kp_bg,
+                                                                              const int* __restrict__ kp_pos, const double* __restrict__ momentum,
+                                                                              const double* __restrict__ rhs_rest, double* __restrict__ tot) {
+    PN_SIM_STAMP(1);
+    PN_SIM_PHASE_DECL;
+    PN_SIM_PHASE(10);
+    PN_SIM_PRIO();
+    constexpr int NW = PN_CELL_WAVES, B = PN_CELL_IPS;
+    __shared__ double red[NW][30][PN_CELL_RSTRIDE];
+    __shared__ int s_last[8], s_k[8], s_b0[8], s_n[8];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6, i = lane & 7;
+    const int vl = w * 8 + (lane >> 3);                       // the point's place in the chunk
+    const int* __restrict__ tab = chunk_tab + (size_t)b * PN_CELL_TAB_INTS;
+    const int count = tab[0];
+    const int kid = tab[1 + i];
+    const bool live = vl < count;
+    const int my_pos = t < 240 ? kp_pos[b * 8 + (t & 7)] : 0; // where this thread's partial sum goes (asked for now, needed at the end)
+    if (t < 8) {                                              // the 8 kernels' runs of partial sums, for whoever completes them (read behind two barriers)
+        const int k = tab[1 + t];
+        const int b0 = kp_bg[k];
+        s_k[t] = k; s_b0[t] = b0; s_n[t] = kp_bg[k + 1] - b0;
+    }
+    const size_t vg = (size_t)b * B + vl;                     // ... and in the chunk-ordered per-point arrays
+    // the previous iteration's rotation (lane 0 of the point's group), asked for before anything else: it is needed last
+    M3 Q0;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) Q0.m[r][c] = (i == 0 && live) ? Vstore[vg * 9 + r * 3 + c] : 0.0;
+    const double m_ = (i == 0 && live) ? mu_cell[vg] : 0.0, l_ = (i == 0 && live) ? lam_cell[vg] : 0.0;
+    double g[30], d[30];                                      // g[c * 10 + x] = dNx[v, i, c, x] (zeros behind the chunk's last point); d[x * 3 + r]
+    {
+        const double2* __restrict__ g2 = dNx_cell + ((size_t)b * NW + w) * 15 * 64 + lane;
+        const double2* __restrict__ d2 = reinterpret_cast<const double2*>(dof + (size_t)kid * 30);
+#pragma unroll
+        for (int j = 0; j < 15; j++) {
+            const double2 gv = g2[j * 64], dv = d2[j];
+            g[2 * j] = gv.x; g[2 * j + 1] = gv.y;
+            d[2 * j] = dv.x; d[2 * j + 1] = dv.y;
+        }
+    }
+    M3 Fm;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) Fm.m[r][c] = 0.0;
+#pragma unroll
+    for (int x = 0; x < 10; x++)                              // the same sums in the same order as k_elastic
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const double gg = g[c * 10 + x];
+            Fm.m[0][c] += d[x * 3] * gg;
+            Fm.m[1][c] += d[x * 3 + 1] * gg;
+            Fm.m[2][c] += d[x * 3 + 2] * gg;
+        }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double s = Fm.m[r][c];
+            s += shfl_xor_d(s, 1);
+            s += shfl_xor_d(s, 2);
+            s += shfl_xor_d(s, 4);
+            Fm.m[r][c] = s;
+        }
+    PN_SIM_PHASE(11);
+    double Pm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (i == 0 && live) {
+        M3 U, V;
+        double sig[3], sp[3];
+        // off-diagonals below 1e-11 of the diagonal (1e-22 on the squares; pairs below 3e-12 are not rotated): seven digits beyond the 1e-4 relative bar
+        // of the DOF displacements; against 1e-24 the third sweep — two take a warm-started decomposition from 1e-3 to 1e-12 — is mostly not run
+        svd3(Fm, U, sig, V, &Q0, PN_CELL_SVD_TOL, PN_CELL_SVD_SKIP);
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) Vstore[vg * 9 + r * 3 + c] = V.m[r][c];
+        volume_invariant_project(sig, sp);
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double R = U.m[r][0] * V.m[c][0] + U.m[r][1] * V.m[c][1] + U.m[r][2] * V.m[c][2];
+                const double Vv = U.m[r][0] * sp[0] * V.m[c][0] + U.m[r][1] * sp[1] * V.m[c][1] + U.m[r][2] * sp[2] * V.m[c][2];
+                Pm[r * 3 + c] = dx3 * (m_ * R + l_ * Vv);
+            }
+    }
+    PN_SIM_PHASE(12);
+    {
+        const int src = lane & ~7;
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            int2 tt = *reinterpret_cast<int2*>(&Pm[q]);
+            tt.x = __shfl(tt.x, src);
+            tt.y = __shfl(tt.y, src);
+            Pm[q] = *reinterpret_cast<double*>(&tt);
+        }
+    }
+    // this (point, slot)'s contribution to its kernel: out[x][r] = sum_c P[r][c] dNx[c][x] (cuda_utils.py:124-151), row x * 3 + r of the wave's buffer
+#pragma unroll
+    for (int x = 0; x < 10; x++)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            red[w][x * 3 + r][lane] = (Pm[r * 3] * g[x] + Pm[r * 3 + 1] * g[10 + x]) + Pm[r * 3 + 2] * g[20 + x];
+    __syncthreads();
+    PN_SIM_PHASE(13);
+    // 240 outputs (slot, row): the chunk's points one after the other, waves in ascending order
+    if (t < 240) {
+        const int o = t >> 3, sl = t & 7;
+        double s = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < NW; ww++)
+#pragma unroll
+            for (int p = 0; p < 8; p++) s += red[ww][o][p * 8 + sl];
+        __hip_atomic_store(part + (size_t)my_pos * 30 + o, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // its place in its kernel's run
+    }
+    __builtin_amdgcn_s_waitcnt(0);  // the sums are at the memory side
+    __syncthreads();
+    PN_SIM_PHASE(14);
+    if (t < 8) {
+        const int k = s_k[t];
+        const int old = __hip_atomic_fetch_add(kcount + k, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (old + 1) == s_n[t];
+        if (last) __hip_atomic_store(kcount + k, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed for the next launch
+        s_last[t] = last;
+    }
+    __syncthreads();
+    PN_SIM_PHASE(15);
+    // The kernels this workgroup completed: none for most, but the workgroups that arrive last complete several — the very last one all 8 of its own —
+    // and the launch ends with them: one thread per (completed kernel, output row), all at once; a row's partial sums lie 240 B apart in the kernel's run
+    // (kp_pos) and are added in ascending order, sixteen loads in flight.
+    if (t < 240) {
+        const int sl = t / 30, q = t - sl * 30;
+        if (s_last[sl]) {
+            const int k = s_k[sl], b0 = s_b0[sl], n = s_n[sl];
+            const size_t o = (size_t)k * 30 + q;
+            const double m0 = momentum[o], r0 = rhs_rest[o];
+            const double* __restrict__ src = part + (size_t)b0 * 30 + q;
+            double sum = 0.0;
+            for (int j0 = 0; j0 < n; j0 += 16) {   // (32 at a time measured slower: 0.215 against 0.208 ms per substep)
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) v[u] = __hip_atomic_load(src + (size_t)min(j0 + u, n - 1) * 30, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int u = 0; u < 16; u++) if (j0 + u < n) sum += v[u];
+            }
+            tot[o] = m0 + sum - r0;
+        }
+    }
+    PN_SIM_PHASE(16);
+    PN_SIM_PHASE_FLUSH;
+}
+
+extern "C" int pn_sim_cells_chunk_ips(void) { return PN_CELL_IPS; }
+// last, momentum, tot [30 n_k each] | partial sums [n_chunks * 240] | rotations [n_chunks * PN_CELL_IPS * 9] | arrival counters [n_k ints]
+extern "C" uint64_t pn_sim_cells_work_doubles(int n_k, int n_chunks) {
+    return (uint64_t)n_k * 30 * 3 + (uint64_t)n_chunks * 240 + (uint64_t)n_chunks * PN_CELL_IPS * 9 + ((uint64_t)n_k + 2) / 2;
+}
+__global__ void __launch_bounds__(256) k_cells_prepare(int n_rot9, int n_k, double* __restrict__ Vstore, int* __restrict__ kcount) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_rot9) Vstore[t] = (t % 9) % 4 == 0 ? 1.0 : 0.0;
+    if (t < n_k) kcount[t] = 0;
+}
+extern "C" int pn_sim_cells_prepare(int n_k, int n_chunks, double* work, void* stream) {
+    PN_REQUIRE(n_k > 0 && n_chunks > 0 && work);
+    double* Vstore = work + (size_t)n_k * 90 + (size_t)n_chunks * 240;
+    int* kcount = reinterpret_cast<int*>(Vstore + (size_t)n_chunks * PN_CELL_IPS * 9);
+    const int n9 = n_chunks * PN_CELL_IPS * 9;
+    k_cells_prepare<<<pn_div_up((uint64_t)std::max(n9, n_k), 256), 256, 0, (hipStream_t)stream>>>(n9, n_k, Vstore, kcount);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+extern "C" int pn_sim_stepforward_cells(int n_k, int n_chunks, int iters, double dt, double dx, const int* chunk_tab, const double* dNx_cell,
+                                        const double* mu_cell, const double* lam_cell, const int* kp_bg, const int* kp_pos, const double* Ainv,
+                                        const double* Mmat, const double* dof_rest, const double* rhs_rest, const double* rhs_gravity, const double* dof_f,
+                                        double* dof, double* dof_vel, double* work, void* stream) {
+    PN_REQUIRE(n_k > 0 && n_chunks > 0 && iters >= 1 && chunk_tab && dNx_cell && mu_cell && lam_cell && kp_bg && kp_pos && Ainv && Mmat);
+    PN_REQUIRE(dof_rest && rhs_rest && rhs_gravity && dof_f && dof && dof_vel && work);
+    hipStream_t st = (hipStream_t)stream;
+    const int n = n_k * 10, n3 = n * 3;
+    double* last = work;
+    double* momentum = work + (size_t)n3;
+    double* tot = work + 2 * (size_t)n3;
+    double* part = work + 3 * (size_t)n3;
+    double* Vstore = part + (size_t)n_chunks * 240;
+    int* kcount = reinterpret_cast<int*>(Vstore + (size_t)n_chunks * PN_CELL_IPS * 9);
+    const double dx3 = pow(dx, 3.0);
+    static const uint32_t mv_wg = std::min(std::max(pn_env_u32("PN_SIM_MV_WG", 64) & ~63u, 64u), 256u);
+    const uint32_t mv_blocks = pn_div_up(n, 2 * (mv_wg / 64));
+    // compute_momentum with dof_tilde = dof + dt * vel on the fly and dof_last = dof (solver.py:574-576,597)
+    k_matvec3<<<mv_blocks, mv_wg, 0, st>>>(n, Mmat, dof, momentum, 1, dof_f, rhs_gravity, dof_vel, dt, last);
+    for (int it = 0; it < iters; it++) {
+        k_cells_elastic_gather<<<n_chunks, PN_CELL_WAVES * 64, 0, st>>>(chunk_tab, reinterpret_cast<const double2*>(dNx_cell), mu_cell, lam_cell, dof, dx3,
+                                                                         Vstore, part, kcount, kp_bg, kp_pos, momentum, rhs_rest, tot);
+        if (it == iters - 1) k_matvec3<<<mv_blocks, mv_wg, 0, st>>>(n, Ainv, tot, dof, 3, dof_rest, last, nullptr, dt, nullptr, dof_vel);  // + vel (:602)
+        else k_matvec3<<<mv_blocks, mv_wg, 0, st>>>(n, Ainv, tot, dof, 2, dof_rest, nullptr);                                                // :600-601
+    }
     PN_LAUNCH_CHECK();
     return PN_OK;
 }

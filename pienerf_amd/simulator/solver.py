@@ -42,6 +42,9 @@ class Simulator:
             persistent = os.environ.get("PN_SIM_COOP", "") == "1"
         self.persistent = bool(persistent)
         self._coop = None
+        # cell_form: calc_elastic + collect_rhs_IP of a local/global iteration as one launch per kernel-grid cell chunk (pn_sim_stepforward_cells, 21
+        # launches per substep instead of 31); PN_SIM_FORM=csr keeps the round-1-4 launch form (three launches per iteration over per-kernel CSR lists)
+        self.cell_form = os.environ.get("PN_SIM_FORM", "cells") != "csr"
         bbox = bbox.clone() * 1.02   # solver.py:24-25 multiply in the caller's dtype (main_gui.py passes float32), then widen
         base = base.clone() * 1.01
         self.dt, self.iters, self.dx, self.kres, self.stiff = dt, iters, dx, kres, stiff
@@ -84,6 +87,9 @@ class Simulator:
         self.precompute()
         self._work = torch.empty(int(lib().pn_sim_work_doubles(self.n_k, self.n_IP)), dtype=torchfloat, device=self.device)
         self._prepared = False  # pn_sim_prepare runs with the first substep (the CSR lists it reads are built further down)
+        if self.cell_form:      # the cell form's work area: identity rotations for the warm-started SVD, arrival counters (never inside a stream capture)
+            self._cells_work = torch.empty(int(lib().pn_sim_cells_work_doubles(self.n_k, self._cells["n_chunks"])), dtype=torchfloat, device=self.device)
+            check(lib().pn_sim_cells_prepare(self.n_k, self._cells["n_chunks"], ptr(self._cells_work), stream_ptr()), "sim_cells_prepare")
         self.rhs_rest = (self.build_rhs() + self._matvec(self.Mmat, self.dof)).contiguous()   # solver.py:314
 
     def precompute(self):
@@ -151,11 +157,58 @@ class Simulator:
         self.csr_pos = torch.empty_like(self.buffer)
         self.csr_pos[order] = torch.arange(order.numel(), dtype=torch.int32, device=dev)   # inverse of `buffer`
 
+        self._IP2K = IP2K
+        self._build_cells()
+
         m = (self.IP_rho * self.dx * self.dx * self.dx)                                      # collect_gravity, cuda_utils.py:262-279
         rg = torch.zeros((n_k * 10, 3), dtype=torchfloat, device=dev)
         rows = (self.IP_kernel.long()[:, :, None] * 10 + torch.arange(10, device=dev)[None, None, :]).reshape(-1)
         gmls.index_add_ordered(rg, rows, (m[:, None, None] * self.IP_Nx).reshape(-1)[:, None] * self.gravity[None, :])
         self.rhs_gravity = rg.reshape(-1).contiguous()
+
+    def _build_cells(self):
+        """Layout of the substep's CELL form (include/pienerf_hip.h: pn_sim_stepforward_cells): the integration points of one kernel-grid cell share
+        their 8 neighbour kernels (IP_kernel rows are equal, solver.py:186-205), so they are sorted by cell and every cell is cut into chunks of at most
+        pn_sim_cells_chunk_ips() points — one workgroup each, computing calc_elastic and the points' contributions to collect_rhs_IP in one launch."""
+        dev, n_IP, n_k, kres = self.device, self.n_IP, self.n_k, self.kres
+        B = int(lib().pn_sim_cells_chunk_ips())
+        cell = (self._IP2K[:, 0] * kres + self._IP2K[:, 1]) * kres + self._IP2K[:, 2]
+        order = torch.sort(cell, stable=True).indices                                  # points by cell, ascending point index inside a cell
+        cs = cell[order]
+        first = torch.ones(n_IP, dtype=torch.bool, device=dev)
+        first[1:] = cs[1:] != cs[:-1]
+        start = torch.nonzero(first).reshape(-1)                                       # where each cell begins in the sorted order
+        cnt = torch.diff(torch.cat([start, torch.tensor([n_IP], device=dev)]))
+        nch = (cnt + B - 1) // B                                                       # chunks per cell
+        n_chunks = int(nch.sum())
+        ch_cell = torch.repeat_interleave(torch.arange(len(cnt), device=dev), nch)     # chunk -> cell
+        ch_first = torch.cumsum(nch, 0) - nch                                          # first chunk of each cell
+        ch_j = torch.arange(n_chunks, device=dev) - ch_first[ch_cell]                  # chunk's index inside its cell
+        ch_begin = start[ch_cell] + ch_j * B                                           # first point (sorted order) of the chunk
+        ch_count = torch.minimum(cnt[ch_cell] - ch_j * B, torch.tensor(B, device=dev))
+        local = torch.arange(B, device=dev)[None, :]
+        valid = local < ch_count[:, None]                                              # [n_chunks, B]
+        src = order[torch.clamp(ch_begin[:, None] + local, max=n_IP - 1)]              # original point index per chunk position
+        topo = self.IP_kernel.long()
+        assert bool((topo[src[valid]] == topo[src[:, :1].expand(-1, B)[valid]]).all()), "points of one kernel-grid cell must share their 8 kernels"
+        tab = torch.zeros((n_chunks, 12), dtype=torch.int32, device=dev)
+        tab[:, 0] = ch_count.to(torch.int32)
+        tab[:, 1:9] = topo[src[:, 0]].to(torch.int32)
+        g = self.IP_dNx.reshape(n_IP, 8, 30)[src] * valid[:, :, None, None].to(torchfloat)   # [n_chunks, B, 8, 30]
+        # lane l of wave w = point w * 8 + l // 8, slot l % 8: [chunk][wave][15][64][2]
+        g = g.reshape(n_chunks, B // 8, 8, 8, 15, 2).permute(0, 1, 4, 2, 3, 5).reshape(n_chunks, B // 8, 15, 64, 2)
+        self._cells = dict(n_chunks=n_chunks, B=B, tab=tab.contiguous(), dNx=g.contiguous(),
+                           mu=(self.IP_mu[src] * valid).reshape(-1).contiguous(), lam=(self.IP_lam[src] * valid).reshape(-1).contiguous(), src=src, valid=valid)
+        # per kernel: the (chunk, slot) pairs that refer to it, ascending
+        keys = tab[:, 1:9].reshape(-1).long()
+        kp = torch.sort(keys, stable=True).indices
+        kcnt = torch.bincount(keys, minlength=n_k)
+        self._cells["kp_list"] = kp.to(torch.int32).contiguous()
+        pos = torch.empty_like(kp)
+        pos[kp] = torch.arange(kp.numel(), device=dev)
+        self._cells["kp_pos"] = pos.to(torch.int32).contiguous()                       # where (chunk, slot) stores its partial sum: its rank in its kernel's run
+        self._cells["kp_bg"] = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(kcnt, 0)]).to(torch.int32).contiguous()
+        self._cells_work = None
 
     def collect_IP(self):  # solver.py:427-450
         n_IP, idx = self.n_IP, self.pts_IP.long()
@@ -270,6 +323,13 @@ class Simulator:
                                                 ptr(self.IP_lam), ptr(self.IP_dNx), ptr(self.dNx_csr), ptr(self.csr_pos), ptr(self.Ainv), ptr(self.Mmat),
                                                 ptr(self.dof_rest), ptr(self.rhs_rest), ptr(self.rhs_gravity), ptr(self.dof_f), ptr(self.dof), ptr(self.dof_vel),
                                                 ptr(self._work), ptr(buf), n_wg, plan, stream_ptr()), "stepforward_coop")
+            return
+        if self.cell_form and self._cells_work is not None and int(self.iters) >= 1:
+            c = self._cells
+            check(lib().pn_sim_stepforward_cells(self.n_k, c["n_chunks"], int(self.iters), float(self.dt), float(self.dx), ptr(c["tab"]), ptr(c["dNx"]),
+                                                 ptr(c["mu"]), ptr(c["lam"]), ptr(c["kp_bg"]), ptr(c["kp_pos"]), ptr(self.Ainv), ptr(self.Mmat),
+                                                 ptr(self.dof_rest), ptr(self.rhs_rest), ptr(self.rhs_gravity), ptr(self.dof_f), ptr(self.dof), ptr(self.dof_vel),
+                                                 ptr(self._cells_work), stream_ptr()), "stepforward_cells")
             return
         check(lib().pn_sim_stepforward(self.n_k, self.n_IP, int(self.iters), float(self.dt), float(self.dx), ptr(self.IP_kernel), ptr(self.kernel_bg),
                                        ptr(self.kernel_cnt), ptr(self.buffer), ptr(self.IP_mu), ptr(self.IP_lam), ptr(self.IP_dNx), ptr(self.dNx_csr), ptr(self.csr_pos), ptr(self.Ainv),

@@ -143,7 +143,8 @@ def test_captured_graphs_follow_an_in_place_weight_refresh_that_moves_the_scales
     for f in range(first + 3):
         out = want_h.step()
         if f >= first:
-            assert np.array_equal(got[f - first][1], out["image"].cpu().numpy()), f
+            want = out["image"][0].cpu().numpy()
+            assert got[f - first][1].shape == want.shape and np.array_equal(got[f - first][1], want), (f, float(np.abs(got[f - first][1] - want).max()))
 
 
 def test_graphs_captured_under_another_network_form_are_refused(small_cloud, small_opt, ckpt):

@@ -212,6 +212,30 @@ def test_simulator_precompute_matches_oracle_init(small_cloud, small_opt, oracle
     for k in (0, s.n_k // 2, s.n_k - 1):
         seg = buf[bg[k]:bg[k] + cnt[k]]
         assert np.all(topo[seg] == k) and np.all(np.diff(seg) > 0)
+    # the cell form's layout (pn_sim_stepforward_cells): every (point, slot) pair exactly once, a chunk's points share their 8 kernels, and the data flow of
+    # k_cells_elastic_gather restated in numpy on this layout — per-chunk partial sums of P dNx added per kernel in kp_list order — is collect_rhs_IP
+    cl = s._cells
+    B, nch = cl["B"], cl["n_chunks"]
+    src, valid, tab = cl["src"].numpy(), cl["valid"].numpy(), cl["tab"].numpy()
+    assert B == 8 * (B // 8) and valid.sum() == s.n_IP and np.array_equal(np.sort(src[valid]), np.arange(s.n_IP))
+    assert np.array_equal(tab[:, 0], valid.sum(1)) and tab[:, 0].min() >= 1 and tab[:, 0].max() <= B
+    tk = s.IP_kernel.numpy()
+    for c in range(nch):
+        assert np.all(tk[src[c][valid[c]]] == tab[c, 1:9][None, :])
+    kp_bg, kp_list = cl["kp_bg"].numpy(), cl["kp_list"].numpy()
+    assert kp_bg[-1] == 8 * nch and np.array_equal(np.sort(kp_list), np.arange(8 * nch))
+    for k in range(s.n_k):
+        seg = kp_list[kp_bg[k]:kp_bg[k + 1]]
+        assert len(seg) >= 1 and np.all(np.diff(seg) > 0) and np.all(tab[seg // 8, 1 + seg % 8] == k)
+    rng = np.random.default_rng(3)
+    P = rng.standard_normal((s.n_IP, 3, 3))
+    g = cl["dNx"].numpy().reshape(nch, B // 8, 15, 8, 8, 2).transpose(0, 1, 3, 4, 2, 5).reshape(nch, B, 8, 3, 10)   # [chunk][point][slot][c][x]
+    assert np.array_equal(g[valid], s.IP_dNx.numpy()[src[valid]]) and not g[~valid].any()
+    part = np.einsum("cprk,cpskx->csxr", np.where(valid[:, :, None, None], P[src], 0.0), g)                         # [chunk][slot][x][r]
+    rhs = np.stack([part.reshape(nch * 8, 10, 3)[kp_list[kp_bg[k]:kp_bg[k + 1]]].sum(0) for k in range(s.n_k)])
+    want = np.zeros((s.n_k, 10, 3))
+    np.add.at(want, tk.reshape(-1), np.einsum("prk,pskx->psxr", P, s.IP_dNx.numpy()).reshape(-1, 10, 3))
+    assert rel_err(rhs, want) < 1e-13
     # the reference's (30 n_k)^2 views
     assert s.global_matrix.shape == (s.n_k * 30, s.n_k * 30)
     x = torch.randn(s.n_k * 30, dtype=torch.float64)

@@ -21,7 +21,7 @@ val() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitl
 for job in "$@"; do
   IFS=: read -r kind a b c <<< "$job"
   case $kind in
-    tests) if [ -n "$a" ]; then python -m pytest tests -m gpu -q -x -k "$a" 2>&1 | tail -15 | tee $O/pytest_gpu_$(echo $a | tr ' ' _).txt; else python -m pytest tests -m gpu -q 2>&1 | tail -15 | tee $O/pytest_gpu.txt; fi ;;
+    tests) if [ -n "$a" ]; then python -m pytest tests -m gpu -q -x -k "$a" > $O/pytest_gpu_$(echo $a | tr ' ' _).txt 2>&1; grep -E "^(FAILED|ERROR)|passed|failed|^E  .*(assert|Error)" $O/pytest_gpu_$(echo $a | tr ' ' _).txt | cut -c1-400 | tail -20; else python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; grep -E "^(FAILED|ERROR)|passed|failed|^E  .*(assert|Error)" $O/pytest_gpu.txt | cut -c1-400 | tail -30; fi ;;
     bench) cfg=${a:-chair}; args=$(echo "$b" | tr + ' '); tag=$(echo "$b" | tr -c 'a-zA-Z0-9\n' _)
            python bench.py --config $cfg $args > $O/bench_${cfg}${tag}.json 2> $O/bench_${cfg}${tag}.err; echo "bench $cfg $args: $(val < $O/bench_${cfg}${tag}.json)" | tee -a $O/summary.txt ;;
     stats) cfg=${a:-chair}; (cd /tmp && rm -rf /tmp/st_$cfg && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$cfg -o $cfg -- python $R/bench.py --no-cpu-baseline --no-extras --config $cfg --steps 100 --warmup 10 > $O/stats_$cfg.out 2> /tmp/st_$cfg.log || echo "stats $cfg failed"; find /tmp/st_$cfg -name "*kernel_stats.csv" -exec cp {} $O/${cfg}_kernel_stats.csv \; ); head -12 $O/${cfg}_kernel_stats.csv ;;

@@ -23,7 +23,7 @@ args = ap.parse_args()
 raw = C.CDLL(LIB_PATH)
 CAP = 65536
 buf = (C.c_uint64 * (1 + CAP))()
-NAMES = {1: "k_elastic", 2: "k_rhs_gather_chunk", 3: "k_matvec3", 4: "k_update_F"}
+NAMES = {1: "k_elastic / k_cells_elastic_gather", 2: "k_rhs_gather_chunk", 3: "k_matvec3", 4: "k_update_F"}
 
 
 def report(tag):
@@ -33,6 +33,14 @@ def report(tag):
     ids, t = (a >> np.uint64(56)).astype(np.int64), (a & np.uint64((1 << 56) - 1)).astype(np.int64)
     o = np.argsort(t, kind="stable")
     ids, t = ids[o], t[o]
+    if hasattr(raw, "pn_sim_phase_read"):   # phase clocks of k_cells_elastic_gather, all workgroups
+        pb = (C.c_uint64 * 24)()
+        assert raw.pn_sim_phase_read(pb, 1) == 0
+        if pb[8]:
+            names = ["loads + F", "SVD + P", "contributions -> LDS", "LDS sums, store, ack", "arrival atomic", "completed kernels' sums"]
+            for p_, nme in enumerate(names):
+                print(f"   {nme:26s} mean {pb[p_] / pb[8] * 0.01:5.2f} us   max {pb[10 + p_] * 0.01:5.2f} us")
+            print(f"   workgroups {pb[8]}, longest start-to-end of one workgroup {pb[9] * 0.01:.2f} us")
     sim = ids < 4                       # the substep's chain: elastic -> gather -> matvec (update_F runs on the render lanes)
     ids_s, t_s = ids[sim], t[sim]
     gaps = np.diff(t_s) / 100.0         # us: from the start of a launch to the start of the next one of the chain = that launch's latency
@@ -55,6 +63,8 @@ with torch.no_grad():
         h.sim.stepforward()
     torch.cuda.synchronize()
     raw.pn_sim_stamps_read(None, 1)
+    if hasattr(raw, 'pn_sim_phase_read'):
+        raw.pn_sim_phase_read(None, 1)
     for _ in range(100):
         h.sim.stepforward()
     report("substep alone")
@@ -63,6 +73,8 @@ with torch.no_grad():
         h.step_pipelined()
     torch.cuda.synchronize()
     raw.pn_sim_stamps_read(None, 1)
+    if hasattr(raw, 'pn_sim_phase_read'):
+        raw.pn_sim_phase_read(None, 1)
     for _ in range(args.frames):
         h.step_pipelined()
     h.drain_pipeline()
