@@ -464,8 +464,10 @@ def pipelined_extras(make_harness, args, steps):
         # its own: `value` and the dominant kernel's roofline block, so that the driver's record of the default run covers every single-GPU config
         import subprocess
         oc = {}
-        for cfg in ("trex", "stress"):
-            cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", "100", "--warmup", "20", "--no-extras", "--no-cpu-baseline"]
+        # ... and SURVEY 8d's second pass of config 2: the chair under a constant update_force on the middle integration point
+        runs = [("trex", ["--config", "trex"]), ("stress", ["--config", "stress"]), ("chair_forced", ["--force", "300", "100", "-200"])]
+        for cfg, extra_args in runs:
+            cmd = [sys.executable, os.path.abspath(__file__)] + extra_args + ["--steps", "100", "--warmup", "20", "--no-extras", "--no-cpu-baseline"]
             try:
                 o_ = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 d = json.loads([ln for ln in o_.stdout.splitlines() if ln.startswith("{")][-1])
@@ -473,7 +475,12 @@ def pipelined_extras(make_harness, args, steps):
                 oc[cfg] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "verified": d.get("verified"), "workload": d["config"]["workload"],
                            "samples_per_frame": d["config"]["samples_per_frame"], "trips_per_frame": d["config"]["trips_per_frame"], "launch": d["config"]["launch"],
                            "roofline": {k: r.get(k) for k in ("kernel", "achieved", "frac", "launch_ms", "launch_ms_alone", "frac_alone", "ms_per_frame", "traffic", "first_trips_march")},
-                           "network_frac": d["network"]["frac"], "render_frame_eager_ms": d["breakdown_ms"]["render_frame_eager"]}
+                           "network_frac": d["network"]["frac"], "render_frame_eager_ms": d["breakdown_ms"]["render_frame_eager"],
+                           "substep_ms_alone": d["breakdown_ms"]["stepforward_alone"]}
+                if cfg in ("trex", "stress"):   # the two-lane rate of a rank of a multi-GPU job on this configuration, for its predicted_scaling below
+                    o2 = subprocess.run(cmd + ["--lanes", "2"], capture_output=True, text=True, timeout=600)
+                    d2 = json.loads([ln for ln in o2.stdout.splitlines() if ln.startswith("{")][-1])
+                    oc[cfg]["two_lanes_steps_per_s"] = d2["value"]
             except Exception as e:  # noqa: BLE001 — measurement only
                 oc[cfg] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
         res["other_configs"] = oc
@@ -511,6 +518,10 @@ def main():
     ap.add_argument("--form", choices=("auto", "whole", "fold", "plain", "trips"), default="auto",
                     help="form of a frame's launches in the pipeline (auto: what harness.capture_pipelined picks from a warm-up frame): the whole frame in the fused "
                          "launch / the first trip's network + composite + compaction folded into it / later trips fused only / trip-by-trip launches")
+    ap.add_argument("--parallelism", choices=("frame", "tile"), default="frame",
+                    help="N > 1: 'frame' = whole frames round-robin over the ranks (throughput; BASELINE configs[3]); 'tile' = every frame split into 8 x 8 pixel tiles "
+                         "over ALL ranks + one all_gather_into_tensor (latency; frames.TileParallel; SURVEY 8e's alternative).  With N = 1 'tile' runs the same "
+                         "eager one-frame-at-a-time path on one rank (PN_FORCE_DIST=1: inside a one-rank RCCL group, collectives included)")
     ap.add_argument("--sigma-gain", type=float, default=1.0, help="scales the synthetic checkpoint's density (samples per frame fall as it rises)")
     args = ap.parse_args()
 
@@ -518,7 +529,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     rccl_ranks = None
-    if world > 1:
+    force_dist = world == 1 and os.environ.get("PN_FORCE_DIST", "") == "1"   # a process group of ONE rank (tests: RCCL itself on a one-GPU box)
+    if force_dist:
+        os.environ.setdefault("MASTER_PORT", "29577")
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" IS RCCL on ROCm.  PN_DIST_BACKEND=gloo lets the N > 1 code path be exercised on a one-GPU box (ranks share cuda:0).
@@ -559,7 +573,25 @@ def main():
         h.wait_frame_copies()   # the copier thread's SDMA copies are on no stream: the clock stops when the last frame enqueued has landed in host memory
 
     frames_done = [0]
-    if world == 1:
+    tile_mode = args.parallelism == "tile"
+    if tile_mode:
+        # every rank renders 1/world of each frame's 8 x 8 tiles from the owner's broadcast DOF snapshot; one all-gather hands every rank the frame.
+        # Launches are eager, one frame at a time: this form divides a frame's LATENCY by the rank count (the frame-parallel form only adds throughput)
+        if world > 1:
+            from pienerf_amd.frames import broadcast_tensors
+            m = h.model
+            broadcast_tensors([m.encoder.embeddings.data, m.density_bitfield] + [l.weight.data for l in list(m.sigma_net) + list(m.color_net)], src=0)
+            m._net_sig = None
+        h.capture_tile_parallel(_force_collectives=force_dist)
+
+        def run_steps(n):
+            for _ in range(n):
+                o_ = h.step_tile_parallel()
+                if copy_out and rank == 0:
+                    h.to_host(o_)
+            frames_done[0] += n
+        launch = f"eager launches, one frame at a time, each frame's 8 x 8 pixel tiles interleaved over {world} rank(s) + one all_gather_into_tensor"
+    elif world == 1:
         if args.eager:
             def run_steps(n):
                 for _ in range(n):
@@ -642,7 +674,9 @@ def main():
         elapsed = time.perf_counter() - t0
         continued = 0
         verified = None
-        if world > 1 or not (args.eager or args.single_graph):  # the last frames in flight are retired here
+        if tile_mode:
+            pass
+        elif world > 1 or not (args.eager or args.single_graph):  # the last frames in flight are retired here
             frames_done[0] += len(h.drain_pipeline())
             continued = h._pipe_backend.continued
             # ... and the last frame the pipeline delivered is rendered again, launch by launch, from the state its workspace holds: bit for bit
@@ -663,7 +697,7 @@ def main():
 
     if rank == 0:
         del_h = h
-        pipelined = world == 1 and not (args.eager or args.single_graph)
+        pipelined = world == 1 and not (args.eager or args.single_graph or tile_mode)
         form_kw = {k: h._pipe_backend.kw.get(k) for k in ("fused_from", "fused_grid", "fused_whole", "fused_fold", "march_throughput", "march_throughput_trips")} if hasattr(h, "_pipe_backend") else None
         with torch.no_grad():
             graph_ms = None
@@ -677,16 +711,16 @@ def main():
             st, roofline, extra = kernel_report(hk, opt, dev, form_kw, graph_ms)
         res = {
             "metric": "sim+render steps/s @800x800 chair" if args.config == "chair" else f"sim+render steps/s, {args.config} configuration",
-            "value": round(args.steps * world / elapsed, 3), "unit": "steps/s", "n_gpus": world,
+            "value": round(args.steps * (1 if tile_mode else world) / elapsed, 3), "unit": "steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
-            "value_unprimed": round(args.steps * world / elapsed_unprimed, 3),
+            "value_unprimed": round(args.steps * (1 if tile_mode else world) / elapsed_unprimed, 3),
             "value_note": (f"`value`: K = {args.steps} timed steps after {args.prime} priming + W = {args.warmup} warm-up steps of the already running pipeline (steady state); "
                            f"`value_unprimed`: the first K timed steps after only the W warm-up steps, right behind the graph captures"),
             "verified": (bool(verified["ok"]) if verified else None),
             "verified_note": (f"frame {verified['frame']} (the last one the timed pipeline delivered, as copied to host memory) == a blocking launch-by-launch render of the "
                               f"same integration-point state and pose, bit for bit on image and depth_0: max abs difference {verified.get('max_abs_diff')}" if verified else
                               "not a pipelined run"),
-            "scaling": "weak", "vs_baseline": None, "dtype": ("f16 tables+MLP / f32 march / f64 sim" if opt.get("fp16") else "f32 render / f64 sim"), "data": "synthetic",
+            "scaling": ("strong" if tile_mode else "weak"), "vs_baseline": None, "dtype": ("f16 tables+MLP / f32 march / f64 sim" if opt.get("fp16") else "f32 render / f64 sim"), "data": "synthetic",
             "config": {"workload": workload + (f", constant force {[float(v) for v in force]} on IP {hk.sim.n_IP // 2}" if force is not None else ", gravity only")
                        + ("" if copy_out else " [--no-d2h: outputs left on the device]") + ("" if args.probe == "none" else f" [--probe {args.probe}: a diagnosis run, not the benchmark]"),
                        "rays": opt["W"] * opt["H"], "n_IP": hk.sim.n_IP, "n_kernels": hk.sim.n_k, "n_points": int(len(cloud["pos"])),
@@ -694,8 +728,10 @@ def main():
                        "frames_continued_past_captured_trips": continued, "launch": launch, "prime_steps": args.prime, "sigma_gain": args.sigma_gain,
                        "hit_rays": st["hit_rays"], "mean_samples_per_hit_ray": round(st["samples"] / max(1, st["hit_rays"]), 2),
                        "ranks": world, "dist_backend": (os.environ.get("PN_DIST_BACKEND", "nccl") if world > 1 else None), "rccl_ranks": rccl_ranks,
-                       "frames_per_rank": per_rank_frames, "dedicated_sim": (bool(del_h._pipe.dedicated) if world > 1 else None),
-                       "parallelism": (f"frame-parallel x{world} ({rccl_ranks} RCCL ranks), dof snapshots broadcast over RCCL, "
+                       "frames_per_rank": per_rank_frames, "dedicated_sim": (bool(del_h._pipe.dedicated) if (world > 1 and not tile_mode) else None),
+                       "parallelism": (f"tile-parallel x{world} ({rccl_ranks} RCCL ranks{', collectives forced' if force_dist else ''}): every frame's 8 x 8 pixel tiles interleaved over the "
+                                       f"ranks, dof snapshot broadcast + one all_gather_into_tensor per frame; ms_per_step is a frame's latency") if tile_mode else
+                                      (f"frame-parallel x{world} ({rccl_ranks} RCCL ranks), dof snapshots broadcast over RCCL, "
                                        + ("rank 0 simulates only, frames round-robin over the other ranks" if del_h._pipe.dedicated else "frames round-robin over all ranks")
                                        + f", frames per rank {per_rank_frames}") if world > 1 else "single GPU"},
             "roofline": roofline,
@@ -710,7 +746,7 @@ def main():
                                          "note": "steps/s of an N-GPU frame-parallel job <= min(owner_frames_per_s [owner dedicated: its substep has the GPU to itself; "
                                                  "as one persistent kernel with PN_SIM_COOP=1 (opt-in: never run beside RCCL), else owner_frames_per_s_launch_form], "
                                                  "renderers x the single-GPU render rate); with the owner also rendering its substep (launch form) shares the GPU and is ~1.8x slower"}
-        if world == 1 and not args.no_extras and not (args.eager or args.single_graph):
+        if world == 1 and not args.no_extras and not (args.eager or args.single_graph or tile_mode):
             with torch.no_grad():
                 res.update(pipelined_extras(make_harness, args, max(40, min(args.steps, 120))))
         if world == 1 and "two_lanes" in res:
@@ -718,11 +754,17 @@ def main():
             # substeps share its GPU with its renders (measured x1.8 slower than alone); N >= 3: rank 0 only simulates (launch form) and broadcasts each
             # <= 82 KB snapshot, N - 1 ranks render with two lanes each; the broadcast (~20 us over xGMI) overlaps on the communication stream
             r2, own = res["two_lanes"]["steps_per_s"], res["frame_parallel_ceiling"]["owner_frames_per_s_launch_form"]
-            res["predicted_scaling"] = {"steps_per_s": {"1": res["value"], "2": round(min(own / 1.8, 2 * r2), 1), "4": round(min(own, 3 * r2), 1), "8": round(min(own, 7 * r2), 1)},
-                                        "bound": {"2": "renderers" if 2 * r2 < own / 1.8 else "sim owner (shared GPU)", "4": "renderers" if 3 * r2 < own else "sim owner",
-                                                  "8": "renderers" if 7 * r2 < own else "sim owner"},
-                                        "note": "prediction, not a measurement (no multi-GPU node was available to the builder): min(sim owner's substep rate, rendering ranks x the "
-                                                "two-lane single-GPU rate); the simulator is time-sequential, so the owner's substep rate caps the job whatever N"}
+            def predict(v1, r2_, own_):
+                return {"steps_per_s": {"1": v1, "2": round(min(own_ / 1.8, 2 * r2_), 1), "4": round(min(own_, 3 * r2_), 1), "8": round(min(own_, 7 * r2_), 1)},
+                        "bound": {"2": "renderers" if 2 * r2_ < own_ / 1.8 else "sim owner (shared GPU)", "4": "renderers" if 3 * r2_ < own_ else "sim owner",
+                                  "8": "renderers" if 7 * r2_ < own_ else "sim owner"}}
+            res["predicted_scaling"] = dict(predict(res["value"], r2, own),
+                                            note="prediction, not a measurement (no multi-GPU node was available to the builder): min(sim owner's substep rate, rendering ranks x the "
+                                                 "two-lane single-GPU rate); the simulator is time-sequential, so the owner's substep rate caps the job whatever N")
+            for cfg in ("trex", "stress"):
+                oc_ = res.get("other_configs", {}).get(cfg, {})
+                if "two_lanes_steps_per_s" in oc_ and oc_.get("substep_ms_alone"):
+                    res["predicted_scaling"][cfg] = predict(oc_["value"], oc_["two_lanes_steps_per_s"], round(1e3 / oc_["substep_ms_alone"], 1))
         if staged and not args.no_extras:  # the same configuration with the frame rendered in one shot (what render_deformed does with these options in the reference)
             with torch.no_grad():
                 opt.pop("ray_batch")
@@ -742,7 +784,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # a reported baseline, timed on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(opt, cloud, ckpt, pose, force, args.cpu_budget)
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 or force_dist:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

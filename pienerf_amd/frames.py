@@ -69,8 +69,10 @@ class TileParallel:
     render_subset(indices [n] int64, -1 = padding) -> float32 tensor [n, channels] on the communication device (image | depth | depth_0 = 5 channels)
     get_dof() / set_dof(t): the owner's state / installing the received state;  sim_step(): one substep on the owner."""
 
-    def __init__(self, W, H, render_subset, get_dof, set_dof, sim_step, sim_owner=0, group=None, tile=8, device="cpu"):
+    def __init__(self, W, H, render_subset, get_dof, set_dof, sim_step, sim_owner=0, group=None, tile=8, device="cpu", force_collectives=False):
         on = dist.is_available() and dist.is_initialized()
+        # force_collectives: a world of ONE rank still runs the broadcast and the all-gather (tests: RCCL itself on a one-GPU box)
+        self.collectives = on and (dist.get_world_size(group) > 1 or bool(force_collectives))
         self.world = dist.get_world_size(group) if on else 1
         self.rank = dist.get_rank(group) if on else 0
         self.W, self.H, self.group, self.owner = W, H, group, sim_owner
@@ -78,20 +80,23 @@ class TileParallel:
         self.parts = [p.to(device) for p in tile_partition(W, H, self.world, tile)]
         self.render_subset, self.get_dof, self.set_dof, self.sim_step = render_subset, get_dof, set_dof, sim_step
         self._recv = None
+        self._gather = None
 
     def step(self):
         """Renders the current state (the state BEFORE this step's substep, trainer.py:300-318) and advances the simulator.  Returns the full
         frame [H*W, channels] on every rank."""
-        if self.world > 1:
+        if self.collectives:
             buf = self.get_dof() if self.rank == self.owner else (self._recv if self._recv is not None else torch.empty_like(self.get_dof()))
             self._recv = None if self.rank == self.owner else buf
             dist.broadcast(buf, src=self.src, group=self.group)
             if self.rank != self.owner:
                 self.set_dof(buf)
-        mine = self.render_subset(self.parts[self.rank])
-        if self.world > 1:
-            gathered = [torch.empty_like(mine) for _ in range(self.world)]
-            dist.all_gather(gathered, mine.contiguous(), group=self.group)   # RCCL: one all-gather of 20 B x N / world per rank
+        mine = self.render_subset(self.parts[self.rank]).contiguous()
+        if self.collectives:
+            if self._gather is None or self._gather.shape[1:] != mine.shape or self._gather.dtype != mine.dtype:
+                self._gather = torch.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+            dist.all_gather_into_tensor(self._gather.view(-1, mine.shape[1]), mine, group=self.group)   # RCCL: ONE all-gather of 20 B x N / world per rank
+            gathered = list(self._gather.unbind(0))
         else:
             gathered = [mine]
         full = torch.empty(self.W * self.H, mine.shape[1], dtype=mine.dtype, device=mine.device)

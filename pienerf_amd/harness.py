@@ -364,7 +364,7 @@ class SimRenderHarness:
 
     # ------------------------------------------------------------------ one frame split over the ranks (interactive latency)
     @torch.no_grad()
-    def capture_tile_parallel(self, group=None, sim_owner=0, tile=8, W=None, H=None):
+    def capture_tile_parallel(self, group=None, sim_owner=0, tile=8, W=None, H=None, _force_collectives=False):
         """Ray-tile-parallel form ("alternative for interactive latency"; frames.TileParallel): every rank renders an
         interleaved 1/world of the 8 x 8 pixel tiles of the SAME frame from the sim owner's broadcast DOF snapshot, and one all-gather
         (20 B x N / world per rank over RCCL) gives every rank the whole frame.  Unlike the frame-parallel pipeline, whose throughput is
@@ -387,7 +387,8 @@ class SimRenderHarness:
 
         def set_dof(t):
             self.sim.dof.copy_(t)
-        self._tile = TileParallel(W, H, render_subset, lambda: self.sim.dof, set_dof, self.sim.stepforward, sim_owner=sim_owner, group=group, tile=tile, device=dev)
+        self._tile = TileParallel(W, H, render_subset, lambda: self.sim.dof, set_dof, self.sim.stepforward, sim_owner=sim_owner, group=group, tile=tile, device=dev,
+                                  force_collectives=_force_collectives)
         self._tile_WH = (W, H)
         return self
 

@@ -111,6 +111,25 @@ def _tile_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _tile_rccl_worker(rank, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))   # "nccl" IS RCCL on ROCm
+    from pienerf_amd.harness import SimRenderHarness
+    opt, cloud, ckpt = _scene()
+    h = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device="cuda:0")
+    h.capture_tile_parallel(_force_collectives=True)
+    assert h._tile.collectives and h._tile.world == 1
+    frames = [h.step_tile_parallel()["image"][0].cpu().numpy() for _ in range(4)]
+    assert h._tile._gather is not None   # the all-gather ran
+    np.save(os.path.join(out_dir, "tile_rccl.npy"), np.stack(frames))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def test_tile_parallel_two_ranks_on_gpu(tmp_path):
     """Ray-tile-parallel rendering (harness.capture_tile_parallel): two gloo ranks on the one GPU each render half of the 8 x 8 tiles of every frame from
     rank 0's broadcast DOFs; both end up with the whole frame, equal to the single-process eager frame bit for bit (rays are independent)."""
@@ -228,3 +247,46 @@ def test_rccl_snapshot_and_checkpoint_broadcasts_beside_graphs_and_copier(tmp_pa
             assert np.abs(want[f] - got[f]).max() < 1e-5, f
         else:
             assert np.abs(want[f] - got[f]).max() == 0.0, f
+
+
+def test_bench_tile_parallel_command_line_with_rccl_world_of_one():
+    """`bench.py --parallelism tile` (frames.TileParallel: every frame's 8 x 8 pixel tiles over the ranks, dof snapshot broadcast + ONE
+    all_gather_into_tensor per frame) inside a one-rank RCCL group (PN_FORCE_DIST=1, collectives forced: RCCL itself runs every collective of the
+    N-rank schedule — all this box has), and the two-rank schedule through gloo ranks sharing the GPU: one JSON line, `scaling` strong, frames counted."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    base = ["bench.py", "--parallelism", "tile", "--steps", "6", "--warmup", "2", "--prime", "2", "--no-cpu-baseline", "--no-extras"]
+    env = dict(os.environ, PN_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable] + base, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["value"] > 0 and d["config"]["rccl_ranks"] == 1
+    assert "collectives forced" in d["config"]["parallelism"] and "all_gather_into_tensor" in d["config"]["parallelism"]
+    env = dict(os.environ, PN_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + base + ["--gpus", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["frames_per_rank"] == [2 * (6 + 2) + 2] * 2 and "tile-parallel x2" in d["config"]["parallelism"]
+
+
+def test_tile_parallel_frames_through_rccl_equal_the_eager_frames(tmp_path):
+    """frames.TileParallel with its collectives forced inside a one-rank RCCL ("nccl") group: the broadcast of the dof snapshot and the
+    all_gather_into_tensor of the rank's tiles run through RCCL, and the frames equal the single-process eager frames bit for bit."""
+    import torch.multiprocessing as mp
+    from pienerf_amd.harness import SimRenderHarness
+    opt, cloud, ckpt = _scene()
+    eager = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device="cuda:0")
+    want = [eager.step()["image"][0].clone().cpu().numpy() for _ in range(4)]
+    eager.synchronize()
+    del eager
+    torch.cuda.empty_cache()
+    mp.spawn(_tile_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    got = np.load(tmp_path / "tile_rccl.npy")
+    for f in range(4):
+        assert np.array_equal(got[f], want[f]), f

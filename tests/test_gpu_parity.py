@@ -344,7 +344,8 @@ def test_sim_kernels_and_step(small_cloud, small_opt):
             ref.clear_force()
     p1, F1, dF1 = (t.cpu().numpy() for t in sim.get_IP_info())
     p2, F2, dF2 = ref.get_IP_info()
-    assert np.abs(p1 - p2).max() < 1e-5 and np.abs(F1 - F2).max() < 1e-4 and rel_err(dF1, dF2) < 1e-3
+    print(f"get_IP_info after 6 substeps: pos {np.abs(p1 - p2).max():.2e} abs, F {np.abs(F1 - F2).max():.2e} abs, dF {rel_err(dF1, dF2):.2e} rel")
+    assert np.abs(p1 - p2).max() < 1e-5 and np.abs(F1 - F2).max() < 1e-4 and rel_err(dF1, dF2) < 1e-4   # north_star's bar for everything in fp32
     assert np.abs(p2 - ref.IP_pos.numpy()).max() > 1e-3  # the configuration really moved
     # op-level: calc_elastic / collect_rhs on the deformed state
     RF, VF, _ = oracle.calc_elastic(ref.IP_kernel.numpy(), ref.IP_dNx, ref.dof)
