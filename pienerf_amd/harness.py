@@ -92,7 +92,8 @@ class SimRenderHarness:
         return dict(self.opt)
 
     @torch.no_grad()
-    def step(self, pose=None, intrinsics=None, W=None, H=None, simulate=True, collect_stats=False, fused=True):
+    def step(self, pose=None, intrinsics=None, W=None, H=None, simulate=True, collect_stats=False, fused=True, render_kw=None):
+        """render_kw: options of THIS render on top of self.opt (the pipeline's probes of a launch form pass theirs here instead of editing self.opt)."""
         o = self.opt
         W, H = W or o["W"], H or o["H"]
         pose = self.pose if pose is None else pose
@@ -120,6 +121,7 @@ class SimRenderHarness:
                 self.sim.stepforward()
             self.frame += 1
         kw = self.render_kwargs()
+        kw.update(render_kw or {})
         kw["collect_stats"] = collect_stats
         with self._amp():
             if fused:
@@ -529,12 +531,8 @@ class _HipBackend:
             # (1 700-1 740 against 1 560 steps/s), worse with three (1 730 against 1 930) or one at a time — include/pienerf_hip.h
             whole = lanes == 2 and kw["fused_from"] == 1
             if whole:
-                h.opt["fused_whole"] = True   # (render_kwargs() hands the option set to the renderer by name)
-                try:
-                    h.step(simulate=False, collect_stats=True, W=W, H=H)
-                    whole = m.fused_clocks(slot=0)["first_trip"] == 0
-                finally:
-                    h.opt.pop("fused_whole", None)
+                h.step(simulate=False, collect_stats=True, W=W, H=H, render_kw=dict(kw, fused_whole=True, fused_from=0, async_trips=0))
+                whole = m.fused_clocks(slot=0)["first_trip"] == 0
             kw["fused_whole"] = bool(whole)
             if whole:
                 kw["fused_from"] = 0
@@ -545,13 +543,17 @@ class _HipBackend:
             # time the launch with the first trip's tiles in front of its rounds is longer than what it replaces, 0.884 against 0.859 ms per step)
             fold = lanes >= 3 and (not kw.get("fused_whole")) and kw["fused_from"] == 1
             if fold:
-                h.opt["fused_fold"] = True
-                try:
-                    h.step(simulate=False, collect_stats=True, W=W, H=H)
-                    fold = m.fused_clocks(slot=0)["mode"] == 2
-                finally:
-                    h.opt.pop("fused_fold", None)
+                h.step(simulate=False, collect_stats=True, W=W, H=H, render_kw=dict(kw, fused_fold=True, async_trips=0))
+                fold = m.fused_clocks(slot=0)["mode"] == 2
             kw["fused_fold"] = bool(fold)
+        if group is not None:
+            # every rank of a frame-parallel job runs the launch form rank `src` picked (each probed its own warm-up frame: the same state and pose, but
+            # nothing guarantees the same answer at a threshold) — round-4 advisor
+            import torch.distributed as dist
+            pick = torch.tensor([int(kw["fused_from"]), int(bool(kw["fused_whole"])), int(bool(kw["fused_fold"]))], dtype=torch.int64,
+                                device=dev if dist.get_backend(group) == "nccl" else "cpu")
+            dist.broadcast(pick, src=src, group=group)
+            kw["fused_from"], kw["fused_whole"], kw["fused_fold"] = int(pick[0]), bool(pick[1]), bool(pick[2])
         pose0 = torch.from_numpy(np.asarray(h.pose, np.float32)).unsqueeze(0)
         self.pose_dev = [pose0.to(dev) for _ in range(n_ws)]
         self.pose_pin = [pose0.clone().pin_memory() for _ in range(n_ws)]
@@ -721,6 +723,12 @@ class _HipBackend:
                 self.copy_out(_HipStream(s), ws, same_buffer=True)
         s.synchronize()
         self.continued += 1
+        if self.continued == 8:
+            # the launch form baked into the graphs (fused_from / fused_whole / fused_fold, the trip count) came from ONE warm-up frame; a scene or pose
+            # that has moved away from it makes every frame end here, blocking — correct, only slow (round-4 advisor): say so once
+            import warnings
+            warnings.warn("8 frames of this pipeline had rays alive behind their captured trips and were finished by blocking renders: the launch form picked "
+                          "at capture no longer fits the scene / pose — capture_pipelined() again from the current state", RuntimeWarning, stacklevel=2)
 
     def result(self, ws):
         o = self.out[ws]

@@ -642,6 +642,22 @@ def test_full_size_chair_frame_on_the_reference_kernels():
     REPORT["frame_full_size_chair"] = dict(trips=st["trips"], samples=st["samples"], image_max_abs=e_img, weights_sum_max_abs=e_ws, record=a["record"])
     print(REPORT["frame_full_size_chair"])
     assert e_img < 1e-4 and e_ws < 1e-4
+    # ... and by the launch sets bench.py's pipelines run (harness._HipBackend: three lanes = the first trip's network / composite / compaction folded into
+    # the fused launch on 128 workgroups, march pass 1 in its throughput form; two lanes = the whole frame in the launch on 160 workgroups): the modes that
+    # produce `value` against the reference's kernels first-hand, not through the trip-by-trip form
+    forms = {"fold_128_three_lanes": dict(fused_from=1, fused_whole=False, fused_fold=True, fused_grid=128, march_throughput=64),
+             "whole_160_two_lanes": dict(fused_from=0, fused_whole=True, fused_fold=False, fused_grid=160, march_throughput=64)}
+    for name, kw in forms.items():
+        with torch.no_grad():
+            f = net.render_deformed(rays_o[None], rays_d[None], collect_stats=True, **dict(opt, **kw))
+            stf = dict(net.last_stats)
+            mode = net.fused_clocks(slot=0)
+        assert (mode["mode"], mode["first_trip"]) == ((2, 1) if kw["fused_fold"] else (1, 0)), (name, mode)   # the launch really ran in that form
+        assert stf["samples"] == a["samples"] and stf["trips"] == len(a["record"]), (name, stf)
+        assert torch.equal(f["image"], c["image"]) and torch.equal(f["depth_0"], c["depth_0"]), name             # every launch form gives the same bits
+        e_f = float((a["image"] - f["image"][0]).abs().max())
+        REPORT["frame_full_size_chair"][name] = dict(image_max_abs=e_f, samples=stf["samples"], trips=stf["trips"])
+        assert e_f < 1e-4, (name, e_f)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "ref_parity_report_fullsize.json"), "w") as f:
         json.dump(REPORT["frame_full_size_chair"], f)
