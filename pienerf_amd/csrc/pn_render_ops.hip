@@ -634,27 +634,40 @@ static_assert(sizeof(TailEntry) == 64, "four 16-byte parts");
 // G = 1: ONE lane per ray, 256 rays per block — every evaluated point is a visited one (no speculation: a quarter of the VALU work per visited point of
 // the windows, whose lanes evaluate 4.6 elements per voxel hop), at one visited point per round (the windows: ~14).  The throughput form of a frame's
 // first trip (pn_render_opts.throughput): the wave-per-ray tail pass that the pipelined step is bound by only gets the rays that outlast the budget.
-template <int K, bool MULTI, int G>
-__global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
+// WPB != 4 (G = 1 only): the PACKED form of the one-lane pass — WPB waves (12 KB of staging each, dynamic LDS) in ONE workgroup that takes a whole CU, the
+// 64-ray chunks dealt per WAVE.  The first trip's ~1 100 busy waves then sit on ~90 CUs, three per SIMD, instead of one workgroup of 4 on every CU of
+// the chip: a march wave is a chain of dependent instructions that leaves its SIMD idle four cycles in five, so three of them interleave almost for
+// free — and the other frames' fused launches (one 157-KB workgroup per CU, which no CU with a march workgroup on it can take) find the rest of the
+// chip free instead of waiting for the march to end.
+#ifndef PN_MARCH_PACK_WAVES
+#define PN_MARCH_PACK_WAVES 12
+#endif
+template <int K, bool MULTI, int G, int WPB = 4>
+__global__ void __launch_bounds__(WPB * 64, WPB == 4 ? PN_MARCH_WAVES : 1) k_march(pnm::MarchParams a, pnm2::March2Tables tb, MarchIO io) {
     uint32_t n_alive = io.n_alive, n_step_trip = io.n_step;
     bool dense = false;
     if (io.trip) { n_alive = (uint32_t)io.trip->n_alive; n_step_trip = (uint32_t)io.trip->n_step; dense = trip_is_dense(io.trip); }
     static_assert(G == 8 || G == 1, "lanes per ray");
-    constexpr uint32_t RB = 256 / G;  // rays per block and chunk
+    constexpr bool WAVE_DEAL = WPB != 4;
+    static_assert(!WAVE_DEAL || G == 1, "the packed form is the one-lane pass");
+    constexpr uint32_t RB = WAVE_DEAL ? 64u : 256u / G;  // rays per chunk: a workgroup's (a wave's) share per step of its loop
     const int lane = threadIdx.x & 63, sub = lane & (G - 1), gbase = lane & ~(G - 1);
     const int budget = io.tail ? io.max_rounds : 0x7fffffff;
-    __shared__ float4 stage_mem[4][PN_STAGE_CAP];
-    float4* stage = stage_mem[threadIdx.x >> 6];
+    __shared__ float4 stage_mem[WAVE_DEAL ? 1 : 4][WAVE_DEAL ? 1 : PN_STAGE_CAP];
+    extern __shared__ __attribute__((aligned(16))) float4 stage_dyn[];   // WAVE_DEAL: WPB x PN_STAGE_CAP entries
+    float4* stage = WAVE_DEAL ? stage_dyn + (size_t)(threadIdx.x >> 6) * PN_STAGE_CAP : stage_mem[WAVE_DEAL ? 0 : (threadIdx.x >> 6)];
     // 32-ray chunks are dealt round-robin to a bounded grid: in frame mode the alive count is only known on the device, and a
     // grid sized for all N rays would push ~20 000 mostly empty workgroups through the dispatcher on every trip.  With an active list
     // (trip 0) workgroup b walks segment b % PN_SEGS of it; either way `seg` names the segment this workgroup's own appends go to.
-    const uint32_t act_seg = blockIdx.x % PN_SEGS;
+    // (WAVE_DEAL: read "wave" for "workgroup".)
+    const uint32_t unit = WAVE_DEAL ? blockIdx.x * WPB + (threadIdx.x >> 6) : blockIdx.x, n_units = WAVE_DEAL ? gridDim.x * WPB : gridDim.x;
+    const uint32_t act_seg = unit % PN_SEGS;
     const uint32_t n_work = io.active ? (uint32_t)seg_count(io.active_counts, (int)act_seg) : n_alive;
-    const uint32_t k0 = io.active ? blockIdx.x / PN_SEGS : blockIdx.x, kstep = io.active ? (uint32_t)seg_workers((int)gridDim.x, (int)act_seg) : gridDim.x;
+    const uint32_t k0 = io.active ? unit / PN_SEGS : unit, kstep = io.active ? (uint32_t)seg_workers((int)n_units, (int)act_seg) : n_units;
     PN_PHASE_DECL(pk);
     for (uint32_t chunk = k0; chunk * RB < n_work; chunk += kstep) {
         const uint32_t seg = io.active ? act_seg : chunk % PN_SEGS;
-        const uint32_t i_work = chunk * RB + threadIdx.x / G;
+        const uint32_t i_work = chunk * RB + (WAVE_DEAL ? (uint32_t)lane : threadIdx.x / G);
         const uint32_t n = io.active ? (i_work < n_work ? (uint32_t)io.active[(size_t)act_seg * io.active_seg_cap + i_work] : 0xffffffffu) : i_work;
         uint32_t emitted = 0;
         bool deferred = false, have = false;
@@ -797,7 +810,22 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march_tail(pnm::MarchPa
 
 template <int K, bool MULTI>
 static void launch_march_km(uint32_t blocks, uint32_t tail_blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb, const MarchIO& io) {
-    if (io.lane_per_ray) k_march<K, MULTI, 1><<<blocks, 256, 0, st>>>(a, tb, io);
+    // the one-lane pass packed into whole-CU workgroups (see k_march, WPB); PN_MARCH_PACK=0: four waves per workgroup all over the chip (rounds 3-4)
+    static const bool pack = pn_env_u32("PN_MARCH_PACK", 1) != 0;
+    if (io.lane_per_ray && pack) {
+        constexpr int W = PN_MARCH_PACK_WAVES;
+        const size_t lds = (size_t)W * PN_STAGE_CAP * sizeof(float4);
+        static bool granted[PN_MAX_DEVICES] = {false};  // dynamic LDS above 64 KB is opted into per function and DEVICE
+        int dev_id = 0;
+        if (hipGetDevice(&dev_id) == hipSuccess && (dev_id < 0 || dev_id >= PN_MAX_DEVICES || !granted[dev_id])) {
+            (void)hipFuncSetAttribute((const void*)k_march<K, MULTI, 1, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (dev_id >= 0 && dev_id < PN_MAX_DEVICES) granted[dev_id] = true;
+        }
+        // as many waves as the unpacked grid had (blocks x 4), at least PN_SEGS of them, at most one workgroup per CU: beyond that the waves loop
+        static const uint32_t pack_grid = pn_env_u32("PN_MARCH_PACK_GRID", 256);
+        const uint32_t wgs = std::max(std::min(pn_div_up(blocks * 4u, (uint32_t)W), pack_grid), pn_div_up((uint32_t)PN_SEGS, (uint32_t)W));
+        k_march<K, MULTI, 1, W><<<wgs, W * 64, lds, st>>>(a, tb, io);
+    } else if (io.lane_per_ray) k_march<K, MULTI, 1><<<blocks, 256, 0, st>>>(a, tb, io);
     else k_march<K, MULTI, 8><<<blocks, 256, 0, st>>>(a, tb, io);
     if (io.tail) k_march_tail<K, MULTI><<<tail_blocks, 256, 0, st>>>(a, tb, io);
 }
