@@ -810,8 +810,9 @@ __global__ void __launch_bounds__(256, PN_MARCH_WAVES) k_march_tail(pnm::MarchPa
 
 template <int K, bool MULTI>
 static void launch_march_km(uint32_t blocks, uint32_t tail_blocks, hipStream_t st, const pnm::MarchParams& a, const pnm2::March2Tables& tb, const MarchIO& io) {
-    // the one-lane pass packed into whole-CU workgroups (see k_march, WPB); PN_MARCH_PACK=0: four waves per workgroup all over the chip (rounds 3-4)
-    static const bool pack = pn_env_u32("PN_MARCH_PACK", 1) != 0;
+    // PN_MARCH_PACK=1 (experiments): the one-lane pass packed into whole-CU workgroups (see k_march, WPB).  Bit-identical, and measured neutral in the
+    // pipeline on all three configurations (profiles/r05/march_pack_ab.txt), so the default stays four waves per workgroup all over the chip
+    static const bool pack = pn_env_u32("PN_MARCH_PACK", 0) != 0;
     if (io.lane_per_ray && pack) {
         constexpr int W = PN_MARCH_PACK_WAVES;
         const size_t lds = (size_t)W * PN_STAGE_CAP * sizeof(float4);
