@@ -739,13 +739,17 @@ def main():
         res.update(extra)
         # what bounds the frame-parallel job: the sim owner's substep rate — the simulator is time-sequential — against N (or N - 1
         # with a dedicated owner) ranks rendering at the single-GPU rate
-        t_sub = extra["breakdown_ms"]["stepforward_persistent_alone"] or extra["breakdown_ms"]["stepforward_alone"]
+        t_launch, t_coop = extra["breakdown_ms"]["stepforward_alone"], extra["breakdown_ms"]["stepforward_persistent_alone"]
+        t_sub = min(t_launch, t_coop) if t_coop else t_launch   # (since round 5 the launch form — 21 launches in its cell form — is the faster one on the chair)
         res["frame_parallel_ceiling"] = {"substep_ms_alone": t_sub, "owner_frames_per_s": round(1e3 / t_sub, 1),
-                                         "substep_form": "persistent kernel" if extra["breakdown_ms"]["stepforward_persistent_alone"] else "launch form",
-                                         "owner_frames_per_s_launch_form": round(1e3 / extra["breakdown_ms"]["stepforward_alone"], 1),
-                                         "note": "steps/s of an N-GPU frame-parallel job <= min(owner_frames_per_s [owner dedicated: its substep has the GPU to itself; "
-                                                 "as one persistent kernel with PN_SIM_COOP=1 (opt-in: never run beside RCCL), else owner_frames_per_s_launch_form], "
-                                                 "renderers x the single-GPU render rate); with the owner also rendering its substep (launch form) shares the GPU and is ~1.8x slower"}
+                                         "substep_form": "persistent kernel" if (t_coop and t_coop < t_launch) else "launch form (cells: calc_elastic + collect_rhs_IP as one launch)",
+                                         "owner_frames_per_s_launch_form": round(1e3 / t_launch, 1),
+                                         "owner_frames_per_s_persistent_form": (round(1e3 / t_coop, 1) if t_coop else None),
+                                         "physical_ceiling_note": "near-linear scaling to 8 GPUs (7 rendering ranks x the two-lane rate) would need a substep of ~0.07 ms, i.e. ~3 us per "
+                                                                  "dependent phase of its 10 local/global iterations — below what one launch boundary or one device-wide exchange costs "
+                                                                  "(~4.5 us): the simulator is time-sequential (Amdahl), see DESIGN.md 6",
+                                         "note": "steps/s of an N-GPU frame-parallel job <= min(owner_frames_per_s [owner dedicated: its substep has the GPU to itself], "
+                                                 "renderers x the single-GPU render rate); with the owner also rendering its substep shares the GPU and is ~1.8x slower"}
         if world == 1 and not args.no_extras and not (args.eager or args.single_graph or tile_mode):
             with torch.no_grad():
                 res.update(pipelined_extras(make_harness, args, max(40, min(args.steps, 120))))
