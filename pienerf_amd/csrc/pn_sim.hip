@@ -959,6 +959,9 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
 #define PN_CELL_WAVES 4
 #endif
 #define PN_CELL_IPS (PN_CELL_WAVES * 8)
+#ifndef PN_CELL_SVD_PACK
+#define PN_CELL_SVD_PACK 1
+#endif
 #ifndef PN_CELL_SVD_TOL
 #define PN_CELL_SVD_TOL 1e-22
 #endif
@@ -994,13 +997,24 @@ __global__ void __launch_bounds__(PN_CELL_WAVES * 64) k_cells_elastic_gather(con
         s_k[t] = k; s_b0[t] = b0; s_n[t] = kp_bg[k + 1] - b0;
     }
     const size_t vg = (size_t)b * B + vl;                     // ... and in the chunk-ordered per-point arrays
-    // the previous iteration's rotation (lane 0 of the point's group), asked for before anything else: it is needed last
+    // Who decomposes.  PN_CELL_SVD_PACK: lane l < PN_CELL_IPS of wave 0 takes point l of the chunk — ONE wave issues the SVD's ~900 dependent instructions
+    // for all 32 points instead of four waves issuing them for 8 lanes each (the chain is as long either way, but beside the render lanes what the substep
+    // costs is vector issue: the lane-sparse form was 3.4 M of the frame's ~107 M vector instructions, in fp64).  F goes there and P comes back through LDS.
+    // Otherwise: lane 0 of the point's own 8-lane group.
+#if PN_CELL_SVD_PACK
+    const bool svd_lane = w == 0 && lane < B && lane < count;
+    const size_t vs = (size_t)b * B + (size_t)(lane & (B - 1));
+#else
+    const bool svd_lane = i == 0 && live;
+    const size_t vs = vg;
+#endif
+    // the previous iteration's rotation, asked for before anything else: it is needed last
     M3 Q0;
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) Q0.m[r][c] = (i == 0 && live) ? Vstore[vg * 9 + r * 3 + c] : 0.0;
-    const double m_ = (i == 0 && live) ? mu_cell[vg] : 0.0, l_ = (i == 0 && live) ? lam_cell[vg] : 0.0;
+        for (int c = 0; c < 3; c++) Q0.m[r][c] = svd_lane ? Vstore[vs * 9 + r * 3 + c] : 0.0;
+    const double m_ = svd_lane ? mu_cell[vs] : 0.0, l_ = svd_lane ? lam_cell[vs] : 0.0;
     double g[30], d[30];                                      // g[c * 10 + x] = dNx[v, i, c, x] (zeros behind the chunk's last point); d[x * 3 + r]
     {
         const double2* __restrict__ g2 = dNx_cell + ((size_t)b * NW + w) * 15 * 64 + lane;
@@ -1038,7 +1052,19 @@ __global__ void __launch_bounds__(PN_CELL_WAVES * 64) k_cells_elastic_gather(con
         }
     PN_SIM_PHASE(11);
     double Pm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (i == 0 && live) {
+#if PN_CELL_SVD_PACK
+    __shared__ double s_F[PN_CELL_IPS][9], s_P[PN_CELL_IPS][9];
+    if (i == 0) {
+#pragma unroll
+        for (int q = 0; q < 9; q++) s_F[vl][q] = Fm.m[q / 3][q % 3];
+    }
+    __syncthreads();
+    if (svd_lane) {
+#pragma unroll
+        for (int q = 0; q < 9; q++) Fm.m[q / 3][q % 3] = s_F[lane][q];
+    }
+#endif
+    if (svd_lane) {
         M3 U, V;
         double sig[3], sp[3];
         // off-diagonals below 1e-11 of the diagonal (1e-22 on the squares; pairs below 3e-12 are not rotated): seven digits beyond the 1e-4 relative bar
@@ -1047,7 +1073,7 @@ __global__ void __launch_bounds__(PN_CELL_WAVES * 64) k_cells_elastic_gather(con
 #pragma unroll
         for (int r = 0; r < 3; r++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) Vstore[vg * 9 + r * 3 + c] = V.m[r][c];
+            for (int c = 0; c < 3; c++) Vstore[vs * 9 + r * 3 + c] = V.m[r][c];
         volume_invariant_project(sig, sp);
 #pragma unroll
         for (int r = 0; r < 3; r++)
@@ -1059,6 +1085,15 @@ __global__ void __launch_bounds__(PN_CELL_WAVES * 64) k_cells_elastic_gather(con
             }
     }
     PN_SIM_PHASE(12);
+#if PN_CELL_SVD_PACK
+    if (w == 0 && lane < B) {
+#pragma unroll
+        for (int q = 0; q < 9; q++) s_P[lane][q] = Pm[q];   // (zeros behind the chunk's last point)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 9; q++) Pm[q] = s_P[vl][q];
+#else
     {
         const int src = lane & ~7;
 #pragma unroll
@@ -1069,6 +1104,7 @@ __global__ void __launch_bounds__(PN_CELL_WAVES * 64) k_cells_elastic_gather(con
             Pm[q] = *reinterpret_cast<double*>(&tt);
         }
     }
+#endif
     // this (point, slot)'s contribution to its kernel: out[x][r] = sum_c P[r][c] dNx[c][x] (cuda_utils.py:124-151), row x * 3 + r of the wave's buffer
 #pragma unroll
     for (int x = 0; x < 10; x++)

@@ -37,6 +37,9 @@
 #ifndef PN_FUSED_WAVES
 #define PN_FUSED_WAVES 12       // waves per workgroup, one workgroup per CU = 3 waves per SIMD: 61 KB weight image + 8 KB of march staging per wave
 #endif
+#ifndef PN_FUSED_LDS_OUT
+#define PN_FUSED_LDS_OUT 1       // the later trips' network outputs go to the composite through the wave's LDS staging area (free between two march rounds)
+#endif
 #define PN_FUSED_STAGE 512      // staging entries per wave (the record heads of a round go through it in two passes: pn_march_window.h, SPLIT)
 // control block of a frame's fused launch, ints: [3 x PN_FUSED_MAX_TRIPS counters][workgroups done]; all zero at launch
 #define PN_FUSED_CTL_HIST 0
@@ -84,9 +87,13 @@ struct FusedArgs {
 // composite_one (kernel_composite_rays, raymarching.cu:827-923) for the 8 slots of one ray of the fused launch: the same operations in the same order,
 // with the eight samples' sigma / rgb / deltas requested up front (one memory round trip instead of one per sample: a lone lane waiting for each
 // was 12 000 cycles of every wave-round) and the ray's t carried in a register (`t` in: rays_t; out: t behind the last composited sample).
+// `srgb` != nullptr (PN_FUSED_LDS_OUT, the later trips' rounds): the 8 samples' (sigma, r, g, b) come from the wave's own LDS area, where its network tiles
+// have just left them — not through global memory and back (four stores per sample, a wait for them, 32 loads per composite lane: the composite phase was 10 k
+// of a wave-round's 80 k cycles, most of it that round trip).
+template <bool LDS_IN>
 __device__ __forceinline__ bool composite_slots8(int index, uint32_t slot0, float T_thresh, float& t, float* rays_t, const float* __restrict__ sigmas,
                                                  const float* __restrict__ rgbs, const float* __restrict__ deltas, float* weights_sum, float* depth,
-                                                 float* image) {
+                                                 float* image, const float4* srgb) {
     float sg[8], d0[8], d1[8], cr[8], cg[8], cb[8];
     // ONE base address per array and constant offsets from it: with `slot0 + k` formed in 32 bits the compiler cannot rule out a wrap once slot0 has an
     // unknown addend (FOLD: N_rays), builds 24 separate 64-bit addresses, hoists them out of the round loop, spills them and reloads them every round
@@ -96,11 +103,16 @@ __device__ __forceinline__ bool composite_slots8(int index, uint32_t slot0, floa
     const float* __restrict__ cp = rgbs + (size_t)slot0 * 3;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        sg[k] = sgp[k];
         const float2 dd = *reinterpret_cast<const float2*>(dlp + k * 2);
         d0[k] = dd.x; d1[k] = dd.y;
-        const pnm3::Float3 c3 = *reinterpret_cast<const pnm3::Float3*>(cp + k * 3);
-        cr[k] = c3.x; cg[k] = c3.y; cb[k] = c3.z;
+        if (LDS_IN) {
+            const float4 v = srgb[k];
+            sg[k] = v.x; cr[k] = v.y; cg[k] = v.z; cb[k] = v.w;
+        } else {
+            sg[k] = sgp[k];
+            const pnm3::Float3 c3 = *reinterpret_cast<const pnm3::Float3*>(cp + k * 3);
+            cr[k] = c3.x; cg[k] = c3.y; cb[k] = c3.z;
+        }
     }
     float ws = weights_sum[index], d = depth[index];
     float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
@@ -251,7 +263,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
     if (clk) { c_t = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
     // the network on 32 consecutive sample slots (two lanes per sample: lanes s32 and s32 + 32 hold sample slot_of_lane's two level halves)
-    auto network_tile = [&](uint32_t slot) __attribute__((always_inline)) {
+    auto network_tile = [&](uint32_t slot, float4* lds_out = nullptr) __attribute__((always_inline)) {
         const pnm3::Float3 p = *reinterpret_cast<const pnm3::Float3*>(fa.xyzs + (size_t)slot * 3), d = *reinterpret_cast<const pnm3::Float3*>(fa.dirs + (size_t)slot * 3);
         float sigma_logit, e[3];
         if (HALF) {
@@ -272,9 +284,15 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
             tile_color_net(wl, wimg, half, h2, d.x, d.y, d.z, e);
         }
         if (half == 0) {
-            fa.sigmas[slot] = tile_sigma_out(fa.density_scale, sigma_logit);
-#pragma unroll
-            for (int o = 0; o < 3; o++) fa.rgbs[(size_t)slot * 3 + o] = HALF ? tile_rgb_out_h(e[o]) : tile_rgb_out(e[o]);
+            const float sg_ = tile_sigma_out(fa.density_scale, sigma_logit);
+            const float c0_ = HALF ? tile_rgb_out_h(e[0]) : tile_rgb_out(e[0]), c1_ = HALF ? tile_rgb_out_h(e[1]) : tile_rgb_out(e[1]),
+                        c2_ = HALF ? tile_rgb_out_h(e[2]) : tile_rgb_out(e[2]);
+            if (lds_out) {   // (uniform) a later trip's round: the composite behind it reads the wave's own LDS area
+                *lds_out = make_float4(sg_, c0_, c1_, c2_);
+            } else {
+                fa.sigmas[slot] = sg_;
+                fa.rgbs[(size_t)slot * 3] = c0_; fa.rgbs[(size_t)slot * 3 + 1] = c1_; fa.rgbs[(size_t)slot * 3 + 2] = c2_;
+            }
         }
     };
     // ... on the wave's 64 slots: tile 0 = slots 0..31, tile 1 = 32..63; `rm`: lanes whose slots carry something
@@ -283,7 +301,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
 #pragma unroll 1
         for (int tile = 0; tile < 2; tile++) {
             if (!((rm >> (32 * tile)) & 0xFFFFFFFFull)) continue;
-            network_tile(own ? slotw + 32u * (uint32_t)tile + (uint32_t)s32 : lane_slot);
+            network_tile(own ? slotw + 32u * (uint32_t)tile + (uint32_t)s32 : lane_slot, (PN_FUSED_LDS_OUT && own) ? stage + 32 * tile + s32 : nullptr);
         }
     };
     auto wave_sync_mem = [&]() __attribute__((always_inline)) {  // the wave's own stores before its own loads of the same addresses by other lanes
@@ -643,7 +661,8 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
         // ---- 4. composite (kernel_composite_rays, raymarching.cu:827-923): one lane per ray; a ray goes on iff it used all 8 samples
         int alive = 0;
         if (have_ray && sub == 0)
-            alive = composite_slots8(index, slot0, fa.T_thresh, r_t, fa.rays_t, fa.sigmas, fa.rgbs, fa.deltas, fa.weights_sum, fa.depth, fa.image) ? 1 : 0;
+            alive = composite_slots8<PN_FUSED_LDS_OUT != 0>(index, slot0, fa.T_thresh, r_t, fa.rays_t, fa.sigmas, fa.rgbs, fa.deltas, fa.weights_sum, fa.depth, fa.image,
+                                                            stage + grp * 8) ? 1 : 0;
         alive = __shfl(alive, gbase);
         r_t = __shfl(r_t, gbase);
         if (have_ray) {
