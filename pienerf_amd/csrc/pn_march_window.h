@@ -952,7 +952,7 @@ __device__ inline bool march_window(const MarchParams& a, const March2Tables& tb
                     float* Dd = dirs + (size_t)slot * 3;
                     float* L = deltas + (size_t)slot * 2;
                     *reinterpret_cast<Float3*>(X) = Float3{ev.x, ev.y, ev.z};
-                    *reinterpret_cast<Float3*>(Dd) = Float3{c.dx, c.dy, c.dz};
+                    if (dirs) *reinterpret_cast<Float3*>(Dd) = Float3{c.dx, c.dy, c.dz};   // (nullptr: a caller that keeps the rays' directions itself)
                     *reinterpret_cast<float2*>(L) = make_float2(ev.dt, nxt - (my_prev >= 0 ? prev_nxt : last_t));
                 }
             }

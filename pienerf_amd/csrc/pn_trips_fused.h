@@ -40,6 +40,9 @@
 #ifndef PN_FUSED_LDS_OUT
 #define PN_FUSED_LDS_OUT 1       // the later trips' network outputs go to the composite through the wave's LDS staging area (free between two march rounds)
 #endif
+#ifndef PN_FUSED_LDS_XYZ
+#define PN_FUSED_LDS_XYZ 1       // ... and the later trips' sample positions reach the network through LDS as well (768 B per wave; directions from the rays' registers):
+#endif                           // no store -> wait -> load round trip through global memory between a round's march and its network tiles (not with the 61-KB bf16 image)
 #define PN_FUSED_STAGE 512      // staging entries per wave (the record heads of a round go through it in two passes: pn_march_window.h, SPLIT)
 // control block of a frame's fused launch, ints: [3 x PN_FUSED_MAX_TRIPS counters][workgroups done]; all zero at launch
 #define PN_FUSED_CTL_HIST 0
@@ -83,6 +86,32 @@ struct FusedArgs {
     // FOLD (MODE 2): the first trip's segmented sample list and the march's tail counters
     const int* list_seg; const int* samp_counts; int list_seg_cap; const int* seg_tail; const int* seg_back;
 };
+
+// The launch's own copy of `fa` in the kernarg segment, re-read WHERE it is used.  The kernel's uniform state (three argument structs: ~45 pointers and
+// as many scalars) is twice what a wave has scalar registers for; what does not fit is parked in lanes of a vector register and every use costs a
+// v_readlane — a VECTOR instruction, on CUs that are bound by vector issue: 132 of the 366 vector instructions of the composite step were such reloads of
+// its ten array pointers.  A scalar load from the kernarg segment costs none; the opaque zero keeps the compiler from treating the address as loop-invariant
+// (it would hoist the loads out of the round loop and park them again).  The offset is the AMDGPU kernarg layout of (MarchParams, March2Tables, FusedArgs):
+// every argument at its natural alignment; the kernel checks it once per launch against the by-value copy (PN_ERR flag 16).
+#ifndef PN_FUSED_FRESH_ARGS
+#define PN_FUSED_FRESH_ARGS 1
+#endif
+__device__ __forceinline__ constexpr size_t pn_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+template <typename T, int WHICH>   // WHICH: 0 = MarchParams, 1 = March2Tables, 2 = FusedArgs
+__device__ __forceinline__ const T& fused_karg_fresh(const T& by_value) {
+#if PN_FUSED_FRESH_ARGS
+    constexpr size_t off_tb = pn_align_up(sizeof(pnm::MarchParams), alignof(pnm2::March2Tables));
+    constexpr size_t off_fa = pn_align_up(off_tb + sizeof(pnm2::March2Tables), alignof(FusedArgs));
+    constexpr size_t off = WHICH == 0 ? 0 : (WHICH == 1 ? off_tb : off_fa);
+    uint32_t z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    const char __attribute__((address_space(4)))* kp = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    return *reinterpret_cast<const T*>((const char*)kp + off + z);
+#else
+    return by_value;
+#endif
+}
+__device__ __forceinline__ const FusedArgs& fused_args_fresh(const FusedArgs& by_value) { return fused_karg_fresh<FusedArgs, 2>(by_value); }
 
 // composite_one (kernel_composite_rays, raymarching.cu:827-923) for the 8 slots of one ray of the fused launch: the same operations in the same order,
 // with the eight samples' sigma / rgb / deltas requested up front (one memory round trip instead of one per sample: a lone lane waiting for each
@@ -189,6 +218,8 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
     uint4* wimg = fused_lds;  // the weight image, then the 16 level records (512 B), as in k_nerf_forward
     float4* stage_all = reinterpret_cast<float4*>(fused_lds + IMG16 + 32);
     int* hist = reinterpret_cast<int*>(stage_all + PN_FUSED_WAVES * PN_FUSED_STAGE);  // [3][MAXT]: rays entering trip j, samples emitted, rays through the 64-lane windows
+    constexpr bool LXYZ = PN_FUSED_LDS_XYZ != 0 && PN_FUSED_LDS_OUT != 0 && NF != 0;
+    float* xyz_all = reinterpret_cast<float*>(hist + 3 * MAXT);   // LXYZ: [waves][64 sample slots][3]
     __shared__ int s_last, s_cursor;
     __shared__ int s_bres, s_bready, s_bhead, s_sres, s_sready, s_shead, s_pending, s_a1done;  // WHOLE: the workgroup's list of rays going on, its straggler queue, chunks without their A3
     __shared__ int s_pend[PN_FUSED_MAXCHUNKS];  // WHOLE: positions of each chunk still open
@@ -196,6 +227,13 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
 
     const PnTrip* tr = fa.trips;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (PN_FUSED_FRESH_ARGS && blockIdx.x == 0 && threadIdx.x == 0) {   // the kernarg layout fused_args_fresh assumes, checked against the by-value copy
+        const FusedArgs& fk = fused_args_fresh(fa);
+        const pnm::MarchParams& ak = fused_karg_fresh<pnm::MarchParams, 0>(a);
+        const pnm2::March2Tables& tk = fused_karg_fresh<pnm2::March2Tables, 1>(tb);
+        if (fk.trips != fa.trips || fk.rays_t != fa.rays_t || fk.N_rays != fa.N_rays || fk.image_out != fa.image_out || fk.seg_back != fa.seg_back || ak.rays_o != a.rays_o ||
+            ak.grid != a.grid || ak.hgs != a.hgs || tk.nb != tb.nb || tk.rec != tb.rec) atomicOr(&fa.dev->err, 16);
+    }
     const float x_scale = XF ? fa.x_scales[0] : 1.0f, x_rscale = XF ? fa.x_scales[1] : 1.0f;  // uniform: two scalar loads
     int A = 0, sb0 = 0, n_active = 0;
     if (QUEUED) {
@@ -245,8 +283,8 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
     const int half = lane >> 5, s32 = lane & 31;
     const PnFusedLevel* lds_lv = reinterpret_cast<const PnFusedLevel*>(wimg + IMG16) + 8 * half;
     __amdgpu_buffer_rsrc_t emb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(fa.emb_h), 0, (int)fa.emb_bytes, 0x00020000);
-    float* const X = fa.xyzs + (size_t)slot0 * 3;
-    float* const Dd = fa.dirs + (size_t)slot0 * 3;
+    float* const X = LXYZ ? xyz_all + wv * 192 + grp * 24 : fa.xyzs + (size_t)slot0 * 3;   // the group's 8 sample slots
+    float* const Dd = LXYZ ? nullptr : fa.dirs + (size_t)slot0 * 3;                           // (LXYZ: nobody reads them)
     float* const dl = fa.deltas + (size_t)slot0 * 2;
 
     const bool clk = fa.clocks != nullptr;
@@ -262,9 +300,20 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
     unsigned long long rt0 = 0;
     if (clk) { c_t = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
+    // what stays in registers while a group's ray lives: origin, direction, 1 / direction, end, and the t the composite has reached (rays_t)
+    float r_ox = 0.f, r_oy = 0.f, r_oz = 0.f, r_dx = 1.f, r_dy = 1.f, r_dz = 1.f, r_rdx = 1.f, r_rdy = 1.f, r_rdz = 1.f, r_far = 0.f, r_t = 0.f;
     // the network on 32 consecutive sample slots (two lanes per sample: lanes s32 and s32 + 32 hold sample slot_of_lane's two level halves)
-    auto network_tile = [&](uint32_t slot, float4* lds_out = nullptr) __attribute__((always_inline)) {
-        const pnm3::Float3 p = *reinterpret_cast<const pnm3::Float3*>(fa.xyzs + (size_t)slot * 3), d = *reinterpret_cast<const pnm3::Float3*>(fa.dirs + (size_t)slot * 3);
+    // `lds_xyz` != nullptr (LXYZ, a later trip's round): the sample's position from the wave's LDS area, its direction from the registers of its ray's group
+    // (lane `dir_lane`) instead of the global sample slot
+    auto network_tile = [&](uint32_t slot, float4* lds_out = nullptr, const float* lds_xyz = nullptr, int dir_lane = 0) __attribute__((always_inline)) {
+        pnm3::Float3 p, d;
+        if (LXYZ && lds_xyz) {   // (uniform)
+            p = *reinterpret_cast<const pnm3::Float3*>(lds_xyz);
+            d.x = __shfl(r_dx, dir_lane); d.y = __shfl(r_dy, dir_lane); d.z = __shfl(r_dz, dir_lane);
+        } else {
+            p = *reinterpret_cast<const pnm3::Float3*>(fa.xyzs + (size_t)slot * 3);
+            d = *reinterpret_cast<const pnm3::Float3*>(fa.dirs + (size_t)slot * 3);
+        }
         float sigma_logit, e[3];
         if (HALF) {
             float g2[8];
@@ -301,7 +350,8 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
 #pragma unroll 1
         for (int tile = 0; tile < 2; tile++) {
             if (!((rm >> (32 * tile)) & 0xFFFFFFFFull)) continue;
-            network_tile(own ? slotw + 32u * (uint32_t)tile + (uint32_t)s32 : lane_slot, (PN_FUSED_LDS_OUT && own) ? stage + 32 * tile + s32 : nullptr);
+            network_tile(own ? slotw + 32u * (uint32_t)tile + (uint32_t)s32 : lane_slot, (PN_FUSED_LDS_OUT && own) ? stage + 32 * tile + s32 : nullptr,
+                         (LXYZ && own) ? xyz_all + wv * 192 + (32 * tile + s32) * 3 : nullptr, (4 * tile + (s32 >> 3)) * 8);
         }
     };
     auto wave_sync_mem = [&]() __attribute__((always_inline)) {  // the wave's own stores before its own loads of the same addresses by other lanes
@@ -504,7 +554,6 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
     int index = -1;  // this group's ray (the same on its 8 lanes), -1: none
     int j = 0;       // trips it has been through in this launch
     // ... and what stays in registers while it lives: origin, direction, 1 / direction, end, and the t the composite has reached (rays_t)
-    float r_ox = 0.f, r_oy = 0.f, r_oz = 0.f, r_dx = 1.f, r_dy = 1.f, r_dz = 1.f, r_rdx = 1.f, r_rdy = 1.f, r_rdz = 1.f, r_far = 0.f, r_t = 0.f;
 
     for (;;) {
         // ---- 1. refill the groups without a ray
@@ -585,19 +634,21 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
         // ---- 2. march: one window round of 8 lanes per ray, then the rays still going with the whole wave
         have_ray = index >= 0;
         if (have_ray && sub == 0) atomicAdd(&hist[j], 1);
+        const pnm::MarchParams& am = fused_karg_fresh<pnm::MarchParams, 0>(a);   // the march's uniform inputs: scalar loads here (see fused_karg_fresh)
+        const pnm2::March2Tables& tbm = fused_karg_fresh<pnm2::March2Tables, 1>(tb);
         pnm3::RayConsts c;
-        pnm3::frame_consts(a, c);
+        pnm3::frame_consts(am, c);
         c.ox = r_ox; c.oy = r_oy; c.oz = r_oz; c.dx = r_dx; c.dy = r_dy; c.dz = r_dz; c.rdx = r_rdx; c.rdy = r_rdy; c.rdz = r_rdz; c.far = r_far;
         pnm3::RayState st{0.f, 0.f, 0u};
         bool have = false;
         if (have_ray) {  // pnm3::ray_start with the ray's t from the register (noise = 0: perturb is off on this path, renderer.py:857)
             float t = r_t;
-            t += pnm::clampf(t * a.dt_gamma, c.dt_min, c.dt_max) * 0.0f;
+            t += pnm::clampf(t * am.dt_gamma, c.dt_min, c.dt_max) * 0.0f;
             st.last_t = t;
             st.t = t;
             have = t < c.far;
         }
-        const bool done = pnm3::march_window<K, MULTI, 8, PN_FUSED_STAGE, 1>(a, tb, c, 8u, sub, gbase, lane, stage, X, Dd, dl, st, 1, have);
+        const bool done = pnm3::march_window<K, MULTI, 8, PN_FUSED_STAGE, 1>(am, tbm, c, 8u, sub, gbase, lane, stage, X, Dd, dl, st, 1, have);
         const bool deferred = have && !done;
         tick(1);
         unsigned long long dm = __ballot(deferred && sub == 0);
@@ -606,14 +657,15 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
             const int L = (int)__builtin_ctzll(dm);
             dm &= dm - 1ull;
             pnm3::RayConsts c2;
-            pnm3::frame_consts(a, c2);
+            pnm3::frame_consts(am, c2);
             c2.ox = readlane_f(c.ox, L); c2.oy = readlane_f(c.oy, L); c2.oz = readlane_f(c.oz, L);
             c2.dx = readlane_f(c.dx, L); c2.dy = readlane_f(c.dy, L); c2.dz = readlane_f(c.dz, L);
             c2.rdx = readlane_f(c.rdx, L); c2.rdy = readlane_f(c.rdy, L); c2.rdz = readlane_f(c.rdz, L);
             c2.far = readlane_f(c.far, L);
             pnm3::RayState s2{readlane_f(st.t, L), readlane_f(st.last_t, L), (uint32_t)__builtin_amdgcn_readlane((int)st.step, L)};
             const size_t sl = (size_t)slotw + (size_t)(L >> 3) * 8;
-            pnm3::march_window<K, MULTI, 64, PN_FUSED_STAGE, 1>(a, tb, c2, 8u, lane, 0, lane, stage, fa.xyzs + sl * 3, fa.dirs + sl * 3, fa.deltas + sl * 2, s2, 0x7fffffff, true);
+            pnm3::march_window<K, MULTI, 64, PN_FUSED_STAGE, 1>(am, tbm, c2, 8u, lane, 0, lane, stage, LXYZ ? xyz_all + wv * 192 + (L >> 3) * 24 : fa.xyzs + sl * 3,
+                                                                LXYZ ? nullptr : fa.dirs + sl * 3, fa.deltas + sl * 2, s2, 0x7fffffff, true);
             if (gbase == L) st.step = s2.step;
         }
         const uint32_t emitted = have_ray ? st.step : 0u;
@@ -625,7 +677,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
         if (have_ray && (uint32_t)sub >= emitted) {
             dl[2 * sub] = 0.0f; dl[2 * sub + 1] = 0.0f;
             X[3 * sub] = X[3 * sub + 1] = X[3 * sub + 2] = 0.0f;
-            Dd[3 * sub] = Dd[3 * sub + 1] = Dd[3 * sub + 2] = 0.0f;
+            if (!LXYZ) Dd[3 * sub] = Dd[3 * sub + 1] = Dd[3 * sub + 2] = 0.0f;
         }
         wave_sync_mem();
         tick(2);
@@ -660,8 +712,9 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
         }
         // ---- 4. composite (kernel_composite_rays, raymarching.cu:827-923): one lane per ray; a ray goes on iff it used all 8 samples
         int alive = 0;
+        const FusedArgs& fc = fused_args_fresh(fa);   // the composite's (and the epilogue's) array pointers: scalar loads here instead of parked registers
         if (have_ray && sub == 0)
-            alive = composite_slots8<PN_FUSED_LDS_OUT != 0>(index, slot0, fa.T_thresh, r_t, fa.rays_t, fa.sigmas, fa.rgbs, fa.deltas, fa.weights_sum, fa.depth, fa.image,
+            alive = composite_slots8<PN_FUSED_LDS_OUT != 0>(index, slot0, fc.T_thresh, r_t, fc.rays_t, fc.sigmas, fc.rgbs, fc.deltas, fc.weights_sum, fc.depth, fc.image,
                                                             stage + grp * 8) ? 1 : 0;
         alive = __shfl(alive, gbase);
         r_t = __shfl(r_t, gbase);
@@ -669,7 +722,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
             // renderer.py:836: the loop ends when `step` reaches max_steps, whatever is still alive
             if (alive && (uint32_t)(sb0 + 8 * (j + (QUEUED ? 0 : 1))) < fa.max_steps && j + 1 < MAXT) j++;
             else {
-                if (QUEUED && fa.finalize && sub == 0) finalize_ray(fa, index);   // the ray leaves the launch: its pixel is final
+                if (QUEUED && fc.finalize && sub == 0) finalize_ray(fc, index);   // the ray leaves the launch: its pixel is final
                 index = -1;
             }
         }
@@ -749,7 +802,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
 
 static size_t fused_lds_bytes(int nf) {
     return (size_t)(nf == 1 ? PN_NET_HALF_BYTES : (nf == 2 ? PN_NET_X_BYTES : PN_NET_SPLIT_BYTES)) + 16 * sizeof(PnFusedLevel) + (size_t)PN_FUSED_WAVES * PN_FUSED_STAGE * sizeof(float4) +
-           3 * PN_FUSED_MAX_TRIPS * sizeof(int);
+           3 * PN_FUSED_MAX_TRIPS * sizeof(int) + ((PN_FUSED_LDS_XYZ != 0 && PN_FUSED_LDS_OUT != 0 && nf != 0) ? (size_t)PN_FUSED_WAVES * 192 * sizeof(float) : 0);
 }
 
 template <int K, bool MULTI, int NF, int MODE>
