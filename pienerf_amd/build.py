@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libpienerf_hip.so")
+TEMPS = os.path.join(HERE, "..", "build", "temps")
 ARCH = "gfx950"
 
 # -fno-slp-vectorize: -O3 does not pack adjacent scalar fp32 adds / multiplies into v_pk_{add,mul,fma}_f32 on its own.  Beside MFMA chains
@@ -76,11 +77,14 @@ def build(force=False, save_temps=False, verbose=False):
         objs.append(o)
         if force or _stale(o, [s] + headers):
             cmd = [cc] + COMMON + extra + ["-c", s, "-o", o]
-            if save_temps:
-                cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+            cwd = OBJ
+            if save_temps:  # intermediates (.hipi/.bc/.s) go to <repo>/build/temps: git-ignored AND gpurun-ignored, never beside the objects
+                cwd = TEMPS
+                os.makedirs(TEMPS, exist_ok=True)
+                cmd += ["-save-temps=cwd", "-Rpass-analysis=kernel-resource-usage"]
             if verbose:
                 print(" ".join(cmd))
-            subprocess.run(cmd, check=True, cwd=OBJ)
+            subprocess.run(cmd, check=True, cwd=cwd)
     if force or _stale(LIB, objs):
         rocm = os.environ.get("ROCM_PATH") or os.path.dirname(os.path.dirname(os.path.realpath(cc)))  # <rocm>/bin/hipcc
         cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-L" + os.path.join(rocm, "lib"), "-lhsa-runtime64", "-lpthread"]
