@@ -445,8 +445,21 @@ uint64_t pn_sim_work_doubles(int n_k, int n_IP);
  *   mu_cell, lam_cell [n_chunks * chunk_ips] fp64 in chunk order;
  *   kp_bg [n_k + 1], kp_pos [8 n_chunks]: the (chunk * 8 + slot) pairs that refer to a kernel, in ascending order, are that kernel's run of partial sums
  *             [kp_bg[k], kp_bg[k + 1]); kp_pos[chunk * 8 + slot] = the pair's place in it (absolute) — where the chunk stores that partial sum.
- * Same results as pn_sim_stepforward up to the summation order of collect_rhs (1e-16 relative), bit-reproducible run to run.
+ * Same results as pn_sim_stepforward up to the summation order of collect_rhs (1e-16 relative) AND the SVD's stopping rule: this form's warm-started
+ * threshold Jacobi stops at off-diagonals <= 1e-11 of the diagonal (squares: 1e-22; pairs below 3e-12 are not rotated) where pn_sim_stepforward's stops at
+ * 1e-12 — measured <= 8e-10 relative on the displacements between the forms (tests/test_gpu_persistent.py asserts 1e-8).  The warm start (each point's V of
+ * the previous local/global iteration, kept in `work`) makes a substep's bits depend on the step HISTORY: bit-reproducible run to run for identical
+ * histories; whoever restores dof / dof_vel to replay a trajectory bit for bit re-runs pn_sim_cells_prepare (Simulator.reset_warm_start) as well.
  * work >= pn_sim_cells_work_doubles doubles, initialised once by pn_sim_cells_prepare (identity rotations for the warm-started SVD, arrival counters). */
+/* Which decomposition stands in for wp.svd3 (simulator/cuda_utils.py:107; warp-lang is third-party and absent) in calc_elastic, for every substep /
+ * calc_elastic call ENQUEUED after it (process-global; a captured graph keeps the choice it was captured with):
+ *   0 (default)  converged Jacobi — the contract: U, V proper rotations, the sign of det F on the last singular value;
+ *   n in 1..64   the published algorithm wp.svd3 implements (McAdams et al., UW-Madison TR1690) with n fixed Jacobi sweeps, approximate Givens
+ *                quaternions, negating-swap sort, Givens-quaternion QR, the paper's 10-digit constants (8 = double-precision setting, 4 = the paper's
+ *                single-precision one).  pn_sim_stepforward, pn_sim_stepforward_cells and pn_sim_calc_elastic honour it; pn_sim_stepforward_coop
+ *                returns PN_ERR_ARG while it is set.  oracle/sim_oracle.cpp: svd3_mcadams is the CPU restatement it is tested against. */
+int pn_sim_set_svd(int mcadams_sweeps);
+int pn_sim_get_svd(void);
 int pn_sim_cells_chunk_ips(void);
 uint64_t pn_sim_cells_work_doubles(int n_k, int n_chunks);
 int pn_sim_cells_prepare(int n_k, int n_chunks, double* work, void* stream);

@@ -366,6 +366,24 @@ def svd3(Fm):
     return U, s, V
 
 
+class svd_mode:
+    """Which restatement of wp.svd3 (simulator/cuda_utils.py:107) the simulator oracle uses inside the `with` block:
+    svd_mode("converged") — the contract (default); svd_mode("mcadams", sweeps=8, rsqrt="exact"|"seeded", qr_eps=1e-12) — the published
+    algorithm (McAdams et al., TR1690) with a fixed sweep count.  Process-global in liboracle.so; restored on exit."""
+
+    def __init__(self, mode="converged", sweeps=8, rsqrt="exact", qr_eps=1e-12, constants="published"):
+        self.args = (dict(converged=0, mcadams=1)[mode], int(sweeps), dict(exact=0, seeded=1)[rsqrt], float(qr_eps), dict(published=0, exact=1)[constants])
+
+    def __enter__(self):
+        assert lib().orc_get_svd_mode() == 0, "svd_mode blocks do not nest"
+        lib().orc_set_svd(I(self.args[0]), I(self.args[1]), I(self.args[2]), D(self.args[3]), I(self.args[4]))
+        return self
+
+    def __exit__(self, *a):
+        lib().orc_set_svd(I(0), I(8), I(0), D(1e-12), I(0))
+        return False
+
+
 def volume_invariant_project(sig):
     sig = _f64(sig)
     out = np.empty(3)

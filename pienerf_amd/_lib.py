@@ -93,6 +93,8 @@ SIGNATURES = {
     "pn_sim_matvec3": (i32, [i32, P, P, P, P]),
     "pn_sim_stepforward": (i32, [i32, i32, i32, f64, f64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, i32, P]),
     "pn_sim_prepare": (i32, [i32, i32, P, P, P, P]),
+    "pn_sim_set_svd": (i32, [i32]),
+    "pn_sim_get_svd": (i32, []),
     "pn_sim_cells_chunk_ips": (i32, []),
     "pn_sim_cells_work_doubles": (u64, [i32, i32]),
     "pn_sim_cells_prepare": (i32, [i32, i32, P, P]),

@@ -182,6 +182,115 @@ __device__ void svd3(const M3& F, M3& U, double* sig, M3& V, const M3* Q0 = null
     for (int j = 0; j < 3; j++) sig[j] = U.m[0][j] * B.m[0][j] + U.m[1][j] * B.m[1][j] + U.m[2][j] * B.m[2][j];
 }
 
+// ------------------------------------------------------------------------------------------------ svd3, the published algorithm (PN_SIM_SVD=mcadams)
+// wp.svd3 (cuda_utils.py:107; warp-lang is absent from /root/reference) implements McAdams, Selle, Tamstorf, Teran, Sifakis, "Computing the
+// Singular Value Decomposition of 3x3 matrices with minimal branching and elementary floating point operations" (UW-Madison TR1690): a FIXED
+// number of cyclic Jacobi sweeps on F^T F with the approximate Givens quaternion (TR section 2), singular values ordered by conditional
+// negating swaps (section 3), U and the diagonal from a Givens-quaternion QR of F V (section 4).  The default decomposition above runs to
+// convergence instead; this one exists so that the simulator can be run ON the reference's algorithm, sweep count included: with 8 sweeps the two
+// agree to 2e-7 of the displacements (the paper's 10-digit constants), with 4 sweeps — the paper's single-precision setting — they differ by
+// 2.6e-4 on the chair (tests/test_oracle_svd.py), which is above the 1e-4 bar: which sweep count the reference's build runs with decides
+// which of the two it is closer to, and both are here.  Same arithmetic as the test suite's CPU restatement of the algorithm (IEEE divide / sqrt, no
+// warm start, no early exit), compared with it at 1e-10 (tests/test_gpu_simpin.py).
+struct Quat4 { double x, y, z, w; };
+__device__ __forceinline__ Quat4 qmul4(const Quat4& a, const Quat4& b) {
+    return {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
+            a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+__device__ __forceinline__ void quat_to_m3(const Quat4& q, M3& r) {
+    const double xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z, xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z, wx = q.w * q.x, wy = q.w * q.y, wz = q.w * q.z;
+    r.m[0][0] = 1 - 2 * (yy + zz); r.m[0][1] = 2 * (xy - wz);     r.m[0][2] = 2 * (xz + wy);
+    r.m[1][0] = 2 * (xy + wz);     r.m[1][1] = 1 - 2 * (xx + zz); r.m[1][2] = 2 * (yz - wx);
+    r.m[2][0] = 2 * (xz - wy);     r.m[2][1] = 2 * (yz + wx);     r.m[2][2] = 1 - 2 * (xx + yy);
+}
+// one conjugation S <- G^T S G in the plane (P, Q), the rotation's half-angle quaternion multiplied onto q (axis AX = 3 - P - Q)
+template <int P, int Q, int AX>
+__device__ __forceinline__ void mc_conjugate(M3& S, Quat4& q) {
+    double ch = 2.0 * (S.m[P][P] - S.m[Q][Q]), sh = S.m[P][Q];
+    const bool ok = 5.828427124 * sh * sh < ch * ch;                 // gamma = 3 + 2 sqrt 2, cos / sin(pi / 8): the paper's digits
+    const double w = 1.0 / sqrt(ch * ch + sh * sh);
+    ch = ok ? w * ch : 0.923879532;
+    sh = ok ? w * sh : 0.3826834323;
+    const double scale = ch * ch + sh * sh, c = (ch * ch - sh * sh) / scale, s = (2.0 * sh * ch) / scale;
+    M3 T = S;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        T.m[i][P] = c * S.m[i][P] + s * S.m[i][Q];
+        T.m[i][Q] = -s * S.m[i][P] + c * S.m[i][Q];
+    }
+    M3 R = T;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        R.m[P][j] = c * T.m[P][j] + s * T.m[Q][j];
+        R.m[Q][j] = -s * T.m[P][j] + c * T.m[Q][j];
+    }
+    R.m[P][Q] = R.m[Q][P] = 0.5 * (R.m[P][Q] + R.m[Q][P]);
+    S = R;
+    Quat4 g{0, 0, 0, ch};
+    (AX == 0 ? g.x : AX == 1 ? g.y : g.z) = sh;
+    q = qmul4(q, g);
+}
+__device__ __forceinline__ void mc_qr_givens(double piv, double low, double eps, double& ch, double& sh) {
+    const double r2 = piv * piv + low * low;
+    const double rho = r2 > 0 ? r2 * (1.0 / sqrt(r2)) : 0.0;
+    sh = rho > eps ? low : 0.0;
+    ch = fabs(piv) + fmax(rho, eps);
+    if (piv < 0) { const double t = sh; sh = ch; ch = t; }
+    const double w = 1.0 / sqrt(ch * ch + sh * sh);
+    ch *= w;
+    sh *= w;
+}
+template <int A, int B_>
+__device__ __forceinline__ void mc_rot_rows(M3& B, double ch, double sh) {
+    const double c = 1.0 - 2.0 * sh * sh, s = 2.0 * ch * sh;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const double x = B.m[A][j], y = B.m[B_][j];
+        B.m[A][j] = c * x + s * y;
+        B.m[B_][j] = -s * x + c * y;
+    }
+}
+__device__ void svd3_mcadams(const M3& F, M3& U, double* sig, M3& V, int sweeps) {
+    M3 S;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) S.m[i][j] = F.m[0][i] * F.m[0][j] + F.m[1][i] * F.m[1][j] + F.m[2][i] * F.m[2][j];
+    Quat4 q{0, 0, 0, 1};
+    for (int sweep = 0; sweep < sweeps; sweep++) {
+        mc_conjugate<0, 1, 2>(S, q);
+        mc_conjugate<1, 2, 0>(S, q);
+        mc_conjugate<2, 0, 1>(S, q);
+    }
+    quat_to_m3(q, V);
+    M3 B = mul33(F, V);
+    double rho[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) rho[j] = B.m[0][j] * B.m[0][j] + B.m[1][j] * B.m[1][j] + B.m[2][j] * B.m[2][j];
+    auto negswap = [&](int a, int b) {
+        if (!(rho[a] < rho[b])) return;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const double ba = B.m[i][a], va = V.m[i][a];
+            B.m[i][a] = B.m[i][b]; B.m[i][b] = -ba;
+            V.m[i][a] = V.m[i][b]; V.m[i][b] = -va;
+        }
+        const double t = rho[a]; rho[a] = rho[b]; rho[b] = t;
+    };
+    negswap(0, 1);
+    negswap(0, 2);
+    negswap(1, 2);
+    double ch1, sh1, ch2, sh2, ch3, sh3;
+    mc_qr_givens(B.m[0][0], B.m[1][0], 1e-12, ch1, sh1);
+    mc_rot_rows<0, 1>(B, ch1, sh1);
+    mc_qr_givens(B.m[0][0], B.m[2][0], 1e-12, ch2, sh2);
+    mc_rot_rows<0, 2>(B, ch2, sh2);
+    mc_qr_givens(B.m[1][1], B.m[2][1], 1e-12, ch3, sh3);
+    mc_rot_rows<1, 2>(B, ch3, sh3);
+    quat_to_m3(qmul4(qmul4(Quat4{0, 0, sh1, ch1}, Quat4{0, -sh2, 0, ch2}), Quat4{sh3, 0, 0, ch3}), U);
+    sig[0] = B.m[0][0]; sig[1] = B.m[1][1]; sig[2] = B.m[2][2];
+}
+
 // simulator/func_utils.py:21-40
 __device__ __forceinline__ void volume_invariant_project(const double* sig, double* out) {
     double D0 = 0, D1 = 0, D2 = 0;
@@ -204,6 +313,16 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) {
 }
 
 }  // namespace
+
+// Which svd3 the substep kernels run: 0 = the converged, warm-started threshold Jacobi (default); n > 0 = McAdams' algorithm with n sweeps
+// (PN_SIM_SVD=mcadams[:n] on the Python side).  Process-global, read when a substep is enqueued (or captured into a graph).
+static int g_pn_svd_mc_sweeps = 0;
+extern "C" int pn_sim_set_svd(int mcadams_sweeps) {
+    PN_REQUIRE(mcadams_sweeps >= 0 && mcadams_sweeps <= 64);
+    g_pn_svd_mc_sweeps = mcadams_sweeps;
+    return PN_OK;
+}
+extern "C" int pn_sim_get_svd(void) { return g_pn_svd_mc_sweeps; }
 
 #ifndef PN_SIM_STAMPS
 #define PN_SIM_STAMPS 0
@@ -303,11 +422,12 @@ extern "C" int pn_sim_update_F(int n_IP, const int* topo, const double* dof, con
 
 // ------------------------------------------------------------------------------------------------ calc_elastic
 // 8 lanes per IP.  Writes RF/VF/FF (op-level, any may be NULL) and/or P = dx^3 (mu R + lam V) (step driver).
+template <bool MC = false>
 __global__ void __launch_bounds__(256) k_elastic(int n_IP, const int* __restrict__ topo, const double* __restrict__ dNx, const double* __restrict__ dof,
                                                  double* __restrict__ RF, double* __restrict__ VF, double* __restrict__ FF, double* __restrict__ P,
                                                  const double* __restrict__ mu, const double* __restrict__ lam, double dx3,
                                                  const int* __restrict__ csr_pos = nullptr, double* __restrict__ P_csr = nullptr, int dbg_nosvd = 0,
-                                                 double* __restrict__ Vstore = nullptr) {
+                                                 double* __restrict__ Vstore = nullptr, int mc_sweeps = 0) {
     PN_SIM_STAMP(1);
     PN_SIM_PRIO();
     const int tid = threadIdx.x + blockIdx.x * blockDim.x;
@@ -355,6 +475,8 @@ __global__ void __launch_bounds__(256) k_elastic(int n_IP, const int* __restrict
 #pragma unroll
                 for (int c = 0; c < 3; c++) { U.m[r][c] = (r == c); V.m[r][c] = (r == c); }
             sig[0] = Fm.m[0][0]; sig[1] = Fm.m[1][1]; sig[2] = Fm.m[2][2];
+        } else if (MC) {
+            svd3_mcadams(Fm, U, sig, V, mc_sweeps);   // the published algorithm: fixed sweeps, no warm start
         } else if (Vstore) {
             // step driver: start from this IP's V of the previous local/global iteration (identity before the first substep), leave the new one.
             // 1e-24: off-diagonals below 1e-12 of the diagonal, ten digits beyond the 1e-4 relative bar of the DOF displacements
@@ -403,7 +525,11 @@ __global__ void __launch_bounds__(256) k_elastic(int n_IP, const int* __restrict
 extern "C" int pn_sim_calc_elastic(int n_IP, const int* topo, const double* dNx, const double* dof, double* RF, double* VF, double* FF,
                                    void* stream) {
     PN_REQUIRE(n_IP > 0 && topo && dNx && dof && RF && VF);
-    k_elastic<<<pn_div_up((uint64_t)n_IP * 8, 256), 256, 0, (hipStream_t)stream>>>(n_IP, topo, dNx, dof, RF, VF, FF, nullptr, nullptr, nullptr, 0.0);
+    if (g_pn_svd_mc_sweeps)
+        k_elastic<true><<<pn_div_up((uint64_t)n_IP * 8, 256), 256, 0, (hipStream_t)stream>>>(n_IP, topo, dNx, dof, RF, VF, FF, nullptr, nullptr, nullptr, 0.0,
+                                                                                             nullptr, nullptr, 0, nullptr, g_pn_svd_mc_sweeps);
+    else
+        k_elastic<false><<<pn_div_up((uint64_t)n_IP * 8, 256), 256, 0, (hipStream_t)stream>>>(n_IP, topo, dNx, dof, RF, VF, FF, nullptr, nullptr, nullptr, 0.0);
     PN_LAUNCH_CHECK();
     return PN_OK;
 }
@@ -914,8 +1040,13 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
         k_matvec3<<<pn_div_up(n, 2 * (mv_wg / 64)), mv_wg, 0, st>>>(n, Mmat, tilde, momentum, 1, dof_f, rhs_gravity);  // compute_momentum (:574-576)
     }
     for (int it = 0; it < iters; it++) {
-        k_elastic<<<pn_div_up((uint64_t)n_IP * 8, el_wg), el_wg, 0, st>>>(n_IP, topo, dNx, dof, nullptr, nullptr, nullptr, pcsr ? nullptr : P, mu, lam, dx3,
-                                                                      pcsr ? csr_pos : nullptr, pcsr ? P_csr : nullptr, dbg_nosvd, Vstore);
+        if (g_pn_svd_mc_sweeps)
+            k_elastic<true><<<pn_div_up((uint64_t)n_IP * 8, el_wg), el_wg, 0, st>>>(n_IP, topo, dNx, dof, nullptr, nullptr, nullptr, pcsr ? nullptr : P, mu, lam,
+                                                                                dx3, pcsr ? csr_pos : nullptr, pcsr ? P_csr : nullptr, dbg_nosvd, Vstore,
+                                                                                g_pn_svd_mc_sweeps);
+        else
+            k_elastic<false><<<pn_div_up((uint64_t)n_IP * 8, el_wg), el_wg, 0, st>>>(n_IP, topo, dNx, dof, nullptr, nullptr, nullptr, pcsr ? nullptr : P, mu, lam,
+                                                                                 dx3, pcsr ? csr_pos : nullptr, pcsr ? P_csr : nullptr, dbg_nosvd, Vstore);
         if (chunked) {
             const bool sum_in_chunk = fuse_sum && !fused_x;
             k_rhs_gather_chunk<<<(uint32_t)chunks_max, PN_GCH * 8, 0, st>>>(chunk, dNx_csr, P_csr, part, gp.kcount, kc_bg, momentum, rhs_rest,
@@ -959,6 +1090,7 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
 #define PN_CELL_WAVES 4
 #endif
 #define PN_CELL_IPS (PN_CELL_WAVES * 8)
+static_assert(PN_CELL_WAVES == 4, "k_cells_elastic_gather's t < 240 phases and its LDS reduction assume 256-thread workgroups");
 #ifndef PN_CELL_SVD_PACK
 #define PN_CELL_SVD_PACK 1
 #endif
@@ -971,12 +1103,13 @@ extern "C" int pn_sim_stepforward(int n_k, int n_IP, int iters, double dt, doubl
 #define PN_CELL_TAB_INTS 12   // per chunk: {points, kernel of slot 0..7, 0, 0, 0}
 #define PN_CELL_RSTRIDE 66    // doubles per output row of the LDS reduction buffer (64 lanes + 2: rows 4 banks apart)
 
+template <bool MC>
 __global__ void __launch_bounds__(PN_CELL_WAVES * 64) k_cells_elastic_gather(const int* __restrict__ chunk_tab, const double2* __restrict__ dNx_cell,
                                                                               const double* __restrict__ mu_cell, const double* __restrict__ lam_cell,
                                                                               const double* __restrict__ dof, double dx3, double* __restrict__ Vstore,
                                                                               double* part, int* kcount, const int* __restrict__ kp_bg,
                                                                               const int* __restrict__ kp_pos, const double* __restrict__ momentum,
-                                                                              const double* __restrict__ rhs_rest, double* __restrict__ tot) {
+                                                                              const double* __restrict__ rhs_rest, double* __restrict__ tot, int mc_sweeps) {
     PN_SIM_STAMP(1);
     PN_SIM_PHASE_DECL;
     PN_SIM_PHASE(10);
@@ -1069,11 +1202,15 @@ __global__ void __launch_bounds__(PN_CELL_WAVES * 64) k_cells_elastic_gather(con
         double sig[3], sp[3];
         // off-diagonals below 1e-11 of the diagonal (1e-22 on the squares; pairs below 3e-12 are not rotated): seven digits beyond the 1e-4 relative bar
         // of the DOF displacements; against 1e-24 the third sweep — two take a warm-started decomposition from 1e-3 to 1e-12 — is mostly not run
-        svd3(Fm, U, sig, V, &Q0, PN_CELL_SVD_TOL, PN_CELL_SVD_SKIP);
+        if (MC) {
+            svd3_mcadams(Fm, U, sig, V, mc_sweeps);   // PN_SIM_SVD=mcadams: the published algorithm, fixed sweeps, no warm start (Vstore untouched)
+        } else {
+            svd3(Fm, U, sig, V, &Q0, PN_CELL_SVD_TOL, PN_CELL_SVD_SKIP);
 #pragma unroll
-        for (int r = 0; r < 3; r++)
+            for (int r = 0; r < 3; r++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) Vstore[vs * 9 + r * 3 + c] = V.m[r][c];
+                for (int c = 0; c < 3; c++) Vstore[vs * 9 + r * 3 + c] = V.m[r][c];
+        }
         volume_invariant_project(sig, sp);
 #pragma unroll
         for (int r = 0; r < 3; r++)
@@ -1200,8 +1337,13 @@ extern "C" int pn_sim_stepforward_cells(int n_k, int n_chunks, int iters, double
     // compute_momentum with dof_tilde = dof + dt * vel on the fly and dof_last = dof (solver.py:574-576,597)
     k_matvec3<<<mv_blocks, mv_wg, 0, st>>>(n, Mmat, dof, momentum, 1, dof_f, rhs_gravity, dof_vel, dt, last);
     for (int it = 0; it < iters; it++) {
-        k_cells_elastic_gather<<<n_chunks, PN_CELL_WAVES * 64, 0, st>>>(chunk_tab, reinterpret_cast<const double2*>(dNx_cell), mu_cell, lam_cell, dof, dx3,
-                                                                         Vstore, part, kcount, kp_bg, kp_pos, momentum, rhs_rest, tot);
+        if (g_pn_svd_mc_sweeps)
+            k_cells_elastic_gather<true><<<n_chunks, PN_CELL_WAVES * 64, 0, st>>>(chunk_tab, reinterpret_cast<const double2*>(dNx_cell), mu_cell, lam_cell, dof,
+                                                                                   dx3, Vstore, part, kcount, kp_bg, kp_pos, momentum, rhs_rest, tot,
+                                                                                   g_pn_svd_mc_sweeps);
+        else
+            k_cells_elastic_gather<false><<<n_chunks, PN_CELL_WAVES * 64, 0, st>>>(chunk_tab, reinterpret_cast<const double2*>(dNx_cell), mu_cell, lam_cell, dof,
+                                                                                    dx3, Vstore, part, kcount, kp_bg, kp_pos, momentum, rhs_rest, tot, 0);
         if (it == iters - 1) k_matvec3<<<mv_blocks, mv_wg, 0, st>>>(n, Ainv, tot, dof, 3, dof_rest, last, nullptr, dt, nullptr, dof_vel);  // + vel (:602)
         else k_matvec3<<<mv_blocks, mv_wg, 0, st>>>(n, Ainv, tot, dof, 2, dof_rest, nullptr);                                                // :600-601
     }
@@ -1675,6 +1817,7 @@ extern "C" int pn_sim_stepforward_coop(int n_k, int n_IP, int iters, double dt, 
                                        double* dof_vel, double* work, void* coop, int n_wg, const int* plan, void* stream) {
     PN_REQUIRE(n_k > 0 && n_IP > 0 && iters >= 1 && iters <= PN_COOP_ITERS && topo && mu && lam && dNx && dNx_csr && csr_pos && Ainv && Mmat);
     PN_REQUIRE(dof_rest && rhs_rest && rhs_gravity && dof_f && dof && dof_vel && work && coop);
+    PN_REQUIRE(g_pn_svd_mc_sweeps == 0);  // the persistent form has the default decomposition only; PN_SIM_SVD=mcadams runs on the cell and CSR forms
     hipStream_t st = (hipStream_t)stream;
     PnCoopPlan pl;
     PN_REQUIRE(plan);

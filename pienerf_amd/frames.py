@@ -26,6 +26,21 @@ import torch
 import torch.distributed as dist
 
 
+def agree_on_launch_form(kw, src=0, group=None, device=None):
+    """Every rank of a frame-parallel job captures the launch form rank `src` picked: kw["fused_from" / "fused_whole" / "fused_fold"] are overwritten
+    in place with src's (one 3-int broadcast; group=None is the default process group).  Each rank probes its own warm-up frame — same state and pose,
+    but nothing guarantees the same answer at a threshold, and ranks running different launch forms would still render the same bits but not the same
+    schedule the owner sized its lanes for."""
+    import torch
+    import torch.distributed as dist
+    on_gpu = dist.get_backend(group) == "nccl"
+    pick = torch.tensor([int(kw["fused_from"]), int(bool(kw["fused_whole"])), int(bool(kw["fused_fold"]))], dtype=torch.int64,
+                        device=device if on_gpu else "cpu")
+    dist.broadcast(pick, src=src, group=group)
+    kw["fused_from"], kw["fused_whole"], kw["fused_fold"] = int(pick[0]), bool(pick[1]), bool(pick[2])
+    return kw
+
+
 def dedicated_sim_default(world_size):
     """Whether the sim owner should only simulate.  The job is bounded by the owner's substep rate (the simulator is time-sequential);
     a substep that shares its GPU with renders runs slower than alone, so from 3 ranks on — where the other

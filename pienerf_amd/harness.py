@@ -174,6 +174,7 @@ class SimRenderHarness:
             self._graph_out = self._step_body(n_trips, W, H)
         self.sim.dof.copy_(keep[0])       # warm-up advanced the simulator; capture itself executes nothing
         self.sim.dof_vel.copy_(keep[1])
+        self.sim.reset_warm_start()       # ... and its SVD warm start: a replay from here has the bits of a simulator that never warmed up
         self._graph_trips = n_trips
         self._graph_done = None
         self._graph_form_epoch = self._net_form_epoch()
@@ -280,7 +281,7 @@ class SimRenderHarness:
             self.sim.enable_persistent()
         be = _HipBackend(self, lanes, depth, int(n_trips), W, H, sim_priority, sim_cus, copy_out, group if on else None,
                          (dist.get_global_rank(group, sim_owner) if (on and group is not None) else sim_owner), _probe_no_substep, _time_trips, copy_on,
-                         render_kw=render_kw)
+                         render_kw=render_kw, distributed=on)
         self._pipe = FramePipeline(be, world=world, rank=rank, lanes=lanes, depth=depth, ahead=(lanes if sim_ahead is None and world == 1 else sim_ahead),
                                    sim_owner=sim_owner, dedicated_sim=dedicated_sim, copy_out=copy_out, on_retire=on_retire,
                                    force_collectives=bool(_force_collectives) and on, sim_on_lanes=sim_on_lanes)
@@ -472,7 +473,7 @@ class _HipBackend:
     as HIP graphs, RCCL broadcasts of the dof snapshots, D2H into pinned buffers."""
 
     def __init__(self, h, lanes, depth, n_trips, W, H, sim_priority, sim_cus, copy_out, group, src, probe_no_substep, time_trips=False, copy_on="host",
-                 render_kw=None):
+                 render_kw=None, distributed=False):
         # stream of the per-frame D2H.  gfx950 runs 4 hardware queues concurrently and time-slices beyond that (DESIGN.md 4): with 3 render lanes +
         # the simulator stream a copy stream of its own is a fifth busy queue (measured: 808 steps/s against 1016 with the copy on the frame's own
         # lane).  "copy": a stream of its own; "lane": the frame's render stream; "sim": the simulator stream; "host": no stream at all — the
@@ -546,14 +547,12 @@ class _HipBackend:
                 h.step(simulate=False, collect_stats=True, W=W, H=H, render_kw=dict(kw, fused_fold=True, async_trips=0))
                 fold = m.fused_clocks(slot=0)["mode"] == 2
             kw["fused_fold"] = bool(fold)
-        if group is not None:
+        if distributed:
             # every rank of a frame-parallel job runs the launch form rank `src` picked (each probed its own warm-up frame: the same state and pose, but
-            # nothing guarantees the same answer at a threshold) — round-4 advisor
-            import torch.distributed as dist
-            pick = torch.tensor([int(kw["fused_from"]), int(bool(kw["fused_whole"])), int(bool(kw["fused_fold"]))], dtype=torch.int64,
-                                device=dev if dist.get_backend(group) == "nccl" else "cpu")
-            dist.broadcast(pick, src=src, group=group)
-            kw["fused_from"], kw["fused_whole"], kw["fused_fold"] = int(pick[0]), bool(pick[1]), bool(pick[2])
+            # nothing guarantees the same answer at a threshold) — round-4 advisor; gated on the job being distributed, NOT on `group`: the default
+            # process group is group=None (round-5 advisor: with `if group is not None` this never ran in a real job)
+            from .frames import agree_on_launch_form
+            agree_on_launch_form(kw, src=src, group=group, device=dev)
         pose0 = torch.from_numpy(np.asarray(h.pose, np.float32)).unsqueeze(0)
         self.pose_dev = [pose0.to(dev) for _ in range(n_ws)]
         self.pose_pin = [pose0.clone().pin_memory() for _ in range(n_ws)]
@@ -629,6 +628,7 @@ class _HipBackend:
                     check(lib().pn_copier_wait(self.copier, t.value), "copier_wait")
         sim.dof.copy_(keep[0])      # warm-up advanced the simulator; capture itself executes nothing
         sim.dof_vel.copy_(keep[1])
+        sim.reset_warm_start()      # ... and its SVD warm start: a replay from here has the bits of a simulator that never warmed up
         torch.cuda.synchronize(dev)
 
     # ---- streams / events

@@ -30,17 +30,32 @@ class _null_ctx:
         return False
 
 
+CELL_CHUNK_IPS = 32   # points per chunk of the substep's cell form = pn_sim_cells_chunk_ips() (csrc/pn_sim.hip: PN_CELL_IPS), checked in _prepare_cells
+
+
 class Simulator:
     def __init__(self, dt=1e-2, iters=20, bbox=torch.tensor([1.0, 1.0, 1.0], dtype=torchfloat), kres=7, dx=1,
                  gravity=torch.tensor([0.0, -9.8, 0.0], dtype=torchfloat), stiff=1e5, base=torch.tensor([-0.5, -0.5, -0.5], dtype=torchfloat),
-                 device="cuda", persistent=None):
+                 device="cuda", persistent=None, svd=None):
         self.device = torch.device(device)
+        # svd: which decomposition stands in for wp.svd3 (cuda_utils.py:107) in calc_elastic.  "jacobi" (default): the converged, warm-started threshold
+        # Jacobi; "mcadams" / "mcadams:N": the published algorithm wp.svd3 implements (McAdams et al., TR1690) with N fixed sweeps (default 8, the setting
+        # of double-precision builds; 4 is the paper's single-precision setting) — csrc/pn_sim.hip: svd3_mcadams.  None: environment PN_SIM_SVD.
+        svd = (svd if svd is not None else os.environ.get("PN_SIM_SVD", "jacobi")).strip().lower()
+        name, _, n = svd.partition(":")
+        if name not in ("jacobi", "mcadams") or (n and not n.isdigit()) or (name == "jacobi" and n):
+            raise ValueError(f"Simulator: svd must be 'jacobi', 'mcadams' or 'mcadams:<sweeps>', got {svd!r}")
+        self.svd_sweeps = 0 if name == "jacobi" else int(n or 8)
+        if self.svd_sweeps == 0 and name == "mcadams" or self.svd_sweeps > 64:
+            raise ValueError("Simulator: mcadams sweeps must be in 1..64")
         # persistent: run the local/global iterations of a substep as ONE cooperative kernel (pn_sim_stepforward_coop) instead of four launches per
         # iteration.  None: environment PN_SIM_COOP (1 / 0), default off — the persistent kernel wants every CU for itself, which suits a GPU that
         # only simulates (the owner rank of a frame-parallel job, a latency-bound single frame) and not one that renders three frames beside it
         if persistent is None:
             persistent = os.environ.get("PN_SIM_COOP", "") == "1"
         self.persistent = bool(persistent)
+        if self.persistent and self.svd_sweeps:
+            raise ValueError("Simulator: the persistent substep has the default decomposition only; svd='mcadams' runs on the cell and CSR forms")
         self._coop = None
         # cell_form: calc_elastic + collect_rhs_IP of a local/global iteration as one launch per kernel-grid cell chunk (pn_sim_stepforward_cells, 21
         # launches per substep instead of 31); PN_SIM_FORM=csr keeps the round-1-4 launch form (three launches per iteration over per-kernel CSR lists)
@@ -87,9 +102,8 @@ class Simulator:
         self.precompute()
         self._work = torch.empty(int(lib().pn_sim_work_doubles(self.n_k, self.n_IP)), dtype=torchfloat, device=self.device)
         self._prepared = False  # pn_sim_prepare runs with the first substep (the CSR lists it reads are built further down)
-        if self.cell_form:      # the cell form's work area: identity rotations for the warm-started SVD, arrival counters (never inside a stream capture)
-            self._cells_work = torch.empty(int(lib().pn_sim_cells_work_doubles(self.n_k, self._cells["n_chunks"])), dtype=torchfloat, device=self.device)
-            check(lib().pn_sim_cells_prepare(self.n_k, self._cells["n_chunks"], ptr(self._cells_work), stream_ptr()), "sim_cells_prepare")
+        if self.cell_form:
+            self._prepare_cells()
         self.rhs_rest = (self.build_rhs() + self._matvec(self.Mmat, self.dof)).contiguous()   # solver.py:314
 
     def precompute(self):
@@ -158,7 +172,9 @@ class Simulator:
         self.csr_pos[order] = torch.arange(order.numel(), dtype=torch.int32, device=dev)   # inverse of `buffer`
 
         self._IP2K = IP2K
-        self._build_cells()
+        self._cells = self._cells_work = None
+        if self.cell_form:   # (torch bookkeeping only; the work area and the check against the library's chunk size: _prepare_cells)
+            self._build_cells()
 
         m = (self.IP_rho * self.dx * self.dx * self.dx)                                      # collect_gravity, cuda_utils.py:262-279
         rg = torch.zeros((n_k * 10, 3), dtype=torchfloat, device=dev)
@@ -171,7 +187,7 @@ class Simulator:
         their 8 neighbour kernels (IP_kernel rows are equal, solver.py:186-205), so they are sorted by cell and every cell is cut into chunks of at most
         pn_sim_cells_chunk_ips() points — one workgroup each, computing calc_elastic and the points' contributions to collect_rhs_IP in one launch."""
         dev, n_IP, n_k, kres = self.device, self.n_IP, self.n_k, self.kres
-        B = int(lib().pn_sim_cells_chunk_ips())
+        B = CELL_CHUNK_IPS
         cell = (self._IP2K[:, 0] * kres + self._IP2K[:, 1]) * kres + self._IP2K[:, 2]
         order = torch.sort(cell, stable=True).indices                                  # points by cell, ascending point index inside a cell
         cs = cell[order]
@@ -208,7 +224,24 @@ class Simulator:
         pos[kp] = torch.arange(kp.numel(), device=dev)
         self._cells["kp_pos"] = pos.to(torch.int32).contiguous()                       # where (chunk, slot) stores its partial sum: its rank in its kernel's run
         self._cells["kp_bg"] = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(kcnt, 0)]).to(torch.int32).contiguous()
-        self._cells_work = None
+        self._cells_work = None   # belongs to the layout: _prepare_cells() makes a new one (initialize(), or the first substep after a rebuild)
+
+    def _prepare_cells(self):
+        """The cell form's work area: identity rotations for the warm-started SVD, arrival counters (never inside a stream capture)."""
+        if int(lib().pn_sim_cells_chunk_ips()) != CELL_CHUNK_IPS:
+            raise RuntimeError(f"libpienerf_hip.so cuts cells into chunks of {lib().pn_sim_cells_chunk_ips()} points, solver.py into {CELL_CHUNK_IPS}")
+        n_chunks = self._cells["n_chunks"]
+        self._cells_work = torch.empty(int(lib().pn_sim_cells_work_doubles(self.n_k, n_chunks)), dtype=torchfloat, device=self.device)
+        check(lib().pn_sim_cells_prepare(self.n_k, n_chunks, ptr(self._cells_work), stream_ptr()), "sim_cells_prepare")
+
+    def reset_warm_start(self):
+        """Forget the SVD warm start (the V of every integration point's previous local/global iteration, kept in the cell form's work area).  Results
+        do not depend on it beyond the decomposition's stopping rule (off-diagonals <= 1e-11 of the diagonal: 1e-10 relative on the displacements), but
+        BIT-equal replays of a trajectory do: whoever restores dof / dof_vel to replay (harness.capture, tests) calls this as well."""
+        if self._cells_work is not None:
+            check(lib().pn_sim_cells_prepare(self.n_k, self._cells["n_chunks"], ptr(self._cells_work), stream_ptr()), "sim_cells_prepare")
+        if self._work is not None and self._prepared:
+            check(lib().pn_sim_prepare(self.n_k, self.n_IP, ptr(self.kernel_bg), ptr(self.kernel_cnt), ptr(self._work), stream_ptr()), "sim_prepare")
 
     def collect_IP(self):  # solver.py:427-450
         n_IP, idx = self.n_IP, self.pts_IP.long()
@@ -255,6 +288,7 @@ class Simulator:
         n = self.n_IP
         RF = torch.empty((n, 3, 3), dtype=torchfloat, device=self.device)
         VF = torch.empty_like(RF)
+        check(lib().pn_sim_set_svd(self.svd_sweeps), "sim_set_svd")
         check(lib().pn_sim_calc_elastic(n, ptr(self.IP_kernel), ptr(self.IP_dNx), ptr(self.dof), ptr(RF), ptr(VF), None, stream_ptr()), "calc_elastic")
         rhs = torch.empty_like(self.dof)
         check(lib().pn_sim_collect_rhs(self.n_k, float(self.dx), ptr(self.kernel_bg), ptr(self.kernel_cnt), ptr(self.buffer), ptr(self.IP_mu),
@@ -312,6 +346,7 @@ class Simulator:
         return flag.value != 0
 
     def stepforward(self):  # solver.py:595-602
+        check(lib().pn_sim_set_svd(self.svd_sweeps), "sim_set_svd")   # process-global in the library: every enqueue names its own choice
         if not self._prepared:
             check(lib().pn_sim_prepare(self.n_k, self.n_IP, ptr(self.kernel_bg), ptr(self.kernel_cnt), ptr(self._work), stream_ptr()), "sim_prepare")
             self._prepared = True
@@ -324,7 +359,9 @@ class Simulator:
                                                 ptr(self.dof_rest), ptr(self.rhs_rest), ptr(self.rhs_gravity), ptr(self.dof_f), ptr(self.dof), ptr(self.dof_vel),
                                                 ptr(self._work), ptr(buf), n_wg, plan, stream_ptr()), "stepforward_coop")
             return
-        if self.cell_form and self._cells_work is not None and int(self.iters) >= 1:
+        if self.cell_form and self._cells is not None and int(self.iters) >= 1:
+            if self._cells_work is None:   # precompute() ran again since initialize(): the layout is new, so is its work area
+                self._prepare_cells()
             c = self._cells
             check(lib().pn_sim_stepforward_cells(self.n_k, c["n_chunks"], int(self.iters), float(self.dt), float(self.dx), ptr(c["tab"]), ptr(c["dNx"]),
                                                  ptr(c["mu"]), ptr(c["lam"]), ptr(c["kp_bg"]), ptr(c["kp_pos"]), ptr(self.Ainv), ptr(self.Mmat),

@@ -175,3 +175,27 @@ def test_tile_parallel_frames(tmp_path, world, W, H):
         for r in range(world):
             assert np.allclose(got[r][f], want, rtol=1e-6, atol=1e-4), (f, r)
         dof = dof * 1.01 + 0.5
+
+
+def _form_worker(rank, world, port, src, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pienerf_amd.frames import agree_on_launch_form
+    # what each rank's own warm-up frame "found": different answers at a threshold
+    kw = [dict(fused_from=1, fused_whole=False, fused_fold=True, other="kept"), dict(fused_from=0, fused_whole=True, fused_fold=False, other="kept"),
+          dict(fused_from=2, fused_whole=False, fused_fold=False, other="kept")][rank]
+    agree_on_launch_form(kw, src=src, group=None)   # group=None = the default process group, what every real call site passes
+    np.save(os.path.join(out_dir, f"f{rank}.npy"), np.array([kw["fused_from"], int(kw["fused_whole"]), int(kw["fused_fold"]), int(kw["other"] == "kept")]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,src", [(2, 0), (3, 1)])
+def test_ranks_agree_on_the_owners_launch_form(tmp_path, world, src):
+    """harness._HipBackend's broadcast of (fused_from, fused_whole, fused_fold) with the DEFAULT process group (group=None): every rank ends with
+    rank src's choice.  Round 5 gated this on `group is not None`, which no real call site satisfies — the ranks kept their own answers."""
+    mp.spawn(_form_worker, args=(world, _free_port(), src, str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(tmp_path / f"f{r}.npy").tolist() for r in range(world)]
+    want = [[1, 0, 1, 1], [0, 1, 0, 1], [2, 0, 0, 1]][src]
+    assert all(g == want for g in got), got

@@ -367,7 +367,7 @@ def test_harness_step_matches_oracle_sequence(small_cloud, small_opt, ckpt):
         ref.stepforward()
         r = oracle.render_deformed(o, d, dict(p_def=p_def, p_ori=p_ori, F=F, dF=dF, IP_dx=ref.dx * 1.05), ckpt, opt)
         out = h.to_host(h.step())
-        assert np.abs(out["image"].reshape(-1, 3) - r["image"]).max() < 2e-4, frame
+        assert np.abs(out["image"].reshape(-1, 3) - r["image"]).max() < 1e-4, frame   # the north-star bar (measured ~4e-6)
     assert h.frame == 3
 
 
