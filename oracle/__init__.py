@@ -38,7 +38,7 @@ _lib = None
 
 def build(force=False):
     """Compile liboracle.so with the committed Makefile (g++)."""
-    srcs = [os.path.join(_HERE, f) for f in ("render_oracle.cpp", "sim_oracle.cpp", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("render_oracle.cpp", "sim_oracle.cpp", "grid_nd_oracle.cpp", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-B"], check=True, stdout=subprocess.DEVNULL)
@@ -200,6 +200,35 @@ def grid_encode_forward(inputs, embeddings, offsets, per_level_scale, base_resol
                                   C.c_uint32(L), F(S), C.c_uint32(base_resolution), C.c_uint32(gridtype), I(int(align_corners)),
                                   C.c_uint32(interpolation))
     return np.ascontiguousarray(out.transpose(1, 0, 2).reshape(B, L * Cf))
+
+
+def grid_nd_forward(inputs, embeddings, offsets, per_level_scale, base_resolution, gridtype=0, align_corners=False, interpolation=0, dy_dx=False):
+    """kernel_grid<float, D, C> for D = inputs.shape[1] in 2..5 (gridencoder.cu:87-245, grid_nd_oracle.cpp): [B, L*C] (and dy_dx [B, L*D*C])."""
+    inputs, embeddings, offsets = _f32(inputs), _f32(embeddings), _i32(offsets)
+    B, Dd = inputs.shape
+    L, Cf = offsets.shape[0] - 1, embeddings.shape[1]
+    out = np.empty((L, B, Cf), np.float32)
+    dd = np.empty((B, L * Dd * Cf), np.float32) if dy_dx else None
+    lib().orc_grid_nd_forward(_p(inputs, F), _p(embeddings, F), _p(offsets, I), _p(out, F), _p(dd, F) if dy_dx else None, C.c_uint32(B), C.c_uint32(Dd),
+                              C.c_uint32(Cf), C.c_uint32(L), F(np.float32(np.log2(per_level_scale))), C.c_uint32(base_resolution), C.c_uint32(gridtype),
+                              I(int(align_corners)), C.c_uint32(interpolation))
+    y = np.ascontiguousarray(out.transpose(1, 0, 2).reshape(B, L * Cf))
+    return (y, dd) if dy_dx else y
+
+
+def grid_nd_backward(grad, inputs, embeddings_shape, offsets, per_level_scale, base_resolution, dy_dx=None, gridtype=0, align_corners=False, interpolation=0):
+    """kernel_grid_backward + kernel_input_backward for D in 2..5 (gridencoder.cu:248-369): grad [B, L*C] -> (grad_inputs [B, D] or None, grad_embeddings)."""
+    inputs, offsets = _f32(inputs), _i32(offsets)
+    B, Dd = inputs.shape
+    L, Cf = offsets.shape[0] - 1, embeddings_shape[1]
+    g = np.ascontiguousarray(_f32(grad).reshape(B, L, Cf).transpose(1, 0, 2))
+    ge = np.zeros(tuple(embeddings_shape), np.float32)
+    gi = np.zeros((B, Dd), np.float32) if dy_dx is not None else None
+    dd = _f32(dy_dx) if dy_dx is not None else None
+    lib().orc_grid_nd_backward(_p(g, F), _p(inputs, F), _p(offsets, I), _p(ge, F), C.c_uint32(B), C.c_uint32(Dd), C.c_uint32(Cf), C.c_uint32(L),
+                               F(np.float32(np.log2(per_level_scale))), C.c_uint32(base_resolution), _p(dd, F) if dd is not None else None,
+                               _p(gi, F) if gi is not None else None, C.c_uint32(gridtype), I(int(align_corners)), C.c_uint32(interpolation))
+    return gi, ge
 
 
 def grid_level_params(L, per_level_scale, base_resolution):

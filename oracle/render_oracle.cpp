@@ -490,6 +490,7 @@ inline void level_params(uint32_t level, float S, uint32_t H, float* scale, uint
 
 // shencoder/src/shencoder.cu:42-68 (degree <= 4).  Constants are the closed
 // forms quoted in the reference's comments, evaluated in double then narrowed.
+void sh_high_bands(const float* in, uint32_t C, float* out, float* gx, float* gy, float* gz);  // bands 4..7, defined with the training-side code below
 void sh_one(const float* in, uint32_t C, float* out) {
     static const double PI_ = 3.14159265358979323846;
     static const float c0 = (float)(1.0 / (2.0 * std::sqrt(PI_)));
@@ -844,8 +845,11 @@ void orc_grid_level_params(uint32_t L, float S, uint32_t H, float* scales, uint3
 
 // shencoder.cu:384-390
 void orc_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C) {
-    if (D != 3 || C > 4) return;
-    for (int64_t b = 0; b < (int64_t)B; b++) sh_one(inputs + b * 3, C, outputs + b * C * C);
+    if (D != 3 || C > 8) return;
+    for (int64_t b = 0; b < (int64_t)B; b++) {
+        sh_one(inputs + b * 3, C < 4 ? C : 4, outputs + b * C * C);
+        if (C > 4) sh_high_bands(inputs + b * 3, C, outputs + b * C * C, nullptr, nullptr, nullptr);
+    }
 }
 
 // NeRFNetwork.forward over M samples (nerf/network.py:98-127), density_scale applied by the caller.
@@ -1045,6 +1049,64 @@ uint32_t train_march_pass(const float* ro, const float* rd, float t0, float far,
         }
     }
     return step;
+}
+
+// Bands l = 4..7 (degree 5-8; shencoder.cu:69-123 lists them as expanded polynomials, :125-355 their derivatives).  Restated from the
+// definition instead of the list, in double, narrowed at the end:
+//   Y_l^m = (-1)^m sqrt2 K_l^|m| T_l^|m|(z) * { A_|m|(x, y) for m > 0, B_|m|(x, y) for m < 0 },   Y_l^0 = K_l^0 T_l^0(z),
+//   K_l^m = sqrt((2l + 1) / (4 pi) * (l - m)! / (l + m)!),  A_m + i B_m = (x + i y)^m,  T_l^m = d^m/dz^m P_l(z)  (no Condon-Shortley
+//   factor inside T; the basis as a whole KEEPS that phase: Y_1^{-1} = -c y, which is what the reference's list has),
+// with the closed sums  P_l(z) = 2^-l sum_k (-1)^k C(l, k) C(2l - 2k, l) z^(l - 2k)  and the binomial expansion of (x + i y)^m — a formulation
+// independent of the recurrences the HIP kernel uses.  As polynomials in (x, y, z) these ARE the reference's expressions (T in z only, A / B in
+// x, y only), so they agree off the unit sphere too, and so do their partial derivatives.
+static double binom(int n, int k) {
+    if (k < 0 || k > n) return 0.0;
+    double r = 1.0;
+    for (int i = 1; i <= k; i++) r = r * (double)(n - k + i) / (double)i;
+    return std::round(r);
+}
+static double fact(int n) { double r = 1.0; for (int i = 2; i <= n; i++) r *= i; return r; }
+// T_l^m(z) and its z-derivative
+static void legendre_deriv(int l, int m, double z, double* T, double* dT) {
+    double t = 0.0, dt = 0.0;
+    for (int k = 0; 2 * k <= l; k++) {
+        const int n = l - 2 * k;           // power of z in P_l
+        if (n < m) break;
+        const double c = ((k & 1) ? -1.0 : 1.0) * binom(l, k) * binom(2 * l - 2 * k, l) / std::ldexp(1.0, l) * fact(n) / fact(n - m);
+        t += c * std::pow(z, n - m);
+        if (n - m >= 1) dt += c * (n - m) * std::pow(z, n - m - 1);
+    }
+    *T = t; *dT = dt;
+}
+// A_m, B_m and their x / y derivatives
+static void azimuth_poly(int m, double x, double y, double* A, double* B, double* Ax, double* Ay, double* Bx, double* By) {
+    double a = 0, b = 0, ax = 0, ay = 0, bx = 0, by = 0;
+    for (int j = 0; j <= m; j++) {
+        const double c = binom(m, j) * ((j / 2) & 1 ? -1.0 : 1.0);     // i^j = (+1, +i, -1, -i)
+        const double mono = std::pow(x, m - j) * std::pow(y, j);
+        const double dmx = (m - j >= 1) ? (m - j) * std::pow(x, m - j - 1) * std::pow(y, j) : 0.0;
+        const double dmy = (j >= 1) ? j * std::pow(x, m - j) * std::pow(y, j - 1) : 0.0;
+        if (j & 1) { b += c * mono; bx += c * dmx; by += c * dmy; }
+        else { a += c * mono; ax += c * dmx; ay += c * dmy; }
+    }
+    *A = a; *B = b; *Ax = ax; *Ay = ay; *Bx = bx; *By = by;
+}
+void sh_high_bands(const float* in, uint32_t C, float* out, float* gx, float* gy, float* gz) {
+    static const double PI_ = 3.14159265358979323846;
+    const double x = in[0], y = in[1], z = in[2];
+    for (int l = 4; l < (int)C; l++)
+        for (int m = 0; m <= l; m++) {
+            double T, dT, A, B, Ax, Ay, Bx, By;
+            legendre_deriv(l, m, z, &T, &dT);
+            azimuth_poly(m, x, y, &A, &B, &Ax, &Ay, &Bx, &By);
+            const double K = std::sqrt((2.0 * l + 1.0) / (4.0 * PI_) * fact(l - m) / fact(l + m)) * (m ? std::sqrt(2.0) * ((m & 1) ? -1.0 : 1.0) : 1.0);
+            const int ip = l * l + l + m, im = l * l + l - m;
+            if (out) { out[ip] = (float)(K * T * A); if (m) out[im] = (float)(K * T * B); }
+            if (gx) {
+                gx[ip] = (float)(K * T * Ax); gy[ip] = (float)(K * T * Ay); gz[ip] = (float)(K * dT * A);
+                if (m) { gx[im] = (float)(K * T * Bx); gy[im] = (float)(K * T * By); gz[im] = (float)(K * dT * B); }
+            }
+        }
 }
 
 // first-order terms of sh_one (d/dx, d/dy, d/dz of the same polynomials; shencoder.cu:125-355 tabulates the same derivatives)
@@ -1308,10 +1370,18 @@ void orc_grad_total_variation(const float* inputs, const float* embeddings, floa
     }
 }
 
-// kernel_sh's dy_dx branch (shencoder.cu:125-355, degree <= 4): dy_dx [B, 3, C*C]; kernel_sh_backward (:358-383): grad_inputs +=
+// kernel_sh's dy_dx branch (shencoder.cu:125-355): dy_dx [B, 3, C*C]; kernel_sh_backward (:358-383): grad_inputs +=
 void orc_sh_encode_dy_dx(const float* inputs, float* dy_dx, uint32_t B, uint32_t C) {
     const uint32_t C2 = C * C;
-    for (uint32_t b = 0; b < B; b++) sh_one_grad(inputs + (size_t)b * 3, C, dy_dx + (size_t)b * 3 * C2, dy_dx + (size_t)b * 3 * C2 + C2, dy_dx + (size_t)b * 3 * C2 + 2 * C2);
+    for (uint32_t b = 0; b < B; b++) {
+        float* g = dy_dx + (size_t)b * 3 * C2;
+        for (uint32_t i = 0; i < 3 * C2; i++) g[i] = 0.0f;
+        if (C <= 4) { sh_one_grad(inputs + (size_t)b * 3, C, g, g + C2, g + 2 * C2); continue; }
+        float lo[3][16];
+        sh_one_grad(inputs + (size_t)b * 3, 4, lo[0], lo[1], lo[2]);
+        for (int d = 0; d < 3; d++) for (int i = 0; i < 16; i++) g[d * C2 + i] = lo[d][i];
+        sh_high_bands(inputs + (size_t)b * 3, C, nullptr, g, g + C2, g + 2 * C2);
+    }
 }
 void orc_sh_encode_backward(const float* grad, uint32_t B, uint32_t C, const float* dy_dx, float* grad_inputs) {
     const uint32_t C2 = C * C;

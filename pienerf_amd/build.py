@@ -33,6 +33,7 @@ UNITS = {
     "pn_grid_state.hip": ["-ffp-contract=off"],
     "pn_nerf_forward.hip": ["-ffp-contract=fast"],
     "pn_encoder_grad.hip": ["-ffp-contract=fast"],
+    "pn_grid_nd.hip": ["-ffp-contract=fast"],
     "pn_sim.hip": ["-ffp-contract=fast"],
     "pn_copier.hip": [],  # host code only: frame copies through the HSA runtime (links libhsa-runtime64)
 }

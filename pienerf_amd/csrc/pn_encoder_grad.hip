@@ -10,6 +10,7 @@
 // (global_atomic_add_f32 at L2, no CAS loop).  Like the reference's atomicAdd the summation order is not fixed, so gradients are
 // compared with the oracle to a tolerance, not bit for bit.
 #include "pn_encoders.h"
+#include "pn_sh_bands.h"
 
 namespace {
 
@@ -264,10 +265,15 @@ __global__ void __launch_bounds__(256) k_sh_dy_dx(const float* __restrict__ inpu
     const uint32_t b = threadIdx.x + blockIdx.x * blockDim.x;
     if (b >= B) return;
     float g[3][16];
-    sh16_grad(inputs[(size_t)b * 3], inputs[(size_t)b * 3 + 1], inputs[(size_t)b * 3 + 2], g[0], g[1], g[2]);
+    const float x = inputs[(size_t)b * 3], y = inputs[(size_t)b * 3 + 1], z = inputs[(size_t)b * 3 + 2];
+    sh16_grad(x, y, z, g[0], g[1], g[2]);
     const uint32_t C2 = C * C;
     for (uint32_t d = 0; d < 3; d++)
-        for (uint32_t i = 0; i < C2; i++) dy_dx[((size_t)b * 3 + d) * C2 + i] = g[d][i];
+        for (uint32_t i = 0; i < (C2 < 16u ? C2 : 16u); i++) dy_dx[((size_t)b * 3 + d) * C2 + i] = g[d][i];
+    if (C > 4) {  // degree 5-8 (shencoder.cu:125-355): bands 4.. by recurrence, straight into the three rows
+        float* row = dy_dx + (size_t)b * 3 * C2;
+        pnsh::high_bands(x, y, z, (int)C, nullptr, row, row + C2, row + 2 * C2);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_sh_backward(const float* __restrict__ grad, uint32_t B, uint32_t C, const float* __restrict__ dy_dx,
@@ -308,6 +314,9 @@ extern "C" int pn_grid_encode_backward(const float* grad, const float* inputs, c
     (void)embeddings;  // the fp32 path never reads the table in backward (the reference passes it for its dtype only)
     if (B == 0) return PN_OK;
     PN_REQUIRE(grad && inputs && offsets_host && grad_embeddings);
+    if (D != 3)  // gridencoder.cu:437-442: D = 2, 4, 5
+        return pn_grid_nd_backward_launch(grad, inputs, offsets_host, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp,
+                                          (hipStream_t)stream);
     PN_REQUIRE(D == 3 && (C == 1 || C == 2 || C == 4 || C == 8) && gridtype <= 1 && interp <= 1);
     PN_REQUIRE((dy_dx == nullptr) == (grad_inputs == nullptr));
     PnGridLevels lv;
@@ -369,7 +378,7 @@ extern "C" int pn_sh_encode_backward(const float* grad, const float* inputs, uin
                                      void* stream) {
     (void)inputs;
     if (B == 0) return PN_OK;
-    PN_REQUIRE(grad && dy_dx && grad_inputs && D == 3 && C >= 1 && C <= 4);
+    PN_REQUIRE(grad && dy_dx && grad_inputs && D == 3 && C >= 1 && C <= 8);
     k_sh_backward<<<pn_div_up((uint64_t)B * 3, 256), 256, 0, (hipStream_t)stream>>>(grad, B, C, dy_dx, grad_inputs);
     PN_LAUNCH_CHECK();
     return PN_OK;

@@ -37,3 +37,10 @@ __device__ __forceinline__ uint32_t grid_index3(const LevelIdx& L, uint32_t g0, 
 int pn_grid_dy_dx_launch(const float* inputs, const float* embeddings, const PnGridLevels& lv, uint32_t B, uint32_t C, int align_corners, uint32_t interp,
                          float* dy_dx, hipStream_t st);
 int pn_sh_dy_dx_launch(const float* inputs, float* dy_dx, uint32_t B, uint32_t C, hipStream_t st);
+// input dimensions 2, 4, 5 of the stand-alone grid op (pn_grid_nd.hip; gridencoder.cu:386-399,430-444): fp32, forward (+ dy_dx) and backward
+int pn_grid_nd_forward_launch(const float* inputs, const float* embeddings, const int* offsets_host, float* outputs, uint32_t B, uint32_t D, uint32_t C,
+                              uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype, int align_corners, uint32_t interp, int out_bl_major,
+                              hipStream_t st);
+int pn_grid_nd_backward_launch(const float* grad, const float* inputs, const int* offsets_host, float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                               uint32_t L, float S, uint32_t H, const float* dy_dx, float* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp,
+                               hipStream_t st);

@@ -19,6 +19,7 @@
 #include "pn_encoders.h"
 
 #include "pn_net_tile.h"
+#include "pn_sh_bands.h"
 
 // ------------------------------------------------------------------------------------------------ level table
 int pn_fill_grid_levels(PnGridLevels* g, const int* offsets_host, uint32_t L, uint32_t C, float S, uint32_t H, uint32_t gridtype,
@@ -135,7 +136,7 @@ static int grid_encode_launch(const float* inputs, const T* embeddings, const in
                               uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int out_bl_major,
                               PnGridLevels* lv_out, hipStream_t st) {
     PN_REQUIRE(inputs && embeddings && offsets_host && outputs);
-    PN_REQUIRE(D == 3);                                   // the reference also has D = 2,4,5 (gridencoder.cu:386-395); not on this path
+    PN_REQUIRE(D == 3);                                   // D = 2, 4, 5 (gridencoder.cu:386-395): fp32 in pn_grid_nd.hip; the half table form is D = 3 only
     PN_REQUIRE(C == 1 || C == 2 || C == 4 || C == 8);     // gridencoder.cu:376-382
     PN_REQUIRE(gridtype <= 1 && interp <= 1);
     PnGridLevels lv;
@@ -175,6 +176,9 @@ extern "C" int pn_grid_encode_forward(const float* inputs, const float* embeddin
                                       uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype, int align_corners,
                                       uint32_t interp, int out_bl_major, void* stream) {
     if (B == 0) return PN_OK;  // empty tensors have null data pointers
+    if (D != 3)                // gridencoder.cu:393-398: D = 2, 4, 5 (anything else: "GridEncoding: D must be 2, 3, 4, 5" -> PN_ERR_ARG)
+        return pn_grid_nd_forward_launch(inputs, embeddings, offsets_host, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp, out_bl_major,
+                                         (hipStream_t)stream);
     PnGridLevels lv;
     const int rc = grid_encode_launch<float>(inputs, embeddings, offsets_host, outputs, B, D, C, L, S, H, gridtype, align_corners, interp, out_bl_major,
                                              &lv, (hipStream_t)stream);
@@ -198,14 +202,26 @@ __global__ void __launch_bounds__(256) k_sh_encode(const float* __restrict__ inp
     float o[16];
     sh16(inputs[b * 3], inputs[b * 3 + 1], inputs[b * 3 + 2], o);
     const uint32_t C2 = C * C;
-    for (uint32_t i = 0; i < C2; i++) outputs[(size_t)b * C2 + i] = o[i];
+    for (uint32_t i = 0; i < (C2 < 16u ? C2 : 16u); i++) outputs[(size_t)b * C2 + i] = o[i];
+}
+
+// degree 5-8 (shencoder.cu:69-123): bands 0-3 as above, bands 4.. by recurrence (pn_sh_bands.h), written straight to the output row
+__global__ void __launch_bounds__(256) k_sh_encode_high(const float* __restrict__ inputs, float* __restrict__ outputs, uint32_t B, uint32_t C) {
+    const uint32_t b = threadIdx.x + blockIdx.x * blockDim.x;
+    if (b >= B) return;
+    const float x = inputs[b * 3], y = inputs[b * 3 + 1], z = inputs[b * 3 + 2];
+    float o[16];
+    sh16(x, y, z, o);
+    float* row = outputs + (size_t)b * C * C;
+    for (uint32_t i = 0; i < 16; i++) row[i] = o[i];
+    pnsh::high_bands(x, y, z, (int)C, row, nullptr, nullptr, nullptr);
 }
 
 extern "C" int pn_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C, float* dy_dx, void* stream) {
     if (B == 0) return PN_OK;  // empty tensors have null data pointers
-    PN_REQUIRE(inputs && outputs && D == 3 && C >= 1 && C <= 4);  // degrees 5-8 (shencoder.cu:70-122): not on this path
-    if (B == 0) return PN_OK;
-    k_sh_encode<<<pn_div_up(B, 256), 256, 0, (hipStream_t)stream>>>(inputs, outputs, B, C);
+    PN_REQUIRE(inputs && outputs && D == 3 && C >= 1 && C <= 8);  // shencoder.cu:42-123 (the wrapper asserts degree <= 8, sphere_harmonics.py:70)
+    if (C > 4) k_sh_encode_high<<<pn_div_up(B, 256), 256, 0, (hipStream_t)stream>>>(inputs, outputs, B, C);
+    else k_sh_encode<<<pn_div_up(B, 256), 256, 0, (hipStream_t)stream>>>(inputs, outputs, B, C);
     PN_LAUNCH_CHECK();
     if (dy_dx) return pn_sh_dy_dx_launch(inputs, dy_dx, B, C, (hipStream_t)stream);  // training side (pn_encoder_grad.hip)
     return PN_OK;

@@ -1,4 +1,4 @@
-"""Drop-in mirror of the reference's ``shencoder`` package (degree <= 4; forward on the render path, dy_dx / backward for training).
+"""Drop-in mirror of the reference's ``shencoder`` package (degree 1-8 like the reference; forward on the render path with degree 4, dy_dx / backward for training).
 
 /root/reference/shencoder/sphere_harmonics.py:14-37 (``_sh_encoder.forward``), :60-87 (``SHEncoder``).
 """
@@ -48,7 +48,7 @@ class SHEncoder(nn.Module):
         self.degree = degree
         self.output_dim = degree ** 2
         assert self.input_dim == 3, "SH encoder only support input dim == 3"
-        assert self.degree > 0 and self.degree <= 4, "this build implements degree in [1, 4] (the reference goes to 8; the renderer uses 4)"
+        assert self.degree > 0 and self.degree <= 8, "SHEncoder: degree must be in [1, 8]"   # sphere_harmonics.py:70
 
     def __repr__(self):
         return f"SHEncoder: input_dim={self.input_dim} degree={self.degree}"

@@ -302,8 +302,60 @@ def test_grid_encode_half_equals_the_reference_half_kernel(mods, ckpt):
     assert min(float((a - f).abs().max()), float((a - r).abs().max())) <= 2e-3 and min(frac_r, frac_f) < 0.02
 
 
-@pytest.mark.parametrize("degree", [1, 2, 3, 4])
+@pytest.mark.parametrize("D,C,gridtype,align,interp", [(2, 2, 0, False, 0), (2, 4, 1, True, 1), (4, 2, 0, False, 0), (4, 1, 0, True, 1), (5, 2, 0, False, 0),
+                                                       (5, 8, 1, False, 1)])
+def test_grid_encode_other_input_dims_equal_the_reference_kernel(mods, D, C, gridtype, align, interp):
+    """kernel_grid<float, D, C> for D = 2, 4, 5 (gridencoder.cu:386-399), kernel_grid_backward + kernel_input_backward (:430-444): the stand-alone op's
+    other input dimensions (csrc/pn_grid_nd.hip) against the reference's own kernels, and the CPU oracle (oracle/grid_nd_oracle.cpp) against them too.
+    Forward + dy_dx: <= 2e-6 against the contracting build (same arithmetic, one rounding of `pos`); backward: fp32 atomics in any order, 1e-4."""
+    from pienerf_amd.gridencoder.grid import level_table_offsets
+    ref, fma, ours = mods
+    pls, base, L = 1.5, 4, 7
+    cap = {2: 9, 4: 13, 5: 13}[D]
+    offsets = level_table_offsets(D, L, pls, base, cap, align)          # low levels dense, upper levels hashed (or tiled) into 2^cap entries
+    assert (np.diff(offsets) == 1 << cap).any() and (np.diff(offsets) < 1 << cap).any()
+    rng = np.random.default_rng(20 + D)
+    emb_np = rng.uniform(-1, 1, (int(offsets[-1]), C)).astype(np.float32)
+    B = 6000
+    x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+    x[0], x[1], x[2], x[3] = 0.0, 1.0, 0.5, 0.999999
+    x[4, 0], x[5, D - 1] = -0.1, 1.2                                      # out of range in one coordinate: zeros, no gradient
+    grad_np = rng.standard_normal((L, B, C)).astype(np.float32)
+    emb, tx, off, grad = T(emb_np), T(x), T(offsets.astype(np.int32)), T(grad_np)
+    S = float(np.log2(pls))
+    out = {}
+    for name, mm in (("ref", ref), ("ours", ours), ("fma", fma)):
+        y, dy = torch.empty(L, B, C, device=DEV), torch.empty(B, L * D * C, device=DEV)
+        mm["gridencoder"].grid_encode_forward(tx, emb, off, y, B, D, C, L, S, base, dy, gridtype, align, interp)
+        y2 = torch.empty(L, B, C, device=DEV)
+        mm["gridencoder"].grid_encode_forward(tx, emb, off, y2, B, D, C, L, S, base, None, gridtype, align, interp)
+        ge, gi = torch.zeros_like(emb), torch.zeros(B, D, device=DEV)
+        mm["gridencoder"].grid_encode_backward(grad, tx, emb, off, ge, B, D, C, L, S, base, dy, gi, gridtype, align, interp)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2)
+        out[name] = (y, dy, ge, gi)
+    key = f"grid_nd[D={D},C={C},{gridtype},{int(align)},{interp}]"
+    REPORT[key] = dict(outputs_vs_fma=mismatch(out["ours"][0], out["fma"][0]), outputs_vs_nocontract=mismatch(out["ours"][0], out["ref"][0]),
+                       dy_dx_rel_vs_fma=rel(out["ours"][1], out["fma"][1]), grad_embeddings_rel=rel(out["ours"][2], out["ref"][2]),
+                       grad_inputs_rel=rel(out["ours"][3], out["fma"][3]))
+    print(key, REPORT[key])
+    assert REPORT[key]["outputs_vs_fma"][1] <= 2e-6 and REPORT[key]["outputs_vs_nocontract"][1] <= 2e-4
+    assert REPORT[key]["dy_dx_rel_vs_fma"] < 1e-5 and REPORT[key]["grad_embeddings_rel"] < 1e-4 and REPORT[key]["grad_inputs_rel"] < 1e-4
+    assert not out["ref"][0][:, 4:6].any() and not out["ours"][0][:, 4:6].any() and not out["ours"][3][4:6].any()
+    # the CPU oracle, first-hand against the reference kernel (contracting build)
+    want_y, want_dy = oracle.grid_nd_forward(x, emb_np, offsets, pls, base, gridtype, align, interp, dy_dx=True)
+    y_fma = out["fma"][0].permute(1, 0, 2).reshape(B, L * C).cpu().numpy()
+    assert np.abs(want_y - y_fma).max() <= 2e-6 and np.abs(want_dy - out["fma"][1].cpu().numpy()).max() <= 1e-5 * np.abs(want_dy).max()
+    gi_o, ge_o = oracle.grid_nd_backward(grad_np.transpose(1, 0, 2).reshape(B, L * C), x, emb_np.shape, offsets, pls, base, want_dy, gridtype, align, interp)
+    assert np.abs(ge_o - out["ref"][2].cpu().numpy()).max() <= 1e-4 * np.abs(ge_o).max()
+    assert np.abs(gi_o - out["fma"][3].cpu().numpy()).max() <= 1e-4 * np.abs(gi_o).max()
+
+
+@pytest.mark.parametrize("degree", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_sh_encode_equals_the_reference_kernel(mods, degree):
+    """kernel_sh (shencoder.cu:27-123 forward, :125-355 dy_dx) and kernel_sh_backward (:358-383).  Degrees 5-8 are evaluated by recurrence in double and
+    narrowed once (csrc/pn_sh_bands.h) where the reference sums expanded float polynomials with coefficients up to 20: the gap is the REFERENCE's float
+    rounding (a few ulp of its largest term), hence the wider bar there."""
     ref, fma, ours = mods
     rng = np.random.default_rng(4)
     B = 20000
@@ -321,7 +373,7 @@ def test_sh_encode_equals_the_reference_kernel(mods, degree):
     for i, what in enumerate(("y", "dy_dx", "grad_inputs")):
         e = min(float((out["ours"][i] - out["ref"][i]).abs().max()), float((out["ours"][i] - out["fma"][i]).abs().max()))
         REPORT[f"sh[{degree}].{what}"] = dict(vs_ref=mismatch(out["ours"][i], out["ref"][i]), vs_fma=mismatch(out["ours"][i], out["fma"][i]))
-        assert e <= (1e-6 if i == 0 else 2e-5), (what, e)
+        assert e <= ((1e-6 if i == 0 else 2e-5) if degree <= 4 else (1e-5 if i == 0 else 4e-4)), (what, e)
 
 
 # ------------------------------------------------------------------------------------------------ the CPU oracle against the reference, first-hand
@@ -432,11 +484,11 @@ def test_cpu_oracle_equals_the_reference_kernels_directly(mods, ckpt):
     # SH
     dd = rng.standard_normal((B, 3)).astype(np.float32)
     dd /= np.linalg.norm(dd, axis=-1, keepdims=True)
-    for degree in (1, 2, 3, 4):
+    for degree in (1, 2, 3, 4, 6, 8):
         y = torch.empty(B, degree ** 2, device=DEV)
         ref["shencoder"].sh_encode_forward(T(dd), y, B, 3, degree, None)
         torch.cuda.synchronize()
-        assert np.abs(y.cpu().numpy() - oracle.sh_encode_forward(dd, degree)).max() <= 1e-6, degree
+        assert np.abs(y.cpu().numpy() - oracle.sh_encode_forward(dd, degree)).max() <= (1e-6 if degree <= 4 else 1e-5), degree
 
 
 # ------------------------------------------------------------------------------------------------ training ops

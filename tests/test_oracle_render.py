@@ -93,11 +93,14 @@ def test_sh_vs_scipy():
     rng = np.random.default_rng(3)
     d = rng.standard_normal((200, 3))
     d /= np.linalg.norm(d, axis=1, keepdims=True)
-    got = oracle.sh_encode_forward(d.astype(np.float32), 4)
+    d = d.astype(np.float32).astype(np.float64)   # the basis is evaluated AT the float inputs
+    got = oracle.sh_encode_forward(d.astype(np.float32), 8)
+    assert np.array_equal(got[:, :16], oracle.sh_encode_forward(d.astype(np.float32), 4))
+    r = np.linalg.norm(d, axis=1)                   # (unit to float rounding: the polynomials are homogeneous per band only on the sphere)
     theta = np.arctan2(d[:, 1], d[:, 0])  # azimuth
-    phi = np.arccos(np.clip(d[:, 2], -1, 1))  # polar
+    phi = np.arccos(np.clip(d[:, 2] / r, -1, 1))  # polar
     k = 0
-    for l in range(4):
+    for l in range(8):
         for m in range(-l, l + 1):
             Y = sph_harm(abs(m), l, theta, phi)
             if m < 0:
@@ -107,8 +110,26 @@ def test_sh_vs_scipy():
             else:
                 real = np.sqrt(2) * Y.real
             # the reference's basis (shencoder.cu:50-68) is the real SH basis that KEEPS the Condon-Shortley phase (Y_1,-1 = -c y)
-            assert np.abs(got[:, k] - real).max() < 2e-6, (l, m)
+            assert np.abs(got[:, k] - real).max() < (2e-6 if l < 4 else 1e-5), (l, m)
             k += 1
+
+
+def test_sh_gradients_are_the_derivatives_of_the_basis():
+    """orc_sh_encode_dy_dx (shencoder.cu:125-355) for degree 1..8 against central differences of the forward in double-stepped float inputs, off the
+    unit sphere too (the reference differentiates its polynomials as polynomials in x, y, z)."""
+    rng = np.random.default_rng(8)
+    d = rng.uniform(-1, 1, (300, 3)).astype(np.float32)
+    for degree in (2, 4, 5, 8):
+        C2 = degree * degree
+        from oracle import training as otr
+        g = otr.sh_encode_dy_dx(d, degree).reshape(-1, 3, C2)
+        h = np.float32(2.0 ** -7)
+        for ax in range(3):
+            e = np.zeros(3, np.float32)
+            e[ax] = h
+            num = (oracle.sh_encode_forward(d + e, degree).astype(np.float64) - oracle.sh_encode_forward(d - e, degree)) / (2.0 * float(h))
+            # central differences of a degree-7 polynomial with coefficients ~10: O(h^2) truncation ~ 1e-2 at worst on the top band
+            assert np.abs(num - g[:, ax]).max() < (2e-3 if degree <= 4 else 6e-2), (degree, ax, np.abs(num - g[:, ax]).max())
 
 
 def test_composite_closed_form():
@@ -394,3 +415,36 @@ def test_sph_from_ray_against_the_closed_form():
     theta, phi = np.arctan2(np.hypot(p[:, 0], p[:, 2]), p[:, 1]), np.arctan2(p[:, 2], p[:, 0])
     assert np.abs(c[:, 0] - (2 * theta / np.pi - 1)).max() < 5e-6 and np.abs(c[:, 1] - phi / np.pi).max() < 5e-6
     assert c.min() >= -1.0 and c.max() <= 1.0
+
+
+def test_grid_nd_oracle_restates_the_d3_oracle_and_interpolates():
+    """oracle/grid_nd_oracle.cpp (kernel_grid<float, D, C> for D = 2..5, gridencoder.cu:386-399) at D = 3 equals render_oracle.cpp's D = 3 code bit for
+    bit (forward, dy_dx, backward, both grid types, align_corners, smoothstep); for D = 2, 4, 5 a constant table encodes to that constant (the 2^D
+    weights sum to one) with zero input gradient, out-of-range inputs to zero, and the backward scatters exactly the incoming gradient's mass."""
+    from oracle import training as otr
+    from pienerf_amd.gridencoder.grid import level_table_offsets
+    rng = np.random.default_rng(11)
+    pls = 1.5
+    for gt in (0, 1):
+        for al in (False, True):
+            for ip in (0, 1):
+                off = level_table_offsets(3, 6, pls, 8, 12, al)
+                emb = rng.uniform(-.5, .5, (int(off[-1]), 2)).astype(np.float32)
+                x = rng.uniform(-0.05, 1.05, (300, 3)).astype(np.float32)
+                a = oracle.grid_encode_forward(x, emb, off, pls, 8, gt, al, ip)
+                b, dd = oracle.grid_nd_forward(x, emb, off, pls, 8, gt, al, ip, dy_dx=True)
+                d0 = otr.grid_encode_dy_dx(x, emb, off, pls, 8, gt, al, ip)
+                g = rng.standard_normal(a.shape).astype(np.float32)
+                gi0, ge0 = otr.grid_encode_backward(g, x, emb.shape, off, pls, 8, d0, gt, al, ip)
+                gi1, ge1 = oracle.grid_nd_backward(g, x, emb.shape, off, pls, 8, dd, gt, al, ip)
+                assert np.array_equal(a, b) and np.array_equal(dd, d0) and np.array_equal(gi0, gi1) and np.array_equal(ge0, ge1), (gt, al, ip)
+    for D in (2, 4, 5):
+        off = level_table_offsets(D, 5, pls, 4, 11, False)
+        emb = np.full((int(off[-1]), 2), 0.75, np.float32)
+        x = rng.uniform(0, 1, (200, D)).astype(np.float32)
+        x[0, 0] = 1.5
+        y, dd = oracle.grid_nd_forward(x, emb, off, pls, 4, 0, False, 0, dy_dx=True)
+        assert not y[0].any() and np.abs(y[1:] - 0.75).max() < 1e-6 and np.abs(dd).max() < 1e-4
+        g = np.ones_like(y)
+        _, ge = oracle.grid_nd_backward(g, x, emb.shape, off, pls, 4, None, 0, False, 0)
+        assert abs(ge.sum() - 199 * 5 * 2) < 1e-2
