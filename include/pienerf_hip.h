@@ -40,8 +40,10 @@ int pn_stream_destroy(void* stream);
  * large value to push every ray through either launch.  Affects renders enqueued afterwards, process-wide. */
 int pn_march_set_tail_rounds(int rounds);
 /* Tests / experiments: 0 makes the frame driver's skip pre-pass walk hop by hop (rounds 1-2), 1 restarts the hop chain just before the first search cell
- * with candidates and hands stragglers to the windowed march (the default), -1 restores the default (environment PN_SKIP_DDA).  Same results bit for
- * bit.  Takes effect for renders enqueued (or captured) afterwards, process-wide. */
+ * with candidates and hands stragglers to the windowed march, and — --cut frames — crosses the empty regions of the static background (8^3-voxel blocks of
+ * the density bitfield without an occupied voxel on any level, outside the cut box) by walking the ray's t-sequence instead of visiting their voxels (the
+ * default), -1 restores the default (environment PN_SKIP_DDA).  Same results bit for bit.  Takes effect for renders enqueued (or captured) afterwards,
+ * process-wide. */
 int pn_march_set_skip_dda(int on);
 /* Number of compute units of the current device. */
 int pn_device_cu_count(void);

@@ -169,6 +169,100 @@ __device__ __forceinline__ int cell_coord(float v, float lo, float hgs, float rh
     return (int)f;
 }
 
+// ---- --cut frames: the leading run through EMPTY REGIONS of the static background --------------------------------------------------------
+// With --cut every ray crosses the whole +-bound volume, hopping from density voxel to density voxel (raymarching.cu:1386-1431) until it meets an occupied
+// voxel of the static background or a search cell with candidates inside the cut box: ~86 hops of ~230 instructions per ray on the trex option set, and the
+// pre-pass is issue-bound on them (12 k waves; keeping the bitfield's block map in LDS so that a hop waits for no load moved nothing).  Most of that way leads
+// through space in which NOTHING can happen, and all the caller needs is an element of the ray's t-sequence that the reference's chain certainly visits
+// just before something can.  Two facts, as for the fixed-step DDA start of skip_empty_cells:
+//   * the t-sequence is grid-independent: T_{k+1} = T_k + clamp(T_k dt_gamma, dt_min, dt_max), whatever the chain visits of it — walking it costs five
+//     instructions per element where visiting one costs 230;
+//   * a REGION is one 8^3-voxel block of the top cascade level (a 64-byte line of the bitfield); its bit says "interesting": some voxel of it is occupied on
+//     ANY level that a point inside it can be tested on, or it meets the cut box (inside which the search cells decide).  A point in a region without the
+//     bit is a static-background sample in an empty voxel whatever its mip level: the chain emits nothing there.
+// region_dda walks the regions the ray crosses until the next one is interesting (crossings within 2e-3 region widths of another face also look at the
+// lateral neighbours the reference's float arithmetic could mean); the chain is then restarted at an element e whose predecessor p satisfies
+//   p < exit(p) - margin,  e >= exit(p) + margin   (exit = the chain's own voxel-exit expression at p, on p's own mip level),
+//   every element of the t-sequence within one top-level voxel diagonal before p is on p's mip level,
+// which makes e a visited element whichever element of p's voxel the chain stands on: an element v <= p whose voxel (on v's level) contains p is on p's
+// level by the second condition, so it is p's voxel, its exit is exit(p) to rounding, and the chain lands on the first element behind it: e.
+#ifndef PN_REGION_RETRY_HOPS
+#define PN_REGION_RETRY_HOPS 6   // exact hops behind a region look-ahead before the next one (a look-ahead costs about two hops)
+#endif
+struct RegionGrid {
+    const uint32_t* bits;  // LDS: bit (b2 R + b1) R + b0
+    int R;                 // regions per axis = H / 8
+    float lo, w, rw;       // -bound, region width 2 bound / R, its reciprocal
+};
+__device__ __forceinline__ bool region_set(const RegionGrid& g, int b0, int b1, int b2) {
+    const int i = (b2 * g.R + b1) * g.R + b0;
+    return ((g.bits[i >> 5] >> (i & 31)) & 1u) != 0;
+}
+// From parameter t (a point strictly inside the volume): the parameter t_stop of the last face crossed into a region without the bit before an interesting
+// region, the volume's boundary or a doubt.  Returns 0: nothing crossed (t_stop = t); 1: t_stop set (axis m_stop); 2: no interesting region before `far`.
+__device__ inline int region_dda(const RegionGrid& g, float ox, float oy, float oz, float dx, float dy, float dz, float rdx, float rdy, float rdz, float t,
+                                 float far, float* t_stop_out, int* m_stop_out) {
+    const float q0 = ((ox + t * dx) - g.lo) * g.rw, q1 = ((oy + t * dy) - g.lo) * g.rw, q2 = ((oz + t * dz) - g.lo) * g.rw;
+    const float f0 = floorf(q0), f1 = floorf(q1), f2 = floorf(q2);
+    const float e0 = q0 - f0, e1 = q1 - f1, e2 = q2 - f2;
+    int c0 = (int)f0, c1 = (int)f1, c2 = (int)f2;
+    *t_stop_out = t;
+    *m_stop_out = 0;
+    if (!(q0 >= 0.0f && q1 >= 0.0f && q2 >= 0.0f) || c0 >= g.R || c1 >= g.R || c2 >= g.R) return 0;   // (NaN fails the first test)
+    {   // the start region, and the ones a start next to a face could be taken for
+        const int l0 = e0 < 2e-3f ? -1 : (e0 > 0.998f ? 1 : 0), l1 = e1 < 2e-3f ? -1 : (e1 > 0.998f ? 1 : 0), l2 = e2 < 2e-3f ? -1 : (e2 > 0.998f ? 1 : 0);
+        for (int q = 0; q < 8; q++) {
+            if (((q & 1) && !l0) || ((q & 2) && !l1) || ((q & 4) && !l2)) continue;
+            const int y0 = c0 + ((q & 1) ? l0 : 0), y1 = c1 + ((q & 2) ? l1 : 0), y2 = c2 + ((q & 4) ? l2 : 0);
+            if (y0 < 0 || y1 < 0 || y2 < 0 || y0 >= g.R || y1 >= g.R || y2 >= g.R) return 0;
+            if (region_set(g, y0, y1, y2)) return 0;
+        }
+    }
+    const int st0 = dx > 0.0f ? 1 : -1, st1 = dy > 0.0f ? 1 : -1, st2 = dz > 0.0f ? 1 : -1;
+    const bool use0 = fabsf(dx) > 1e-6f, use1 = fabsf(dy) > 1e-6f, use2 = fabsf(dz) > 1e-6f;
+    float tf0 = use0 ? ((g.lo + (float)(c0 + (st0 > 0)) * g.w) - ox) * rdx : FLT_MAX;
+    float tf1 = use1 ? ((g.lo + (float)(c1 + (st1 > 0)) * g.w) - oy) * rdy : FLT_MAX;
+    float tf2 = use2 ? ((g.lo + (float)(c2 + (st2 > 0)) * g.w) - oz) * rdz : FLT_MAX;
+    int crossed = 0;
+    float t_stop = t;
+    int m_stop = 0;
+    for (int it = 0; it < 3 * g.R + 3; it++) {
+        const int m = (tf0 <= tf1 && tf0 <= tf2) ? 0 : (tf1 <= tf2 ? 1 : 2);
+        const float tx = m == 0 ? tf0 : (m == 1 ? tf1 : tf2);
+        if (!(tx < far)) { *t_stop_out = t_stop; *m_stop_out = m_stop; return 2; }
+        const float fr0 = ((ox + tx * dx) - g.lo) * g.rw - (float)c0, fr1 = ((oy + tx * dy) - g.lo) * g.rw - (float)c1, fr2 = ((oz + tx * dz) - g.lo) * g.rw - (float)c2;
+        const bool ok0 = m == 0 || (fr0 >= 2e-3f && fr0 <= 0.998f), ok1 = m == 1 || (fr1 >= 2e-3f && fr1 <= 0.998f), ok2 = m == 2 || (fr2 >= 2e-3f && fr2 <= 0.998f);
+        const bool unsafe = !(ok0 && ok1 && ok2) || !(tx > t_stop);
+        const int n0 = c0 + (m == 0 ? st0 : 0), n1 = c1 + (m == 1 ? st1 : 0), n2 = c2 + (m == 2 ? st2 : 0);
+        const bool behind = !(tx > t_stop - 1e-6f * fmaxf(1.0f, fabsf(tx)));   // a face clearly BEHIND the last one: not a rounding matter
+        if (tx > t_stop) { t_stop = tx; m_stop = m; }
+        if (n0 < 0 || n1 < 0 || n2 < 0 || n0 >= g.R || n1 >= g.R || n2 >= g.R) break;   // the volume's boundary: points beyond are clamped onto it
+        if (region_set(g, n0, n1, n2)) break;
+        if (unsafe) {
+            const int l0 = (m == 0 || ok0) ? 0 : (fr0 < 0.5f ? -1 : 1), l1 = (m == 1 || ok1) ? 0 : (fr1 < 0.5f ? -1 : 1), l2 = (m == 2 || ok2) ? 0 : (fr2 < 0.5f ? -1 : 1);
+            bool blocked = behind;
+            for (int q = 1; q < 8 && !blocked; q++) {
+                if (((q & 1) && !l0) || ((q & 2) && !l1) || ((q & 4) && !l2)) continue;
+                const int s0 = (q & 1) ? l0 : 0, s1 = (q & 2) ? l1 : 0, s2 = (q & 4) ? l2 : 0;
+                for (int side = 0; side < 2; side++) {
+                    const int y0 = (side ? n0 : c0) + s0, y1 = (side ? n1 : c1) + s1, y2 = (side ? n2 : c2) + s2;
+                    if (y0 < 0 || y1 < 0 || y2 < 0 || y0 >= g.R || y1 >= g.R || y2 >= g.R) { blocked = true; break; }
+                    if (region_set(g, y0, y1, y2)) { blocked = true; break; }
+                }
+            }
+            if (blocked) break;
+        }
+        c0 = n0; c1 = n1; c2 = n2;
+        if (m == 0) tf0 = ((g.lo + (float)(c0 + (st0 > 0)) * g.w) - ox) * rdx;
+        else if (m == 1) tf1 = ((g.lo + (float)(c1 + (st1 > 0)) * g.w) - oy) * rdy;
+        else tf2 = ((g.lo + (float)(c2 + (st2 > 0)) * g.w) - oz) * rdz;
+        crossed++;
+    }
+    *t_stop_out = t_stop;
+    *m_stop_out = m_stop;
+    return crossed >= 1 ? 1 : 0;
+}
+
 // Leading run of marching iterations that can neither emit nor warp, ONE lane per ray: search cells whose 27-neighbourhood holds no IP
 // and, in --cut mode, static-background points (outside the cut box) in empty density voxels.  In --cut mode every ray crosses the
 // whole +-bound volume, so without this pre-pass all of those iterations went through the 8-lane / wave-per-ray kernels
@@ -203,7 +297,7 @@ __device__ __forceinline__ int cell_coord(float v, float lo, float hgs, float rh
 // it behind.  Bit-identical by construction; the march tests compare every ray with the oracle and with the reference's own kernel.
 __device__ inline float skip_empty_cells(const MarchParams& a, const March2Tables& tb, int index, float noise, unsigned* n_iter_out,
                                          const uint32_t* cell_bits = nullptr, float far_override = -1.0f, const uint32_t* cell_bits2 = nullptr,
-                                         int hop_budget = 0) {
+                                         int hop_budget = 0, const uint32_t* grid_regions = nullptr) {
     const Float3 o = *reinterpret_cast<const Float3*>(a.rays_o + (size_t)index * 3), d = *reinterpret_cast<const Float3*>(a.rays_d + (size_t)index * 3);
     const float ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
     const uint32_t H = a.H, C = a.C;
@@ -388,11 +482,76 @@ __device__ inline float skip_empty_cells(const MarchParams& a, const March2Table
         *n_iter_out = n_iter;
         return t;
     }
+    // --cut with the region map (see region_dda): skip the empty regions in front of the first interesting one.  Levels: bound == 2^(C - 1) (the caller checked),
+    // so level l's voxels are 2^(l + 1) / H wide and a region is 8^3 voxels of level C - 1.
+    const bool regions_on = cut && grid_regions != nullptr;
+    RegionGrid rg{grid_regions, (int)(H / 8), -a.bound, 16.0f * a.bound * rH, (float)H / (16.0f * a.bound)};
+    const float rnorm = __builtin_amdgcn_rsqf(dx * dx + dy * dy + dz * dz);
+    const float w_t = 1.7320508f * 2.0f * a.bound * rH * rnorm * 1.02f;   // one top-level voxel diagonal in units of t (+ 2 %)
+    int hops_since_try = 0, retry_hops = PN_REGION_RETRY_HOPS;
+    bool try_regions = regions_on && w_t > 0.0f && w_t < 1e3f;
 #if PN_DBG_SKIP_HOPS  // timing experiment: at most this many hops per ray (results invalid)
     while (t < far && n_iter < PN_DBG_SKIP_HOPS) {
 #else
     while (t < far) {
 #endif
+        if (try_regions) {
+            try_regions = false;
+            hops_since_try = 0;
+            const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
+            if (fabsf(px) < a.bound && fabsf(py) < a.bound && fabsf(pz) < a.bound) {   // strictly inside: the clamp of the sample position is the identity
+                float t_stop;
+                int m_stop;
+                const int kind = region_dda(rg, ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, t, far, &t_stop, &m_stop);
+                if (kind == 2) { *n_iter_out = n_iter; return far; }   // nothing interesting before `far`: the chain walks there and emits nothing
+                const float rd_stop = fabsf(m_stop == 0 ? rdx : (m_stop == 1 ? rdy : rdz));
+                const float m_face = 2e-4f * fmaxf(1.0f, fabsf(t_stop)) + 1e-5f * fminf(rd_stop, 1e3f);
+                const float target = t_stop - m_face;
+                // the zone in front of `target` in which the restart pair is looked for: a voxel diagonal of same-level elements behind p, then p and e
+                const float zone_len = 1.1f * w_t + 3.0f * clampf(target * a.dt_gamma, dt_min, dt_max);
+                if (kind == 1 && rd_stop < 1e3f && target - zone_len - w_t > t) {
+                    // walk the t-sequence (the chain's own step expression) to the zone [target - zone_len, target), then look for the LAST pair (p, e) of consecutive
+                    // elements in it that restarts the chain (conditions above)
+                    float T = t;
+                    const float zone = target - zone_len;
+                    while (true) {
+                        const float Tn = T + clampf(T * a.dt_gamma, dt_min, dt_max);
+                        if (!(Tn < zone)) break;
+                        T = Tn;
+                    }
+                    float best = -1.0f, run_start = FLT_MAX;
+                    int run_level = -1;
+                    for (int it = 0; it < 512; it++) {   // (w_t / dt_min elements at most: a few dozen)
+                        const float pT = T, eT = T + clampf(T * a.dt_gamma, dt_min, dt_max);
+                        if (!(eT < target)) break;
+                        const float x = clampf(ox + pT * dx, lo0, hi0), y = clampf(oy + pT * dy, lo1, hi1), z = clampf(oz + pT * dz, lo2, hi2);
+                        const float dtp = clampf(pT * a.dt_gamma, dt_min, dt_max);
+                        const int level = one_cascade ? 0 : max(mip_from_pos(x, y, z, (float)C), mip_from_dt(dtp, (float)H, (float)C));
+                        if (level != run_level) { run_level = level; run_start = pT; }
+                        if (run_start <= pT - w_t) {
+                            const float pw = scalbnf(1.0f, level);
+                            const bool use_pw = pw <= a.bound;
+                            const float mip_bound = use_pw ? pw : a.bound;
+                            const float mip_rbound = use_pw ? scalbnf(1.0f, -level) : rbound;
+                            const int nx = (int)clampf((x * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
+                            const int ny = (int)clampf((y * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
+                            const int nz = (int)clampf((z * mip_rbound + 1) * halfH, 0.0f, (float)(H - 1));
+                            const float ux = ((((float)nx + sx) * rH * 2 - 1) * mip_bound - x) * rdx;
+                            const float uy = ((((float)ny + sy) * rH * 2 - 1) * mip_bound - y) * rdy;
+                            const float uz = ((((float)nz + sz) * rH * 2 - 1) * mip_bound - z) * rdz;
+                            const float um = fminf(ux, fminf(uy, uz));
+                            const float rd_min = fabsf(um == ux ? rdx : (um == uy ? rdy : rdz));
+                            const float m_vox = 3e-5f * fmaxf(1.0f, fabsf(pT)) + 2e-6f * rd_min;
+                            const float ttp = pT + fmaxf(0.0f, um);
+                            if (rd_min < 1e3f && pT < ttp - m_vox && eT >= ttp + m_vox && eT < far) best = eT;
+                        }
+                        T = eT;
+                    }
+                    if (best > t) t = best;   // a visited element, in a region without the bit: the exact hops go on from here
+                    else retry_hops *= 4;     // (no pair: a mip level change or a grazing ray — do not pay for the same look-ahead every few hops)
+                }
+            }
+        }
         const float x = clampf(ox + t * dx, lo0, hi0);
         const float y = clampf(oy + t * dy, lo1, hi1);
         const float z = clampf(oz + t * dz, lo2, hi2);
@@ -427,6 +586,7 @@ __device__ inline float skip_empty_cells(const MarchParams& a, const March2Table
             if (a.grid[vox / 8] & (1 << (vox % 8))) break;
         }
         n_iter++;
+        if (regions_on && ++hops_since_try >= retry_hops) try_regions = true;   // past an interesting region without an event: look ahead again
         // (n + 0.5f + 0.5f * sign) == n + (0.5f + 0.5f * sign): n is an integer below 2^23 and the addend 0, 0.5 or 1 — both sums are exact
         const float tx = ((((float)nx + sx) * rH * 2 - 1) * mip_bound - x) * rdx;
         const float ty = ((((float)ny + sy) * rH * 2 - 1) * mip_bound - y) * rdy;

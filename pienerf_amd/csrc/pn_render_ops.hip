@@ -531,6 +531,10 @@ struct MarchIO {
     uint32_t group_rays;
     int lane_per_ray;           // k_march: one lane per ray instead of eight (the throughput form of a frame's first trip)
     int dda_start, hop_budget;  // k_march_skip: restart the hop chain just before the first cell with candidates; hops before a ray is handed on (pn_march_window.h)
+    // optional (--cut frames): the region map of pn_march_window.h (region_dda) — one bit per 8^3-voxel block of the top cascade level, set when a point of
+    // the region can meet an occupied voxel on any level or the cut box (k_frame_prologue); k_march_skip keeps it in LDS
+    const uint32_t* grid_regions;
+    int grid_regions_words;
 };
 
 // Append lists are SEGMENTED: PN_SEGS independent (counter, region) pairs, every counter on a cache line of its own, the producer picking
@@ -571,6 +575,13 @@ __global__ void __launch_bounds__(256) k_march_skip(pnm::MarchParams a, pnm2::Ma
         }
         __syncthreads();
     }
+    const uint32_t* grid_regions = nullptr;
+    if (io.grid_regions_words > 0) {  // uniform; behind the cell maps (the launch's dynamic LDS counts it in)
+        uint32_t* gb = bits_lds + (io.cell_bits_words > 0 ? io.cell_bits_words * ((io.cell_bits2 && io.fars_eff && !a.cut) ? 2 : 1) : 0);
+        for (int w = threadIdx.x; w < io.grid_regions_words; w += blockDim.x) gb[w] = io.grid_regions[w];
+        grid_regions = gb;
+        __syncthreads();
+    }
     bool work = false;
     if (n < n_alive) {
         unsigned n_iter = 0;
@@ -586,7 +597,7 @@ __global__ void __launch_bounds__(256) k_march_skip(pnm::MarchParams a, pnm2::Ma
             io.fars_eff[index] = far;
         }
         const float t = pnm3::skip_empty_cells(a, tb, index, io.noises ? io.noises[n] : 0.0f, &n_iter, cell_bits, cell_bits2 ? far : -1.0f,
-                                               io.dda_start ? cell_bits2 : nullptr, io.dda_start && cell_bits2 ? io.hop_budget : 0);
+                                               io.dda_start ? cell_bits2 : nullptr, io.dda_start && cell_bits2 ? io.hop_budget : 0, grid_regions);
         io.t_resume[n] = t;
         if (!PN_DBG_PHASES_ON && a.stats && n_iter) atomicAdd(a.stats, (unsigned long long)n_iter);
         work = t < far;
@@ -1546,6 +1557,7 @@ struct pn_frame {
     uint32_t seg_cap;
     uint32_t* cell_bits;  // [2][(max_cells + 31) / 32] bit c: search cell c has candidates / is within one cell of such a cell (cleared by
                           // k_frame_tables, set by k_frame_lists)
+    uint32_t* grid_regions;  // [PN_GRID_REGION_WORDS] --cut frames: the region map of the skip pre-pass (MarchIO::grid_regions; k_frame_prologue)
     float* fars_eff;      // [max_rays] the rays' ends shortened to where they can still find candidates (k_march_skip)
     int* seg_counters;  // [6][PN_SEGS] counters, one per 128 B: tail | sample | emitted | tail cursor | tail back (cleared by each trip's compaction) | active (k_frame_rays)
     int* tail_counts;   // [PN_MAX_TRIPS + 2] diagnostics: rays each trip handed to the tail pass
@@ -1795,7 +1807,10 @@ struct FramePrologue {
     uint32_t tile_w, tile_lw;  // tile_w > 0: alive list starts in 16 x 4 pixel tile order (pn_render_opts.ray_tile_w, validated by the host)
     // early_finish: the frame's epilogue is left to the fused launch (pn_trips_fused.h: finalize) — every ray gets the pixel of a ray without samples here
     int early_finish; float bg; float* image_out; float* depth_out;
+    // --cut frames: the region map (MarchIO::grid_regions): gr_blocks workgroups, a lane per region of the (H / 8)^3 grid
+    const uint8_t* grid; uint32_t* grid_regions; int gr_blocks; int gr_R; int gr_C; uint32_t gr_H; float gr_bound; const float* cut_bounds;
 };
+#define PN_GRID_REGION_WORDS 1024  // 32 768 regions: H <= 256
 
 __device__ __forceinline__ void frame_lists_block(const FramePrologue& a) {
     extern __shared__ uint32_t lds_bits[];  // [2][lds_words] when lds_words > 0
@@ -1972,7 +1987,44 @@ __global__ void __launch_bounds__(256) k_frame_prologue(FramePrologue a) {
         if (ip < a.n_vtx) a.rec[t] = pnm2::pack_ip_float(j, ip, a.p_ori, a.p_def, a.F_IP, a.dF_IP);
         return;
     }
-    frame_rays_block(a, (uint32_t)(b - a.list_blocks - a.pack_blocks));
+    if (b < a.list_blocks + a.pack_blocks + a.gr_blocks) {  // region map of the density bitfield (pn_march_window.h: region_dda)
+        const int R = a.gr_R, n_reg = R * R * R;
+        const int r = threadIdx.x + (b - a.list_blocks - a.pack_blocks) * 256;
+        bool any = false;
+        if (r < n_reg) {
+            const int b0 = r % R, b1 = (r / R) % R, b2 = r / (R * R);
+            const uint32_t lines_per_level = (a.gr_H * a.gr_H * a.gr_H) >> 9;
+            const uint4* g4 = reinterpret_cast<const uint4*>(a.grid);
+            uint32_t acc = 0;
+            for (int l = 0; l < a.gr_C; l++) {
+                // on level l (R blocks over +-2^l) the region is the aligned cube of 2^j blocks per axis at R / 2 + (b - R / 2) 2^j, j = C - 1 - l — contiguous
+                // lines in morton order — or lies outside the level's volume, where no point can be tested on it
+                const int j = a.gr_C - 1 - l, side = 1 << j;
+                const int c0 = R / 2 + (b0 - R / 2) * side, c1 = R / 2 + (b1 - R / 2) * side, c2 = R / 2 + (b2 - R / 2) * side;
+                if (c0 < 0 || c1 < 0 || c2 < 0 || c0 + side > R || c1 + side > R || c2 + side > R) continue;
+                const uint32_t first = (uint32_t)l * lines_per_level + pnm2::morton3D((uint32_t)c0, (uint32_t)c1, (uint32_t)c2);
+                const uint32_t n_lines = 1u << (3 * j);
+                for (uint32_t q = 0; q < n_lines * 4; q++) {
+                    const uint4 v = g4[(size_t)first * 4 + q];
+                    acc |= v.x | v.y | v.z | v.w;
+                }
+            }
+            any = acc != 0u;
+            // ... or it meets the cut box: x in (cb0, cb1), y > cb2, z in (cb4, cb5) — a superset of the reference's test (raymarching.cu:1210 compares x with
+            // cut_bounds[3] where y is meant), widened by a hundredth of a region
+            const float w = 2.0f * a.gr_bound / (float)R, eps = 0.01f * w;
+            const float x0 = -a.gr_bound + (float)b0 * w, y0 = -a.gr_bound + (float)b1 * w, z0 = -a.gr_bound + (float)b2 * w;
+            const float* cb = a.cut_bounds;
+            if (x0 + w > cb[0] - eps && x0 < cb[1] + eps && y0 + w > cb[2] - eps && z0 + w > cb[4] - eps && z0 < cb[5] + eps) any = true;
+        }
+        const unsigned long long m = __ballot(any);
+        if ((threadIdx.x & 63) == 0 && r < n_reg) {   // (R^3 is a multiple of 64: whole words only)
+            a.grid_regions[r >> 5] = (uint32_t)m;
+            a.grid_regions[(r >> 5) + 1] = (uint32_t)(m >> 32);
+        }
+        return;
+    }
+    frame_rays_block(a, (uint32_t)(b - a.list_blocks - a.pack_blocks - a.gr_blocks));
 }
 
 extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_vtx, uint32_t max_grid_cells) {
@@ -2015,6 +2067,7 @@ extern "C" int pn_frame_create(pn_frame** out, uint32_t max_rays, uint32_t max_v
     PN_ALLOC(f->seg_counters, (size_t)6 * PN_SEGS * PN_SEG_STRIDE * 4);
     PN_ALLOC(f->cell_bits, 2 * (((size_t)max_grid_cells + 31) / 32) * 4);
     PN_ALLOC(f->fars_eff, N * 4);
+    PN_ALLOC(f->grid_regions, (size_t)PN_GRID_REGION_WORDS * 4);
     PN_ALLOC(f->trips, sizeof(PnTrip) * (PN_MAX_TRIPS + 2)); PN_ALLOC(f->dev, sizeof(PnFrameDev)); PN_ALLOC(f->cut_bounds, 6 * 4);
     f->max_groups = pn_div_up(max_rays, PN_MIN_RAY_BATCH) + 1;
     PN_ALLOC(f->groups, sizeof(PnGroup) * 2 * f->max_groups); PN_ALLOC(f->group_cnt, sizeof(int) * f->max_groups);
@@ -2034,7 +2087,7 @@ extern "C" void pn_frame_destroy(pn_frame* f) {
     void* ptrs[] = {f->acc_image, f->nears, f->fars, f->rays_t, f->xyzs, f->dirs, f->deltas, f->sigmas, f->rgbs, f->alive_a, f->alive_b, f->list,
                     f->chunk_counts, f->pig_cnt, f->pig_bgn, f->pig_cursor, f->pig_idx, f->trips, f->dev, f->cut_bounds,
                     f->side.nb_rng, f->side.nb, f->side.rec, f->march_counters, f->tail, f->tail_counts, f->stamps,
-                    f->list_seg, f->active_seg, f->seg_counters, f->cell_bits, f->fars_eff, f->groups, f->group_cnt, f->fused_ctl, f->fused_clocks, f->t_resume, f->blist, f->strag};
+                    f->list_seg, f->active_seg, f->seg_counters, f->cell_bits, f->fars_eff, f->grid_regions, f->groups, f->group_cnt, f->fused_ctl, f->fused_clocks, f->t_resume, f->blist, f->strag};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int t = 0; t < PN_TIMED_TRIPS; t++)
         for (int e = 0; e < 3; e++) if (f->ev[t][e]) (void)hipEventDestroy(f->ev[t][e]);
@@ -2101,7 +2154,15 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     const size_t bit_words = (f->max_cells + 31) / 32;
     const bool short_rays = !is_static && !o->cut && bit_words * 8 <= 48 * 1024;  // both maps in LDS: rays end where their candidates end
     const int skip_bits_words = (short_rays || bit_words * 4 <= 48 * 1024) ? (int)bit_words : 0;
-    const size_t skip_lds = (size_t)skip_bits_words * 4 * (short_rays ? 2 : 1);
+    // --cut: the region map for the skip pre-pass (MarchIO::grid_regions; pn_march_window.h: region_dda) where its assumptions hold: the top cascade level
+    // spans exactly +-bound (bound == 2^(C - 1)), regions are whole 64-byte lines of the bitfield and nest on every level, the map fits
+    static const bool grid_regions_off = pn_env_u32("PN_GRID_REGIONS_OFF", 0) != 0;   // A/B runs: same frames, bit for bit
+    const uint32_t reg_R = o->grid_size / 8;
+    const bool reg_ok = !is_static && o->cut && !grid_regions_off && dda_start && bitfield && o->grid_size % 32 == 0 && o->cascade >= 1 && o->cascade <= 3 &&
+                        o->bound == (float)(1u << (o->cascade - 1)) && (reg_R / 2) % (1u << (o->cascade - 1)) == 0 &&
+                        (uint64_t)reg_R * reg_R * reg_R / 32 <= PN_GRID_REGION_WORDS && ((uintptr_t)bitfield & 15) == 0;
+    const int grid_region_words = reg_ok ? (int)((uint64_t)reg_R * reg_R * reg_R / 32) : 0;
+    const size_t skip_lds = (size_t)skip_bits_words * 4 * (short_rays ? 2 : 1) + (size_t)grid_region_words * 4;
 
     if (!f->cut_bounds_valid || memcmp(f->cut_bounds_host, o->cut_bounds, sizeof(f->cut_bounds_host)) != 0) {  // uploaded only when it changes
         memcpy(f->cut_bounds_host, o->cut_bounds, sizeof(f->cut_bounds_host));
@@ -2186,7 +2247,11 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     // both cell maps of a workgroup in LDS while it builds its lists (up to 64 KB = 262 k cells; beyond that straight to global memory, where
     // the maps then span enough cache lines for the atomics not to queue)
     fp.lds_words = (fp.list_blocks > 0 && bit_words * 8 <= 64 * 1024) ? (int)bit_words : 0;
-    k_frame_prologue<<<(uint32_t)(fp.list_blocks + fp.pack_blocks) + nblk, 256, (size_t)fp.lds_words * 8, st>>>(fp);
+    if (grid_region_words > 0) {
+        fp.grid = bitfield; fp.grid_regions = f->grid_regions; fp.gr_R = (int)(o->grid_size / 8); fp.gr_C = (int)o->cascade; fp.gr_H = o->grid_size;
+        fp.gr_bound = o->bound; fp.cut_bounds = f->cut_bounds; fp.gr_blocks = (int)pn_div_up((uint64_t)grid_region_words * 32, 256);
+    }
+    k_frame_prologue<<<(uint32_t)(fp.list_blocks + fp.pack_blocks + fp.gr_blocks) + nblk, 256, (size_t)fp.lds_words * 8, st>>>(fp);
     PN_LAUNCH_CHECK();
     }
     pnm2::March2Tables tb{f->side.nb_rng, f->side.nb, (const float4*)f->side.rec};
@@ -2256,7 +2321,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                        (int)f->seg_cap, f->list_seg, seg_samp, (int)f->seg_cap, seg_emit, f->cell_bits, skip_bits_words,
                        short_rays ? f->cell_bits + bit_words : nullptr, short_rays ? f->fars_eff : nullptr,
                        group_rays ? f->groups + (size_t)(tt & 1) * f->max_groups : nullptr, group_rays, lpr ? 1 : 0, dda_start,
-                       (int)skip_hop_budget};
+                       (int)skip_hop_budget, grid_region_words > 0 ? f->grid_regions : nullptr, grid_region_words};
     };
     while (!done && t < PN_MAX_TRIPS) {
         const bool whole = whole_try;

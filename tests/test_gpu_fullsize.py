@@ -156,6 +156,41 @@ def test_strided_subset_of_the_full_frame_matches_the_oracle(full):
     assert ws.min() >= 0.0 and ws.max() <= 1.0 + 1e-5 and np.abs(ws - ref["weights_sum"]).max() < 1e-4
 
 
+def test_full_trex_frame_independent_of_the_skip_pre_pass_form():
+    """BASELINE configs[2] as bench.py builds it (1008 x 756, bound 2 with two cascades, --cut, dt_gamma 1 / 128, static background in 2 % of the density
+    blocks, deformed by 12 substeps under the bench's force): the frame with the skip pre-pass crossing the static background's empty regions on the
+    ray's t-sequence (pn_march_window.h: region_dda, the default) and visiting them voxel by voxel (pn_march_set_skip_dda(0)) — the same trip records,
+    the same number of marched samples, the same pixels bit for bit; from three camera poses (rays along different axes, grazing the volume's faces)."""
+    from pienerf_amd._lib import check, lib
+    from pienerf_amd.harness import SimRenderHarness
+    opt = scene.trex_opt(radius=4.5)
+    cloud = scene.make_chair_points(hgs=opt["hash_grid_size"], bound=opt["bound"])
+    ckpt = scene.make_checkpoint(bound=2.0, seed=3)
+    blobs = np.repeat(np.random.default_rng(5).random(len(ckpt["density_bitfield"]) // 64) < 0.02, 64)
+    ckpt["density_bitfield"] = ckpt["density_bitfield"] | np.where(blobs, 0xFF, 0).astype(np.uint8)
+    h = SimRenderHarness(opt, cloud=cloud, ckpt=ckpt, device=DEV, overlap_sim=False)
+    h.sim.update_force(h.sim.n_IP // 2, np.array([250.0, 120.0, -180.0]))
+    for _ in range(12):
+        h.sim.stepforward()
+    try:
+        for pose in (scene.orbit_pose(4.5, 25.0, -10.0), scene.orbit_pose(3.0, 90.0, 0.0), scene.orbit_pose(6.0, -45.0, 35.0)):
+            h.pose = pose
+            res = []
+            with torch.no_grad():
+                for on in (0, 1):
+                    check(lib().pn_march_set_skip_dda(on), "set_skip_dda")
+                    out = h.step(simulate=False, collect_stats=True)
+                    torch.cuda.synchronize()
+                    res.append((dict(h.model.last_stats), h.model.trip_records(), {k: out[k].clone() for k in ("image", "depth", "depth_0")}))
+            (s0, r0, o0), (s1, r1, o1) = res
+            assert s0["samples"] == s1["samples"] > 100000 and s0["trips"] == s1["trips"] and s0["err"] == s1["err"] == 0, (s0, s1)
+            assert [r[:5] for r in r0] == [r[:5] for r in r1]
+            for k in o0:
+                assert torch.equal(torch.nan_to_num(o0[k], nan=-1.0), torch.nan_to_num(o1[k], nan=-1.0)), k
+    finally:
+        check(lib().pn_march_set_skip_dda(-1), "set_skip_dda")
+
+
 def test_full_size_substeps_match_the_oracle(full):
     """Three substeps of the 139-kernel / 3 576-IP system against the fp64 oracle (fresh simulators, same load)."""
     from pienerf_amd.harness import SimRenderHarness
