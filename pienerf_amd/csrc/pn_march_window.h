@@ -187,7 +187,7 @@ __device__ __forceinline__ int cell_coord(float v, float lo, float hgs, float rh
 // which makes e a visited element whichever element of p's voxel the chain stands on: an element v <= p whose voxel (on v's level) contains p is on p's
 // level by the second condition, so it is p's voxel, its exit is exit(p) to rounding, and the chain lands on the first element behind it: e.
 #ifndef PN_REGION_RETRY_HOPS
-#define PN_REGION_RETRY_HOPS 6   // exact hops behind a region look-ahead before the next one (a look-ahead costs about two hops)
+#define PN_REGION_RETRY_HOPS 6   // exact hops behind a region look-ahead before the next one (measured alone on trex: 2 / 6 / 10 / 16 / 24 hops -> 201 / 175 / 178 / 185 / 205 us; hop by hop 285)
 #endif
 struct RegionGrid {
     const uint32_t* bits;  // LDS: bit (b2 R + b1) R + b0
@@ -204,16 +204,17 @@ __device__ inline int region_dda(const RegionGrid& g, float ox, float oy, float 
                                  float far, float* t_stop_out, int* m_stop_out) {
     const float q0 = ((ox + t * dx) - g.lo) * g.rw, q1 = ((oy + t * dy) - g.lo) * g.rw, q2 = ((oz + t * dz) - g.lo) * g.rw;
     const float f0 = floorf(q0), f1 = floorf(q1), f2 = floorf(q2);
-    const float e0 = q0 - f0, e1 = q1 - f1, e2 = q2 - f2;
     int c0 = (int)f0, c1 = (int)f1, c2 = (int)f2;
     *t_stop_out = t;
     *m_stop_out = 0;
     if (!(q0 >= 0.0f && q1 >= 0.0f && q2 >= 0.0f) || c0 >= g.R || c1 >= g.R || c2 >= g.R) return 0;   // (NaN fails the first test)
-    {   // the start region, and the ones a start next to a face could be taken for
-        const int l0 = e0 < 2e-3f ? -1 : (e0 > 0.998f ? 1 : 0), l1 = e1 < 2e-3f ? -1 : (e1 > 0.998f ? 1 : 0), l2 = e2 < 2e-3f ? -1 : (e2 > 0.998f ? 1 : 0);
-        for (int q = 0; q < 8; q++) {
-            if (((q & 1) && !l0) || ((q & 2) && !l1) || ((q & 4) && !l2)) continue;
-            const int y0 = c0 + ((q & 1) ? l0 : 0), y1 = c1 + ((q & 2) ? l1 : 0), y2 = c2 + ((q & 4) ? l2 : 0);
+    if (region_set(g, c0, c1, c2)) return 0;   // the common early exit: inside an interesting region
+    const float e0 = q0 - f0, e1 = q1 - f1, e2 = q2 - f2;
+    const int s_l0 = e0 < 2e-3f ? -1 : (e0 > 0.998f ? 1 : 0), s_l1 = e1 < 2e-3f ? -1 : (e1 > 0.998f ? 1 : 0), s_l2 = e2 < 2e-3f ? -1 : (e2 > 0.998f ? 1 : 0);
+    if (s_l0 | s_l1 | s_l2) {   // a start next to a face: the regions it could be taken for
+        for (int q = 1; q < 8; q++) {
+            if (((q & 1) && !s_l0) || ((q & 2) && !s_l1) || ((q & 4) && !s_l2)) continue;
+            const int y0 = c0 + ((q & 1) ? s_l0 : 0), y1 = c1 + ((q & 2) ? s_l1 : 0), y2 = c2 + ((q & 4) ? s_l2 : 0);
             if (y0 < 0 || y1 < 0 || y2 < 0 || y0 >= g.R || y1 >= g.R || y2 >= g.R) return 0;
             if (region_set(g, y0, y1, y2)) return 0;
         }
@@ -223,6 +224,10 @@ __device__ inline int region_dda(const RegionGrid& g, float ox, float oy, float 
     float tf0 = use0 ? ((g.lo + (float)(c0 + (st0 > 0)) * g.w) - ox) * rdx : FLT_MAX;
     float tf1 = use1 ? ((g.lo + (float)(c1 + (st1 > 0)) * g.w) - oy) * rdy : FLT_MAX;
     float tf2 = use2 ? ((g.lo + (float)(c2 + (st2 > 0)) * g.w) - oz) * rdz : FLT_MAX;
+    // where a crossing lies between the faces of another axis, from the face parameters alone: u = (tf_axis - tx) |d_axis| / w is the way left to that
+    // axis's next face in region widths (0: on it, 1: on the one behind).  An axis the ray runs along keeps its start position between its faces.
+    const float k0 = fabsf(dx) * g.rw, k1 = fabsf(dy) * g.rw, k2 = fabsf(dz) * g.rw;
+    const float u_fix0 = st0 > 0 ? 1.0f - e0 : e0, u_fix1 = st1 > 0 ? 1.0f - e1 : e1, u_fix2 = st2 > 0 ? 1.0f - e2 : e2;
     int crossed = 0;
     float t_stop = t;
     int m_stop = 0;
@@ -230,8 +235,8 @@ __device__ inline int region_dda(const RegionGrid& g, float ox, float oy, float 
         const int m = (tf0 <= tf1 && tf0 <= tf2) ? 0 : (tf1 <= tf2 ? 1 : 2);
         const float tx = m == 0 ? tf0 : (m == 1 ? tf1 : tf2);
         if (!(tx < far)) { *t_stop_out = t_stop; *m_stop_out = m_stop; return 2; }
-        const float fr0 = ((ox + tx * dx) - g.lo) * g.rw - (float)c0, fr1 = ((oy + tx * dy) - g.lo) * g.rw - (float)c1, fr2 = ((oz + tx * dz) - g.lo) * g.rw - (float)c2;
-        const bool ok0 = m == 0 || (fr0 >= 2e-3f && fr0 <= 0.998f), ok1 = m == 1 || (fr1 >= 2e-3f && fr1 <= 0.998f), ok2 = m == 2 || (fr2 >= 2e-3f && fr2 <= 0.998f);
+        const float u0 = use0 ? (tf0 - tx) * k0 : u_fix0, u1 = use1 ? (tf1 - tx) * k1 : u_fix1, u2 = use2 ? (tf2 - tx) * k2 : u_fix2;
+        const bool ok0 = m == 0 || (u0 >= 2e-3f && u0 <= 0.998f), ok1 = m == 1 || (u1 >= 2e-3f && u1 <= 0.998f), ok2 = m == 2 || (u2 >= 2e-3f && u2 <= 0.998f);
         const bool unsafe = !(ok0 && ok1 && ok2) || !(tx > t_stop);
         const int n0 = c0 + (m == 0 ? st0 : 0), n1 = c1 + (m == 1 ? st1 : 0), n2 = c2 + (m == 2 ? st2 : 0);
         const bool behind = !(tx > t_stop - 1e-6f * fmaxf(1.0f, fabsf(tx)));   // a face clearly BEHIND the last one: not a rounding matter
@@ -239,7 +244,8 @@ __device__ inline int region_dda(const RegionGrid& g, float ox, float oy, float 
         if (n0 < 0 || n1 < 0 || n2 < 0 || n0 >= g.R || n1 >= g.R || n2 >= g.R) break;   // the volume's boundary: points beyond are clamped onto it
         if (region_set(g, n0, n1, n2)) break;
         if (unsafe) {
-            const int l0 = (m == 0 || ok0) ? 0 : (fr0 < 0.5f ? -1 : 1), l1 = (m == 1 || ok1) ? 0 : (fr1 < 0.5f ? -1 : 1), l2 = (m == 2 || ok2) ? 0 : (fr2 < 0.5f ? -1 : 1);
+            // towards the face the crossing is close to: the next one (u small: in the ray's direction) or the one behind (u near 1)
+            const int l0 = (m == 0 || ok0) ? 0 : (u0 < 0.5f ? st0 : -st0), l1 = (m == 1 || ok1) ? 0 : (u1 < 0.5f ? st1 : -st1), l2 = (m == 2 || ok2) ? 0 : (u2 < 0.5f ? st2 : -st2);
             bool blocked = behind;
             for (int q = 1; q < 8 && !blocked; q++) {
                 if (((q & 1) && !l0) || ((q & 2) && !l1) || ((q & 4) && !l2)) continue;
@@ -548,7 +554,7 @@ __device__ inline float skip_empty_cells(const MarchParams& a, const March2Table
                         T = eT;
                     }
                     if (best > t) t = best;   // a visited element, in a region without the bit: the exact hops go on from here
-                    else retry_hops *= 4;     // (no pair: a mip level change or a grazing ray — do not pay for the same look-ahead every few hops)
+                    else retry_hops = min(retry_hops * 4, 64);   // (no pair: a mip level change or a grazing ray — do not pay for the same look-ahead every few hops)
                 }
             }
         }
