@@ -144,6 +144,9 @@ def collect_samples(m, rays_o, rays_d, kw):
     return x[keep].contiguous(), d[keep].contiguous()
 
 
+TRAFFIC_INSTANCES = {}
+
+
 def load_traffic(real_trips, config="chair"):
     """HBM-side bytes per launch from the committed PMC passes of THIS workload — only when they were taken on THIS code (profiles/pmc_traffic*.json
     are stamped with pienerf_amd.build.source_hash by tools/pmc_traffic.py); a stale file gives null, never a number that belongs to other kernels."""
@@ -159,6 +162,8 @@ def load_traffic(real_trips, config="chair"):
     out = {}
     for k, v in pmc["kernels"].items():
         out[k.split("<")[0]] = out.get(k.split("<")[0], 0) + v["fetch_bytes_per_frame"] + v["write_bytes_per_frame"]
+        if "<" in k and v["fetch_bytes_per_frame"] + v["write_bytes_per_frame"] > 0:
+            TRAFFIC_INSTANCES.setdefault(k.split("<")[0], k)   # the template instance the passes saw (checked against the timed launch's)
     per_launch = {k: int(v / max(real_trips, 1)) for k, v in out.items()}
     if all(k in out for k in ("k_march", "k_march_tail", "k_march_skip")):
         per_launch["march_group"] = int((out["k_march"] + out["k_march_tail"] + out["k_march_skip"]) / max(real_trips, 1))
@@ -295,8 +300,17 @@ def kernel_report(h, opt, dev, form_kw=None, graph_ms=None):
         head_march_graph = float(np.sum(g_march[:ff])) if (g_march is not None and ff >= 1) else None
         head_bytes = march_bytes(head, N + int(sum(r[0] for r in recs[1:ff]))) if ff >= 1 else 0
         net_share = phases["share_of_wave_time"].get("network", 0.0) + phases["share_of_wave_time"].get("a_network", 0.0) if phases else 0.0
+        # the template instance rocprofv3 names: k_trips_fused<K, MULTI, NF, MODE> (NF: 0 bf16 pieces, 1 fp16 network, 2 fp16 hi / lo; MODE: 0 later trips, 1 whole
+        # frame, 2 first trip's network / composite / compaction folded in) — the PMC stamp must name the same one
+        from pienerf_amd import _lib
+        nf = 1 if fp16 else int(_lib.lib().pn_net_form(h.model._net_handle()))
+        fused_instance = f"k_trips_fused<{opt['num_seek_IP']}, {'true' if opt['max_iter_num'] > 1 else 'false'}, {nf}, {int(fc0.get('mode', 0))}>"
+        if traffic.get("k_trips_fused") is not None and TRAFFIC_INSTANCES.get("k_trips_fused") not in (None, fused_instance):
+            traffic_note = (f"profiles/pmc_traffic*.json holds {TRAFFIC_INSTANCES.get('k_trips_fused')}, the timed launch is {fused_instance}: not reported "
+                            "(tools/gpu_run.sh traffic runs the passes on the launch set the bench times)")
+            traffic = dict(traffic, k_trips_fused=None)
         roofline = {
-            "kernel": f"k_trips_fused<{opt['num_seek_IP']},{'true' if opt['max_iter_num'] > 1 else 'false'},{'true' if fp16 else 'false'},{'true' if ff == 0 else 'false'}> — "
+            "kernel": f"{fused_instance} — "
                       f"every loop trip from trip {ff} on as ONE persistent launch: per ray { '{' } march 8 samples + inverse-GMLS warp; hash grid + SH + MLP on MFMA; composite { '}' } "
                       "until the ray dies (csrc/pn_trips_fused.h); the largest kernel of the mode that produced `value`",
             "bound": "hbm", "achieved": round(fused_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fused_gbs / HBM_PEAK_GBS, 4),

@@ -17,6 +17,7 @@ export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/$1; shift
 mkdir -p $O
+form() { [ "$1" = chair ] && echo fold || echo pipeline; }   # the launch set bench.py times: on the chair the first trip is folded into the fused launch (k_trips_fused<.., 2>)
 val() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d.get('ms_per_step'), d.get('verified'), d['roofline']['frac'] if d.get('roofline') else None)" 2>/dev/null || echo ERR; }
 for job in "$@"; do
   IFS=: read -r kind a b c <<< "$job"
@@ -25,11 +26,11 @@ for job in "$@"; do
     bench) cfg=${a:-chair}; args=$(echo "$b" | tr + ' '); tag=$(echo "$b" | tr -c 'a-zA-Z0-9\n' _)
            python bench.py --config $cfg $args > $O/bench_${cfg}${tag}.json 2> $O/bench_${cfg}${tag}.err; echo "bench $cfg $args: $(val < $O/bench_${cfg}${tag}.json)" | tee -a $O/summary.txt ;;
     stats) cfg=${a:-chair}; (cd /tmp && rm -rf /tmp/st_$cfg && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$cfg -o $cfg -- python $R/bench.py --no-cpu-baseline --no-extras --config $cfg --steps 100 --warmup 10 > $O/stats_$cfg.out 2> /tmp/st_$cfg.log || echo "stats $cfg failed"; find /tmp/st_$cfg -name "*kernel_stats.csv" -exec cp {} $O/${cfg}_kernel_stats.csv \; ); head -12 $O/${cfg}_kernel_stats.csv ;;
-    eager) cfg=${a:-chair}; (cd /tmp && rm -rf /tmp/st_eager_$cfg && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_eager_$cfg -o eager -- python $R/tools/run_frames.py --config $cfg --frames 20 --no-counters --form pipeline > $O/eager_$cfg.out 2> /tmp/st_eager_$cfg.log || echo "eager $cfg failed"; find /tmp/st_eager_$cfg -name "*kernel_stats.csv" -exec cp {} $O/eager_${cfg}_kernel_stats.csv \; ); head -12 $O/eager_${cfg}_kernel_stats.csv ;;
+    eager) cfg=${a:-chair}; (cd /tmp && rm -rf /tmp/st_eager_$cfg && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_eager_$cfg -o eager -- python $R/tools/run_frames.py --config $cfg --frames 20 --no-counters --form $(form $cfg) > $O/eager_$cfg.out 2> /tmp/st_eager_$cfg.log || echo "eager $cfg failed"; find /tmp/st_eager_$cfg -name "*kernel_stats.csv" -exec cp {} $O/eager_${cfg}_kernel_stats.csv \; ); head -12 $O/eager_${cfg}_kernel_stats.csv ;;
     pmc) cfg=$a; name=$b; ctrs=$(echo "$c" | tr + ' ')
-         (cd /tmp && rm -rf /tmp/pmc_${cfg}_$name && timeout 300 rocprofv3 --pmc $ctrs --kernel-trace -d /tmp/pmc_${cfg}_$name -o $name --output-format csv -- python $R/tools/run_frames.py --config $cfg --frames 3 --no-sim --no-counters --form pipeline > /tmp/pmc_${cfg}_$name.log 2>&1 || echo "pass $cfg $name failed"; python $R/tools/pmc_summary.py /tmp/pmc_${cfg}_$name k_ > $O/pmc_${cfg}_${name}_per_kernel.txt 2>&1) ;;
+         (cd /tmp && rm -rf /tmp/pmc_${cfg}_$name && timeout 300 rocprofv3 --pmc $ctrs --kernel-trace -d /tmp/pmc_${cfg}_$name -o $name --output-format csv -- python $R/tools/run_frames.py --config $cfg --frames 3 --no-sim --no-counters --form $(form $cfg) > /tmp/pmc_${cfg}_$name.log 2>&1 || echo "pass $cfg $name failed"; python $R/tools/pmc_summary.py /tmp/pmc_${cfg}_$name k_ > $O/pmc_${cfg}_${name}_per_kernel.txt 2>&1) ;;
     traffic) cfg=${a:-chair}
-         for ctr in FETCH_SIZE WRITE_SIZE; do n=$(echo $ctr | tr A-Z a-z | cut -d_ -f1); (cd /tmp && rm -rf /tmp/pmc_${cfg}_$n && timeout 300 rocprofv3 --pmc $ctr --kernel-trace -d /tmp/pmc_${cfg}_$n -o $n --output-format csv -- python $R/tools/run_frames.py --config $cfg --frames 3 --no-sim --no-counters --form pipeline > /tmp/pmc_${cfg}_$n.log 2>&1 || echo "pass $cfg $n failed"); done
+         for ctr in FETCH_SIZE WRITE_SIZE; do n=$(echo $ctr | tr A-Z a-z | cut -d_ -f1); (cd /tmp && rm -rf /tmp/pmc_${cfg}_$n && timeout 300 rocprofv3 --pmc $ctr --kernel-trace -d /tmp/pmc_${cfg}_$n -o $n --output-format csv -- python $R/tools/run_frames.py --config $cfg --frames 3 --no-sim --no-counters --form $(form $cfg) > /tmp/pmc_${cfg}_$n.log 2>&1 || echo "pass $cfg $n failed"); done
          out=$R/profiles/pmc_traffic.json; [ $cfg != chair ] && out=$R/profiles/pmc_traffic_$cfg.json
          python tools/pmc_traffic.py /tmp/pmc_${cfg}_fetch /tmp/pmc_${cfg}_write 3 $out > $O/pmc_traffic_$cfg.txt 2>&1 || echo "traffic $cfg failed"; cp $out $O/ ;;
     sim) python tools/time_sim.py 2>&1 | grep -v amdgpu.ids | tee $O/time_sim.txt; python tools/time_sim.py --persistent 2>&1 | grep -v amdgpu.ids | tee $O/time_sim_persistent.txt ;;

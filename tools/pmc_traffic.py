@@ -28,7 +28,7 @@ def per_kernel(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()   # template arguments kept: bench.py checks the instance against the launch it times
         tot[k] += float(r["Counter_Value"])
         cnt[k].add(r["Dispatch_Id"])
     return tot, {k: len(v) for k, v in cnt.items()}

@@ -21,8 +21,10 @@ ap.add_argument("--W", type=int, default=800)
 ap.add_argument("--graph", action="store_true")
 ap.add_argument("--no-counters", action="store_true", help="skip the extra frame rendered with the march work counters on")
 ap.add_argument("--config", choices=("chair", "stress", "trex"), default="chair", help="bench.py's workloads (stress: with its 4096-ray batches)")
-ap.add_argument("--form", choices=("blocking", "pipeline"), default="blocking",
-                help="pipeline: the kernels of the pipelined bench (first trip one lane per ray, fused launch on half the CUs), launched one frame at a time")
+ap.add_argument("--form", choices=("blocking", "pipeline", "fold"), default="blocking",
+                help="pipeline: the kernels of the pipelined bench (first trip one lane per ray, fused launch on half the CUs), launched one frame at a time; "
+                     "fold: the launch set the three-lane bench really times on the chair — the same with the first trip's network / composite / compaction "
+                     "folded into the fused launch (k_trips_fused<.., 2>), where the frame allows it")
 args = ap.parse_args()
 if args.config == "chair":
     opt = scene.default_opt(W=args.W, H=args.W)
@@ -37,8 +39,10 @@ else:
     h.pose = pose
     if force is not None:
         h.sim.update_force(h.sim.n_IP // 2, force)
-if args.form == "pipeline" and not h.opt.get("ray_batch"):
+if args.form in ("pipeline", "fold") and not h.opt.get("ray_batch"):
     h.opt.update(march_throughput=64, fused_grid=max(torch.cuda.get_device_properties(0).multi_processor_count // 2, 1))
+if args.form == "fold" and not h.opt.get("ray_batch"):
+    h.opt.update(fused_fold=True)
 for _ in range(args.presim):
     h.sim.stepforward()
 if args.graph:
