@@ -367,6 +367,14 @@ def kernel_report(h, opt, dev, form_kw=None, graph_ms=None):
         "bound": "hbm", "achieved": round(net_loop_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(net_loop_gbs / HBM_PEAK_GBS, 4),
         "bytes_per_sample": bps, "traffic": traffic.get(kname), "traffic_note": traffic_note,
         "ms_per_frame": round(net_loop_ms, 4), "samples_per_frame": st["samples"],
+        # the fused launch runs on `fused_grid` of the chip's CUs (two frames' launches side by side): per CU-time the network phases are measured against the
+        # stand-alone kernel, which has all 256 CUs.  frac x 256 / workgroups, only when every network tile of the frame runs inside the fused launch
+        "frac_per_cu_time": (round(net_loop_gbs / HBM_PEAK_GBS * 256.0 / float(h.opt["fused_grid"]), 4)
+                             if (ff >= 0 and folded and h.opt.get("fused_grid") and per_trip <= 1) else None),
+        "frac_per_cu_time_note": ("network.frac is bytes / (the launch's duration x the network phases' share of wave time) of a launch on fused_grid = "
+                                  f"{h.opt.get('fused_grid')} of 256 CUs; a launch of that width doing nothing but network tiles at the stand-alone kernel's per-CU rate "
+                                  "(all_samples_one_launch, all 256 CUs) would read frac_of_hbm_peak x fused_grid / 256 — that is the ceiling network.frac is to be held "
+                                  "against, and frac_per_cu_time = frac x 256 / fused_grid is the figure comparable with the stand-alone kernel's"),
         "definition": ("network time of a frame = the network launches of the per-trip trips (HIP events) + the fused launch's duration x the share of its waves' time "
                        "spent in network phases (phase clocks), both of a blocking render; achieved = samples x bytes_per_sample / that" if ff >= 0 else
                        "network launches inside the render loop, HIP events"),

@@ -177,7 +177,7 @@ __device__ __forceinline__ int cell_coord(float v, float lo, float hgs, float rh
 // just before something can.  Two facts, as for the fixed-step DDA start of skip_empty_cells:
 //   * the t-sequence is grid-independent: T_{k+1} = T_k + clamp(T_k dt_gamma, dt_min, dt_max), whatever the chain visits of it — walking it costs five
 //     instructions per element where visiting one costs 230;
-//   * a REGION is one 8^3-voxel block of the top cascade level (a 64-byte line of the bitfield); its bit says "interesting": some voxel of it is occupied on
+//   * a REGION is one 8^3-voxel block of the top cascade level (a 64-byte line of the bitfield; the caller may choose 4^3); its bit says "interesting": some voxel of it is occupied on
 //     ANY level that a point inside it can be tested on, or it meets the cut box (inside which the search cells decide).  A point in a region without the
 //     bit is a static-background sample in an empty voxel whatever its mip level: the chain emits nothing there.
 // region_dda walks the regions the ray crosses until the next one is interesting (crossings within 2e-3 region widths of another face also look at the
@@ -303,7 +303,7 @@ __device__ inline int region_dda(const RegionGrid& g, float ox, float oy, float 
 // it behind.  Bit-identical by construction; the march tests compare every ray with the oracle and with the reference's own kernel.
 __device__ inline float skip_empty_cells(const MarchParams& a, const March2Tables& tb, int index, float noise, unsigned* n_iter_out,
                                          const uint32_t* cell_bits = nullptr, float far_override = -1.0f, const uint32_t* cell_bits2 = nullptr,
-                                         int hop_budget = 0, const uint32_t* grid_regions = nullptr) {
+                                         int hop_budget = 0, const uint32_t* grid_regions = nullptr, int regions_R = 0) {
     const Float3 o = *reinterpret_cast<const Float3*>(a.rays_o + (size_t)index * 3), d = *reinterpret_cast<const Float3*>(a.rays_d + (size_t)index * 3);
     const float ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
     const uint32_t H = a.H, C = a.C;
@@ -490,8 +490,8 @@ __device__ inline float skip_empty_cells(const MarchParams& a, const March2Table
     }
     // --cut with the region map (see region_dda): skip the empty regions in front of the first interesting one.  Levels: bound == 2^(C - 1) (the caller checked),
     // so level l's voxels are 2^(l + 1) / H wide and a region is 8^3 voxels of level C - 1.
-    const bool regions_on = cut && grid_regions != nullptr;
-    RegionGrid rg{grid_regions, (int)(H / 8), -a.bound, 16.0f * a.bound * rH, (float)H / (16.0f * a.bound)};
+    const bool regions_on = cut && grid_regions != nullptr && regions_R > 0;
+    RegionGrid rg{grid_regions, regions_R, -a.bound, 2.0f * a.bound / (float)max(regions_R, 1), (float)max(regions_R, 1) / (2.0f * a.bound)};
     const float rnorm = __builtin_amdgcn_rsqf(dx * dx + dy * dy + dz * dz);
     const float w_t = 1.7320508f * 2.0f * a.bound * rH * rnorm * 1.02f;   // one top-level voxel diagonal in units of t (+ 2 %)
     int hops_since_try = 0, retry_hops = PN_REGION_RETRY_HOPS;

@@ -535,6 +535,7 @@ struct MarchIO {
     // the region can meet an occupied voxel on any level or the cut box (k_frame_prologue); k_march_skip keeps it in LDS
     const uint32_t* grid_regions;
     int grid_regions_words;
+    int grid_regions_R;   // regions per axis: H / 8 (8^3-voxel regions) or H / 4
 };
 
 // Append lists are SEGMENTED: PN_SEGS independent (counter, region) pairs, every counter on a cache line of its own, the producer picking
@@ -597,7 +598,7 @@ __global__ void __launch_bounds__(256) k_march_skip(pnm::MarchParams a, pnm2::Ma
             io.fars_eff[index] = far;
         }
         const float t = pnm3::skip_empty_cells(a, tb, index, io.noises ? io.noises[n] : 0.0f, &n_iter, cell_bits, cell_bits2 ? far : -1.0f,
-                                               io.dda_start ? cell_bits2 : nullptr, io.dda_start && cell_bits2 ? io.hop_budget : 0, grid_regions);
+                                               io.dda_start ? cell_bits2 : nullptr, io.dda_start && cell_bits2 ? io.hop_budget : 0, grid_regions, io.grid_regions_R);
         io.t_resume[n] = t;
         if (!PN_DBG_PHASES_ON && a.stats && n_iter) atomicAdd(a.stats, (unsigned long long)n_iter);
         work = t < far;
@@ -1993,20 +1994,22 @@ __global__ void __launch_bounds__(256) k_frame_prologue(FramePrologue a) {
         bool any = false;
         if (r < n_reg) {
             const int b0 = r % R, b1 = (r / R) % R, b2 = r / (R * R);
-            const uint32_t lines_per_level = (a.gr_H * a.gr_H * a.gr_H) >> 9;
-            const uint4* g4 = reinterpret_cast<const uint4*>(a.grid);
+            // a region is V = (H / R)^3 voxels = V / 64 consecutive 8-byte words of a level's bitfield in morton order (R = H / 8: a 64-byte line; R = H / 4: one word)
+            const uint32_t vox_side = a.gr_H / (uint32_t)R, words_per_region = (vox_side * vox_side * vox_side) >> 6;
+            const uint32_t words_per_level = (a.gr_H * a.gr_H * a.gr_H) >> 6;
+            const uint2* g2 = reinterpret_cast<const uint2*>(a.grid);
             uint32_t acc = 0;
             for (int l = 0; l < a.gr_C; l++) {
                 // on level l (R blocks over +-2^l) the region is the aligned cube of 2^j blocks per axis at R / 2 + (b - R / 2) 2^j, j = C - 1 - l — contiguous
-                // lines in morton order — or lies outside the level's volume, where no point can be tested on it
+                // words in morton order — or lies outside the level's volume, where no point can be tested on it
                 const int j = a.gr_C - 1 - l, side = 1 << j;
                 const int c0 = R / 2 + (b0 - R / 2) * side, c1 = R / 2 + (b1 - R / 2) * side, c2 = R / 2 + (b2 - R / 2) * side;
                 if (c0 < 0 || c1 < 0 || c2 < 0 || c0 + side > R || c1 + side > R || c2 + side > R) continue;
-                const uint32_t first = (uint32_t)l * lines_per_level + pnm2::morton3D((uint32_t)c0, (uint32_t)c1, (uint32_t)c2);
-                const uint32_t n_lines = 1u << (3 * j);
-                for (uint32_t q = 0; q < n_lines * 4; q++) {
-                    const uint4 v = g4[(size_t)first * 4 + q];
-                    acc |= v.x | v.y | v.z | v.w;
+                const uint32_t first = (uint32_t)l * words_per_level + pnm2::morton3D((uint32_t)c0, (uint32_t)c1, (uint32_t)c2) * words_per_region;
+                const uint32_t n_words = words_per_region << (3 * j);
+                for (uint32_t q = 0; q < n_words; q++) {
+                    const uint2 v = g2[(size_t)first + q];
+                    acc |= v.x | v.y;
                 }
             }
             any = acc != 0u;
@@ -2157,7 +2160,11 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     // --cut: the region map for the skip pre-pass (MarchIO::grid_regions; pn_march_window.h: region_dda) where its assumptions hold: the top cascade level
     // spans exactly +-bound (bound == 2^(C - 1)), regions are whole 64-byte lines of the bitfield and nest on every level, the map fits
     static const bool grid_regions_off = pn_env_u32("PN_GRID_REGIONS_OFF", 0) != 0;   // A/B runs: same frames, bit for bit
-    const uint32_t reg_R = o->grid_size / 8;
+    // regions of 8^3 voxels (a 64-byte line of the bitfield).  PN_REGION_SIDE=4: 4^3-voxel regions (one 8-byte word) — measured on the trex option set alone:
+    // 232 against 177 us (hop by hop 285): the restart zone in front of an interesting region is longer than a 4-voxel region, so fewer runs qualify
+    static const uint32_t reg_side_env = pn_env_u32("PN_REGION_SIDE", 0);
+    const uint32_t reg_side = reg_side_env == 4 ? 4u : 8u;
+    const uint32_t reg_R = o->grid_size / reg_side;
     const bool reg_ok = !is_static && o->cut && !grid_regions_off && dda_start && bitfield && o->grid_size % 32 == 0 && o->cascade >= 1 && o->cascade <= 3 &&
                         o->bound == (float)(1u << (o->cascade - 1)) && (reg_R / 2) % (1u << (o->cascade - 1)) == 0 &&
                         (uint64_t)reg_R * reg_R * reg_R / 32 <= PN_GRID_REGION_WORDS && ((uintptr_t)bitfield & 15) == 0;
@@ -2248,7 +2255,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     // the maps then span enough cache lines for the atomics not to queue)
     fp.lds_words = (fp.list_blocks > 0 && bit_words * 8 <= 64 * 1024) ? (int)bit_words : 0;
     if (grid_region_words > 0) {
-        fp.grid = bitfield; fp.grid_regions = f->grid_regions; fp.gr_R = (int)(o->grid_size / 8); fp.gr_C = (int)o->cascade; fp.gr_H = o->grid_size;
+        fp.grid = bitfield; fp.grid_regions = f->grid_regions; fp.gr_R = (int)reg_R; fp.gr_C = (int)o->cascade; fp.gr_H = o->grid_size;
         fp.gr_bound = o->bound; fp.cut_bounds = f->cut_bounds; fp.gr_blocks = (int)pn_div_up((uint64_t)grid_region_words * 32, 256);
     }
     k_frame_prologue<<<(uint32_t)(fp.list_blocks + fp.pack_blocks + fp.gr_blocks) + nblk, 256, (size_t)fp.lds_words * 8, st>>>(fp);
@@ -2321,7 +2328,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
                        (int)f->seg_cap, f->list_seg, seg_samp, (int)f->seg_cap, seg_emit, f->cell_bits, skip_bits_words,
                        short_rays ? f->cell_bits + bit_words : nullptr, short_rays ? f->fars_eff : nullptr,
                        group_rays ? f->groups + (size_t)(tt & 1) * f->max_groups : nullptr, group_rays, lpr ? 1 : 0, dda_start,
-                       (int)skip_hop_budget, grid_region_words > 0 ? f->grid_regions : nullptr, grid_region_words};
+                       (int)skip_hop_budget, grid_region_words > 0 ? f->grid_regions : nullptr, grid_region_words, (int)reg_R};
     };
     while (!done && t < PN_MAX_TRIPS) {
         const bool whole = whole_try;
