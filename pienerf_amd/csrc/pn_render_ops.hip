@@ -64,6 +64,10 @@ struct PnFrameDev {
     int alive_at_exit;  // rays alive behind the last trip enqueued
     int pad0;
     long long stat_samples;  // samples marched (dense trips: emitted; list trips: listed)
+    // cells [ip_lo, ip_hi] per axis hold every integration point (k_frame_tables); with --cut the search grid spans +-bound (67^3 cells on the trex option
+    // set) while the points fill a fortieth of it: k_frame_prologue builds candidate lists for the cells within one cell of that box only
+    int ip_lo[3], ip_hi[3];
+    int pad1[2];
 };
 
 // ------------------------------------------------------------------------------------------------ sph_from_ray
@@ -1684,6 +1688,12 @@ __global__ void __launch_bounds__(1024) k_frame_tables(const float* __restrict__
             dev->resolution[c] = r;
             sh_res[c] = r;
             ncell *= r;
+            {   // the points' own extent in cells (p2g's arithmetic, one cell wider for its rounding)
+                float pa = smin[c][0], pb = smax[c][0];
+                for (int w = 1; w < 16; w++) { pa = fminf(pa, smin[c][w]); pb = fmaxf(pb, smax[c][w]); }
+                dev->ip_lo[c] = max((int)floorf((pa - lo) / hgs) - 1, 0);
+                dev->ip_hi[c] = min((int)floorf((pb - lo) / hgs) + 1, r - 1);
+            }
         }
         int err = 0;
         if (ncell > max_cells || ncell <= 0) { err = 4; ncell = 0; }
@@ -1822,6 +1832,7 @@ __device__ __forceinline__ void frame_lists_block(const FramePrologue& a) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = threadIdx.x & 7;
     const int words = (a.n_grid_max + 31) / 32;
     const int per_round = a.list_blocks * 32;
+    const int ilo0 = a.dev->ip_lo[0], ilo1 = a.dev->ip_lo[1], ilo2 = a.dev->ip_lo[2], ihi0 = a.dev->ip_hi[0], ihi1 = a.dev->ip_hi[1], ihi2 = a.dev->ip_hi[2];
     const bool in_lds = a.lds_words > 0;
     if (in_lds) {
         for (int w = threadIdx.x; w < 2 * a.lds_words; w += blockDim.x) lds_bits[w] = 0u;
@@ -1832,12 +1843,14 @@ __device__ __forceinline__ void frame_lists_block(const FramePrologue& a) {
         const bool valid = c < n_grid;
         int g0 = 0, g1 = 0, g2 = 0;
         if (valid) nb_cell_coords(c, r0, r1, g0, g1, g2);
+        // a cell more than one cell away from every integration point has an empty list: no neighbour to look at (PnFrameDev::ip_lo / ip_hi)
+        const bool near_ips = valid && g0 >= ilo0 - 1 && g0 <= ihi0 + 1 && g1 >= ilo1 - 1 && g1 <= ihi1 + 1 && g2 >= ilo2 - 1 && g2 <= ihi2 + 1;
         int cell[4], cnt[4], before[4];
         int total = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {  // visiting position q = 0 is the cell itself, q = 1..26 its neighbours q - 1
             const int q = sub + 8 * k;
-            cell[k] = (valid && q < 27) ? ((q == 0) ? c : nb_neighbour(q - 1, a.swap, g0, g1, g2, r0, r1, r2)) : -1;
+            cell[k] = (near_ips && q < 27) ? ((q == 0) ? c : nb_neighbour(q - 1, a.swap, g0, g1, g2, r0, r1, r2)) : -1;
             cnt[k] = cell[k] >= 0 ? a.pig_cnt[cell[k]] : 0;
             int inc = cnt[k];  // running sum over the 8 lanes of the group
 #pragma unroll
