@@ -202,8 +202,8 @@ class NeRFRenderer(nn.Module):
         if stats[2]:
             raise RuntimeError(f"render_deformed: device error flags {int(stats[2])} (1: sample cell outside the spatial hash, "
                                "2: IP outside it, 4: spatial-hash capacity exceeded, 8: candidate-list capacity exceeded, "
-                               "16: the fused composite/compaction gave up waiting for an earlier chunk, or the fused launch found its kernarg segment laid out "
-                               "otherwise than csrc/pn_trips_fused.h: fused_karg_fresh assumes)")
+                               "16: the fused composite/compaction gave up waiting for an earlier chunk, 32: the fused launch found its kernarg segment laid "
+                               "out otherwise than csrc/pn_trips_fused.h: fused_karg_fresh assumes)")
 
     def march_counters(self, enable, read=False, slot=0):
         """Measurement hook on workspace `slot`: 1 = device-side work counters of the march kernel (iterations, candidates, warps, samples);
