@@ -231,6 +231,17 @@ def grid_nd_backward(grad, inputs, embeddings_shape, offsets, per_level_scale, b
     return gi, ge
 
 
+def grid_nd_grad_tv(inputs, embeddings, offsets, weight, per_level_scale, base_resolution, gridtype=0, align_corners=False):
+    """kernel_grad_tv<float, D, C> for D in 2..5 (gridencoder.cu:506-611): the gradient it adds to a zero tensor."""
+    inputs, embeddings, offsets = _f32(inputs), _f32(embeddings), _i32(offsets)
+    B, Dd = inputs.shape
+    L, Cf = offsets.shape[0] - 1, embeddings.shape[1]
+    g = np.zeros_like(embeddings)
+    lib().orc_grid_nd_grad_tv(_p(inputs, F), _p(embeddings, F), _p(g, F), _p(offsets, I), F(weight), C.c_uint32(B), C.c_uint32(Dd), C.c_uint32(Cf), C.c_uint32(L),
+                              F(np.float32(np.log2(per_level_scale))), C.c_uint32(base_resolution), C.c_uint32(gridtype), I(int(align_corners)))
+    return g
+
+
 def grid_level_params(L, per_level_scale, base_resolution):
     scales, res = np.empty(L, np.float32), np.empty(L, np.uint32)
     lib().orc_grid_level_params(C.c_uint32(L), F(np.float32(np.log2(per_level_scale))), C.c_uint32(base_resolution), _p(scales, F),

@@ -137,4 +137,42 @@ void orc_grid_nd_backward(const float* grad, const float* inputs, const int* off
     }
 }
 
+// kernel_grad_tv<float, D, C> (gridencoder.cu:506-611): grad (accumulated into; the caller's tensor) [offsets[L], C]; sequential in (level, sample) order
+void orc_grid_nd_grad_tv(const float* inputs, const float* embeddings, float* grad, const int* offsets, float weight, uint32_t B, uint32_t D, uint32_t C,
+                         uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners) {
+    if (D < 2 || D > 5 || C > 8) return;
+    for (uint32_t l = 0; l < L; l++) {
+        const float scale = exp2f(l * S) * H - 1.0f;
+        const uint32_t res = (uint32_t)std::ceil(scale) + 1, hs = (uint32_t)(offsets[l + 1] - offsets[l]);
+        const float* table = embeddings + (size_t)(uint32_t)offsets[l] * C;
+        float* gt = grad + (size_t)(uint32_t)offsets[l] * C;
+        for (uint32_t b = 0; b < B; b++) {
+            const float* in = inputs + (size_t)b * D;
+            bool oob = false;
+            for (uint32_t d = 0; d < D; d++) if (in[d] < 0 || in[d] > 1) oob = true;
+            if (oob) continue;
+            uint32_t pg[5];
+            for (uint32_t d = 0; d < D; d++) pg[d] = (uint32_t)std::floor(std::fmaf(in[d], scale, align_corners ? 0.0f : 0.5f));
+            float results[8] = {0, 0, 0, 0, 0, 0, 0, 0}, idelta[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const uint32_t index = index_nd(D, gridtype, align_corners != 0, C, hs, res, pg);
+            const float w = weight / (2 * D);
+            for (uint32_t d = 0; d < D; d++) {
+                const uint32_t cur = pg[d];
+                if (cur < res) {
+                    pg[d] = cur + 1;
+                    const uint32_t ir = index_nd(D, gridtype, align_corners != 0, C, hs, res, pg);
+                    for (uint32_t ch = 0; ch < C; ch++) { const float gv = table[index + ch] - table[ir + ch]; results[ch] += gv; idelta[ch] += gv * gv; }
+                }
+                if (cur > 0) {
+                    pg[d] = cur - 1;
+                    const uint32_t il = index_nd(D, gridtype, align_corners != 0, C, hs, res, pg);
+                    for (uint32_t ch = 0; ch < C; ch++) { const float gv = table[index + ch] - table[il + ch]; results[ch] += gv; idelta[ch] += gv * gv; }
+                }
+                pg[d] = cur;
+            }
+            for (uint32_t ch = 0; ch < C; ch++) gt[index + ch] += w * results[ch] * (1.0f / std::sqrt(idelta[ch] + 1e-9f));
+        }
+    }
+}
+
 }  // extern "C"

@@ -359,6 +359,8 @@ extern "C" int pn_grad_total_variation(const float* inputs, const float* embeddi
                                        uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, void* stream) {
     if (B == 0) return PN_OK;
     PN_REQUIRE(inputs && embeddings && grad && offsets_host);
+    if (D != 3)  // gridencoder.cu:629-634: D = 2, 4, 5
+        return pn_grid_nd_grad_tv_launch(inputs, embeddings, grad, offsets_host, weight, B, D, C, L, S, H, gridtype, align_corners, (hipStream_t)stream);
     PN_REQUIRE(D == 3 && (C == 1 || C == 2 || C == 4 || C == 8) && gridtype <= 1);
     PnGridLevels lv;
     if (pn_fill_grid_levels(&lv, offsets_host, L, C, S, H, gridtype, align_corners)) { PN_REQUIRE(L >= 1 && L <= PN_MAX_LEVELS); }

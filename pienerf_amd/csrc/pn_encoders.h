@@ -41,6 +41,8 @@ int pn_sh_dy_dx_launch(const float* inputs, float* dy_dx, uint32_t B, uint32_t C
 int pn_grid_nd_forward_launch(const float* inputs, const float* embeddings, const int* offsets_host, float* outputs, uint32_t B, uint32_t D, uint32_t C,
                               uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype, int align_corners, uint32_t interp, int out_bl_major,
                               hipStream_t st);
+int pn_grid_nd_grad_tv_launch(const float* inputs, const float* embeddings, float* grad, const int* offsets_host, float weight, uint32_t B, uint32_t D, uint32_t C,
+                              uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, hipStream_t st);
 int pn_grid_nd_backward_launch(const float* grad, const float* inputs, const int* offsets_host, float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
                                uint32_t L, float S, uint32_t H, const float* dy_dx, float* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp,
                                hipStream_t st);

@@ -168,6 +168,50 @@ __global__ void __launch_bounds__(256) k_grid_nd_input_backward(const float* __r
     grad_inputs[t] = r;
 }
 
+// kernel_grad_tv<float, D, C> (gridencoder.cu:506-611)
+template <uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(256) k_grid_nd_grad_tv(const float* __restrict__ inputs, const float* __restrict__ emb, float* __restrict__ grad, NdLevels lv,
+                                                         float weight, uint32_t B, uint32_t gridtype, int align) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const uint32_t level = blockIdx.y, hs = lv.hs[level], res = lv.res[level];
+    const float scale = lv.scale[level];
+    const float* __restrict__ in = inputs + (size_t)b * D;
+    bool inside = true;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) inside = inside && !(in[d] < 0 || in[d] > 1);
+    if (!inside) return;
+    const float* __restrict__ table = emb + (size_t)lv.offset[level] * C;
+    float* __restrict__ gt = grad + (size_t)lv.offset[level] * C;
+    uint32_t pg[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) pg[d] = (uint32_t)floorf(fmaf(in[d], scale, align ? 0.0f : 0.5f));
+    float results[C], idelta[C];
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) { results[ch] = 0; idelta[ch] = 0; }
+    const uint32_t index = index_nd<D>(gridtype, align != 0, hs, res, pg) * C;
+    const float w = weight / (2 * D);
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const uint32_t cur = pg[d];
+        if (cur < res) {
+            pg[d] = cur + 1;
+            const uint32_t ir = index_nd<D>(gridtype, align != 0, hs, res, pg) * C;
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) { const float gv = table[index + ch] - table[ir + ch]; results[ch] += gv; idelta[ch] += gv * gv; }
+        }
+        if (cur > 0) {
+            pg[d] = cur - 1;
+            const uint32_t il = index_nd<D>(gridtype, align != 0, hs, res, pg) * C;
+#pragma unroll
+            for (uint32_t ch = 0; ch < C; ch++) { const float gv = table[index + ch] - table[il + ch]; results[ch] += gv; idelta[ch] += gv * gv; }
+        }
+        pg[d] = cur;
+    }
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ch++) unsafeAtomicAdd(gt + index + ch, w * results[ch] * (1.0f / sqrtf(idelta[ch] + 1e-9f)));
+}
+
 int fill_levels(NdLevels* lv, const int* offsets_host, uint32_t L, float S, uint32_t H) {
     if (L == 0 || L > PN_MAX_LEVELS) return PN_ERR_ARG;
     lv->L = L;
@@ -228,6 +272,18 @@ int pn_grid_nd_backward_launch(const float* grad, const float* inputs, const int
     const dim3 grid(pn_div_up(B, 256), L, 1);
     PN_ND_DISPATCH(k_grid_nd_backward, grad, inputs, lv, B, gridtype, align_corners, interp, grad_embeddings);
     if (dy_dx) k_grid_nd_input_backward<<<pn_div_up((uint64_t)B * D, 256), 256, 0, st>>>(grad, dy_dx, grad_inputs, B, L, D, C);
+    PN_LAUNCH_CHECK();
+    return PN_OK;
+}
+
+int pn_grid_nd_grad_tv_launch(const float* inputs, const float* embeddings, float* grad, const int* offsets_host, float weight, uint32_t B, uint32_t D, uint32_t C,
+                              uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners, hipStream_t st) {
+    PN_REQUIRE(inputs && embeddings && grad && offsets_host);
+    PN_REQUIRE((D == 2 || D == 4 || D == 5) && gridtype <= 1);   // gridencoder.cu:629-634
+    NdLevels lv;
+    if (fill_levels(&lv, offsets_host, L, S, H)) { PN_REQUIRE(L >= 1 && L <= PN_MAX_LEVELS); }
+    const dim3 grid(pn_div_up(B, 256), L, 1);
+    PN_ND_DISPATCH(k_grid_nd_grad_tv, inputs, embeddings, grad, lv, weight, B, gridtype, align_corners);
     PN_LAUNCH_CHECK();
     return PN_OK;
 }

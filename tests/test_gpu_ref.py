@@ -331,16 +331,19 @@ def test_grid_encode_other_input_dims_equal_the_reference_kernel(mods, D, C, gri
         mm["gridencoder"].grid_encode_forward(tx, emb, off, y2, B, D, C, L, S, base, None, gridtype, align, interp)
         ge, gi = torch.zeros_like(emb), torch.zeros(B, D, device=DEV)
         mm["gridencoder"].grid_encode_backward(grad, tx, emb, off, ge, B, D, C, L, S, base, dy, gi, gridtype, align, interp)
+        tv = torch.zeros_like(emb)
+        mm["gridencoder"].grad_total_variation(tx, emb, tv, off, 0.3, B, D, C, L, S, base, gridtype, align)   # kernel_grad_tv<float, D, C> (:506-634)
         torch.cuda.synchronize()
         assert torch.equal(y, y2)
-        out[name] = (y, dy, ge, gi)
+        out[name] = (y, dy, ge, gi, tv)
     key = f"grid_nd[D={D},C={C},{gridtype},{int(align)},{interp}]"
     REPORT[key] = dict(outputs_vs_fma=mismatch(out["ours"][0], out["fma"][0]), outputs_vs_nocontract=mismatch(out["ours"][0], out["ref"][0]),
                        dy_dx_rel_vs_fma=rel(out["ours"][1], out["fma"][1]), grad_embeddings_rel=rel(out["ours"][2], out["ref"][2]),
-                       grad_inputs_rel=rel(out["ours"][3], out["fma"][3]))
+                       grad_inputs_rel=rel(out["ours"][3], out["fma"][3]), grad_tv_rel=rel(out["ours"][4], out["ref"][4]))
     print(key, REPORT[key])
     assert REPORT[key]["outputs_vs_fma"][1] <= 2e-6 and REPORT[key]["outputs_vs_nocontract"][1] <= 2e-4
     assert REPORT[key]["dy_dx_rel_vs_fma"] < 1e-5 and REPORT[key]["grad_embeddings_rel"] < 1e-4 and REPORT[key]["grad_inputs_rel"] < 1e-4
+    assert REPORT[key]["grad_tv_rel"] < 1e-4 and float(out["ref"][4].abs().max()) > 1e-4
     assert not out["ref"][0][:, 4:6].any() and not out["ours"][0][:, 4:6].any() and not out["ours"][3][4:6].any()
     # the CPU oracle, first-hand against the reference kernel (contracting build)
     want_y, want_dy = oracle.grid_nd_forward(x, emb_np, offsets, pls, base, gridtype, align, interp, dy_dx=True)
@@ -349,6 +352,8 @@ def test_grid_encode_other_input_dims_equal_the_reference_kernel(mods, D, C, gri
     gi_o, ge_o = oracle.grid_nd_backward(grad_np.transpose(1, 0, 2).reshape(B, L * C), x, emb_np.shape, offsets, pls, base, want_dy, gridtype, align, interp)
     assert np.abs(ge_o - out["ref"][2].cpu().numpy()).max() <= 1e-4 * np.abs(ge_o).max()
     assert np.abs(gi_o - out["fma"][3].cpu().numpy()).max() <= 1e-4 * np.abs(gi_o).max()
+    tv_o = oracle.grid_nd_grad_tv(x, emb_np, offsets, 0.3, pls, base, gridtype, align)
+    assert np.abs(tv_o - out["ref"][4].cpu().numpy()).max() <= 1e-4 * np.abs(tv_o).max()
 
 
 @pytest.mark.parametrize("degree", [1, 2, 3, 4, 5, 6, 7, 8])

@@ -438,6 +438,8 @@ def test_grid_nd_oracle_restates_the_d3_oracle_and_interpolates():
                 gi0, ge0 = otr.grid_encode_backward(g, x, emb.shape, off, pls, 8, d0, gt, al, ip)
                 gi1, ge1 = oracle.grid_nd_backward(g, x, emb.shape, off, pls, 8, dd, gt, al, ip)
                 assert np.array_equal(a, b) and np.array_equal(dd, d0) and np.array_equal(gi0, gi1) and np.array_equal(ge0, ge1), (gt, al, ip)
+                if ip == 0:
+                    assert np.array_equal(otr.grad_total_variation(x, emb, np.zeros_like(emb), off, pls, 8, 0.3, gt, al), oracle.grid_nd_grad_tv(x, emb, off, 0.3, pls, 8, gt, al))
     for D in (2, 4, 5):
         off = level_table_offsets(D, 5, pls, 4, 11, False)
         emb = np.full((int(off[-1]), 2), 0.75, np.float32)
