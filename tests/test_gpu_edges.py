@@ -200,6 +200,51 @@ def test_frame_independent_of_the_skip_pre_pass_form(deformed_ip_state, small_op
     assert torch.equal(torch.nan_to_num(d0, nan=-1.0), torch.nan_to_num(d1, nan=-1.0))
 
 
+@pytest.mark.parametrize("bound,dt_gamma,blob_frac,radius,theta,phi", [
+    (1.0, 0.0, 0.02, 3.0, 25.0, -10.0),        # one cascade, fixed step (the chair's stepping) with --cut
+    (1.0, 1.0 / 64, 0.10, 0.7, 80.0, 30.0),    # camera INSIDE the volume, dense background
+    (2.0, 1.0 / 128, 0.02, 4.5, 25.0, -10.0),  # the trex option set's geometry
+    (2.0, 1.0 / 128, 0.002, 3.0, 0.0, 0.0),    # rays along the axes: crossings on faces, edges and corners of the regions
+    (2.0, 0.0, 0.05, 1.5, 90.0, 0.0),          # two cascades with the fixed step: the mip level changes at |x| = 1 only
+    (2.0, 1.0 / 16, 0.02, 5.0, -45.0, 35.0),   # large steps: dt reaches dt_max, levels from dt as well as from the position
+    (4.0, 1.0 / 128, 0.01, 7.0, 30.0, 20.0),   # three cascades
+    (4.0, 1.0 / 256, 0.05, 2.5, -120.0, -5.0),
+])
+def test_cut_frame_independent_of_the_region_skip(deformed_ip_state, small_opt, skip_dda, bound, dt_gamma, blob_frac, radius, theta, phi):
+    """--cut frames with the skip pre-pass crossing the static background's empty regions on the ray's t-sequence (pn_march_window.h: region_dda; the default)
+    and visiting them voxel by voxel (pn_march_set_skip_dda(0)): the same trips, the same sample count and the same pixels bit for bit — over one, two and three
+    cascades, fixed and growing steps, sparse and dense backgrounds (random 8^3-voxel blocks of the bitfield on every level), a camera inside the volume and
+    rays along the grid axes."""
+    from pienerf_amd.nerf.network import NeRFNetwork
+    ck = scene.make_checkpoint(bound=bound, seed=7)
+    blobs = np.repeat(np.random.default_rng(int(1000 * blob_frac) + int(bound)).random(len(ck["density_bitfield"]) // 64) < blob_frac, 64)
+    ck["density_bitfield"] = ck["density_bitfield"] | np.where(blobs, 0xFF, 0).astype(np.uint8)
+    net = NeRFNetwork(encoding="hashgrid", bound=bound, cuda_ray=True).to(DEV).load_checkpoint_dict(ck)
+    ip = deformed_ip_state
+    net.p_def, net.p_ori, net.IP_F, net.IP_dF, net.IP_dx = T(ip["p_def"]), T(ip["p_ori"]), T(ip["F"]), T(ip["dF"]), ip["IP_dx"]
+    opt = dict(small_opt, bound=bound, dt_gamma=dt_gamma, cut=True, cut_bounds=[-0.62, 1.0, -0.82, 0.42, -0.52, 0.28], max_steps=300 if dt_gamma else 1024,
+               T_thresh=5e-2, num_seek_IP=1)
+    W = 112
+    o, d = oracle.get_rays(scene.orbit_pose(radius, theta, phi), scene.orbit_intrinsics(W, W, 50.0), W, W)
+    res = []
+    with torch.no_grad():
+        visited = []
+        net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **opt)   # (creates the workspace the counters live in)
+        for on in (0, 1):
+            skip_dda(on)
+            net.march_counters(1)
+            out = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **opt)
+            visited.append(net.march_counters(1, read=True)["iterations"])
+            net.march_counters(0)
+            res.append((dict(net.last_stats), out["image"].clone(), out["depth"].clone(), out["depth_0"].clone()))
+    (s0, i0, d0, e0), (s1, i1, d1, e1) = res
+    assert s0["samples"] == s1["samples"] > 500 and s0["trips"] == s1["trips"] and s0["err"] == s1["err"] == 0, (s0, s1)
+    assert torch.equal(i0, i1) and torch.equal(e0, e1)
+    assert torch.equal(torch.nan_to_num(d0, nan=-1.0), torch.nan_to_num(d1, nan=-1.0))
+    print(f"bound {bound}, dt_gamma {dt_gamma:.4f}, background {blob_frac}: visited points {visited[0]} voxel by voxel, {visited[1]} with the region skip")
+    assert visited[1] <= visited[0] and (blob_frac > 0.02 or visited[1] < visited[0])   # a sparse background: the region path was taken, not silently switched off
+
+
 @pytest.mark.parametrize("rounds", [1, 5, 64])
 @pytest.mark.parametrize("num_seek_IP,max_iter_num", [(3, 1), (2, 4), (1, 1)])
 def test_frame_independent_of_the_first_trip_form(deformed_ip_state, small_opt, ckpt, rounds, num_seek_IP, max_iter_num):
