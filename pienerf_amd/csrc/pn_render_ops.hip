@@ -1688,12 +1688,7 @@ __global__ void __launch_bounds__(1024) k_frame_tables(const float* __restrict__
             dev->resolution[c] = r;
             sh_res[c] = r;
             ncell *= r;
-            {   // the points' own extent in cells (p2g's arithmetic, one cell wider for its rounding)
-                float pa = smin[c][0], pb = smax[c][0];
-                for (int w = 1; w < 16; w++) { pa = fminf(pa, smin[c][w]); pb = fmaxf(pb, smax[c][w]); }
-                dev->ip_lo[c] = max((int)floorf((pa - lo) / hgs) - 1, 0);
-                dev->ip_hi[c] = min((int)floorf((pb - lo) / hgs) + 1, r - 1);
-            }
+
         }
         int err = 0;
         if (ncell > max_cells || ncell <= 0) { err = 4; ncell = 0; }
@@ -1704,10 +1699,31 @@ __global__ void __launch_bounds__(1024) k_frame_tables(const float* __restrict__
         carry_s = 0;
     }
     __syncthreads();
-    const int n_grid = sh_res[3], r0 = sh_res[0], r1 = sh_res[1], r2 = sh_res[2];
+    const int n_grid_all = sh_res[3], r0 = sh_res[0], r1 = sh_res[1], r2 = sh_res[2];
     const float b0 = sh_min[0], b1 = sh_min[1], b2 = sh_min[2];
-    if (n_grid == 0) return;
+    if (n_grid_all == 0) return;
+    // the cells that hold integration points, exactly as p2g files them (a point outside the grid whose flat index still lies in [0, n_grid) is filed under that
+    // index, as in the reference): their extent per axis -> PnFrameDev::ip_lo / ip_hi (k_frame_prologue builds lists only near them)
+    __shared__ int s_lo[3], s_hi[3];
+    if (threadIdx.x < 3) { s_lo[threadIdx.x] = 0x7fffffff; s_hi[threadIdx.x] = -1; }
+    __syncthreads();
+    for (int p = threadIdx.x; p < n_vtx; p += blockDim.x) {
+        const int q0 = (int)floorf((p_def[p * 3] - b0) / hgs), q1 = (int)floorf((p_def[p * 3 + 1] - b1) / hgs), q2 = (int)floorf((p_def[p * 3 + 2] - b2) / hgs);
+        const int gid = q2 * r1 * r0 + q1 * r0 + q0;
+        if (gid < 0 || gid >= n_grid_all) continue;
+        const int c0 = gid % r0, c1 = (gid / r0) % r1, c2 = gid / (r0 * r1);
+        atomicMin(&s_lo[0], c0); atomicMax(&s_hi[0], c0);
+        atomicMin(&s_lo[1], c1); atomicMax(&s_hi[1], c1);
+        atomicMin(&s_lo[2], c2); atomicMax(&s_hi[2], c2);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const bool any = s_hi[threadIdx.x] >= 0;
+        dev->ip_lo[threadIdx.x] = any ? s_lo[threadIdx.x] : 0;
+        dev->ip_hi[threadIdx.x] = any ? s_hi[threadIdx.x] : -1;
+    }
     if (LARGE) return;  // the tables themselves are built by the multi-workgroup kernels (pn_frame_prologue)
+    const int n_grid = n_grid_all;
     for (int g = threadIdx.x; g < (n_grid + 1) / 2; g += blockDim.x) cnt2[g] = 0u;
     __syncthreads();
     auto cell_of = [&](int p) {  // p2g, nerf/utils.py:389-407
@@ -2220,6 +2236,9 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     // two 16-bit cell counters per LDS word + the staged point-index table
     const size_t tables_lds = ((size_t)f->max_cells + 1) / 2 * sizeof(unsigned) + (size_t)f->max_vtx * sizeof(int);
     const bool large = tables_lds > 150 * 1024;  // grid too large for the one-workgroup LDS build
+    // (Round 6 built the one-workgroup LDS build over the BOX of cells that hold integration points for such grids — one launch instead of eight — and measured it
+    // on the trex option set while the body fits the box: 1 739 / 1 737 / 1 736 steps/s for the eight launches against 1 747 / 1 741 / 1 724, no gain: the pipeline is not bound by that
+    // chain; and a body that spreads beyond the box's 64 000 cells, as bench.py's does within 250 substeps, had to stop with a capacity flag.  Removed.)
     const bool keep_tables = !is_static && o->reuse_tables && f->tables_n_vtx == n_vtx;  // staged batches of one frame: same IP state
     if (is_static) {
         k_set_aabb<<<1, 1, 0, st>>>(f->dev, aabb_static[0], aabb_static[1], aabb_static[2], aabb_static[3], aabb_static[4], aabb_static[5]);
@@ -2235,7 +2254,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
             if (dev_id >= 0 && dev_id < PN_MAX_DEVICES) tables_lds_set[dev_id] = tables_lds;
         }
         k_frame_tables<false><<<1, 1024, tables_lds, st>>>(p_def, n_vtx, o->cut, o->bound, o->hash_grid_size, (int)f->max_cells, f->dev, f->pig_cnt,
-                                                           f->pig_bgn, f->pig_idx, f->pig_cursor, f->cell_bits);
+                                                       f->pig_bgn, f->pig_idx, f->pig_cursor, f->cell_bits);
     } else {
         k_frame_tables<true><<<1, 1024, 0, st>>>(p_def, n_vtx, o->cut, o->bound, o->hash_grid_size, (int)f->max_cells, f->dev, f->pig_cnt, f->pig_bgn,
                                                  f->pig_idx, f->pig_cursor, f->cell_bits);

@@ -96,6 +96,30 @@ def test_frame_in_cut_mode(deformed_ip_state, small_opt, ckpt, num_seek_IP):
     assert np.abs(out["weights_sum"].cpu().numpy() - ref["weights_sum"]).max() < 1e-4
 
 
+def test_cut_frame_with_points_outside_the_grid(deformed_ip_state, small_opt, ckpt):
+    """--cut: the spatial hash spans +-bound whatever the body does, and the reference files a point that has left it under its FLAT cell index when that
+    still lies in [0, n_grid) (nerf/utils.py:389-407: no per-axis test) — a cell far from the body.  The frame prologue builds candidate lists only near
+    the cells that hold points (PnFrameDev::ip_lo / ip_hi): those are the cells the points are FILED in, wrapped ones included, so the frame still equals
+    the oracle's (which restates p2g literally): a fifth of the points pushed 0.2-0.5 beyond the +x face (filed in the next row's first cells)."""
+    ip = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in deformed_ip_state.items()}
+    rng = np.random.default_rng(9)
+    n = len(ip["p_def"])
+    far = rng.choice(n, n // 5, replace=False)
+    ip["p_def"][far, 0] = 1.0 + rng.uniform(0.2, 0.5, len(far)).astype(np.float32)
+    # (a flat index outside [0, n_grid) — beyond -z, or +x in the grid's last row — is error flag 2 here, loudly, where the reference drops the point silently)
+    W = 64
+    opt = dict(small_opt, cut=True, cut_bounds=[-0.9, 0.95, -0.9, 0.9, -0.95, 0.9], num_seek_IP=3, max_steps=256)
+    o, d = oracle.get_rays(scene.orbit_pose(4.0, 35.0, -15.0), scene.orbit_intrinsics(W, W, 50.0), W, W)
+    ref = oracle.render_deformed(o, d, ip, ckpt, opt)
+    net = _net(ckpt, ip)
+    with torch.no_grad():
+        out = net.render_deformed(T(o)[None], T(d)[None], collect_stats=True, **opt)
+    st = dict(net.last_stats)
+    assert ref["samples"] > 1000
+    assert st["trips"] == ref["trips"] and st["samples"] == ref["samples"] and st["alive_at_exit"] == 0, (st, ref["samples"], ref["trips"])
+    assert np.abs(out["image"][0].cpu().numpy() - ref["image"]).max() < 1e-4
+
+
 def test_frame_in_trex_configuration(deformed_ip_state):
     """The option set of BASELINE config 3 (README.md:134 of the reference) at test size: bound 2 -> two density cascades and the
     4096-resolution hash grid, dt_gamma = 1/128 (step length grows along the ray), --cut with cut_bounds (static background rendered
