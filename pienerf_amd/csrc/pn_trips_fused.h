@@ -36,6 +36,9 @@
 #include "pn_net_tile.h"
 
 #define PN_FUSED_MAX_TRIPS 128  // fused trips per frame: (max_steps - 1) / 8 for max_steps <= 1024
+#ifndef PN_FUSED_WROUNDS
+#define PN_FUSED_WROUNDS 1   // 8-lane window rounds a later-trip ray gets before the whole wave walks it on in 64-element windows (2 / 3: measured, round 6)
+#endif
 #ifndef PN_FUSED_WAVES
 #define PN_FUSED_WAVES 12       // waves per workgroup, one workgroup per CU = 3 waves per SIMD: 61 KB weight image + 8 KB of march staging per wave
 #endif
@@ -656,7 +659,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
             st.t = t;
             have = t < c.far;
         }
-        const bool done = pnm3::march_window<K, MULTI, 8, PN_FUSED_STAGE, 1>(am, tbm, c, 8u, sub, gbase, lane, stage, X, Dd, dl, st, 1, have);
+        const bool done = pnm3::march_window<K, MULTI, 8, PN_FUSED_STAGE, 1>(am, tbm, c, 8u, sub, gbase, lane, stage, X, Dd, dl, st, PN_FUSED_WROUNDS, have);
         const bool deferred = have && !done;
         tick(1);
         unsigned long long dm = __ballot(deferred && sub == 0);
