@@ -13,3 +13,4 @@ PN_LIB_PATH=$R/pienerf_amd/lib/variants/simstamps.so python tools/sim_stamps.py 
 python bench.py --parallelism tile --steps 40 --warmup 5 --no-extras --no-cpu-baseline > $O/bench_tile_n1.json 2>/dev/null
 timeout 900 python tools/soak.py --frames 3000 > $O/soak_3000.json 2> $O/soak.err; tail -c 300 $O/soak_3000.json
 ls $O | wc -l
+python tools/trex_region_trajectory.py --frames 300 --every 10 > $O/trex_region_trajectory.json 2>/dev/null
