@@ -180,8 +180,8 @@ __device__ __forceinline__ int cell_coord(float v, float lo, float hgs, float rh
 //   * a REGION is one 8^3-voxel block of the top cascade level (a 64-byte line of the bitfield; the caller may choose 4^3); its bit says "interesting": some voxel of it is occupied on
 //     ANY level that a point inside it can be tested on, or it meets the cut box (inside which the search cells decide).  A point in a region without the
 //     bit is a static-background sample in an empty voxel whatever its mip level: the chain emits nothing there.
-// region_dda walks the regions the ray crosses until the next one is interesting (crossings within 2e-3 region widths of another face also look at the
-// lateral neighbours the reference's float arithmetic could mean); the chain is then restarted at an element e whose predecessor p satisfies
+// region_dda walks the regions the ray crosses until the next one is interesting or a crossing lies within 2e-3 region widths of another face (where the
+// reference's float arithmetic could mean a lateral neighbour: the walk ends at the last crossing that is clear of that); the chain is then restarted at an element e whose predecessor p satisfies
 //   p < exit(p) - margin,  e >= exit(p) + margin   (exit = the chain's own voxel-exit expression at p, on p's own mip level),
 //   every element of the t-sequence within one top-level voxel diagonal before p is on p's mip level,
 // which makes e a visited element whichever element of p's voxel the chain stands on: an element v <= p whose voxel (on v's level) contains p is on p's
@@ -202,20 +202,25 @@ __device__ __forceinline__ bool region_set(const RegionGrid& g, int b0, int b1, 
 // region, the volume's boundary or a doubt.  Returns 0: nothing crossed (t_stop = t); 1: t_stop set (axis m_stop); 2: no interesting region before `far`.
 __device__ inline int region_dda(const RegionGrid& g, float ox, float oy, float oz, float dx, float dy, float dz, float rdx, float rdy, float rdz, float t,
                                  float far, float* t_stop_out, int* m_stop_out) {
-    const float q0 = ((ox + t * dx) - g.lo) * g.rw, q1 = ((oy + t * dy) - g.lo) * g.rw, q2 = ((oz + t * dz) - g.lo) * g.rw;
-    const float f0 = floorf(q0), f1 = floorf(q1), f2 = floorf(q2);
-    int c0 = (int)f0, c1 = (int)f1, c2 = (int)f2;
+    // the start may lie ON (or a padding in front of) the volume's boundary — a frame's rays start where they enter the box +-(bound + 1e-3) — and the chain clamps
+    // its sample positions onto +-bound: a clamp along the face normal only.  So the start's coordinates are clamped into the grid, and a lateral neighbour
+    // beyond the volume does not exist — nothing can be filed there — instead of blocking the look-ahead
+    const float Rf = (float)g.R;
+    const float q0 = fminf(fmaxf(((ox + t * dx) - g.lo) * g.rw, 0.0f), Rf), q1 = fminf(fmaxf(((oy + t * dy) - g.lo) * g.rw, 0.0f), Rf),
+                q2 = fminf(fmaxf(((oz + t * dz) - g.lo) * g.rw, 0.0f), Rf);
     *t_stop_out = t;
     *m_stop_out = 0;
-    if (!(q0 >= 0.0f && q1 >= 0.0f && q2 >= 0.0f) || c0 >= g.R || c1 >= g.R || c2 >= g.R) return 0;   // (NaN fails the first test)
+    if (!(q0 >= 0.0f && q1 >= 0.0f && q2 >= 0.0f)) return 0;   // NaN
+    const float f0 = fminf(floorf(q0), Rf - 1.0f), f1 = fminf(floorf(q1), Rf - 1.0f), f2 = fminf(floorf(q2), Rf - 1.0f);
+    int c0 = (int)f0, c1 = (int)f1, c2 = (int)f2;
     if (region_set(g, c0, c1, c2)) return 0;   // the common early exit: inside an interesting region
-    const float e0 = q0 - f0, e1 = q1 - f1, e2 = q2 - f2;
+    const float e0 = q0 - f0, e1 = q1 - f1, e2 = q2 - f2;   // in [0, 1] (1: on the volume's far face)
     const int s_l0 = e0 < 2e-3f ? -1 : (e0 > 0.998f ? 1 : 0), s_l1 = e1 < 2e-3f ? -1 : (e1 > 0.998f ? 1 : 0), s_l2 = e2 < 2e-3f ? -1 : (e2 > 0.998f ? 1 : 0);
     if (s_l0 | s_l1 | s_l2) {   // a start next to a face: the regions it could be taken for
         for (int q = 1; q < 8; q++) {
             if (((q & 1) && !s_l0) || ((q & 2) && !s_l1) || ((q & 4) && !s_l2)) continue;
             const int y0 = c0 + ((q & 1) ? s_l0 : 0), y1 = c1 + ((q & 2) ? s_l1 : 0), y2 = c2 + ((q & 4) ? s_l2 : 0);
-            if (y0 < 0 || y1 < 0 || y2 < 0 || y0 >= g.R || y1 >= g.R || y2 >= g.R) return 0;
+            if (y0 < 0 || y1 < 0 || y2 < 0 || y0 >= g.R || y1 >= g.R || y2 >= g.R) continue;   // beyond the volume
             if (region_set(g, y0, y1, y2)) return 0;
         }
     }
@@ -237,27 +242,25 @@ __device__ inline int region_dda(const RegionGrid& g, float ox, float oy, float 
         if (!(tx < far)) { *t_stop_out = t_stop; *m_stop_out = m_stop; return 2; }
         const float u0 = use0 ? (tf0 - tx) * k0 : u_fix0, u1 = use1 ? (tf1 - tx) * k1 : u_fix1, u2 = use2 ? (tf2 - tx) * k2 : u_fix2;
         const bool ok0 = m == 0 || (u0 >= 2e-3f && u0 <= 0.998f), ok1 = m == 1 || (u1 >= 2e-3f && u1 <= 0.998f), ok2 = m == 2 || (u2 >= 2e-3f && u2 <= 0.998f);
-        const bool unsafe = !(ok0 && ok1 && ok2) || !(tx > t_stop);
+        // a crossing within 2e-3 region widths of another face: the reference's float arithmetic may file the elements around it under the lateral neighbour
+        // across that face — of the region being left or of the one being entered.  ONE such face: those two regions are looked at, and the walk goes on if
+        // neither has the bit.  Two (an edge or a corner, or two faces at one parameter): the walk ends at the last crossing that was clear — between two clear
+        // crossings the ray's distance to the lateral faces lies between its values at the two — and the exact hops take the ray past the doubtful one.
+        // (The first version ran a 14-way neighbour loop here, which one lane in a hundred takes and its whole wave waits for: 26 of the first look-ahead's 62 us
+        // on the trex option set; ending the walk at EVERY doubtful crossing instead cost more than that in the extra look-aheads of the rays that meet nothing.)
         const int n0 = c0 + (m == 0 ? st0 : 0), n1 = c1 + (m == 1 ? st1 : 0), n2 = c2 + (m == 2 ? st2 : 0);
-        const bool behind = !(tx > t_stop - 1e-6f * fmaxf(1.0f, fabsf(tx)));   // a face clearly BEHIND the last one: not a rounding matter
-        if (tx > t_stop) { t_stop = tx; m_stop = m; }
+        if (!(tx > t_stop)) break;
+        if (!(ok0 && ok1 && ok2)) {
+            const int l0 = (m == 0 || ok0) ? 0 : (u0 < 0.5f ? st0 : -st0), l1 = (m == 1 || ok1) ? 0 : (u1 < 0.5f ? st1 : -st1), l2 = (m == 2 || ok2) ? 0 : (u2 < 0.5f ? st2 : -st2);
+            if ((l0 != 0) + (l1 != 0) + (l2 != 0) != 1) break;
+            const int a0 = c0 + l0, a1 = c1 + l1, a2 = c2 + l2, b0 = n0 + l0, b1 = n1 + l1, b2 = n2 + l2;
+            if (a0 < 0 || a1 < 0 || a2 < 0 || a0 >= g.R || a1 >= g.R || a2 >= g.R || b0 < 0 || b1 < 0 || b2 < 0 || b0 >= g.R || b1 >= g.R || b2 >= g.R) break;
+            if (region_set(g, a0, a1, a2) || region_set(g, b0, b1, b2)) break;
+        }
+        t_stop = tx;
+        m_stop = m;
         if (n0 < 0 || n1 < 0 || n2 < 0 || n0 >= g.R || n1 >= g.R || n2 >= g.R) break;   // the volume's boundary: points beyond are clamped onto it
         if (region_set(g, n0, n1, n2)) break;
-        if (unsafe) {
-            // towards the face the crossing is close to: the next one (u small: in the ray's direction) or the one behind (u near 1)
-            const int l0 = (m == 0 || ok0) ? 0 : (u0 < 0.5f ? st0 : -st0), l1 = (m == 1 || ok1) ? 0 : (u1 < 0.5f ? st1 : -st1), l2 = (m == 2 || ok2) ? 0 : (u2 < 0.5f ? st2 : -st2);
-            bool blocked = behind;
-            for (int q = 1; q < 8 && !blocked; q++) {
-                if (((q & 1) && !l0) || ((q & 2) && !l1) || ((q & 4) && !l2)) continue;
-                const int s0 = (q & 1) ? l0 : 0, s1 = (q & 2) ? l1 : 0, s2 = (q & 4) ? l2 : 0;
-                for (int side = 0; side < 2; side++) {
-                    const int y0 = (side ? n0 : c0) + s0, y1 = (side ? n1 : c1) + s1, y2 = (side ? n2 : c2) + s2;
-                    if (y0 < 0 || y1 < 0 || y2 < 0 || y0 >= g.R || y1 >= g.R || y2 >= g.R) { blocked = true; break; }
-                    if (region_set(g, y0, y1, y2)) { blocked = true; break; }
-                }
-            }
-            if (blocked) break;
-        }
         c0 = n0; c1 = n1; c2 = n2;
         if (m == 0) tf0 = ((g.lo + (float)(c0 + (st0 > 0)) * g.w) - ox) * rdx;
         else if (m == 1) tf1 = ((g.lo + (float)(c1 + (st1 > 0)) * g.w) - oy) * rdy;
@@ -505,7 +508,11 @@ __device__ inline float skip_empty_cells(const MarchParams& a, const March2Table
             try_regions = false;
             hops_since_try = 0;
             const float px = ox + t * dx, py = oy + t * dy, pz = oz + t * dz;
-            if (fabsf(px) < a.bound && fabsf(py) < a.bound && fabsf(pz) < a.bound) {   // strictly inside: the clamp of the sample position is the identity
+            // inside the volume, or just in front of it: a frame's rays start on the box +-(bound + 1e-3) (renderer.py:782-791 pads the box), and the chain clamps its
+            // sample positions onto +-bound — which region_dda's clamped start coordinates reproduce.  (Rounds of the first version began with a look-ahead that
+            // this test refused for every ray: the real first one came six hops later.)
+            const float b_in = a.bound + 2e-3f;
+            if (fabsf(px) <= b_in && fabsf(py) <= b_in && fabsf(pz) <= b_in) {
                 float t_stop;
                 int m_stop;
                 const int kind = region_dda(rg, ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, t, far, &t_stop, &m_stop);
@@ -520,10 +527,14 @@ __device__ inline float skip_empty_cells(const MarchParams& a, const March2Table
                     // elements in it that restarts the chain (conditions above)
                     float T = t;
                     const float zone = target - zone_len;
-                    while (true) {
-                        const float Tn = T + clampf(T * a.dt_gamma, dt_min, dt_max);
-                        if (!(Tn < zone)) break;
-                        T = Tn;
+                    while (true) {   // four elements per exit test (the walk is a large part of a long look-ahead: up to ~150 elements)
+                        const float T1 = T + clampf(T * a.dt_gamma, dt_min, dt_max);
+                        const float T2 = T1 + clampf(T1 * a.dt_gamma, dt_min, dt_max);
+                        const float T3 = T2 + clampf(T2 * a.dt_gamma, dt_min, dt_max);
+                        const float T4 = T3 + clampf(T3 * a.dt_gamma, dt_min, dt_max);
+                        if (T4 < zone) { T = T4; continue; }
+                        T = T3 < zone ? T3 : (T2 < zone ? T2 : (T1 < zone ? T1 : T));   // the last element in front of the zone
+                        break;
                     }
                     float best = -1.0f, run_start = FLT_MAX;
                     int run_level = -1;
