@@ -178,7 +178,7 @@ __device__ __forceinline__ int cell_coord(float v, float lo, float hgs, float rh
 //   * the t-sequence is grid-independent: T_{k+1} = T_k + clamp(T_k dt_gamma, dt_min, dt_max), whatever the chain visits of it — walking it costs five
 //     instructions per element where visiting one costs 230;
 //   * a REGION is one 8^3-voxel block of the top cascade level (a 64-byte line of the bitfield; the caller may choose 4^3); its bit says "interesting": some voxel of it is occupied on
-//     ANY level that a point inside it can be tested on, or it meets the cut box (inside which the search cells decide).  A point in a region without the
+//     ANY level >= L that a point inside it can be tested on (one map per L: a ray asks the map of the lowest level its dt still allows), or it meets the cut box (inside which the search cells decide).  A point in a region without the
 //     bit is a static-background sample in an empty voxel whatever its mip level: the chain emits nothing there.
 // region_dda walks the regions the ray crosses until the next one is interesting or a crossing lies within 2e-3 region widths of another face (where the
 // reference's float arithmetic could mean a lateral neighbour: the walk ends at the last crossing that is clear of that); the chain is then restarted at an element e whose predecessor p satisfies
@@ -515,6 +515,10 @@ __device__ inline float skip_empty_cells(const MarchParams& a, const March2Table
             if (fabsf(px) <= b_in && fabsf(py) <= b_in && fabsf(pz) <= b_in) {
                 float t_stop;
                 int m_stop;
+                // the map of the ray's minimum mip level from here on: level = max(from the position, from dt) >= mip_from_dt(dt(t)), and dt does not fall along the ray —
+                // on the trex option set dt puts every point on level 1, and what is occupied on level 0 only cannot be met
+                const int lv_min = one_cascade ? 0 : mip_from_dt(clampf(t * a.dt_gamma, dt_min, dt_max), (float)H, (float)C);
+                rg.bits = grid_regions + (size_t)lv_min * (size_t)((rg.R * rg.R * rg.R) >> 5);
                 const int kind = region_dda(rg, ox, oy, oz, dx, dy, dz, rdx, rdy, rdz, t, far, &t_stop, &m_stop);
                 if (kind == 2) { *n_iter_out = n_iter; return far; }   // nothing interesting before `far`: the chain walks there and emits nothing
                 const float rd_stop = fabsf(m_stop == 0 ? rdx : (m_stop == 1 ? rdy : rdz));

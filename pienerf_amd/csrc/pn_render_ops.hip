@@ -2020,14 +2020,14 @@ __global__ void __launch_bounds__(256) k_frame_prologue(FramePrologue a) {
     if (b < a.list_blocks + a.pack_blocks + a.gr_blocks) {  // region map of the density bitfield (pn_march_window.h: region_dda)
         const int R = a.gr_R, n_reg = R * R * R;
         const int r = threadIdx.x + (b - a.list_blocks - a.pack_blocks) * 256;
-        bool any = false;
         if (r < n_reg) {
+            bool any = false;
             const int b0 = r % R, b1 = (r / R) % R, b2 = r / (R * R);
             // a region is V = (H / R)^3 voxels = V / 64 consecutive 8-byte words of a level's bitfield in morton order (R = H / 8: a 64-byte line; R = H / 4: one word)
             const uint32_t vox_side = a.gr_H / (uint32_t)R, words_per_region = (vox_side * vox_side * vox_side) >> 6;
             const uint32_t words_per_level = (a.gr_H * a.gr_H * a.gr_H) >> 6;
             const uint2* g2 = reinterpret_cast<const uint2*>(a.grid);
-            uint32_t acc = 0;
+            uint32_t acc_l[3] = {0u, 0u, 0u};   // occupancy of the region on level l (gr_C <= 3)
             for (int l = 0; l < a.gr_C; l++) {
                 // on level l (R blocks over +-2^l) the region is the aligned cube of 2^j blocks per axis at R / 2 + (b - R / 2) 2^j, j = C - 1 - l — contiguous
                 // words in morton order — or lies outside the level's volume, where no point can be tested on it
@@ -2038,21 +2038,24 @@ __global__ void __launch_bounds__(256) k_frame_prologue(FramePrologue a) {
                 const uint32_t n_words = words_per_region << (3 * j);
                 for (uint32_t q = 0; q < n_words; q++) {
                     const uint2 v = g2[(size_t)first + q];
-                    acc |= v.x | v.y;
+                    acc_l[l] |= v.x | v.y;
                 }
             }
-            any = acc != 0u;
+            // map L serves the rays whose mip level cannot fall below L any more (level >= mip_from_dt(dt), dt grows with t): occupied on a level >= L
+            for (int L = a.gr_C - 2; L >= 0; L--) acc_l[L] |= acc_l[L + 1];
             // ... or it meets the cut box: x in (cb0, cb1), y > cb2, z in (cb4, cb5) — a superset of the reference's test (raymarching.cu:1210 compares x with
             // cut_bounds[3] where y is meant), widened by a hundredth of a region
             const float w = 2.0f * a.gr_bound / (float)R, eps = 0.01f * w;
             const float x0 = -a.gr_bound + (float)b0 * w, y0 = -a.gr_bound + (float)b1 * w, z0 = -a.gr_bound + (float)b2 * w;
             const float* cb = a.cut_bounds;
             if (x0 + w > cb[0] - eps && x0 < cb[1] + eps && y0 + w > cb[2] - eps && z0 + w > cb[4] - eps && z0 < cb[5] + eps) any = true;
-        }
-        const unsigned long long m = __ballot(any);
-        if ((threadIdx.x & 63) == 0 && r < n_reg) {   // (R^3 is a multiple of 64: whole words only)
-            a.grid_regions[r >> 5] = (uint32_t)m;
-            a.grid_regions[(r >> 5) + 1] = (uint32_t)(m >> 32);
+            for (int L = 0; L < a.gr_C; L++) {   // one map per minimum level, behind each other
+                const unsigned long long m = __ballot(any || acc_l[L] != 0u);
+                if ((threadIdx.x & 63) == 0) {   // (R^3 is a multiple of 64: whole words only, whole waves inside n_reg)
+                    a.grid_regions[(size_t)L * (n_reg >> 5) + (r >> 5)] = (uint32_t)m;
+                    a.grid_regions[(size_t)L * (n_reg >> 5) + (r >> 5) + 1] = (uint32_t)(m >> 32);
+                }
+            }
         }
         return;
     }
@@ -2196,8 +2199,9 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     const uint32_t reg_R = o->grid_size / reg_side;
     const bool reg_ok = !is_static && o->cut && !grid_regions_off && dda_start && bitfield && o->grid_size % 32 == 0 && o->cascade >= 1 && o->cascade <= 3 &&
                         o->bound == (float)(1u << (o->cascade - 1)) && (reg_R / 2) % (1u << (o->cascade - 1)) == 0 &&
-                        (uint64_t)reg_R * reg_R * reg_R / 32 <= PN_GRID_REGION_WORDS && ((uintptr_t)bitfield & 15) == 0;
-    const int grid_region_words = reg_ok ? (int)((uint64_t)reg_R * reg_R * reg_R / 32) : 0;
+                        (uint64_t)reg_R * reg_R * reg_R / 32 * o->cascade <= PN_GRID_REGION_WORDS && ((uintptr_t)bitfield & 15) == 0;
+    const int grid_region_words_1 = reg_ok ? (int)((uint64_t)reg_R * reg_R * reg_R / 32) : 0;   // one map
+    const int grid_region_words = grid_region_words_1 * (int)o->cascade;                          // one per minimum mip level (pn_march_window.h)
     const size_t skip_lds = (size_t)skip_bits_words * 4 * (short_rays ? 2 : 1) + (size_t)grid_region_words * 4;
 
     if (!f->cut_bounds_valid || memcmp(f->cut_bounds_host, o->cut_bounds, sizeof(f->cut_bounds_host)) != 0) {  // uploaded only when it changes
@@ -2288,7 +2292,7 @@ static int render_impl(pn_frame* f, const pn_net* net, const pn_render_opts* o, 
     fp.lds_words = (fp.list_blocks > 0 && bit_words * 8 <= 64 * 1024) ? (int)bit_words : 0;
     if (grid_region_words > 0) {
         fp.grid = bitfield; fp.grid_regions = f->grid_regions; fp.gr_R = (int)reg_R; fp.gr_C = (int)o->cascade; fp.gr_H = o->grid_size;
-        fp.gr_bound = o->bound; fp.cut_bounds = f->cut_bounds; fp.gr_blocks = (int)pn_div_up((uint64_t)grid_region_words * 32, 256);
+        fp.gr_bound = o->bound; fp.cut_bounds = f->cut_bounds; fp.gr_blocks = (int)pn_div_up((uint64_t)grid_region_words_1 * 32, 256);
     }
     k_frame_prologue<<<(uint32_t)(fp.list_blocks + fp.pack_blocks + fp.gr_blocks) + nblk, 256, (size_t)fp.lds_words * 8, st>>>(fp);
     PN_LAUNCH_CHECK();
@@ -2576,7 +2580,7 @@ extern "C" int pn_frame_march_counters(pn_frame* f, int enable, uint64_t* counte
     hipStream_t st = (hipStream_t)stream;
     if (counters_host) {
         PN_HIP_CHECK(hipMemcpyAsync(counters_host, f->march_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-#if PN_DBG_PHASES
+#if PN_DBG_PHASES || PN_DBG_STATS   // (timing / counting builds only: tools/build_variant.py name -DPN_DBG_STATS=1 prints the debug slots [4..15])
         {
             unsigned long long ph[16];
             PN_HIP_CHECK(hipMemcpy(ph, f->march_counters, sizeof(ph), hipMemcpyDeviceToHost));
