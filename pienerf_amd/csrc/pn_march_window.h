@@ -1026,7 +1026,10 @@ __device__ inline bool march_window(const MarchParams& a, const March2Tables& tb
         // it) needs no lists, no scan and no record heads: what is left of the round is the voxel arithmetic and the chain
         const bool any_list = __any(pc.e != pc.b);
         int my_off = -1;
-        if (any_list) my_off = stage_lists<CAP>(stage, tb.nb, pc.b, pc.e - pc.b, lane);
+#ifndef PN_G1_NOSTAGE
+#define PN_G1_NOSTAGE 0   // 1: the one-lane form scans its candidate lists from global memory instead of staging the wave's distinct lists in LDS (A/B build)
+#endif
+        if (any_list && !(G == 1 && PN_G1_NOSTAGE)) my_off = stage_lists<CAP>(stage, tb.nb, pc.b, pc.e - pc.b, lane);
         PN_PHASE(pk, 2);
         PointEval ev;
         ev.emit = false; ev.oob = false; ev.tt = 0.f; ev.dt = 0.f; ev.x = ev.y = ev.z = 0.f; ev.n_cand = 0; ev.n_warp = 0;

@@ -36,6 +36,12 @@
 #include "pn_net_tile.h"
 
 #define PN_FUSED_MAX_TRIPS 128  // fused trips per frame: (max_steps - 1) / 8 for max_steps <= 1024
+// (-DPN_DBG_PHASES=1 timing builds give march_window a phase clock: the fused launch has clocks of its own and hands it a dummy)
+#if PN_DBG_PHASES
+#define PN_FUSED_PK , pk_dummy_
+#else
+#define PN_FUSED_PK
+#endif
 #ifndef PN_FUSED_WROUNDS
 #define PN_FUSED_WROUNDS 1   // 8-lane window rounds a later-trip ray gets before the whole wave walks it on in 64-element windows (2 / 3: measured, round 6)
 #endif
@@ -236,6 +242,9 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
     __shared__ int s_pend[PN_FUSED_MAXCHUNKS];  // WHOLE: positions of each chunk still open
     __shared__ int s_pref[PN_SEGS + 1];
 
+#if PN_DBG_PHASES
+    pnm3::PhaseClock pk_dummy_;
+#endif
     const PnTrip* tr = fa.trips;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (PN_FUSED_FRESH_ARGS && blockIdx.x == 0 && threadIdx.x == 0) {   // the kernarg layout fused_args_fresh assumes, checked against the by-value copy
@@ -504,7 +513,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
                 float* const Da = fa.dirs + sl * 3;
                 float* const La = fa.deltas + sl * 2;
                 tick(0);
-                const bool done = pnm3::march_window<K, MULTI, 1, PN_FUSED_STAGE, 1>(a, tb, c, 1u, 0, lane, lane, stage, Xa, Da, La, st, fa.a_rounds, have);
+                const bool done = pnm3::march_window<K, MULTI, 1, PN_FUSED_STAGE, 1>(a, tb, c, 1u, 0, lane, lane, stage, Xa, Da, La, st, fa.a_rounds, have PN_FUSED_PK);
                 const bool deferred = have && !done;
                 const unsigned long long dm = __ballot(deferred);
                 const int n_def = (int)__popcll(dm);
@@ -535,7 +544,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
                 pnm3::ray_consts(a, se.w, c2);
                 pnm3::RayState s2{__int_as_float(se.y), __int_as_float(se.z), 0u};
                 const size_t sl = (size_t)a_base + (size_t)se.x;
-                pnm3::march_window<K, MULTI, 64, PN_FUSED_STAGE, 1>(a, tb, c2, 1u, lane, 0, lane, stage, fa.xyzs + sl * 3, fa.dirs + sl * 3, fa.deltas + sl * 2, s2, 0x7fffffff, true);
+                pnm3::march_window<K, MULTI, 64, PN_FUSED_STAGE, 1>(a, tb, c2, 1u, lane, 0, lane, stage, fa.xyzs + sl * 3, fa.dirs + sl * 3, fa.deltas + sl * 2, s2, 0x7fffffff, true PN_FUSED_PK);
                 if (s2.step == 0u && lane < 8) {
                     if (lane < 2) fa.deltas[sl * 2 + lane] = 0.0f;
                     else if (lane < 5) fa.xyzs[sl * 3 + (lane - 2)] = 0.0f;
@@ -659,7 +668,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
             st.t = t;
             have = t < c.far;
         }
-        const bool done = pnm3::march_window<K, MULTI, 8, PN_FUSED_STAGE, 1>(am, tbm, c, 8u, sub, gbase, lane, stage, X, Dd, dl, st, PN_FUSED_WROUNDS, have);
+        const bool done = pnm3::march_window<K, MULTI, 8, PN_FUSED_STAGE, 1>(am, tbm, c, 8u, sub, gbase, lane, stage, X, Dd, dl, st, PN_FUSED_WROUNDS, have PN_FUSED_PK);
         const bool deferred = have && !done;
         tick(1);
         unsigned long long dm = __ballot(deferred && sub == 0);
@@ -676,7 +685,7 @@ __global__ void __launch_bounds__(PN_FUSED_WAVES * 64, (PN_FUSED_WAVES + 3) / 4)
             pnm3::RayState s2{readlane_f(st.t, L), readlane_f(st.last_t, L), (uint32_t)__builtin_amdgcn_readlane((int)st.step, L)};
             const size_t sl = (size_t)slotw + (size_t)(L >> 3) * 8;
             pnm3::march_window<K, MULTI, 64, PN_FUSED_STAGE, 1>(am, tbm, c2, 8u, lane, 0, lane, stage, LXYZ ? xyz_all + wv * 192 + (L >> 3) * 24 : fa.xyzs + sl * 3,
-                                                                LXYZ ? nullptr : fa.dirs + sl * 3, fa.deltas + sl * 2, s2, 0x7fffffff, true);
+                                                                LXYZ ? nullptr : fa.dirs + sl * 3, fa.deltas + sl * 2, s2, 0x7fffffff, true PN_FUSED_PK);
             if (gbase == L) st.step = s2.step;
         }
         const uint32_t emitted = have_ray ? st.step : 0u;
